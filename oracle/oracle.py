@@ -1,0 +1,176 @@
+"""ctypes front-end of oracle/tgs_oracle.c (TEST INFRASTRUCTURE ONLY, see that file's header).
+
+May be imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg -- never by the
+product package.  numpy in / numpy out; absent inputs are ``None`` (the reference's nullptr).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Dict, Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libtgs_oracle.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "tgs_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "libtgs_oracle.so"])
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        fp, ip, vp = C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_void_p
+        L.tgs_oracle_forward.restype = vp
+        L.tgs_oracle_forward.argtypes = [C.c_int, C.c_int, C.c_int, fp, C.c_int, C.c_int, fp, fp, fp, fp, fp,
+                                         C.c_float, fp, fp, fp, fp, fp, C.c_float, C.c_float, fp, ip]
+        L.tgs_oracle_backward.restype = None
+        L.tgs_oracle_backward.argtypes = [vp, fp, fp, fp, fp, fp, C.c_float, fp, fp, fp, fp, fp, C.c_float,
+                                          C.c_float] + [fp] * 10
+        L.tgs_oracle_free.argtypes = [vp]
+        L.tgs_oracle_free.restype = None
+        L.tgs_oracle_num_rendered.argtypes = [vp]
+        L.tgs_oracle_num_rendered.restype = C.c_int64
+        L.tgs_oracle_field.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
+        L.tgs_oracle_field.restype = vp
+        L.tgs_oracle_mark_visible.argtypes = [C.c_int, fp, fp, fp, C.POINTER(C.c_uint8)]
+        L.tgs_oracle_mark_visible.restype = None
+        L.tgs_oracle_threads.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _f(a: Optional[np.ndarray]):
+    if a is None:
+        return None
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _c32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+
+_FIELDS = {"depths": np.float32, "means2D": np.float32, "cov3D": np.float32, "conic_opacity": np.float32,
+           "rgb": np.float32, "clamped": np.uint8, "tiles_touched": np.uint32, "point_offsets": np.uint32,
+           "radii": np.int32, "point_list": np.uint32, "point_keys": np.uint64, "ranges": np.uint32,
+           "final_T": np.float32, "n_contrib": np.uint32}
+
+
+class OracleState:
+    """Owns the C state of one forward pass (the reference's three byte buffers)."""
+
+    def __init__(self, handle, keep):
+        self._h = handle
+        self._keep = keep
+
+    def field(self, name: str) -> np.ndarray:
+        cnt = C.c_int64()
+        p = lib().tgs_oracle_field(self._h, name.encode(), C.byref(cnt))
+        if cnt.value < 0:
+            raise KeyError(name)
+        dt = np.dtype(_FIELDS[name])
+        if cnt.value == 0:
+            return np.zeros(0, dt)
+        buf = (C.c_char * (cnt.value * dt.itemsize)).from_address(p)
+        return np.frombuffer(buf, dtype=dt).copy()
+
+    @property
+    def num_rendered(self) -> int:
+        return int(lib().tgs_oracle_num_rendered(self._h))
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().tgs_oracle_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def forward(*, bg, means3D, opacities, viewmatrix, projmatrix, campos, tanfovx, tanfovy, image_height,
+            image_width, sh_degree=0, shs=None, colors_precomp=None, scales=None, rotations=None,
+            cov3D_precomp=None, scale_modifier=1.0):
+    """Returns (color[3,H,W], radii[P], OracleState).  Mirrors Rasterizer::forward
+    (cuda_rasterizer/rasterizer_impl.cu:198-336)."""
+    means3D = _c32(means3D)
+    P = means3D.shape[0]
+    shs, colors_precomp, scales, rotations, cov3D_precomp = map(_c32, (shs, colors_precomp, scales, rotations, cov3D_precomp))
+    M = shs.shape[1] if shs is not None and shs.shape[0] != 0 else 0
+    bg, opacities, viewmatrix, projmatrix, campos = map(_c32, (bg, opacities, viewmatrix, projmatrix, campos))
+    H, W = int(image_height), int(image_width)
+    color = np.zeros((3, H, W), np.float32)
+    radii = np.zeros(P, np.int32)
+    keep = (bg, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, campos)
+    h = lib().tgs_oracle_forward(P, int(sh_degree), M, _f(bg), W, H, _f(means3D), _f(shs), _f(colors_precomp),
+                                 _f(opacities), _f(scales), float(scale_modifier), _f(rotations), _f(cov3D_precomp),
+                                 _f(viewmatrix), _f(projmatrix), _f(campos), float(tanfovx), float(tanfovy),
+                                 _f(color), radii.ctypes.data_as(C.POINTER(C.c_int)))
+    return color, radii, OracleState(h, keep)
+
+
+def backward(state: OracleState, dL_dout_color, *, bg, means3D, viewmatrix, projmatrix, campos, tanfovx, tanfovy,
+             shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None,
+             scale_modifier=1.0) -> Dict[str, np.ndarray]:
+    """Returns the 8 tensors of RasterizeGaussiansBackwardCUDA (rasterize_points.cu:195) plus dL_dconic."""
+    means3D = _c32(means3D)
+    P = means3D.shape[0]
+    shs, colors_precomp, scales, rotations, cov3D_precomp = map(_c32, (shs, colors_precomp, scales, rotations, cov3D_precomp))
+    M = shs.shape[1] if shs is not None and shs.shape[0] != 0 else 0
+    bg, viewmatrix, projmatrix, campos, dL = map(_c32, (bg, viewmatrix, projmatrix, campos, dL_dout_color))
+    z = lambda *s: np.zeros(s, np.float32)
+    out = {"dL_dmeans2D": z(P, 3), "dL_dconic": z(P, 4), "dL_dopacity": z(P, 1), "dL_dcolors": z(P, 3),
+           "dL_dmeans3D": z(P, 3), "dL_dcov3D": z(P, 6), "dL_dsh": z(P, M, 3), "dL_dscales": z(P, 3),
+           "dL_drotations": z(P, 4)}
+    lib().tgs_oracle_backward(state._h, _f(bg), _f(means3D), _f(shs), _f(colors_precomp), _f(scales),
+                              float(scale_modifier), _f(rotations), _f(cov3D_precomp), _f(viewmatrix), _f(projmatrix),
+                              _f(campos), float(tanfovx), float(tanfovy), _f(dL), _f(out["dL_dmeans2D"]),
+                              _f(out["dL_dconic"]), _f(out["dL_dopacity"]), _f(out["dL_dcolors"]),
+                              _f(out["dL_dmeans3D"]), _f(out["dL_dcov3D"]), _f(out["dL_dsh"]), _f(out["dL_dscales"]),
+                              _f(out["dL_drotations"]))
+    return out
+
+
+def mark_visible(means3D, viewmatrix, projmatrix) -> np.ndarray:
+    means3D, viewmatrix, projmatrix = map(_c32, (means3D, viewmatrix, projmatrix))
+    P = means3D.shape[0]
+    out = np.zeros(P, np.uint8)
+    lib().tgs_oracle_mark_visible(P, _f(means3D), _f(viewmatrix), _f(projmatrix), out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out.astype(bool)
+
+
+def threads() -> int:
+    return int(lib().tgs_oracle_threads())
+
+
+def run_scene(cloud: dict, cam, dL=None, mode: str = "sh", cov_mode: str = "scale_rot"):
+    """Convenience for tests/bench: cloud from scenes.make_cloud, cam from scenes.orbit_camera.
+    mode: 'sh' (SH evaluated in the rasterizer) or 'precomp' (caller-side SH->RGB)."""
+    from youreditableavatar_amd import scenes
+    kw = dict(bg=cam.bg, means3D=cloud["means3D"], viewmatrix=cam.viewmatrix, projmatrix=cam.projmatrix,
+              campos=cam.campos, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, scale_modifier=cam.scale_modifier)
+    if mode == "sh":
+        kw["shs"] = cloud["shs"]
+    else:
+        kw["colors_precomp"] = cloud.get("colors_precomp")
+        if kw["colors_precomp"] is None:
+            kw["colors_precomp"] = scenes.sh_to_rgb_numpy(cloud["shs"], cloud["means3D"], cam.campos, cloud["sh_degree"])
+    if cov_mode == "scale_rot":
+        kw["scales"], kw["rotations"] = cloud["scales"], cloud["rotations"]
+    else:
+        kw["cov3D_precomp"] = cloud["cov3D_precomp"]
+    color, radii, st = forward(opacities=cloud["opacities"], image_height=cam.image_height, image_width=cam.image_width,
+                               sh_degree=cloud["sh_degree"], **kw)
+    grads = None
+    if dL is not None:
+        grads = backward(st, dL, **kw)
+    return color, radii, st, grads
