@@ -1,0 +1,101 @@
+/*
+ * tgs_raster.h -- C ABI of the MI355X-native differentiable 3D-Gaussian rasterizer
+ * (libtgs_raster.so, built from youreditableavatar_amd/csrc by plain hipcc for gfx950).
+ *
+ * Drop-in boundary.  Each entry point replaces one static of the reference's
+ * CudaRasterizer::Rasterizer (Edit_core/thirdparties/diff-gaussian-rasterization/
+ * cuda_rasterizer/rasterizer.h:20-85), i.e. exactly what the reference's own FFI for this path
+ * (rasterize_points.cu:35-217 behind ext.cpp:15-19) binds:
+ *
+ *   tgs_forward       <- Rasterizer::forward      rasterizer.h:33-58   (impl rasterizer_impl.cu:198-336)
+ *   tgs_backward      <- Rasterizer::backward     rasterizer.h:60-85   (impl rasterizer_impl.cu:340-434)
+ *   tgs_mark_visible  <- Rasterizer::markVisible  rasterizer.h:24-31   (impl rasterizer_impl.cu:141-153)
+ *
+ * Same argument meaning and order; the differences are the ones a C ABI forces:
+ *   - the three std::function<char*(size_t)> allocators (rasterize_points.cu:27-33) become one
+ *     callback  void* alloc(void* ctx, int which, size_t bytes)  returning a DEVICE pointer that
+ *     stays valid until the matching backward; which = TGS_BUF_GEOM / _BINNING / _IMAGE;
+ *   - an explicit hipStream_t (as void*): every kernel and copy is enqueued on it (the reference
+ *     uses the legacy default stream, rasterizer_impl.cu:148,289);
+ *   - errors are return codes (< 0) plus tgs_last_error() instead of C++ exceptions
+ *     (std::runtime_error at rasterizer_impl.cu:242-245, auxiliary.h:166-173);
+ *   - an absent input (the reference's nullptr: colors_precomp / shs / scales+rotations /
+ *     cov3D_precomp, rasterizer_impl.cu:321,389,411) is a NULL pointer here as well.
+ * All pointers are device pointers to contiguous fp32 (int32 for radii) unless noted.  The layout
+ * inside the three state buffers is private to this library (the reference's is private too:
+ * rasterizer_impl.h:29-65); they only have to be handed back to tgs_backward unmodified.
+ * The library keeps no state between calls and is re-entrant.
+ */
+#ifndef TGS_RASTER_H
+#define TGS_RASTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TGS_ABI_VERSION 1
+
+enum { TGS_BUF_GEOM = 0, TGS_BUF_BINNING = 1, TGS_BUF_IMAGE = 2 };
+
+enum {
+    TGS_OK = 0,
+    TGS_ERR_INVALID = -1,     /* bad argument (e.g. neither shs nor colors_precomp)            */
+    TGS_ERR_HIP = -2,         /* a HIP call or kernel failed (debug=1 checks after every stage) */
+    TGS_ERR_ALLOC = -3,       /* the allocation callback returned NULL                          */
+    TGS_ERR_TOO_MANY = -4,    /* more than 2^31-1 tile instances                                */
+    TGS_ERR_PREFILTERED = -5  /* prefiltered=1 but a Gaussian was culled (auxiliary.h:156-160)   */
+};
+
+typedef void* (*tgs_alloc_fn)(void* ctx, int which, size_t bytes);
+
+/* Returns num_rendered (>= 0) or a negative TGS_ERR_*.  out_color[3,H,W], radii[P] (int32; may be
+ * NULL like rasterizer.h:56).  D = active SH degree, M = SH coefficient triplets per Gaussian. */
+int64_t tgs_forward(tgs_alloc_fn alloc, void* alloc_ctx, void* stream,
+                    int P, int D, int M,
+                    const float* background, int width, int height,
+                    const float* means3D, const float* shs, const float* colors_precomp,
+                    const float* opacities, const float* scales, float scale_modifier,
+                    const float* rotations, const float* cov3D_precomp,
+                    const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                    float tan_fovx, float tan_fovy, int prefiltered,
+                    float* out_color, int* radii, int debug);
+
+/* Gradient outputs need NOT be zero-initialised (the reference requires torch::zeros,
+ * rasterize_points.cu:151-159); every element is written.  dL_dconic[P,4] is scratch.
+ * dL_dsh may be NULL when M == 0, dL_dscale / dL_drot may be NULL when scales == NULL. */
+int tgs_backward(void* stream, int P, int D, int M, int64_t R,
+                 const float* background, int width, int height,
+                 const float* means3D, const float* shs, const float* colors_precomp,
+                 const float* scales, float scale_modifier, const float* rotations,
+                 const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                 const float* campos, float tan_fovx, float tan_fovy, const int* radii,
+                 const void* geom_buffer, const void* binning_buffer, const void* img_buffer,
+                 const float* dL_dpix,
+                 float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+                 float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                 int debug);
+
+/* present[P]: 1 byte per Gaussian, 1 iff view-space z > 0.2 (auxiliary.h:154). */
+int tgs_mark_visible(void* stream, int P, const float* means3D, const float* viewmatrix,
+                     const float* projmatrix, uint8_t* present);
+
+/* Introspection of a finished forward pass (tests, bench): copies are enqueued on `stream`.
+ * field: "n_contrib" (u32[H*W]), "final_T" (f32[H*W]), "ranges" (u32[2*T]), "point_list" (u32[R]),
+ * "means2D" (f32[2P]), "depths" (f32[P]), "conic_opacity" (f32[4P]), "rgb" (f32[3P], SH path only),
+ * "tiles_touched" (u32[P]).  dst is a device pointer with room for the whole field.
+ * Returns the element count or a negative error. */
+int64_t tgs_state_field(void* stream, const char* field, int P, int width, int height, int64_t R,
+                        int has_sh, int has_scale_rot,
+                        const void* geom_buffer, const void* binning_buffer, const void* img_buffer,
+                        void* dst, size_t dst_bytes);
+
+const char* tgs_last_error(void);   /* thread-local message of the last failing call */
+int tgs_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TGS_RASTER_H */

@@ -1,0 +1,141 @@
+"""Shared helpers of the test-suite: golden loading, oracle / HIP runners, the parity metric."""
+from __future__ import annotations
+
+import glob
+import os
+from typing import Dict, Optional
+
+import numpy as np
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+REL_TOL = 1e-4          # BASELINE.json: "within 1e-4 rel-L2 of reference"
+NOISY = ("dL_dmeans3D", "dL_dcov3D", "dL_dscales", "dL_drotations")
+GRAD_KEYS = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations")
+
+
+def rel_l2(x, ref) -> float:
+    """SURVEY.md section 8d parity metric: ||x - ref|| / max(||ref||, 1e-12)."""
+    x = np.asarray(x, np.float64); ref = np.asarray(ref, np.float64)
+    return float(np.linalg.norm(x - ref) / max(np.linalg.norm(ref), 1e-12))
+
+
+def golden_names():
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def load_golden(name: str):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    inp = {k[3:]: z[k] for k in z.files if k.startswith("in_")}
+    out = {k[4:]: z[k] for k in z.files if k.startswith("out_")}
+    return inp, out
+
+
+def tolerance(key: str, golden_out: Optional[dict]) -> float:
+    """1e-4, except where the reference's own arithmetic (FMA contraction on/off of the SAME kernel
+    text, stored in the fixture as nofma_*) already moves a cancellation-prone tensor by more."""
+    tol = REL_TOL
+    if golden_out is not None and key in NOISY and ("nofma_" + key) in golden_out:
+        tol = max(tol, 3.0 * rel_l2(golden_out["nofma_" + key], golden_out[key]))
+    return tol
+
+
+def oracle_run(inp: dict, dL: Optional[np.ndarray] = None):
+    from oracle import oracle
+    kw = dict(bg=inp["bg"], means3D=inp["means3D"], viewmatrix=inp["viewmatrix"], projmatrix=inp["projmatrix"],
+              campos=inp["campos"], tanfovx=float(inp["tanfovx"]), tanfovy=float(inp["tanfovy"]),
+              scale_modifier=float(inp.get("scale_modifier", 1.0)))
+    for k in ("shs", "colors_precomp", "scales", "rotations", "cov3D_precomp"):
+        kw[k] = inp.get(k)
+    color, radii, st = oracle.forward(opacities=inp["opacities"], image_height=int(inp["image_height"]),
+                                      image_width=int(inp["image_width"]), sh_degree=int(inp["sh_degree"]), **kw)
+    H, W = int(inp["image_height"]), int(inp["image_width"])
+    out = dict(color=color, radii=radii, num_rendered=st.num_rendered, n_contrib=st.field("n_contrib").reshape(H, W),
+               final_T=st.field("final_T").reshape(H, W), point_list=st.field("point_list"),
+               ranges=st.field("ranges").reshape(-1, 2), means2D=st.field("means2D").reshape(-1, 2),
+               depths=st.field("depths"), conic_opacity=st.field("conic_opacity").reshape(-1, 4),
+               rgb=st.field("rgb").reshape(-1, 3), tiles_touched=st.field("tiles_touched"))
+    if dL is not None:
+        out.update(oracle.backward(st, dL, **kw))
+    return out
+
+
+def scene_input(cloud: dict, cam, mode: str = "sh", cov_mode: str = "scale_rot") -> dict:
+    from youreditableavatar_amd import scenes
+    inp = dict(bg=cam.bg, means3D=cloud["means3D"], opacities=cloud["opacities"], viewmatrix=cam.viewmatrix,
+               projmatrix=cam.projmatrix, campos=cam.campos, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
+               image_height=cam.image_height, image_width=cam.image_width, sh_degree=cloud["sh_degree"],
+               scale_modifier=cam.scale_modifier)
+    if mode == "sh":
+        inp["shs"] = cloud["shs"]
+    else:
+        inp["colors_precomp"] = scenes.sh_to_rgb_numpy(cloud["shs"], cloud["means3D"], cam.campos, cloud["sh_degree"])
+    if cov_mode == "scale_rot":
+        inp["scales"], inp["rotations"] = cloud["scales"], cloud["rotations"]
+    else:
+        inp["cov3D_precomp"] = cloud["cov3D_precomp"]
+    return inp
+
+
+def hip_run(inp: dict, dL: Optional[np.ndarray] = None, device="cuda:0", debug=False, introspect=True) -> Dict[str, np.ndarray]:
+    """The HIP path through the reference's ``_C`` surface (ctypes over the C ABI of include/tgs_raster.h)."""
+    import torch
+    from diff_gaussian_rasterization import _C
+    dev = torch.device(device)
+    t = lambda k: (torch.from_numpy(np.ascontiguousarray(inp[k], np.float32)).to(dev) if inp.get(k) is not None else torch.Tensor([]))
+    bg, means3D, opac, view, proj, campos = t("bg"), t("means3D"), t("opacities"), t("viewmatrix"), t("projmatrix"), t("campos")
+    sh, colors, scales, rots, cov = t("shs"), t("colors_precomp"), t("scales"), t("rotations"), t("cov3D_precomp")
+    H, W, D = int(inp["image_height"]), int(inp["image_width"]), int(inp["sh_degree"])
+    sm, tfx, tfy = float(inp.get("scale_modifier", 1.0)), float(inp["tanfovx"]), float(inp["tanfovy"])
+    R, color, radii, geom, binning, img = _C.rasterize_gaussians(bg, means3D, colors, opac, scales, rots, sm, cov, view, proj,
+                                                                 tfx, tfy, H, W, sh, D, campos, False, debug)
+    P = means3D.shape[0]
+    out = dict(color=color.cpu().numpy(), radii=radii.cpu().numpy(), num_rendered=R)
+    has_sh, has_sr = inp.get("shs") is not None, inp.get("scales") is not None
+    if introspect and P > 0:
+        f = lambda n: _C.state_field(n, P, W, H, R, has_sh, has_sr, geom, binning, img).cpu().numpy()
+        out["n_contrib"] = f("n_contrib").astype(np.uint32).reshape(H, W)
+        out["final_T"] = f("final_T").reshape(H, W)
+        out["ranges"] = f("ranges").astype(np.uint32).reshape(-1, 2)
+        out["point_list"] = f("point_list").astype(np.uint32)
+        out["means2D"] = f("means2D").reshape(-1, 2)
+        out["depths"] = f("depths")
+        out["conic_opacity"] = f("conic_opacity").reshape(-1, 4)
+        out["tiles_touched"] = f("tiles_touched").astype(np.uint32)
+        if has_sh:
+            out["rgb"] = f("rgb").reshape(-1, 3)
+    if dL is not None:
+        g = _C.rasterize_gaussians_backward(bg, means3D, radii, colors, scales, rots, sm, cov, view, proj, tfx, tfy,
+                                            torch.from_numpy(np.ascontiguousarray(dL, np.float32)).to(dev), sh, D, campos, geom, R, binning, img, debug)
+        names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations")
+        out.update({n: v.cpu().numpy() for n, v in zip(names, g)})
+    torch.cuda.synchronize()
+    return out
+
+
+def compare(mine: dict, ref: dict, golden_out: Optional[dict] = None, nc_frac: float = 0.999, check_lists: bool = True):
+    """Asserts the SURVEY.md section 8d parity bar; returns {tensor: rel_l2} for reporting."""
+    H, W = ref["n_contrib"].shape
+    rep = {}
+    assert int(mine["num_rendered"]) == int(ref["num_rendered"]), "num_rendered differs"
+    vis = np.asarray(ref["radii"]) > 0
+    assert np.array_equal(np.asarray(mine["radii"]), np.asarray(ref["radii"])), "radii differ"
+    if check_lists and "point_list" in mine:
+        assert np.array_equal(mine["point_list"], ref["point_list"]), "per-tile sorted lists differ"
+    if "n_contrib" in mine:
+        frac = float((mine["n_contrib"] == ref["n_contrib"]).mean())
+        rep["n_contrib_equal"] = frac
+        assert frac >= nc_frac, f"n_contrib equal on {frac:.5f} of pixels"
+    e = rel_l2(mine["color"], ref["color"]); rep["color"] = e
+    assert e <= REL_TOL, f"color rel-L2 {e:.3e}"
+    for k in GRAD_KEYS:
+        if k in mine and k in ref:
+            a, b = np.asarray(mine[k]), np.asarray(ref[k])
+            if k == "dL_dmeans2D":
+                assert np.all(a[:, 2] == 0)
+            e = rel_l2(a, b); rep[k] = e
+            tol = tolerance(k, golden_out)
+            assert e <= tol, f"{k} rel-L2 {e:.3e} > {tol:.1e}"
+            assert np.all(a[~vis] == 0), f"{k}: culled Gaussians must have zero gradient"
+    return rep

@@ -1,0 +1,225 @@
+// tgs_api.hip -- the C ABI of include/tgs_raster.h: argument checks, state-buffer carving, launches.
+// Host orchestration counterpart of cuda_rasterizer/rasterizer_impl.cu:141-434.
+#include "tgs_device.hpp"
+#include "../../include/tgs_raster.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+namespace tgs {
+void launch_preprocess_fwd(hipStream_t, const FwdIn&, const CamParams&, const GeomState&, const ImgState&);
+void launch_scan(hipStream_t, const GeomState&, const ImgState&, uint32_t nblocks, uint32_t T);
+void launch_scatter(hipStream_t, int P, const GeomState&, const ImgState&, const BinState&, uint32_t gx);
+void launch_tile_sort(hipStream_t, const GeomState&, const ImgState&, const BinState&, const float* colors, uint32_t gx, uint32_t T,
+                      uint32_t max_count, uint32_t n_overflow);
+void launch_render_fwd(hipStream_t, const ImgState&, const BinState&, int W, int H, uint32_t gx, uint32_t T, const float* bg, float* out_color);
+void launch_mark_visible(hipStream_t, int P, const float* means3D, const float* view, uint8_t* present);
+void launch_render_bwd(hipStream_t, const ImgState&, const BinState&, int W, int H, uint32_t gx, uint32_t T, const float* bg, const float* dL_dpix);
+void launch_preprocess_bwd(hipStream_t, const BwdIn&, const CamParams&, const GeomState&, const BinState&);
+}  // namespace tgs
+
+using namespace tgs;
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                     \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess) return fail(TGS_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// the reference's CHECK_CUDA (auxiliary.h:166-173): in debug mode synchronise after every stage
+#define STAGE_CHECK(name)                                                                                 \
+    do {                                                                                                  \
+        hipError_t e_ = hipGetLastError();                                                                \
+        if (e_ == hipSuccess && debug) e_ = hipStreamSynchronize(st);                                     \
+        if (e_ != hipSuccess) return fail(TGS_ERR_HIP, "stage %s: %s", name, hipGetErrorString(e_));       \
+    } while (0)
+
+static CamParams make_cam(const float* view, const float* proj, const float* campos, float tan_fovx, float tan_fovy, float scale_modifier,
+                          int W, int H)
+{
+    CamParams c;
+    c.view = view; c.proj = proj; c.campos = campos;
+    c.tan_fovx = tan_fovx; c.tan_fovy = tan_fovy;
+    c.focal_y = H / (2.0f * tan_fovy);            // rasterizer_impl.cu:222-223
+    c.focal_x = W / (2.0f * tan_fovx);
+    c.scale_modifier = scale_modifier;
+    c.W = W; c.H = H;
+    c.gx = (uint32_t)((W + TILE - 1) / TILE);
+    c.gy = (uint32_t)((H + TILE - 1) / TILE);
+    return c;
+}
+
+extern "C" {
+
+int tgs_abi_version(void) { return TGS_ABI_VERSION; }
+const char* tgs_last_error(void) { return g_err; }
+
+int64_t tgs_forward(tgs_alloc_fn alloc, void* alloc_ctx, void* stream, int P, int D, int M, const float* background, int width,
+                    int height, const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+                    const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                    const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
+                    int prefiltered, float* out_color, int* radii, int debug)
+{
+    hipStream_t st = (hipStream_t)stream;
+    g_err[0] = 0;
+    if (!alloc) return fail(TGS_ERR_INVALID, "alloc callback is NULL");
+    if (P < 0 || width <= 0 || height <= 0) return fail(TGS_ERR_INVALID, "bad sizes P=%d W=%d H=%d", P, width, height);
+    if ((shs == nullptr) == (colors_precomp == nullptr)) return fail(TGS_ERR_INVALID, "provide exactly one of shs / colors_precomp");
+    const bool has_sr = scales != nullptr && rotations != nullptr;
+    if (has_sr == (cov3D_precomp != nullptr) || (scales == nullptr) != (rotations == nullptr))
+        return fail(TGS_ERR_INVALID, "provide exactly one of (scales, rotations) / cov3D_precomp");
+    if (shs && (D < 0 || D > 3 || M < (D + 1) * (D + 1))) return fail(TGS_ERR_INVALID, "SH degree %d needs M >= %d (M=%d)", D, (D + 1) * (D + 1), M);
+    if (!background || !means3D || !opacities || !viewmatrix || !projmatrix || !cam_pos || !out_color)
+        return fail(TGS_ERR_INVALID, "NULL required pointer");
+    const CamParams cam = make_cam(viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, scale_modifier, width, height);
+    if (cam.gx > 65535u || cam.gy > 65535u) return fail(TGS_ERR_INVALID, "image too large");
+    const size_t N = (size_t)width * height, T = (size_t)cam.gx * cam.gy;
+    const bool has_sh = shs != nullptr;
+    if (P == 0) {   // rasterize_points.cu:81: nothing runs, the image keeps its zero fill
+        HIP_TRY(hipMemsetAsync(out_color, 0, 3 * N * sizeof(float), st));
+        return 0;
+    }
+
+    GeomState g; ImgState s; BinState b;
+    const size_t geom_bytes = geom_carve(g, nullptr, (size_t)P, has_sh, has_sr);
+    const size_t img_bytes = img_carve(s, nullptr, N, T);
+    char* geom_ptr = (char*)alloc(alloc_ctx, TGS_BUF_GEOM, geom_bytes);
+    char* img_ptr = (char*)alloc(alloc_ctx, TGS_BUF_IMAGE, img_bytes);
+    if (!geom_ptr || !img_ptr) return fail(TGS_ERR_ALLOC, "state buffer allocation failed");
+    geom_carve(g, geom_ptr, (size_t)P, has_sh, has_sr);
+    img_carve(s, img_ptr, N, T);
+
+    // meta + ranges + tile_count are contiguous at the head of the image buffer: one memset
+    HIP_TRY(hipMemsetAsync(img_ptr, 0, (size_t)((char*)s.cursor - img_ptr), st));
+
+    FwdIn in;
+    in.P = P; in.D = D; in.M = M; in.means3D = means3D; in.shs = shs; in.colors_precomp = colors_precomp; in.opacities = opacities;
+    in.scales = scales; in.rotations = rotations; in.cov3D_precomp = cov3D_precomp; in.background = background;
+    in.prefiltered = prefiltered; in.out_color = out_color; in.radii = radii;
+
+    uint64_t R = 0;
+    Meta meta;
+    memset(&meta, 0, sizeof(meta));
+    if (P > 0) {
+        launch_preprocess_fwd(st, in, cam, g, s);
+        STAGE_CHECK("preprocess");
+        launch_scan(st, g, s, (uint32_t)n_blocks((size_t)P), (uint32_t)T);
+        STAGE_CHECK("scan");
+        // the one host synchronisation of the forward pass (rasterizer_impl.cu:280-281): R sizes the binning buffer
+        HIP_TRY(hipMemcpyAsync(&meta, s.meta, sizeof(Meta), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (meta.error & 1u) return fail(TGS_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
+        R = meta.R;
+        if (R > 0x7fffffffull) return fail(TGS_ERR_TOO_MANY, "%llu tile instances exceed 2^31-1", (unsigned long long)R);
+    }
+    const size_t bin_bytes = bin_carve(b, nullptr, (size_t)R);
+    char* bin_ptr = (char*)alloc(alloc_ctx, TGS_BUF_BINNING, bin_bytes);
+    if (!bin_ptr) return fail(TGS_ERR_ALLOC, "binning buffer allocation failed");
+    bin_carve(b, bin_ptr, (size_t)R);
+
+    if (R > 0) {
+        launch_scatter(st, P, g, s, b, cam.gx);
+        STAGE_CHECK("scatter");
+        const float* colors = has_sh ? g.rgb : colors_precomp;       // rasterizer_impl.cu:321
+        launch_tile_sort(st, g, s, b, colors, cam.gx, (uint32_t)T, meta.max_count, meta.n_overflow);
+        STAGE_CHECK("tile_sort");
+    }
+    launch_render_fwd(st, s, b, width, height, cam.gx, (uint32_t)T, background, out_color);
+    STAGE_CHECK("render");
+    return (int64_t)R;
+}
+
+int tgs_backward(void* stream, int P, int D, int M, int64_t R, const float* background, int width, int height, const float* means3D,
+                 const float* shs, const float* colors_precomp, const float* scales, float scale_modifier, const float* rotations,
+                 const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx,
+                 float tan_fovy, const int* radii, const void* geom_buffer, const void* binning_buffer, const void* img_buffer,
+                 const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
+                 float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug)
+{
+    hipStream_t st = (hipStream_t)stream;
+    g_err[0] = 0;
+    if (P == 0) return TGS_OK;
+    if (P < 0 || R < 0 || width <= 0 || height <= 0) return fail(TGS_ERR_INVALID, "bad sizes");
+    const bool has_sh = shs != nullptr, has_sr = scales != nullptr && rotations != nullptr;
+    if (has_sh == (colors_precomp != nullptr)) return fail(TGS_ERR_INVALID, "provide exactly one of shs / colors_precomp");
+    if (has_sr == (cov3D_precomp != nullptr)) return fail(TGS_ERR_INVALID, "provide exactly one of (scales, rotations) / cov3D_precomp");
+    if (!geom_buffer || !binning_buffer || !img_buffer || !radii || !dL_dpix || !dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor ||
+        !dL_dmean3D || !dL_dcov3D || (has_sh && !dL_dsh))
+        return fail(TGS_ERR_INVALID, "NULL required pointer");
+    const CamParams cam = make_cam(viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, scale_modifier, width, height);
+    const size_t N = (size_t)width * height, T = (size_t)cam.gx * cam.gy;
+    GeomState g; ImgState s; BinState b;
+    geom_carve(g, (char*)geom_buffer, (size_t)P, has_sh, has_sr);
+    img_carve(s, (char*)img_buffer, N, T);
+    bin_carve(b, (char*)binning_buffer, (size_t)R);
+
+    BwdIn in;
+    in.P = P; in.D = D; in.M = M; in.means3D = means3D; in.shs = shs; in.colors_precomp = colors_precomp; in.scales = scales;
+    in.rotations = rotations; in.cov3D_precomp = cov3D_precomp; in.background = background; in.radii = radii; in.dL_dpix = dL_dpix;
+    in.dL_dmean2D = dL_dmean2D; in.dL_dconic = dL_dconic; in.dL_dopacity = dL_dopacity; in.dL_dcolor = dL_dcolor;
+    in.dL_dmean3D = dL_dmean3D; in.dL_dcov3D = dL_dcov3D; in.dL_dsh = dL_dsh; in.dL_dscale = dL_dscale; in.dL_drot = dL_drot;
+
+    if (R > 0) {
+        launch_render_bwd(st, s, b, width, height, cam.gx, (uint32_t)T, background, dL_dpix);
+        STAGE_CHECK("render_bwd");
+    }
+    launch_preprocess_bwd(st, in, cam, g, b);
+    STAGE_CHECK("preprocess_bwd");
+    return TGS_OK;
+}
+
+int tgs_mark_visible(void* stream, int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present)
+{
+    hipStream_t st = (hipStream_t)stream;
+    g_err[0] = 0;
+    (void)projmatrix;       // the reference's x/y frustum test is commented out (auxiliary.h:154)
+    if (P == 0) return TGS_OK;
+    if (P < 0 || !means3D || !viewmatrix || !present) return fail(TGS_ERR_INVALID, "bad arguments");
+    launch_mark_visible(st, P, means3D, viewmatrix, present);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(TGS_ERR_HIP, "mark_visible: %s", hipGetErrorString(e));
+    return TGS_OK;
+}
+
+int64_t tgs_state_field(void* stream, const char* field, int P, int width, int height, int64_t R, int has_sh, int has_scale_rot,
+                        const void* geom_buffer, const void* binning_buffer, const void* img_buffer, void* dst, size_t dst_bytes)
+{
+    hipStream_t st = (hipStream_t)stream;
+    g_err[0] = 0;
+    const uint32_t gx = (uint32_t)((width + TILE - 1) / TILE), gy = (uint32_t)((height + TILE - 1) / TILE);
+    const size_t N = (size_t)width * height, T = (size_t)gx * gy;
+    GeomState g; ImgState s; BinState b;
+    geom_carve(g, (char*)geom_buffer, (size_t)P, has_sh != 0, has_scale_rot != 0);
+    img_carve(s, (char*)img_buffer, N, T);
+    bin_carve(b, (char*)binning_buffer, (size_t)R);
+    const void* src = nullptr; size_t count = 0, esz = 4, stride = 0;
+    if (!strcmp(field, "n_contrib")) { src = s.n_contrib; count = N; }
+    else if (!strcmp(field, "final_T")) { src = s.final_T; count = N; }
+    else if (!strcmp(field, "ranges")) { src = s.ranges; count = 2 * T; }
+    else if (!strcmp(field, "means2D")) { src = g.xy; count = 2 * (size_t)P; }
+    else if (!strcmp(field, "depths")) { src = g.depth; count = (size_t)P; }
+    else if (!strcmp(field, "conic_opacity")) { src = g.conic_opacity; count = 4 * (size_t)P; }
+    else if (!strcmp(field, "rgb")) { if (!has_sh) return fail(TGS_ERR_INVALID, "rgb only exists on the SH path"); src = g.rgb; count = 3 * (size_t)P; }
+    else if (!strcmp(field, "tiles_touched")) { src = g.tiles_touched; count = (size_t)P; }
+    else if (!strcmp(field, "point_list")) { src = b.keys; count = (size_t)R; stride = 8; }   // low 32 bits of each sorted key
+    else return fail(TGS_ERR_INVALID, "unknown field %s", field);
+    if (dst_bytes < count * esz) return fail(TGS_ERR_INVALID, "dst too small for %s", field);
+    if (count == 0) return 0;
+    if (stride) HIP_TRY(hipMemcpy2DAsync(dst, esz, src, stride, esz, count, hipMemcpyDeviceToDevice, st));
+    else HIP_TRY(hipMemcpyAsync(dst, src, count * esz, hipMemcpyDeviceToDevice, st));
+    return (int64_t)count;
+}
+
+}  // extern "C"

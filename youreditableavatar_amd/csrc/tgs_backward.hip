@@ -1,0 +1,367 @@
+// tgs_backward.hip -- backward pass kernels for gfx950 (wave64).
+//
+//   k_render_bwd      back-to-front gradient of the compositing                      (backward.cu:399-557)
+//   k_preprocess_bwd  per-Gaussian: sum of the tile partials, then cov2D / projection / SH / cov3D
+//                     backward fused in one pass          (backward.cu:144-274 + :346-396, two kernels there)
+//
+// The reference adds 9 floats per (pixel, Gaussian) fragment with global atomicAdd
+// (backward.cu:523,545-554).  Here all 64 lanes of a wave work on the SAME list entry at the same
+// time, so the 9 partials are first summed across the wave with DPP row operations, then across the
+// tile's 4 waves through LDS, and the tile stores ONE 36-byte row per (tile, Gaussian) instance with
+// plain stores into a slab indexed in Gaussian order (row = offsets[g] + ordinal of the tile inside
+// g's rectangle).  k_preprocess_bwd then sums each Gaussian's contiguous rows in a fixed order: no
+// float atomics at all, and gradients are bitwise reproducible run to run (the reference's are not).
+#include "tgs_device.hpp"
+
+namespace tgs {
+
+constexpr int BCHUNK = 256;    // list entries staged per round
+constexpr int NACC = 9;        // colour rgb, mean2D xy, conic xx/xy/yy, opacity
+
+__global__ __launch_bounds__(256) void k_render_bwd(const ImgState s, const BinState b, int W, int H, uint32_t gx,
+                                                    const float* __restrict__ bg, const float* __restrict__ dL_dpix)
+{
+    __shared__ float4 sA[BCHUNK];
+    __shared__ float4 sB[BCHUNK];
+    __shared__ float sC[BCHUNK];
+    __shared__ uint32_t sSlot[BCHUNK];
+    __shared__ float wacc[4][NACC][BCHUNK];               // per-wave partial sums of the current round
+    __shared__ unsigned long long touched[4][BCHUNK / 64];
+    __shared__ uint32_t wmax[4];
+
+    const uint32_t tile = blockIdx.x;
+    const uint32_t tx = tile % gx, ty = tile / gx;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int px = tx * TILE + (wv & 1) * 8 + (lane & 7);
+    const int py = ty * TILE + (wv >> 1) * 8 + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const float pixfx = (float)px, pixfy = (float)py;
+    const uint2 rg = s.ranges[tile];
+    const uint32_t n = rg.y - rg.x;
+    if (n == 0) return;
+    const size_t pix_id = (size_t)W * py + px, N = (size_t)W * H;
+
+    const float T_final = inside ? s.final_T[pix_id] : 0.f;
+    float T = T_final;
+    const uint32_t last_contributor = inside ? s.n_contrib[pix_id] : 0u;
+    float dpx0 = 0.f, dpx1 = 0.f, dpx2 = 0.f;
+    if (inside) { dpx0 = dL_dpix[pix_id]; dpx1 = dL_dpix[N + pix_id]; dpx2 = dL_dpix[2 * N + pix_id]; }
+    float bg_dot_dpixel = 0.f;                              // backward.cu:533-535
+    bg_dot_dpixel += bg[0] * dpx0; bg_dot_dpixel += bg[1] * dpx1; bg_dot_dpixel += bg[2] * dpx2;
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;               // accum_rec
+    float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
+    const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);   // backward.cu:460-461
+
+    // Entries behind every pixel's last contributor get no gradient (backward.cu:487-488): find the
+    // deepest one any pixel of the tile needs and start there.
+    uint32_t m = wave_max_u32(last_contributor);
+    if (lane == 0) wmax[wv] = m;
+    __syncthreads();
+    const uint32_t qmax = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+
+    // rows of the never-visited tail are zero
+    for (uint32_t q = qmax + threadIdx.x; q < n; q += 256) {
+        float* row = b.slab + (size_t)b.slot[rg.x + q] * NACC;
+#pragma unroll
+        for (int k = 0; k < NACC; k++) row[k] = 0.f;
+    }
+
+    for (uint32_t qhi = qmax; qhi > 0; qhi = qhi > BCHUNK ? qhi - BCHUNK : 0) {
+        const uint32_t cnt = min((uint32_t)BCHUNK, qhi);
+        __syncthreads();                                    // previous round's flush has read wacc / sSlot
+        if (threadIdx.x < cnt) {                            // slot t of the round = list position qhi-1-t
+            const uint32_t pos = rg.x + qhi - 1 - threadIdx.x;
+            sA[threadIdx.x] = b.recA[pos];
+            sB[threadIdx.x] = b.recB[pos];
+            sC[threadIdx.x] = b.recC[pos].x;
+            sSlot[threadIdx.x] = b.slot[pos];
+        }
+        __syncthreads();
+
+#pragma unroll 1
+        for (uint32_t jj = 0; jj < BCHUNK / 64; jj++) {
+            unsigned long long tmask = 0;
+            const uint32_t jend = min(cnt, (jj + 1) * 64u);
+            for (uint32_t j = jj * 64; j < jend; j++) {
+                const uint32_t q = qhi - 1 - j;
+                const float4 a = sA[j];
+                const float4 bb = sB[j];
+                const float dx = a.x - pixfx, dy = a.y - pixfy;
+                const float power = -0.5f * (a.z * dx * dx + bb.x * dy * dy) - a.w * dx * dy;
+                const float G = expf(power);
+                const float alpha = fminf(0.99f, bb.y * G);
+                const bool valid = (q < last_contributor) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+                if (__builtin_amdgcn_ballot_w64(valid) == 0) continue;
+                float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f, v5 = 0.f, v6 = 0.f, v7 = 0.f, v8 = 0.f;
+                if (valid) {                                // backward.cu:507-555
+                    T = T / (1.f - alpha);
+                    const float dchannel_dcolor = alpha * T;
+                    float dL_dalpha = 0.0f;
+                    const float c0 = bb.z, c1 = bb.w, c2 = sC[j];
+                    acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0; lc0 = c0; dL_dalpha += (c0 - acc0) * dpx0; v0 = dchannel_dcolor * dpx0;
+                    acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1; lc1 = c1; dL_dalpha += (c1 - acc1) * dpx1; v1 = dchannel_dcolor * dpx1;
+                    acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2; lc2 = c2; dL_dalpha += (c2 - acc2) * dpx2; v2 = dchannel_dcolor * dpx2;
+                    dL_dalpha *= T;
+                    last_alpha = alpha;
+                    dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
+                    const float dL_dG = bb.y * dL_dalpha;
+                    const float gdx = G * dx, gdy = G * dy;
+                    const float dG_ddelx = -gdx * a.z - gdy * a.w;
+                    const float dG_ddely = -gdy * bb.x - gdx * a.w;
+                    v3 = dL_dG * dG_ddelx * ddelx_dx;
+                    v4 = dL_dG * dG_ddely * ddely_dy;
+                    v5 = -0.5f * gdx * dx * dL_dG;
+                    v6 = -0.5f * gdx * dy * dL_dG;
+                    v7 = -0.5f * gdy * dy * dL_dG;
+                    v8 = G * dL_dalpha;
+                }
+                // wave-level sums (the total ends up in every lane; lane 0 stores)
+                v0 = wave_sum(v0); v1 = wave_sum(v1); v2 = wave_sum(v2); v3 = wave_sum(v3); v4 = wave_sum(v4);
+                v5 = wave_sum(v5); v6 = wave_sum(v6); v7 = wave_sum(v7); v8 = wave_sum(v8);
+                if (lane == 0) {
+                    wacc[wv][0][j] = v0; wacc[wv][1][j] = v1; wacc[wv][2][j] = v2; wacc[wv][3][j] = v3; wacc[wv][4][j] = v4;
+                    wacc[wv][5][j] = v5; wacc[wv][6][j] = v6; wacc[wv][7][j] = v7; wacc[wv][8][j] = v8;
+                }
+                tmask |= 1ull << (j & 63);
+            }
+            if (lane == 0) touched[wv][jj] = tmask;
+        }
+        __syncthreads();
+        // flush: thread j adds the (up to) 4 wave partials of entry j in wave order and stores the row
+        if (threadIdx.x < cnt) {
+            const uint32_t j = threadIdx.x;
+            float r[NACC];
+#pragma unroll
+            for (int k = 0; k < NACC; k++) r[k] = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                if ((touched[w][j >> 6] >> (j & 63)) & 1ull) {
+#pragma unroll
+                    for (int k = 0; k < NACC; k++) r[k] += wacc[w][k][j];
+                }
+            }
+            float* row = b.slab + (size_t)sSlot[j] * NACC;
+#pragma unroll
+            for (int k = 0; k < NACC; k++) row[k] = r[k];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_preprocess_bwd
+// ---------------------------------------------------------------------------------------------
+template <bool HAS_SH, bool HAS_SCALE_ROT>
+__global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, const CamParams cam, const GeomState g, const BinState b)
+{
+    const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
+    const ViewMat V = load_mat(cam.view), PM = load_mat(cam.proj);
+    const float camx = cam.campos[0], camy = cam.campos[1], camz = cam.campos[2];
+    if (idx >= in.P) return;
+    const size_t i3 = 3 * (size_t)idx;
+    float a[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; k++) a[k] = 0.f;
+    float dmean[3] = {0.f, 0.f, 0.f};
+    float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float dscale[3] = {0.f, 0.f, 0.f};
+    float drot[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool live = in.radii[idx] > 0;                   // backward.cu:156,367
+    float mx = 0.f, my = 0.f, mz = 0.f;
+    float dRGB[3] = {0.f, 0.f, 0.f};
+    if (live) {
+        // sum of this Gaussian's tile partials, fixed order
+        const uint32_t tiles = g.tiles_touched[idx];
+        const float* row = b.slab + (size_t)g.offsets[idx] * NACC;
+        for (uint32_t k = 0; k < tiles; k++, row += NACC) {
+#pragma unroll
+            for (int c = 0; c < NACC; c++) a[c] += row[c];
+        }
+        mx = in.means3D[i3]; my = in.means3D[i3 + 1]; mz = in.means3D[i3 + 2];
+
+        // ---- computeCov2DCUDA (backward.cu:144-274) ----
+        float cov3d[6];
+        const float* csrc = HAS_SCALE_ROT ? (g.cov3D + 6 * (size_t)idx) : (in.cov3D_precomp + 6 * (size_t)idx);
+#pragma unroll
+        for (int i = 0; i < 6; i++) cov3d[i] = csrc[i];
+        const Cov2D c2 = compute_cov2d(mx, my, mz, cov3d, cam, V);
+        const float limx = 1.3f * cam.tan_fovx, limy = 1.3f * cam.tan_fovy;
+        const float x_grad_mul = (c2.txtz < -limx || c2.txtz > limx) ? 0.f : 1.f;
+        const float y_grad_mul = (c2.tytz < -limy || c2.tytz > limy) ? 0.f : 1.f;
+        const float ca = c2.cov.m[0][0] + 0.3f, cb = c2.cov.m[0][1], cc = c2.cov.m[1][1] + 0.3f;
+        const float dLc0 = a[5], dLc1 = a[6], dLc2 = a[7];    // dL_dconic .x .y .w
+        const float denom = ca * cc - cb * cb;
+        float dL_da = 0, dL_db = 0, dL_dc = 0;
+        const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+#define Tm(c_, r_) c2.T.m[c_][r_]
+        if (denom2inv != 0) {
+            dL_da = denom2inv * (-cc * cc * dLc0 + 2 * cb * cc * dLc1 + (denom - ca * cc) * dLc2);
+            dL_dc = denom2inv * (-ca * ca * dLc2 + 2 * ca * cb * dLc1 + (denom - ca * cc) * dLc0);
+            dL_db = denom2inv * 2 * (cb * cc * dLc0 - (denom + 2 * cb * cb) * dLc1 + ca * cb * dLc2);
+            dcov[0] = (Tm(0, 0) * Tm(0, 0) * dL_da + Tm(0, 0) * Tm(1, 0) * dL_db + Tm(1, 0) * Tm(1, 0) * dL_dc);
+            dcov[3] = (Tm(0, 1) * Tm(0, 1) * dL_da + Tm(0, 1) * Tm(1, 1) * dL_db + Tm(1, 1) * Tm(1, 1) * dL_dc);
+            dcov[5] = (Tm(0, 2) * Tm(0, 2) * dL_da + Tm(0, 2) * Tm(1, 2) * dL_db + Tm(1, 2) * Tm(1, 2) * dL_dc);
+            dcov[1] = 2 * Tm(0, 0) * Tm(0, 1) * dL_da + (Tm(0, 0) * Tm(1, 1) + Tm(0, 1) * Tm(1, 0)) * dL_db + 2 * Tm(1, 0) * Tm(1, 1) * dL_dc;
+            dcov[2] = 2 * Tm(0, 0) * Tm(0, 2) * dL_da + (Tm(0, 0) * Tm(1, 2) + Tm(0, 2) * Tm(1, 0)) * dL_db + 2 * Tm(1, 0) * Tm(1, 2) * dL_dc;
+            dcov[4] = 2 * Tm(0, 2) * Tm(0, 1) * dL_da + (Tm(0, 1) * Tm(1, 2) + Tm(0, 2) * Tm(1, 1)) * dL_db + 2 * Tm(1, 1) * Tm(1, 2) * dL_dc;
+        }
+#define Vk(c_, r_) c2.Vrk.m[c_][r_]
+        const float dL_dT00 = 2 * (Tm(0, 0) * Vk(0, 0) + Tm(0, 1) * Vk(0, 1) + Tm(0, 2) * Vk(0, 2)) * dL_da + (Tm(1, 0) * Vk(0, 0) + Tm(1, 1) * Vk(0, 1) + Tm(1, 2) * Vk(0, 2)) * dL_db;
+        const float dL_dT01 = 2 * (Tm(0, 0) * Vk(1, 0) + Tm(0, 1) * Vk(1, 1) + Tm(0, 2) * Vk(1, 2)) * dL_da + (Tm(1, 0) * Vk(1, 0) + Tm(1, 1) * Vk(1, 1) + Tm(1, 2) * Vk(1, 2)) * dL_db;
+        const float dL_dT02 = 2 * (Tm(0, 0) * Vk(2, 0) + Tm(0, 1) * Vk(2, 1) + Tm(0, 2) * Vk(2, 2)) * dL_da + (Tm(1, 0) * Vk(2, 0) + Tm(1, 1) * Vk(2, 1) + Tm(1, 2) * Vk(2, 2)) * dL_db;
+        const float dL_dT10 = 2 * (Tm(1, 0) * Vk(0, 0) + Tm(1, 1) * Vk(0, 1) + Tm(1, 2) * Vk(0, 2)) * dL_dc + (Tm(0, 0) * Vk(0, 0) + Tm(0, 1) * Vk(0, 1) + Tm(0, 2) * Vk(0, 2)) * dL_db;
+        const float dL_dT11 = 2 * (Tm(1, 0) * Vk(1, 0) + Tm(1, 1) * Vk(1, 1) + Tm(1, 2) * Vk(1, 2)) * dL_dc + (Tm(0, 0) * Vk(1, 0) + Tm(0, 1) * Vk(1, 1) + Tm(0, 2) * Vk(1, 2)) * dL_db;
+        const float dL_dT12 = 2 * (Tm(1, 0) * Vk(2, 0) + Tm(1, 1) * Vk(2, 1) + Tm(1, 2) * Vk(2, 2)) * dL_dc + (Tm(0, 0) * Vk(2, 0) + Tm(0, 1) * Vk(2, 1) + Tm(0, 2) * Vk(2, 2)) * dL_db;
+#undef Vk
+#undef Tm
+#define Wg(c_, r_) c2.W.m[c_][r_]
+        const float dL_dJ00 = Wg(0, 0) * dL_dT00 + Wg(0, 1) * dL_dT01 + Wg(0, 2) * dL_dT02;
+        const float dL_dJ02 = Wg(2, 0) * dL_dT00 + Wg(2, 1) * dL_dT01 + Wg(2, 2) * dL_dT02;
+        const float dL_dJ11 = Wg(1, 0) * dL_dT10 + Wg(1, 1) * dL_dT11 + Wg(1, 2) * dL_dT12;
+        const float dL_dJ12 = Wg(2, 0) * dL_dT10 + Wg(2, 1) * dL_dT11 + Wg(2, 2) * dL_dT12;
+#undef Wg
+        const float tz = 1.f / c2.tz, tz2 = tz * tz, tz3 = tz2 * tz;
+        const float h_x = cam.focal_x, h_y = cam.focal_y;
+        const float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
+        const float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
+        const float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * c2.tx) * tz3 * dL_dJ02 + (2 * h_y * c2.ty) * tz3 * dL_dJ12;
+        const float* vm = V.m;                                  // transformVec4x3Transpose (auxiliary.h:89-97)
+        dmean[0] = vm[0] * dL_dtx + vm[1] * dL_dty + vm[2] * dL_dtz;
+        dmean[1] = vm[4] * dL_dtx + vm[5] * dL_dty + vm[6] * dL_dtz;
+        dmean[2] = vm[8] * dL_dtx + vm[9] * dL_dty + vm[10] * dL_dtz;
+
+        // ---- preprocessCUDA backward (backward.cu:346-396) ----
+        const float* proj = PM.m;
+        const float m_hom_w = proj[3] * mx + proj[7] * my + proj[11] * mz + proj[15];
+        const float m_w = 1.0f / (m_hom_w + 0.0000001f);
+        const float mul1 = (proj[0] * mx + proj[4] * my + proj[8] * mz + proj[12]) * m_w * m_w;
+        const float mul2 = (proj[1] * mx + proj[5] * my + proj[9] * mz + proj[13]) * m_w * m_w;
+        const float g2x = a[3], g2y = a[4];
+        dmean[0] += (proj[0] * m_w - proj[3] * mul1) * g2x + (proj[1] * m_w - proj[3] * mul2) * g2y;
+        dmean[1] += (proj[4] * m_w - proj[7] * mul1) * g2x + (proj[5] * m_w - proj[7] * mul2) * g2y;
+        dmean[2] += (proj[8] * m_w - proj[11] * mul1) * g2x + (proj[9] * m_w - proj[11] * mul2) * g2y;
+
+        if (HAS_SCALE_ROT) {
+            // computeCov3D backward (backward.cu:278-341)
+            const float s0 = in.scales[i3], s1 = in.scales[i3 + 1], s2 = in.scales[i3 + 2];
+            const float4 q = reinterpret_cast<const float4*>(in.rotations)[idx];
+            const float r = q.x, x = q.y, y = q.z, z = q.w;
+            const mat3 R = quat_to_R(r, x, y, z);
+            const float sx = cam.scale_modifier * s0, sy = cam.scale_modifier * s1, sz = cam.scale_modifier * s2;
+            const mat3 S = m3make(sx, 0.f, 0.f, 0.f, sy, 0.f, 0.f, 0.f, sz);
+            const mat3 Mx = m3mul(S, R);
+            const mat3 dSig = m3make(dcov[0], 0.5f * dcov[1], 0.5f * dcov[2], 0.5f * dcov[1], dcov[3], 0.5f * dcov[4], 0.5f * dcov[2], 0.5f * dcov[4], dcov[5]);
+            mat3 M2;
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+#pragma unroll
+                for (int w = 0; w < 3; w++) M2.m[c][w] = 2.0f * Mx.m[c][w];
+            const mat3 dM = m3mul(M2, dSig);
+            const mat3 Rt = m3t(R);
+            mat3 dMt = m3t(dM);
+            dscale[0] = Rt.m[0][0] * dMt.m[0][0] + Rt.m[0][1] * dMt.m[0][1] + Rt.m[0][2] * dMt.m[0][2];
+            dscale[1] = Rt.m[1][0] * dMt.m[1][0] + Rt.m[1][1] * dMt.m[1][1] + Rt.m[1][2] * dMt.m[1][2];
+            dscale[2] = Rt.m[2][0] * dMt.m[2][0] + Rt.m[2][1] * dMt.m[2][1] + Rt.m[2][2] * dMt.m[2][2];
+#pragma unroll
+            for (int w = 0; w < 3; w++) { dMt.m[0][w] *= sx; dMt.m[1][w] *= sy; dMt.m[2][w] *= sz; }
+#define A(c_, w_) dMt.m[c_][w_]
+            drot[0] = 2 * z * (A(0, 1) - A(1, 0)) + 2 * y * (A(2, 0) - A(0, 2)) + 2 * x * (A(1, 2) - A(2, 1));
+            drot[1] = 2 * y * (A(1, 0) + A(0, 1)) + 2 * z * (A(2, 0) + A(0, 2)) + 2 * r * (A(1, 2) - A(2, 1)) - 4 * x * (A(2, 2) + A(1, 1));
+            drot[2] = 2 * x * (A(1, 0) + A(0, 1)) + 2 * r * (A(2, 0) - A(0, 2)) + 2 * z * (A(1, 2) + A(2, 1)) - 4 * y * (A(2, 2) + A(0, 0));
+            drot[3] = 2 * r * (A(0, 1) - A(1, 0)) + 2 * x * (A(2, 0) + A(0, 2)) + 2 * y * (A(1, 2) + A(2, 1)) - 4 * z * (A(1, 1) + A(0, 0));
+#undef A
+        }
+    }
+
+    if (HAS_SH) {
+        // computeColorFromSH backward (backward.cu:20-139); culled Gaussians write zeros
+        float* dsh = in.dL_dsh + (size_t)idx * in.M * 3;
+        const int ncoef = (in.D + 1) * (in.D + 1);
+        if (!live) {
+            for (int k = 0; k < in.M * 3; k++) dsh[k] = 0.f;
+        } else {
+            const float* sh = in.shs + (size_t)idx * in.M * 3;
+            const uint32_t cl = g.clamped[idx];
+            dRGB[0] = a[0] * ((cl & 1u) ? 0.f : 1.f);
+            dRGB[1] = a[1] * ((cl & 2u) ? 0.f : 1.f);
+            dRGB[2] = a[2] * ((cl & 4u) ? 0.f : 1.f);
+            const float ox = mx - camx, oy = my - camy, oz = mz - camz;
+            const float len = sqrtf(ox * ox + oy * oy + oz * oz);
+            const float x = ox / len, y = oy / len, z = oz / len;
+            float gxv[3] = {0.f, 0.f, 0.f}, gyv[3] = {0.f, 0.f, 0.f}, gzv[3] = {0.f, 0.f, 0.f};
+#define SH(k) sh[3 * (k) + c]
+#define DSH(k, v) { const float vv = (v); dsh[3 * (k)] = vv * dRGB[0]; dsh[3 * (k) + 1] = vv * dRGB[1]; dsh[3 * (k) + 2] = vv * dRGB[2]; }
+            DSH(0, SH_C0);
+            if (in.D > 0) {
+                DSH(1, -SH_C1 * y); DSH(2, SH_C1 * z); DSH(3, -SH_C1 * x);
+#pragma unroll
+                for (int c = 0; c < 3; c++) { gxv[c] = -SH_C1 * SH(3); gyv[c] = -SH_C1 * SH(1); gzv[c] = SH_C1 * SH(2); }
+                if (in.D > 1) {
+                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                    DSH(4, SH_C2_0 * xy); DSH(5, SH_C2_1 * yz); DSH(6, SH_C2_2 * (2.f * zz - xx - yy)); DSH(7, SH_C2_3 * xz); DSH(8, SH_C2_4 * (xx - yy));
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        gxv[c] += SH_C2_0 * y * SH(4) + SH_C2_2 * 2.f * -x * SH(6) + SH_C2_3 * z * SH(7) + SH_C2_4 * 2.f * x * SH(8);
+                        gyv[c] += SH_C2_0 * x * SH(4) + SH_C2_1 * z * SH(5) + SH_C2_2 * 2.f * -y * SH(6) + SH_C2_4 * 2.f * -y * SH(8);
+                        gzv[c] += SH_C2_1 * y * SH(5) + SH_C2_2 * 2.f * 2.f * z * SH(6) + SH_C2_3 * x * SH(7);
+                    }
+                    if (in.D > 2) {
+                        DSH(9, SH_C3_0 * y * (3.f * xx - yy)); DSH(10, SH_C3_1 * xy * z); DSH(11, SH_C3_2 * y * (4.f * zz - xx - yy));
+                        DSH(12, SH_C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy)); DSH(13, SH_C3_4 * x * (4.f * zz - xx - yy));
+                        DSH(14, SH_C3_5 * z * (xx - yy)); DSH(15, SH_C3_6 * x * (xx - 3.f * yy));
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+                            gxv[c] += (SH_C3_0 * SH(9) * 3.f * 2.f * xy + SH_C3_1 * SH(10) * yz + SH_C3_2 * SH(11) * -2.f * xy +
+                                       SH_C3_3 * SH(12) * -3.f * 2.f * xz + SH_C3_4 * SH(13) * (-3.f * xx + 4.f * zz - yy) +
+                                       SH_C3_5 * SH(14) * 2.f * xz + SH_C3_6 * SH(15) * 3.f * (xx - yy));
+                            gyv[c] += (SH_C3_0 * SH(9) * 3.f * (xx - yy) + SH_C3_1 * SH(10) * xz + SH_C3_2 * SH(11) * (-3.f * yy + 4.f * zz - xx) +
+                                       SH_C3_3 * SH(12) * -3.f * 2.f * yz + SH_C3_4 * SH(13) * -2.f * xy + SH_C3_5 * SH(14) * -2.f * yz +
+                                       SH_C3_6 * SH(15) * -3.f * 2.f * xy);
+                            gzv[c] += (SH_C3_1 * SH(10) * xy + SH_C3_2 * SH(11) * 4.f * 2.f * yz + SH_C3_3 * SH(12) * 3.f * (2.f * zz - xx - yy) +
+                                       SH_C3_4 * SH(13) * 4.f * 2.f * xz + SH_C3_5 * SH(14) * (xx - yy));
+                        }
+                    }
+                }
+            }
+#undef SH
+#undef DSH
+            // coefficients above the active degree keep the reference's zeros (torch::zeros, rasterize_points.cu:157)
+            for (int k = ncoef * 3; k < in.M * 3; k++) dsh[k] = 0.f;
+            const float ddx = gxv[0] * dRGB[0] + gxv[1] * dRGB[1] + gxv[2] * dRGB[2];
+            const float ddy = gyv[0] * dRGB[0] + gyv[1] * dRGB[1] + gyv[2] * dRGB[2];
+            const float ddz = gzv[0] * dRGB[0] + gzv[1] * dRGB[1] + gzv[2] * dRGB[2];
+            // dnormvdv (auxiliary.h:107-117)
+            const float sum2 = ox * ox + oy * oy + oz * oz;
+            const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+            dmean[0] += ((+sum2 - ox * ox) * ddx - oy * ox * ddy - oz * ox * ddz) * invsum32;
+            dmean[1] += (-ox * oy * ddx + (sum2 - oy * oy) * ddy - oz * oy * ddz) * invsum32;
+            dmean[2] += (-ox * oz * ddx - oy * oz * ddy + (sum2 - oz * oz) * ddz) * invsum32;
+        }
+    }
+
+    // every output element is written (zeros for culled Gaussians)
+    in.dL_dmean2D[i3] = a[3]; in.dL_dmean2D[i3 + 1] = a[4]; in.dL_dmean2D[i3 + 2] = 0.f;   // .z never written: backward.cu:545-546
+    reinterpret_cast<float4*>(in.dL_dconic)[idx] = make_float4(a[5], a[6], 0.f, a[7]);   // .z never written: backward.cu:549-551
+    in.dL_dopacity[idx] = a[8];
+    in.dL_dcolor[i3] = a[0]; in.dL_dcolor[i3 + 1] = a[1]; in.dL_dcolor[i3 + 2] = a[2];
+    in.dL_dmean3D[i3] = dmean[0]; in.dL_dmean3D[i3 + 1] = dmean[1]; in.dL_dmean3D[i3 + 2] = dmean[2];
+#pragma unroll
+    for (int i = 0; i < 6; i++) in.dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
+    if (in.dL_dscale) { in.dL_dscale[i3] = dscale[0]; in.dL_dscale[i3 + 1] = dscale[1]; in.dL_dscale[i3 + 2] = dscale[2]; }
+    if (in.dL_drot) reinterpret_cast<float4*>(in.dL_drot)[idx] = make_float4(drot[0], drot[1], drot[2], drot[3]);
+}
+
+void launch_render_bwd(hipStream_t st, const ImgState& s, const BinState& b, int W, int H, uint32_t gx, uint32_t T, const float* bg, const float* dL_dpix)
+{
+    hipLaunchKernelGGL(k_render_bwd, dim3(T), dim3(256), 0, st, s, b, W, H, gx, bg, dL_dpix);
+}
+void launch_preprocess_bwd(hipStream_t st, const BwdIn& in, const CamParams& cam, const GeomState& g, const BinState& b)
+{
+    const dim3 grid((unsigned)n_blocks(in.P)), blk(PRE_BLOCK);
+    const bool sh = in.shs != nullptr, sr = in.scales != nullptr;
+    if (sh && sr) hipLaunchKernelGGL((k_preprocess_bwd<true, true>), grid, blk, 0, st, in, cam, g, b);
+    else if (sh) hipLaunchKernelGGL((k_preprocess_bwd<true, false>), grid, blk, 0, st, in, cam, g, b);
+    else if (sr) hipLaunchKernelGGL((k_preprocess_bwd<false, true>), grid, blk, 0, st, in, cam, g, b);
+    else hipLaunchKernelGGL((k_preprocess_bwd<false, false>), grid, blk, 0, st, in, cam, g, b);
+}
+
+}  // namespace tgs

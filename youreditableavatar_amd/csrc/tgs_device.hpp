@@ -1,0 +1,263 @@
+// tgs_device.hpp -- shared device helpers and the private layout of the three state buffers.
+// gfx950 (CDNA4) only: wave64, DPP row operations, 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tgs {
+
+constexpr int TILE = 16;            // the reference's BLOCK_X = BLOCK_Y (cuda_rasterizer/config.h:16-17)
+constexpr int TILE_PIX = TILE * TILE;
+constexpr int WAVE = 64;
+constexpr int PRE_BLOCK = 256;      // Gaussians per workgroup in the per-Gaussian kernels
+constexpr uint32_t SORT_LDS_CAP = 8192;   // longest tile list sorted inside LDS (64 KiB of u64 keys)
+constexpr int COOP_TILES = 64;      // a Gaussian touching more tiles than this is emitted by the whole workgroup
+
+// ---------------------------------------------------------------------------------------------
+// state buffers (opaque to callers; the reference's equivalents: rasterizer_impl.h:29-65)
+// ---------------------------------------------------------------------------------------------
+struct Meta {                 // lives at the start of the image buffer
+    unsigned long long R;     // number of tile instances ("num_rendered")
+    uint32_t max_count;       // longest tile list
+    uint32_t n_overflow;      // tiles whose list is longer than SORT_LDS_CAP
+    uint32_t error;           // bit0: prefiltered Gaussian culled
+    uint32_t pad[11];
+};
+
+struct GeomState {
+    float2* xy;               // pixel-space mean                   (geomState.means2D)
+    float* depth;             // view-space z                       (geomState.depths)
+    float4* conic_opacity;    // inverse 2D covariance + opacity    (geomState.conic_opacity)
+    float* rgb;               // SH colour, SH path only            (geomState.rgb)
+    float* cov3D;             // 6 floats, scale/rot path only      (geomState.cov3D)
+    uint8_t* clamped;         // 3 clamp bits per Gaussian          (geomState.clamped)
+    ushort4* rect;            // tile rectangle (minx, miny, maxx, maxy)
+    uint32_t* tiles_touched;  //                                    (geomState.tiles_touched)
+    uint32_t* offsets;        // EXCLUSIVE scan of tiles_touched    (geomState.point_offsets is inclusive)
+    uint32_t* block_sums;     // per PRE_BLOCK partial sums / their exclusive scan
+};
+struct ImgState {
+    Meta* meta;
+    uint2* ranges;            // per tile [start, end)              (imgState.ranges)
+    uint32_t* tile_count;     // per tile instance count
+    uint32_t* cursor;         // per tile scatter cursor
+    uint32_t* ovf_tiles;      // list of overflow tiles
+    float* final_T;           //                                    (imgState.accum_alpha)
+    uint32_t* n_contrib;      //                                    (imgState.n_contrib)
+};
+struct BinState {
+    unsigned long long* keys; // (depth bits << 32 | gaussian idx), per tile segment, sorted after k_tile_sort
+    float4* recA;             // sorted per-instance records: xy.x, xy.y, conic.x, conic.y
+    float4* recB;             //                              conic.z, opacity, r, g
+    float2* recC;             //                              b, bits(gaussian idx)
+    uint32_t* slot;           // offsets[g] + ordinal of this tile in g's rectangle (gradient slab row)
+    float* slab;              // backward scratch: 9 floats per instance, Gaussian-major rows (see tgs_backward.hip)
+};
+
+template <typename T>
+__host__ __device__ inline void carve(char*& p, T*& out, size_t count)
+{
+    uintptr_t a = (reinterpret_cast<uintptr_t>(p) + 255) & ~uintptr_t(255);
+    out = reinterpret_cast<T*>(a);
+    p = reinterpret_cast<char*>(out + count);
+}
+__host__ __device__ inline size_t n_blocks(size_t P) { return (P + PRE_BLOCK - 1) / PRE_BLOCK; }
+
+__host__ __device__ inline size_t geom_carve(GeomState& g, char* base, size_t P, bool has_sh, bool has_scale_rot)
+{
+    char* p = base;
+    carve(p, g.xy, P); carve(p, g.depth, P); carve(p, g.conic_opacity, P);
+    carve(p, g.rgb, has_sh ? 3 * P : 0); carve(p, g.cov3D, has_scale_rot ? 6 * P : 0);
+    carve(p, g.clamped, P); carve(p, g.rect, P); carve(p, g.tiles_touched, P); carve(p, g.offsets, P);
+    carve(p, g.block_sums, n_blocks(P) + 1);
+    return (size_t)(p - base) + 256;
+}
+__host__ __device__ inline size_t img_carve(ImgState& s, char* base, size_t N, size_t T)
+{
+    char* p = base;
+    carve(p, s.meta, 1); carve(p, s.ranges, T); carve(p, s.tile_count, T); carve(p, s.cursor, T);
+    carve(p, s.ovf_tiles, T); carve(p, s.final_T, N); carve(p, s.n_contrib, N);
+    return (size_t)(p - base) + 256;
+}
+__host__ __device__ inline size_t bin_carve(BinState& b, char* base, size_t R)
+{
+    char* p = base;
+    carve(p, b.keys, R); carve(p, b.recA, R); carve(p, b.recB, R); carve(p, b.recC, R); carve(p, b.slot, R); carve(p, b.slab, 9 * R);
+    return (size_t)(p - base) + 256;
+}
+
+#ifdef __HIPCC__
+// ---------------------------------------------------------------------------------------------
+// wave64 primitives
+// ---------------------------------------------------------------------------------------------
+#define TGS_DPP_ADD(v, ctrl, rowmask)                                                                      \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rowmask, 0xf, false))
+
+// Sum over the 64 lanes of a wave; the total is returned in every lane (via readlane 63).
+// 6 v_add_f32 with DPP modifiers: quad swaps, row_half_mirror, row_mirror, row_bcast15, row_bcast31.
+__device__ __forceinline__ float wave_sum(float v)
+{
+    TGS_DPP_ADD(v, 0xB1, 0xf);    // quad_perm [1,0,3,2]
+    TGS_DPP_ADD(v, 0x4E, 0xf);    // quad_perm [2,3,0,1]
+    TGS_DPP_ADD(v, 0x141, 0xf);   // row_half_mirror
+    TGS_DPP_ADD(v, 0x140, 0xf);   // row_mirror
+    TGS_DPP_ADD(v, 0x142, 0xa);   // row_bcast15 -> rows 1,3
+    TGS_DPP_ADD(v, 0x143, 0xc);   // row_bcast31 -> rows 2,3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { uint32_t t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
+    return v;
+}
+// inclusive scan over the wave
+__device__ __forceinline__ uint32_t wave_iscan_u32(uint32_t v, int lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(v, o, 64); if (lane >= o) v += t; }
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_iscan_u64(unsigned long long v, int lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { unsigned long long t = __shfl_up(v, o, 64); if (lane >= o) v += t; }
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3x3 helpers in GLM's column-major convention, m[c][r] = column c, row r, product order of
+// third_party/glm/glm/detail/type_mat3x3.inl:486-518 -- so that the fp32 operation order of the
+// reference's glm expressions is kept.
+// ---------------------------------------------------------------------------------------------
+struct mat3 { float m[3][3]; };
+__device__ __forceinline__ mat3 m3mul(const mat3& a, const mat3& b)
+{
+    mat3 r;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int w = 0; w < 3; w++)
+            r.m[c][w] = a.m[0][w] * b.m[c][0] + a.m[1][w] * b.m[c][1] + a.m[2][w] * b.m[c][2];
+    return r;
+}
+__device__ __forceinline__ mat3 m3t(const mat3& a)
+{
+    mat3 r;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int w = 0; w < 3; w++) r.m[c][w] = a.m[w][c];
+    return r;
+}
+__device__ __forceinline__ mat3 m3make(float a, float b, float c, float d, float e, float f, float g, float h, float i)
+{
+    mat3 r;
+    r.m[0][0] = a; r.m[0][1] = b; r.m[0][2] = c; r.m[1][0] = d; r.m[1][1] = e; r.m[1][2] = f;
+    r.m[2][0] = g; r.m[2][1] = h; r.m[2][2] = i;
+    return r;
+}
+
+// SH basis constants (cuda_rasterizer/auxiliary.h:22-39)
+__device__ constexpr float SH_C0 = 0.28209479177387814f;
+__device__ constexpr float SH_C1 = 0.4886025119029199f;
+__device__ constexpr float SH_C2_0 = 1.0925484305920792f, SH_C2_1 = -1.0925484305920792f, SH_C2_2 = 0.31539156525252005f,
+                           SH_C2_3 = -1.0925484305920792f, SH_C2_4 = 0.5462742152960396f;
+__device__ constexpr float SH_C3_0 = -0.5900435899266435f, SH_C3_1 = 2.890611442640554f, SH_C3_2 = -0.4570457994644658f,
+                           SH_C3_3 = 0.3731763325901154f, SH_C3_4 = -0.4570457994644658f, SH_C3_5 = 1.445305721320277f,
+                           SH_C3_6 = -0.5900435899266435f;
+
+// auxiliary.h:41-44 -- evaluated in double because the reference's literals are double
+__device__ __forceinline__ float ndc2pix(float v, int S) { return (float)((((double)v + 1.0) * (double)S - 1.0) * 0.5); }
+
+// auxiliary.h:46-56
+__device__ __forceinline__ void get_rect(float px, float py, int max_radius, uint32_t gx, uint32_t gy, uint32_t& minx,
+                                         uint32_t& miny, uint32_t& maxx, uint32_t& maxy)
+{
+    int v;
+    v = (int)((px - (float)max_radius) / (float)TILE); v = v < 0 ? 0 : v; minx = (uint32_t)v < gx ? (uint32_t)v : gx;
+    v = (int)((py - (float)max_radius) / (float)TILE); v = v < 0 ? 0 : v; miny = (uint32_t)v < gy ? (uint32_t)v : gy;
+    v = (int)((px + (float)max_radius + (float)TILE - 1.0f) / (float)TILE); v = v < 0 ? 0 : v; maxx = (uint32_t)v < gx ? (uint32_t)v : gx;
+    v = (int)((py + (float)max_radius + (float)TILE - 1.0f) / (float)TILE); v = v < 0 ? 0 : v; maxy = (uint32_t)v < gy ? (uint32_t)v : gy;
+}
+
+struct CamParams {          // kernel argument; the matrices stay device pointers like in the reference
+    const float* view;      // [16] transposed world-to-camera (consumed as m[0]x+m[4]y+m[8]z+m[12])
+    const float* proj;      // [16] full projection, same convention
+    const float* campos;    // [3]
+    float tan_fovx, tan_fovy, focal_x, focal_y, scale_modifier;
+    int W, H;
+    uint32_t gx, gy;
+};
+struct ViewMat { float m[16]; };   // a matrix pulled into registers/SGPRs at kernel entry
+__device__ __forceinline__ ViewMat load_mat(const float* __restrict__ p)
+{
+    ViewMat r;
+#pragma unroll
+    for (int i = 0; i < 16; i++) r.m[i] = p[i];
+    return r;
+}
+
+// EWA projection shared by forward (forward.cu:74-113) and backward (backward.cu:163-198).
+struct Cov2D {
+    float tx, ty, tz;        // clamped view-space mean
+    float txtz, tytz;
+    mat3 T, W, Vrk, cov;     // cov BEFORE the +0.3 dilation
+};
+__device__ __forceinline__ Cov2D compute_cov2d(float mx, float my, float mz, const float* cov3D, const CamParams& c, const ViewMat& V)
+{
+    Cov2D o;
+    const float* vm = V.m;
+    float tx = vm[0] * mx + vm[4] * my + vm[8] * mz + vm[12];
+    float ty = vm[1] * mx + vm[5] * my + vm[9] * mz + vm[13];
+    float tz = vm[2] * mx + vm[6] * my + vm[10] * mz + vm[14];
+    const float limx = 1.3f * c.tan_fovx, limy = 1.3f * c.tan_fovy;
+    o.txtz = tx / tz; o.tytz = ty / tz;
+    tx = fminf(limx, fmaxf(-limx, o.txtz)) * tz;
+    ty = fminf(limy, fmaxf(-limy, o.tytz)) * tz;
+    mat3 J = m3make(c.focal_x / tz, 0.0f, -(c.focal_x * tx) / (tz * tz), 0.0f, c.focal_y / tz, -(c.focal_y * ty) / (tz * tz), 0.f, 0.f, 0.f);
+    o.W = m3make(vm[0], vm[4], vm[8], vm[1], vm[5], vm[9], vm[2], vm[6], vm[10]);
+    o.T = m3mul(o.W, J);
+    o.Vrk = m3make(cov3D[0], cov3D[1], cov3D[2], cov3D[1], cov3D[3], cov3D[4], cov3D[2], cov3D[4], cov3D[5]);
+    mat3 Tt = m3t(o.T), Vt = m3t(o.Vrk);
+    mat3 tmp = m3mul(Tt, Vt);
+    o.cov = m3mul(tmp, o.T);
+    o.tx = tx; o.ty = ty; o.tz = tz;
+    return o;
+}
+
+// quaternion (r,x,y,z) -> GLM-layout rotation matrix of forward.cu:134-138 (not normalised, :127)
+__device__ __forceinline__ mat3 quat_to_R(float r, float x, float y, float z)
+{
+    return m3make(1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
+                  2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
+                  2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y));
+}
+#endif  // __HIPCC__
+
+// ---------------------------------------------------------------------------------------------
+// host-side launchers (tgs_forward.hip / tgs_backward.hip), called by tgs_api.hip
+// ---------------------------------------------------------------------------------------------
+struct FwdIn {
+    int P, D, M;
+    const float *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp, *background;
+    int prefiltered;
+    float* out_color;
+    int* radii;
+};
+struct BwdIn {
+    int P, D, M;
+    const float *means3D, *shs, *colors_precomp, *scales, *rotations, *cov3D_precomp, *background;
+    const int* radii;
+    const float* dL_dpix;
+    float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot;
+};
+
+}  // namespace tgs

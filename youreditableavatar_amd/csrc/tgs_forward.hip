@@ -1,0 +1,519 @@
+// tgs_forward.hip -- forward pass kernels for gfx950 (wave64).
+//
+// Pipeline (what it replaces in cuda_rasterizer/rasterizer_impl.cu:198-336):
+//   k_preprocess_fwd   per-Gaussian EWA projection, SH colour, tile rectangle        (forward.cu:155-256)
+//                      + per-tile instance COUNT by integer atomics and per-block sums of tiles_touched
+//   k_scan             exclusive scans: block sums (-> Gaussian offsets) and tile counts (-> ranges)
+//                                                                   (cub InclusiveSum, identifyTileRanges)
+//   [host reads R, longest list]                                     (the reference's D2H copy, :280-281)
+//   k_scatter          every instance goes straight to its tile's segment              (duplicateWithKeys)
+//   k_tile_sort        per-tile sort by (depth, index) inside LDS + gather of the       (cub SortPairs)
+//                      per-instance records; lists longer than SORT_LDS_CAP take the k_ovf_* path
+//   k_render_fwd       front-to-back compositing, one 16x16 tile per workgroup           (forward.cu:261-374)
+//
+// The reference sorts 64-bit (tile|depth) keys globally with a 6-pass radix sort (12 B x R per pass);
+// here the tile is known when an instance is emitted, so only the depth order inside one tile's list
+// has to be established, and that happens in LDS.  Ties in depth resolve to ascending Gaussian index
+// exactly like the reference's stable sort over index-ordered emission.
+#include "tgs_device.hpp"
+
+namespace tgs {
+
+// ---------------------------------------------------------------------------------------------
+// k_preprocess_fwd
+// ---------------------------------------------------------------------------------------------
+template <bool HAS_SH, bool HAS_SCALE_ROT>
+__global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd(const FwdIn in, const CamParams cam, const GeomState g,
+                                                              const ImgState s)
+{
+    const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
+    uint32_t tiles = 0;
+    const ViewMat V = load_mat(cam.view), PM = load_mat(cam.proj);      // uniform -> scalar loads, before any store
+    const float camx = cam.campos[0], camy = cam.campos[1], camz = cam.campos[2];
+    if (idx < in.P) {
+        int my_radius_i = 0;
+        uint32_t minx = 0, miny = 0, maxx = 0, maxy = 0;
+        const float mx = in.means3D[3 * (size_t)idx], my = in.means3D[3 * (size_t)idx + 1], mz = in.means3D[3 * (size_t)idx + 2];
+        // in_frustum (auxiliary.h:139-164)
+        const float* pm = PM.m;
+        const float hx = pm[0] * mx + pm[4] * my + pm[8] * mz + pm[12];
+        const float hy = pm[1] * mx + pm[5] * my + pm[9] * mz + pm[13];
+        const float hw = pm[3] * mx + pm[7] * my + pm[11] * mz + pm[15];
+        const float p_w = 1.0f / (hw + 0.0000001f);
+        const float projx = hx * p_w, projy = hy * p_w;
+        const float* vm = V.m;
+        const float view_z = vm[2] * mx + vm[6] * my + vm[10] * mz + vm[14];
+        bool ok = !(view_z <= 0.2f);
+        if (!ok && in.prefiltered) atomicOr(&s.meta->error, 1u);
+        if (ok) {
+            float cov3d[6];
+            if (HAS_SCALE_ROT) {
+                // computeCov3D (forward.cu:118-152)
+                const float sx = cam.scale_modifier * in.scales[3 * (size_t)idx], sy = cam.scale_modifier * in.scales[3 * (size_t)idx + 1],
+                            sz = cam.scale_modifier * in.scales[3 * (size_t)idx + 2];
+                const float4 q = reinterpret_cast<const float4*>(in.rotations)[idx];
+                mat3 S = m3make(sx, 0.f, 0.f, 0.f, sy, 0.f, 0.f, 0.f, sz);
+                mat3 R = quat_to_R(q.x, q.y, q.z, q.w);
+                mat3 Mx = m3mul(S, R);
+                mat3 Sg = m3mul(m3t(Mx), Mx);
+                cov3d[0] = Sg.m[0][0]; cov3d[1] = Sg.m[0][1]; cov3d[2] = Sg.m[0][2];
+                cov3d[3] = Sg.m[1][1]; cov3d[4] = Sg.m[1][2]; cov3d[5] = Sg.m[2][2];
+#pragma unroll
+                for (int i = 0; i < 6; i++) g.cov3D[6 * (size_t)idx + i] = cov3d[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 6; i++) cov3d[i] = in.cov3D_precomp[6 * (size_t)idx + i];
+            }
+            const Cov2D c2 = compute_cov2d(mx, my, mz, cov3d, cam, V);
+            const float cx = c2.cov.m[0][0] + 0.3f, cy = c2.cov.m[0][1], cz = c2.cov.m[1][1] + 0.3f;   // forward.cu:110-111
+            const float det = (cx * cz - cy * cy);
+            ok = det != 0.0f;
+            if (ok) {
+                const float det_inv = 1.f / det;
+                const float conx = cz * det_inv, cony = -cy * det_inv, conz = cx * det_inv;
+                const float mid = 0.5f * (cx + cz);
+                const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+                const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+                const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+                const float pix = ndc2pix(projx, cam.W), piy = ndc2pix(projy, cam.H);
+                get_rect(pix, piy, (int)my_radius, cam.gx, cam.gy, minx, miny, maxx, maxy);
+                tiles = (maxx - minx) * (maxy - miny);
+                if (tiles != 0) {
+                    if (HAS_SH) {
+                        // computeColorFromSH (forward.cu:20-71)
+                        float dx = mx - camx, dy = my - camy, dz = mz - camz;
+                        const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+                        const float x = dx / len, y = dy / len, z = dz / len;
+                        const float* sh = in.shs + (size_t)idx * in.M * 3;
+                        float res[3];
+                        uint32_t clampbits = 0;
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+#define SH(k) sh[3 * (k) + c]
+                            float r = SH_C0 * SH(0);
+                            if (in.D > 0) {
+                                r = r - SH_C1 * y * SH(1) + SH_C1 * z * SH(2) - SH_C1 * x * SH(3);
+                                if (in.D > 1) {
+                                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                                    r = r + SH_C2_0 * xy * SH(4) + SH_C2_1 * yz * SH(5) + SH_C2_2 * (2.0f * zz - xx - yy) * SH(6) +
+                                        SH_C2_3 * xz * SH(7) + SH_C2_4 * (xx - yy) * SH(8);
+                                    if (in.D > 2) {
+                                        r = r + SH_C3_0 * y * (3.0f * xx - yy) * SH(9) + SH_C3_1 * xy * z * SH(10) +
+                                            SH_C3_2 * y * (4.0f * zz - xx - yy) * SH(11) +
+                                            SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * SH(12) +
+                                            SH_C3_4 * x * (4.0f * zz - xx - yy) * SH(13) + SH_C3_5 * z * (xx - yy) * SH(14) +
+                                            SH_C3_6 * x * (xx - 3.0f * yy) * SH(15);
+                                    }
+                                }
+                            }
+#undef SH
+                            r += 0.5f;
+                            if (r < 0.f) clampbits |= 1u << c;
+                            res[c] = fmaxf(r, 0.0f);
+                        }
+                        g.rgb[3 * (size_t)idx] = res[0]; g.rgb[3 * (size_t)idx + 1] = res[1]; g.rgb[3 * (size_t)idx + 2] = res[2];
+                        g.clamped[idx] = (uint8_t)clampbits;
+                    }
+                    g.depth[idx] = view_z;
+                    my_radius_i = (int)my_radius;
+                    g.xy[idx] = make_float2(pix, piy);
+                    g.conic_opacity[idx] = make_float4(conx, cony, conz, in.opacities[idx]);
+                    // per-tile instance count (replaces the tile half of the reference's 64-bit sort keys)
+                    for (uint32_t ty = miny; ty < maxy; ty++)
+                        for (uint32_t tx = minx; tx < maxx; tx++) atomicAdd(&s.tile_count[ty * cam.gx + tx], 1u);
+                }
+            }
+        }
+        if (in.radii) in.radii[idx] = my_radius_i;
+        g.tiles_touched[idx] = tiles;
+        g.rect[idx] = make_ushort4((unsigned short)minx, (unsigned short)miny, (unsigned short)maxx, (unsigned short)maxy);
+    }
+    // per-block sum of tiles_touched (first level of the offsets scan)
+    __shared__ uint32_t wsum[PRE_BLOCK / WAVE];
+    const uint32_t w = wave_sum_u32(tiles);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) g.block_sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_scan: block 0 scans the per-block sums, block 1 scans the tile counts.
+// ---------------------------------------------------------------------------------------------
+constexpr int SCAN_THREADS = 1024;
+constexpr int SCAN_ITEMS = 4;
+
+__device__ __forceinline__ unsigned long long block_exscan_u64(unsigned long long v, unsigned long long* lds, unsigned long long& total)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long inc = wave_iscan_u64(v, lane);
+    if (lane == 63) lds[wv] = inc;
+    __syncthreads();
+    unsigned long long base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_THREADS / WAVE; i++) { const unsigned long long t = lds[i]; if (i < wv) base += t; tot += t; }
+    __syncthreads();
+    total = tot;
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const ImgState s, uint32_t nblocks, uint32_t T)
+{
+    __shared__ unsigned long long lds[SCAN_THREADS / WAVE];
+    __shared__ uint32_t lds_max[SCAN_THREADS / WAVE];
+    __shared__ uint32_t ovf_n;
+    if (blockIdx.x == 0) {
+        unsigned long long carry = 0;
+        for (uint32_t base = 0; base < nblocks; base += SCAN_THREADS * SCAN_ITEMS) {
+            uint32_t v[SCAN_ITEMS];
+            unsigned long long sum = 0;
+            const uint32_t i0 = base + threadIdx.x * SCAN_ITEMS;
+#pragma unroll
+            for (int k = 0; k < SCAN_ITEMS; k++) { v[k] = (i0 + k < nblocks) ? g.block_sums[i0 + k] : 0u; sum += v[k]; }
+            unsigned long long tot;
+            unsigned long long ex = block_exscan_u64(sum, lds, tot) + carry;
+#pragma unroll
+            for (int k = 0; k < SCAN_ITEMS; k++) { if (i0 + k < nblocks) g.block_sums[i0 + k] = (uint32_t)ex; ex += v[k]; }
+            carry += tot;
+        }
+        if (threadIdx.x == 0) s.meta->R = carry;
+    } else {
+        if (threadIdx.x == 0) ovf_n = 0;
+        __syncthreads();
+        unsigned long long carry = 0;
+        uint32_t mx = 0;
+        for (uint32_t base = 0; base < T; base += SCAN_THREADS * SCAN_ITEMS) {
+            uint32_t v[SCAN_ITEMS];
+            unsigned long long sum = 0;
+            const uint32_t i0 = base + threadIdx.x * SCAN_ITEMS;
+#pragma unroll
+            for (int k = 0; k < SCAN_ITEMS; k++) { v[k] = (i0 + k < T) ? s.tile_count[i0 + k] : 0u; sum += v[k]; mx = v[k] > mx ? v[k] : mx; }
+            unsigned long long tot;
+            unsigned long long ex = block_exscan_u64(sum, lds, tot) + carry;
+#pragma unroll
+            for (int k = 0; k < SCAN_ITEMS; k++) {
+                if (i0 + k < T) {
+                    s.ranges[i0 + k] = make_uint2((uint32_t)ex, (uint32_t)(ex + v[k]));
+                    s.cursor[i0 + k] = (uint32_t)ex;
+                    if (v[k] > SORT_LDS_CAP) s.ovf_tiles[atomicAdd(&ovf_n, 1u)] = i0 + k;
+                }
+                ex += v[k];
+            }
+            carry += tot;
+        }
+        mx = wave_max_u32(mx);
+        if ((threadIdx.x & 63) == 0) lds_max[threadIdx.x >> 6] = mx;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t m = 0;
+            for (int i = 0; i < SCAN_THREADS / WAVE; i++) m = lds_max[i] > m ? lds_max[i] : m;
+            s.meta->max_count = m;
+            s.meta->n_overflow = ovf_n;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_scatter: instance -> its tile's segment.  Also finishes the Gaussian offsets (exclusive scan).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PRE_BLOCK) void k_scatter(int P, const GeomState g, const ImgState s, const BinState b, uint32_t gx)
+{
+    __shared__ uint32_t wtot[PRE_BLOCK / WAVE];
+    __shared__ uint32_t queue[PRE_BLOCK];
+    __shared__ uint32_t qn;
+    const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) qn = 0;
+    const uint32_t tiles = idx < P ? g.tiles_touched[idx] : 0u;
+    const uint32_t inc = wave_iscan_u32(tiles, lane);
+    if (lane == 63) wtot[wv] = inc;
+    __syncthreads();
+    uint32_t base = g.block_sums[blockIdx.x];
+    for (int i = 0; i < wv; i++) base += wtot[i];
+    if (idx < P) g.offsets[idx] = base + inc - tiles;
+
+    if (tiles > 0) {
+        if (tiles <= (uint32_t)COOP_TILES) {
+            const ushort4 r = g.rect[idx];
+            const unsigned long long key = ((unsigned long long)__float_as_uint(g.depth[idx]) << 32) | (uint32_t)idx;
+            for (uint32_t ty = r.y; ty < r.w; ty++)
+                for (uint32_t tx = r.x; tx < r.z; tx++) {
+                    const uint32_t pos = atomicAdd(&s.cursor[ty * gx + tx], 1u);
+                    b.keys[pos] = key;
+                }
+        } else {
+            queue[atomicAdd(&qn, 1u)] = (uint32_t)idx;
+        }
+    }
+    __syncthreads();
+    // large splats: the whole workgroup emits one Gaussian's rectangle (the reference's thread-serial
+    // double loop, rasterizer_impl.cu:98-109, is its tail-latency problem)
+    const uint32_t nq = qn;
+    for (uint32_t q = 0; q < nq; q++) {
+        const uint32_t id = queue[q];
+        const ushort4 r = g.rect[id];
+        const uint32_t w = (uint32_t)r.z - r.x, n = w * ((uint32_t)r.w - r.y);
+        const unsigned long long key = ((unsigned long long)__float_as_uint(g.depth[id]) << 32) | id;
+        for (uint32_t k = threadIdx.x; k < n; k += PRE_BLOCK) {
+            const uint32_t ty = r.y + k / w, tx = r.x + k % w;
+            const uint32_t pos = atomicAdd(&s.cursor[ty * gx + tx], 1u);
+            b.keys[pos] = key;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// bitonic network, all comparators ascending ("flip" + "disperse" form): because the larger key
+// always moves to the higher index, virtual +inf padding behind n never has to exist in memory.
+//   for k = 2,4,..,npad:  flip(k);  for j = k/4,..,1: disperse(j)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pair_flip(uint32_t t, uint32_t k, uint32_t& i, uint32_t& l)
+{
+    const uint32_t h = k >> 1, blk = t / h, off = t % h;
+    i = blk * k + off;
+    l = blk * k + (k - 1 - off);
+}
+__device__ __forceinline__ void pair_disperse(uint32_t t, uint32_t j, uint32_t& i, uint32_t& l)
+{
+    i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+    l = i + j;
+}
+__device__ __forceinline__ uint32_t next_pow2(uint32_t n)
+{
+    return n <= 1 ? 1u : 1u << (32 - __builtin_clz(n - 1));
+}
+
+template <typename KeyPtr>
+__device__ __forceinline__ void cmp_swap(KeyPtr keys, uint32_t i, uint32_t l, uint32_t n)
+{
+    if (l < n) {
+        const unsigned long long a = keys[i], c = keys[l];
+        if (a > c) { keys[i] = c; keys[l] = a; }
+    }
+}
+
+// gathers the per-instance record of sorted entry i of a tile (what renderCUDA fetches per entry:
+// forward.cu:315-321,355 and backward.cu:470-480)
+__device__ __forceinline__ void finalize_entry(unsigned long long key, uint32_t pos, uint32_t tile, uint32_t gx, const GeomState& g,
+                                               const BinState& b, const float* colors)
+{
+    const uint32_t id = (uint32_t)key;
+    const float2 xy = g.xy[id];
+    const float4 co = g.conic_opacity[id];
+    const float cr = colors[3 * (size_t)id], cg = colors[3 * (size_t)id + 1], cb = colors[3 * (size_t)id + 2];
+    const ushort4 r = g.rect[id];
+    const uint32_t tx = tile % gx, ty = tile / gx;
+    b.recA[pos] = make_float4(xy.x, xy.y, co.x, co.y);
+    b.recB[pos] = make_float4(co.z, co.w, cr, cg);
+    b.recC[pos] = make_float2(cb, __uint_as_float(id));
+    b.slot[pos] = g.offsets[id] + (ty - r.y) * ((uint32_t)r.z - r.x) + (tx - r.x);
+}
+
+__global__ __launch_bounds__(256) void k_tile_sort(const GeomState g, const ImgState s, const BinState b, const float* colors, uint32_t gx)
+{
+    extern __shared__ unsigned long long lk[];
+    const uint32_t tile = blockIdx.x;
+    const uint2 rg = s.ranges[tile];
+    const uint32_t n = rg.y - rg.x;
+    if (n == 0 || n > SORT_LDS_CAP) return;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) lk[i] = b.keys[rg.x + i];
+    __syncthreads();
+    const uint32_t npad = next_pow2(n), half = npad >> 1;
+    for (uint32_t k = 2; k <= npad; k <<= 1) {
+        for (uint32_t t = threadIdx.x; t < half; t += 256) { uint32_t i, l; pair_flip(t, k, i, l); cmp_swap(lk, i, l, n); }
+        __syncthreads();
+        for (uint32_t j = k >> 2; j > 0; j >>= 1) {
+            for (uint32_t t = threadIdx.x; t < half; t += 256) { uint32_t i, l; pair_disperse(t, j, i, l); cmp_swap(lk, i, l, n); }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        const unsigned long long key = lk[i];
+        b.keys[rg.x + i] = key;
+        finalize_entry(key, rg.x + i, tile, gx, g, b, colors);
+    }
+}
+
+// ---- overflow path: lists longer than SORT_LDS_CAP, sorted in global memory by many workgroups ----
+// grid = (ceil(npad_max / SORT_LDS_CAP), n_overflow)
+__global__ __launch_bounds__(256) void k_ovf_local(const ImgState s, const BinState b, uint32_t k_only)
+{
+    // k_only == 0: full network for k = 2..SORT_LDS_CAP on each aligned block of SORT_LDS_CAP keys;
+    // k_only  > 0: only the disperse steps j = SORT_LDS_CAP/2..1 of merge size k_only.
+    extern __shared__ unsigned long long lk[];
+    const uint32_t tile = s.ovf_tiles[blockIdx.y];
+    const uint2 rg = s.ranges[tile];
+    const uint32_t n = rg.y - rg.x;
+    const uint32_t b0 = blockIdx.x * SORT_LDS_CAP;
+    if (b0 >= n) return;
+    if (k_only > next_pow2(n)) return;
+    const uint32_t m = min(SORT_LDS_CAP, n - b0);          // real keys in this block
+    unsigned long long* gk = b.keys + rg.x + b0;
+    for (uint32_t i = threadIdx.x; i < m; i += 256) lk[i] = gk[i];
+    __syncthreads();
+    const uint32_t half = SORT_LDS_CAP >> 1;
+    if (k_only == 0) {
+        for (uint32_t k = 2; k <= SORT_LDS_CAP; k <<= 1) {
+            for (uint32_t t = threadIdx.x; t < half; t += 256) { uint32_t i, l; pair_flip(t, k, i, l); cmp_swap(lk, i, l, m); }
+            __syncthreads();
+            for (uint32_t j = k >> 2; j > 0; j >>= 1) {
+                for (uint32_t t = threadIdx.x; t < half; t += 256) { uint32_t i, l; pair_disperse(t, j, i, l); cmp_swap(lk, i, l, m); }
+                __syncthreads();
+            }
+        }
+    } else {
+        for (uint32_t j = SORT_LDS_CAP >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = threadIdx.x; t < half; t += 256) { uint32_t i, l; pair_disperse(t, j, i, l); cmp_swap(lk, i, l, m); }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < m; i += 256) gk[i] = lk[i];
+}
+
+// one comparator per thread; flip != 0: flip step of merge size k, else disperse step of distance j
+__global__ __launch_bounds__(256) void k_ovf_global(const ImgState s, const BinState b, uint32_t k, uint32_t j, int flip)
+{
+    const uint32_t tile = s.ovf_tiles[blockIdx.y];
+    const uint2 rg = s.ranges[tile];
+    const uint32_t n = rg.y - rg.x, npad = next_pow2(n);
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (k > npad || t >= (npad >> 1)) return;
+    uint32_t i, l;
+    if (flip) pair_flip(t, k, i, l); else pair_disperse(t, j, i, l);
+    cmp_swap(b.keys + rg.x, i, l, n);
+}
+
+__global__ __launch_bounds__(256) void k_ovf_finalize(const GeomState g, const ImgState s, const BinState b, const float* colors, uint32_t gx)
+{
+    const uint32_t tile = s.ovf_tiles[blockIdx.y];
+    const uint2 rg = s.ranges[tile];
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= rg.y - rg.x) return;
+    finalize_entry(b.keys[rg.x + i], rg.x + i, tile, gx, g, b, colors);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_render_fwd: one 16x16 tile per 256-thread workgroup; each of the 4 waves owns an 8x8 pixel
+// quadrant so that a wave's 64 pixels are spatially compact (whole-wave skips of small splats).
+// The tile's records are staged through LDS in rounds of 256 and read back as broadcasts.
+// ---------------------------------------------------------------------------------------------
+constexpr int RCHUNK = 256;
+
+__global__ __launch_bounds__(256) void k_render_fwd(const ImgState s, const BinState b, int W, int H, uint32_t gx,
+                                                    const float* __restrict__ bg, float* __restrict__ out_color)
+{
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+    __shared__ float4 sA[RCHUNK];
+    __shared__ float4 sB[RCHUNK];
+    __shared__ float sC[RCHUNK];
+    const uint32_t tile = blockIdx.x;
+    const uint32_t tx = tile % gx, ty = tile / gx;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int px = tx * TILE + (wv & 1) * 8 + (lane & 7);
+    const int py = ty * TILE + (wv >> 1) * 8 + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const float pixfx = (float)px, pixfy = (float)py;
+    const uint2 rg = s.ranges[tile];
+    bool done = !inside;
+    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
+    uint32_t contributor = 0, last_contributor = 0;
+
+    for (uint32_t base = rg.x; base < rg.y; base += RCHUNK) {
+        if (__syncthreads_and(done)) break;                     // forward.cu:307-310
+        const uint32_t cnt = min((uint32_t)RCHUNK, rg.y - base);
+        if (threadIdx.x < cnt) {
+            sA[threadIdx.x] = b.recA[base + threadIdx.x];
+            sB[threadIdx.x] = b.recB[base + threadIdx.x];
+            sC[threadIdx.x] = b.recC[base + threadIdx.x].x;
+        }
+        __syncthreads();
+        const bool wave_live = __builtin_amdgcn_ballot_w64(!done) != 0;   // else this wave's 64 pixels are finished
+        for (uint32_t j = 0; wave_live && j < cnt; j++) {       // forward.cu:325-362
+            const float4 a = sA[j];
+            const float4 bb = sB[j];
+            const float dx = a.x - pixfx, dy = a.y - pixfy;
+            const float power = -0.5f * (a.z * dx * dx + bb.x * dy * dy) - a.w * dx * dy;
+            const float alpha = fminf(0.99f, bb.y * expf(power));
+            const float test_T = T * (1.f - alpha);
+            const bool skip = done || (power > 0.0f) || (alpha < 1.0f / 255.0f);
+            const bool stop = !skip && (test_T < 0.0001f);
+            if (!skip && !stop) {
+                const float w = alpha * T;
+                C0 += bb.z * w; C1 += bb.w * w; C2 += sC[j] * w;
+                T = test_T;
+                last_contributor = contributor + j + 1;
+            }
+            done = done || stop;
+        }
+        contributor += cnt;
+    }
+    if (inside) {
+        const size_t pix_id = (size_t)W * py + px, N = (size_t)W * H;
+        s.final_T[pix_id] = T;
+        s.n_contrib[pix_id] = last_contributor;
+        out_color[pix_id] = C0 + T * bg0;
+        out_color[N + pix_id] = C1 + T * bg1;
+        out_color[2 * N + pix_id] = C2 + T * bg2;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_mark_visible (rasterizer_impl.cu:54-66)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mark_visible(int P, const float* __restrict__ means3D, const float* __restrict__ view, uint8_t* present)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P) return;
+    const float mx = means3D[3 * (size_t)idx], my = means3D[3 * (size_t)idx + 1], mz = means3D[3 * (size_t)idx + 2];
+    const float z = view[2] * mx + view[6] * my + view[10] * mz + view[14];
+    present[idx] = !(z <= 0.2f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------------------------
+void launch_preprocess_fwd(hipStream_t st, const FwdIn& in, const CamParams& cam, const GeomState& g, const ImgState& s)
+{
+    const dim3 grid((unsigned)n_blocks(in.P)), blk(PRE_BLOCK);
+    const bool sh = in.colors_precomp == nullptr, sr = in.cov3D_precomp == nullptr;
+    if (sh && sr) hipLaunchKernelGGL((k_preprocess_fwd<true, true>), grid, blk, 0, st, in, cam, g, s);
+    else if (sh) hipLaunchKernelGGL((k_preprocess_fwd<true, false>), grid, blk, 0, st, in, cam, g, s);
+    else if (sr) hipLaunchKernelGGL((k_preprocess_fwd<false, true>), grid, blk, 0, st, in, cam, g, s);
+    else hipLaunchKernelGGL((k_preprocess_fwd<false, false>), grid, blk, 0, st, in, cam, g, s);
+}
+void launch_scan(hipStream_t st, const GeomState& g, const ImgState& s, uint32_t nblocks, uint32_t T)
+{
+    hipLaunchKernelGGL(k_scan, dim3(2), dim3(SCAN_THREADS), 0, st, g, s, nblocks, T);
+}
+void launch_scatter(hipStream_t st, int P, const GeomState& g, const ImgState& s, const BinState& b, uint32_t gx)
+{
+    hipLaunchKernelGGL(k_scatter, dim3((unsigned)n_blocks(P)), dim3(PRE_BLOCK), 0, st, P, g, s, b, gx);
+}
+static uint32_t host_next_pow2(uint32_t n) { uint32_t p = 1; while (p < n) p <<= 1; return p; }
+void launch_tile_sort(hipStream_t st, const GeomState& g, const ImgState& s, const BinState& b, const float* colors, uint32_t gx, uint32_t T,
+                      uint32_t max_count, uint32_t n_overflow)
+{
+    const uint32_t cap = max_count < SORT_LDS_CAP ? max_count : SORT_LDS_CAP;
+    const size_t lds = (size_t)(cap ? cap : 1) * 8;
+    hipLaunchKernelGGL(k_tile_sort, dim3(T), dim3(256), lds, st, g, s, b, colors, gx);
+    if (n_overflow == 0) return;
+    const uint32_t npad = host_next_pow2(max_count);
+    const dim3 lgrid((npad + SORT_LDS_CAP - 1) / SORT_LDS_CAP, n_overflow), ggrid((npad / 2 + 255) / 256, n_overflow);
+    const size_t ldsb = (size_t)SORT_LDS_CAP * 8;
+    hipLaunchKernelGGL(k_ovf_local, lgrid, dim3(256), ldsb, st, s, b, 0u);
+    for (uint32_t k = SORT_LDS_CAP * 2; k <= npad; k <<= 1) {
+        hipLaunchKernelGGL(k_ovf_global, ggrid, dim3(256), 0, st, s, b, k, 0u, 1);
+        for (uint32_t j = k >> 2; j >= SORT_LDS_CAP; j >>= 1) hipLaunchKernelGGL(k_ovf_global, ggrid, dim3(256), 0, st, s, b, k, j, 0);
+        hipLaunchKernelGGL(k_ovf_local, lgrid, dim3(256), ldsb, st, s, b, k);
+    }
+    hipLaunchKernelGGL(k_ovf_finalize, dim3((max_count + 255) / 256, n_overflow), dim3(256), 0, st, g, s, b, colors, gx);
+}
+void launch_render_fwd(hipStream_t st, const ImgState& s, const BinState& b, int W, int H, uint32_t gx, uint32_t T, const float* bg, float* out_color)
+{
+    hipLaunchKernelGGL(k_render_fwd, dim3(T), dim3(256), 0, st, s, b, W, H, gx, bg, out_color);
+}
+void launch_mark_visible(hipStream_t st, int P, const float* means3D, const float* view, uint8_t* present)
+{
+    hipLaunchKernelGGL(k_mark_visible, dim3((P + 255) / 256), dim3(256), 0, st, P, means3D, view, present);
+}
+
+}  // namespace tgs

@@ -1,0 +1,185 @@
+"""``_C`` -- the native-extension surface of the reference package, served by libtgs_raster.so.
+
+Mirrors the three pybind11 exports of the reference (diff-gaussian-rasterization/ext.cpp:15-19,
+signatures rasterize_points.h:18-67) with identical positional arguments and return tuples, but is
+a thin ctypes binding over the C ABI in include/tgs_raster.h: torch supplies device memory and the
+current HIP stream, nothing else.  There is NO CPU fallback -- if the HIP library cannot be loaded,
+importing this module raises, and tensors that are not on a HIP device are rejected.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Tuple
+
+import torch
+
+from .. import build as _build
+
+_LIB_PATH = _build.LIB
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(_LIB_PATH):
+        try:
+            _build.build_native()
+        except Exception as e:  # loud: no silent fallback
+            raise ImportError(f"libtgs_raster.so is missing and could not be built ({e}); run "
+                              f"`python -c 'import __graft_entry__ as g; g.build()'` on a ROCm machine") from e
+    lib = C.CDLL(_LIB_PATH)
+    vp, fl, it = C.c_void_p, C.c_float, C.c_int
+    lib.tgs_abi_version.restype = it
+    if lib.tgs_abi_version() != 1:
+        raise ImportError("libtgs_raster.so ABI version mismatch")
+    lib.tgs_last_error.restype = C.c_char_p
+    lib.tgs_forward.restype = C.c_int64
+    lib.tgs_forward.argtypes = [vp, vp, vp, it, it, it, vp, it, it, vp, vp, vp, vp, vp, fl, vp, vp, vp, vp, vp, fl, fl, it, vp, vp, it]
+    lib.tgs_backward.restype = it
+    lib.tgs_backward.argtypes = [vp, it, it, it, C.c_int64, vp, it, it, vp, vp, vp, vp, fl, vp, vp, vp, vp, vp, fl, fl, vp,
+                                 vp, vp, vp, vp] + [vp] * 9 + [it]
+    lib.tgs_mark_visible.restype = it
+    lib.tgs_mark_visible.argtypes = [vp, it, vp, vp, vp, vp]
+    lib.tgs_state_field.restype = C.c_int64
+    lib.tgs_state_field.argtypes = [vp, C.c_char_p, it, it, it, C.c_int64, it, it, vp, vp, vp, vp, C.c_size_t]
+    return lib
+
+
+_lib = _load()
+_ALLOC_T = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, C.c_size_t)
+
+
+def loaded_library() -> str:
+    """Path of the native library this process is using (for diagnostics)."""
+    return _LIB_PATH
+
+
+def _err(code: int) -> RuntimeError:
+    msg = _lib.tgs_last_error()
+    return RuntimeError(f"{msg.decode() if msg else 'tgs_raster error'} (code {code})")
+
+
+def _dev_f32(t: torch.Tensor, dev: torch.device, name: str) -> Optional[torch.Tensor]:
+    """contiguous fp32 tensor on ``dev``; an empty tensor is the reference's 'absent' (NULL)."""
+    if t is None or t.numel() == 0:
+        return None
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"expected scalar type Float but found {t.dtype} for {name}")
+    if t.device != dev:
+        t = t.to(dev)
+    return t.contiguous()
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _require_gpu(means3D: torch.Tensor) -> torch.device:
+    if not means3D.is_cuda:
+        raise RuntimeError("diff_gaussian_rasterization (MI355X build) has no CPU path: means3D must be on a HIP device")
+    return means3D.device
+
+
+def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                        viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+                        prefiltered, debug) -> Tuple[int, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """RasterizeGaussiansCUDA (rasterize_points.cu:35-115)."""
+    if means3D.dim() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    dev = _require_gpu(means3D)
+    P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
+    M = int(sh.size(1)) if (sh.dim() > 1 and sh.size(0) != 0) else 0
+    with torch.cuda.device(dev):
+        out_color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+        radii = torch.empty((P,), dtype=torch.int32, device=dev)
+        bufs: List[Optional[torch.Tensor]] = [torch.empty(0, dtype=torch.uint8, device=dev) for _ in range(3)]
+
+        def alloc(_ctx, which, nbytes):     # resizeFunctional (rasterize_points.cu:27-33)
+            bufs[which] = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+            return bufs[which].data_ptr()
+
+        cb = _ALLOC_T(alloc)
+        t = dict(bg=_dev_f32(background, dev, "background"), means=_dev_f32(means3D, dev, "means3D"),
+                 colors=_dev_f32(colors, dev, "colors"), opac=_dev_f32(opacity, dev, "opacity"),
+                 scales=_dev_f32(scales, dev, "scales"), rots=_dev_f32(rotations, dev, "rotations"),
+                 cov=_dev_f32(cov3D_precomp, dev, "cov3D_precomp"), view=_dev_f32(viewmatrix, dev, "viewmatrix"),
+                 proj=_dev_f32(projmatrix, dev, "projmatrix"), sh=_dev_f32(sh, dev, "sh"), campos=_dev_f32(campos, dev, "campos"))
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        r = _lib.tgs_forward(C.cast(cb, C.c_void_p), None, stream, P, int(degree), M, _p(t["bg"]), W, H, _p(t["means"]),
+                             _p(t["sh"]), _p(t["colors"]), _p(t["opac"]), _p(t["scales"]), float(scale_modifier), _p(t["rots"]),
+                             _p(t["cov"]), _p(t["view"]), _p(t["proj"]), _p(t["campos"]), float(tan_fovx), float(tan_fovy),
+                             int(bool(prefiltered)), out_color.data_ptr(), _p(radii) if P else None, int(bool(debug)))
+        if r < 0:
+            raise _err(int(r))
+    return int(r), out_color, radii, bufs[0], bufs[1], bufs[2]
+
+
+def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
+                                 viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos,
+                                 geomBuffer, R, binningBuffer, imageBuffer, debug):
+    """RasterizeGaussiansBackwardCUDA (rasterize_points.cu:117-196); return order of :195."""
+    dev = _require_gpu(means3D)
+    P = int(means3D.size(0))
+    H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
+    M = int(sh.size(1)) if (sh.dim() > 1 and sh.size(0) != 0) else 0
+    with torch.cuda.device(dev):
+        e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dconic = e(P, 3), e(P, 3), e(P, 3), e(P, 2, 2)
+        dL_dopacity, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations = e(P, 1), e(P, 6), e(P, M, 3), e(P, 3), e(P, 4)
+        t = dict(bg=_dev_f32(background, dev, "background"), means=_dev_f32(means3D, dev, "means3D"),
+                 colors=_dev_f32(colors, dev, "colors"), scales=_dev_f32(scales, dev, "scales"),
+                 rots=_dev_f32(rotations, dev, "rotations"), cov=_dev_f32(cov3D_precomp, dev, "cov3D_precomp"),
+                 view=_dev_f32(viewmatrix, dev, "viewmatrix"), proj=_dev_f32(projmatrix, dev, "projmatrix"),
+                 sh=_dev_f32(sh, dev, "sh"), campos=_dev_f32(campos, dev, "campos"), dL=_dev_f32(dL_dout_color, dev, "dL_dout_color"))
+        if P != 0:
+            has_sr = t["scales"] is not None
+            if not has_sr:      # the reference leaves these at zero on the cov3D_precomp path
+                dL_dscales.zero_(); dL_drotations.zero_()
+            radii_c = radii.contiguous()
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            r = _lib.tgs_backward(stream, P, int(degree), M, int(R), _p(t["bg"]), W, H, _p(t["means"]), _p(t["sh"]), _p(t["colors"]),
+                                  _p(t["scales"]), float(scale_modifier), _p(t["rots"]), _p(t["cov"]), _p(t["view"]), _p(t["proj"]),
+                                  _p(t["campos"]), float(tan_fovx), float(tan_fovy), radii_c.data_ptr(), geomBuffer.data_ptr(),
+                                  binningBuffer.data_ptr(), imageBuffer.data_ptr(), _p(t["dL"]), dL_dmeans2D.data_ptr(),
+                                  dL_dconic.data_ptr(), dL_dopacity.data_ptr(), dL_dcolors.data_ptr(), dL_dmeans3D.data_ptr(),
+                                  dL_dcov3D.data_ptr(), dL_dsh.data_ptr() if M else None,
+                                  dL_dscales.data_ptr() if has_sr else None, dL_drotations.data_ptr() if has_sr else None,
+                                  int(bool(debug)))
+            if r < 0:
+                raise _err(int(r))
+    return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
+
+
+def mark_visible(means3D, viewmatrix, projmatrix) -> torch.Tensor:
+    """markVisible (rasterize_points.cu:198-217)."""
+    dev = _require_gpu(means3D)
+    P = int(means3D.size(0))
+    with torch.cuda.device(dev):
+        present = torch.zeros((P,), dtype=torch.bool, device=dev)
+        if P != 0:
+            m, v, pj = _dev_f32(means3D, dev, "means3D"), _dev_f32(viewmatrix, dev, "viewmatrix"), _dev_f32(projmatrix, dev, "projmatrix")
+            r = _lib.tgs_mark_visible(torch.cuda.current_stream(dev).cuda_stream, P, _p(m), _p(v), _p(pj), present.data_ptr())
+            if r < 0:
+                raise _err(int(r))
+    return present
+
+
+_FIELD_DTYPES = {"n_contrib": torch.int32, "final_T": torch.float32, "ranges": torch.int32, "point_list": torch.int32,
+                 "means2D": torch.float32, "depths": torch.float32, "conic_opacity": torch.float32, "rgb": torch.float32,
+                 "tiles_touched": torch.int32}
+
+
+def state_field(name: str, P: int, width: int, height: int, R: int, has_sh: bool, has_scale_rot: bool,
+                geomBuffer, binningBuffer, imageBuffer) -> torch.Tensor:
+    """Test/bench introspection of the opaque state buffers (tgs_state_field)."""
+    dev = geomBuffer.device
+    T = ((width + 15) // 16) * ((height + 15) // 16)
+    count = {"n_contrib": width * height, "final_T": width * height, "ranges": 2 * T, "point_list": R, "means2D": 2 * P,
+             "depths": P, "conic_opacity": 4 * P, "rgb": 3 * P, "tiles_touched": P}[name]
+    out = torch.empty((count,), dtype=_FIELD_DTYPES[name], device=dev)
+    with torch.cuda.device(dev):
+        r = _lib.tgs_state_field(torch.cuda.current_stream(dev).cuda_stream, name.encode(), P, width, height, int(R),
+                                 int(has_sh), int(has_scale_rot), geomBuffer.data_ptr(), binningBuffer.data_ptr(),
+                                 imageBuffer.data_ptr(), out.data_ptr(), out.numel() * out.element_size())
+    if r < 0:
+        raise _err(int(r))
+    return out

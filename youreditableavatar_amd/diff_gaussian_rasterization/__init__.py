@@ -1,0 +1,114 @@
+"""Drop-in ``diff_gaussian_rasterization`` for MI355X.
+
+Public surface = the reference package's (diff_gaussian_rasterization/__init__.py:21-220):
+``GaussianRasterizationSettings``, ``GaussianRasterizer`` and ``rasterize_gaussians`` with the same
+field order, argument names, validation messages, debug snapshot files and gradient ordering, so
+``tetgs_scene`` (tetgs_model.py:7, tetgs_edit_2d.py:6, tetgs_edit_3d.py:5) imports it unchanged.
+"""
+from __future__ import annotations
+
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _C
+
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians"]
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    # field order of __init__.py:157-169 (callers construct it by keyword, tetgs_model.py:507-520)
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _cpu_snapshot(args):
+    """Host copies taken BEFORE the native call (debug mode, __init__.py:18-20)."""
+    return tuple(a.detach().cpu().clone() if isinstance(a, torch.Tensor) else a for a in args)
+
+
+def _call_native(fn, args, debug: bool, dump_name: str, what: str):
+    if not debug:
+        return fn(*args)
+    saved = _cpu_snapshot(args)
+    try:
+        return fn(*args)
+    except Exception:
+        torch.save(saved, dump_name)
+        print(f"\nAn error occured in {what}. Please forward {dump_name} for debugging.")
+        raise
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+        rs = raster_settings
+        # native argument order (__init__.py:60-80)
+        args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
+                rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree, rs.campos,
+                rs.prefiltered, rs.debug)
+        num_rendered, color, radii, geom, binning, img = _call_native(_C.rasterize_gaussians, args, rs.debug, "snapshot_fw.dump", "forward")
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img)
+        ctx.mark_non_differentiable(radii)
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _grad_radii):
+        rs = ctx.raster_settings
+        colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img = ctx.saved_tensors
+        # native argument order (__init__.py:109-129)
+        args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
+                rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, sh, rs.sh_degree, rs.campos, geom, ctx.num_rendered,
+                binning, img, rs.debug)
+        (g_means2D, g_colors, g_opac, g_means3D, g_cov3D, g_sh, g_scales, g_rots) = _call_native(
+            _C.rasterize_gaussians_backward, args, rs.debug, "snapshot_bw.dump", "backward")
+        # forward-argument order (__init__.py:143-153); all eight are always returned
+        return g_means3D, g_means2D, g_sh, g_colors, g_opac, g_scales, g_rots, g_cov3D, None
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        """bool per Gaussian: view-space z > 0.2 for this camera (__init__.py:176-185)."""
+        with torch.no_grad():
+            rs = self.raster_settings
+            return _C.mark_visible(positions, rs.viewmatrix, rs.projmatrix)
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None):
+        rs = self.raster_settings
+        if (shs is None) == (colors_precomp is None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        has_sr = scales is not None and rotations is not None
+        any_sr = scales is not None or rotations is not None
+        if (not has_sr and cov3D_precomp is None) or (any_sr and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        absent = torch.Tensor([])       # empty CPU tensor = "not provided" (__init__.py:197-207)
+        return rasterize_gaussians(
+            means3D, means2D,
+            absent if shs is None else shs,
+            absent if colors_precomp is None else colors_precomp,
+            opacities,
+            absent if scales is None else scales,
+            absent if rotations is None else rotations,
+            absent if cov3D_precomp is None else cov3D_precomp,
+            rs)
