@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""bench.py -- rasterized fragments/sec (fwd+bwd) of the MI355X-native Gaussian rasterizer.
+
+Workload (BASELINE.json configs[2]/[3]): 500k Gaussians, 1920x1080, SH degree 3 evaluated inside the
+rasterizer, orbit cameras of the 64-view batch.  A *step* = one frame = one forward + one backward
+of the rasterizer through the public drop-in API (GaussianRasterizer + autograd) with the upstream
+gradient supplied; rank r renders view (step*N + r) mod 64 (frames shard across GPUs, weak scaling),
+and at N > 1 the per-Gaussian gradients are summed with one RCCL all-reduce per tensor.
+Metric numerator: F = sum over pixels of n_contrib, counted per view outside the
+timed region.  Inputs are resident in HBM before the timed region starts.
+
+Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--config 3] [--mode sh|precomp] [--no-cpu]
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=int, default=3, help="BASELINE.json config index (1-based); 3 = 500k/1080p/SH3")
+    ap.add_argument("--mode", default="sh", choices=["sh", "precomp"])
+    ap.add_argument("--views", type=int, default=64)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-frames", type=int, default=3)
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    N = world
+
+    from youreditableavatar_amd import scenes
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _C
+
+    cfg = dict(scenes.CONFIGS[a.config])
+    P, W, H, D = cfg["P"], cfg["width"], cfg["height"], cfg["sh_degree"]
+    cloud = scenes.make_cloud(P, D, cfg["seed"], tiny_fraction=cfg.get("tiny_fraction", 0.0), n_oversized=cfg.get("n_oversized", 0))
+    dL_np = scenes.upstream_gradient(W, H, seed=cfg["seed"] + 1000)
+    V = a.views
+    cams = [scenes.orbit_camera(W, H, azimuth_deg=k * 360.0 / V) for k in range(V)]
+
+    g = lambda x, rg=False: torch.from_numpy(np.ascontiguousarray(x)).to(dev).requires_grad_(rg)
+    means3D, opac = g(cloud["means3D"], True), g(cloud["opacities"], True)
+    scales, rots, shs = g(cloud["scales"], True), g(cloud["rotations"], True), g(cloud["shs"], True)
+    params = [means3D, opac, scales, rots, shs]
+    dL = g(dL_np)
+    settings = []
+    for c in cams:
+        settings.append(GaussianRasterizationSettings(
+            image_height=H, image_width=W, tanfovx=c.tanfovx, tanfovy=c.tanfovy, bg=g(c.bg), scale_modifier=1.0,
+            viewmatrix=g(c.viewmatrix), projmatrix=g(c.projmatrix), sh_degree=D, campos=g(c.campos), prefiltered=False, debug=False))
+    colors_pre = None
+    if a.mode == "precomp":
+        colors_pre = [None] * V
+
+    def frame(view):
+        rs = settings[view]
+        means2D = torch.zeros(P, 3, device=dev, requires_grad=True)
+        rast = GaussianRasterizer(rs)
+        if a.mode == "sh":
+            img, radii = rast(means3D=means3D, means2D=means2D, opacities=opac, shs=shs, scales=scales, rotations=rots)
+        else:
+            if colors_pre[view] is None:
+                colors_pre[view] = g(scenes.sh_to_rgb_numpy(cloud["shs"], cloud["means3D"], cams[view].campos, D), True)
+            img, radii = rast(means3D=means3D, means2D=means2D, opacities=opac, colors_precomp=colors_pre[view], scales=scales, rotations=rots)
+        img.backward(dL)
+        return img
+
+    def view_of(step):
+        return (step * N + rank) % V
+
+    # fragment / instance counts of the views this rank will time (outside the timed region)
+    used = sorted({view_of(s) for s in range(a.steps)})
+    F_view, R_view = {}, {}
+    empty = torch.Tensor([])
+    for v in used:
+        rs = settings[v]
+        R, color, radii, geom, binning, img = _C.rasterize_gaussians(rs.bg, means3D.detach(), empty, opac.detach(), scales.detach(), rots.detach(), 1.0,
+                                                                   empty, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, H, W, shs.detach(), D,
+                                                                   rs.campos, False, False)
+        nc = _C.state_field("n_contrib", P, W, H, R, True, True, geom, binning, img)
+        F_view[v] = int(nc.to(torch.int64).sum().item())
+        R_view[v] = int(R)
+        del geom, binning, img, color, radii, nc
+    torch.cuda.synchronize()
+
+    def step(s):
+        for p in params:
+            p.grad = None
+        frame(view_of(s))
+        if dist is not None:
+            for p in params:
+                dist.all_reduce(p.grad)
+
+    for s in range(a.warmup):
+        step(s)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    _C.profile_begin(a.steps * 8 + 64)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(a.steps):
+        step(s)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof = _C.profile_end()
+
+    F_rank = sum(F_view[view_of(s)] for s in range(a.steps))
+    R_rank = sum(R_view[view_of(s)] for s in range(a.steps))
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = torch.tensor([F_rank, R_rank], device=dev, dtype=torch.int64)
+        dist.all_reduce(c)
+        F_tot, R_tot = int(c[0].item()), int(c[1].item())
+    else:
+        F_tot, R_tot = F_rank, R_rank
+
+    if rank == 0:
+        ms_per_step = elapsed / a.steps * 1e3
+        value = F_tot / elapsed / 1e6
+        # dominant kernel and its roofline (algorithmic bytes per launch: DESIGN.md "Roofline accounting")
+        kern = {k: (ms / max(n, 1)) for k, (ms, n) in prof.items() if n > 0}
+        dom = max(kern, key=kern.get) if kern else None
+        Rm = R_rank / a.steps
+        Npix = W * H
+        Cin = 12 * (D + 1) ** 2 if a.mode == "sh" else 12
+        alg = {   # bytes per launch, single-touch model (SURVEY.md section 8d terms, regrouped per kernel)
+            "preprocess_fwd": (44 + Cin + (75 if a.mode == "sh" else 60)) * P + 4 * Rm,
+            "scan": 8 * P / 256 + 12 * (Npix / 256),
+            "scatter": 20 * P + 12 * Rm,
+            "tile_sort": (8 + 8 + 36 + 40 + 4) * Rm,
+            "render_fwd": 40 * Rm + 20 * Npix,
+            "render_bwd": 44 * Rm + 20 * Npix + 36 * Rm,
+            "preprocess_bwd": (36 * Rm) + ((107 + Cin) + (40 + Cin) + 56 + 36) * P if a.mode == "sh" else (36 * Rm) + (92 + 40 + 56 + 36) * P,
+        }
+        roof = None
+        if dom:
+            ach = alg[dom] / (kern[dom] * 1e-3) / 1e9
+            roof = {"kernel": "k_" + dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "avg_launch_ms": round(kern[dom], 4),
+                    "algorithmic_bytes_per_launch": int(alg[dom])}
+        k_P = (430 + 3 * Cin) if a.mode == "sh" else 412
+        B_alg = k_P * P + 124 * Rm + 40 * Npix
+        out = {
+            "metric": "rasterized fragments/sec (fwd+bwd) @500k Gaussians 1080p" if a.config in (3, 4) else f"rasterized fragments/sec (fwd+bwd) config {a.config}",
+            "value": round(value, 2), "unit": "Mfrag/s", "n_gpus": N, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"cfg{a.config}: {P} Gaussians, {W}x{H}, SH degree {D}, colour mode {a.mode}, {V}-view orbit, 1 frame per GPU per step",
+                       "frames_per_step": N, "fragments_per_frame": int(F_rank / a.steps), "instances_per_frame": int(Rm),
+                       "parallelism": f"view-sharded dp{N}" + (", RCCL all-reduce of 5 gradient tensors" if N > 1 else "")},
+            "roofline": roof,
+            "kernels_ms": {k: round(v, 4) for k, v in kern.items()},
+            "frame_algorithmic_bytes": int(B_alg),
+            "frame_hbm_frac": round(B_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+            "other_rates": {"Minstances/s": round(R_tot / elapsed / 1e6, 2), "Mpixels/s": round(Npix * a.steps * N / elapsed / 1e6, 2),
+                            "MGaussians/s": round(P * a.steps * N / elapsed / 1e6, 2)},
+        }
+        if N == 1 and not a.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(cloud, cams[0], dL_np, a)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(cloud, cam, dL_np, a):
+    """The CPU oracle (C restatement of the reference, OpenMP over tiles) timed on this box's host
+    cores on the SAME workload frame (view 0): a reported baseline, not the target."""
+    from oracle import oracle
+    mode = a.mode
+    t_all = []
+    F = 0
+    for i in range(a.cpu_frames):
+        t0 = time.perf_counter()
+        color, radii, st, grads = oracle.run_scene(cloud, cam, dL_np, mode=mode)
+        t_all.append(time.perf_counter() - t0)
+        F = int(st.field("n_contrib").astype(np.int64).sum())
+        del st
+    t = float(np.median(t_all))
+    return {"value": round(F / t / 1e6, 2), "unit": "Mfrag/s", "cores": oracle.threads(), "kind": "port",
+            "sample": f"{a.cpu_frames} full fwd+bwd frames of view 0 of the same workload (median {t:.2f} s/frame, F={F})",
+            "host_cpus": os.cpu_count()}
+
+
+if __name__ == "__main__":
+    main()

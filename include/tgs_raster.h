@@ -92,6 +92,17 @@ int64_t tgs_state_field(void* stream, const char* field, int P, int width, int h
                         const void* geom_buffer, const void* binning_buffer, const void* img_buffer,
                         void* dst, size_t dst_bytes);
 
+/* Bench instrumentation (process-global, not re-entrant): between begin and end every pipeline stage is
+ * bracketed by two hipEvents recorded on the caller's stream -- no synchronisation is added.  end()
+ * waits for the events and returns per-stage summed milliseconds and launch counts (arrays of
+ * TGS_STAGE_COUNT).  Records beyond max_records are dropped. */
+enum {
+    TGS_STAGE_PREPROCESS_FWD = 0, TGS_STAGE_SCAN, TGS_STAGE_SCATTER, TGS_STAGE_TILE_SORT, TGS_STAGE_RENDER_FWD,
+    TGS_STAGE_RENDER_BWD, TGS_STAGE_PREPROCESS_BWD, TGS_STAGE_COUNT
+};
+int tgs_profile_begin(int max_records);
+int tgs_profile_end(double* ms_sum, int64_t* counts);
+
 const char* tgs_last_error(void);   /* thread-local message of the last failing call */
 int tgs_abi_version(void);
 

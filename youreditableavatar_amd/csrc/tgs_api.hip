@@ -23,6 +23,37 @@ using namespace tgs;
 
 static thread_local char g_err[512] = "";
 
+// ---- optional per-stage timing (bench only): hipEvents recorded on the caller's stream, no sync ----
+#include <mutex>
+#include <vector>
+namespace {
+struct ProfRec { int stage; hipEvent_t e0, e1; };
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+size_t g_prof_cap = 0;
+std::vector<ProfRec> g_prof;
+hipEvent_t g_prof_open = nullptr;
+
+void prof_begin_stage(hipStream_t st)
+{
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_prof_on || g_prof.size() >= g_prof_cap) { g_prof_open = nullptr; return; }
+    if (hipEventCreate(&g_prof_open) != hipSuccess) { g_prof_open = nullptr; return; }
+    hipEventRecord(g_prof_open, st);
+}
+void prof_end_stage(hipStream_t st, int stage)
+{
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_prof_open) return;
+    ProfRec r; r.stage = stage; r.e0 = g_prof_open; g_prof_open = nullptr;
+    if (hipEventCreate(&r.e1) != hipSuccess) { hipEventDestroy(r.e0); return; }
+    hipEventRecord(r.e1, st);
+    g_prof.push_back(r);
+}
+}  // namespace
+
 static int fail(int code, const char* fmt, ...)
 {
     va_list ap;
@@ -39,8 +70,10 @@ static int fail(int code, const char* fmt, ...)
     } while (0)
 
 // the reference's CHECK_CUDA (auxiliary.h:166-173): in debug mode synchronise after every stage
-#define STAGE_CHECK(name)                                                                                 \
+#define STAGE_BEGIN() prof_begin_stage(st)
+#define STAGE_CHECK(name, id)                                                                             \
     do {                                                                                                  \
+        prof_end_stage(st, id);                                                                                                  \
         hipError_t e_ = hipGetLastError();                                                                \
         if (e_ == hipSuccess && debug) e_ = hipStreamSynchronize(st);                                     \
         if (e_ != hipSuccess) return fail(TGS_ERR_HIP, "stage %s: %s", name, hipGetErrorString(e_));       \
@@ -64,6 +97,34 @@ static CamParams make_cam(const float* view, const float* proj, const float* cam
 extern "C" {
 
 int tgs_abi_version(void) { return TGS_ABI_VERSION; }
+
+int tgs_profile_begin(int max_records)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (g_prof_on) return TGS_ERR_INVALID;
+    g_prof.clear();
+    g_prof_cap = max_records > 0 ? (size_t)max_records : 0;
+    g_prof.reserve(g_prof_cap);
+    g_prof_open = nullptr;
+    g_prof_on = true;
+    return TGS_OK;
+}
+
+int tgs_profile_end(double* ms_sum, int64_t* counts)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_prof_on) return TGS_ERR_INVALID;
+    g_prof_on = false;
+    for (int i = 0; i < TGS_STAGE_COUNT; i++) { ms_sum[i] = 0.0; counts[i] = 0; }
+    for (ProfRec& r : g_prof) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess &&
+            r.stage >= 0 && r.stage < TGS_STAGE_COUNT) { ms_sum[r.stage] += ms; counts[r.stage]++; }
+        hipEventDestroy(r.e0); hipEventDestroy(r.e1);
+    }
+    g_prof.clear();
+    return TGS_OK;
+}
 const char* tgs_last_error(void) { return g_err; }
 
 int64_t tgs_forward(tgs_alloc_fn alloc, void* alloc_ctx, void* stream, int P, int D, int M, const float* background, int width,
@@ -113,10 +174,12 @@ int64_t tgs_forward(tgs_alloc_fn alloc, void* alloc_ctx, void* stream, int P, in
     Meta meta;
     memset(&meta, 0, sizeof(meta));
     if (P > 0) {
+        STAGE_BEGIN();
         launch_preprocess_fwd(st, in, cam, g, s);
-        STAGE_CHECK("preprocess");
+        STAGE_CHECK("preprocess", TGS_STAGE_PREPROCESS_FWD);
+        STAGE_BEGIN();
         launch_scan(st, g, s, (uint32_t)n_blocks((size_t)P), (uint32_t)T);
-        STAGE_CHECK("scan");
+        STAGE_CHECK("scan", TGS_STAGE_SCAN);
         // the one host synchronisation of the forward pass (rasterizer_impl.cu:280-281): R sizes the binning buffer
         HIP_TRY(hipMemcpyAsync(&meta, s.meta, sizeof(Meta), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -130,14 +193,17 @@ int64_t tgs_forward(tgs_alloc_fn alloc, void* alloc_ctx, void* stream, int P, in
     bin_carve(b, bin_ptr, (size_t)R);
 
     if (R > 0) {
+        STAGE_BEGIN();
         launch_scatter(st, P, g, s, b, cam.gx);
-        STAGE_CHECK("scatter");
+        STAGE_CHECK("scatter", TGS_STAGE_SCATTER);
         const float* colors = has_sh ? g.rgb : colors_precomp;       // rasterizer_impl.cu:321
+        STAGE_BEGIN();
         launch_tile_sort(st, g, s, b, colors, cam.gx, (uint32_t)T, meta.max_count, meta.n_overflow);
-        STAGE_CHECK("tile_sort");
+        STAGE_CHECK("tile_sort", TGS_STAGE_TILE_SORT);
     }
+    STAGE_BEGIN();
     launch_render_fwd(st, s, b, width, height, cam.gx, (uint32_t)T, background, out_color);
-    STAGE_CHECK("render");
+    STAGE_CHECK("render", TGS_STAGE_RENDER_FWD);
     return (int64_t)R;
 }
 
@@ -172,11 +238,13 @@ int tgs_backward(void* stream, int P, int D, int M, int64_t R, const float* back
     in.dL_dmean3D = dL_dmean3D; in.dL_dcov3D = dL_dcov3D; in.dL_dsh = dL_dsh; in.dL_dscale = dL_dscale; in.dL_drot = dL_drot;
 
     if (R > 0) {
+        STAGE_BEGIN();
         launch_render_bwd(st, s, b, width, height, cam.gx, (uint32_t)T, background, dL_dpix);
-        STAGE_CHECK("render_bwd");
+        STAGE_CHECK("render_bwd", TGS_STAGE_RENDER_BWD);
     }
+    STAGE_BEGIN();
     launch_preprocess_bwd(st, in, cam, g, b);
-    STAGE_CHECK("preprocess_bwd");
+    STAGE_CHECK("preprocess_bwd", TGS_STAGE_PREPROCESS_BWD);
     return TGS_OK;
 }
 

@@ -41,10 +41,30 @@ def _load() -> C.CDLL:
     lib.tgs_mark_visible.argtypes = [vp, it, vp, vp, vp, vp]
     lib.tgs_state_field.restype = C.c_int64
     lib.tgs_state_field.argtypes = [vp, C.c_char_p, it, it, it, C.c_int64, it, it, vp, vp, vp, vp, C.c_size_t]
+    lib.tgs_profile_begin.restype = it
+    lib.tgs_profile_begin.argtypes = [it]
+    lib.tgs_profile_end.restype = it
+    lib.tgs_profile_end.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     return lib
 
 
 _lib = _load()
+STAGES = ("preprocess_fwd", "scan", "scatter", "tile_sort", "render_fwd", "render_bwd", "preprocess_bwd")
+
+
+def profile_begin(max_records: int = 100000) -> None:
+    """Bench instrumentation: hipEvents around every pipeline stage on the caller's stream (no syncs)."""
+    if _lib.tgs_profile_begin(int(max_records)) < 0:
+        raise RuntimeError("profiling already active")
+
+
+def profile_end():
+    """-> {stage: (total_ms, launches)}; waits for the recorded events."""
+    ms = (C.c_double * len(STAGES))()
+    cnt = (C.c_int64 * len(STAGES))()
+    if _lib.tgs_profile_end(ms, cnt) < 0:
+        raise RuntimeError("profiling not active")
+    return {n: (float(ms[i]), int(cnt[i])) for i, n in enumerate(STAGES)}
 _ALLOC_T = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, C.c_size_t)
 
 
