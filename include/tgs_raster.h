@@ -103,6 +103,10 @@ enum {
 int tgs_profile_begin(int max_records);
 int tgs_profile_end(double* ms_sum, int64_t* counts);
 
+/* Hardware self-test of the wave-level 36-value reduction used by the backward render kernel:
+ * in[64][36] (one row per lane) -> out[4][9], out[e][k] = sum over lanes of in[lane][e*9+k]. */
+int tgs_selftest_reduce36(void* stream, const float* in, float* out);
+
 const char* tgs_last_error(void);   /* thread-local message of the last failing call */
 int tgs_abi_version(void);
 

@@ -143,6 +143,24 @@ SCENES = {
 }
 
 
+def f64_truth(inp, dL):
+    import torch
+    from oracle import torch_splat
+    dt = torch.float64
+    t = lambda x, g=False: torch.tensor(np.asarray(x), dtype=dt, requires_grad=g)
+    P = inp["means3D"].shape[0]
+    leaves = {"means3D": t(inp["means3D"], True), "means2D": torch.zeros(P, 3, dtype=dt, requires_grad=True), "opacities": t(inp["opacities"], True)}
+    for k in ("shs", "colors_precomp", "scales", "rotations", "cov3D_precomp"):
+        if inp.get(k) is not None:
+            leaves[k] = t(inp[k], True)
+    color, _ = torch_splat.splat(viewmatrix=t(inp["viewmatrix"]), projmatrix=t(inp["projmatrix"]), campos=t(inp["campos"]), bg=t(inp["bg"]),
+                                 tanfovx=float(inp["tanfovx"]), tanfovy=float(inp["tanfovy"]), image_height=int(inp["image_height"]),
+                                 image_width=int(inp["image_width"]), sh_degree=int(inp["sh_degree"]),
+                                 scale_modifier=float(inp["scale_modifier"]), **leaves)
+    color.backward(torch.tensor(dL, dtype=dt))
+    return {k: v.grad.numpy() for k, v in leaves.items() if v.grad is not None}
+
+
 def rel(a, b):
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-12))
@@ -187,6 +205,13 @@ def main():
         # cancellation-prone tensors (tests scale their tolerance with it)
         for k in ("dL_dmeans3D", "dL_dcov3D", "dL_dscales", "dL_drotations"):
             out["out_nofma_" + k] = b[k]
+        # exact-arithmetic value of the same gradients (independent fp64 autograd splat, oracle/torch_splat.py):
+        # how far the reference's OWN fp32 result is from the truth bounds what "parity" can mean
+        tr = f64_truth(inp, dL)
+        for k, leaf in (("dL_dmeans3D", "means3D"), ("dL_dscales", "scales"), ("dL_drotations", "rotations"), ("dL_dcov3D", "cov3D_precomp")):
+            if leaf in tr:
+                out["out_f64_" + k] = tr[leaf].astype(np.float32)
+                print(f"    reference fp32 vs fp64 truth {k}: {rel(a[k], tr[leaf]):.2e}")
         np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
     print("worst rel-L2 (oracle vs emu-fma, emu-nofma vs emu-fma):")
     for k, (x, y) in worst.items():

@@ -61,3 +61,14 @@ def test_backward_is_bitwise_reproducible(gpu_device):
     b = util.hip_run(inp, dL, introspect=False)
     for k in ("color",) + util.GRAD_KEYS:
         assert np.array_equal(a[k], b[k]), k
+
+
+def test_wave_reduce36_on_hardware(gpu_device):
+    """The 36-value wave reduction (v_permlane32/16_swap + DPP) against a float64 sum."""
+    import torch
+    from diff_gaussian_rasterization import _C
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(64, 36, generator=g)
+    out = _C.selftest_reduce36(x.to(gpu_device)).cpu().double()
+    ref = x.double().sum(0).reshape(4, 9)
+    assert torch.allclose(out, ref, rtol=1e-5, atol=1e-5), (out - ref).abs().max()

@@ -18,6 +18,8 @@ LIB = os.path.join(LIBDIR, "libtgs_raster.so")
 SOURCES = ["tgs_forward.hip", "tgs_backward.hip", "tgs_api.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+# experiment knobs, e.g. TGS_DEFINES="-DTGS_FAST_MATH=0" python -m youreditableavatar_amd.build --force
+FLAGS += os.environ.get("TGS_DEFINES", "").split()
 
 
 def hipcc() -> str:

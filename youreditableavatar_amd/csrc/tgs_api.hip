@@ -17,6 +17,7 @@ void launch_render_fwd(hipStream_t, const ImgState&, const BinState&, int W, int
 void launch_mark_visible(hipStream_t, int P, const float* means3D, const float* view, uint8_t* present);
 void launch_render_bwd(hipStream_t, const ImgState&, const BinState&, int W, int H, uint32_t gx, uint32_t T, const float* bg, const float* dL_dpix);
 void launch_preprocess_bwd(hipStream_t, const BwdIn&, const CamParams&, const GeomState&, const BinState&);
+void launch_selftest_reduce36(hipStream_t, const float* in, float* out);
 }  // namespace tgs
 
 using namespace tgs;
@@ -40,7 +41,7 @@ void prof_begin_stage(hipStream_t st)
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if (!g_prof_on || g_prof.size() >= g_prof_cap) { g_prof_open = nullptr; return; }
     if (hipEventCreate(&g_prof_open) != hipSuccess) { g_prof_open = nullptr; return; }
-    hipEventRecord(g_prof_open, st);
+    (void)hipEventRecord(g_prof_open, st);
 }
 void prof_end_stage(hipStream_t st, int stage)
 {
@@ -48,8 +49,8 @@ void prof_end_stage(hipStream_t st, int stage)
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if (!g_prof_open) return;
     ProfRec r; r.stage = stage; r.e0 = g_prof_open; g_prof_open = nullptr;
-    if (hipEventCreate(&r.e1) != hipSuccess) { hipEventDestroy(r.e0); return; }
-    hipEventRecord(r.e1, st);
+    if (hipEventCreate(&r.e1) != hipSuccess) { (void)hipEventDestroy(r.e0); return; }
+    (void)hipEventRecord(r.e1, st);
     g_prof.push_back(r);
 }
 }  // namespace
@@ -98,6 +99,12 @@ extern "C" {
 
 int tgs_abi_version(void) { return TGS_ABI_VERSION; }
 
+int tgs_selftest_reduce36(void* stream, const float* in, float* out)
+{
+    launch_selftest_reduce36((hipStream_t)stream, in, out);
+    return hipGetLastError() == hipSuccess ? TGS_OK : TGS_ERR_HIP;
+}
+
 int tgs_profile_begin(int max_records)
 {
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -120,7 +127,7 @@ int tgs_profile_end(double* ms_sum, int64_t* counts)
         float ms = 0.f;
         if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess &&
             r.stage >= 0 && r.stage < TGS_STAGE_COUNT) { ms_sum[r.stage] += ms; counts[r.stage]++; }
-        hipEventDestroy(r.e0); hipEventDestroy(r.e1);
+        (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
     }
     g_prof.clear();
     return TGS_OK;

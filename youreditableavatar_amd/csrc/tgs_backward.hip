@@ -15,21 +15,21 @@
 
 namespace tgs {
 
-constexpr int BCHUNK = 256;    // list entries staged per round
 constexpr int NACC = 9;        // colour rgb, mean2D xy, conic xx/xy/yy, opacity
 
 __global__ __launch_bounds__(256) void k_render_bwd(const ImgState s, const BinState b, int W, int H, uint32_t gx,
                                                     const float* __restrict__ bg, const float* __restrict__ dL_dpix)
 {
-    __shared__ float4 sA[BCHUNK];
-    __shared__ float4 sB[BCHUNK];
-    __shared__ float sC[BCHUNK];
-    __shared__ uint32_t sSlot[BCHUNK];
-    __shared__ float wacc[4][NACC][BCHUNK];               // per-wave partial sums of the current round
-    __shared__ unsigned long long touched[4][BCHUNK / 64];
+    __shared__ float4 sA[RCHUNK + 1];
+    __shared__ float4 sB[RCHUNK + 1];
+    __shared__ float sC[RCHUNK + 1];
+    __shared__ uint32_t sSlot[RCHUNK];
+    __shared__ float wacc[4][NACC][RCHUNK + 1];            // per-wave partial sums of the current round (+1: null slot)
+    __shared__ unsigned long long touched[4][RCHUNK / 64];
+    __shared__ QuadLists L;
     __shared__ uint32_t wmax[4];
 
-    const uint32_t tile = blockIdx.x;
+    const uint32_t tile = s.tile_order[blockIdx.x];
     const uint32_t tx = tile % gx, ty = tile / gx;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int px = tx * TILE + (wv & 1) * 8 + (lane & 7);
@@ -39,7 +39,9 @@ __global__ __launch_bounds__(256) void k_render_bwd(const ImgState s, const BinS
     const uint2 rg = s.ranges[tile];
     const uint32_t n = rg.y - rg.x;
     if (n == 0) return;
+    set_wave_priority(n);
     const size_t pix_id = (size_t)W * py + px, N = (size_t)W * H;
+    if (threadIdx.x == 0) { sA[RNULL] = make_float4(0.f, 0.f, 0.f, 0.f); sB[RNULL] = make_float4(0.f, 0.f, 0.f, 0.f); sC[RNULL] = 0.f; }
 
     const float T_final = inside ? s.final_T[pix_id] : 0.f;
     float T = T_final;
@@ -54,8 +56,8 @@ __global__ __launch_bounds__(256) void k_render_bwd(const ImgState s, const BinS
 
     // Entries behind every pixel's last contributor get no gradient (backward.cu:487-488): find the
     // deepest one any pixel of the tile needs and start there.
-    uint32_t m = wave_max_u32(last_contributor);
-    if (lane == 0) wmax[wv] = m;
+    uint32_t mq = wave_max_u32(last_contributor);
+    if (lane == 0) wmax[wv] = mq;
     __syncthreads();
     const uint32_t qmax = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
 
@@ -66,65 +68,93 @@ __global__ __launch_bounds__(256) void k_render_bwd(const ImgState s, const BinS
         for (int k = 0; k < NACC; k++) row[k] = 0.f;
     }
 
-    for (uint32_t qhi = qmax; qhi > 0; qhi = qhi > BCHUNK ? qhi - BCHUNK : 0) {
-        const uint32_t cnt = min((uint32_t)BCHUNK, qhi);
+    // register-staged prefetch (slot t of a round = list position qhi-1-t: back to front)
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
+    float2 rc = make_float2(0.f, 0.f);
+    uint32_t rs = 0;
+    if (threadIdx.x < qmax) { const uint32_t pos = rg.x + qmax - 1 - threadIdx.x; ra = b.recA[pos]; rb = b.recB[pos]; rc = b.recC[pos]; rs = b.slot[pos]; }
+
+    for (uint32_t qhi = qmax; qhi > 0; qhi = qhi > RCHUNK ? qhi - RCHUNK : 0) {
+        const uint32_t cnt = min((uint32_t)RCHUNK, qhi);
         __syncthreads();                                    // previous round's flush has read wacc / sSlot
-        if (threadIdx.x < cnt) {                            // slot t of the round = list position qhi-1-t
-            const uint32_t pos = rg.x + qhi - 1 - threadIdx.x;
-            sA[threadIdx.x] = b.recA[pos];
-            sB[threadIdx.x] = b.recB[pos];
-            sC[threadIdx.x] = b.recC[pos].x;
-            sSlot[threadIdx.x] = b.slot[pos];
-        }
+        uint32_t qm = 0;
+        if (threadIdx.x < cnt) { sA[threadIdx.x] = ra; sB[threadIdx.x] = rb; sC[threadIdx.x] = rc.x; qm = __float_as_uint(rc.y); sSlot[threadIdx.x] = rs; }
+        build_quad_lists(L, qm, wv, lane);
+        if (lane < RCHUNK / 64) touched[wv][lane] = 0ull;
         __syncthreads();
+        if (qhi > RCHUNK && threadIdx.x < qhi - RCHUNK) {
+            const uint32_t pos = rg.x + qhi - RCHUNK - 1 - threadIdx.x;
+            ra = b.recA[pos]; rb = b.recB[pos]; rc = b.recC[pos]; rs = b.slot[pos];
+        }
 
 #pragma unroll 1
-        for (uint32_t jj = 0; jj < BCHUNK / 64; jj++) {
+        for (int sw = 0; sw < 4; sw++) {
+            const uint32_t nl = __builtin_amdgcn_readfirstlane(L.cnt[wv][sw]);
             unsigned long long tmask = 0;
-            const uint32_t jend = min(cnt, (jj + 1) * 64u);
-            for (uint32_t j = jj * 64; j < jend; j++) {
-                const uint32_t q = qhi - 1 - j;
-                const float4 a = sA[j];
-                const float4 bb = sB[j];
-                const float dx = a.x - pixfx, dy = a.y - pixfy;
-                const float power = -0.5f * (a.z * dx * dx + bb.x * dy * dy) - a.w * dx * dy;
-                const float G = expf(power);
-                const float alpha = fminf(0.99f, bb.y * G);
-                const bool valid = (q < last_contributor) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-                if (__builtin_amdgcn_ballot_w64(valid) == 0) continue;
-                float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f, v5 = 0.f, v6 = 0.f, v7 = 0.f, v8 = 0.f;
-                if (valid) {                                // backward.cu:507-555
-                    T = T / (1.f - alpha);
-                    const float dchannel_dcolor = alpha * T;
-                    float dL_dalpha = 0.0f;
-                    const float c0 = bb.z, c1 = bb.w, c2 = sC[j];
-                    acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0; lc0 = c0; dL_dalpha += (c0 - acc0) * dpx0; v0 = dchannel_dcolor * dpx0;
-                    acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1; lc1 = c1; dL_dalpha += (c1 - acc1) * dpx1; v1 = dchannel_dcolor * dpx1;
-                    acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2; lc2 = c2; dL_dalpha += (c2 - acc2) * dpx2; v2 = dchannel_dcolor * dpx2;
-                    dL_dalpha *= T;
-                    last_alpha = alpha;
-                    dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
-                    const float dL_dG = bb.y * dL_dalpha;
-                    const float gdx = G * dx, gdy = G * dy;
-                    const float dG_ddelx = -gdx * a.z - gdy * a.w;
-                    const float dG_ddely = -gdy * bb.x - gdx * a.w;
-                    v3 = dL_dG * dG_ddelx * ddelx_dx;
-                    v4 = dL_dG * dG_ddely * ddely_dy;
-                    v5 = -0.5f * gdx * dx * dL_dG;
-                    v6 = -0.5f * gdx * dy * dL_dG;
-                    v7 = -0.5f * gdy * dy * dL_dG;
-                    v8 = G * dL_dalpha;
+#pragma unroll 1
+            for (uint32_t k = 0; k < nl; k += RUNROLL) {    // only entries that can reach this wave's quadrant
+                const uint2 pk = *reinterpret_cast<const uint2*>(&L.idx[wv][sw][k]);
+                const uint32_t j[RUNROLL] = {pk.x & 0xffffu, pk.x >> 16, pk.y & 0xffffu, pk.y >> 16};
+                float4 a[RUNROLL], bb[RUNROLL];
+                float cc[RUNROLL], dx[RUNROLL], dy[RUNROLL], G[RUNROLL], alpha[RUNROLL];
+                bool valid[RUNROLL];
+#pragma unroll
+                for (int u = 0; u < RUNROLL; u++) { a[u] = sA[j[u]]; bb[u] = sB[j[u]]; cc[u] = sC[j[u]]; }
+                bool any = false;
+#pragma unroll
+                for (int u = 0; u < RUNROLL; u++) {
+                    dx[u] = a[u].x - pixfx; dy[u] = a[u].y - pixfy;
+                    const float power = -0.5f * (a[u].z * dx[u] * dx[u] + bb[u].x * dy[u] * dy[u]) - a[u].w * dx[u] * dy[u];
+                    G[u] = tgs_exp(power);
+                    alpha[u] = fminf(0.99f, bb[u].y * G[u]);
+                    // list position of slot j is qhi-1-j; "contributor >= last_contributor" skip of backward.cu:487
+                    valid[u] = (qhi - 1 - j[u] < last_contributor) && (j[u] < cnt) && !(power > 0.0f) && !(alpha[u] < 1.0f / 255.0f);
+                    any = any || valid[u];
                 }
-                // wave-level sums (the total ends up in every lane; lane 0 stores)
-                v0 = wave_sum(v0); v1 = wave_sum(v1); v2 = wave_sum(v2); v3 = wave_sum(v3); v4 = wave_sum(v4);
-                v5 = wave_sum(v5); v6 = wave_sum(v6); v7 = wave_sum(v7); v8 = wave_sum(v8);
-                if (lane == 0) {
-                    wacc[wv][0][j] = v0; wacc[wv][1][j] = v1; wacc[wv][2][j] = v2; wacc[wv][3][j] = v3; wacc[wv][4][j] = v4;
-                    wacc[wv][5][j] = v5; wacc[wv][6][j] = v6; wacc[wv][7][j] = v7; wacc[wv][8][j] = v8;
+                if (__builtin_amdgcn_ballot_w64(any) == 0) continue;
+                float v[36];
+#pragma unroll
+                for (int u = 0; u < RUNROLL; u++) {
+#pragma unroll
+                    for (int c = 0; c < NACC; c++) v[u * NACC + c] = 0.f;
+                    if (valid[u]) {                         // backward.cu:507-555
+                        const float om = 1.f - alpha[u];
+                        T = tgs_div(T, om);
+                        const float dchannel_dcolor = alpha[u] * T;
+                        float dL_dalpha = 0.0f;
+                        const float c0 = bb[u].z, c1 = bb[u].w, c2 = cc[u];
+                        acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0; lc0 = c0; dL_dalpha += (c0 - acc0) * dpx0;
+                        acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1; lc1 = c1; dL_dalpha += (c1 - acc1) * dpx1;
+                        acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2; lc2 = c2; dL_dalpha += (c2 - acc2) * dpx2;
+                        v[u * NACC + 0] = dchannel_dcolor * dpx0; v[u * NACC + 1] = dchannel_dcolor * dpx1; v[u * NACC + 2] = dchannel_dcolor * dpx2;
+                        dL_dalpha *= T;
+                        last_alpha = alpha[u];
+                        dL_dalpha += tgs_div(-T_final, om) * bg_dot_dpixel;
+                        const float dL_dG = bb[u].y * dL_dalpha;
+                        const float gdx = G[u] * dx[u], gdy = G[u] * dy[u];
+                        const float dG_ddelx = -gdx * a[u].z - gdy * a[u].w;
+                        const float dG_ddely = -gdy * bb[u].x - gdx * a[u].w;
+                        v[u * NACC + 3] = dL_dG * dG_ddelx * ddelx_dx;
+                        v[u * NACC + 4] = dL_dG * dG_ddely * ddely_dy;
+                        v[u * NACC + 5] = -0.5f * gdx * dx[u] * dL_dG;
+                        v[u * NACC + 6] = -0.5f * gdx * dy[u] * dL_dG;
+                        v[u * NACC + 7] = -0.5f * gdy * dy[u] * dL_dG;
+                        v[u * NACC + 8] = G[u] * dL_dalpha;
+                    }
                 }
-                tmask |= 1ull << (j & 63);
+                float r[NACC];
+                wave_reduce36(v, r);                        // row e of r[k]: total of entry e, component k
+                // lane 16e stores entry e's nine sums (entries with no valid lane store zeros; null slots go to the spare column)
+                const int row = lane >> 4;
+                const uint32_t jr = row == 0 ? j[0] : row == 1 ? j[1] : row == 2 ? j[2] : j[3];
+                if ((lane & 15) == 0) {
+#pragma unroll
+                    for (int c = 0; c < NACC; c++) wacc[wv][c][jr] = r[c];
+                }
+#pragma unroll
+                for (int u = 0; u < RUNROLL; u++) if (j[u] < RCHUNK) tmask |= 1ull << (j[u] & 63);
             }
-            if (lane == 0) touched[wv][jj] = tmask;
+            if (lane == 0 && tmask) touched[wv][sw] = tmask;
         }
         __syncthreads();
         // flush: thread j adds the (up to) 4 wave partials of entry j in wave order and stores the row
@@ -348,6 +378,23 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
     for (int i = 0; i < 6; i++) in.dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
     if (in.dL_dscale) { in.dL_dscale[i3] = dscale[0]; in.dL_dscale[i3 + 1] = dscale[1]; in.dL_dscale[i3 + 2] = dscale[2]; }
     if (in.dL_drot) reinterpret_cast<float4*>(in.dL_drot)[idx] = make_float4(drot[0], drot[1], drot[2], drot[3]);
+}
+
+// hardware self-test of wave_reduce36: in[64][36] -> out[4][9] (row e, component k)
+__global__ void k_selftest_reduce36(const float* in, float* out)
+{
+    float v[36], r[9];
+#pragma unroll
+    for (int i = 0; i < 36; i++) v[i] = in[threadIdx.x * 36 + i];
+    wave_reduce36(v, r);
+    if ((threadIdx.x & 15) == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) out[(threadIdx.x >> 4) * 9 + k] = r[k];
+    }
+}
+void launch_selftest_reduce36(hipStream_t st, const float* in, float* out)
+{
+    hipLaunchKernelGGL(k_selftest_reduce36, dim3(1), dim3(64), 0, st, in, out);
 }
 
 void launch_render_bwd(hipStream_t st, const ImgState& s, const BinState& b, int W, int H, uint32_t gx, uint32_t T, const float* bg, const float* dL_dpix)

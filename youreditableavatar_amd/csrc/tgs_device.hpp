@@ -42,6 +42,7 @@ struct ImgState {
     uint32_t* tile_count;     // per tile instance count
     uint32_t* cursor;         // per tile scatter cursor
     uint32_t* ovf_tiles;      // list of overflow tiles
+    uint32_t* tile_order;     // tiles by descending list length: render kernels start the long lists first
     float* final_T;           //                                    (imgState.accum_alpha)
     uint32_t* n_contrib;      //                                    (imgState.n_contrib)
 };
@@ -76,7 +77,7 @@ __host__ __device__ inline size_t img_carve(ImgState& s, char* base, size_t N, s
 {
     char* p = base;
     carve(p, s.meta, 1); carve(p, s.ranges, T); carve(p, s.tile_count, T); carve(p, s.cursor, T);
-    carve(p, s.ovf_tiles, T); carve(p, s.final_T, N); carve(p, s.n_contrib, N);
+    carve(p, s.ovf_tiles, T); carve(p, s.tile_order, T); carve(p, s.final_T, N); carve(p, s.n_contrib, N);
     return (size_t)(p - base) + 256;
 }
 __host__ __device__ inline size_t bin_carve(BinState& b, char* base, size_t R)
@@ -163,6 +164,100 @@ __device__ __forceinline__ mat3 m3make(float a, float b, float c, float d, float
     r.m[0][0] = a; r.m[0][1] = b; r.m[0][2] = c; r.m[1][0] = d; r.m[1][1] = e; r.m[1][2] = f;
     r.m[2][0] = g; r.m[2][1] = h; r.m[2][2] = i;
     return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// render-kernel staging shared by forward and backward
+// ---------------------------------------------------------------------------------------------
+constexpr int RCHUNK = 256;            // list entries staged per round (one per thread)
+constexpr int RNULL = RCHUNK;          // LDS slot of a null record (opacity 0: never contributes)
+constexpr int RUNROLL = 4;             // entries evaluated together by a wave
+constexpr int QL_STRIDE = 64 + RUNROLL;
+
+// Per round: for every pixel quadrant (= compute wave) and every staging wave, the compacted list of
+// staged slots whose splat can reach the quadrant (quadrant_mask() bit), padded with RNULL to a
+// multiple of RUNROLL.  A compute wave walks its 4 sub-lists with plain LDS reads -- no scalar
+// bit-twiddling in the hot loop.
+struct alignas(16) QuadLists {       // rows are read 8 bytes at a time: QL_STRIDE*2 is a multiple of 8
+    unsigned short idx[4][4][QL_STRIDE];   // [quadrant][staging wave][k]
+    uint32_t cnt[4][4];
+};
+__device__ __forceinline__ void build_quad_lists(QuadLists& L, uint32_t qm, int wv, int lane)
+{
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const bool on = (qm >> q) & 1u;
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(on);
+        const uint32_t n = (uint32_t)__builtin_popcountll(bal);
+        const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        if (on) L.idx[q][wv][pos] = (unsigned short)threadIdx.x;
+        if (lane < RUNROLL) L.idx[q][wv][n + lane] = (unsigned short)RNULL;
+        if (lane == 0) L.cnt[q][wv] = n;
+    }
+}
+
+#ifndef TGS_FAST_MATH
+#define TGS_FAST_MATH 1                // v_exp_f32 / v_rcp_f32 forms in the render loops (parity measured in tests)
+#endif
+__device__ __forceinline__ float tgs_exp(float x)
+{
+#if TGS_FAST_MATH
+    return __expf(x);
+#else
+    return expf(x);
+#endif
+}
+__device__ __forceinline__ float tgs_div(float a, float b)
+{
+#if TGS_FAST_MATH
+    return __fdividef(a, b);
+#else
+    return a / b;
+#endif
+}
+// wave priority by list length: the kernel ends when the longest list ends, so long lists go first
+__device__ __forceinline__ void set_wave_priority(uint32_t n)
+{
+    if (n > 1024u) __builtin_amdgcn_s_setprio(3);
+    else if (n > 512u) __builtin_amdgcn_s_setprio(2);
+    else if (n > 256u) __builtin_amdgcn_s_setprio(1);
+}
+
+// Sums 36 per-lane values (4 list entries x 9 gradient components, v[e*9+k]) over the 64 lanes of a wave.
+// Result: r[k], and in row e (lanes 16e..16e+15) every lane holds the total of entry e, component k.
+// v_permlane32_swap / v_permlane16_swap halve the register count while they fold lane halves, so the
+// whole reduction is 90 VALU operations instead of 36 x 6.
+// NOTE (hipcc / ROCm 7.2, gfx950): `r[0] + r[1]` written directly on the builtin's two results is
+// miscompiled to `v_add_f32 v, r0, r0` (seen in the .s; the second result is dropped).  Passing both
+// through an empty asm keeps them apart.  tgs_selftest_reduce36 (tests/) checks the result on hardware.
+__device__ __forceinline__ float swap32_add(float x, float y)
+{
+    auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y), false, false);
+    unsigned r0 = r[0], r1 = r[1];
+    asm volatile("" : "+v"(r0), "+v"(r1));
+    return __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
+}
+__device__ __forceinline__ float swap16_add(float x, float y)
+{
+    auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y), false, false);
+    unsigned r0 = r[0], r1 = r[1];
+    asm volatile("" : "+v"(r0), "+v"(r1));
+    return __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
+}
+__device__ __forceinline__ void wave_reduce36(const float (&v)[36], float (&r)[9])
+{
+    float a[18];
+#pragma unroll
+    for (int i = 0; i < 18; i++) a[i] = swap32_add(v[i], v[i + 18]);     // lanes <32: value i, lanes >=32: value i+18
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        float x = swap16_add(a[i], a[i + 9]);                            // rows 0..3: values i, i+9, i+18, i+27
+        TGS_DPP_ADD(x, 0xB1, 0xf);
+        TGS_DPP_ADD(x, 0x4E, 0xf);
+        TGS_DPP_ADD(x, 0x141, 0xf);
+        TGS_DPP_ADD(x, 0x140, 0xf);
+        r[i] = x;
+    }
 }
 
 // SH basis constants (cuda_rasterizer/auxiliary.h:22-39)

@@ -200,6 +200,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const 
             }
             carry += tot;
         }
+        // tiles by descending list length (power-of-two buckets; order inside a bucket does not matter)
+        __shared__ uint32_t hist[34];
+        if (threadIdx.x < 34) hist[threadIdx.x] = 0;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < T; i += SCAN_THREADS) { const uint32_t c = s.tile_count[i]; atomicAdd(&hist[c ? 32 - __builtin_clz(c) : 0], 1u); }
+        __syncthreads();
+        if (threadIdx.x == 0) { uint32_t acc = 0; for (int bk = 33; bk-- > 0;) { const uint32_t h = hist[bk]; hist[bk] = acc; acc += h; } }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < T; i += SCAN_THREADS) { const uint32_t c = s.tile_count[i]; s.tile_order[atomicAdd(&hist[c ? 32 - __builtin_clz(c) : 0], 1u)] = i; }
         mx = wave_max_u32(mx);
         if ((threadIdx.x & 63) == 0) lds_max[threadIdx.x >> 6] = mx;
         __syncthreads();
@@ -291,6 +300,33 @@ __device__ __forceinline__ void cmp_swap(KeyPtr keys, uint32_t i, uint32_t l, ui
     }
 }
 
+// Conservative 4-bit mask of the tile's 8x8 pixel quadrants that a splat can reach with alpha >= 1/255:
+// alpha = o*exp(power) >= 1/255  <=>  power >= -tau, tau = ln(255 o); the level set 1/2 d^T Q d <= tau of the
+// conic Q = [[A,B],[B,C]] has the bounding box |dx| <= sqrt(2 tau C/det Q), |dy| <= sqrt(2 tau A/det Q).
+// The exact per-pixel tests of forward.cu:336-343 stay in the render kernels, so a conservative mask only
+// removes work, never a contribution.  Comparisons are written so that NaNs keep every quadrant.
+__device__ __forceinline__ uint32_t quadrant_mask(float2 xy, float4 co, uint32_t tx, uint32_t ty)
+{
+    const float o255 = 255.0f * co.w;
+    if (o255 < 0.999f) return 0u;                       // alpha <= o < 1/255 for every pixel (G <= 1)
+    const float tau = fmaxf(logf(o255), 0.f) + 0.01f;
+    const float det = co.x * co.z - co.y * co.y;
+    float hx = 3.0e38f, hy = 3.0e38f;
+    if (det > 0.f && co.x > 0.f && co.z > 0.f) {
+        hx = sqrtf(2.f * tau * co.z / det) * 1.001f + 0.01f;
+        hy = sqrtf(2.f * tau * co.x / det) * 1.001f + 0.01f;
+    }
+    const float x0 = (float)(tx * TILE), y0 = (float)(ty * TILE);
+    uint32_t m = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const float qx = x0 + (float)((q & 1) * 8), qy = y0 + (float)((q >> 1) * 8);
+        const bool out = (xy.x + hx < qx) || (xy.x - hx > qx + 7.f) || (xy.y + hy < qy) || (xy.y - hy > qy + 7.f);
+        if (!out) m |= 1u << q;
+    }
+    return m;
+}
+
 // gathers the per-instance record of sorted entry i of a tile (what renderCUDA fetches per entry:
 // forward.cu:315-321,355 and backward.cu:470-480)
 __device__ __forceinline__ void finalize_entry(unsigned long long key, uint32_t pos, uint32_t tile, uint32_t gx, const GeomState& g,
@@ -304,7 +340,7 @@ __device__ __forceinline__ void finalize_entry(unsigned long long key, uint32_t 
     const uint32_t tx = tile % gx, ty = tile / gx;
     b.recA[pos] = make_float4(xy.x, xy.y, co.x, co.y);
     b.recB[pos] = make_float4(co.z, co.w, cr, cg);
-    b.recC[pos] = make_float2(cb, __uint_as_float(id));
+    b.recC[pos] = make_float2(cb, __uint_as_float(quadrant_mask(xy, co, tx, ty)));
     b.slot[pos] = g.offsets[id] + (ty - r.y) * ((uint32_t)r.z - r.x) + (tx - r.x);
 }
 
@@ -396,16 +432,20 @@ __global__ __launch_bounds__(256) void k_ovf_finalize(const GeomState g, const I
 // quadrant so that a wave's 64 pixels are spatially compact (whole-wave skips of small splats).
 // The tile's records are staged through LDS in rounds of 256 and read back as broadcasts.
 // ---------------------------------------------------------------------------------------------
-constexpr int RCHUNK = 256;
-
+// The critical path of this kernel is the longest tile list times the per-entry latency of ONE wave
+// (work per tile is tiny against the chip, lists are long), so tiles are visited longest-first, long
+// lists run at raised wave priority, and the inner loop is written for instruction-level parallelism:
+// 4 entries' LDS reads, power and exp are issued together, only the transmittance chain is sequential,
+// and it is branch-free.
 __global__ __launch_bounds__(256) void k_render_fwd(const ImgState s, const BinState b, int W, int H, uint32_t gx,
                                                     const float* __restrict__ bg, float* __restrict__ out_color)
 {
+    __shared__ float4 sA[RCHUNK + 1];
+    __shared__ float4 sB[RCHUNK + 1];
+    __shared__ float sC[RCHUNK + 1];
+    __shared__ QuadLists L;
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-    __shared__ float4 sA[RCHUNK];
-    __shared__ float4 sB[RCHUNK];
-    __shared__ float sC[RCHUNK];
-    const uint32_t tile = blockIdx.x;
+    const uint32_t tile = s.tile_order[blockIdx.x];
     const uint32_t tx = tile % gx, ty = tile / gx;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int px = tx * TILE + (wv & 1) * 8 + (lane & 7);
@@ -413,38 +453,64 @@ __global__ __launch_bounds__(256) void k_render_fwd(const ImgState s, const BinS
     const bool inside = px < W && py < H;
     const float pixfx = (float)px, pixfy = (float)py;
     const uint2 rg = s.ranges[tile];
+    set_wave_priority(rg.y - rg.x);
     bool done = !inside;
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
-    uint32_t contributor = 0, last_contributor = 0;
+    uint32_t last_contributor = 0;
+    if (threadIdx.x == 0) { sA[RNULL] = make_float4(0.f, 0.f, 0.f, 0.f); sB[RNULL] = make_float4(0.f, 0.f, 0.f, 0.f); sC[RNULL] = 0.f; }
+
+    // register-staged prefetch of the next round (global loads stay in flight under the compute)
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
+    float2 rc = make_float2(0.f, 0.f);
+    if (rg.x + threadIdx.x < rg.y) { ra = b.recA[rg.x + threadIdx.x]; rb = b.recB[rg.x + threadIdx.x]; rc = b.recC[rg.x + threadIdx.x]; }
 
     for (uint32_t base = rg.x; base < rg.y; base += RCHUNK) {
         if (__syncthreads_and(done)) break;                     // forward.cu:307-310
         const uint32_t cnt = min((uint32_t)RCHUNK, rg.y - base);
-        if (threadIdx.x < cnt) {
-            sA[threadIdx.x] = b.recA[base + threadIdx.x];
-            sB[threadIdx.x] = b.recB[base + threadIdx.x];
-            sC[threadIdx.x] = b.recC[base + threadIdx.x].x;
-        }
+        uint32_t qm = 0;
+        if (threadIdx.x < cnt) { sA[threadIdx.x] = ra; sB[threadIdx.x] = rb; sC[threadIdx.x] = rc.x; qm = __float_as_uint(rc.y); }
+        build_quad_lists(L, qm, wv, lane);
         __syncthreads();
-        const bool wave_live = __builtin_amdgcn_ballot_w64(!done) != 0;   // else this wave's 64 pixels are finished
-        for (uint32_t j = 0; wave_live && j < cnt; j++) {       // forward.cu:325-362
-            const float4 a = sA[j];
-            const float4 bb = sB[j];
-            const float dx = a.x - pixfx, dy = a.y - pixfy;
-            const float power = -0.5f * (a.z * dx * dx + bb.x * dy * dy) - a.w * dx * dy;
-            const float alpha = fminf(0.99f, bb.y * expf(power));
-            const float test_T = T * (1.f - alpha);
-            const bool skip = done || (power > 0.0f) || (alpha < 1.0f / 255.0f);
-            const bool stop = !skip && (test_T < 0.0001f);
-            if (!skip && !stop) {
-                const float w = alpha * T;
-                C0 += bb.z * w; C1 += bb.w * w; C2 += sC[j] * w;
-                T = test_T;
-                last_contributor = contributor + j + 1;
-            }
-            done = done || stop;
+        {
+            const uint32_t nxt = base + RCHUNK + threadIdx.x;
+            if (nxt < rg.y) { ra = b.recA[nxt]; rb = b.recB[nxt]; rc = b.recC[nxt]; }
         }
-        contributor += cnt;
+        bool wave_live = __builtin_amdgcn_ballot_w64(!done) != 0;   // else this wave's 64 pixels are finished
+        const uint32_t cbase = base - rg.x + 1;
+#pragma unroll 1
+        for (int sw = 0; wave_live && sw < 4; sw++) {
+            const uint32_t n = __builtin_amdgcn_readfirstlane(L.cnt[wv][sw]);
+#pragma unroll 1
+            for (uint32_t k = 0; k < n; k += RUNROLL) {         // forward.cu:325-362, only entries that can reach this quadrant
+                const uint2 pk = *reinterpret_cast<const uint2*>(&L.idx[wv][sw][k]);
+                const uint32_t j[RUNROLL] = {pk.x & 0xffffu, pk.x >> 16, pk.y & 0xffffu, pk.y >> 16};
+                float4 a[RUNROLL], bb[RUNROLL];
+                float cc[RUNROLL], power[RUNROLL], alpha[RUNROLL];
+#pragma unroll
+                for (int u = 0; u < RUNROLL; u++) { a[u] = sA[j[u]]; bb[u] = sB[j[u]]; cc[u] = sC[j[u]]; }
+#pragma unroll
+                for (int u = 0; u < RUNROLL; u++) {
+                    const float dx = a[u].x - pixfx, dy = a[u].y - pixfy;
+                    power[u] = -0.5f * (a[u].z * dx * dx + bb[u].x * dy * dy) - a[u].w * dx * dy;
+                    alpha[u] = fminf(0.99f, bb[u].y * tgs_exp(power[u]));
+                }
+                bool any_stop = false;
+#pragma unroll
+                for (int u = 0; u < RUNROLL; u++) {
+                    const float test_T = T * (1.f - alpha[u]);
+                    const bool live = !done && !(power[u] > 0.0f) && !(alpha[u] < 1.0f / 255.0f);
+                    const bool stop = live && (test_T < 0.0001f);
+                    const bool upd = live && !stop;
+                    const float w = upd ? alpha[u] * T : 0.f;
+                    C0 += bb[u].z * w; C1 += bb[u].w * w; C2 += cc[u] * w;
+                    T = upd ? test_T : T;
+                    last_contributor = upd ? cbase + j[u] : last_contributor;
+                    done = done || stop;
+                    any_stop = any_stop || stop;
+                }
+                if (__builtin_amdgcn_ballot_w64(any_stop) != 0 && __builtin_amdgcn_ballot_w64(!done) == 0) { wave_live = false; break; }
+            }
+        }
     }
     if (inside) {
         const size_t pix_id = (size_t)W * py + px, N = (size_t)W * H;

@@ -41,6 +41,8 @@ def _load() -> C.CDLL:
     lib.tgs_mark_visible.argtypes = [vp, it, vp, vp, vp, vp]
     lib.tgs_state_field.restype = C.c_int64
     lib.tgs_state_field.argtypes = [vp, C.c_char_p, it, it, it, C.c_int64, it, it, vp, vp, vp, vp, C.c_size_t]
+    lib.tgs_selftest_reduce36.restype = it
+    lib.tgs_selftest_reduce36.argtypes = [vp, vp, vp]
     lib.tgs_profile_begin.restype = it
     lib.tgs_profile_begin.argtypes = [it]
     lib.tgs_profile_end.restype = it
@@ -50,6 +52,16 @@ def _load() -> C.CDLL:
 
 _lib = _load()
 STAGES = ("preprocess_fwd", "scan", "scatter", "tile_sort", "render_fwd", "render_bwd", "preprocess_bwd")
+
+
+def selftest_reduce36(x: torch.Tensor) -> torch.Tensor:
+    """x[64,36] on the GPU -> [4,9] sums over the wave (checks the permlane-swap reduction on hardware)."""
+    x = x.contiguous().float()
+    out = torch.empty((4, 9), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        if _lib.tgs_selftest_reduce36(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), out.data_ptr()) < 0:
+            raise RuntimeError("selftest launch failed")
+    return out
 
 
 def profile_begin(max_records: int = 100000) -> None:
