@@ -1,0 +1,112 @@
+"""CPU: the host-side mirror of the reference interface (names, argument meaning, error behaviour)
+and the scene/camera helpers against fixtures recorded from the reference's own Python helpers."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import GOLDEN_DIR
+
+
+def test_settings_tuple_matches_reference_field_order():
+    from diff_gaussian_rasterization import GaussianRasterizationSettings
+    # diff_gaussian_rasterization/__init__.py:157-169
+    assert GaussianRasterizationSettings._fields == ("image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier",
+                                                     "viewmatrix", "projmatrix", "sh_degree", "campos", "prefiltered", "debug")
+
+
+def _rast():
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    rs = GaussianRasterizationSettings(16, 16, 1.0, 1.0, torch.zeros(3), 1.0, torch.eye(4), torch.eye(4), 0, torch.zeros(3), False, False)
+    return GaussianRasterizer(rs)
+
+
+def test_validation_messages_are_the_reference_ones():
+    r = _rast()
+    m, z, o = torch.zeros(4, 3), torch.zeros(4, 3), torch.zeros(4, 1)
+    with pytest.raises(Exception, match="Please provide excatly one of either SHs or precomputed colors!"):
+        r(m, z, o)
+    with pytest.raises(Exception, match="Please provide excatly one of either SHs or precomputed colors!"):
+        r(m, z, o, shs=torch.zeros(4, 1, 3), colors_precomp=torch.zeros(4, 3))
+    with pytest.raises(Exception, match="exactly one of either scale/rotation pair or precomputed 3D covariance"):
+        r(m, z, o, colors_precomp=torch.zeros(4, 3))
+    with pytest.raises(Exception, match="exactly one of either scale/rotation pair or precomputed 3D covariance"):
+        r(m, z, o, colors_precomp=torch.zeros(4, 3), scales=torch.ones(4, 3), rotations=torch.ones(4, 4), cov3D_precomp=torch.zeros(4, 6))
+    with pytest.raises(Exception, match="exactly one of either scale/rotation pair or precomputed 3D covariance"):
+        r(m, z, o, colors_precomp=torch.zeros(4, 3), scales=torch.ones(4, 3))
+
+
+def test_no_cpu_fallback_fails_loudly():
+    r = _rast()
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        r(torch.zeros(4, 3), torch.zeros(4, 3), torch.zeros(4, 1), colors_precomp=torch.zeros(4, 3), scales=torch.ones(4, 3), rotations=torch.ones(4, 4))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        r.markVisible(torch.zeros(4, 3))
+
+
+def test_means3d_shape_error_is_the_reference_one():
+    from diff_gaussian_rasterization import _C
+    e = torch.Tensor([])
+    with pytest.raises(RuntimeError, match=r"means3D must have dimensions \(num_points, 3\)"):
+        _C.rasterize_gaussians(torch.zeros(3), torch.zeros(4, 2), e, torch.zeros(4, 1), e, e, 1.0, e, torch.eye(4), torch.eye(4), 1.0, 1.0,
+                               16, 16, e, 0, torch.zeros(3), False, False)
+
+
+def test_import_surface():
+    import diff_gaussian_rasterization as dgr
+    assert hasattr(dgr, "GaussianRasterizationSettings") and hasattr(dgr, "GaussianRasterizer") and hasattr(dgr, "rasterize_gaussians")
+    for f in ("rasterize_gaussians", "rasterize_gaussians_backward", "mark_visible"):      # ext.cpp:15-19
+        assert hasattr(dgr._C, f)
+    assert os.path.exists(dgr._C.loaded_library())
+
+
+# ---- scene helpers vs the reference's own helpers (fixture made by tests/make_ref_utils_fixture.py) ----
+@pytest.fixture(scope="module")
+def ref_fix():
+    return np.load(os.path.join(GOLDEN_DIR, "ref_utils_fixture.npz"))
+
+
+def test_projection_matrix_matches_reference(ref_fix):
+    from youreditableavatar_amd import scenes
+    for args, out in zip(ref_fix["proj_args"], ref_fix["proj_out"]):
+        assert np.allclose(scenes.projection_matrix(*args), out, rtol=1e-6, atol=0)
+
+
+def test_world_to_view_matches_reference(ref_fix):
+    from youreditableavatar_amd import scenes
+    for R, t, out in zip(ref_fix["w2v_R"], ref_fix["w2v_t"], ref_fix["w2v_out"]):
+        assert np.allclose(scenes.world_to_view(R.astype(np.float32), t.astype(np.float32)), out, rtol=1e-6, atol=1e-7)
+
+
+def test_caller_side_sh_to_rgb_matches_reference_eval_sh(ref_fix):
+    from youreditableavatar_amd import scenes
+    sh, d = ref_fix["sh_coeffs"], ref_fix["sh_dirs"]
+    for deg in range(4):
+        ours = scenes.sh_to_rgb_numpy(sh, d, np.zeros(3, np.float32), deg)      # campos 0 => dirs = means / |means| = d
+        ref = np.maximum(ref_fix[f"sh_out_deg{deg}"] + 0.5, 0.0)               # tetgs_model.py:436-441
+        assert np.allclose(ours, ref, rtol=2e-5, atol=2e-6), deg
+
+
+def test_orbit_camera_geometry():
+    from youreditableavatar_amd import scenes
+    cam = scenes.orbit_camera(1920, 1080, azimuth_deg=33.0, elevation_deg=5.0, radius=3.0)
+    origin_h = np.array([0, 0, 0, 1], np.float32)
+    pv = origin_h @ cam.viewmatrix
+    assert abs(pv[0]) < 1e-5 and abs(pv[1]) < 1e-5 and abs(pv[2] - 3.0) < 1e-5       # look-at origin, depth = radius
+    ph = origin_h @ cam.projmatrix
+    assert abs(ph[0] / ph[3]) < 1e-5 and abs(ph[1] / ph[3]) < 1e-5                    # projects to the image centre
+    assert abs(cam.tanfovx / cam.tanfovy - 1920 / 1080) < 1e-6                       # square pixels
+    assert np.allclose(np.linalg.norm(cam.campos), 3.0, atol=1e-5)
+    # config table is BASELINE.json's
+    assert scenes.CONFIGS[3]["P"] == 500_000 and (scenes.CONFIGS[3]["width"], scenes.CONFIGS[3]["height"]) == (1920, 1080)
+    assert scenes.CONFIGS[5]["P"] == 2_000_000 and scenes.CONFIGS[4]["views"] == 64
+
+
+def test_cloud_is_deterministic():
+    from youreditableavatar_amd import scenes
+    a, b = scenes.make_cloud(1000, 3, seed=9), scenes.make_cloud(1000, 3, seed=9)
+    for k in ("means3D", "scales", "rotations", "opacities", "shs"):
+        assert np.array_equal(a[k], b[k])
+    assert a["shs"].shape == (1000, 16, 3) and a["opacities"].shape == (1000, 1)
+    assert np.allclose(np.linalg.norm(a["rotations"], axis=1), 1.0, atol=1e-5)

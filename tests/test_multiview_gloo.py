@@ -1,0 +1,113 @@
+"""CPU, world size 2 over gloo: the view-sharded data-parallel step (youreditableavatar_amd/multiview.py)
+gives every rank the gradient of the whole batch, equal to the unsharded sum of per-view gradients.
+The per-view renderer is the CPU oracle wrapped in an autograd.Function (test-only)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+class OracleRasterize(torch.autograd.Function):
+    """Test-only: the oracle as a differentiable per-view renderer on CPU tensors."""
+
+    @staticmethod
+    def forward(ctx, means3D, opacities, scales, rotations, shs, cam, deg):
+        from oracle import oracle
+        kw = dict(bg=cam.bg, means3D=means3D.detach().numpy(), viewmatrix=cam.viewmatrix, projmatrix=cam.projmatrix, campos=cam.campos,
+                  tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, shs=shs.detach().numpy(), scales=scales.detach().numpy(),
+                  rotations=rotations.detach().numpy())
+        color, radii, st = oracle.forward(opacities=opacities.detach().numpy(), image_height=cam.image_height, image_width=cam.image_width,
+                                          sh_degree=deg, **kw)
+        ctx.st, ctx.kw = st, kw
+        return torch.from_numpy(color)
+
+    @staticmethod
+    def backward(ctx, g):
+        from oracle import oracle
+        r = oracle.backward(ctx.st, g.contiguous().numpy(), **ctx.kw)
+        t = torch.from_numpy
+        return t(r["dL_dmeans3D"]), t(r["dL_dopacity"]), t(r["dL_dscales"]), t(r["dL_drotations"]), t(r["dL_dsh"]), None, None
+
+
+def _scene():
+    from youreditableavatar_amd import scenes
+    cloud = scenes.make_cloud(300, 1, seed=4, scale_mult=6.0)
+    cams = [scenes.orbit_camera(48, 32, azimuth_deg=k * 60.0) for k in range(5)]     # 5 views: uneven shards on 2 ranks
+    dLs = [scenes.upstream_gradient(48, 32, seed=100 + k) for k in range(5)]
+    return cloud, cams, dLs
+
+
+def _params(cloud):
+    return [torch.tensor(cloud[k], requires_grad=True) for k in ("means3D", "opacities", "scales", "rotations", "shs")]
+
+
+def _step(rank, world, port, out_q):
+    from youreditableavatar_amd import multiview
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "1"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cloud, cams, dLs = _scene()
+    params = _params(cloud)
+    grads = multiview.FlatGradients(params)
+    mine = multiview.render_batch_sharded(lambda v: OracleRasterize.apply(*params, cams[v], cloud["sh_degree"]),
+                                          lambda v, img: torch.from_numpy(dLs[v]), len(cams), grads)
+    out_q.put((rank, mine, grads.flat.clone().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+@pytest.mark.timeout(300)
+def test_sharded_step_equals_unsharded_sum():
+    from youreditableavatar_amd import multiview
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_step, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(2)], key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # single-process reference: sum over all views
+    cloud, cams, dLs = _scene()
+    params = _params(cloud)
+    grads = multiview.FlatGradients(params)
+    multiview.render_batch_sharded(lambda v: OracleRasterize.apply(*params, cams[v], cloud["sh_degree"]),
+                                   lambda v, img: torch.from_numpy(dLs[v]), len(cams), grads, rank=0, world_size=1)
+    ref = grads.flat.numpy()
+    assert res[0][1] == [0, 1, 2] and res[1][1] == [3, 4]                   # contiguous shards, sizes differ by at most one
+    for _rank, _mine, flat in res:
+        assert np.allclose(flat, ref, rtol=1e-5, atol=1e-9)
+    assert np.array_equal(res[0][2], res[1][2])                            # every rank holds the same reduced buffer
+    assert np.abs(ref).max() > 0
+
+
+def test_shard_views_partitions():
+    from youreditableavatar_amd.multiview import shard_views
+    for V, Wd in [(64, 8), (5, 2), (7, 8), (0, 4), (8, 8)]:
+        got = [v for r in range(Wd) for v in shard_views(V, r, Wd)]
+        assert got == list(range(V))
+        sizes = [len(shard_views(V, r, Wd)) for r in range(Wd)]
+        assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_views(4, 4, 4)
+
+
+def test_flat_gradients_are_views():
+    from youreditableavatar_amd.multiview import FlatGradients
+    a, b = torch.zeros(3, 2, requires_grad=True), torch.zeros(4, requires_grad=True)
+    fg = FlatGradients([a, b])
+    (a.sum() * 2 + (b * torch.arange(4.0)).sum()).backward()
+    assert fg.flat.tolist() == [2.0] * 6 + [0.0, 1.0, 2.0, 3.0]
+    assert a.grad.data_ptr() == fg.flat.data_ptr()
+    assert fg.all_reduce() is None          # no process group: no-op

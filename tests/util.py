@@ -22,7 +22,7 @@ def rel_l2(x, ref) -> float:
 
 
 def golden_names():
-    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "g[0-9]*.npz")))
 
 
 def load_golden(name: str):
