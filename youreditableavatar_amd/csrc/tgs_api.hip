@@ -288,6 +288,8 @@ int64_t tgs_state_field(void* stream, const char* field, int P, int width, int h
     else if (!strcmp(field, "conic_opacity")) { src = g.conic_opacity; count = 4 * (size_t)P; }
     else if (!strcmp(field, "rgb")) { if (!has_sh) return fail(TGS_ERR_INVALID, "rgb only exists on the SH path"); src = g.rgb; count = 3 * (size_t)P; }
     else if (!strcmp(field, "tiles_touched")) { src = g.tiles_touched; count = (size_t)P; }
+    else if (!strcmp(field, "tile_order")) { src = s.tile_order; count = T; }
+    else if (!strcmp(field, "stamps")) { src = s.stamps; count = 4 * T; esz = 8; }
     else if (!strcmp(field, "point_list")) { src = b.keys; count = (size_t)R; stride = 8; }   // low 32 bits of each sorted key
     else return fail(TGS_ERR_INVALID, "unknown field %s", field);
     if (dst_bytes < count * esz) return fail(TGS_ERR_INVALID, "dst too small for %s", field);

@@ -40,6 +40,7 @@ __global__ __launch_bounds__(256) void k_render_bwd(const ImgState s, const BinS
     const uint32_t n = rg.y - rg.x;
     if (n == 0) return;
     set_wave_priority(n);
+    stamp(s, tile, 2);
     const size_t pix_id = (size_t)W * py + px, N = (size_t)W * H;
     if (threadIdx.x == 0) { sA[RNULL] = make_float4(0.f, 0.f, 0.f, 0.f); sB[RNULL] = make_float4(0.f, 0.f, 0.f, 0.f); sC[RNULL] = 0.f; }
 
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(256) void k_render_bwd(const ImgState s, const BinS
         const uint32_t cnt = min((uint32_t)RCHUNK, qhi);
         __syncthreads();                                    // previous round's flush has read wacc / sSlot
         uint32_t qm = 0;
-        if (threadIdx.x < cnt) { sA[threadIdx.x] = ra; sB[threadIdx.x] = rb; sC[threadIdx.x] = rc.x; qm = __float_as_uint(rc.y); sSlot[threadIdx.x] = rs; }
+        if (threadIdx.x < cnt) { sA[threadIdx.x] = ra; sB[threadIdx.x] = rb; sC[threadIdx.x] = rc.x; qm = block_to_quadrant_mask(__float_as_uint(rc.y)); sSlot[threadIdx.x] = rs; }
         build_quad_lists(L, qm, wv, lane);
         if (lane < RCHUNK / 64) touched[wv][lane] = 0ull;
         __syncthreads();
@@ -175,6 +176,7 @@ __global__ __launch_bounds__(256) void k_render_bwd(const ImgState s, const BinS
             for (int k = 0; k < NACC; k++) row[k] = r[k];
         }
     }
+    stamp(s, tile, 3);
 }
 
 // ---------------------------------------------------------------------------------------------

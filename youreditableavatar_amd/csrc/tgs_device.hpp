@@ -45,6 +45,7 @@ struct ImgState {
     uint32_t* tile_order;     // tiles by descending list length: render kernels start the long lists first
     float* final_T;           //                                    (imgState.accum_alpha)
     uint32_t* n_contrib;      //                                    (imgState.n_contrib)
+    unsigned long long* stamps; // diagnostic builds (-DTGS_STAMPS=1): per tile {fwd start, fwd end, bwd start, bwd end}, 100 MHz ticks
 };
 struct BinState {
     unsigned long long* keys; // (depth bits << 32 | gaussian idx), per tile segment, sorted after k_tile_sort
@@ -78,6 +79,7 @@ __host__ __device__ inline size_t img_carve(ImgState& s, char* base, size_t N, s
     char* p = base;
     carve(p, s.meta, 1); carve(p, s.ranges, T); carve(p, s.tile_count, T); carve(p, s.cursor, T);
     carve(p, s.ovf_tiles, T); carve(p, s.tile_order, T); carve(p, s.final_T, N); carve(p, s.n_contrib, N);
+    carve(p, s.stamps, 4 * T);
     return (size_t)(p - base) + 256;
 }
 __host__ __device__ inline size_t bin_carve(BinState& b, char* base, size_t R)
@@ -194,6 +196,48 @@ __device__ __forceinline__ void build_quad_lists(QuadLists& L, uint32_t qm, int 
         if (lane < RUNROLL) L.idx[q][wv][n + lane] = (unsigned short)RNULL;
         if (lane == 0) L.cnt[q][wv] = n;
     }
+}
+
+// 16-block variant (4x4 blocks of 4x4 pixels): one compute wave per block, staged by STG staging waves
+template <int STG>
+struct alignas(16) BlockLists {
+    unsigned short idx[16][STG][QL_STRIDE];   // [block][staging wave][k]
+    uint32_t cnt[16][STG];
+};
+template <int STG>
+__device__ __forceinline__ void build_block_lists(BlockLists<STG>& L, uint32_t bm, int sw, int lane)
+{
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const bool on = (bm >> q) & 1u;
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(on);
+        const uint32_t n = (uint32_t)__builtin_popcountll(bal);
+        const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        if (on) L.idx[q][sw][pos] = (unsigned short)threadIdx.x;
+        if (lane < RUNROLL) L.idx[q][sw][n + lane] = (unsigned short)RNULL;
+        if (lane == 0) L.cnt[q][sw] = n;
+    }
+}
+// 16-bit block mask -> 4-bit quadrant mask (quadrant q: bit0 = right half, bit1 = lower half)
+__device__ __forceinline__ uint32_t block_to_quadrant_mask(uint32_t m)
+{
+    return ((m & 0x0033u) ? 1u : 0u) | ((m & 0x00CCu) ? 2u : 0u) | ((m & 0x3300u) ? 4u : 0u) | ((m & 0xCC00u) ? 8u : 0u);
+}
+// value of lane (quad base + E) broadcast to the 4 lanes of each quad
+template <int E>
+__device__ __forceinline__ float quad_bcast(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), E * 0x55, 0xf, 0xf, false));
+}
+
+#ifndef TGS_STAMPS
+#define TGS_STAMPS 0
+#endif
+__device__ __forceinline__ void stamp(const ImgState& s, uint32_t tile, int which)
+{
+#if TGS_STAMPS
+    if (threadIdx.x == 0) s.stamps[4 * (size_t)tile + which] = wall_clock64();
+#endif
 }
 
 #ifndef TGS_FAST_MATH

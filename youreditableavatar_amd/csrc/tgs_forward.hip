@@ -300,12 +300,12 @@ __device__ __forceinline__ void cmp_swap(KeyPtr keys, uint32_t i, uint32_t l, ui
     }
 }
 
-// Conservative 4-bit mask of the tile's 8x8 pixel quadrants that a splat can reach with alpha >= 1/255:
-// alpha = o*exp(power) >= 1/255  <=>  power >= -tau, tau = ln(255 o); the level set 1/2 d^T Q d <= tau of the
-// conic Q = [[A,B],[B,C]] has the bounding box |dx| <= sqrt(2 tau C/det Q), |dy| <= sqrt(2 tau A/det Q).
-// The exact per-pixel tests of forward.cu:336-343 stay in the render kernels, so a conservative mask only
-// removes work, never a contribution.  Comparisons are written so that NaNs keep every quadrant.
-__device__ __forceinline__ uint32_t quadrant_mask(float2 xy, float4 co, uint32_t tx, uint32_t ty)
+// Conservative 16-bit mask of the tile's 4x4 blocks of 4x4 pixels (bit by*4+bx) that a splat can reach with
+// alpha >= 1/255:  alpha = o*exp(power) >= 1/255  <=>  power >= -tau, tau = ln(255 o); the level set
+// 1/2 d^T Q d <= tau of the conic Q = [[A,B],[B,C]] has the bounding box |dx| <= sqrt(2 tau C/det Q),
+// |dy| <= sqrt(2 tau A/det Q).  The exact per-pixel tests of forward.cu:336-343 stay in the render kernels,
+// so a conservative mask only removes work, never a contribution.  NaNs keep every block.
+__device__ __forceinline__ uint32_t block_mask(float2 xy, float4 co, uint32_t tx, uint32_t ty)
 {
     const float o255 = 255.0f * co.w;
     if (o255 < 0.999f) return 0u;                       // alpha <= o < 1/255 for every pixel (G <= 1)
@@ -317,13 +317,16 @@ __device__ __forceinline__ uint32_t quadrant_mask(float2 xy, float4 co, uint32_t
         hy = sqrtf(2.f * tau * co.x / det) * 1.001f + 0.01f;
     }
     const float x0 = (float)(tx * TILE), y0 = (float)(ty * TILE);
+    uint32_t mx = 0, my = 0;                            // 4-bit column / row masks; the box test is separable
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float lo_x = x0 + (float)(4 * k), lo_y = y0 + (float)(4 * k);
+        if (!((xy.x + hx < lo_x) || (xy.x - hx > lo_x + 3.f))) mx |= 1u << k;
+        if (!((xy.y + hy < lo_y) || (xy.y - hy > lo_y + 3.f))) my |= 1u << k;
+    }
     uint32_t m = 0;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const float qx = x0 + (float)((q & 1) * 8), qy = y0 + (float)((q >> 1) * 8);
-        const bool out = (xy.x + hx < qx) || (xy.x - hx > qx + 7.f) || (xy.y + hy < qy) || (xy.y - hy > qy + 7.f);
-        if (!out) m |= 1u << q;
-    }
+    for (int r = 0; r < 4; r++) if ((my >> r) & 1u) m |= mx << (4 * r);
     return m;
 }
 
@@ -340,7 +343,7 @@ __device__ __forceinline__ void finalize_entry(unsigned long long key, uint32_t 
     const uint32_t tx = tile % gx, ty = tile / gx;
     b.recA[pos] = make_float4(xy.x, xy.y, co.x, co.y);
     b.recB[pos] = make_float4(co.z, co.w, cr, cg);
-    b.recC[pos] = make_float2(cb, __uint_as_float(quadrant_mask(xy, co, tx, ty)));
+    b.recC[pos] = make_float2(cb, __uint_as_float(block_mask(xy, co, tx, ty)));
     b.slot[pos] = g.offsets[id] + (ty - r.y) * ((uint32_t)r.z - r.x) + (tx - r.x);
 }
 
@@ -432,87 +435,108 @@ __global__ __launch_bounds__(256) void k_ovf_finalize(const GeomState g, const I
 // quadrant so that a wave's 64 pixels are spatially compact (whole-wave skips of small splats).
 // The tile's records are staged through LDS in rounds of 256 and read back as broadcasts.
 // ---------------------------------------------------------------------------------------------
-// The critical path of this kernel is the longest tile list times the per-entry latency of ONE wave
-// (work per tile is tiny against the chip, lists are long), so tiles are visited longest-first, long
-// lists run at raised wave priority, and the inner loop is written for instruction-level parallelism:
-// 4 entries' LDS reads, power and exp are issued together, only the transmittance chain is sequential,
-// and it is branch-free.
-__global__ __launch_bounds__(256) void k_render_fwd(const ImgState s, const BinState b, int W, int H, uint32_t gx,
-                                                    const float* __restrict__ bg, float* __restrict__ out_color)
+// k_render_fwd: one 16x16 tile per 1024-thread workgroup = 16 waves, one wave per 4x4-pixel block.
+// Inside a wave the 64 lanes are 16 pixels x 4 CONSECUTIVE list entries: every lane evaluates one
+// (pixel, entry) pair -- conic power, exp, alpha -- and the four lanes of a quad then walk the
+// transmittance chain of their pixel together (DPP quad broadcasts of 1-alpha), so one pass of the
+// loop retires four entries of the front-to-back order with the sequential semantics of
+// forward.cu:325-362 intact (T is multiplied in list order; the first entry that would push T below
+// 1e-4 stops the pixel and is not blended).
+// Why: the kernel's duration is the longest tile list times the per-entry latency of the waves that
+// own it (work per tile is tiny against the chip), so a tile is spread over 16 waves, long lists are
+// visited first (tile_order) at raised priority, and the per-entry dependent chain is 1/4 as long.
+constexpr int FWD_THREADS = 1024;
+constexpr int FWD_STG = RCHUNK / 64;       // staging waves per round
+
+__global__ __launch_bounds__(FWD_THREADS) void k_render_fwd(const ImgState s, const BinState b, int W, int H, uint32_t gx,
+                                                            const float* __restrict__ bg, float* __restrict__ out_color)
 {
     __shared__ float4 sA[RCHUNK + 1];
     __shared__ float4 sB[RCHUNK + 1];
     __shared__ float sC[RCHUNK + 1];
-    __shared__ QuadLists L;
+    __shared__ BlockLists<FWD_STG> L;
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     const uint32_t tile = s.tile_order[blockIdx.x];
     const uint32_t tx = tile % gx, ty = tile / gx;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int px = tx * TILE + (wv & 1) * 8 + (lane & 7);
-    const int py = ty * TILE + (wv >> 1) * 8 + (lane >> 3);
+    const int pp = lane >> 2, e = lane & 3;                // pixel of the block, entry slot of the group
+    const int px = tx * TILE + (wv & 3) * 4 + (pp & 3);
+    const int py = ty * TILE + (wv >> 2) * 4 + (pp >> 2);
     const bool inside = px < W && py < H;
     const float pixfx = (float)px, pixfy = (float)py;
     const uint2 rg = s.ranges[tile];
     set_wave_priority(rg.y - rg.x);
-    bool done = !inside;
-    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
+    stamp(s, tile, 0);
+    bool done = !inside;                                   // per pixel; identical in the 4 lanes of a quad
+    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;          // C: this lane's share (entries of slot e)
     uint32_t last_contributor = 0;
     if (threadIdx.x == 0) { sA[RNULL] = make_float4(0.f, 0.f, 0.f, 0.f); sB[RNULL] = make_float4(0.f, 0.f, 0.f, 0.f); sC[RNULL] = 0.f; }
 
     // register-staged prefetch of the next round (global loads stay in flight under the compute)
     float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
     float2 rc = make_float2(0.f, 0.f);
-    if (rg.x + threadIdx.x < rg.y) { ra = b.recA[rg.x + threadIdx.x]; rb = b.recB[rg.x + threadIdx.x]; rc = b.recC[rg.x + threadIdx.x]; }
+    if (threadIdx.x < RCHUNK && rg.x + threadIdx.x < rg.y) { ra = b.recA[rg.x + threadIdx.x]; rb = b.recB[rg.x + threadIdx.x]; rc = b.recC[rg.x + threadIdx.x]; }
 
     for (uint32_t base = rg.x; base < rg.y; base += RCHUNK) {
         if (__syncthreads_and(done)) break;                     // forward.cu:307-310
         const uint32_t cnt = min((uint32_t)RCHUNK, rg.y - base);
-        uint32_t qm = 0;
-        if (threadIdx.x < cnt) { sA[threadIdx.x] = ra; sB[threadIdx.x] = rb; sC[threadIdx.x] = rc.x; qm = __float_as_uint(rc.y); }
-        build_quad_lists(L, qm, wv, lane);
+        if (wv < FWD_STG) {
+            uint32_t bm = 0;
+            if (threadIdx.x < cnt) { sA[threadIdx.x] = ra; sB[threadIdx.x] = rb; sC[threadIdx.x] = rc.x; bm = __float_as_uint(rc.y); }
+            build_block_lists(L, bm, wv, lane);
+        }
         __syncthreads();
-        {
+        if (threadIdx.x < RCHUNK) {
             const uint32_t nxt = base + RCHUNK + threadIdx.x;
             if (nxt < rg.y) { ra = b.recA[nxt]; rb = b.recB[nxt]; rc = b.recC[nxt]; }
         }
-        bool wave_live = __builtin_amdgcn_ballot_w64(!done) != 0;   // else this wave's 64 pixels are finished
+        bool wave_live = __builtin_amdgcn_ballot_w64(!done) != 0;   // else this wave's 16 pixels are finished
         const uint32_t cbase = base - rg.x + 1;
 #pragma unroll 1
-        for (int sw = 0; wave_live && sw < 4; sw++) {
+        for (int sw = 0; wave_live && sw < FWD_STG; sw++) {
             const uint32_t n = __builtin_amdgcn_readfirstlane(L.cnt[wv][sw]);
 #pragma unroll 1
-            for (uint32_t k = 0; k < n; k += RUNROLL) {         // forward.cu:325-362, only entries that can reach this quadrant
-                const uint2 pk = *reinterpret_cast<const uint2*>(&L.idx[wv][sw][k]);
-                const uint32_t j[RUNROLL] = {pk.x & 0xffffu, pk.x >> 16, pk.y & 0xffffu, pk.y >> 16};
-                float4 a[RUNROLL], bb[RUNROLL];
-                float cc[RUNROLL], power[RUNROLL], alpha[RUNROLL];
-#pragma unroll
-                for (int u = 0; u < RUNROLL; u++) { a[u] = sA[j[u]]; bb[u] = sB[j[u]]; cc[u] = sC[j[u]]; }
-#pragma unroll
-                for (int u = 0; u < RUNROLL; u++) {
-                    const float dx = a[u].x - pixfx, dy = a[u].y - pixfy;
-                    power[u] = -0.5f * (a[u].z * dx * dx + bb[u].x * dy * dy) - a[u].w * dx * dy;
-                    alpha[u] = fminf(0.99f, bb[u].y * tgs_exp(power[u]));
-                }
-                bool any_stop = false;
-#pragma unroll
-                for (int u = 0; u < RUNROLL; u++) {
-                    const float test_T = T * (1.f - alpha[u]);
-                    const bool live = !done && !(power[u] > 0.0f) && !(alpha[u] < 1.0f / 255.0f);
-                    const bool stop = live && (test_T < 0.0001f);
-                    const bool upd = live && !stop;
-                    const float w = upd ? alpha[u] * T : 0.f;
-                    C0 += bb[u].z * w; C1 += bb[u].w * w; C2 += cc[u] * w;
-                    T = upd ? test_T : T;
-                    last_contributor = upd ? cbase + j[u] : last_contributor;
-                    done = done || stop;
-                    any_stop = any_stop || stop;
-                }
-                if (__builtin_amdgcn_ballot_w64(any_stop) != 0 && __builtin_amdgcn_ballot_w64(!done) == 0) { wave_live = false; break; }
+            for (uint32_t k = 0; k < n; k += 4) {               // 4 list entries per pass, only those that can reach this block
+                const uint32_t j = L.idx[wv][sw][k + e];
+                const float4 a = sA[j];
+                const float4 bb = sB[j];
+                const float cc = sC[j];
+                const float dx = a.x - pixfx, dy = a.y - pixfy;
+                const float power = -0.5f * (a.z * dx * dx + bb.x * dy * dy) - a.w * dx * dy;
+                const float alpha = fminf(0.99f, bb.y * tgs_exp(power));
+                const bool live = !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+                const float pown = live ? 1.f - alpha : 1.0f;   // a skipped entry leaves T alone
+                // the pixel's transmittance chain over the group's 4 entries, in list order (all 4 lanes of the quad agree)
+                bool alive = !done;
+                const float t0 = T;
+                const float x0 = t0 * quad_bcast<0>(pown); const bool ok0 = alive && !(x0 < 0.0001f); const float t1 = ok0 ? x0 : t0; alive = ok0;
+                const float x1 = t1 * quad_bcast<1>(pown); const bool ok1 = alive && !(x1 < 0.0001f); const float t2 = ok1 ? x1 : t1; alive = ok1;
+                const float x2 = t2 * quad_bcast<2>(pown); const bool ok2 = alive && !(x2 < 0.0001f); const float t3 = ok2 ? x2 : t2; alive = ok2;
+                const float x3 = t3 * quad_bcast<3>(pown); const bool ok3 = alive && !(x3 < 0.0001f); const float t4 = ok3 ? x3 : t3; alive = ok3;
+                const float Tb = e == 0 ? t0 : e == 1 ? t1 : e == 2 ? t2 : t3;
+                const bool okown = e == 0 ? ok0 : e == 1 ? ok1 : e == 2 ? ok2 : ok3;
+                const bool upd = live && okown;
+                const float w = upd ? alpha * Tb : 0.f;
+                C0 += bb.z * w; C1 += bb.w * w; C2 += cc * w;
+                last_contributor = upd ? cbase + j : last_contributor;
+                T = t4;
+                const bool newly_done = !alive && !done;
+                done = !alive;
+                if (__builtin_amdgcn_ballot_w64(newly_done) != 0 && __builtin_amdgcn_ballot_w64(!done) == 0) { wave_live = false; break; }
             }
         }
     }
-    if (inside) {
+    // the 4 lanes of a quad hold the pixel's colour in shares and the candidates for its last contributor
+    TGS_DPP_ADD(C0, 0xB1, 0xf); TGS_DPP_ADD(C0, 0x4E, 0xf);
+    TGS_DPP_ADD(C1, 0xB1, 0xf); TGS_DPP_ADD(C1, 0x4E, 0xf);
+    TGS_DPP_ADD(C2, 0xB1, 0xf); TGS_DPP_ADD(C2, 0x4E, 0xf);
+    {
+        uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)last_contributor, 0xB1, 0xf, 0xf, false);
+        last_contributor = max(last_contributor, o);
+        o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)last_contributor, 0x4E, 0xf, 0xf, false);
+        last_contributor = max(last_contributor, o);
+    }
+    if (inside && e == 0) {
         const size_t pix_id = (size_t)W * py + px, N = (size_t)W * H;
         s.final_T[pix_id] = T;
         s.n_contrib[pix_id] = last_contributor;
@@ -520,6 +544,7 @@ __global__ __launch_bounds__(256) void k_render_fwd(const ImgState s, const BinS
         out_color[N + pix_id] = C1 + T * bg1;
         out_color[2 * N + pix_id] = C2 + T * bg2;
     }
+    stamp(s, tile, 1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -575,7 +600,7 @@ void launch_tile_sort(hipStream_t st, const GeomState& g, const ImgState& s, con
 }
 void launch_render_fwd(hipStream_t st, const ImgState& s, const BinState& b, int W, int H, uint32_t gx, uint32_t T, const float* bg, float* out_color)
 {
-    hipLaunchKernelGGL(k_render_fwd, dim3(T), dim3(256), 0, st, s, b, W, H, gx, bg, out_color);
+    hipLaunchKernelGGL(k_render_fwd, dim3(T), dim3(FWD_THREADS), 0, st, s, b, W, H, gx, bg, out_color);
 }
 void launch_mark_visible(hipStream_t st, int P, const float* means3D, const float* view, uint8_t* present)
 {
