@@ -103,6 +103,11 @@ enum {
 int tgs_profile_begin(int max_records);
 int tgs_profile_end(double* ms_sum, int64_t* counts);
 
+/* Process-wide switch for the backward render kernel: 1 = fixed summation order inside a tile (gradients
+ * bitwise reproducible run to run, about 2.5x slower in that kernel), 0 = LDS float atomics inside a tile
+ * (default), -1 = follow the environment variable TGS_DETERMINISTIC.  Neither mode uses global atomics. */
+void tgs_set_deterministic(int on);
+
 /* Hardware self-test of the wave-level 36-value reduction used by the backward render kernel:
  * in[64][36] (one row per lane) -> out[4][9], out[e][k] = sum over lanes of in[lane][e*9+k]. */
 int tgs_selftest_reduce36(void* stream, const float* in, float* out);

@@ -51,16 +51,35 @@ def test_vs_oracle_seeded(P, W, H, deg, mode, cov_mode, scale_mult, gpu_device):
 
 
 def test_backward_is_bitwise_reproducible(gpu_device):
-    """No float atomics anywhere: two runs give identical bits (the reference's do not)."""
+    """Deterministic mode: no float atomics anywhere, two runs give identical bits (the reference's do not)."""
     from youreditableavatar_amd import scenes
+    from diff_gaussian_rasterization import _C
+    _C.set_deterministic(True)
     cloud = scenes.make_cloud(20_000, 3, seed=3, scale_mult=3.0)
     cam = scenes.orbit_camera(256, 192)
     inp = util.scene_input(cloud, cam)
     dL = scenes.upstream_gradient(256, 192)
     a = util.hip_run(inp, dL, introspect=False)
     b = util.hip_run(inp, dL, introspect=False)
+    _C.set_deterministic(False)
+    c = util.hip_run(inp, dL, introspect=False)
     for k in ("color",) + util.GRAD_KEYS:
         assert np.array_equal(a[k], b[k]), k
+        assert util.rel_l2(c[k], a[k]) <= 1e-5, k          # the default (LDS-atomic) kernel agrees with it
+
+
+@pytest.mark.parametrize("name", ["g01_sh3_scale_rot", "g08_opaque_termination", "g09_giant_splat", "g13_dense_2k"])
+def test_golden_deterministic_kernel(name, gpu_device):
+    from diff_gaussian_rasterization import _C
+    inp, gold = util.load_golden(name)
+    _C.set_deterministic(True)
+    try:
+        mine = util.hip_run(inp, inp["dL_dout_color"])
+    finally:
+        _C.set_deterministic(False)
+    ref = dict(gold)
+    ref["n_contrib"] = gold["n_contrib"].reshape(int(inp["image_height"]), int(inp["image_width"]))
+    util.compare(mine, ref, gold)
 
 
 def test_wave_reduce36_on_hardware(gpu_device):

@@ -13,9 +13,11 @@ void launch_scan(hipStream_t, const GeomState&, const ImgState&, uint32_t nblock
 void launch_scatter(hipStream_t, int P, const GeomState&, const ImgState&, const BinState&, uint32_t gx);
 void launch_tile_sort(hipStream_t, const GeomState&, const ImgState&, const BinState&, const float* colors, uint32_t gx, uint32_t T,
                       uint32_t max_count, uint32_t n_overflow);
-void launch_render_fwd(hipStream_t, const ImgState&, const BinState&, int W, int H, uint32_t gx, uint32_t T, const float* bg, float* out_color);
+void launch_render_fwd(hipStream_t, const ImgState&, const BinState&, int W, int H, uint32_t gx, uint32_t T, uint32_t n_nonempty, const float* bg,
+                       float* out_color);
 void launch_mark_visible(hipStream_t, int P, const float* means3D, const float* view, uint8_t* present);
-void launch_render_bwd(hipStream_t, const ImgState&, const BinState&, int W, int H, uint32_t gx, uint32_t T, const float* bg, const float* dL_dpix);
+void launch_render_bwd(hipStream_t, const ImgState&, const BinState&, int W, int H, uint32_t gx, uint32_t T, const float* bg, const float* dL_dpix,
+                       bool deterministic);
 void launch_preprocess_bwd(hipStream_t, const BwdIn&, const CamParams&, const GeomState&, const BinState&);
 void launch_selftest_reduce36(hipStream_t, const float* in, float* out);
 }  // namespace tgs
@@ -23,6 +25,18 @@ void launch_selftest_reduce36(hipStream_t, const float* in, float* out);
 using namespace tgs;
 
 static thread_local char g_err[512] = "";
+
+#include <atomic>
+#include <cstdlib>
+// -1: not set by the API -> environment variable TGS_DETERMINISTIC decides (default 0)
+static std::atomic<int> g_deterministic{-1};
+static bool deterministic_mode()
+{
+    const int v = g_deterministic.load(std::memory_order_relaxed);
+    if (v >= 0) return v != 0;
+    const char* e = getenv("TGS_DETERMINISTIC");
+    return e && e[0] && e[0] != '0';
+}
 
 // ---- optional per-stage timing (bench only): hipEvents recorded on the caller's stream, no sync ----
 #include <mutex>
@@ -98,6 +112,8 @@ static CamParams make_cam(const float* view, const float* proj, const float* cam
 extern "C" {
 
 int tgs_abi_version(void) { return TGS_ABI_VERSION; }
+
+void tgs_set_deterministic(int on) { g_deterministic.store(on < 0 ? -1 : (on ? 1 : 0), std::memory_order_relaxed); }
 
 int tgs_selftest_reduce36(void* stream, const float* in, float* out)
 {
@@ -209,7 +225,7 @@ int64_t tgs_forward(tgs_alloc_fn alloc, void* alloc_ctx, void* stream, int P, in
         STAGE_CHECK("tile_sort", TGS_STAGE_TILE_SORT);
     }
     STAGE_BEGIN();
-    launch_render_fwd(st, s, b, width, height, cam.gx, (uint32_t)T, background, out_color);
+    launch_render_fwd(st, s, b, width, height, cam.gx, (uint32_t)T, meta.n_nonempty, background, out_color);
     STAGE_CHECK("render", TGS_STAGE_RENDER_FWD);
     return (int64_t)R;
 }
@@ -246,7 +262,7 @@ int tgs_backward(void* stream, int P, int D, int M, int64_t R, const float* back
 
     if (R > 0) {
         STAGE_BEGIN();
-        launch_render_bwd(st, s, b, width, height, cam.gx, (uint32_t)T, background, dL_dpix);
+        launch_render_bwd(st, s, b, width, height, cam.gx, (uint32_t)T, background, dL_dpix, deterministic_mode());
         STAGE_CHECK("render_bwd", TGS_STAGE_RENDER_BWD);
     }
     STAGE_BEGIN();

@@ -17,7 +17,7 @@ namespace tgs {
 
 constexpr int NACC = 9;        // colour rgb, mean2D xy, conic xx/xy/yy, opacity
 
-__global__ __launch_bounds__(256) void k_render_bwd(const ImgState s, const BinState b, int W, int H, uint32_t gx,
+__global__ __launch_bounds__(256) void k_render_bwd_det(const ImgState s, const BinState b, int W, int H, uint32_t gx,
                                                     const float* __restrict__ bg, const float* __restrict__ dL_dpix)
 {
     __shared__ float4 sA[RCHUNK + 1];
@@ -174,6 +174,175 @@ __global__ __launch_bounds__(256) void k_render_bwd(const ImgState s, const BinS
             float* row = b.slab + (size_t)sSlot[j] * NACC;
 #pragma unroll
             for (int k = 0; k < NACC; k++) row[k] = r[k];
+        }
+    }
+    stamp(s, tile, 3);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_render_bwd (default): same geometry as k_render_fwd -- 16 waves per tile, one wave per 4x4-pixel
+// block, 64 lanes = 16 pixels x 4 consecutive list entries (back to front).  Every lane evaluates its
+// own (pixel, entry) pair; the 4 lanes of a quad walk the pixel's sequential state (T, accum_rec,
+// last_alpha, last_color of backward.cu:505-531) through the group's 4 entries with DPP quad
+// broadcasts and each lane keeps the state of its own step; a skipped entry is walked as alpha = 0,
+// which leaves T and every later accum_rec value bit-identical to not visiting it
+// (acc' = la*lc + (1-la)*acc, (la,lc) <- (0,c);  next: 0*c + 1*acc' = acc').
+// The nine per-entry sums over the block's 16 pixels are formed with DPP row rotations and
+// v_permlane16/32_swap (34 operations per 4 entries), then added to the tile's per-round accumulator
+// in LDS with ds_add_f32: up to 16 waves add to one entry, so the in-tile summation order -- and the
+// last bit of a gradient -- can vary run to run.  k_render_bwd_det above keeps a fixed order
+// (bitwise reproducible) at about 2.5x the time; tgs_set_deterministic(1) selects it.
+// ---------------------------------------------------------------------------------------------
+constexpr int BWD_THREADS = 1024;
+constexpr int BCH = 256;                   // list entries per round
+constexpr int BWD_STG = BCH / 64;
+constexpr int BNULL = BCH;
+
+__global__ __launch_bounds__(BWD_THREADS) void k_render_bwd(const ImgState s, const BinState b, int W, int H, uint32_t gx,
+                                                            const float* __restrict__ bg, const float* __restrict__ dL_dpix)
+{
+    __shared__ float4 sA[BCH + 1];
+    __shared__ float4 sB[BCH + 1];
+    __shared__ float sC[BCH + 1];
+    __shared__ uint32_t sSlot[BCH];
+    __shared__ float acc[NACC][BCH + 1];                   // per-round sums; column BNULL swallows the padding entries
+    __shared__ BlockLists<BWD_STG> L;
+    __shared__ uint32_t wmax[16];
+
+    const uint32_t tile = s.tile_order[blockIdx.x];
+    const uint32_t tx = tile % gx, ty = tile / gx;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int pp = lane >> 2, e = lane & 3;
+    const int px = tx * TILE + (wv & 3) * 4 + (pp & 3);
+    const int py = ty * TILE + (wv >> 2) * 4 + (pp >> 2);
+    const bool inside = px < W && py < H;
+    const float pixfx = (float)px, pixfy = (float)py;
+    const uint2 rg = s.ranges[tile];
+    const uint32_t n = rg.y - rg.x;
+    if (n == 0) return;
+    set_wave_priority(n);
+    stamp(s, tile, 2);
+    const size_t pix_id = (size_t)W * py + px, N = (size_t)W * H;
+    if (threadIdx.x == 0) { sA[BNULL] = make_float4(0.f, 0.f, 0.f, 0.f); sB[BNULL] = make_float4(0.f, 0.f, 0.f, 0.f); sC[BNULL] = 0.f; }
+
+    const float T_final = inside ? s.final_T[pix_id] : 0.f;
+    float T = T_final;
+    const uint32_t last_contributor = inside ? s.n_contrib[pix_id] : 0u;
+    float dpx0 = 0.f, dpx1 = 0.f, dpx2 = 0.f;
+    if (inside) { dpx0 = dL_dpix[pix_id]; dpx1 = dL_dpix[N + pix_id]; dpx2 = dL_dpix[2 * N + pix_id]; }
+    float bg_dot_dpixel = 0.f;                              // backward.cu:533-535
+    bg_dot_dpixel += bg[0] * dpx0; bg_dot_dpixel += bg[1] * dpx1; bg_dot_dpixel += bg[2] * dpx2;
+    float ar0 = 0.f, ar1 = 0.f, ar2 = 0.f;                  // accum_rec
+    float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
+    const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);   // backward.cu:460-461
+
+    uint32_t mq = wave_max_u32(last_contributor);
+    if (lane == 0) wmax[wv] = mq;
+    __syncthreads();
+    uint32_t qmax = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) qmax = max(qmax, wmax[i]);
+
+    // rows of the never-visited tail are zero
+    for (uint32_t q = qmax + threadIdx.x; q < n; q += BWD_THREADS) {
+        float* row = b.slab + (size_t)b.slot[rg.x + q] * NACC;
+#pragma unroll
+        for (int k = 0; k < NACC; k++) row[k] = 0.f;
+    }
+
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
+    float2 rc = make_float2(0.f, 0.f);
+    uint32_t rs = 0;
+    if (threadIdx.x < BCH && threadIdx.x < qmax) { const uint32_t pos = rg.x + qmax - 1 - threadIdx.x; ra = b.recA[pos]; rb = b.recB[pos]; rc = b.recC[pos]; rs = b.slot[pos]; }
+
+    for (uint32_t qhi = qmax; qhi > 0; qhi = qhi > BCH ? qhi - BCH : 0) {
+        const uint32_t cnt = min((uint32_t)BCH, qhi);
+        __syncthreads();                                    // previous round's flush has read acc / sSlot
+        if (wv < BWD_STG) {
+            uint32_t bm = 0;
+            if (threadIdx.x < cnt) { sA[threadIdx.x] = ra; sB[threadIdx.x] = rb; sC[threadIdx.x] = rc.x; bm = __float_as_uint(rc.y); sSlot[threadIdx.x] = rs; }
+            if (wv * 64u < cnt) build_block_lists(L, bm, wv, lane, BNULL);
+        }
+        for (uint32_t i = threadIdx.x; i < NACC * (BCH + 1); i += BWD_THREADS) (&acc[0][0])[i] = 0.f;
+        __syncthreads();
+        if (threadIdx.x < BCH && qhi > BCH && threadIdx.x < qhi - BCH) {
+            const uint32_t pos = rg.x + qhi - BCH - 1 - threadIdx.x;
+            ra = b.recA[pos]; rb = b.recB[pos]; rc = b.recC[pos]; rs = b.slot[pos];
+        }
+        const int nsw = (int)((cnt + 63) >> 6);
+#pragma unroll 1
+        for (int sw = 0; sw < nsw; sw++) {
+            const uint32_t nl = __builtin_amdgcn_readfirstlane(L.cnt[wv][sw]);
+#pragma unroll 1
+            for (uint32_t k = 0; k < nl; k += 4) {
+                const uint32_t j = L.idx[wv][sw][k + e];
+                const float4 a = sA[j];
+                const float4 bb = sB[j];
+                const float c0 = bb.z, c1 = bb.w, c2 = sC[j];
+                const float dx = a.x - pixfx, dy = a.y - pixfy;
+                const float power = -0.5f * (a.z * dx * dx + bb.x * dy * dy) - a.w * dx * dy;
+                const float G = tgs_exp(power);
+                const float alpha = fminf(0.99f, bb.y * G);
+                // list position of slot j is qhi-1-j; "contributor >= last_contributor" skip of backward.cu:487
+                const bool valid = (qhi - 1 - j < last_contributor) && (j < cnt) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+                if (__builtin_amdgcn_ballot_w64(valid) == 0) continue;
+                const float aeff = valid ? alpha : 0.f;
+                // walk the pixel's sequential state through the 4 entries (processing order = slot order)
+                float Town = 0.f, a0own = 0.f, a1own = 0.f, a2own = 0.f;
+#define TGS_BWD_STEP(E)                                                                                        \
+                {                                                                                              \
+                    const float ae = quad_bcast<E>(aeff);                                                      \
+                    const float e0 = quad_bcast<E>(c0), e1 = quad_bcast<E>(c1), e2 = quad_bcast<E>(c2);         \
+                    T = tgs_div(T, 1.f - ae);                                                                  \
+                    const float om = 1.f - last_alpha;                                                         \
+                    ar0 = last_alpha * lc0 + om * ar0; ar1 = last_alpha * lc1 + om * ar1; ar2 = last_alpha * lc2 + om * ar2; \
+                    lc0 = e0; lc1 = e1; lc2 = e2; last_alpha = ae;                                             \
+                    if (e == E) { Town = T; a0own = ar0; a1own = ar1; a2own = ar2; }                           \
+                }
+                TGS_BWD_STEP(0) TGS_BWD_STEP(1) TGS_BWD_STEP(2) TGS_BWD_STEP(3)
+#undef TGS_BWD_STEP
+                // this lane's (pixel, entry) gradient terms, backward.cu:507-555
+                const float dchannel_dcolor = alpha * Town;
+                float dL_dalpha = 0.0f;
+                dL_dalpha += (c0 - a0own) * dpx0; dL_dalpha += (c1 - a1own) * dpx1; dL_dalpha += (c2 - a2own) * dpx2;
+                dL_dalpha *= Town;
+                dL_dalpha += tgs_div(-T_final, 1.f - alpha) * bg_dot_dpixel;
+                const float dL_dG = bb.y * dL_dalpha;
+                const float gdx = G * dx, gdy = G * dy;
+                const float dG_ddelx = -gdx * a.z - gdy * a.w;
+                const float dG_ddely = -gdy * bb.x - gdx * a.w;
+                float v[NACC];
+                v[0] = dchannel_dcolor * dpx0; v[1] = dchannel_dcolor * dpx1; v[2] = dchannel_dcolor * dpx2;
+                v[3] = dL_dG * dG_ddelx * ddelx_dx;
+                v[4] = dL_dG * dG_ddely * ddely_dy;
+                v[5] = -0.5f * gdx * dx * dL_dG;
+                v[6] = -0.5f * gdx * dy * dL_dG;
+                v[7] = -0.5f * gdy * dy * dL_dG;
+                v[8] = G * dL_dalpha;
+#pragma unroll
+                for (int c = 0; c < NACC; c++) {
+                    float x = valid ? v[c] : 0.f;
+                    TGS_DPP_ADD(x, 0x124, 0xf);             // row_ror:4  } the 4 lanes of a row that share an entry slot
+                    TGS_DPP_ADD(x, 0x128, 0xf);             // row_ror:8  }
+                    v[c] = x;
+                }
+                // fold the 4 rows: afterwards s0 rows 0..3 = components 0..3, s1 rows = components 4..7, s2 = component 8
+                const float q0 = swap16_add(v[0], v[1]), q1 = swap16_add(v[2], v[3]), q2 = swap16_add(v[4], v[5]), q3 = swap16_add(v[6], v[7]);
+                const float q4 = swap16_add(v[8], v[8]);
+                const float s0 = swap32_add(q0, q1), s1 = swap32_add(q2, q3), s2 = swap32_add(q4, q4);
+                if ((lane & 15) < 4) {                      // lane l of row r: entry slot l (its own j), component r / 4+r / 8
+                    const int row = lane >> 4;
+                    atomicAdd(&acc[row][j], s0);
+                    atomicAdd(&acc[4 + row][j], s1);
+                    if (row == 0) atomicAdd(&acc[8][j], s2);
+                }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < cnt) {
+            float* row = b.slab + (size_t)sSlot[threadIdx.x] * NACC;
+#pragma unroll
+            for (int k = 0; k < NACC; k++) row[k] = acc[k][threadIdx.x];
         }
     }
     stamp(s, tile, 3);
@@ -399,9 +568,11 @@ void launch_selftest_reduce36(hipStream_t st, const float* in, float* out)
     hipLaunchKernelGGL(k_selftest_reduce36, dim3(1), dim3(64), 0, st, in, out);
 }
 
-void launch_render_bwd(hipStream_t st, const ImgState& s, const BinState& b, int W, int H, uint32_t gx, uint32_t T, const float* bg, const float* dL_dpix)
+void launch_render_bwd(hipStream_t st, const ImgState& s, const BinState& b, int W, int H, uint32_t gx, uint32_t T, const float* bg, const float* dL_dpix,
+                       bool deterministic)
 {
-    hipLaunchKernelGGL(k_render_bwd, dim3(T), dim3(256), 0, st, s, b, W, H, gx, bg, dL_dpix);
+    if (deterministic) hipLaunchKernelGGL(k_render_bwd_det, dim3(T), dim3(256), 0, st, s, b, W, H, gx, bg, dL_dpix);
+    else hipLaunchKernelGGL(k_render_bwd, dim3(T), dim3(BWD_THREADS), 0, st, s, b, W, H, gx, bg, dL_dpix);
 }
 void launch_preprocess_bwd(hipStream_t st, const BwdIn& in, const CamParams& cam, const GeomState& g, const BinState& b)
 {

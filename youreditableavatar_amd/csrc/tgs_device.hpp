@@ -21,7 +21,8 @@ struct Meta {                 // lives at the start of the image buffer
     uint32_t max_count;       // longest tile list
     uint32_t n_overflow;      // tiles whose list is longer than SORT_LDS_CAP
     uint32_t error;           // bit0: prefiltered Gaussian culled
-    uint32_t pad[11];
+    uint32_t n_nonempty;      // tiles with at least one instance (they come first in tile_order)
+    uint32_t pad[10];
 };
 
 struct GeomState {
@@ -205,7 +206,7 @@ struct alignas(16) BlockLists {
     uint32_t cnt[16][STG];
 };
 template <int STG>
-__device__ __forceinline__ void build_block_lists(BlockLists<STG>& L, uint32_t bm, int sw, int lane)
+__device__ __forceinline__ void build_block_lists(BlockLists<STG>& L, uint32_t bm, int sw, int lane, int null_slot = RNULL)
 {
 #pragma unroll
     for (int q = 0; q < 16; q++) {
@@ -214,7 +215,7 @@ __device__ __forceinline__ void build_block_lists(BlockLists<STG>& L, uint32_t b
         const uint32_t n = (uint32_t)__builtin_popcountll(bal);
         const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
         if (on) L.idx[q][sw][pos] = (unsigned short)threadIdx.x;
-        if (lane < RUNROLL) L.idx[q][sw][n + lane] = (unsigned short)RNULL;
+        if (lane < RUNROLL) L.idx[q][sw][n + lane] = (unsigned short)null_slot;
         if (lane == 0) L.cnt[q][sw] = n;
     }
 }

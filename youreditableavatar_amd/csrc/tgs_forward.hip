@@ -206,7 +206,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const 
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < T; i += SCAN_THREADS) { const uint32_t c = s.tile_count[i]; atomicAdd(&hist[c ? 32 - __builtin_clz(c) : 0], 1u); }
         __syncthreads();
-        if (threadIdx.x == 0) { uint32_t acc = 0; for (int bk = 33; bk-- > 0;) { const uint32_t h = hist[bk]; hist[bk] = acc; acc += h; } }
+        if (threadIdx.x == 0) { uint32_t acc = 0; for (int bk = 33; bk-- > 0;) { const uint32_t h = hist[bk]; hist[bk] = acc; if (bk == 1) s.meta->n_nonempty = acc + h; acc += h; } }
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < T; i += SCAN_THREADS) { const uint32_t c = s.tile_count[i]; s.tile_order[atomicAdd(&hist[c ? 32 - __builtin_clz(c) : 0], 1u)] = i; }
         mx = wave_max_u32(mx);
@@ -446,15 +446,18 @@ __global__ __launch_bounds__(256) void k_ovf_finalize(const GeomState g, const I
 // own it (work per tile is tiny against the chip), so a tile is spread over 16 waves, long lists are
 // visited first (tile_order) at raised priority, and the per-entry dependent chain is 1/4 as long.
 constexpr int FWD_THREADS = 1024;
-constexpr int FWD_STG = RCHUNK / 64;       // staging waves per round
+constexpr int FCH = 512;                   // list entries staged per round
+constexpr int FWD_STG = FCH / 64;          // staging waves per round
+constexpr int FNULL = FCH;                 // LDS slot of the null record
 
 __global__ __launch_bounds__(FWD_THREADS) void k_render_fwd(const ImgState s, const BinState b, int W, int H, uint32_t gx,
                                                             const float* __restrict__ bg, float* __restrict__ out_color)
 {
-    __shared__ float4 sA[RCHUNK + 1];
-    __shared__ float4 sB[RCHUNK + 1];
-    __shared__ float sC[RCHUNK + 1];
+    __shared__ float4 sA[FCH + 1];
+    __shared__ float4 sB[FCH + 1];
+    __shared__ float sC[FCH + 1];
     __shared__ BlockLists<FWD_STG> L;
+    __shared__ uint32_t wave_alive[2][16];                 // double-buffered "this wave still has live pixels"
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     const uint32_t tile = s.tile_order[blockIdx.x];
     const uint32_t tx = tile % gx, ty = tile / gx;
@@ -470,30 +473,41 @@ __global__ __launch_bounds__(FWD_THREADS) void k_render_fwd(const ImgState s, co
     bool done = !inside;                                   // per pixel; identical in the 4 lanes of a quad
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;          // C: this lane's share (entries of slot e)
     uint32_t last_contributor = 0;
-    if (threadIdx.x == 0) { sA[RNULL] = make_float4(0.f, 0.f, 0.f, 0.f); sB[RNULL] = make_float4(0.f, 0.f, 0.f, 0.f); sC[RNULL] = 0.f; }
+    if (threadIdx.x == 0) { sA[FNULL] = make_float4(0.f, 0.f, 0.f, 0.f); sB[FNULL] = make_float4(0.f, 0.f, 0.f, 0.f); sC[FNULL] = 0.f; }
 
     // register-staged prefetch of the next round (global loads stay in flight under the compute)
     float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
     float2 rc = make_float2(0.f, 0.f);
-    if (threadIdx.x < RCHUNK && rg.x + threadIdx.x < rg.y) { ra = b.recA[rg.x + threadIdx.x]; rb = b.recB[rg.x + threadIdx.x]; rc = b.recC[rg.x + threadIdx.x]; }
+    if (threadIdx.x < FCH && rg.x + threadIdx.x < rg.y) { ra = b.recA[rg.x + threadIdx.x]; rb = b.recB[rg.x + threadIdx.x]; rc = b.recC[rg.x + threadIdx.x]; }
 
-    for (uint32_t base = rg.x; base < rg.y; base += RCHUNK) {
-        if (__syncthreads_and(done)) break;                     // forward.cu:307-310
-        const uint32_t cnt = min((uint32_t)RCHUNK, rg.y - base);
+    bool wave_live = __builtin_amdgcn_ballot_w64(!done) != 0;
+    int round = 0;
+    for (uint32_t base = rg.x; base < rg.y; base += FCH, round++) {
+        // two barriers per round: (A) everybody has finished reading the previous round's LDS and has posted
+        // its liveness; (B) the new round is staged.  The block stops when no wave has a live pixel (forward.cu:307-310).
+        if (lane == 0) wave_alive[round & 1][wv] = wave_live ? 1u : 0u;
+        __syncthreads();
+        {
+            const uint4* wa = reinterpret_cast<const uint4*>(wave_alive[round & 1]);
+            const uint4 f0 = wa[0], f1 = wa[1], f2 = wa[2], f3 = wa[3];
+            if (((f0.x | f0.y | f0.z | f0.w) | (f1.x | f1.y | f1.z | f1.w) | (f2.x | f2.y | f2.z | f2.w) | (f3.x | f3.y | f3.z | f3.w)) == 0u) break;
+        }
+        const uint32_t cnt = min((uint32_t)FCH, rg.y - base);
         if (wv < FWD_STG) {
             uint32_t bm = 0;
             if (threadIdx.x < cnt) { sA[threadIdx.x] = ra; sB[threadIdx.x] = rb; sC[threadIdx.x] = rc.x; bm = __float_as_uint(rc.y); }
-            build_block_lists(L, bm, wv, lane);
+            if (wv * 64u < cnt) build_block_lists(L, bm, wv, lane, FNULL);
+            else if (lane < 16) L.cnt[lane][wv] = 0;
         }
         __syncthreads();
-        if (threadIdx.x < RCHUNK) {
-            const uint32_t nxt = base + RCHUNK + threadIdx.x;
+        if (threadIdx.x < FCH) {
+            const uint32_t nxt = base + FCH + threadIdx.x;
             if (nxt < rg.y) { ra = b.recA[nxt]; rb = b.recB[nxt]; rc = b.recC[nxt]; }
         }
-        bool wave_live = __builtin_amdgcn_ballot_w64(!done) != 0;   // else this wave's 16 pixels are finished
         const uint32_t cbase = base - rg.x + 1;
+        const int nsw = (int)((cnt + 63) >> 6);
 #pragma unroll 1
-        for (int sw = 0; wave_live && sw < FWD_STG; sw++) {
+        for (int sw = 0; wave_live && sw < nsw; sw++) {
             const uint32_t n = __builtin_amdgcn_readfirstlane(L.cnt[wv][sw]);
 #pragma unroll 1
             for (uint32_t k = 0; k < n; k += 4) {               // 4 list entries per pass, only those that can reach this block
@@ -547,6 +561,20 @@ __global__ __launch_bounds__(FWD_THREADS) void k_render_fwd(const ImgState s, co
     stamp(s, tile, 1);
 }
 
+// tiles without any instance: background only (they sit at the end of tile_order)
+__global__ __launch_bounds__(256) void k_fill_empty(const ImgState s, int W, int H, uint32_t gx, uint32_t first, const float* __restrict__ bg,
+                                                    float* __restrict__ out_color)
+{
+    const uint32_t tile = s.tile_order[first + blockIdx.x];
+    const int px = (tile % gx) * TILE + (threadIdx.x & 15), py = (tile / gx) * TILE + (threadIdx.x >> 4);
+    if (px < W && py < H) {
+        const size_t pix_id = (size_t)W * py + px, N = (size_t)W * H;
+        s.final_T[pix_id] = 1.0f;
+        s.n_contrib[pix_id] = 0;
+        out_color[pix_id] = bg[0]; out_color[N + pix_id] = bg[1]; out_color[2 * N + pix_id] = bg[2];   // C + T*bg with C = 0, T = 1
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_mark_visible (rasterizer_impl.cu:54-66)
 // ---------------------------------------------------------------------------------------------
@@ -598,9 +626,11 @@ void launch_tile_sort(hipStream_t st, const GeomState& g, const ImgState& s, con
     }
     hipLaunchKernelGGL(k_ovf_finalize, dim3((max_count + 255) / 256, n_overflow), dim3(256), 0, st, g, s, b, colors, gx);
 }
-void launch_render_fwd(hipStream_t st, const ImgState& s, const BinState& b, int W, int H, uint32_t gx, uint32_t T, const float* bg, float* out_color)
+void launch_render_fwd(hipStream_t st, const ImgState& s, const BinState& b, int W, int H, uint32_t gx, uint32_t T, uint32_t n_nonempty,
+                       const float* bg, float* out_color)
 {
-    hipLaunchKernelGGL(k_render_fwd, dim3(T), dim3(FWD_THREADS), 0, st, s, b, W, H, gx, bg, out_color);
+    if (n_nonempty > 0) hipLaunchKernelGGL(k_render_fwd, dim3(n_nonempty), dim3(FWD_THREADS), 0, st, s, b, W, H, gx, bg, out_color);
+    if (T > n_nonempty) hipLaunchKernelGGL(k_fill_empty, dim3(T - n_nonempty), dim3(256), 0, st, s, W, H, gx, n_nonempty, bg, out_color);
 }
 void launch_mark_visible(hipStream_t st, int P, const float* means3D, const float* view, uint8_t* present)
 {

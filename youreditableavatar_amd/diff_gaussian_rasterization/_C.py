@@ -41,6 +41,8 @@ def _load() -> C.CDLL:
     lib.tgs_mark_visible.argtypes = [vp, it, vp, vp, vp, vp]
     lib.tgs_state_field.restype = C.c_int64
     lib.tgs_state_field.argtypes = [vp, C.c_char_p, it, it, it, C.c_int64, it, it, vp, vp, vp, vp, C.c_size_t]
+    lib.tgs_set_deterministic.restype = None
+    lib.tgs_set_deterministic.argtypes = [it]
     lib.tgs_selftest_reduce36.restype = it
     lib.tgs_selftest_reduce36.argtypes = [vp, vp, vp]
     lib.tgs_profile_begin.restype = it
@@ -52,6 +54,11 @@ def _load() -> C.CDLL:
 
 _lib = _load()
 STAGES = ("preprocess_fwd", "scan", "scatter", "tile_sort", "render_fwd", "render_bwd", "preprocess_bwd")
+
+
+def set_deterministic(on: bool) -> None:
+    """True: bitwise-reproducible backward (fixed in-tile summation order, slower); False: default."""
+    _lib.tgs_set_deterministic(1 if on else 0)
 
 
 def selftest_reduce36(x: torch.Tensor) -> torch.Tensor:
