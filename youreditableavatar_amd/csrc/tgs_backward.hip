@@ -233,7 +233,7 @@ __global__ __launch_bounds__(BWD_THREADS) void k_render_bwd(const ImgState s, co
     float bg_dot_dpixel = 0.f;                              // backward.cu:533-535
     bg_dot_dpixel += bg[0] * dpx0; bg_dot_dpixel += bg[1] * dpx1; bg_dot_dpixel += bg[2] * dpx2;
     float ar0 = 0.f, ar1 = 0.f, ar2 = 0.f;                  // accum_rec
-    float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
+    float last_alpha = 0.f, lm0 = 0.f, lm1 = 0.f, lm2 = 0.f;   // last_alpha and last_alpha*last_color
     const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);   // backward.cu:460-461
 
     uint32_t mq = wave_max_u32(last_contributor);
@@ -286,29 +286,31 @@ __global__ __launch_bounds__(BWD_THREADS) void k_render_bwd(const ImgState s, co
                 // list position of slot j is qhi-1-j; "contributor >= last_contributor" skip of backward.cu:487
                 const bool valid = (qhi - 1 - j < last_contributor) && (j < cnt) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
                 if (__builtin_amdgcn_ballot_w64(valid) == 0) continue;
-                const float aeff = valid ? alpha : 0.f;
-                // walk the pixel's sequential state through the 4 entries (processing order = slot order)
-                float Town = 0.f, a0own = 0.f, a1own = 0.f, a2own = 0.f;
+                const float aeff = valid ? alpha : 0.f;     // a skipped entry is walked as alpha = 0, G = 0
+                const float Geff = valid ? G : 0.f;
+                // transmittance after each of the 4 entries: T / prod(1 - alpha), prefix product over the quad
+                const float Town = tgs_div(T, quad_prefix_product(1.f - aeff, e));
+                T = quad_bcast<3>(Town);
+                // accum_rec walk (backward.cu:516-518): ar <- la*lc + (1-la)*ar with (la, lc) of the PREVIOUS step
+                const float m0 = aeff * c0, m1 = aeff * c1, m2 = aeff * c2;
+                float a0own = 0.f, a1own = 0.f, a2own = 0.f;
 #define TGS_BWD_STEP(E)                                                                                        \
                 {                                                                                              \
-                    const float ae = quad_bcast<E>(aeff);                                                      \
-                    const float e0 = quad_bcast<E>(c0), e1 = quad_bcast<E>(c1), e2 = quad_bcast<E>(c2);         \
-                    T = tgs_div(T, 1.f - ae);                                                                  \
                     const float om = 1.f - last_alpha;                                                         \
-                    ar0 = last_alpha * lc0 + om * ar0; ar1 = last_alpha * lc1 + om * ar1; ar2 = last_alpha * lc2 + om * ar2; \
-                    lc0 = e0; lc1 = e1; lc2 = e2; last_alpha = ae;                                             \
-                    if (e == E) { Town = T; a0own = ar0; a1own = ar1; a2own = ar2; }                           \
+                    ar0 = lm0 + om * ar0; ar1 = lm1 + om * ar1; ar2 = lm2 + om * ar2;                          \
+                    if (e == E) { a0own = ar0; a1own = ar1; a2own = ar2; }                                     \
+                    last_alpha = quad_bcast<E>(aeff); lm0 = quad_bcast<E>(m0); lm1 = quad_bcast<E>(m1); lm2 = quad_bcast<E>(m2); \
                 }
                 TGS_BWD_STEP(0) TGS_BWD_STEP(1) TGS_BWD_STEP(2) TGS_BWD_STEP(3)
 #undef TGS_BWD_STEP
-                // this lane's (pixel, entry) gradient terms, backward.cu:507-555
-                const float dchannel_dcolor = alpha * Town;
+                // this lane's (pixel, entry) gradient terms, backward.cu:507-555 (all zero for a skipped entry)
+                const float dchannel_dcolor = aeff * Town;
                 float dL_dalpha = 0.0f;
                 dL_dalpha += (c0 - a0own) * dpx0; dL_dalpha += (c1 - a1own) * dpx1; dL_dalpha += (c2 - a2own) * dpx2;
                 dL_dalpha *= Town;
                 dL_dalpha += tgs_div(-T_final, 1.f - alpha) * bg_dot_dpixel;
                 const float dL_dG = bb.y * dL_dalpha;
-                const float gdx = G * dx, gdy = G * dy;
+                const float gdx = Geff * dx, gdy = Geff * dy;
                 const float dG_ddelx = -gdx * a.z - gdy * a.w;
                 const float dG_ddely = -gdy * bb.x - gdx * a.w;
                 float v[NACC];
@@ -318,10 +320,10 @@ __global__ __launch_bounds__(BWD_THREADS) void k_render_bwd(const ImgState s, co
                 v[5] = -0.5f * gdx * dx * dL_dG;
                 v[6] = -0.5f * gdx * dy * dL_dG;
                 v[7] = -0.5f * gdy * dy * dL_dG;
-                v[8] = G * dL_dalpha;
+                v[8] = Geff * dL_dalpha;
 #pragma unroll
                 for (int c = 0; c < NACC; c++) {
-                    float x = valid ? v[c] : 0.f;
+                    float x = v[c];
                     TGS_DPP_ADD(x, 0x124, 0xf);             // row_ror:4  } the 4 lanes of a row that share an entry slot
                     TGS_DPP_ADD(x, 0x128, 0xf);             // row_ror:8  }
                     v[c] = x;

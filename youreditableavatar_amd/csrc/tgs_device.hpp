@@ -11,7 +11,11 @@ constexpr int TILE_PIX = TILE * TILE;
 constexpr int WAVE = 64;
 constexpr int PRE_BLOCK = 256;      // Gaussians per workgroup in the per-Gaussian kernels
 constexpr uint32_t SORT_LDS_CAP = 8192;   // longest tile list sorted inside LDS (64 KiB of u64 keys)
-constexpr int COOP_TILES = 64;      // a Gaussian touching more tiles than this is emitted by the whole workgroup
+constexpr int COOP_TILES = 64;
+#ifndef TGS_CSTRIDE
+#define TGS_CSTRIDE 16
+#endif
+constexpr int CSTRIDE = TGS_CSTRIDE;  // u32 stride of the per-tile counters (16 = one counter per 64-B line)      // a Gaussian touching more tiles than this is emitted by the whole workgroup
 
 // ---------------------------------------------------------------------------------------------
 // state buffers (opaque to callers; the reference's equivalents: rasterizer_impl.h:29-65)
@@ -78,7 +82,7 @@ __host__ __device__ inline size_t geom_carve(GeomState& g, char* base, size_t P,
 __host__ __device__ inline size_t img_carve(ImgState& s, char* base, size_t N, size_t T)
 {
     char* p = base;
-    carve(p, s.meta, 1); carve(p, s.ranges, T); carve(p, s.tile_count, T); carve(p, s.cursor, T);
+    carve(p, s.meta, 1); carve(p, s.ranges, T); carve(p, s.tile_count, T * CSTRIDE); carve(p, s.cursor, T * CSTRIDE);
     carve(p, s.ovf_tiles, T); carve(p, s.tile_order, T); carve(p, s.final_T, N); carve(p, s.n_contrib, N);
     carve(p, s.stamps, 4 * T);
     return (size_t)(p - base) + 256;
@@ -223,6 +227,14 @@ __device__ __forceinline__ void build_block_lists(BlockLists<STG>& L, uint32_t b
 __device__ __forceinline__ uint32_t block_to_quadrant_mask(uint32_t m)
 {
     return ((m & 0x0033u) ? 1u : 0u) | ((m & 0x00CCu) ? 2u : 0u) | ((m & 0x3300u) ? 4u : 0u) | ((m & 0xCC00u) ? 8u : 0u);
+}
+// inclusive prefix product over the 4 lanes of each quad (lane e: x_0 * ... * x_e); e = lane & 3
+__device__ __forceinline__ float quad_prefix_product(float x, int e)
+{
+    const float y1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x90, 0xf, 0xf, false));   // quad_perm [0,0,1,2]
+    x *= (e == 0) ? 1.0f : y1;                            // x_e * x_{e-1}
+    const float y2 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x44, 0xf, 0xf, false));   // quad_perm [0,1,0,1]
+    return x * ((e < 2) ? 1.0f : y2);
 }
 // value of lane (quad base + E) broadcast to the 4 lanes of each quad
 template <int E>

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd(const FwdIn in, co
                     g.conic_opacity[idx] = make_float4(conx, cony, conz, in.opacities[idx]);
                     // per-tile instance count (replaces the tile half of the reference's 64-bit sort keys)
                     for (uint32_t ty = miny; ty < maxy; ty++)
-                        for (uint32_t tx = minx; tx < maxx; tx++) atomicAdd(&s.tile_count[ty * cam.gx + tx], 1u);
+                        for (uint32_t tx = minx; tx < maxx; tx++) atomicAdd(&s.tile_count[(size_t)(ty * cam.gx + tx) * CSTRIDE], 1u);
                 }
             }
         }
@@ -186,14 +186,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const 
             unsigned long long sum = 0;
             const uint32_t i0 = base + threadIdx.x * SCAN_ITEMS;
 #pragma unroll
-            for (int k = 0; k < SCAN_ITEMS; k++) { v[k] = (i0 + k < T) ? s.tile_count[i0 + k] : 0u; sum += v[k]; mx = v[k] > mx ? v[k] : mx; }
+            for (int k = 0; k < SCAN_ITEMS; k++) { v[k] = (i0 + k < T) ? s.tile_count[(size_t)(i0 + k) * CSTRIDE] : 0u; sum += v[k]; mx = v[k] > mx ? v[k] : mx; }
             unsigned long long tot;
             unsigned long long ex = block_exscan_u64(sum, lds, tot) + carry;
 #pragma unroll
             for (int k = 0; k < SCAN_ITEMS; k++) {
                 if (i0 + k < T) {
                     s.ranges[i0 + k] = make_uint2((uint32_t)ex, (uint32_t)(ex + v[k]));
-                    s.cursor[i0 + k] = (uint32_t)ex;
+                    s.cursor[(size_t)(i0 + k) * CSTRIDE] = (uint32_t)ex;
                     if (v[k] > SORT_LDS_CAP) s.ovf_tiles[atomicAdd(&ovf_n, 1u)] = i0 + k;
                 }
                 ex += v[k];
@@ -204,11 +204,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const 
         __shared__ uint32_t hist[34];
         if (threadIdx.x < 34) hist[threadIdx.x] = 0;
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < T; i += SCAN_THREADS) { const uint32_t c = s.tile_count[i]; atomicAdd(&hist[c ? 32 - __builtin_clz(c) : 0], 1u); }
+        for (uint32_t i = threadIdx.x; i < T; i += SCAN_THREADS) { const uint32_t c = s.tile_count[(size_t)i * CSTRIDE]; atomicAdd(&hist[c ? 32 - __builtin_clz(c) : 0], 1u); }
         __syncthreads();
         if (threadIdx.x == 0) { uint32_t acc = 0; for (int bk = 33; bk-- > 0;) { const uint32_t h = hist[bk]; hist[bk] = acc; if (bk == 1) s.meta->n_nonempty = acc + h; acc += h; } }
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < T; i += SCAN_THREADS) { const uint32_t c = s.tile_count[i]; s.tile_order[atomicAdd(&hist[c ? 32 - __builtin_clz(c) : 0], 1u)] = i; }
+        for (uint32_t i = threadIdx.x; i < T; i += SCAN_THREADS) { const uint32_t c = s.tile_count[(size_t)i * CSTRIDE]; s.tile_order[atomicAdd(&hist[c ? 32 - __builtin_clz(c) : 0], 1u)] = i; }
         mx = wave_max_u32(mx);
         if ((threadIdx.x & 63) == 0) lds_max[threadIdx.x >> 6] = mx;
         __syncthreads();
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_scatter(int P, const GeomState g,
             const unsigned long long key = ((unsigned long long)__float_as_uint(g.depth[idx]) << 32) | (uint32_t)idx;
             for (uint32_t ty = r.y; ty < r.w; ty++)
                 for (uint32_t tx = r.x; tx < r.z; tx++) {
-                    const uint32_t pos = atomicAdd(&s.cursor[ty * gx + tx], 1u);
+                    const uint32_t pos = atomicAdd(&s.cursor[(size_t)(ty * gx + tx) * CSTRIDE], 1u);
                     b.keys[pos] = key;
                 }
         } else {
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_scatter(int P, const GeomState g,
         const unsigned long long key = ((unsigned long long)__float_as_uint(g.depth[id]) << 32) | id;
         for (uint32_t k = threadIdx.x; k < n; k += PRE_BLOCK) {
             const uint32_t ty = r.y + k / w, tx = r.x + k % w;
-            const uint32_t pos = atomicAdd(&s.cursor[ty * gx + tx], 1u);
+            const uint32_t pos = atomicAdd(&s.cursor[(size_t)(ty * gx + tx) * CSTRIDE], 1u);
             b.keys[pos] = key;
         }
     }
