@@ -103,6 +103,10 @@ enum {
 int tgs_profile_begin(int max_records);
 int tgs_profile_end(double* ms_sum, int64_t* counts);
 
+/* Test knob (process-wide): longest tile list that is depth-sorted inside LDS; longer lists take the
+ * multi-workgroup global-memory path.  Power of two in [2, 8192]; default 8192. */
+int tgs_set_sort_lds_cap(unsigned cap);
+
 /* Process-wide switch for the backward render kernel: 1 = fixed summation order inside a tile (gradients
  * bitwise reproducible run to run, about 2.5x slower in that kernel), 0 = LDS float atomics inside a tile
  * (default), -1 = follow the environment variable TGS_DETERMINISTIC.  Neither mode uses global atomics. */

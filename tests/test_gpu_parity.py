@@ -91,3 +91,27 @@ def test_wave_reduce36_on_hardware(gpu_device):
     out = _C.selftest_reduce36(x.to(gpu_device)).cpu().double()
     ref = x.double().sum(0).reshape(4, 9)
     assert torch.allclose(out, ref, rtol=1e-5, atol=1e-5), (out - ref).abs().max()
+
+
+@pytest.mark.parametrize("cap", [2, 64, 512])
+def test_tile_list_overflow_path(cap, gpu_device):
+    """Lists longer than the LDS budget are sorted in global memory by many workgroups; with the budget
+    lowered to ``cap`` entries nearly every tile takes that path.  Results must not change."""
+    from diff_gaussian_rasterization import _C
+    from youreditableavatar_amd import scenes
+    cloud = scenes.make_cloud(20_000, 1, seed=77, scale_mult=3.0, n_oversized=20, oversize=30.0)
+    cam = scenes.orbit_camera(200, 136, azimuth_deg=10.0)
+    inp = util.scene_input(cloud, cam)
+    dL = scenes.upstream_gradient(200, 136, seed=6)
+    ref = util.oracle_run(inp, dL)
+    lens = ref["ranges"][:, 1] - ref["ranges"][:, 0]
+    assert lens.max() > 512                      # the scene really has long lists
+    _C.set_sort_lds_cap(cap)
+    try:
+        mine = util.hip_run(inp, dL)
+    finally:
+        _C.set_sort_lds_cap(8192)
+    util.compare(mine, ref)
+    base = util.hip_run(inp, dL)
+    assert np.array_equal(mine["point_list"], base["point_list"])
+    assert np.array_equal(mine["color"], base["color"])

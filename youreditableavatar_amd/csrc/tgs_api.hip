@@ -9,10 +9,10 @@
 
 namespace tgs {
 void launch_preprocess_fwd(hipStream_t, const FwdIn&, const CamParams&, const GeomState&, const ImgState&);
-void launch_scan(hipStream_t, const GeomState&, const ImgState&, uint32_t nblocks, uint32_t T);
+void launch_scan(hipStream_t, const GeomState&, const ImgState&, uint32_t nblocks, uint32_t T, uint32_t sort_cap);
 void launch_scatter(hipStream_t, int P, const GeomState&, const ImgState&, const BinState&, uint32_t gx);
 void launch_tile_sort(hipStream_t, const GeomState&, const ImgState&, const BinState&, const float* colors, uint32_t gx, uint32_t T,
-                      uint32_t max_count, uint32_t n_overflow);
+                      uint32_t max_count, uint32_t n_overflow, uint32_t sort_cap);
 void launch_render_fwd(hipStream_t, const ImgState&, const BinState&, int W, int H, uint32_t gx, uint32_t T, uint32_t n_nonempty, const float* bg,
                        float* out_color);
 void launch_mark_visible(hipStream_t, int P, const float* means3D, const float* view, uint8_t* present);
@@ -30,6 +30,7 @@ static thread_local char g_err[512] = "";
 #include <cstdlib>
 // -1: not set by the API -> environment variable TGS_DETERMINISTIC decides (default 0)
 static std::atomic<int> g_deterministic{-1};
+static std::atomic<uint32_t> g_sort_cap{SORT_LDS_CAP};
 static bool deterministic_mode()
 {
     const int v = g_deterministic.load(std::memory_order_relaxed);
@@ -113,6 +114,13 @@ extern "C" {
 
 int tgs_abi_version(void) { return TGS_ABI_VERSION; }
 
+int tgs_set_sort_lds_cap(unsigned cap)
+{
+    if (cap < 2 || cap > SORT_LDS_CAP || (cap & (cap - 1))) return fail(TGS_ERR_INVALID, "sort cap must be a power of two in [2, %u]", SORT_LDS_CAP);
+    g_sort_cap.store(cap, std::memory_order_relaxed);
+    return TGS_OK;
+}
+
 void tgs_set_deterministic(int on) { g_deterministic.store(on < 0 ? -1 : (on ? 1 : 0), std::memory_order_relaxed); }
 
 int tgs_selftest_reduce36(void* stream, const float* in, float* out)
@@ -176,6 +184,7 @@ int64_t tgs_forward(tgs_alloc_fn alloc, void* alloc_ctx, void* stream, int P, in
         return 0;
     }
 
+    const uint32_t sort_cap = g_sort_cap.load(std::memory_order_relaxed);
     GeomState g; ImgState s; BinState b;
     const size_t geom_bytes = geom_carve(g, nullptr, (size_t)P, has_sh, has_sr);
     const size_t img_bytes = img_carve(s, nullptr, N, T);
@@ -201,7 +210,7 @@ int64_t tgs_forward(tgs_alloc_fn alloc, void* alloc_ctx, void* stream, int P, in
         launch_preprocess_fwd(st, in, cam, g, s);
         STAGE_CHECK("preprocess", TGS_STAGE_PREPROCESS_FWD);
         STAGE_BEGIN();
-        launch_scan(st, g, s, (uint32_t)n_blocks((size_t)P), (uint32_t)T);
+        launch_scan(st, g, s, (uint32_t)n_blocks((size_t)P), (uint32_t)T, sort_cap);
         STAGE_CHECK("scan", TGS_STAGE_SCAN);
         // the one host synchronisation of the forward pass (rasterizer_impl.cu:280-281): R sizes the binning buffer
         HIP_TRY(hipMemcpyAsync(&meta, s.meta, sizeof(Meta), hipMemcpyDeviceToHost, st));
@@ -221,7 +230,7 @@ int64_t tgs_forward(tgs_alloc_fn alloc, void* alloc_ctx, void* stream, int P, in
         STAGE_CHECK("scatter", TGS_STAGE_SCATTER);
         const float* colors = has_sh ? g.rgb : colors_precomp;       // rasterizer_impl.cu:321
         STAGE_BEGIN();
-        launch_tile_sort(st, g, s, b, colors, cam.gx, (uint32_t)T, meta.max_count, meta.n_overflow);
+        launch_tile_sort(st, g, s, b, colors, cam.gx, (uint32_t)T, meta.max_count, meta.n_overflow, sort_cap);
         STAGE_CHECK("tile_sort", TGS_STAGE_TILE_SORT);
     }
     STAGE_BEGIN();

@@ -198,7 +198,7 @@ constexpr int BCH = 256;                   // list entries per round
 constexpr int BWD_STG = BCH / 64;
 constexpr int BNULL = BCH;
 
-__global__ __launch_bounds__(BWD_THREADS) void k_render_bwd(const ImgState s, const BinState b, int W, int H, uint32_t gx,
+__global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s, const BinState b, int W, int H, uint32_t gx,
                                                             const float* __restrict__ bg, const float* __restrict__ dL_dpix)
 {
     __shared__ float4 sA[BCH + 1];

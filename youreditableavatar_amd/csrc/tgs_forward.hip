@@ -156,7 +156,7 @@ __device__ __forceinline__ unsigned long long block_exscan_u64(unsigned long lon
     return base + inc - v;
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const ImgState s, uint32_t nblocks, uint32_t T)
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const ImgState s, uint32_t nblocks, uint32_t T, uint32_t sort_cap)
 {
     __shared__ unsigned long long lds[SCAN_THREADS / WAVE];
     __shared__ uint32_t lds_max[SCAN_THREADS / WAVE];
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const 
                 if (i0 + k < T) {
                     s.ranges[i0 + k] = make_uint2((uint32_t)ex, (uint32_t)(ex + v[k]));
                     s.cursor[(size_t)(i0 + k) * CSTRIDE] = (uint32_t)ex;
-                    if (v[k] > SORT_LDS_CAP) s.ovf_tiles[atomicAdd(&ovf_n, 1u)] = i0 + k;
+                    if (v[k] > sort_cap) s.ovf_tiles[atomicAdd(&ovf_n, 1u)] = i0 + k;
                 }
                 ex += v[k];
             }
@@ -347,13 +347,14 @@ __device__ __forceinline__ void finalize_entry(unsigned long long key, uint32_t 
     b.slot[pos] = g.offsets[id] + (ty - r.y) * ((uint32_t)r.z - r.x) + (tx - r.x);
 }
 
-__global__ __launch_bounds__(256) void k_tile_sort(const GeomState g, const ImgState s, const BinState b, const float* colors, uint32_t gx)
+__global__ __launch_bounds__(256) void k_tile_sort(const GeomState g, const ImgState s, const BinState b, const float* colors, uint32_t gx,
+                                                   uint32_t sort_cap)
 {
     extern __shared__ unsigned long long lk[];
     const uint32_t tile = blockIdx.x;
     const uint2 rg = s.ranges[tile];
     const uint32_t n = rg.y - rg.x;
-    if (n == 0 || n > SORT_LDS_CAP) return;
+    if (n == 0 || n > sort_cap) return;
     for (uint32_t i = threadIdx.x; i < n; i += 256) lk[i] = b.keys[rg.x + i];
     __syncthreads();
     const uint32_t npad = next_pow2(n), half = npad >> 1;
@@ -373,25 +374,25 @@ __global__ __launch_bounds__(256) void k_tile_sort(const GeomState g, const ImgS
 }
 
 // ---- overflow path: lists longer than SORT_LDS_CAP, sorted in global memory by many workgroups ----
-// grid = (ceil(npad_max / SORT_LDS_CAP), n_overflow)
-__global__ __launch_bounds__(256) void k_ovf_local(const ImgState s, const BinState b, uint32_t k_only)
+// grid = (ceil(npad_max / cap), n_overflow); cap = power of two <= SORT_LDS_CAP (the LDS block of keys)
+__global__ __launch_bounds__(256) void k_ovf_local(const ImgState s, const BinState b, uint32_t k_only, uint32_t cap)
 {
-    // k_only == 0: full network for k = 2..SORT_LDS_CAP on each aligned block of SORT_LDS_CAP keys;
-    // k_only  > 0: only the disperse steps j = SORT_LDS_CAP/2..1 of merge size k_only.
+    // k_only == 0: full network for k = 2..cap on each aligned block of cap keys;
+    // k_only  > 0: only the disperse steps j = cap/2..1 of merge size k_only.
     extern __shared__ unsigned long long lk[];
     const uint32_t tile = s.ovf_tiles[blockIdx.y];
     const uint2 rg = s.ranges[tile];
     const uint32_t n = rg.y - rg.x;
-    const uint32_t b0 = blockIdx.x * SORT_LDS_CAP;
+    const uint32_t b0 = blockIdx.x * cap;
     if (b0 >= n) return;
     if (k_only > next_pow2(n)) return;
-    const uint32_t m = min(SORT_LDS_CAP, n - b0);          // real keys in this block
+    const uint32_t m = min(cap, n - b0);                   // real keys in this block
     unsigned long long* gk = b.keys + rg.x + b0;
     for (uint32_t i = threadIdx.x; i < m; i += 256) lk[i] = gk[i];
     __syncthreads();
-    const uint32_t half = SORT_LDS_CAP >> 1;
+    const uint32_t half = cap >> 1;
     if (k_only == 0) {
-        for (uint32_t k = 2; k <= SORT_LDS_CAP; k <<= 1) {
+        for (uint32_t k = 2; k <= cap; k <<= 1) {
             for (uint32_t t = threadIdx.x; t < half; t += 256) { uint32_t i, l; pair_flip(t, k, i, l); cmp_swap(lk, i, l, m); }
             __syncthreads();
             for (uint32_t j = k >> 2; j > 0; j >>= 1) {
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(256) void k_ovf_local(const ImgState s, const BinSt
             }
         }
     } else {
-        for (uint32_t j = SORT_LDS_CAP >> 1; j > 0; j >>= 1) {
+        for (uint32_t j = cap >> 1; j > 0; j >>= 1) {
             for (uint32_t t = threadIdx.x; t < half; t += 256) { uint32_t i, l; pair_disperse(t, j, i, l); cmp_swap(lk, i, l, m); }
             __syncthreads();
         }
@@ -599,9 +600,9 @@ void launch_preprocess_fwd(hipStream_t st, const FwdIn& in, const CamParams& cam
     else if (sr) hipLaunchKernelGGL((k_preprocess_fwd<false, true>), grid, blk, 0, st, in, cam, g, s);
     else hipLaunchKernelGGL((k_preprocess_fwd<false, false>), grid, blk, 0, st, in, cam, g, s);
 }
-void launch_scan(hipStream_t st, const GeomState& g, const ImgState& s, uint32_t nblocks, uint32_t T)
+void launch_scan(hipStream_t st, const GeomState& g, const ImgState& s, uint32_t nblocks, uint32_t T, uint32_t sort_cap)
 {
-    hipLaunchKernelGGL(k_scan, dim3(2), dim3(SCAN_THREADS), 0, st, g, s, nblocks, T);
+    hipLaunchKernelGGL(k_scan, dim3(2), dim3(SCAN_THREADS), 0, st, g, s, nblocks, T, sort_cap);
 }
 void launch_scatter(hipStream_t st, int P, const GeomState& g, const ImgState& s, const BinState& b, uint32_t gx)
 {
@@ -609,20 +610,21 @@ void launch_scatter(hipStream_t st, int P, const GeomState& g, const ImgState& s
 }
 static uint32_t host_next_pow2(uint32_t n) { uint32_t p = 1; while (p < n) p <<= 1; return p; }
 void launch_tile_sort(hipStream_t st, const GeomState& g, const ImgState& s, const BinState& b, const float* colors, uint32_t gx, uint32_t T,
-                      uint32_t max_count, uint32_t n_overflow)
+                      uint32_t max_count, uint32_t n_overflow, uint32_t sort_cap)
 {
-    const uint32_t cap = max_count < SORT_LDS_CAP ? max_count : SORT_LDS_CAP;
+    const uint32_t cap = max_count < sort_cap ? max_count : sort_cap;
     const size_t lds = (size_t)(cap ? cap : 1) * 8;
-    hipLaunchKernelGGL(k_tile_sort, dim3(T), dim3(256), lds, st, g, s, b, colors, gx);
+    hipLaunchKernelGGL(k_tile_sort, dim3(T), dim3(256), lds, st, g, s, b, colors, gx, sort_cap);
     if (n_overflow == 0) return;
+    // lists longer than sort_cap: sorted in global memory by many workgroups, LDS for strides < sort_cap
     const uint32_t npad = host_next_pow2(max_count);
-    const dim3 lgrid((npad + SORT_LDS_CAP - 1) / SORT_LDS_CAP, n_overflow), ggrid((npad / 2 + 255) / 256, n_overflow);
-    const size_t ldsb = (size_t)SORT_LDS_CAP * 8;
-    hipLaunchKernelGGL(k_ovf_local, lgrid, dim3(256), ldsb, st, s, b, 0u);
-    for (uint32_t k = SORT_LDS_CAP * 2; k <= npad; k <<= 1) {
+    const dim3 lgrid((npad + sort_cap - 1) / sort_cap, n_overflow), ggrid((npad / 2 + 255) / 256, n_overflow);
+    const size_t ldsb = (size_t)sort_cap * 8;
+    hipLaunchKernelGGL(k_ovf_local, lgrid, dim3(256), ldsb, st, s, b, 0u, sort_cap);
+    for (uint32_t k = sort_cap * 2; k <= npad; k <<= 1) {
         hipLaunchKernelGGL(k_ovf_global, ggrid, dim3(256), 0, st, s, b, k, 0u, 1);
-        for (uint32_t j = k >> 2; j >= SORT_LDS_CAP; j >>= 1) hipLaunchKernelGGL(k_ovf_global, ggrid, dim3(256), 0, st, s, b, k, j, 0);
-        hipLaunchKernelGGL(k_ovf_local, lgrid, dim3(256), ldsb, st, s, b, k);
+        for (uint32_t j = k >> 2; j >= sort_cap; j >>= 1) hipLaunchKernelGGL(k_ovf_global, ggrid, dim3(256), 0, st, s, b, k, j, 0);
+        hipLaunchKernelGGL(k_ovf_local, lgrid, dim3(256), ldsb, st, s, b, k, sort_cap);
     }
     hipLaunchKernelGGL(k_ovf_finalize, dim3((max_count + 255) / 256, n_overflow), dim3(256), 0, st, g, s, b, colors, gx);
 }

@@ -41,6 +41,8 @@ def _load() -> C.CDLL:
     lib.tgs_mark_visible.argtypes = [vp, it, vp, vp, vp, vp]
     lib.tgs_state_field.restype = C.c_int64
     lib.tgs_state_field.argtypes = [vp, C.c_char_p, it, it, it, C.c_int64, it, it, vp, vp, vp, vp, C.c_size_t]
+    lib.tgs_set_sort_lds_cap.restype = it
+    lib.tgs_set_sort_lds_cap.argtypes = [C.c_uint]
     lib.tgs_set_deterministic.restype = None
     lib.tgs_set_deterministic.argtypes = [it]
     lib.tgs_selftest_reduce36.restype = it
@@ -54,6 +56,12 @@ def _load() -> C.CDLL:
 
 _lib = _load()
 STAGES = ("preprocess_fwd", "scan", "scatter", "tile_sort", "render_fwd", "render_bwd", "preprocess_bwd")
+
+
+def set_sort_lds_cap(cap: int) -> None:
+    """Test knob: tile lists longer than ``cap`` (power of two <= 8192) take the global-memory sort path."""
+    if _lib.tgs_set_sort_lds_cap(int(cap)) < 0:
+        raise _err(-1)
 
 
 def set_deterministic(on: bool) -> None:
