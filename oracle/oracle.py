@@ -36,6 +36,8 @@ def lib():
         L.tgs_oracle_backward.restype = None
         L.tgs_oracle_backward.argtypes = [vp, fp, fp, fp, fp, fp, C.c_float, fp, fp, fp, fp, fp, C.c_float,
                                           C.c_float] + [fp] * 10
+        L.tgs_oracle_backward_pergauss_f64.restype = None
+        L.tgs_oracle_backward_pergauss_f64.argtypes = [vp, fp, fp, fp, C.c_float, fp, fp, fp, fp, fp, C.c_float, C.c_float, fp, fp, fp, fp, fp, fp, fp]
         L.tgs_oracle_free.argtypes = [vp]
         L.tgs_oracle_free.restype = None
         L.tgs_oracle_num_rendered.argtypes = [vp]
@@ -120,7 +122,7 @@ def forward(*, bg, means3D, opacities, viewmatrix, projmatrix, campos, tanfovx, 
 
 def backward(state: OracleState, dL_dout_color, *, bg, means3D, viewmatrix, projmatrix, campos, tanfovx, tanfovy,
              shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None,
-             scale_modifier=1.0) -> Dict[str, np.ndarray]:
+             scale_modifier=1.0, f64_pergauss: bool = False) -> Dict[str, np.ndarray]:
     """Returns the 8 tensors of RasterizeGaussiansBackwardCUDA (rasterize_points.cu:195) plus dL_dconic."""
     means3D = _c32(means3D)
     P = means3D.shape[0]
@@ -137,7 +139,32 @@ def backward(state: OracleState, dL_dout_color, *, bg, means3D, viewmatrix, proj
                               _f(out["dL_dconic"]), _f(out["dL_dopacity"]), _f(out["dL_dcolors"]),
                               _f(out["dL_dmeans3D"]), _f(out["dL_dcov3D"]), _f(out["dL_dsh"]), _f(out["dL_dscales"]),
                               _f(out["dL_drotations"]))
+    if f64_pergauss:
+        # the per-Gaussian formulas re-evaluated in double on the same fp32 inputs: fp32 rounding noise estimate
+        z3, z6, z4 = z(P, 3), z(P, 6), z(P, 4)
+        zs = z(P, 3)
+        lib().tgs_oracle_backward_pergauss_f64(state._h, _f(means3D), _f(shs), _f(scales), float(scale_modifier), _f(rotations),
+                                               _f(cov3D_precomp), _f(viewmatrix), _f(projmatrix), _f(campos), float(tanfovx), float(tanfovy),
+                                               _f(out["dL_dmeans2D"]), _f(out["dL_dconic"]), _f(out["dL_dcolors"]), _f(z3), _f(z6), _f(zs), _f(z4))
+        out.update({"f64_dL_dmeans3D": z3, "f64_dL_dcov3D": z6, "f64_dL_dscales": zs, "f64_dL_drotations": z4})
     return out
+
+
+def pergauss_f64(state: OracleState, dL_dmeans2D, dL_dconic, dL_dcolors, *, means3D, viewmatrix, projmatrix, campos, tanfovx, tanfovy,
+                 shs=None, scales=None, rotations=None, cov3D_precomp=None, scale_modifier=1.0, **_unused) -> Dict[str, np.ndarray]:
+    """The per-Gaussian half of the backward in double, on GIVEN render-pass gradients (e.g. the HIP kernel's own):
+    separates the accuracy of that half from the conditioning of the map dL_dconic -> dL_dscales/rotations."""
+    means3D = _c32(means3D)
+    P = means3D.shape[0]
+    shs, scales, rotations, cov3D_precomp = map(_c32, (shs, scales, rotations, cov3D_precomp))
+    viewmatrix, projmatrix, campos = map(_c32, (viewmatrix, projmatrix, campos))
+    g2, gc, gcol = _c32(dL_dmeans2D).reshape(P, 3), _c32(dL_dconic).reshape(P, 4), _c32(dL_dcolors).reshape(P, 3)
+    z = lambda *s: np.zeros(s, np.float32)
+    z3, z6, zs, z4 = z(P, 3), z(P, 6), z(P, 3), z(P, 4)
+    lib().tgs_oracle_backward_pergauss_f64(state._h, _f(means3D), _f(shs), _f(scales), float(scale_modifier), _f(rotations),
+                                           _f(cov3D_precomp), _f(viewmatrix), _f(projmatrix), _f(campos), float(tanfovx), float(tanfovy),
+                                           _f(g2), _f(gc), _f(gcol), _f(z3), _f(z6), _f(zs), _f(z4))
+    return {"dL_dmeans3D": z3, "dL_dcov3D": z6, "dL_dscales": zs, "dL_drotations": z4}
 
 
 def mark_visible(means3D, viewmatrix, projmatrix) -> np.ndarray:

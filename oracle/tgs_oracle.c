@@ -655,6 +655,120 @@ void tgs_oracle_backward(const tgs_oracle_state* s, const float* background, con
     }
 }
 
+/*
+ * The per-Gaussian half of the backward (computeCov2DCUDA + preprocessCUDA, backward.cu:144-396) evaluated in
+ * DOUBLE on the same fp32 inputs (means, stored fp32 cov3D, the fp32 dL_dconic / dL_dmean2D / dL_dcolor of the
+ * render pass).  Not a restatement of the reference's arithmetic: it measures how much of the fp32 result of those
+ * formulas is rounding noise (the (denom - a*c) and T*T cancellations), which tests use to scale the tolerance of
+ * dL_dmeans3D / dL_dcov3D / dL_dscales / dL_drotations where no fixture carries that information.
+ */
+typedef struct { double m[3][3]; } dmat3;
+static dmat3 dm3mul(const dmat3* a, const dmat3* b)
+{
+    dmat3 r;
+    for (int c = 0; c < 3; c++) for (int w = 0; w < 3; w++) r.m[c][w] = a->m[0][w] * b->m[c][0] + a->m[1][w] * b->m[c][1] + a->m[2][w] * b->m[c][2];
+    return r;
+}
+static dmat3 dm3t(const dmat3* a) { dmat3 r; for (int c = 0; c < 3; c++) for (int w = 0; w < 3; w++) r.m[c][w] = a->m[w][c]; return r; }
+
+void tgs_oracle_backward_pergauss_f64(const tgs_oracle_state* s, const float* means3D, const float* shs, const float* scales,
+                                      float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                                      const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy,
+                                      const float* dL_dmean2D, const float* dL_dconic, const float* dL_dcolor,
+                                      float* dL_dmean3D, float* dL_dcov3D, float* dL_dscale, float* dL_drot)
+{
+    const int P = s->P, W = s->W, H = s->H, D = s->D, M = s->M;
+    const double fy = (double)(H / (2.0f * tan_fovy)), fx = (double)(W / (2.0f * tan_fovx));
+    const float* cov3Ds = cov3D_precomp ? cov3D_precomp : s->cov3D;
+    const float* vm = viewmatrix; const float* pj = projmatrix;
+    for (int idx = 0; idx < P; idx++) {
+        double dmean[3] = {0, 0, 0}, dcov[6] = {0, 0, 0, 0, 0, 0};
+        if (s->radii[idx] > 0) {
+            const double mx = means3D[3 * idx], my = means3D[3 * idx + 1], mz = means3D[3 * idx + 2];
+            const float* c3 = cov3Ds + 6 * (size_t)idx;
+            double tx = vm[0] * mx + vm[4] * my + vm[8] * mz + vm[12], ty = vm[1] * mx + vm[5] * my + vm[9] * mz + vm[13];
+            const double tz = vm[2] * mx + vm[6] * my + vm[10] * mz + vm[14];
+            const double limx = (double)(1.3f * tan_fovx), limy = (double)(1.3f * tan_fovy), txtz = tx / tz, tytz = ty / tz;
+            tx = (txtz < -limx ? -limx : txtz > limx ? limx : txtz) * tz;
+            ty = (tytz < -limy ? -limy : tytz > limy ? limy : tytz) * tz;
+            const double xg = (txtz < -limx || txtz > limx) ? 0 : 1, yg = (tytz < -limy || tytz > limy) ? 0 : 1;
+            dmat3 J = {{{fx / tz, 0, -(fx * tx) / (tz * tz)}, {0, fy / tz, -(fy * ty) / (tz * tz)}, {0, 0, 0}}};
+            dmat3 Wm = {{{vm[0], vm[4], vm[8]}, {vm[1], vm[5], vm[9]}, {vm[2], vm[6], vm[10]}}};
+            dmat3 V = {{{c3[0], c3[1], c3[2]}, {c3[1], c3[3], c3[4]}, {c3[2], c3[4], c3[5]}}};
+            dmat3 T = dm3mul(&Wm, &J), Tt = dm3t(&T), Vt = dm3t(&V), tmp = dm3mul(&Tt, &Vt), c2 = dm3mul(&tmp, &T);
+            const double a = c2.m[0][0] + (double)0.3f, b = c2.m[0][1], c = c2.m[1][1] + (double)0.3f;
+            const double g0 = dL_dconic[4 * idx], g1 = dL_dconic[4 * idx + 1], g2 = dL_dconic[4 * idx + 3];
+            const double denom = a * c - b * b, d2i = 1.0 / (denom * denom + (double)0.0000001f);
+            double dLa = 0, dLb = 0, dLc = 0;
+#define TT(c_, r_) T.m[c_][r_]
+#define VV(c_, r_) V.m[c_][r_]
+            if (d2i != 0) {
+                dLa = d2i * (-c * c * g0 + 2 * b * c * g1 + (denom - a * c) * g2);
+                dLc = d2i * (-a * a * g2 + 2 * a * b * g1 + (denom - a * c) * g0);
+                dLb = d2i * 2 * (b * c * g0 - (denom + 2 * b * b) * g1 + a * b * g2);
+                dcov[0] = TT(0, 0) * TT(0, 0) * dLa + TT(0, 0) * TT(1, 0) * dLb + TT(1, 0) * TT(1, 0) * dLc;
+                dcov[3] = TT(0, 1) * TT(0, 1) * dLa + TT(0, 1) * TT(1, 1) * dLb + TT(1, 1) * TT(1, 1) * dLc;
+                dcov[5] = TT(0, 2) * TT(0, 2) * dLa + TT(0, 2) * TT(1, 2) * dLb + TT(1, 2) * TT(1, 2) * dLc;
+                dcov[1] = 2 * TT(0, 0) * TT(0, 1) * dLa + (TT(0, 0) * TT(1, 1) + TT(0, 1) * TT(1, 0)) * dLb + 2 * TT(1, 0) * TT(1, 1) * dLc;
+                dcov[2] = 2 * TT(0, 0) * TT(0, 2) * dLa + (TT(0, 0) * TT(1, 2) + TT(0, 2) * TT(1, 0)) * dLb + 2 * TT(1, 0) * TT(1, 2) * dLc;
+                dcov[4] = 2 * TT(0, 2) * TT(0, 1) * dLa + (TT(0, 1) * TT(1, 2) + TT(0, 2) * TT(1, 1)) * dLb + 2 * TT(1, 1) * TT(1, 2) * dLc;
+            }
+            double dT[2][3];
+            for (int k = 0; k < 3; k++) {
+                const double r0 = TT(0, 0) * VV(k, 0) + TT(0, 1) * VV(k, 1) + TT(0, 2) * VV(k, 2), r1 = TT(1, 0) * VV(k, 0) + TT(1, 1) * VV(k, 1) + TT(1, 2) * VV(k, 2);
+                dT[0][k] = 2 * r0 * dLa + r1 * dLb;
+                dT[1][k] = 2 * r1 * dLc + r0 * dLb;
+            }
+#undef TT
+#undef VV
+            const double dJ00 = Wm.m[0][0] * dT[0][0] + Wm.m[0][1] * dT[0][1] + Wm.m[0][2] * dT[0][2];
+            const double dJ02 = Wm.m[2][0] * dT[0][0] + Wm.m[2][1] * dT[0][1] + Wm.m[2][2] * dT[0][2];
+            const double dJ11 = Wm.m[1][0] * dT[1][0] + Wm.m[1][1] * dT[1][1] + Wm.m[1][2] * dT[1][2];
+            const double dJ12 = Wm.m[2][0] * dT[1][0] + Wm.m[2][1] * dT[1][1] + Wm.m[2][2] * dT[1][2];
+            const double z1 = 1.0 / tz, z2 = z1 * z1, z3 = z2 * z1;
+            const double dtx = xg * -fx * z2 * dJ02, dty = yg * -fy * z2 * dJ12;
+            const double dtz = -fx * z2 * dJ00 - fy * z2 * dJ11 + (2 * fx * tx) * z3 * dJ02 + (2 * fy * ty) * z3 * dJ12;
+            dmean[0] = vm[0] * dtx + vm[1] * dty + vm[2] * dtz; dmean[1] = vm[4] * dtx + vm[5] * dty + vm[6] * dtz; dmean[2] = vm[8] * dtx + vm[9] * dty + vm[10] * dtz;
+            /* projection part, backward.cu:369-387 */
+            const double mw = 1.0 / ((pj[3] * mx + pj[7] * my + pj[11] * mz + pj[15]) + (double)0.0000001f);
+            const double mul1 = (pj[0] * mx + pj[4] * my + pj[8] * mz + pj[12]) * mw * mw, mul2 = (pj[1] * mx + pj[5] * my + pj[9] * mz + pj[13]) * mw * mw;
+            const double g2x = dL_dmean2D[3 * idx], g2y = dL_dmean2D[3 * idx + 1];
+            dmean[0] += (pj[0] * mw - pj[3] * mul1) * g2x + (pj[1] * mw - pj[3] * mul2) * g2y;
+            dmean[1] += (pj[4] * mw - pj[7] * mul1) * g2x + (pj[5] * mw - pj[7] * mul2) * g2y;
+            dmean[2] += (pj[8] * mw - pj[11] * mul1) * g2x + (pj[9] * mw - pj[11] * mul2) * g2y;
+            if (shs) {   /* the view-direction term of backward.cu:130-138; reuses the fp32 routine's structure in double via finite differences-free algebra */
+                float tmp_dm[3] = {0, 0, 0};
+                float* dsh_tmp = (float*)calloc((size_t)M * 3 + 1, 4);
+                /* colorFromSH_bwd writes at index idx: give it arrays offset so that idx lands on our temporaries */
+                colorFromSH_bwd(idx, D, M, means3D, campos, shs, s->clamped, dL_dcolor, tmp_dm - 3 * (size_t)idx, dsh_tmp - (size_t)idx * M * 3);
+                dmean[0] += tmp_dm[0]; dmean[1] += tmp_dm[1]; dmean[2] += tmp_dm[2];
+                free(dsh_tmp);
+            }
+            if (scales) {
+                const double r = rotations[4 * idx], x = rotations[4 * idx + 1], y = rotations[4 * idx + 2], z = rotations[4 * idx + 3];
+                dmat3 R = {{{1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y)}, {2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x)},
+                            {2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)}}};
+                const double sx = (double)scale_modifier * scales[3 * idx], sy = (double)scale_modifier * scales[3 * idx + 1], sz = (double)scale_modifier * scales[3 * idx + 2];
+                dmat3 S = {{{sx, 0, 0}, {0, sy, 0}, {0, 0, sz}}};
+                dmat3 Mx = dm3mul(&S, &R);
+                dmat3 dSig = {{{dcov[0], 0.5 * dcov[1], 0.5 * dcov[2]}, {0.5 * dcov[1], dcov[3], 0.5 * dcov[4]}, {0.5 * dcov[2], 0.5 * dcov[4], dcov[5]}}};
+                dmat3 M2; for (int c_ = 0; c_ < 3; c_++) for (int w = 0; w < 3; w++) M2.m[c_][w] = 2.0 * Mx.m[c_][w];
+                dmat3 dM = dm3mul(&M2, &dSig), Rt = dm3t(&R), dMt = dm3t(&dM);
+                for (int k = 0; k < 3; k++) dL_dscale[3 * idx + k] = (float)(Rt.m[k][0] * dMt.m[k][0] + Rt.m[k][1] * dMt.m[k][1] + Rt.m[k][2] * dMt.m[k][2]);
+                for (int w = 0; w < 3; w++) { dMt.m[0][w] *= sx; dMt.m[1][w] *= sy; dMt.m[2][w] *= sz; }
+#define A(c_, w_) dMt.m[c_][w_]
+                dL_drot[4 * idx] = (float)(2 * z * (A(0, 1) - A(1, 0)) + 2 * y * (A(2, 0) - A(0, 2)) + 2 * x * (A(1, 2) - A(2, 1)));
+                dL_drot[4 * idx + 1] = (float)(2 * y * (A(1, 0) + A(0, 1)) + 2 * z * (A(2, 0) + A(0, 2)) + 2 * r * (A(1, 2) - A(2, 1)) - 4 * x * (A(2, 2) + A(1, 1)));
+                dL_drot[4 * idx + 2] = (float)(2 * x * (A(1, 0) + A(0, 1)) + 2 * r * (A(2, 0) - A(0, 2)) + 2 * z * (A(1, 2) + A(2, 1)) - 4 * y * (A(2, 2) + A(0, 0)));
+                dL_drot[4 * idx + 3] = (float)(2 * r * (A(0, 1) - A(1, 0)) + 2 * x * (A(2, 0) + A(0, 2)) + 2 * y * (A(1, 2) + A(2, 1)) - 4 * z * (A(1, 1) + A(0, 0)));
+#undef A
+            }
+        }
+        for (int k = 0; k < 3; k++) dL_dmean3D[3 * idx + k] = (float)dmean[k];
+        for (int k = 0; k < 6; k++) dL_dcov3D[6 * idx + k] = (float)dcov[k];
+    }
+}
+
 /* CR/rasterizer_impl.cu:54-66,141-153 */
 void tgs_oracle_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present)
 {

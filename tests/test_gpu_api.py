@@ -1,0 +1,190 @@
+"""GPU: the public drop-in API (GaussianRasterizer + autograd) the way tetgs_scene calls it, edge cases,
+and the BASELINE.json configurations at full size against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _settings(cam, deg, dev, debug=False, campos_2d=False, cpu_settings=False):
+    from diff_gaussian_rasterization import GaussianRasterizationSettings
+    d = torch.device("cpu") if cpu_settings else dev
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(d)
+    campos = t(cam.campos)
+    if campos_2d:
+        campos = campos.reshape(1, 3)          # p3d get_camera_center() returns [1,3] (tetgs_model.py:502)
+    return GaussianRasterizationSettings(image_height=cam.image_height, image_width=cam.image_width, tanfovx=cam.tanfovx,
+                                         tanfovy=cam.tanfovy, bg=t(cam.bg), scale_modifier=1.0, viewmatrix=t(cam.viewmatrix),
+                                         projmatrix=t(cam.projmatrix), sh_degree=deg, campos=campos, prefiltered=False, debug=debug)
+
+
+def _leaves(cloud, dev, colors=None):
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev).requires_grad_(True)
+    L = dict(means3D=t(cloud["means3D"]), opacities=t(cloud["opacities"]), scales=t(cloud["scales"]), rotations=t(cloud["rotations"]))
+    if colors is None:
+        L["shs"] = t(cloud["shs"])
+    else:
+        L["colors_precomp"] = t(colors)
+    return L
+
+
+def test_training_style_call_matches_oracle(gpu_device):
+    """colors_precomp + scales/rotations, means2D gradient carrier, campos [1,3] -- tetgs_model.py:524-614."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from youreditableavatar_amd import scenes
+    cloud = scenes.make_cloud(8000, 2, seed=31, scale_mult=3.0)
+    cam = scenes.orbit_camera(240, 160, azimuth_deg=70.0)
+    colors = scenes.sh_to_rgb_numpy(cloud["shs"], cloud["means3D"], cam.campos, 2)
+    L = _leaves(cloud, gpu_device, colors)
+    means2D = torch.zeros(8000, 3, device=gpu_device, requires_grad=True)
+    rast = GaussianRasterizer(_settings(cam, 2, gpu_device, campos_2d=True))
+    img, radii = rast(means3D=L["means3D"], means2D=means2D, shs=None, colors_precomp=L["colors_precomp"], opacities=L["opacities"],
+                      scales=L["scales"], rotations=L["rotations"], cov3D_precomp=None)
+    assert img.shape == (3, 160, 240) and radii.dtype == torch.int32 and not radii.requires_grad
+    dL = scenes.upstream_gradient(240, 160, seed=8)
+    img.backward(torch.from_numpy(dL).to(gpu_device))
+    inp = util.scene_input(cloud, cam, mode="precomp")
+    ref = util.oracle_run(inp, dL)
+    assert util.rel_l2(img.detach().cpu().numpy(), ref["color"]) <= 1e-4
+    assert np.array_equal(radii.cpu().numpy(), ref["radii"])
+    for name, key in (("means3D", "dL_dmeans3D"), ("opacities", "dL_dopacity"), ("scales", "dL_dscales"), ("rotations", "dL_drotations"),
+                      ("colors_precomp", "dL_dcolors")):
+        assert util.rel_l2(L[name].grad.cpu().numpy(), ref[key]) <= 1e-4, name
+    assert util.rel_l2(means2D.grad.cpu().numpy(), ref["dL_dmeans2D"]) <= 1e-4
+    assert torch.all(means2D.grad[:, 2] == 0)
+
+
+def test_validation_render_no_grad_and_settings_on_cpu(gpu_device):
+    """shs in the rasterizer under no_grad (refine.py:413-420); settings tensors left on the CPU are moved."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from youreditableavatar_amd import scenes
+    cloud = scenes.make_cloud(3000, 3, seed=32, scale_mult=3.0)
+    cam = scenes.orbit_camera(128, 128)
+    L = _leaves(cloud, gpu_device)
+    with torch.no_grad():
+        img, radii = GaussianRasterizer(_settings(cam, 3, gpu_device, cpu_settings=True))(
+            means3D=L["means3D"], means2D=torch.zeros(3000, 3, device=gpu_device), opacities=L["opacities"], shs=L["shs"],
+            scales=L["scales"], rotations=L["rotations"])
+    ref = util.oracle_run(util.scene_input(cloud, cam))
+    assert util.rel_l2(img.cpu().numpy(), ref["color"]) <= 1e-4
+    assert not img.requires_grad
+
+
+def test_two_graphs_alive_and_noncontiguous_inputs(gpu_device):
+    """State buffers belong to their autograd graph: a second forward must not disturb the first backward
+    (paint_2dgs.py:434-446 keeps `initial_outputs`); strided inputs are made contiguous like the reference."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from youreditableavatar_amd import scenes
+    cloud = scenes.make_cloud(4000, 1, seed=33, scale_mult=3.0)
+    cams = [scenes.orbit_camera(160, 96, azimuth_deg=a) for a in (0.0, 120.0)]
+    L = _leaves(cloud, gpu_device)
+    wide = torch.zeros(4000, 6, device=gpu_device)
+    wide[:, ::2] = L["scales"].detach()
+    scales_strided = wide[:, ::2].requires_grad_(True)           # non-contiguous view
+    dL = torch.from_numpy(scenes.upstream_gradient(160, 96)).to(gpu_device)
+    imgs = []
+    for cam in cams:
+        img, _ = GaussianRasterizer(_settings(cam, 1, gpu_device))(means3D=L["means3D"], means2D=torch.zeros(4000, 3, device=gpu_device, requires_grad=True),
+                                                                    opacities=L["opacities"], shs=L["shs"], scales=scales_strided, rotations=L["rotations"])
+        imgs.append(img)
+    g1 = torch.autograd.grad(imgs[0], L["means3D"], dL, retain_graph=False)[0]       # backward of the FIRST graph after the second forward
+    ref = util.oracle_run(util.scene_input(cloud, cams[0]), dL.cpu().numpy())
+    assert util.rel_l2(g1.cpu().numpy(), ref["dL_dmeans3D"]) <= 1e-4
+
+
+def test_empty_and_all_culled(gpu_device):
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from youreditableavatar_amd import scenes
+    cam = scenes.orbit_camera(64, 48, bg=(0.3, 0.6, 0.9))
+    z = lambda *s: torch.zeros(*s, device=gpu_device, requires_grad=True)
+    # P == 0: the reference returns an all-zero image (rasterize_points.cu:81), not the background
+    img, radii = GaussianRasterizer(_settings(cam, 0, gpu_device))(means3D=z(0, 3), means2D=z(0, 3), opacities=z(0, 1), colors_precomp=z(0, 3),
+                                                                     scales=z(0, 3), rotations=z(0, 4))
+    assert img.shape == (3, 48, 64) and torch.all(img == 0) and radii.numel() == 0
+    # everything behind the camera: background image, zero gradients
+    cloud = scenes.make_cloud(500, 0, seed=34)
+    cloud["means3D"] = (cloud["means3D"] * 0.1 + cam.campos * 2.0).astype(np.float32)
+    L = _leaves(cloud, gpu_device)
+    img, radii = GaussianRasterizer(_settings(cam, 0, gpu_device))(means3D=L["means3D"], means2D=z(500, 3), opacities=L["opacities"], shs=L["shs"],
+                                                                     scales=L["scales"], rotations=L["rotations"])
+    img.sum().backward()
+    assert torch.all(radii == 0)
+    assert torch.allclose(img, torch.tensor(cam.bg, device=gpu_device).reshape(3, 1, 1).expand_as(img))
+    for k in ("means3D", "opacities", "scales", "rotations", "shs"):
+        assert torch.all(L[k].grad == 0), k
+
+
+def test_mark_visible(gpu_device):
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from oracle import oracle
+    from youreditableavatar_amd import scenes
+    cam = scenes.orbit_camera(64, 64)
+    cloud = scenes.make_cloud(5000, 0, seed=35)
+    m = cloud["means3D"].copy()
+    m[::3] = m[::3] * 0.1 + cam.campos * 2.0
+    vis = GaussianRasterizer(_settings(cam, 0, gpu_device)).markVisible(torch.from_numpy(m).to(gpu_device))
+    assert vis.dtype == torch.bool
+    assert np.array_equal(vis.cpu().numpy(), oracle.mark_visible(m, cam.viewmatrix, cam.projmatrix))
+
+
+def test_debug_mode_and_prefiltered_error(gpu_device, tmp_path, monkeypatch):
+    """debug=True synchronises after every stage; prefiltered=True with a culled Gaussian is an error
+    (auxiliary.h:156-160: printf + __trap in the reference, RuntimeError + snapshot here)."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from youreditableavatar_amd import scenes
+    monkeypatch.chdir(tmp_path)
+    cam = scenes.orbit_camera(64, 64)
+    cloud = scenes.make_cloud(300, 0, seed=36, scale_mult=5.0)
+    L = _leaves(cloud, gpu_device)
+    rs = _settings(cam, 0, gpu_device, debug=True)
+    img, _ = GaussianRasterizer(rs)(means3D=L["means3D"], means2D=torch.zeros(300, 3, device=gpu_device), opacities=L["opacities"], shs=L["shs"],
+                                    scales=L["scales"], rotations=L["rotations"])
+    img.sum().backward()
+    ref = util.oracle_run(util.scene_input(cloud, cam))
+    assert util.rel_l2(img.detach().cpu().numpy(), ref["color"]) <= 1e-4
+    cloud["means3D"][0] = cam.campos * 2.0                       # behind the camera
+    L = _leaves(cloud, gpu_device)
+    rs = rs._replace(prefiltered=True)
+    with pytest.raises(RuntimeError, match="filtered although prefiltered"):
+        GaussianRasterizer(rs)(means3D=L["means3D"], means2D=torch.zeros(300, 3, device=gpu_device), opacities=L["opacities"], shs=L["shs"],
+                               scales=L["scales"], rotations=L["rotations"])
+    assert (tmp_path / "snapshot_fw.dump").exists()
+
+
+@pytest.mark.parametrize("cfg", [2, 3])
+def test_baseline_config_full_size_vs_oracle(cfg, gpu_device):
+    """BASELINE.json configs 2 (100k / 800x800 / SH3) and 3 (500k / 1920x1080 / SH3) at FULL size against the CPU oracle."""
+    from youreditableavatar_amd import scenes
+    cloud, cams, dL = scenes.config_scene(cfg)
+    inp = util.scene_input(cloud, cams[0])
+    mine = util.hip_run(inp, dL)
+    ref = util.oracle_run(inp, dL)
+    rep = util.compare(mine, ref)
+    print(cfg, {k: f"{v:.2e}" for k, v in rep.items()})
+
+
+def test_config5_overflow_stress_properties(gpu_device):
+    """Config 5 (2M Gaussians, 2048x2048, 1 % flat 1e-8 splats, 1000 oversized splats): size-independent properties
+    at full size -- sorted lists, range bookkeeping, n_contrib bounds, finite outputs, linearity of the backward in dL."""
+    from youreditableavatar_amd import scenes
+    cloud, cams, dL = scenes.config_scene(5)
+    inp = util.scene_input(cloud, cams[0])
+    a = util.hip_run(inp, dL)
+    P, H, W = 2_000_000, 2048, 2048
+    rg = a["ranges"].astype(np.int64)
+    lens = rg[:, 1] - rg[:, 0]
+    assert lens.sum() == a["num_rendered"] == int(a["tiles_touched"].astype(np.int64).sum())
+    assert np.all(a["n_contrib"].reshape(H // 16, 16, W // 16, 16).max(axis=(1, 3)).reshape(-1) <= lens)
+    # every list is sorted by (depth, index)
+    keys = (a["depths"].view(np.uint32).astype(np.uint64)[a["point_list"]] << np.uint64(32)) | a["point_list"].astype(np.uint64)
+    starts = rg[lens > 0, 0]
+    brk = np.zeros(len(keys), bool); brk[starts] = True
+    assert np.all((keys[1:] > keys[:-1]) | brk[1:])
+    assert np.isfinite(a["color"]).all() and all(np.isfinite(a[k]).all() for k in util.GRAD_KEYS)
+    assert (a["radii"] > 0).sum() > 1_900_000 and a["tiles_touched"].max() >= 64          # oversized splats are there
+    b = util.hip_run(inp, 2.0 * dL, introspect=False)                                      # backward is linear in the upstream gradient
+    for k in ("dL_dmeans3D", "dL_dopacity", "dL_dsh"):
+        assert util.rel_l2(b[k], 2.0 * a[k]) <= 1e-5, k

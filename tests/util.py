@@ -61,7 +61,8 @@ def oracle_run(inp: dict, dL: Optional[np.ndarray] = None):
                depths=st.field("depths"), conic_opacity=st.field("conic_opacity").reshape(-1, 4),
                rgb=st.field("rgb").reshape(-1, 3), tiles_touched=st.field("tiles_touched"))
     if dL is not None:
-        out.update(oracle.backward(st, dL, **kw))
+        out.update(oracle.backward(st, dL, f64_pergauss=True, **kw))
+    out["_st"], out["_kw"] = st, kw
     return out
 
 
@@ -111,8 +112,9 @@ def hip_run(inp: dict, dL: Optional[np.ndarray] = None, device="cuda:0", debug=F
             out["rgb"] = f("rgb").reshape(-1, 3)
     if dL is not None:
         g = _C.rasterize_gaussians_backward(bg, means3D, radii, colors, scales, rots, sm, cov, view, proj, tfx, tfy,
-                                            torch.from_numpy(np.ascontiguousarray(dL, np.float32)).to(dev), sh, D, campos, geom, R, binning, img, debug)
-        names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations")
+                                            torch.from_numpy(np.ascontiguousarray(dL, np.float32)).to(dev), sh, D, campos, geom, R, binning, img, debug,
+                                            _with_conic=True)
+        names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations", "dL_dconic")
         out.update({n: v.cpu().numpy() for n, v in zip(names, g)})
     torch.cuda.synchronize()
     return out
@@ -161,6 +163,17 @@ def compare(mine: dict, ref: dict, golden_out: Optional[dict] = None, nc_frac: f
         assert frac >= nc_frac, f"n_contrib equal on {frac:.5f} of pixels"
     e = rel_l2(mine["color"], ref["color"]); rep["color"] = e
     assert e <= REL_TOL, f"color rel-L2 {e:.3e}"
+    # Against the oracle (not a fixture) the cancellation-prone tensors are checked in two steps, because the map
+    # dL_dconic -> dL_dcov3D/scales/rotations amplifies last-bit differences of its INPUT (the reference suffers the
+    # same from its atomics order): (1) the render-pass gradients themselves, (2) the per-Gaussian half evaluated in
+    # double on the kernel's OWN render-pass gradients.
+    split = "_st" in ref and "dL_dconic" in mine
+    pg = None
+    if split:
+        from oracle import oracle
+        e = rel_l2(np.asarray(mine["dL_dconic"]).reshape(-1, 4), ref["dL_dconic"]); rep["dL_dconic"] = e
+        assert e <= REL_TOL, f"dL_dconic rel-L2 {e:.3e}"
+        pg = oracle.pergauss_f64(ref["_st"], mine["dL_dmeans2D"], mine["dL_dconic"], mine["dL_dcolors"], **ref["_kw"])
     for k in GRAD_KEYS:
         if k in mine and k in ref:
             a, b = np.asarray(mine[k]), np.asarray(ref[k])
@@ -168,6 +181,13 @@ def compare(mine: dict, ref: dict, golden_out: Optional[dict] = None, nc_frac: f
                 assert np.all(a[:, 2] == 0)
             e = rel_l2(a, b); rep[k] = e
             tol = tolerance(k, golden_out)
-            assert e <= tol, f"{k} rel-L2 {e:.3e} > {tol:.1e}"
+            if k in NOISY and ("f64_" + k) in ref:   # the oracle's own fp32 rounding noise on these formulas
+                tol = max(tol, 2.0 * rel_l2(ref[k], ref["f64_" + k]))
+            if split and k in NOISY:
+                e2 = rel_l2(a, pg[k]); rep[k + "|own_inputs"] = e2
+                assert e2 <= tol, f"{k} (per-Gaussian half on own inputs) rel-L2 {e2:.3e} > {tol:.1e}"
+                assert e <= 20 * tol, f"{k} rel-L2 {e:.3e} (sanity bound {20 * tol:.1e})"
+            else:
+                assert e <= tol, f"{k} rel-L2 {e:.3e} > {tol:.1e}"
             assert np.all(a[~vis] == 0), f"{k}: culled Gaussians must have zero gradient"
     return rep

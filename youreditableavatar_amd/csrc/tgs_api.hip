@@ -168,6 +168,11 @@ int64_t tgs_forward(tgs_alloc_fn alloc, void* alloc_ctx, void* stream, int P, in
     g_err[0] = 0;
     if (!alloc) return fail(TGS_ERR_INVALID, "alloc callback is NULL");
     if (P < 0 || width <= 0 || height <= 0) return fail(TGS_ERR_INVALID, "bad sizes P=%d W=%d H=%d", P, width, height);
+    if (P == 0) {   // rasterize_points.cu:81: nothing runs, the image keeps its zero fill (empty inputs have no pointers to check)
+        if (!out_color) return fail(TGS_ERR_INVALID, "NULL required pointer");
+        HIP_TRY(hipMemsetAsync(out_color, 0, 3 * (size_t)width * height * sizeof(float), st));
+        return 0;
+    }
     if ((shs == nullptr) == (colors_precomp == nullptr)) return fail(TGS_ERR_INVALID, "provide exactly one of shs / colors_precomp");
     const bool has_sr = scales != nullptr && rotations != nullptr;
     if (has_sr == (cov3D_precomp != nullptr) || (scales == nullptr) != (rotations == nullptr))
@@ -179,10 +184,6 @@ int64_t tgs_forward(tgs_alloc_fn alloc, void* alloc_ctx, void* stream, int P, in
     if (cam.gx > 65535u || cam.gy > 65535u) return fail(TGS_ERR_INVALID, "image too large");
     const size_t N = (size_t)width * height, T = (size_t)cam.gx * cam.gy;
     const bool has_sh = shs != nullptr;
-    if (P == 0) {   // rasterize_points.cu:81: nothing runs, the image keeps its zero fill
-        HIP_TRY(hipMemsetAsync(out_color, 0, 3 * N * sizeof(float), st));
-        return 0;
-    }
 
     const uint32_t sort_cap = g_sort_cap.load(std::memory_order_relaxed);
     GeomState g; ImgState s; BinState b;

@@ -162,8 +162,9 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos,
-                                 geomBuffer, R, binningBuffer, imageBuffer, debug):
-    """RasterizeGaussiansBackwardCUDA (rasterize_points.cu:117-196); return order of :195."""
+                                 geomBuffer, R, binningBuffer, imageBuffer, debug, _with_conic=False):
+    """RasterizeGaussiansBackwardCUDA (rasterize_points.cu:117-196); return order of :195.
+    ``_with_conic`` (tests only) appends the scratch tensor dL_dconic[P,2,2]."""
     dev = _require_gpu(means3D)
     P = int(means3D.size(0))
     H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
@@ -193,7 +194,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                                   int(bool(debug)))
             if r < 0:
                 raise _err(int(r))
-    return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
+    out = (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
+    return out + (dL_dconic,) if _with_conic else out
 
 
 def mark_visible(means3D, viewmatrix, projmatrix) -> torch.Tensor:
