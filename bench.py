@@ -2,10 +2,11 @@
 """bench.py -- rasterized fragments/sec (fwd+bwd) of the MI355X-native Gaussian rasterizer.
 
 Workload (BASELINE.json configs[2]/[3]): 500k Gaussians, 1920x1080, SH degree 3 evaluated inside the
-rasterizer, orbit cameras of the 64-view batch.  A *step* = one frame = one forward + one backward
-of the rasterizer through the public drop-in API (GaussianRasterizer + autograd) with the upstream
-gradient supplied; rank r renders view (step*N + r) mod 64 (frames shard across GPUs, weak scaling),
-and at N > 1 the per-Gaussian gradients are summed with one RCCL all-reduce per tensor.
+rasterizer, orbit cameras of the 64-view batch.  A *step* = one data-parallel batch: every GPU renders
+``--views-per-gpu`` (default 8 = 64 views / 8 GPUs) frames, each one forward + one backward of the
+rasterizer through the public drop-in API (GaussianRasterizer + autograd) with the upstream gradient
+supplied, accumulating the per-Gaussian gradients in one flat buffer; at N > 1 the step ends with ONE
+RCCL all-reduce of that buffer (236 B/Gaussian).  Per-GPU work is fixed as N grows (weak scaling).
 Metric numerator: F = sum over pixels of n_contrib, counted per view outside the
 timed region.  Inputs are resident in HBM before the timed region starts.
 
@@ -32,8 +33,9 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--views-per-gpu", type=int, default=8, help="frames each GPU renders per step (64-view batch / 8 GPUs)")
     ap.add_argument("--config", type=int, default=3, help="BASELINE.json config index (1-based); 3 = 500k/1080p/SH3")
     ap.add_argument("--mode", default="sh", choices=["sh", "precomp"])
     ap.add_argument("--views", type=int, default=64)
@@ -94,11 +96,15 @@ def main():
         img.backward(dL)
         return img
 
-    def view_of(step):
-        return (step * N + rank) % V
+    VPG = a.views_per_gpu
+
+    def views_of(step):
+        """contiguous shard of the step's N*VPG-view batch (multiview.shard_views), cycling through the V orbit views"""
+        b0 = step * N * VPG + rank * VPG
+        return [(b0 + i) % V for i in range(VPG)]
 
     # fragment / instance counts of the views this rank will time (outside the timed region)
-    used = sorted({view_of(s) for s in range(a.steps)})
+    used = sorted({v for s in range(a.steps) for v in views_of(s)})
     F_view, R_view = {}, {}
     empty = torch.Tensor([])
     for v in used:
@@ -112,20 +118,21 @@ def main():
         del geom, binning, img, color, radii, nc
     torch.cuda.synchronize()
 
+    from youreditableavatar_amd.multiview import FlatGradients
+    flat = FlatGradients(params)            # parameter .grad tensors are views of one buffer: one collective per step
+
     def step(s):
-        for p in params:
-            p.grad = None
-        frame(view_of(s))
-        if dist is not None:
-            for p in params:
-                dist.all_reduce(p.grad)
+        flat.zero_()
+        for v in views_of(s):
+            frame(v)
+        flat.all_reduce()
 
     for s in range(a.warmup):
         step(s)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
-    _C.profile_begin(a.steps * 8 + 64)
+    _C.profile_begin(a.steps * VPG * 8 + 64)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for s in range(a.steps):
@@ -137,8 +144,9 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = _C.profile_end()
 
-    F_rank = sum(F_view[view_of(s)] for s in range(a.steps))
-    R_rank = sum(R_view[view_of(s)] for s in range(a.steps))
+    F_rank = sum(F_view[v] for s in range(a.steps) for v in views_of(s))
+    R_rank = sum(R_view[v] for s in range(a.steps) for v in views_of(s))
+    frames_rank = a.steps * VPG
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -155,7 +163,7 @@ def main():
         # dominant kernel and its roofline (algorithmic bytes per launch: DESIGN.md "Roofline accounting")
         kern = {k: (ms / max(n, 1)) for k, (ms, n) in prof.items() if n > 0}
         dom = max(kern, key=kern.get) if kern else None
-        Rm = R_rank / a.steps
+        Rm = R_rank / frames_rank
         Npix = W * H
         Cin = 12 * (D + 1) ** 2 if a.mode == "sh" else 12
         alg = {   # bytes per launch, single-touch model (SURVEY.md section 8d terms, regrouped per kernel)
@@ -180,15 +188,16 @@ def main():
             "value": round(value, 2), "unit": "Mfrag/s", "n_gpus": N, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"cfg{a.config}: {P} Gaussians, {W}x{H}, SH degree {D}, colour mode {a.mode}, {V}-view orbit, 1 frame per GPU per step",
-                       "frames_per_step": N, "fragments_per_frame": int(F_rank / a.steps), "instances_per_frame": int(Rm),
-                       "parallelism": f"view-sharded dp{N}" + (", RCCL all-reduce of 5 gradient tensors" if N > 1 else "")},
+            "config": {"workload": f"cfg{a.config}: {P} Gaussians, {W}x{H}, SH degree {D}, colour mode {a.mode}, {V}-view orbit, {VPG} frames per GPU per step",
+                       "frames_per_step": N * VPG, "views_per_gpu_per_step": VPG, "fragments_per_frame": int(F_rank / frames_rank),
+                       "instances_per_frame": int(Rm), "ms_per_frame_per_gpu": round(ms_per_step / VPG, 4),
+                       "parallelism": f"view-sharded dp{N}" + (", one RCCL all-reduce of the flat gradient buffer per step" if N > 1 else "")},
             "roofline": roof,
             "kernels_ms": {k: round(v, 4) for k, v in kern.items()},
             "frame_algorithmic_bytes": int(B_alg),
-            "frame_hbm_frac": round(B_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-            "other_rates": {"Minstances/s": round(R_tot / elapsed / 1e6, 2), "Mpixels/s": round(Npix * a.steps * N / elapsed / 1e6, 2),
-                            "MGaussians/s": round(P * a.steps * N / elapsed / 1e6, 2)},
+            "frame_hbm_frac": round(B_alg / (ms_per_step / VPG * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+            "other_rates": {"Minstances/s": round(R_tot / elapsed / 1e6, 2), "Mpixels/s": round(Npix * frames_rank * N / elapsed / 1e6, 2),
+                            "MGaussians/s": round(P * frames_rank * N / elapsed / 1e6, 2), "frames/s": round(frames_rank * N / elapsed, 1)},
         }
         if N == 1 and not a.no_cpu:
             out["cpu_baseline"] = cpu_baseline(cloud, cams[0], dL_np, a)

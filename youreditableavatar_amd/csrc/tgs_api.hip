@@ -11,7 +11,7 @@ namespace tgs {
 void launch_preprocess_fwd(hipStream_t, const FwdIn&, const CamParams&, const GeomState&, const ImgState&);
 void launch_scan(hipStream_t, const GeomState&, const ImgState&, uint32_t nblocks, uint32_t T, uint32_t sort_cap);
 void launch_scatter(hipStream_t, int P, const GeomState&, const ImgState&, const BinState&, uint32_t gx);
-void launch_tile_sort(hipStream_t, const GeomState&, const ImgState&, const BinState&, const float* colors, uint32_t gx, uint32_t T,
+void launch_tile_sort(hipStream_t, const GeomState&, const ImgState&, const BinState&, uint32_t gx, uint32_t T,
                       uint32_t max_count, uint32_t n_overflow, uint32_t sort_cap);
 void launch_render_fwd(hipStream_t, const ImgState&, const BinState&, int W, int H, uint32_t gx, uint32_t T, uint32_t n_nonempty, const float* bg,
                        float* out_color);
@@ -229,9 +229,8 @@ int64_t tgs_forward(tgs_alloc_fn alloc, void* alloc_ctx, void* stream, int P, in
         STAGE_BEGIN();
         launch_scatter(st, P, g, s, b, cam.gx);
         STAGE_CHECK("scatter", TGS_STAGE_SCATTER);
-        const float* colors = has_sh ? g.rgb : colors_precomp;       // rasterizer_impl.cu:321
         STAGE_BEGIN();
-        launch_tile_sort(st, g, s, b, colors, cam.gx, (uint32_t)T, meta.max_count, meta.n_overflow, sort_cap);
+        launch_tile_sort(st, g, s, b, cam.gx, (uint32_t)T, meta.max_count, meta.n_overflow, sort_cap);
         STAGE_CHECK("tile_sort", TGS_STAGE_TILE_SORT);
     }
     STAGE_BEGIN();
@@ -305,23 +304,24 @@ int64_t tgs_state_field(void* stream, const char* field, int P, int width, int h
     geom_carve(g, (char*)geom_buffer, (size_t)P, has_sh != 0, has_scale_rot != 0);
     img_carve(s, (char*)img_buffer, N, T);
     bin_carve(b, (char*)binning_buffer, (size_t)R);
-    const void* src = nullptr; size_t count = 0, esz = 4, stride = 0;
+    const void* src = nullptr; size_t count = 0, esz = 4, stride = 0, rows = 0;   // stride != 0: `rows` rows of `esz` bytes, `stride` apart
     if (!strcmp(field, "n_contrib")) { src = s.n_contrib; count = N; }
     else if (!strcmp(field, "final_T")) { src = s.final_T; count = N; }
     else if (!strcmp(field, "ranges")) { src = s.ranges; count = 2 * T; }
-    else if (!strcmp(field, "means2D")) { src = g.xy; count = 2 * (size_t)P; }
+    else if (!strcmp(field, "means2D")) { src = g.pack; count = 2 * (size_t)P; esz = 8; stride = 64; rows = (size_t)P; }
     else if (!strcmp(field, "depths")) { src = g.depth; count = (size_t)P; }
-    else if (!strcmp(field, "conic_opacity")) { src = g.conic_opacity; count = 4 * (size_t)P; }
-    else if (!strcmp(field, "rgb")) { if (!has_sh) return fail(TGS_ERR_INVALID, "rgb only exists on the SH path"); src = g.rgb; count = 3 * (size_t)P; }
+    else if (!strcmp(field, "conic_opacity")) { src = (const char*)g.pack + 8; count = 4 * (size_t)P; esz = 16; stride = 64; rows = (size_t)P; }
+    else if (!strcmp(field, "rgb")) { src = (const char*)g.pack + 24; count = 3 * (size_t)P; esz = 12; stride = 64; rows = (size_t)P; }
     else if (!strcmp(field, "tiles_touched")) { src = g.tiles_touched; count = (size_t)P; }
     else if (!strcmp(field, "tile_order")) { src = s.tile_order; count = T; }
     else if (!strcmp(field, "stamps")) { src = s.stamps; count = 4 * T; esz = 8; }
-    else if (!strcmp(field, "point_list")) { src = b.keys; count = (size_t)R; stride = 8; }   // low 32 bits of each sorted key
+    else if (!strcmp(field, "point_list")) { src = b.keys; count = (size_t)R; esz = 4; stride = 8; rows = (size_t)R; }   // low 32 bits of each sorted key
     else return fail(TGS_ERR_INVALID, "unknown field %s", field);
-    if (dst_bytes < count * esz) return fail(TGS_ERR_INVALID, "dst too small for %s", field);
+    const size_t total = stride ? rows * esz : count * esz;
+    if (dst_bytes < total) return fail(TGS_ERR_INVALID, "dst too small for %s", field);
     if (count == 0) return 0;
-    if (stride) HIP_TRY(hipMemcpy2DAsync(dst, esz, src, stride, esz, count, hipMemcpyDeviceToDevice, st));
-    else HIP_TRY(hipMemcpyAsync(dst, src, count * esz, hipMemcpyDeviceToDevice, st));
+    if (stride) HIP_TRY(hipMemcpy2DAsync(dst, esz, src, stride, esz, rows, hipMemcpyDeviceToDevice, st));
+    else HIP_TRY(hipMemcpyAsync(dst, src, total, hipMemcpyDeviceToDevice, st));
     return (int64_t)count;
 }
 

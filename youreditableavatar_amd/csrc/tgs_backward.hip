@@ -64,9 +64,8 @@ __global__ __launch_bounds__(256) void k_render_bwd_det(const ImgState s, const 
 
     // rows of the never-visited tail are zero
     for (uint32_t q = qmax + threadIdx.x; q < n; q += 256) {
-        float* row = b.slab + (size_t)b.slot[rg.x + q] * NACC;
-#pragma unroll
-        for (int k = 0; k < NACC; k++) row[k] = 0.f;
+        float4* row = b.slab + (size_t)b.slot[rg.x + q] * SLAB_ROW;
+        row[0] = make_float4(0.f, 0.f, 0.f, 0.f); row[1] = make_float4(0.f, 0.f, 0.f, 0.f); row[2] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 
     // register-staged prefetch (slot t of a round = list position qhi-1-t: back to front)
@@ -171,9 +170,8 @@ __global__ __launch_bounds__(256) void k_render_bwd_det(const ImgState s, const 
                     for (int k = 0; k < NACC; k++) r[k] += wacc[w][k][j];
                 }
             }
-            float* row = b.slab + (size_t)sSlot[j] * NACC;
-#pragma unroll
-            for (int k = 0; k < NACC; k++) row[k] = r[k];
+            float4* row = b.slab + (size_t)sSlot[j] * SLAB_ROW;
+            row[0] = make_float4(r[0], r[1], r[2], r[3]); row[1] = make_float4(r[4], r[5], r[6], r[7]); row[2] = make_float4(r[8], 0.f, 0.f, 0.f);
         }
     }
     stamp(s, tile, 3);
@@ -245,9 +243,8 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
 
     // rows of the never-visited tail are zero
     for (uint32_t q = qmax + threadIdx.x; q < n; q += BWD_THREADS) {
-        float* row = b.slab + (size_t)b.slot[rg.x + q] * NACC;
-#pragma unroll
-        for (int k = 0; k < NACC; k++) row[k] = 0.f;
+        float4* row = b.slab + (size_t)b.slot[rg.x + q] * SLAB_ROW;
+        row[0] = make_float4(0.f, 0.f, 0.f, 0.f); row[1] = make_float4(0.f, 0.f, 0.f, 0.f); row[2] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 
     float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
@@ -342,9 +339,11 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
         }
         __syncthreads();
         if (threadIdx.x < cnt) {
-            float* row = b.slab + (size_t)sSlot[threadIdx.x] * NACC;
-#pragma unroll
-            for (int k = 0; k < NACC; k++) row[k] = acc[k][threadIdx.x];
+            const uint32_t j = threadIdx.x;
+            float4* row = b.slab + (size_t)sSlot[j] * SLAB_ROW;
+            row[0] = make_float4(acc[0][j], acc[1][j], acc[2][j], acc[3][j]);
+            row[1] = make_float4(acc[4][j], acc[5][j], acc[6][j], acc[7][j]);
+            row[2] = make_float4(acc[8][j], 0.f, 0.f, 0.f);
         }
     }
     stamp(s, tile, 3);
@@ -374,10 +373,10 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
     if (live) {
         // sum of this Gaussian's tile partials, fixed order
         const uint32_t tiles = g.tiles_touched[idx];
-        const float* row = b.slab + (size_t)g.offsets[idx] * NACC;
-        for (uint32_t k = 0; k < tiles; k++, row += NACC) {
-#pragma unroll
-            for (int c = 0; c < NACC; c++) a[c] += row[c];
+        const float4* row = b.slab + (size_t)g.offsets[idx] * SLAB_ROW;
+        for (uint32_t k = 0; k < tiles; k++, row += SLAB_ROW) {
+            const float4 r0 = row[0], r1 = row[1], r2 = row[2];
+            a[0] += r0.x; a[1] += r0.y; a[2] += r0.z; a[3] += r0.w; a[4] += r1.x; a[5] += r1.y; a[6] += r1.z; a[7] += r1.w; a[8] += r2.x;
         }
         mx = in.means3D[i3]; my = in.means3D[i3 + 1]; mz = in.means3D[i3 + 2];
 
@@ -476,13 +475,26 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
     }
 
     if (HAS_SH) {
-        // computeColorFromSH backward (backward.cu:20-139); culled Gaussians write zeros
+        // computeColorFromSH backward (backward.cu:20-139); culled Gaussians write zeros.
+        // dL_dsh[k][c] = basis_k * dL_dRGB[c]; M = 16 rows (192 B, 16-B aligned) move as float4.
         float* dsh = in.dL_dsh + (size_t)idx * in.M * 3;
         const int ncoef = (in.D + 1) * (in.D + 1);
-        if (!live) {
-            for (int k = 0; k < in.M * 3; k++) dsh[k] = 0.f;
-        } else {
-            const float* sh = in.shs + (size_t)idx * in.M * 3;
+        float coef[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) coef[k] = 0.f;
+        if (live) {
+            float shv[48];
+            if (in.M == 16) {
+                const float4* s4 = reinterpret_cast<const float4*>(in.shs) + (size_t)idx * 12;
+#pragma unroll
+                for (int q = 0; q < 12; q++) {
+                    if (q * 4 < ncoef * 3) { const float4 t = s4[q]; shv[4 * q] = t.x; shv[4 * q + 1] = t.y; shv[4 * q + 2] = t.z; shv[4 * q + 3] = t.w; }
+                }
+            } else {
+                const float* sh = in.shs + (size_t)idx * in.M * 3;
+#pragma unroll
+                for (int q = 0; q < 48; q++) if (q < ncoef * 3) shv[q] = sh[q];
+            }
             const uint32_t cl = g.clamped[idx];
             dRGB[0] = a[0] * ((cl & 1u) ? 0.f : 1.f);
             dRGB[1] = a[1] * ((cl & 2u) ? 0.f : 1.f);
@@ -491,16 +503,15 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
             const float len = sqrtf(ox * ox + oy * oy + oz * oz);
             const float x = ox / len, y = oy / len, z = oz / len;
             float gxv[3] = {0.f, 0.f, 0.f}, gyv[3] = {0.f, 0.f, 0.f}, gzv[3] = {0.f, 0.f, 0.f};
-#define SH(k) sh[3 * (k) + c]
-#define DSH(k, v) { const float vv = (v); dsh[3 * (k)] = vv * dRGB[0]; dsh[3 * (k) + 1] = vv * dRGB[1]; dsh[3 * (k) + 2] = vv * dRGB[2]; }
-            DSH(0, SH_C0);
+#define SH(k) shv[3 * (k) + c]
+            coef[0] = SH_C0;
             if (in.D > 0) {
-                DSH(1, -SH_C1 * y); DSH(2, SH_C1 * z); DSH(3, -SH_C1 * x);
+                coef[1] = -SH_C1 * y; coef[2] = SH_C1 * z; coef[3] = -SH_C1 * x;
 #pragma unroll
                 for (int c = 0; c < 3; c++) { gxv[c] = -SH_C1 * SH(3); gyv[c] = -SH_C1 * SH(1); gzv[c] = SH_C1 * SH(2); }
                 if (in.D > 1) {
                     const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                    DSH(4, SH_C2_0 * xy); DSH(5, SH_C2_1 * yz); DSH(6, SH_C2_2 * (2.f * zz - xx - yy)); DSH(7, SH_C2_3 * xz); DSH(8, SH_C2_4 * (xx - yy));
+                    coef[4] = SH_C2_0 * xy; coef[5] = SH_C2_1 * yz; coef[6] = SH_C2_2 * (2.f * zz - xx - yy); coef[7] = SH_C2_3 * xz; coef[8] = SH_C2_4 * (xx - yy);
 #pragma unroll
                     for (int c = 0; c < 3; c++) {
                         gxv[c] += SH_C2_0 * y * SH(4) + SH_C2_2 * 2.f * -x * SH(6) + SH_C2_3 * z * SH(7) + SH_C2_4 * 2.f * x * SH(8);
@@ -508,9 +519,9 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
                         gzv[c] += SH_C2_1 * y * SH(5) + SH_C2_2 * 2.f * 2.f * z * SH(6) + SH_C2_3 * x * SH(7);
                     }
                     if (in.D > 2) {
-                        DSH(9, SH_C3_0 * y * (3.f * xx - yy)); DSH(10, SH_C3_1 * xy * z); DSH(11, SH_C3_2 * y * (4.f * zz - xx - yy));
-                        DSH(12, SH_C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy)); DSH(13, SH_C3_4 * x * (4.f * zz - xx - yy));
-                        DSH(14, SH_C3_5 * z * (xx - yy)); DSH(15, SH_C3_6 * x * (xx - 3.f * yy));
+                        coef[9] = SH_C3_0 * y * (3.f * xx - yy); coef[10] = SH_C3_1 * xy * z; coef[11] = SH_C3_2 * y * (4.f * zz - xx - yy);
+                        coef[12] = SH_C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy); coef[13] = SH_C3_4 * x * (4.f * zz - xx - yy);
+                        coef[14] = SH_C3_5 * z * (xx - yy); coef[15] = SH_C3_6 * x * (xx - 3.f * yy);
 #pragma unroll
                         for (int c = 0; c < 3; c++) {
                             gxv[c] += (SH_C3_0 * SH(9) * 3.f * 2.f * xy + SH_C3_1 * SH(10) * yz + SH_C3_2 * SH(11) * -2.f * xy +
@@ -526,9 +537,6 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
                 }
             }
 #undef SH
-#undef DSH
-            // coefficients above the active degree keep the reference's zeros (torch::zeros, rasterize_points.cu:157)
-            for (int k = ncoef * 3; k < in.M * 3; k++) dsh[k] = 0.f;
             const float ddx = gxv[0] * dRGB[0] + gxv[1] * dRGB[1] + gxv[2] * dRGB[2];
             const float ddy = gyv[0] * dRGB[0] + gyv[1] * dRGB[1] + gyv[2] * dRGB[2];
             const float ddz = gzv[0] * dRGB[0] + gzv[1] * dRGB[1] + gzv[2] * dRGB[2];
@@ -538,6 +546,22 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
             dmean[0] += ((+sum2 - ox * ox) * ddx - oy * ox * ddy - oz * ox * ddz) * invsum32;
             dmean[1] += (-ox * oy * ddx + (sum2 - oy * oy) * ddy - oz * oy * ddz) * invsum32;
             dmean[2] += (-ox * oz * ddx - oy * oz * ddy + (sum2 - oz * oz) * ddz) * invsum32;
+        }
+        // coefficients above the active degree (and culled Gaussians) keep the reference's zeros (torch::zeros, rasterize_points.cu:157)
+        if (in.M == 16) {
+            float4* d4 = reinterpret_cast<float4*>(dsh);
+#pragma unroll
+            for (int q = 0; q < 12; q++) {
+                float o[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) { const int i = 4 * q + t; o[t] = coef[i / 3] * dRGB[i % 3]; }
+                d4[q] = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        } else {
+            for (int k = 0; k < in.M; k++) {
+                const float ck = k < 16 ? coef[k < 16 ? k : 0] : 0.f;
+                dsh[3 * k] = ck * dRGB[0]; dsh[3 * k + 1] = ck * dRGB[1]; dsh[3 * k + 2] = ck * dRGB[2];
+            }
         }
     }
 

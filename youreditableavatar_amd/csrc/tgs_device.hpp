@@ -12,6 +12,7 @@ constexpr int WAVE = 64;
 constexpr int PRE_BLOCK = 256;      // Gaussians per workgroup in the per-Gaussian kernels
 constexpr uint32_t SORT_LDS_CAP = 8192;   // longest tile list sorted inside LDS (64 KiB of u64 keys)
 constexpr int COOP_TILES = 64;
+constexpr int SLAB_ROW = 3;          // float4 per gradient-slab row: 9 sums padded to 48 B so rows move as three 16-B accesses
 #ifndef TGS_CSTRIDE
 #define TGS_CSTRIDE 16
 #endif
@@ -30,10 +31,12 @@ struct Meta {                 // lives at the start of the image buffer
 };
 
 struct GeomState {
-    float2* xy;               // pixel-space mean                   (geomState.means2D)
+    // One 64-byte line per Gaussian with everything the per-tile gather needs (geomState.means2D,
+    // .conic_opacity, .rgb of the reference, plus the tile rectangle and the slab offset):
+    //   pack[4g+0] = (x, y, conic.x, conic.y)   pack[4g+1] = (conic.z, opacity, r, g)
+    //   pack[4g+2] = (b, bits(minx | miny<<16), bits(maxx | maxy<<16), bits(offset))   pack[4g+3] unused
+    float4* pack;
     float* depth;             // view-space z                       (geomState.depths)
-    float4* conic_opacity;    // inverse 2D covariance + opacity    (geomState.conic_opacity)
-    float* rgb;               // SH colour, SH path only            (geomState.rgb)
     float* cov3D;             // 6 floats, scale/rot path only      (geomState.cov3D)
     uint8_t* clamped;         // 3 clamp bits per Gaussian          (geomState.clamped)
     ushort4* rect;            // tile rectangle (minx, miny, maxx, maxy)
@@ -58,7 +61,7 @@ struct BinState {
     float4* recB;             //                              conic.z, opacity, r, g
     float2* recC;             //                              b, bits(gaussian idx)
     uint32_t* slot;           // offsets[g] + ordinal of this tile in g's rectangle (gradient slab row)
-    float* slab;              // backward scratch: 9 floats per instance, Gaussian-major rows (see tgs_backward.hip)
+    float4* slab;             // backward scratch: SLAB_ROW float4 (9 sums + padding) per instance, Gaussian-major rows
 };
 
 template <typename T>
@@ -73,8 +76,8 @@ __host__ __device__ inline size_t n_blocks(size_t P) { return (P + PRE_BLOCK - 1
 __host__ __device__ inline size_t geom_carve(GeomState& g, char* base, size_t P, bool has_sh, bool has_scale_rot)
 {
     char* p = base;
-    carve(p, g.xy, P); carve(p, g.depth, P); carve(p, g.conic_opacity, P);
-    carve(p, g.rgb, has_sh ? 3 * P : 0); carve(p, g.cov3D, has_scale_rot ? 6 * P : 0);
+    (void)has_sh;
+    carve(p, g.pack, 4 * P); carve(p, g.depth, P); carve(p, g.cov3D, has_scale_rot ? 6 * P : 0);
     carve(p, g.clamped, P); carve(p, g.rect, P); carve(p, g.tiles_touched, P); carve(p, g.offsets, P);
     carve(p, g.block_sums, n_blocks(P) + 1);
     return (size_t)(p - base) + 256;
@@ -90,7 +93,7 @@ __host__ __device__ inline size_t img_carve(ImgState& s, char* base, size_t N, s
 __host__ __device__ inline size_t bin_carve(BinState& b, char* base, size_t R)
 {
     char* p = base;
-    carve(p, b.keys, R); carve(p, b.recA, R); carve(p, b.recB, R); carve(p, b.recC, R); carve(p, b.slot, R); carve(p, b.slab, 9 * R);
+    carve(p, b.keys, R); carve(p, b.recA, R); carve(p, b.recB, R); carve(p, b.recC, R); carve(p, b.slot, R); carve(p, b.slab, (size_t)SLAB_ROW * R);
     return (size_t)(p - base) + 256;
 }
 

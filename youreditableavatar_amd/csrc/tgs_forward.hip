@@ -79,17 +79,31 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd(const FwdIn in, co
                 get_rect(pix, piy, (int)my_radius, cam.gx, cam.gy, minx, miny, maxx, maxy);
                 tiles = (maxx - minx) * (maxy - miny);
                 if (tiles != 0) {
+                    float col0, col1, col2;
                     if (HAS_SH) {
                         // computeColorFromSH (forward.cu:20-71)
                         float dx = mx - camx, dy = my - camy, dz = mz - camz;
                         const float len = sqrtf(dx * dx + dy * dy + dz * dz);
                         const float x = dx / len, y = dy / len, z = dz / len;
-                        const float* sh = in.shs + (size_t)idx * in.M * 3;
+                        // coefficients of the active degree; M = 16 rows are 192 B and 16-B aligned: read them as float4
+                        float shv[48];
+                        const int ncoef = (in.D + 1) * (in.D + 1);
+                        if (in.M == 16) {
+                            const float4* s4 = reinterpret_cast<const float4*>(in.shs) + (size_t)idx * 12;
+#pragma unroll
+                            for (int q = 0; q < 12; q++) {
+                                if (q * 4 < ncoef * 3) { const float4 t = s4[q]; shv[4 * q] = t.x; shv[4 * q + 1] = t.y; shv[4 * q + 2] = t.z; shv[4 * q + 3] = t.w; }
+                            }
+                        } else {
+                            const float* sh = in.shs + (size_t)idx * in.M * 3;
+#pragma unroll
+                            for (int q = 0; q < 48; q++) if (q < ncoef * 3) shv[q] = sh[q];
+                        }
                         float res[3];
                         uint32_t clampbits = 0;
 #pragma unroll
                         for (int c = 0; c < 3; c++) {
-#define SH(k) sh[3 * (k) + c]
+#define SH(k) shv[3 * (k) + c]
                             float r = SH_C0 * SH(0);
                             if (in.D > 0) {
                                 r = r - SH_C1 * y * SH(1) + SH_C1 * z * SH(2) - SH_C1 * x * SH(3);
@@ -111,13 +125,17 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd(const FwdIn in, co
                             if (r < 0.f) clampbits |= 1u << c;
                             res[c] = fmaxf(r, 0.0f);
                         }
-                        g.rgb[3 * (size_t)idx] = res[0]; g.rgb[3 * (size_t)idx + 1] = res[1]; g.rgb[3 * (size_t)idx + 2] = res[2];
+                        col0 = res[0]; col1 = res[1]; col2 = res[2];
                         g.clamped[idx] = (uint8_t)clampbits;
+                    } else {
+                        col0 = in.colors_precomp[3 * (size_t)idx]; col1 = in.colors_precomp[3 * (size_t)idx + 1]; col2 = in.colors_precomp[3 * (size_t)idx + 2];
                     }
                     g.depth[idx] = view_z;
                     my_radius_i = (int)my_radius;
-                    g.xy[idx] = make_float2(pix, piy);
-                    g.conic_opacity[idx] = make_float4(conx, cony, conz, in.opacities[idx]);
+                    float4* pk = g.pack + 4 * (size_t)idx;
+                    pk[0] = make_float4(pix, piy, conx, cony);
+                    pk[1] = make_float4(conz, in.opacities[idx], col0, col1);
+                    pk[2] = make_float4(col2, __uint_as_float(minx | (miny << 16)), __uint_as_float(maxx | (maxy << 16)), 0.f);   // .w: slab offset, k_scatter
                     // per-tile instance count (replaces the tile half of the reference's 64-bit sort keys)
                     for (uint32_t ty = miny; ty < maxy; ty++)
                         for (uint32_t tx = minx; tx < maxx; tx++) atomicAdd(&s.tile_count[(size_t)(ty * cam.gx + tx) * CSTRIDE], 1u);
@@ -177,38 +195,59 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const 
         }
         if (threadIdx.x == 0) s.meta->R = carry;
     } else {
+        // Tile pass.  One workgroup is latency bound, so every global access is issued 8-deep: the counters of a
+        // super-chunk of 8192 tiles are pulled into LDS with 8 independent loads per thread, and the scan, the
+        // longest-list search and the length histogram then run out of LDS.
+        constexpr uint32_t SC = SCAN_THREADS * 8;
+        __shared__ uint32_t lc[SC];
+        __shared__ uint32_t hist[34];
         if (threadIdx.x == 0) ovf_n = 0;
+        if (threadIdx.x < 34) hist[threadIdx.x] = 0;
         __syncthreads();
         unsigned long long carry = 0;
         uint32_t mx = 0;
-        for (uint32_t base = 0; base < T; base += SCAN_THREADS * SCAN_ITEMS) {
-            uint32_t v[SCAN_ITEMS];
-            unsigned long long sum = 0;
-            const uint32_t i0 = base + threadIdx.x * SCAN_ITEMS;
+        for (uint32_t sc = 0; sc < T; sc += SC) {
+            const uint32_t n = min(SC, T - sc);
+            uint32_t v[8];
 #pragma unroll
-            for (int k = 0; k < SCAN_ITEMS; k++) { v[k] = (i0 + k < T) ? s.tile_count[(size_t)(i0 + k) * CSTRIDE] : 0u; sum += v[k]; mx = v[k] > mx ? v[k] : mx; }
+            for (int k = 0; k < 8; k++) { const uint32_t i = k * SCAN_THREADS + threadIdx.x; v[k] = i < n ? s.tile_count[(size_t)(sc + i) * CSTRIDE] : 0u; }
+#pragma unroll
+            for (int k = 0; k < 8; k++) lc[k * SCAN_THREADS + threadIdx.x] = v[k];
+            __syncthreads();
+            unsigned long long sum = 0;
+            const uint32_t i0 = threadIdx.x * 8;
+#pragma unroll
+            for (int k = 0; k < 8; k++) { v[k] = lc[i0 + k]; sum += v[k]; mx = v[k] > mx ? v[k] : mx; }
             unsigned long long tot;
             unsigned long long ex = block_exscan_u64(sum, lds, tot) + carry;
 #pragma unroll
-            for (int k = 0; k < SCAN_ITEMS; k++) {
-                if (i0 + k < T) {
-                    s.ranges[i0 + k] = make_uint2((uint32_t)ex, (uint32_t)(ex + v[k]));
-                    s.cursor[(size_t)(i0 + k) * CSTRIDE] = (uint32_t)ex;
-                    if (v[k] > sort_cap) s.ovf_tiles[atomicAdd(&ovf_n, 1u)] = i0 + k;
+            for (int k = 0; k < 8; k++) {
+                if (i0 + k < n) {
+                    const uint32_t t = sc + i0 + k;
+                    s.ranges[t] = make_uint2((uint32_t)ex, (uint32_t)(ex + v[k]));
+                    s.cursor[(size_t)t * CSTRIDE] = (uint32_t)ex;
+                    if (v[k] > sort_cap) s.ovf_tiles[atomicAdd(&ovf_n, 1u)] = t;
+                    atomicAdd(&hist[v[k] ? 32 - __builtin_clz(v[k]) : 0], 1u);
                 }
                 ex += v[k];
             }
             carry += tot;
+            __syncthreads();
         }
         // tiles by descending list length (power-of-two buckets; order inside a bucket does not matter)
-        __shared__ uint32_t hist[34];
-        if (threadIdx.x < 34) hist[threadIdx.x] = 0;
+        if (threadIdx.x == 0) { uint32_t acc = 0; for (int b2 = 33; b2-- > 0;) { const uint32_t h = hist[b2]; hist[b2] = acc; if (b2 == 1) s.meta->n_nonempty = acc + h; acc += h; } }
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < T; i += SCAN_THREADS) { const uint32_t c = s.tile_count[(size_t)i * CSTRIDE]; atomicAdd(&hist[c ? 32 - __builtin_clz(c) : 0], 1u); }
-        __syncthreads();
-        if (threadIdx.x == 0) { uint32_t acc = 0; for (int bk = 33; bk-- > 0;) { const uint32_t h = hist[bk]; hist[bk] = acc; if (bk == 1) s.meta->n_nonempty = acc + h; acc += h; } }
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < T; i += SCAN_THREADS) { const uint32_t c = s.tile_count[(size_t)i * CSTRIDE]; s.tile_order[atomicAdd(&hist[c ? 32 - __builtin_clz(c) : 0], 1u)] = i; }
+        for (uint32_t sc = 0; sc < T; sc += SC) {
+            const uint32_t n = min(SC, T - sc);
+            uint2 r[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) { const uint32_t i = k * SCAN_THREADS + threadIdx.x; r[k] = i < n ? s.ranges[sc + i] : make_uint2(0u, 0u); }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t i = k * SCAN_THREADS + threadIdx.x;
+                if (i < n) { const uint32_t c = r[k].y - r[k].x; s.tile_order[atomicAdd(&hist[c ? 32 - __builtin_clz(c) : 0], 1u)] = sc + i; }
+            }
+        }
         mx = wave_max_u32(mx);
         if ((threadIdx.x & 63) == 0) lds_max[threadIdx.x >> 6] = mx;
         __syncthreads();
@@ -238,7 +277,10 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_scatter(int P, const GeomState g,
     __syncthreads();
     uint32_t base = g.block_sums[blockIdx.x];
     for (int i = 0; i < wv; i++) base += wtot[i];
-    if (idx < P) g.offsets[idx] = base + inc - tiles;
+    if (idx < P) {
+        g.offsets[idx] = base + inc - tiles;
+        if (tiles > 0) reinterpret_cast<uint32_t*>(g.pack + 4 * (size_t)idx + 2)[3] = base + inc - tiles;
+    }
 
     if (tiles > 0) {
         if (tiles <= (uint32_t)COOP_TILES) {
@@ -333,22 +375,21 @@ __device__ __forceinline__ uint32_t block_mask(float2 xy, float4 co, uint32_t tx
 // gathers the per-instance record of sorted entry i of a tile (what renderCUDA fetches per entry:
 // forward.cu:315-321,355 and backward.cu:470-480)
 __device__ __forceinline__ void finalize_entry(unsigned long long key, uint32_t pos, uint32_t tile, uint32_t gx, const GeomState& g,
-                                               const BinState& b, const float* colors)
+                                               const BinState& b)
 {
     const uint32_t id = (uint32_t)key;
-    const float2 xy = g.xy[id];
-    const float4 co = g.conic_opacity[id];
-    const float cr = colors[3 * (size_t)id], cg = colors[3 * (size_t)id + 1], cb = colors[3 * (size_t)id + 2];
-    const ushort4 r = g.rect[id];
+    const float4* pk = g.pack + 4 * (size_t)id;               // one 64-B line per Gaussian
+    const float4 p0 = pk[0], p1 = pk[1], p2 = pk[2];
+    const uint32_t rmin = __float_as_uint(p2.y), rmax = __float_as_uint(p2.z);
+    const uint32_t minx = rmin & 0xffffu, miny = rmin >> 16, maxx = rmax & 0xffffu;
     const uint32_t tx = tile % gx, ty = tile / gx;
-    b.recA[pos] = make_float4(xy.x, xy.y, co.x, co.y);
-    b.recB[pos] = make_float4(co.z, co.w, cr, cg);
-    b.recC[pos] = make_float2(cb, __uint_as_float(block_mask(xy, co, tx, ty)));
-    b.slot[pos] = g.offsets[id] + (ty - r.y) * ((uint32_t)r.z - r.x) + (tx - r.x);
+    b.recA[pos] = p0;
+    b.recB[pos] = p1;
+    b.recC[pos] = make_float2(p2.x, __uint_as_float(block_mask(make_float2(p0.x, p0.y), make_float4(p0.z, p0.w, p1.x, p1.y), tx, ty)));
+    b.slot[pos] = __float_as_uint(p2.w) + (ty - miny) * (maxx - minx) + (tx - minx);
 }
 
-__global__ __launch_bounds__(256) void k_tile_sort(const GeomState g, const ImgState s, const BinState b, const float* colors, uint32_t gx,
-                                                   uint32_t sort_cap)
+__global__ __launch_bounds__(256) void k_tile_sort(const GeomState g, const ImgState s, const BinState b, uint32_t gx, uint32_t sort_cap)
 {
     extern __shared__ unsigned long long lk[];
     const uint32_t tile = blockIdx.x;
@@ -369,7 +410,7 @@ __global__ __launch_bounds__(256) void k_tile_sort(const GeomState g, const ImgS
     for (uint32_t i = threadIdx.x; i < n; i += 256) {
         const unsigned long long key = lk[i];
         b.keys[rg.x + i] = key;
-        finalize_entry(key, rg.x + i, tile, gx, g, b, colors);
+        finalize_entry(key, rg.x + i, tile, gx, g, b);
     }
 }
 
@@ -422,13 +463,13 @@ __global__ __launch_bounds__(256) void k_ovf_global(const ImgState s, const BinS
     cmp_swap(b.keys + rg.x, i, l, n);
 }
 
-__global__ __launch_bounds__(256) void k_ovf_finalize(const GeomState g, const ImgState s, const BinState b, const float* colors, uint32_t gx)
+__global__ __launch_bounds__(256) void k_ovf_finalize(const GeomState g, const ImgState s, const BinState b, uint32_t gx)
 {
     const uint32_t tile = s.ovf_tiles[blockIdx.y];
     const uint2 rg = s.ranges[tile];
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= rg.y - rg.x) return;
-    finalize_entry(b.keys[rg.x + i], rg.x + i, tile, gx, g, b, colors);
+    finalize_entry(b.keys[rg.x + i], rg.x + i, tile, gx, g, b);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -609,12 +650,12 @@ void launch_scatter(hipStream_t st, int P, const GeomState& g, const ImgState& s
     hipLaunchKernelGGL(k_scatter, dim3((unsigned)n_blocks(P)), dim3(PRE_BLOCK), 0, st, P, g, s, b, gx);
 }
 static uint32_t host_next_pow2(uint32_t n) { uint32_t p = 1; while (p < n) p <<= 1; return p; }
-void launch_tile_sort(hipStream_t st, const GeomState& g, const ImgState& s, const BinState& b, const float* colors, uint32_t gx, uint32_t T,
+void launch_tile_sort(hipStream_t st, const GeomState& g, const ImgState& s, const BinState& b, uint32_t gx, uint32_t T,
                       uint32_t max_count, uint32_t n_overflow, uint32_t sort_cap)
 {
     const uint32_t cap = max_count < sort_cap ? max_count : sort_cap;
     const size_t lds = (size_t)(cap ? cap : 1) * 8;
-    hipLaunchKernelGGL(k_tile_sort, dim3(T), dim3(256), lds, st, g, s, b, colors, gx, sort_cap);
+    hipLaunchKernelGGL(k_tile_sort, dim3(T), dim3(256), lds, st, g, s, b, gx, sort_cap);
     if (n_overflow == 0) return;
     // lists longer than sort_cap: sorted in global memory by many workgroups, LDS for strides < sort_cap
     const uint32_t npad = host_next_pow2(max_count);
@@ -626,7 +667,7 @@ void launch_tile_sort(hipStream_t st, const GeomState& g, const ImgState& s, con
         for (uint32_t j = k >> 2; j >= sort_cap; j >>= 1) hipLaunchKernelGGL(k_ovf_global, ggrid, dim3(256), 0, st, s, b, k, j, 0);
         hipLaunchKernelGGL(k_ovf_local, lgrid, dim3(256), ldsb, st, s, b, k, sort_cap);
     }
-    hipLaunchKernelGGL(k_ovf_finalize, dim3((max_count + 255) / 256, n_overflow), dim3(256), 0, st, g, s, b, colors, gx);
+    hipLaunchKernelGGL(k_ovf_finalize, dim3((max_count + 255) / 256, n_overflow), dim3(256), 0, st, g, s, b, gx);
 }
 void launch_render_fwd(hipStream_t st, const ImgState& s, const BinState& b, int W, int H, uint32_t gx, uint32_t T, uint32_t n_nonempty,
                        const float* bg, float* out_color)
