@@ -290,16 +290,22 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
                 T = quad_bcast<3>(Town);
                 // accum_rec walk (backward.cu:516-518): ar <- la*lc + (1-la)*ar with (la, lc) of the PREVIOUS step
                 const float m0 = aeff * c0, m1 = aeff * c1, m2 = aeff * c2;
-                float a0own = 0.f, a1own = 0.f, a2own = 0.f;
-#define TGS_BWD_STEP(E)                                                                                        \
-                {                                                                                              \
-                    const float om = 1.f - last_alpha;                                                         \
-                    ar0 = lm0 + om * ar0; ar1 = lm1 + om * ar1; ar2 = lm2 + om * ar2;                          \
-                    if (e == E) { a0own = ar0; a1own = ar1; a2own = ar2; }                                     \
-                    last_alpha = quad_bcast<E>(aeff); lm0 = quad_bcast<E>(m0); lm1 = quad_bcast<E>(m1); lm2 = quad_bcast<E>(m2); \
+                float a0own, a1own, a2own;
+                {   // step 0 uses the state left by the previous group
+                    const float om = 1.f - last_alpha;
+                    ar0 = lm0 + om * ar0; ar1 = lm1 + om * ar1; ar2 = lm2 + om * ar2;
+                    a0own = ar0; a1own = ar1; a2own = ar2;
                 }
-                TGS_BWD_STEP(0) TGS_BWD_STEP(1) TGS_BWD_STEP(2) TGS_BWD_STEP(3)
+#define TGS_BWD_STEP(E)  /* steps 1..3 use (alpha, alpha*colour) of entry E-1, fetched by DPP inside the add */ \
+                {                                                                                              \
+                    const float om = 1.f - quad_bcast<E - 1>(aeff);                                            \
+                    ar0 *= om; ar1 *= om; ar2 *= om;                                                           \
+                    TGS_QUAD_BCAST_ADD(ar0, m0, E - 1); TGS_QUAD_BCAST_ADD(ar1, m1, E - 1); TGS_QUAD_BCAST_ADD(ar2, m2, E - 1); \
+                    if (e == E) { a0own = ar0; a1own = ar1; a2own = ar2; }                                     \
+                }
+                TGS_BWD_STEP(1) TGS_BWD_STEP(2) TGS_BWD_STEP(3)
 #undef TGS_BWD_STEP
+                last_alpha = quad_bcast<3>(aeff); lm0 = quad_bcast<3>(m0); lm1 = quad_bcast<3>(m1); lm2 = quad_bcast<3>(m2);
                 // this lane's (pixel, entry) gradient terms, backward.cu:507-555 (all zero for a skipped entry)
                 const float dchannel_dcolor = aeff * Town;
                 float dL_dalpha = 0.0f;

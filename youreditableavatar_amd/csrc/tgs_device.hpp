@@ -239,6 +239,9 @@ __device__ __forceinline__ float quad_prefix_product(float x, int e)
     const float y2 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x44, 0xf, 0xf, false));   // quad_perm [0,1,0,1]
     return x * ((e < 2) ? 1.0f : y2);
 }
+// x + (value of lane quad base + E): one v_add_f32 with a DPP source
+#define TGS_QUAD_BCAST_ADD(x, y, E) \
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y), (E) * 0x55, 0xf, 0xf, false))
 // value of lane (quad base + E) broadcast to the 4 lanes of each quad
 template <int E>
 __device__ __forceinline__ float quad_bcast(float v)
@@ -270,7 +273,7 @@ __device__ __forceinline__ float tgs_exp(float x)
 __device__ __forceinline__ float tgs_div(float a, float b)
 {
 #if TGS_FAST_MATH
-    return __fdividef(a, b);
+    return a * __builtin_amdgcn_rcpf(b);               // v_rcp_f32 (1 ulp) + v_mul_f32
 #else
     return a / b;
 #endif
@@ -287,22 +290,20 @@ __device__ __forceinline__ void set_wave_priority(uint32_t n)
 // Result: r[k], and in row e (lanes 16e..16e+15) every lane holds the total of entry e, component k.
 // v_permlane32_swap / v_permlane16_swap halve the register count while they fold lane halves, so the
 // whole reduction is 90 VALU operations instead of 36 x 6.
-// NOTE (hipcc / ROCm 7.2, gfx950): `r[0] + r[1]` written directly on the builtin's two results is
-// miscompiled to `v_add_f32 v, r0, r0` (seen in the .s; the second result is dropped).  Passing both
-// through an empty asm keeps them apart.  tgs_selftest_reduce36 (tests/) checks the result on hardware.
+// NOTE (hipcc / ROCm 7.2, gfx950): `r[0] + r[1]` written directly on the two results of
+// __builtin_amdgcn_permlane{16,32}_swap is miscompiled to `v_add_f32 v, r0, r0` (seen in the .s; the second
+// result is dropped), so the swap is issued as inline asm.  tgs_selftest_reduce36 (tests/) checks it on hardware.
 __device__ __forceinline__ float swap32_add(float x, float y)
 {
-    auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y), false, false);
-    unsigned r0 = r[0], r1 = r[1];
-    asm volatile("" : "+v"(r0), "+v"(r1));
-    return __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
+    // in-place swap of x's upper 32 lanes with y's lower 32 lanes; s_nop 1 = the 2 wait states a VALU-written
+    // operand needs before a permlane swap reads it (hipcc pads nothing inside asm)
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+    return x + y;
 }
 __device__ __forceinline__ float swap16_add(float x, float y)
 {
-    auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y), false, false);
-    unsigned r0 = r[0], r1 = r[1];
-    asm volatile("" : "+v"(r0), "+v"(r1));
-    return __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+    return x + y;
 }
 __device__ __forceinline__ void wave_reduce36(const float (&v)[36], float (&r)[9])
 {
