@@ -364,8 +364,18 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
     const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
     const ViewMat V = load_mat(cam.view), PM = load_mat(cam.proj);
     const float camx = cam.campos[0], camy = cam.campos[1], camz = cam.campos[2];
-    if (idx >= in.P) return;
-    const size_t i3 = 3 * (size_t)idx;
+    // SH rows in, dL_dsh rows out: staged through LDS so that global memory sees 16 B per lane, fully coalesced
+    __shared__ float4 sh_lds[HAS_SH ? PRE_BLOCK * 12 : 1];
+    const bool sh_staged = HAS_SH && in.M == 16;
+    const size_t base4 = (size_t)blockIdx.x * PRE_BLOCK * 12, total4 = (size_t)in.P * 12;
+    if (sh_staged) {
+        const float4* s4 = reinterpret_cast<const float4*>(in.shs);
+#pragma unroll
+        for (int q = 0; q < 12; q++) { const size_t i = base4 + q * PRE_BLOCK + threadIdx.x; if (i < total4) sh_lds[q * PRE_BLOCK + threadIdx.x] = s4[i]; }
+        __syncthreads();
+    }
+    const bool in_range = idx < in.P;
+    const size_t i3 = 3 * (size_t)(in_range ? idx : 0);
     float a[NACC];
 #pragma unroll
     for (int k = 0; k < NACC; k++) a[k] = 0.f;
@@ -373,7 +383,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
     float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float dscale[3] = {0.f, 0.f, 0.f};
     float drot[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool live = in.radii[idx] > 0;                   // backward.cu:156,367
+    const bool live = in_range && in.radii[idx] > 0;        // backward.cu:156,367
     float mx = 0.f, my = 0.f, mz = 0.f;
     float dRGB[3] = {0.f, 0.f, 0.f};
     if (live) {
@@ -490,11 +500,10 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
         for (int k = 0; k < 16; k++) coef[k] = 0.f;
         if (live) {
             float shv[48];
-            if (in.M == 16) {
-                const float4* s4 = reinterpret_cast<const float4*>(in.shs) + (size_t)idx * 12;
+            if (sh_staged) {
 #pragma unroll
                 for (int q = 0; q < 12; q++) {
-                    if (q * 4 < ncoef * 3) { const float4 t = s4[q]; shv[4 * q] = t.x; shv[4 * q + 1] = t.y; shv[4 * q + 2] = t.z; shv[4 * q + 3] = t.w; }
+                    if (q * 4 < ncoef * 3) { const float4 t = sh_lds[threadIdx.x * 12 + q]; shv[4 * q] = t.x; shv[4 * q + 1] = t.y; shv[4 * q + 2] = t.z; shv[4 * q + 3] = t.w; }
                 }
             } else {
                 const float* sh = in.shs + (size_t)idx * in.M * 3;
@@ -554,16 +563,20 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
             dmean[2] += (-ox * oz * ddx - oy * oz * ddy + (sum2 - oz * oz) * ddz) * invsum32;
         }
         // coefficients above the active degree (and culled Gaussians) keep the reference's zeros (torch::zeros, rasterize_points.cu:157)
-        if (in.M == 16) {
-            float4* d4 = reinterpret_cast<float4*>(dsh);
+        if (sh_staged) {
+            __syncthreads();                                   // every thread has consumed its SH row
 #pragma unroll
             for (int q = 0; q < 12; q++) {
                 float o[4];
 #pragma unroll
                 for (int t = 0; t < 4; t++) { const int i = 4 * q + t; o[t] = coef[i / 3] * dRGB[i % 3]; }
-                d4[q] = make_float4(o[0], o[1], o[2], o[3]);
+                sh_lds[threadIdx.x * 12 + q] = make_float4(o[0], o[1], o[2], o[3]);
             }
-        } else {
+            __syncthreads();
+            float4* d4 = reinterpret_cast<float4*>(in.dL_dsh);
+#pragma unroll
+            for (int q = 0; q < 12; q++) { const size_t i = base4 + q * PRE_BLOCK + threadIdx.x; if (i < total4) d4[i] = sh_lds[q * PRE_BLOCK + threadIdx.x]; }
+        } else if (in_range) {
             for (int k = 0; k < in.M; k++) {
                 const float ck = k < 16 ? coef[k < 16 ? k : 0] : 0.f;
                 dsh[3 * k] = ck * dRGB[0]; dsh[3 * k + 1] = ck * dRGB[1]; dsh[3 * k + 2] = ck * dRGB[2];
@@ -572,6 +585,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
     }
 
     // every output element is written (zeros for culled Gaussians)
+    if (!in_range) return;
     in.dL_dmean2D[i3] = a[3]; in.dL_dmean2D[i3 + 1] = a[4]; in.dL_dmean2D[i3 + 2] = 0.f;   // .z never written: backward.cu:545-546
     reinterpret_cast<float4*>(in.dL_dconic)[idx] = make_float4(a[5], a[6], 0.f, a[7]);   // .z never written: backward.cu:549-551
     in.dL_dopacity[idx] = a[8];

@@ -30,6 +30,17 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd(const FwdIn in, co
     uint32_t tiles = 0;
     const ViewMat V = load_mat(cam.view), PM = load_mat(cam.proj);      // uniform -> scalar loads, before any store
     const float camx = cam.campos[0], camy = cam.campos[1], camz = cam.campos[2];
+    // SH rows of the workgroup's 256 Gaussians (M = 16: 192 B each, 48 KB in all) are fetched with fully coalesced
+    // 16-B-per-lane loads into LDS; a per-thread walk over its own 192-B row would touch 64 lines per instruction.
+    __shared__ float4 sh_lds[HAS_SH ? PRE_BLOCK * 12 : 1];
+    const bool sh_staged = HAS_SH && in.M == 16;
+    if (sh_staged) {
+        const float4* s4 = reinterpret_cast<const float4*>(in.shs);
+        const size_t base4 = (size_t)blockIdx.x * PRE_BLOCK * 12, total4 = (size_t)in.P * 12;
+#pragma unroll
+        for (int q = 0; q < 12; q++) { const size_t i = base4 + q * PRE_BLOCK + threadIdx.x; if (i < total4) sh_lds[q * PRE_BLOCK + threadIdx.x] = s4[i]; }
+        __syncthreads();
+    }
     if (idx < in.P) {
         int my_radius_i = 0;
         uint32_t minx = 0, miny = 0, maxx = 0, maxy = 0;
@@ -88,11 +99,10 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd(const FwdIn in, co
                         // coefficients of the active degree; M = 16 rows are 192 B and 16-B aligned: read them as float4
                         float shv[48];
                         const int ncoef = (in.D + 1) * (in.D + 1);
-                        if (in.M == 16) {
-                            const float4* s4 = reinterpret_cast<const float4*>(in.shs) + (size_t)idx * 12;
+                        if (sh_staged) {
 #pragma unroll
                             for (int q = 0; q < 12; q++) {
-                                if (q * 4 < ncoef * 3) { const float4 t = s4[q]; shv[4 * q] = t.x; shv[4 * q + 1] = t.y; shv[4 * q + 2] = t.z; shv[4 * q + 3] = t.w; }
+                                if (q * 4 < ncoef * 3) { const float4 t = sh_lds[threadIdx.x * 12 + q]; shv[4 * q] = t.x; shv[4 * q + 1] = t.y; shv[4 * q + 2] = t.z; shv[4 * q + 3] = t.w; }
                             }
                         } else {
                             const float* sh = in.shs + (size_t)idx * in.M * 3;
@@ -137,8 +147,10 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd(const FwdIn in, co
                     pk[1] = make_float4(conz, in.opacities[idx], col0, col1);
                     pk[2] = make_float4(col2, __uint_as_float(minx | (miny << 16)), __uint_as_float(maxx | (maxy << 16)), 0.f);   // .w: slab offset, k_scatter
                     // per-tile instance count (replaces the tile half of the reference's 64-bit sort keys)
+#ifndef TGS_EXPERIMENT_NO_COUNT
                     for (uint32_t ty = miny; ty < maxy; ty++)
                         for (uint32_t tx = minx; tx < maxx; tx++) atomicAdd(&s.tile_count[(size_t)(ty * cam.gx + tx) * CSTRIDE], 1u);
+#endif
                 }
             }
         }
