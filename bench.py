@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--config", type=int, default=3, help="BASELINE.json config index (1-based); 3 = 500k/1080p/SH3")
     ap.add_argument("--mode", default="sh", choices=["sh", "precomp"])
     ap.add_argument("--views", type=int, default=64)
+    ap.add_argument("--no-fused-accumulate", action="store_true", help="let autograd add each view's gradients in a separate pass")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-frames", type=int, default=3)
     return ap.parse_args()
@@ -60,6 +61,7 @@ def main():
     N = world
 
     from youreditableavatar_amd import scenes
+    from youreditableavatar_amd.multiview import FlatGradients, rasterize_accumulate
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _C
 
     cfg = dict(scenes.CONFIGS[a.config])
@@ -86,7 +88,10 @@ def main():
     def frame(view):
         rs = settings[view]
         means2D = torch.zeros(P, 3, device=dev, requires_grad=True)
-        rast = GaussianRasterizer(rs)
+        if a.no_fused_accumulate or a.mode != "sh":
+            rast = GaussianRasterizer(rs)
+        else:       # multi-view path: the backward adds into the flat gradient buffer directly (multiview.rasterize_accumulate)
+            rast = lambda **kw: rasterize_accumulate(rs, **kw)
         if a.mode == "sh":
             img, radii = rast(means3D=means3D, means2D=means2D, opacities=opac, shs=shs, scales=scales, rotations=rots)
         else:
@@ -118,7 +123,6 @@ def main():
         del geom, binning, img, color, radii, nc
     torch.cuda.synchronize()
 
-    from youreditableavatar_amd.multiview import FlatGradients
     flat = FlatGradients(params)            # parameter .grad tensors are views of one buffer: one collective per step
 
     def step(s):

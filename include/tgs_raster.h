@@ -78,6 +78,22 @@ int tgs_backward(void* stream, int P, int D, int M, int64_t R,
                  float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
                  int debug);
 
+/* Multi-view batches (new capability, not in the reference): same as tgs_backward, but the PARAMETER gradients
+ * (dL_dopacity, dL_dmean3D, dL_dsh, dL_dscale, dL_drot, and dL_dcolor / dL_dcov3D where they are inputs' gradients)
+ * are ADDED to what the buffers hold, so a batch of views accumulates without a separate pass.  dL_dmean2D and
+ * dL_dconic are still overwritten.  dL_dcolor may be NULL on the SH path, dL_dcov3D on the scale/rotation path. */
+int tgs_backward_accumulate(void* stream, int P, int D, int M, int64_t R,
+                            const float* background, int width, int height,
+                            const float* means3D, const float* shs, const float* colors_precomp,
+                            const float* scales, float scale_modifier, const float* rotations,
+                            const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                            const float* campos, float tan_fovx, float tan_fovy, const int* radii,
+                            const void* geom_buffer, const void* binning_buffer, const void* img_buffer,
+                            const float* dL_dpix,
+                            float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+                            float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                            int debug);
+
 /* present[P]: 1 byte per Gaussian, 1 iff view-space z > 0.2 (auxiliary.h:154). */
 int tgs_mark_visible(void* stream, int P, const float* means3D, const float* viewmatrix,
                      const float* projmatrix, uint8_t* present);

@@ -188,3 +188,28 @@ def test_config5_overflow_stress_properties(gpu_device):
     b = util.hip_run(inp, 2.0 * dL, introspect=False)                                      # backward is linear in the upstream gradient
     for k in ("dL_dmeans3D", "dL_dopacity", "dL_dsh"):
         assert util.rel_l2(b[k], 2.0 * a[k]) <= 1e-5, k
+
+
+def test_fused_accumulate_equals_autograd_sum(gpu_device):
+    """multiview.rasterize_accumulate: gradients of several views added in place == autograd's sum of per-view gradients."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from youreditableavatar_amd import scenes
+    from youreditableavatar_amd.multiview import FlatGradients, rasterize_accumulate
+    cloud = scenes.make_cloud(6000, 3, seed=41, scale_mult=3.0)
+    cams = [scenes.orbit_camera(176, 112, azimuth_deg=a) for a in (0.0, 90.0, 200.0)]
+    dL = torch.from_numpy(scenes.upstream_gradient(176, 112)).to(gpu_device)
+    names = ("means3D", "opacities", "scales", "rotations", "shs")
+
+    def run(fused):
+        L = _leaves(cloud, gpu_device)
+        flat = FlatGradients([L[n] for n in names])
+        for cam in cams:
+            rs = _settings(cam, 3, gpu_device)
+            kw = dict(means3D=L["means3D"], means2D=torch.zeros(6000, 3, device=gpu_device, requires_grad=True), opacities=L["opacities"],
+                      shs=L["shs"], scales=L["scales"], rotations=L["rotations"])
+            img, _ = rasterize_accumulate(rs, **kw) if fused else GaussianRasterizer(rs)(**kw)
+            img.backward(dL)
+        return flat.flat.clone()
+
+    a, b = run(True), run(False)
+    assert torch.allclose(a, b, rtol=1e-5, atol=1e-9) and a.abs().max() > 0

@@ -239,7 +239,7 @@ int64_t tgs_forward(tgs_alloc_fn alloc, void* alloc_ctx, void* stream, int P, in
     return (int64_t)R;
 }
 
-int tgs_backward(void* stream, int P, int D, int M, int64_t R, const float* background, int width, int height, const float* means3D,
+static int backward_impl(int accumulate, void* stream, int P, int D, int M, int64_t R, const float* background, int width, int height, const float* means3D,
                  const float* shs, const float* colors_precomp, const float* scales, float scale_modifier, const float* rotations,
                  const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx,
                  float tan_fovy, const int* radii, const void* geom_buffer, const void* binning_buffer, const void* img_buffer,
@@ -253,8 +253,9 @@ int tgs_backward(void* stream, int P, int D, int M, int64_t R, const float* back
     const bool has_sh = shs != nullptr, has_sr = scales != nullptr && rotations != nullptr;
     if (has_sh == (colors_precomp != nullptr)) return fail(TGS_ERR_INVALID, "provide exactly one of shs / colors_precomp");
     if (has_sr == (cov3D_precomp != nullptr)) return fail(TGS_ERR_INVALID, "provide exactly one of (scales, rotations) / cov3D_precomp");
-    if (!geom_buffer || !binning_buffer || !img_buffer || !radii || !dL_dpix || !dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor ||
-        !dL_dmean3D || !dL_dcov3D || (has_sh && !dL_dsh))
+    if (!geom_buffer || !binning_buffer || !img_buffer || !radii || !dL_dpix || !dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dmean3D ||
+        (has_sh && !dL_dsh) || (!accumulate && (!dL_dcolor || !dL_dcov3D)) || (accumulate && !has_sh && !dL_dcolor) ||
+        (accumulate && !has_sr && !dL_dcov3D))
         return fail(TGS_ERR_INVALID, "NULL required pointer");
     const CamParams cam = make_cam(viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, scale_modifier, width, height);
     const size_t N = (size_t)width * height, T = (size_t)cam.gx * cam.gy;
@@ -268,6 +269,7 @@ int tgs_backward(void* stream, int P, int D, int M, int64_t R, const float* back
     in.rotations = rotations; in.cov3D_precomp = cov3D_precomp; in.background = background; in.radii = radii; in.dL_dpix = dL_dpix;
     in.dL_dmean2D = dL_dmean2D; in.dL_dconic = dL_dconic; in.dL_dopacity = dL_dopacity; in.dL_dcolor = dL_dcolor;
     in.dL_dmean3D = dL_dmean3D; in.dL_dcov3D = dL_dcov3D; in.dL_dsh = dL_dsh; in.dL_dscale = dL_dscale; in.dL_drot = dL_drot;
+    in.accumulate = accumulate;
 
     if (R > 0) {
         STAGE_BEGIN();
@@ -278,6 +280,30 @@ int tgs_backward(void* stream, int P, int D, int M, int64_t R, const float* back
     launch_preprocess_bwd(st, in, cam, g, b);
     STAGE_CHECK("preprocess_bwd", TGS_STAGE_PREPROCESS_BWD);
     return TGS_OK;
+}
+
+int tgs_backward(void* stream, int P, int D, int M, int64_t R, const float* background, int width, int height, const float* means3D,
+                 const float* shs, const float* colors_precomp, const float* scales, float scale_modifier, const float* rotations,
+                 const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx,
+                 float tan_fovy, const int* radii, const void* geom_buffer, const void* binning_buffer, const void* img_buffer,
+                 const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
+                 float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug)
+{
+    return backward_impl(0, stream, P, D, M, R, background, width, height, means3D, shs, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp,
+                         viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer, img_buffer, dL_dpix, dL_dmean2D,
+                         dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug);
+}
+
+int tgs_backward_accumulate(void* stream, int P, int D, int M, int64_t R, const float* background, int width, int height, const float* means3D,
+                            const float* shs, const float* colors_precomp, const float* scales, float scale_modifier, const float* rotations,
+                            const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx,
+                            float tan_fovy, const int* radii, const void* geom_buffer, const void* binning_buffer, const void* img_buffer,
+                            const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
+                            float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug)
+{
+    return backward_impl(1, stream, P, D, M, R, background, width, height, means3D, shs, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp,
+                         viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer, img_buffer, dL_dpix, dL_dmean2D,
+                         dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug);
 }
 
 int tgs_mark_visible(void* stream, int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present)

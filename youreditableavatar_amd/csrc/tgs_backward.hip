@@ -575,11 +575,19 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
             __syncthreads();
             float4* d4 = reinterpret_cast<float4*>(in.dL_dsh);
 #pragma unroll
-            for (int q = 0; q < 12; q++) { const size_t i = base4 + q * PRE_BLOCK + threadIdx.x; if (i < total4) d4[i] = sh_lds[q * PRE_BLOCK + threadIdx.x]; }
+            for (int q = 0; q < 12; q++) {
+                const size_t i = base4 + q * PRE_BLOCK + threadIdx.x;
+                if (i < total4) {
+                    float4 o = sh_lds[q * PRE_BLOCK + threadIdx.x];
+                    if (in.accumulate) { const float4 p = d4[i]; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+                    d4[i] = o;
+                }
+            }
         } else if (in_range) {
             for (int k = 0; k < in.M; k++) {
                 const float ck = k < 16 ? coef[k < 16 ? k : 0] : 0.f;
-                dsh[3 * k] = ck * dRGB[0]; dsh[3 * k + 1] = ck * dRGB[1]; dsh[3 * k + 2] = ck * dRGB[2];
+                const float o0 = in.accumulate ? dsh[3 * k] : 0.f, o1 = in.accumulate ? dsh[3 * k + 1] : 0.f, o2 = in.accumulate ? dsh[3 * k + 2] : 0.f;
+                dsh[3 * k] = o0 + ck * dRGB[0]; dsh[3 * k + 1] = o1 + ck * dRGB[1]; dsh[3 * k + 2] = o2 + ck * dRGB[2];
             }
         }
     }
@@ -588,6 +596,19 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
     if (!in_range) return;
     in.dL_dmean2D[i3] = a[3]; in.dL_dmean2D[i3 + 1] = a[4]; in.dL_dmean2D[i3 + 2] = 0.f;   // .z never written: backward.cu:545-546
     reinterpret_cast<float4*>(in.dL_dconic)[idx] = make_float4(a[5], a[6], 0.f, a[7]);   // .z never written: backward.cu:549-551
+    if (in.accumulate) {
+        // fused gradient accumulation of a multi-view batch (youreditableavatar_amd/multiview.py): += on the parameter gradients
+        in.dL_dopacity[idx] += a[8];
+        if (in.dL_dcolor) { in.dL_dcolor[i3] += a[0]; in.dL_dcolor[i3 + 1] += a[1]; in.dL_dcolor[i3 + 2] += a[2]; }   // NULL: intermediate on the SH path
+        in.dL_dmean3D[i3] += dmean[0]; in.dL_dmean3D[i3 + 1] += dmean[1]; in.dL_dmean3D[i3 + 2] += dmean[2];
+        if (in.dL_dcov3D) {                                                                                         // NULL: intermediate on the scale/rot path
+#pragma unroll
+            for (int i = 0; i < 6; i++) in.dL_dcov3D[6 * (size_t)idx + i] += dcov[i];
+        }
+        if (in.dL_dscale) { in.dL_dscale[i3] += dscale[0]; in.dL_dscale[i3 + 1] += dscale[1]; in.dL_dscale[i3 + 2] += dscale[2]; }
+        if (in.dL_drot) { float4 p = reinterpret_cast<float4*>(in.dL_drot)[idx]; p.x += drot[0]; p.y += drot[1]; p.z += drot[2]; p.w += drot[3]; reinterpret_cast<float4*>(in.dL_drot)[idx] = p; }
+        return;
+    }
     in.dL_dopacity[idx] = a[8];
     in.dL_dcolor[i3] = a[0]; in.dL_dcolor[i3 + 1] = a[1]; in.dL_dcolor[i3 + 2] = a[2];
     in.dL_dmean3D[i3] = dmean[0]; in.dL_dmean3D[i3 + 1] = dmean[1]; in.dL_dmean3D[i3 + 2] = dmean[2];

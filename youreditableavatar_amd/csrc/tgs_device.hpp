@@ -414,6 +414,7 @@ struct BwdIn {
     const int* radii;
     const float* dL_dpix;
     float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot;
+    int accumulate;   // 1: parameter gradients (all but dL_dmean2D / dL_dconic) are added to what the buffers hold
 };
 
 }  // namespace tgs

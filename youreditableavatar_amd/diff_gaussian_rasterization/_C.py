@@ -37,6 +37,8 @@ def _load() -> C.CDLL:
     lib.tgs_backward.restype = it
     lib.tgs_backward.argtypes = [vp, it, it, it, C.c_int64, vp, it, it, vp, vp, vp, vp, fl, vp, vp, vp, vp, vp, fl, fl, vp,
                                  vp, vp, vp, vp] + [vp] * 9 + [it]
+    lib.tgs_backward_accumulate.restype = it
+    lib.tgs_backward_accumulate.argtypes = lib.tgs_backward.argtypes
     lib.tgs_mark_visible.restype = it
     lib.tgs_mark_visible.argtypes = [vp, it, vp, vp, vp, vp]
     lib.tgs_state_field.restype = C.c_int64
@@ -196,6 +198,49 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 raise _err(int(r))
     out = (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
     return out + (dL_dconic,) if _with_conic else out
+
+
+def rasterize_gaussians_backward_accumulate(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
+                                            viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos,
+                                            geomBuffer, R, binningBuffer, imageBuffer, debug, into):
+    """Multi-view extension (tgs_backward_accumulate): parameter gradients are ADDED into the fp32 tensors of ``into``
+    (keys: means3D, opacities, and sh|colors_precomp, scales+rotations|cov3D_precomp; contiguous, on the device).
+    Returns dL_dmeans2D[P,3], the only per-view gradient."""
+    dev = _require_gpu(means3D)
+    P = int(means3D.size(0))
+    H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
+    M = int(sh.size(1)) if (sh.dim() > 1 and sh.size(0) != 0) else 0
+    with torch.cuda.device(dev):
+        dL_dmeans2D = torch.empty((P, 3), dtype=torch.float32, device=dev)
+        if P == 0:
+            return dL_dmeans2D
+        dL_dconic = torch.empty((P, 4), dtype=torch.float32, device=dev)
+        t = dict(bg=_dev_f32(background, dev, "background"), means=_dev_f32(means3D, dev, "means3D"),
+                 colors=_dev_f32(colors, dev, "colors"), scales=_dev_f32(scales, dev, "scales"),
+                 rots=_dev_f32(rotations, dev, "rotations"), cov=_dev_f32(cov3D_precomp, dev, "cov3D_precomp"),
+                 view=_dev_f32(viewmatrix, dev, "viewmatrix"), proj=_dev_f32(projmatrix, dev, "projmatrix"),
+                 sh=_dev_f32(sh, dev, "sh"), campos=_dev_f32(campos, dev, "campos"), dL=_dev_f32(dL_dout_color, dev, "dL_dout_color"))
+
+        def dst(name, shape):
+            g = into.get(name)
+            if g is None:
+                return None
+            if g.dtype != torch.float32 or g.device != dev or not g.is_contiguous() or tuple(g.shape) != shape:
+                raise RuntimeError(f"accumulation buffer for {name} must be a contiguous fp32 tensor of shape {shape} on {dev}")
+            return g.data_ptr()
+
+        has_sh, has_sr = t["sh"] is not None, t["scales"] is not None
+        r = _lib.tgs_backward_accumulate(
+            torch.cuda.current_stream(dev).cuda_stream, P, int(degree), M, int(R), _p(t["bg"]), W, H, _p(t["means"]), _p(t["sh"]), _p(t["colors"]),
+            _p(t["scales"]), float(scale_modifier), _p(t["rots"]), _p(t["cov"]), _p(t["view"]), _p(t["proj"]), _p(t["campos"]),
+            float(tan_fovx), float(tan_fovy), radii.contiguous().data_ptr(), geomBuffer.data_ptr(), binningBuffer.data_ptr(),
+            imageBuffer.data_ptr(), _p(t["dL"]), dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dst("opacities", (P, 1)),
+            None if has_sh else dst("colors_precomp", (P, 3)), dst("means3D", (P, 3)), None if has_sr else dst("cov3D_precomp", (P, 6)),
+            dst("sh", (P, M, 3)) if has_sh else None, dst("scales", (P, 3)) if has_sr else None, dst("rotations", (P, 4)) if has_sr else None,
+            int(bool(debug)))
+        if r < 0:
+            raise _err(int(r))
+    return dL_dmeans2D
 
 
 def mark_visible(means3D, viewmatrix, projmatrix) -> torch.Tensor:

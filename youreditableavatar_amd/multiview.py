@@ -78,3 +78,50 @@ def render_batch_sharded(render_view: Callable[[int], torch.Tensor], upstream: C
         img.backward(upstream(v, img.detach()))
     grads.all_reduce(group)
     return list(mine)
+
+
+class _RasterizeAccumulate(torch.autograd.Function):
+    """Rasterizer call for multi-view batches: identical forward; the backward ADDS the parameter gradients
+    straight into the ``.grad`` tensors of the leaf parameters (tgs_backward_accumulate) instead of returning them
+    for autograd to add in a second pass.  Every differentiable input must be a leaf that already has a ``.grad``
+    buffer (e.g. from FlatGradients); ``means2D`` keeps its ordinary per-view gradient."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+        from .diff_gaussian_rasterization import _C
+        rs = raster_settings
+        num_rendered, color, radii, geom, binning, img = _C.rasterize_gaussians(
+            rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix, rs.projmatrix,
+            rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
+        ctx.rs, ctx.num_rendered = rs, num_rendered
+        ctx.leaves = dict(means3D=means3D, sh=sh, colors_precomp=colors_precomp, opacities=opacities, scales=scales, rotations=rotations,
+                          cov3D_precomp=cov3Ds_precomp)
+        ctx.save_for_backward(radii, geom, binning, img)
+        ctx.mark_non_differentiable(radii)
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _grad_radii):
+        from .diff_gaussian_rasterization import _C
+        rs, L = ctx.rs, ctx.leaves
+        radii, geom, binning, img = ctx.saved_tensors
+        into = {}
+        for name, t in L.items():
+            if t.numel() and t.requires_grad:
+                if not t.is_leaf or t.grad is None:
+                    raise RuntimeError(f"rasterize_accumulate: {name} must be a leaf parameter with an allocated .grad (see FlatGradients)")
+                into[name] = t.grad
+        g2d = _C.rasterize_gaussians_backward_accumulate(
+            rs.bg, L["means3D"].detach(), radii, L["colors_precomp"].detach(), L["scales"].detach(), L["rotations"].detach(), rs.scale_modifier,
+            L["cov3D_precomp"].detach(), rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, L["sh"].detach(), rs.sh_degree,
+            rs.campos, geom, ctx.num_rendered, binning, img, rs.debug, into)
+        return None, g2d, None, None, None, None, None, None, None
+
+
+def rasterize_accumulate(raster_settings, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                         cov3D_precomp=None):
+    """``GaussianRasterizer(raster_settings)(...)`` with fused gradient accumulation (HIP device only)."""
+    e = torch.Tensor([])
+    return _RasterizeAccumulate.apply(means3D, means2D, e if shs is None else shs, e if colors_precomp is None else colors_precomp, opacities,
+                                      e if scales is None else scales, e if rotations is None else rotations,
+                                      e if cov3D_precomp is None else cov3D_precomp, raster_settings)
