@@ -193,7 +193,6 @@ __global__ __launch_bounds__(256) void k_render_bwd_det(const ImgState s, const 
 // ---------------------------------------------------------------------------------------------
 constexpr int BWD_THREADS = 1024;
 constexpr int BCH = 256;                   // list entries per round
-constexpr int BWD_STG = BCH / 64;
 constexpr int BNULL = BCH;
 
 __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s, const BinState b, int W, int H, uint32_t gx,
@@ -204,7 +203,8 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
     __shared__ float sC[BCH + 1];
     __shared__ uint32_t sSlot[BCH];
     __shared__ float acc[NACC][BCH + 1];                   // per-round sums; column BNULL swallows the padding entries
-    __shared__ BlockLists<BWD_STG> L;
+    __shared__ unsigned short sMask[BCH];
+    __shared__ __attribute__((aligned(16))) unsigned short lists[16][BCH + 8];   // one list per block (= per wave)
     __shared__ uint32_t wmax[16];
 
     const uint32_t tile = s.tile_order[blockIdx.x];
@@ -255,24 +255,18 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
     for (uint32_t qhi = qmax; qhi > 0; qhi = qhi > BCH ? qhi - BCH : 0) {
         const uint32_t cnt = min((uint32_t)BCH, qhi);
         __syncthreads();                                    // previous round's flush has read acc / sSlot
-        if (wv < BWD_STG) {
-            uint32_t bm = 0;
-            if (threadIdx.x < cnt) { sA[threadIdx.x] = ra; sB[threadIdx.x] = rb; sC[threadIdx.x] = rc.x; bm = __float_as_uint(rc.y); sSlot[threadIdx.x] = rs; }
-            if (wv * 64u < cnt) build_block_lists(L, bm, wv, lane, BNULL);
-        }
+        if (threadIdx.x < cnt) { sA[threadIdx.x] = ra; sB[threadIdx.x] = rb; sC[threadIdx.x] = rc.x; sMask[threadIdx.x] = (unsigned short)__float_as_uint(rc.y); sSlot[threadIdx.x] = rs; }
         for (uint32_t i = threadIdx.x; i < NACC * (BCH + 1); i += BWD_THREADS) (&acc[0][0])[i] = 0.f;
         __syncthreads();
         if (threadIdx.x < BCH && qhi > BCH && threadIdx.x < qhi - BCH) {
             const uint32_t pos = rg.x + qhi - BCH - 1 - threadIdx.x;
             ra = b.recA[pos]; rb = b.recB[pos]; rc = b.recC[pos]; rs = b.slot[pos];
         }
-        const int nsw = (int)((cnt + 63) >> 6);
-#pragma unroll 1
-        for (int sw = 0; sw < nsw; sw++) {
-            const uint32_t nl = __builtin_amdgcn_readfirstlane(L.cnt[wv][sw]);
+        {
+            const uint32_t nl = build_own_list<BCH>(lists[wv], sMask, cnt, wv, lane, BNULL);
 #pragma unroll 1
             for (uint32_t k = 0; k < nl; k += 4) {
-                const uint32_t j = L.idx[wv][sw][k + e];
+                const uint32_t j = lists[wv][k + e];
                 const float4 a = sA[j];
                 const float4 bb = sB[j];
                 const float c0 = bb.z, c1 = bb.w, c2 = sC[j];

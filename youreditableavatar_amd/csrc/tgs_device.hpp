@@ -226,6 +226,25 @@ __device__ __forceinline__ void build_block_lists(BlockLists<STG>& L, uint32_t b
         if (lane == 0) L.cnt[q][sw] = n;
     }
 }
+// Per-wave list of the staged slots whose splat can reach the wave's block, in slot order, padded with `null_slot`
+// to a multiple of 4.  Each compute wave builds its OWN list from the staged 16-bit masks (CH/64 ballots and an
+// in-wave running base), so no list is shared between waves and one round yields one contiguous list per block.
+template <int CH>
+__device__ __forceinline__ uint32_t build_own_list(unsigned short* list, const unsigned short* masks, uint32_t cnt, int blk, int lane, int null_slot)
+{
+    uint32_t base = 0;
+#pragma unroll
+    for (int k = 0; k < CH / 64; k++) {
+        const uint32_t slot = k * 64 + lane;
+        const bool on = slot < cnt && ((masks[slot] >> blk) & 1u);
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(on);
+        if (on) list[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (unsigned short)slot;
+        base += (uint32_t)__builtin_popcountll(bal);
+    }
+    if (lane < 4) list[base + lane] = (unsigned short)null_slot;
+    return base;
+}
+
 // 16-bit block mask -> 4-bit quadrant mask (quadrant q: bit0 = right half, bit1 = lower half)
 __device__ __forceinline__ uint32_t block_to_quadrant_mask(uint32_t m)
 {

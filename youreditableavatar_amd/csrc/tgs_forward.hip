@@ -501,7 +501,6 @@ __global__ __launch_bounds__(256) void k_ovf_finalize(const GeomState g, const I
 // visited first (tile_order) at raised priority, and the per-entry dependent chain is 1/4 as long.
 constexpr int FWD_THREADS = 1024;
 constexpr int FCH = 512;                   // list entries staged per round
-constexpr int FWD_STG = FCH / 64;          // staging waves per round
 constexpr int FNULL = FCH;                 // LDS slot of the null record
 
 __global__ __launch_bounds__(FWD_THREADS) void k_render_fwd(const ImgState s, const BinState b, int W, int H, uint32_t gx,
@@ -510,7 +509,8 @@ __global__ __launch_bounds__(FWD_THREADS) void k_render_fwd(const ImgState s, co
     __shared__ float4 sA[FCH + 1];
     __shared__ float4 sB[FCH + 1];
     __shared__ float sC[FCH + 1];
-    __shared__ BlockLists<FWD_STG> L;
+    __shared__ unsigned short sMask[FCH];
+    __shared__ __attribute__((aligned(16))) unsigned short lists[16][FCH + 8];   // one list per block (= per wave)
     __shared__ uint32_t wave_alive[2][16];                 // double-buffered "this wave still has live pixels"
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     const uint32_t tile = s.tile_order[blockIdx.x];
@@ -547,25 +547,18 @@ __global__ __launch_bounds__(FWD_THREADS) void k_render_fwd(const ImgState s, co
             if (((f0.x | f0.y | f0.z | f0.w) | (f1.x | f1.y | f1.z | f1.w) | (f2.x | f2.y | f2.z | f2.w) | (f3.x | f3.y | f3.z | f3.w)) == 0u) break;
         }
         const uint32_t cnt = min((uint32_t)FCH, rg.y - base);
-        if (wv < FWD_STG) {
-            uint32_t bm = 0;
-            if (threadIdx.x < cnt) { sA[threadIdx.x] = ra; sB[threadIdx.x] = rb; sC[threadIdx.x] = rc.x; bm = __float_as_uint(rc.y); }
-            if (wv * 64u < cnt) build_block_lists(L, bm, wv, lane, FNULL);
-            else if (lane < 16) L.cnt[lane][wv] = 0;
-        }
+        if (threadIdx.x < cnt) { sA[threadIdx.x] = ra; sB[threadIdx.x] = rb; sC[threadIdx.x] = rc.x; sMask[threadIdx.x] = (unsigned short)__float_as_uint(rc.y); }
         __syncthreads();
         if (threadIdx.x < FCH) {
             const uint32_t nxt = base + FCH + threadIdx.x;
             if (nxt < rg.y) { ra = b.recA[nxt]; rb = b.recB[nxt]; rc = b.recC[nxt]; }
         }
         const uint32_t cbase = base - rg.x + 1;
-        const int nsw = (int)((cnt + 63) >> 6);
-#pragma unroll 1
-        for (int sw = 0; wave_live && sw < nsw; sw++) {
-            const uint32_t n = __builtin_amdgcn_readfirstlane(L.cnt[wv][sw]);
+        {
+            const uint32_t n = wave_live ? build_own_list<FCH>(lists[wv], sMask, cnt, wv, lane, FNULL) : 0u;
 #pragma unroll 1
             for (uint32_t k = 0; k < n; k += 4) {               // 4 list entries per pass, only those that can reach this block
-                const uint32_t j = L.idx[wv][sw][k + e];
+                const uint32_t j = lists[wv][k + e];
                 const float4 a = sA[j];
                 const float4 bb = sB[j];
                 const float cc = sC[j];
