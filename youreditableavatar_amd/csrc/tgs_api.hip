@@ -11,8 +11,8 @@ namespace tgs {
 void launch_preprocess_fwd(hipStream_t, const FwdIn&, const CamParams&, const GeomState&, const ImgState&);
 void launch_scan(hipStream_t, const GeomState&, const ImgState&, uint32_t nblocks, uint32_t T, uint32_t sort_cap);
 void launch_scatter(hipStream_t, int P, const GeomState&, const ImgState&, const BinState&, uint32_t gx);
-void launch_tile_sort(hipStream_t, const GeomState&, const ImgState&, const BinState&, uint32_t gx, uint32_t T,
-                      uint32_t max_count, uint32_t n_overflow, uint32_t sort_cap);
+void launch_tile_sort(hipStream_t, const GeomState&, const ImgState&, const BinState&, uint32_t gx, uint32_t T, uint32_t R,
+                      uint32_t max_count, uint32_t n_overflow, uint32_t n_nonempty, uint32_t n_heavy, uint32_t sort_cap);
 void launch_render_fwd(hipStream_t, const ImgState&, const BinState&, int W, int H, uint32_t gx, uint32_t T, uint32_t n_nonempty, const float* bg,
                        float* out_color);
 void launch_mark_visible(hipStream_t, int P, const float* means3D, const float* view, uint8_t* present);
@@ -230,7 +230,7 @@ int64_t tgs_forward(tgs_alloc_fn alloc, void* alloc_ctx, void* stream, int P, in
         launch_scatter(st, P, g, s, b, cam.gx);
         STAGE_CHECK("scatter", TGS_STAGE_SCATTER);
         STAGE_BEGIN();
-        launch_tile_sort(st, g, s, b, cam.gx, (uint32_t)T, meta.max_count, meta.n_overflow, sort_cap);
+        launch_tile_sort(st, g, s, b, cam.gx, (uint32_t)T, (uint32_t)R, meta.max_count, meta.n_overflow, meta.n_nonempty, meta.n_heavy, sort_cap);
         STAGE_CHECK("tile_sort", TGS_STAGE_TILE_SORT);
     }
     STAGE_BEGIN();

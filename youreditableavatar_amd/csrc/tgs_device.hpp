@@ -27,7 +27,8 @@ struct Meta {                 // lives at the start of the image buffer
     uint32_t n_overflow;      // tiles whose list is longer than SORT_LDS_CAP
     uint32_t error;           // bit0: prefiltered Gaussian culled
     uint32_t n_nonempty;      // tiles with at least one instance (they come first in tile_order)
-    uint32_t pad[10];
+    uint32_t n_heavy;         // tiles with >= 1024 instances (first in tile_order): sorted by 1024-thread workgroups
+    uint32_t pad[9];
 };
 
 struct GeomState {

@@ -247,7 +247,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const 
             __syncthreads();
         }
         // tiles by descending list length (power-of-two buckets; order inside a bucket does not matter)
-        if (threadIdx.x == 0) { uint32_t acc = 0; for (int b2 = 33; b2-- > 0;) { const uint32_t h = hist[b2]; hist[b2] = acc; if (b2 == 1) s.meta->n_nonempty = acc + h; acc += h; } }
+        if (threadIdx.x == 0) { uint32_t acc = 0; for (int b2 = 33; b2-- > 0;) { const uint32_t h = hist[b2]; hist[b2] = acc; if (b2 == 1) s.meta->n_nonempty = acc + h; if (b2 == 11) s.meta->n_heavy = acc + h; acc += h; } }
         __syncthreads();
         for (uint32_t sc = 0; sc < T; sc += SC) {
             const uint32_t n = min(SC, T - sc);
@@ -355,20 +355,31 @@ __device__ __forceinline__ void cmp_swap(KeyPtr keys, uint32_t i, uint32_t l, ui
 }
 
 // Conservative 16-bit mask of the tile's 4x4 blocks of 4x4 pixels (bit by*4+bx) that a splat can reach with
-// alpha >= 1/255:  alpha = o*exp(power) >= 1/255  <=>  power >= -tau, tau = ln(255 o); the level set
-// 1/2 d^T Q d <= tau of the conic Q = [[A,B],[B,C]] has the bounding box |dx| <= sqrt(2 tau C/det Q),
-// |dy| <= sqrt(2 tau A/det Q).  The exact per-pixel tests of forward.cu:336-343 stay in the render kernels,
-// so a conservative mask only removes work, never a contribution.  NaNs keep every block.
+// alpha >= 1/255:  alpha = o*exp(power) >= 1/255  <=>  -power <= tau, tau = ln(255 o), where
+// -power = f(d) = 1/2 (A dx^2 + C dy^2) + B dx dy is the conic's quadratic form in d = pixel - mean.
+// Stage 1: bounding box of the level set f <= tau (|dx| <= sqrt(2 tau C/det), |dy| <= sqrt(2 tau A/det)), separable.
+// Stage 2, for the blocks that survive: the exact minimum of the convex f over the block's pixel rectangle
+// (0 if the mean is inside; otherwise on one of the 4 edges, a clamped 1-D parabola each).
+// The exact per-pixel tests of forward.cu:336-343 stay in the render kernels, so a conservative mask only removes
+// work, never a contribution (margins: +0.01 on tau plus 0.1 % on f).  NaNs and non-convex conics keep every block.
+__device__ __forceinline__ float conic_min_on_edge(float dfix, float lo, float hi, float Pfix, float Pvar, float B, float mB_over_Pvar)
+{
+    // minimise 1/2 Pfix dfix^2 + B dfix t + 1/2 Pvar t^2 over t in [lo, hi]; the stationary point is t = -B dfix / Pvar
+    const float t = fminf(hi, fmaxf(lo, dfix * mB_over_Pvar));
+    return 0.5f * (Pfix * dfix * dfix + Pvar * t * t) + B * dfix * t;
+}
 __device__ __forceinline__ uint32_t block_mask(float2 xy, float4 co, uint32_t tx, uint32_t ty)
 {
     const float o255 = 255.0f * co.w;
     if (o255 < 0.999f) return 0u;                       // alpha <= o < 1/255 for every pixel (G <= 1)
     const float tau = fmaxf(logf(o255), 0.f) + 0.01f;
-    const float det = co.x * co.z - co.y * co.y;
+    const float A = co.x, B = co.y, Cc = co.z;
+    const float det = A * Cc - B * B;
+    const bool convex = det > 0.f && A > 0.f && Cc > 0.f;
     float hx = 3.0e38f, hy = 3.0e38f;
-    if (det > 0.f && co.x > 0.f && co.z > 0.f) {
-        hx = sqrtf(2.f * tau * co.z / det) * 1.001f + 0.01f;
-        hy = sqrtf(2.f * tau * co.x / det) * 1.001f + 0.01f;
+    if (convex) {
+        hx = sqrtf(2.f * tau * Cc / det) * 1.001f + 0.01f;
+        hy = sqrtf(2.f * tau * A / det) * 1.001f + 0.01f;
     }
     const float x0 = (float)(tx * TILE), y0 = (float)(ty * TILE);
     uint32_t mx = 0, my = 0;                            // 4-bit column / row masks; the box test is separable
@@ -381,7 +392,25 @@ __device__ __forceinline__ uint32_t block_mask(float2 xy, float4 co, uint32_t tx
     uint32_t m = 0;
 #pragma unroll
     for (int r = 0; r < 4; r++) if ((my >> r) & 1u) m |= mx << (4 * r);
-    return m;
+    if (!convex || m == 0u) return m;
+    const float tau_x = tau * 1.001f;
+    const float rC = -B / Cc, rA = -B / A;
+    uint32_t keep = 0;
+#pragma unroll
+    for (int blk = 0; blk < 16; blk++) {
+        if (!((m >> blk) & 1u)) continue;
+        // block rectangle in d = pixel - mean coordinates
+        const float xl = x0 + (float)(4 * (blk & 3)) - xy.x, xh = xl + 3.f;
+        const float yl = y0 + (float)(4 * (blk >> 2)) - xy.y, yh = yl + 3.f;
+        float fmin_ = 0.f;
+        if (!(xl <= 0.f && xh >= 0.f && yl <= 0.f && yh >= 0.f)) {
+            const float e0 = conic_min_on_edge(xl, yl, yh, A, Cc, B, rC), e1 = conic_min_on_edge(xh, yl, yh, A, Cc, B, rC);
+            const float e2 = conic_min_on_edge(yl, xl, xh, Cc, A, B, rA), e3 = conic_min_on_edge(yh, xl, xh, Cc, A, B, rA);
+            fmin_ = fminf(fminf(e0, e1), fminf(e2, e3));
+        }
+        if (!(fmin_ > tau_x)) keep |= 1u << blk;
+    }
+    return keep;
 }
 
 // gathers the per-instance record of sorted entry i of a tile (what renderCUDA fetches per entry:
@@ -401,29 +430,41 @@ __device__ __forceinline__ void finalize_entry(unsigned long long key, uint32_t 
     b.slot[pos] = __float_as_uint(p2.w) + (ty - miny) * (maxx - minx) + (tx - minx);
 }
 
-__global__ __launch_bounds__(256) void k_tile_sort(const GeomState g, const ImgState s, const BinState b, uint32_t gx, uint32_t sort_cap)
+// One workgroup per tile, visited in tile_order (longest lists first); lists of >= 1024 entries get 1024 threads.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_tile_sort(const ImgState s, const BinState b, uint32_t first, uint32_t sort_cap)
 {
     extern __shared__ unsigned long long lk[];
-    const uint32_t tile = blockIdx.x;
+    const uint32_t tile = s.tile_order[first + blockIdx.x];
     const uint2 rg = s.ranges[tile];
     const uint32_t n = rg.y - rg.x;
-    if (n == 0 || n > sort_cap) return;
-    for (uint32_t i = threadIdx.x; i < n; i += 256) lk[i] = b.keys[rg.x + i];
+    if (n < 2 || n > sort_cap) return;
+    for (uint32_t i = threadIdx.x; i < n; i += NT) lk[i] = b.keys[rg.x + i];
     __syncthreads();
     const uint32_t npad = next_pow2(n), half = npad >> 1;
     for (uint32_t k = 2; k <= npad; k <<= 1) {
-        for (uint32_t t = threadIdx.x; t < half; t += 256) { uint32_t i, l; pair_flip(t, k, i, l); cmp_swap(lk, i, l, n); }
+        for (uint32_t t = threadIdx.x; t < half; t += NT) { uint32_t i, l; pair_flip(t, k, i, l); cmp_swap(lk, i, l, n); }
         __syncthreads();
         for (uint32_t j = k >> 2; j > 0; j >>= 1) {
-            for (uint32_t t = threadIdx.x; t < half; t += 256) { uint32_t i, l; pair_disperse(t, j, i, l); cmp_swap(lk, i, l, n); }
+            for (uint32_t t = threadIdx.x; t < half; t += NT) { uint32_t i, l; pair_disperse(t, j, i, l); cmp_swap(lk, i, l, n); }
             __syncthreads();
         }
     }
-    for (uint32_t i = threadIdx.x; i < n; i += 256) {
-        const unsigned long long key = lk[i];
-        b.keys[rg.x + i] = key;
-        finalize_entry(key, rg.x + i, tile, gx, g, b);
+    for (uint32_t i = threadIdx.x; i < n; i += NT) b.keys[rg.x + i] = lk[i];
+}
+
+// One thread per sorted instance, evenly over all R of them: finds its tile by binary search in the (monotone)
+// range starts, gathers the Gaussian's 64-B line and writes the 40-B record, the block mask and the slab row.
+__global__ __launch_bounds__(256) void k_finalize(const GeomState g, const ImgState s, const BinState b, uint32_t gx, uint32_t T, uint32_t R)
+{
+    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= R) return;
+    uint32_t lo = 0, hi = T - 1;                            // last tile whose start is <= p (empty tiles before it share its start)
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (s.ranges[mid].x <= p) lo = mid; else hi = mid - 1;
     }
+    finalize_entry(b.keys[p], p, lo, gx, g, b);
 }
 
 // ---- overflow path: lists longer than SORT_LDS_CAP, sorted in global memory by many workgroups ----
@@ -473,15 +514,6 @@ __global__ __launch_bounds__(256) void k_ovf_global(const ImgState s, const BinS
     uint32_t i, l;
     if (flip) pair_flip(t, k, i, l); else pair_disperse(t, j, i, l);
     cmp_swap(b.keys + rg.x, i, l, n);
-}
-
-__global__ __launch_bounds__(256) void k_ovf_finalize(const GeomState g, const ImgState s, const BinState b, uint32_t gx)
-{
-    const uint32_t tile = s.ovf_tiles[blockIdx.y];
-    const uint2 rg = s.ranges[tile];
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= rg.y - rg.x) return;
-    finalize_entry(b.keys[rg.x + i], rg.x + i, tile, gx, g, b);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -655,24 +687,30 @@ void launch_scatter(hipStream_t st, int P, const GeomState& g, const ImgState& s
     hipLaunchKernelGGL(k_scatter, dim3((unsigned)n_blocks(P)), dim3(PRE_BLOCK), 0, st, P, g, s, b, gx);
 }
 static uint32_t host_next_pow2(uint32_t n) { uint32_t p = 1; while (p < n) p <<= 1; return p; }
-void launch_tile_sort(hipStream_t st, const GeomState& g, const ImgState& s, const BinState& b, uint32_t gx, uint32_t T,
-                      uint32_t max_count, uint32_t n_overflow, uint32_t sort_cap)
+void launch_tile_sort(hipStream_t st, const GeomState& g, const ImgState& s, const BinState& b, uint32_t gx, uint32_t T, uint32_t R,
+                      uint32_t max_count, uint32_t n_overflow, uint32_t n_nonempty, uint32_t n_heavy, uint32_t sort_cap)
 {
     const uint32_t cap = max_count < sort_cap ? max_count : sort_cap;
     const size_t lds = (size_t)(cap ? cap : 1) * 8;
-    hipLaunchKernelGGL(k_tile_sort, dim3(T), dim3(256), lds, st, g, s, b, gx, sort_cap);
-    if (n_overflow == 0) return;
-    // lists longer than sort_cap: sorted in global memory by many workgroups, LDS for strides < sort_cap
-    const uint32_t npad = host_next_pow2(max_count);
-    const dim3 lgrid((npad + sort_cap - 1) / sort_cap, n_overflow), ggrid((npad / 2 + 255) / 256, n_overflow);
-    const size_t ldsb = (size_t)sort_cap * 8;
-    hipLaunchKernelGGL(k_ovf_local, lgrid, dim3(256), ldsb, st, s, b, 0u, sort_cap);
-    for (uint32_t k = sort_cap * 2; k <= npad; k <<= 1) {
-        hipLaunchKernelGGL(k_ovf_global, ggrid, dim3(256), 0, st, s, b, k, 0u, 1);
-        for (uint32_t j = k >> 2; j >= sort_cap; j >>= 1) hipLaunchKernelGGL(k_ovf_global, ggrid, dim3(256), 0, st, s, b, k, j, 0);
-        hipLaunchKernelGGL(k_ovf_local, lgrid, dim3(256), ldsb, st, s, b, k, sort_cap);
+    if (n_heavy > n_nonempty) n_heavy = n_nonempty;
+    if (n_heavy > 0) hipLaunchKernelGGL((k_tile_sort<1024>), dim3(n_heavy), dim3(1024), lds, st, s, b, 0u, sort_cap);
+    if (n_nonempty > n_heavy) {
+        const uint32_t cap2 = cap < 1024u ? cap : 1024u;    // these lists are shorter than 1024
+        hipLaunchKernelGGL((k_tile_sort<256>), dim3(n_nonempty - n_heavy), dim3(256), (size_t)(cap2 ? cap2 : 1) * 8, st, s, b, n_heavy, sort_cap);
     }
-    hipLaunchKernelGGL(k_ovf_finalize, dim3((max_count + 255) / 256, n_overflow), dim3(256), 0, st, g, s, b, gx);
+    if (n_overflow > 0) {
+        // lists longer than sort_cap: sorted in global memory by many workgroups, LDS for strides < sort_cap
+        const uint32_t npad = host_next_pow2(max_count);
+        const dim3 lgrid((npad + sort_cap - 1) / sort_cap, n_overflow), ggrid((npad / 2 + 255) / 256, n_overflow);
+        const size_t ldsb = (size_t)sort_cap * 8;
+        hipLaunchKernelGGL(k_ovf_local, lgrid, dim3(256), ldsb, st, s, b, 0u, sort_cap);
+        for (uint32_t k = sort_cap * 2; k <= npad; k <<= 1) {
+            hipLaunchKernelGGL(k_ovf_global, ggrid, dim3(256), 0, st, s, b, k, 0u, 1);
+            for (uint32_t j = k >> 2; j >= sort_cap; j >>= 1) hipLaunchKernelGGL(k_ovf_global, ggrid, dim3(256), 0, st, s, b, k, j, 0);
+            hipLaunchKernelGGL(k_ovf_local, lgrid, dim3(256), ldsb, st, s, b, k, sort_cap);
+        }
+    }
+    hipLaunchKernelGGL(k_finalize, dim3((R + 255) / 256), dim3(256), 0, st, g, s, b, gx, T, R);
 }
 void launch_render_fwd(hipStream_t st, const ImgState& s, const BinState& b, int W, int H, uint32_t gx, uint32_t T, uint32_t n_nonempty,
                        const float* bg, float* out_color)
