@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void k_render_bwd_det(const ImgState s, const 
 // (bitwise reproducible) at about 2.5x the time; tgs_set_deterministic(1) selects it.
 // ---------------------------------------------------------------------------------------------
 constexpr int BWD_THREADS = 1024;
-constexpr int BCH = 256;                   // list entries per round
+constexpr int BCH = 512;                   // list entries per round
 constexpr int BNULL = BCH;
 
 __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s, const BinState b, int W, int H, uint32_t gx,
