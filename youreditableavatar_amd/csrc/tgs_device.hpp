@@ -12,10 +12,12 @@ constexpr int WAVE = 64;
 constexpr int PRE_BLOCK = 256;      // Gaussians per workgroup in the per-Gaussian kernels
 constexpr uint32_t SORT_LDS_CAP = 8192;   // longest tile list sorted inside LDS (64 KiB of u64 keys)
 constexpr int COOP_TILES = 64;
+constexpr int RANK_TILES = 4;        // splats touching at most this many tiles get their in-tile ranks while they are counted
 constexpr int SLAB_ROW = 3;          // float4 per gradient-slab row: 9 sums padded to 48 B so rows move as three 16-B accesses
 #ifndef TGS_CSTRIDE
 #define TGS_CSTRIDE 16
 #endif
+static_assert(TGS_CSTRIDE >= 4, "the per-tile counter line holds 3 words");
 constexpr int CSTRIDE = TGS_CSTRIDE;  // u32 stride of the per-tile counters (16 = one counter per 64-B line)      // a Gaussian touching more tiles than this is emitted by the whole workgroup
 
 // ---------------------------------------------------------------------------------------------
@@ -35,7 +37,8 @@ struct GeomState {
     // One 64-byte line per Gaussian with everything the per-tile gather needs (geomState.means2D,
     // .conic_opacity, .rgb of the reference, plus the tile rectangle and the slab offset):
     //   pack[4g+0] = (x, y, conic.x, conic.y)   pack[4g+1] = (conic.z, opacity, r, g)
-    //   pack[4g+2] = (b, bits(minx | miny<<16), bits(maxx | maxy<<16), bits(offset))   pack[4g+3] unused
+    //   pack[4g+2] = (b, bits(minx | miny<<16), bits(maxx | maxy<<16), bits(offset))
+    //   pack[4g+3] = in-tile ranks of its (<= RANK_TILES) instances, row-major over the rectangle
     float4* pack;
     float* depth;             // view-space z                       (geomState.depths)
     float* cov3D;             // 6 floats, scale/rot path only      (geomState.cov3D)
@@ -48,8 +51,9 @@ struct GeomState {
 struct ImgState {
     Meta* meta;
     uint2* ranges;            // per tile [start, end)              (imgState.ranges)
-    uint32_t* tile_count;     // per tile instance count
-    uint32_t* cursor;         // per tile scatter cursor
+    uint32_t* tile_count;     // per tile, one 64-B line (CSTRIDE words): [0] instances of splats touching <= RANK_TILES tiles
+                              // (their ranks are taken in k_preprocess_fwd), [1] instances of larger splats, [2] scatter cursor of those
+    uint32_t* cursor;         // (unused, kept for layout stability)
     uint32_t* ovf_tiles;      // list of overflow tiles
     uint32_t* tile_order;     // tiles by descending list length: render kernels start the long lists first
     float* final_T;           //                                    (imgState.accum_alpha)
@@ -86,7 +90,7 @@ __host__ __device__ inline size_t geom_carve(GeomState& g, char* base, size_t P,
 __host__ __device__ inline size_t img_carve(ImgState& s, char* base, size_t N, size_t T)
 {
     char* p = base;
-    carve(p, s.meta, 1); carve(p, s.ranges, T); carve(p, s.tile_count, T * CSTRIDE); carve(p, s.cursor, T * CSTRIDE);
+    carve(p, s.meta, 1); carve(p, s.ranges, T); carve(p, s.tile_count, T * CSTRIDE); carve(p, s.cursor, 1);
     carve(p, s.ovf_tiles, T); carve(p, s.tile_order, T); carve(p, s.final_T, N); carve(p, s.n_contrib, N);
     carve(p, s.stamps, 4 * T);
     return (size_t)(p - base) + 256;

@@ -146,11 +146,19 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd(const FwdIn in, co
                     pk[0] = make_float4(pix, piy, conx, cony);
                     pk[1] = make_float4(conz, in.opacities[idx], col0, col1);
                     pk[2] = make_float4(col2, __uint_as_float(minx | (miny << 16)), __uint_as_float(maxx | (maxy << 16)), 0.f);   // .w: slab offset, k_scatter
-                    // per-tile instance count (replaces the tile half of the reference's 64-bit sort keys)
-#ifndef TGS_EXPERIMENT_NO_COUNT
-                    for (uint32_t ty = miny; ty < maxy; ty++)
-                        for (uint32_t tx = minx; tx < maxx; tx++) atomicAdd(&s.tile_count[(size_t)(ty * cam.gx + tx) * CSTRIDE], 1u);
-#endif
+                    // Per-tile instance count (replaces the tile half of the reference's 64-bit sort keys).  A splat on <= 4 tiles
+                    // (almost all) takes its rank inside each tile from the same atomic, so k_scatter needs no second atomic pass.
+                    if (tiles <= (uint32_t)RANK_TILES) {
+                        uint32_t rk[RANK_TILES] = {0u, 0u, 0u, 0u};
+                        const uint32_t rw = maxx - minx;
+#pragma unroll
+                        for (int k = 0; k < RANK_TILES; k++)       // constant indices: rk stays in registers
+                            if ((uint32_t)k < tiles) rk[k] = atomicAdd(&s.tile_count[(size_t)((miny + k / rw) * cam.gx + minx + k % rw) * CSTRIDE], 1u);
+                        pk[3] = make_float4(__uint_as_float(rk[0]), __uint_as_float(rk[1]), __uint_as_float(rk[2]), __uint_as_float(rk[3]));
+                    } else {
+                        for (uint32_t ty = miny; ty < maxy; ty++)
+                            for (uint32_t tx = minx; tx < maxx; tx++) atomicAdd(&s.tile_count[(size_t)(ty * cam.gx + tx) * CSTRIDE + 1], 1u);
+                    }
                 }
             }
         }
@@ -222,7 +230,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const 
             const uint32_t n = min(SC, T - sc);
             uint32_t v[8];
 #pragma unroll
-            for (int k = 0; k < 8; k++) { const uint32_t i = k * SCAN_THREADS + threadIdx.x; v[k] = i < n ? s.tile_count[(size_t)(sc + i) * CSTRIDE] : 0u; }
+            for (int k = 0; k < 8; k++) { const uint32_t i = k * SCAN_THREADS + threadIdx.x; if (i < n) { const uint2 c2 = *reinterpret_cast<const uint2*>(&s.tile_count[(size_t)(sc + i) * CSTRIDE]); v[k] = c2.x + c2.y; } else v[k] = 0u; }
 #pragma unroll
             for (int k = 0; k < 8; k++) lc[k * SCAN_THREADS + threadIdx.x] = v[k];
             __syncthreads();
@@ -237,7 +245,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const 
                 if (i0 + k < n) {
                     const uint32_t t = sc + i0 + k;
                     s.ranges[t] = make_uint2((uint32_t)ex, (uint32_t)(ex + v[k]));
-                    s.cursor[(size_t)t * CSTRIDE] = (uint32_t)ex;
                     if (v[k] > sort_cap) s.ovf_tiles[atomicAdd(&ovf_n, 1u)] = t;
                     atomicAdd(&hist[v[k] ? 32 - __builtin_clz(v[k]) : 0], 1u);
                 }
@@ -295,13 +302,22 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_scatter(int P, const GeomState g,
     }
 
     if (tiles > 0) {
-        if (tiles <= (uint32_t)COOP_TILES) {
+        const unsigned long long key = ((unsigned long long)__float_as_uint(g.depth[idx]) << 32) | (uint32_t)idx;
+        if (tiles <= (uint32_t)RANK_TILES) {
+            // position = start of the tile's segment + the rank taken in k_preprocess_fwd: no atomic
             const ushort4 r = g.rect[idx];
-            const unsigned long long key = ((unsigned long long)__float_as_uint(g.depth[idx]) << 32) | (uint32_t)idx;
+            const float4 rk4 = g.pack[4 * (size_t)idx + 3];
+            const uint32_t rk[RANK_TILES] = {__float_as_uint(rk4.x), __float_as_uint(rk4.y), __float_as_uint(rk4.z), __float_as_uint(rk4.w)};
+            const uint32_t rw = (uint32_t)r.z - r.x;
+#pragma unroll
+            for (int k = 0; k < RANK_TILES; k++)
+                if ((uint32_t)k < tiles) b.keys[s.ranges[(r.y + k / rw) * gx + r.x + k % rw].x + rk[k]] = key;
+        } else if (tiles <= (uint32_t)COOP_TILES) {
+            const ushort4 r = g.rect[idx];
             for (uint32_t ty = r.y; ty < r.w; ty++)
                 for (uint32_t tx = r.x; tx < r.z; tx++) {
-                    const uint32_t pos = atomicAdd(&s.cursor[(size_t)(ty * gx + tx) * CSTRIDE], 1u);
-                    b.keys[pos] = key;
+                    uint32_t* line = s.tile_count + (size_t)(ty * gx + tx) * CSTRIDE;
+                    b.keys[s.ranges[ty * gx + tx].x + line[0] + atomicAdd(&line[2], 1u)] = key;
                 }
         } else {
             queue[atomicAdd(&qn, 1u)] = (uint32_t)idx;
@@ -318,8 +334,8 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_scatter(int P, const GeomState g,
         const unsigned long long key = ((unsigned long long)__float_as_uint(g.depth[id]) << 32) | id;
         for (uint32_t k = threadIdx.x; k < n; k += PRE_BLOCK) {
             const uint32_t ty = r.y + k / w, tx = r.x + k % w;
-            const uint32_t pos = atomicAdd(&s.cursor[(size_t)(ty * gx + tx) * CSTRIDE], 1u);
-            b.keys[pos] = key;
+            uint32_t* line = s.tile_count + (size_t)(ty * gx + tx) * CSTRIDE;
+            b.keys[s.ranges[ty * gx + tx].x + line[0] + atomicAdd(&line[2], 1u)] = key;
         }
     }
 }
