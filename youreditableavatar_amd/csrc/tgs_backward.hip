@@ -201,7 +201,7 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
     __shared__ float4 sA[BCH + 1];
     __shared__ float4 sB[BCH + 1];
     __shared__ float sC[BCH + 1];
-    __shared__ uint32_t sSlot[BCH];
+    __shared__ uint32_t sSlot[2][BCH];                       // double-buffered: the flush of round r overlaps the staging of r+1
     __shared__ float acc[NACC][BCH + 1];                   // per-round sums; column BNULL swallows the padding entries
     __shared__ unsigned short sMask[BCH];
     __shared__ __attribute__((aligned(16))) unsigned short lists[16][BCH + 8];   // one list per block (= per wave)
@@ -252,16 +252,20 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
     uint32_t rs = 0;
     if (threadIdx.x < BCH && threadIdx.x < qmax) { const uint32_t pos = rg.x + qmax - 1 - threadIdx.x; ra = b.recA[pos]; rb = b.recB[pos]; rc = b.recC[pos]; rs = b.slot[pos]; }
 
-    for (uint32_t qhi = qmax; qhi > 0; qhi = qhi > BCH ? qhi - BCH : 0) {
-        const uint32_t cnt = min((uint32_t)BCH, qhi);
-        __syncthreads();                                    // previous round's flush has read acc / sSlot
-        if (threadIdx.x < cnt) { sA[threadIdx.x] = ra; sB[threadIdx.x] = rb; sC[threadIdx.x] = rc.x; sMask[threadIdx.x] = (unsigned short)__float_as_uint(rc.y); sSlot[threadIdx.x] = rs; }
-        for (uint32_t i = threadIdx.x; i < NACC * (BCH + 1); i += BWD_THREADS) (&acc[0][0])[i] = 0.f;
-        __syncthreads();
-        if (threadIdx.x < BCH && qhi > BCH && threadIdx.x < qhi - BCH) {
-            const uint32_t pos = rg.x + qhi - BCH - 1 - threadIdx.x;
+    // Two barriers per round: [compute r] | flush r + zero its accumulator column + stage r+1 | [compute r+1] ...
+    for (uint32_t i = threadIdx.x; i < NACC * (BCH + 1); i += BWD_THREADS) (&acc[0][0])[i] = 0.f;
+    {
+        const uint32_t cnt0 = min((uint32_t)BCH, qmax);
+        if (threadIdx.x < cnt0) { sA[threadIdx.x] = ra; sB[threadIdx.x] = rb; sC[threadIdx.x] = rc.x; sMask[threadIdx.x] = (unsigned short)__float_as_uint(rc.y); sSlot[0][threadIdx.x] = rs; }
+        if (threadIdx.x < BCH && qmax > BCH && threadIdx.x < qmax - BCH) {
+            const uint32_t pos = rg.x + qmax - BCH - 1 - threadIdx.x;
             ra = b.recA[pos]; rb = b.recB[pos]; rc = b.recC[pos]; rs = b.slot[pos];
         }
+    }
+    __syncthreads();
+    int rnd = 0;
+    for (uint32_t qhi = qmax; qhi > 0; qhi = qhi > BCH ? qhi - BCH : 0, rnd ^= 1) {
+        const uint32_t cnt = min((uint32_t)BCH, qhi);
         {
             const uint32_t nl = build_own_list<BCH>(lists[wv], sMask, cnt, wv, lane, BNULL);
 #pragma unroll 1
@@ -337,13 +341,24 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
                 }
             }
         }
-        __syncthreads();
-        if (threadIdx.x < cnt) {
+        __syncthreads();                                    // every wave is done with the records and the accumulator of this round
+        if (threadIdx.x < cnt) {                            // flush: one 48-B row per instance, then clear the column for the next round
             const uint32_t j = threadIdx.x;
-            float4* row = b.slab + (size_t)sSlot[j] * SLAB_ROW;
+            float4* row = b.slab + (size_t)sSlot[rnd][j] * SLAB_ROW;
             row[0] = make_float4(acc[0][j], acc[1][j], acc[2][j], acc[3][j]);
             row[1] = make_float4(acc[4][j], acc[5][j], acc[6][j], acc[7][j]);
             row[2] = make_float4(acc[8][j], 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < NACC; k++) acc[k][j] = 0.f;
+        }
+        if (qhi > BCH) {                                    // stage the next round (its records were prefetched into registers)
+            const uint32_t qn = qhi - BCH, cntn = min((uint32_t)BCH, qn);
+            if (threadIdx.x < cntn) { sA[threadIdx.x] = ra; sB[threadIdx.x] = rb; sC[threadIdx.x] = rc.x; sMask[threadIdx.x] = (unsigned short)__float_as_uint(rc.y); sSlot[rnd ^ 1][threadIdx.x] = rs; }
+            if (threadIdx.x < BCH && qn > BCH && threadIdx.x < qn - BCH) {
+                const uint32_t pos = rg.x + qn - BCH - 1 - threadIdx.x;
+                ra = b.recA[pos]; rb = b.recB[pos]; rc = b.recC[pos]; rs = b.slot[pos];
+            }
+            __syncthreads();
         }
     }
     stamp(s, tile, 3);
