@@ -29,14 +29,15 @@ __global__ __launch_bounds__(256) void k_render_bwd_det(const ImgState s, const 
     __shared__ QuadLists L;
     __shared__ uint32_t wmax[4];
 
-    const uint32_t tile = s.tile_order[blockIdx.x];
+    const uint4 td = s.tile_desc[blockIdx.x];
+    const uint32_t tile = td.x;
     const uint32_t tx = tile % gx, ty = tile / gx;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int px = tx * TILE + (wv & 1) * 8 + (lane & 7);
     const int py = ty * TILE + (wv >> 1) * 8 + (lane >> 3);
     const bool inside = px < W && py < H;
     const float pixfx = (float)px, pixfy = (float)py;
-    const uint2 rg = s.ranges[tile];
+    const uint2 rg = make_uint2(td.y, td.z);
     const uint32_t n = rg.y - rg.x;
     if (n == 0) return;
     set_wave_priority(n);
@@ -205,9 +206,9 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
     __shared__ float acc[NACC][BCH + 1];                   // per-round sums; column BNULL swallows the padding entries
     __shared__ unsigned short sMask[BCH];
     __shared__ __attribute__((aligned(16))) unsigned short lists[16][BCH + 8];   // one list per block (= per wave)
-    __shared__ uint32_t wmax[16];
 
-    const uint32_t tile = s.tile_order[blockIdx.x];
+    const uint4 td = s.tile_desc[blockIdx.x];
+    const uint32_t tile = td.x;
     const uint32_t tx = tile % gx, ty = tile / gx;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int pp = lane >> 2, e = lane & 3;
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
     const int py = ty * TILE + (wv >> 2) * 4 + (pp >> 2);
     const bool inside = px < W && py < H;
     const float pixfx = (float)px, pixfy = (float)py;
-    const uint2 rg = s.ranges[tile];
+    const uint2 rg = make_uint2(td.y, td.z);
     const uint32_t n = rg.y - rg.x;
     if (n == 0) return;
     set_wave_priority(n);
@@ -234,12 +235,8 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
     float last_alpha = 0.f, lm0 = 0.f, lm1 = 0.f, lm2 = 0.f;   // last_alpha and last_alpha*last_color
     const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);   // backward.cu:460-461
 
-    uint32_t mq = wave_max_u32(last_contributor);
-    if (lane == 0) wmax[wv] = mq;
-    __syncthreads();
-    uint32_t qmax = 0;
-#pragma unroll
-    for (int i = 0; i < 16; i++) qmax = max(qmax, wmax[i]);
+    const uint32_t qmax = min(s.tile_qmax[tile], n);        // deepest position any pixel of the tile blended (k_render_fwd)
+    __syncthreads();                                        // the null record is in LDS
 
     // rows of the never-visited tail are zero
     for (uint32_t q = qmax + threadIdx.x; q < n; q += BWD_THREADS) {

@@ -56,6 +56,8 @@ struct ImgState {
     uint32_t* cursor;         // (unused, kept for layout stability)
     uint32_t* ovf_tiles;      // list of overflow tiles
     uint32_t* tile_order;     // tiles by descending list length: render kernels start the long lists first
+    uint4* tile_desc;         // the same order with the range inlined: (tile, start, end, 0) -- one load instead of a dependent pair
+    uint32_t* tile_qmax;      // per tile: deepest list position any of its pixels blended (max n_contrib), written by k_render_fwd
     float* final_T;           //                                    (imgState.accum_alpha)
     uint32_t* n_contrib;      //                                    (imgState.n_contrib)
     unsigned long long* stamps; // diagnostic builds (-DTGS_STAMPS=1): per tile {fwd start, fwd end, bwd start, bwd end}, 100 MHz ticks
@@ -91,7 +93,8 @@ __host__ __device__ inline size_t img_carve(ImgState& s, char* base, size_t N, s
 {
     char* p = base;
     carve(p, s.meta, 1); carve(p, s.ranges, T); carve(p, s.tile_count, T * CSTRIDE); carve(p, s.cursor, 1);
-    carve(p, s.ovf_tiles, T); carve(p, s.tile_order, T); carve(p, s.final_T, N); carve(p, s.n_contrib, N);
+    carve(p, s.ovf_tiles, T); carve(p, s.tile_order, T); carve(p, s.tile_desc, T); carve(p, s.tile_qmax, T);
+    carve(p, s.final_T, N); carve(p, s.n_contrib, N);
     carve(p, s.stamps, 4 * T);
     return (size_t)(p - base) + 256;
 }

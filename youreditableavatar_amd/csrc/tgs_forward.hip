@@ -264,7 +264,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const 
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const uint32_t i = k * SCAN_THREADS + threadIdx.x;
-                if (i < n) { const uint32_t c = r[k].y - r[k].x; s.tile_order[atomicAdd(&hist[c ? 32 - __builtin_clz(c) : 0], 1u)] = sc + i; }
+                if (i < n) {
+                    const uint32_t c = r[k].y - r[k].x, pos = atomicAdd(&hist[c ? 32 - __builtin_clz(c) : 0], 1u);
+                    s.tile_order[pos] = sc + i;
+                    s.tile_desc[pos] = make_uint4(sc + i, r[k].x, r[k].y, 0u);
+                }
             }
         }
         mx = wave_max_u32(mx);
@@ -451,8 +455,8 @@ template <int NT>
 __global__ __launch_bounds__(NT) void k_tile_sort(const ImgState s, const BinState b, uint32_t first, uint32_t sort_cap)
 {
     extern __shared__ unsigned long long lk[];
-    const uint32_t tile = s.tile_order[first + blockIdx.x];
-    const uint2 rg = s.ranges[tile];
+    const uint4 td = s.tile_desc[first + blockIdx.x];
+    const uint2 rg = make_uint2(td.y, td.z);
     const uint32_t n = rg.y - rg.x;
     if (n < 2 || n > sort_cap) return;
     for (uint32_t i = threadIdx.x; i < n; i += NT) lk[i] = b.keys[rg.x + i];
@@ -560,8 +564,10 @@ __global__ __launch_bounds__(FWD_THREADS) void k_render_fwd(const ImgState s, co
     __shared__ unsigned short sMask[FCH];
     __shared__ __attribute__((aligned(16))) unsigned short lists[16][FCH + 8];   // one list per block (= per wave)
     __shared__ uint32_t wave_alive[2][16];                 // double-buffered "this wave still has live pixels"
+    __shared__ uint32_t wave_qmax[16];
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-    const uint32_t tile = s.tile_order[blockIdx.x];
+    const uint4 td = s.tile_desc[blockIdx.x];
+    const uint32_t tile = td.x;
     const uint32_t tx = tile % gx, ty = tile / gx;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int pp = lane >> 2, e = lane & 3;                // pixel of the block, entry slot of the group
@@ -569,7 +575,7 @@ __global__ __launch_bounds__(FWD_THREADS) void k_render_fwd(const ImgState s, co
     const int py = ty * TILE + (wv >> 2) * 4 + (pp >> 2);
     const bool inside = px < W && py < H;
     const float pixfx = (float)px, pixfy = (float)py;
-    const uint2 rg = s.ranges[tile];
+    const uint2 rg = make_uint2(td.y, td.z);
     set_wave_priority(rg.y - rg.x);
     stamp(s, tile, 0);
     bool done = !inside;                                   // per pixel; identical in the 4 lanes of a quad
@@ -653,6 +659,18 @@ __global__ __launch_bounds__(FWD_THREADS) void k_render_fwd(const ImgState s, co
         out_color[N + pix_id] = C1 + T * bg1;
         out_color[2 * N + pix_id] = C2 + T * bg2;
     }
+    // deepest blended list position of the tile: the backward starts there without a reduction of its own
+    {
+        const uint32_t m = wave_max_u32(inside ? last_contributor : 0u);
+        if (lane == 0) wave_qmax[wv] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t q = 0;
+#pragma unroll
+            for (int i = 0; i < 16; i++) q = max(q, wave_qmax[i]);
+            s.tile_qmax[tile] = q;
+        }
+    }
     stamp(s, tile, 1);
 }
 
@@ -660,8 +678,9 @@ __global__ __launch_bounds__(FWD_THREADS) void k_render_fwd(const ImgState s, co
 __global__ __launch_bounds__(256) void k_fill_empty(const ImgState s, int W, int H, uint32_t gx, uint32_t first, const float* __restrict__ bg,
                                                     float* __restrict__ out_color)
 {
-    const uint32_t tile = s.tile_order[first + blockIdx.x];
+    const uint32_t tile = s.tile_desc[first + blockIdx.x].x;
     const int px = (tile % gx) * TILE + (threadIdx.x & 15), py = (tile / gx) * TILE + (threadIdx.x >> 4);
+    if (threadIdx.x == 0) s.tile_qmax[tile] = 0;
     if (px < W && py < H) {
         const size_t pix_id = (size_t)W * py + px, N = (size_t)W * H;
         s.final_T[pix_id] = 1.0f;
