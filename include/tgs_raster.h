@@ -119,6 +119,18 @@ enum {
 int tgs_profile_begin(int max_records);
 int tgs_profile_end(double* ms_sum, int64_t* counts);
 
+/* ---- "next" row 1: the caller-side SH -> RGB of every training step, fused ----
+ * Replaces TetGS.get_points_rgb (Edit_core/tetgs_scene/tetgs_model.py:413-442: F.normalize(positions - camera_center),
+ * eval_sh of Edit_core/utils/spherical_harmonics.py:117-172, + 0.5, clamp_min 0) and its autograd.
+ * sh[P,M,3] (M <= 16), levels = sh_levels (1..4, uses levels^2 coefficients).  Exactly one of
+ * (positions[P,3] + camera_center[3]) / directions[P,3].  colors[P,3].  Backward writes every element of
+ * dL_dsh[P,M,3] (zeros above the active levels), and dL_dpositions or dL_ddirections (either may be NULL). */
+int tgs_sh_rgb_forward(void* stream, int P, int M, int levels, const float* sh, const float* positions,
+                       const float* camera_center, const float* directions, float* colors);
+int tgs_sh_rgb_backward(void* stream, int P, int M, int levels, const float* sh, const float* positions,
+                        const float* camera_center, const float* directions, const float* dL_dcolors,
+                        float* dL_dsh, float* dL_dpositions, float* dL_ddirections);
+
 /* Test knob (process-wide): longest tile list that is depth-sorted inside LDS; longer lists take the
  * multi-workgroup global-memory path.  Power of two in [2, 8192]; default 8192. */
 int tgs_set_sort_lds_cap(unsigned cap);

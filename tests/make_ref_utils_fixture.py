@@ -45,6 +45,23 @@ def main():
         n = (deg + 1) ** 2
         res = shu.eval_sh(deg, torch.from_numpy(sh[:, :n, :]).transpose(1, 2), torch.from_numpy(d))
         out[f"sh_out_deg{deg}"] = res.numpy()
+    # get_points_rgb (tetgs_model.py:413-442) composed from the reference's own eval_sh, with autograd gradients
+    Pn = 200
+    shc = torch.tensor(rng.standard_normal((Pn, 16, 3)) * 0.6, dtype=torch.float32, requires_grad=True)
+    pos = torch.tensor(rng.standard_normal((Pn, 3)), dtype=torch.float32, requires_grad=True)
+    cam = torch.tensor([[0.3, -2.0, 1.5]], dtype=torch.float32)
+    gcol = torch.tensor(rng.standard_normal((Pn, 3)), dtype=torch.float32)
+    out["rgb_sh"] = shc.detach().numpy(); out["rgb_pos"] = pos.detach().numpy(); out["rgb_cam"] = cam.numpy(); out["rgb_gcol"] = gcol.numpy()
+    for levels in (1, 2, 3, 4):
+        for t in (shc, pos):
+            t.grad = None
+        dirs = torch.nn.functional.normalize(pos - cam, dim=-1)
+        view = shc[:, :levels ** 2].transpose(-1, -2).reshape(-1, 3, levels ** 2)
+        colors = torch.clamp_min(shu.eval_sh(levels - 1, view, dirs) + 0.5, 0.0).view(-1, 3)
+        colors.backward(gcol)
+        out[f"rgb_colors_l{levels}"] = colors.detach().numpy()
+        out[f"rgb_dsh_l{levels}"] = shc.grad.numpy().copy()
+        out[f"rgb_dpos_l{levels}"] = pos.grad.numpy().copy() if pos.grad is not None else np.zeros((Pn, 3), np.float32)
     np.savez_compressed(OUT, **out)
     print("wrote", OUT)
 

@@ -110,3 +110,26 @@ def test_cloud_is_deterministic():
         assert np.array_equal(a[k], b[k])
     assert a["shs"].shape == (1000, 16, 3) and a["opacities"].shape == (1000, 1)
     assert np.allclose(np.linalg.norm(a["rotations"], axis=1), 1.0, atol=1e-5)
+
+
+def test_sh_color_oracle_matches_reference_get_points_rgb(ref_fix):
+    """oracle/sh_color_ref.py (the checker of the fused SH->RGB op) against outputs AND gradients of the reference's
+    own eval_sh composed as in tetgs_model.py:413-442."""
+    from oracle import sh_color_ref
+    for levels in (1, 2, 3, 4):
+        sh = torch.tensor(ref_fix["rgb_sh"], requires_grad=True)
+        pos = torch.tensor(ref_fix["rgb_pos"], requires_grad=True)
+        col = sh_color_ref.points_rgb(sh, levels, positions=pos, camera_centers=torch.tensor(ref_fix["rgb_cam"]))
+        col.backward(torch.tensor(ref_fix["rgb_gcol"]))
+        assert np.allclose(col.detach().numpy(), ref_fix[f"rgb_colors_l{levels}"], rtol=1e-6, atol=1e-7)
+        assert np.allclose(sh.grad.numpy(), ref_fix[f"rgb_dsh_l{levels}"], rtol=1e-6, atol=1e-7)
+        if levels > 1:
+            assert np.allclose(pos.grad.numpy(), ref_fix[f"rgb_dpos_l{levels}"], rtol=1e-5, atol=1e-6)
+
+
+def test_sh_color_requires_gpu_and_a_mode():
+    from youreditableavatar_amd import sh_color
+    with pytest.raises(ValueError, match="Either camera_centers or directions must be provided."):
+        sh_color.points_rgb(torch.zeros(4, 16, 3), 4, positions=torch.zeros(4, 3))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        sh_color.points_rgb(torch.zeros(4, 16, 3), 4, directions=torch.zeros(4, 3))

@@ -1,0 +1,200 @@
+// tgs_shcolor.hip -- fused SH -> RGB of the Gaussian colours OUTSIDE the rasterizer ("next" row 1 of SURVEY.md 8f).
+//
+// Replaces what every training step of the reference does in ~25 PyTorch element-wise kernels over [P,3,16]
+// (Edit_core/tetgs_scene/tetgs_model.py:413-442  get_points_rgb:
+//      dirs = normalize(positions - camera_center);  colors = clamp_min(eval_sh(levels-1, sh, dirs) + 0.5, 0)
+//  with eval_sh of Edit_core/utils/spherical_harmonics.py:117-172) and its autograd.
+// One thread per Gaussian; M = 16 rows (192 B) are staged through LDS so global memory sees coalesced 16-B accesses.
+#include "tgs_device.hpp"
+
+namespace tgs {
+
+// basis[k] = d colour / d sh[k] (same polynomials as cuda_rasterizer/forward.cu:20-71), levels = degree + 1
+__device__ __forceinline__ void sh_basis(int levels, float x, float y, float z, float (&bs)[16])
+{
+#pragma unroll
+    for (int k = 0; k < 16; k++) bs[k] = 0.f;
+    bs[0] = SH_C0;
+    if (levels > 1) {
+        bs[1] = -SH_C1 * y; bs[2] = SH_C1 * z; bs[3] = -SH_C1 * x;
+        if (levels > 2) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            bs[4] = SH_C2_0 * xy; bs[5] = SH_C2_1 * yz; bs[6] = SH_C2_2 * (2.f * zz - xx - yy); bs[7] = SH_C2_3 * xz; bs[8] = SH_C2_4 * (xx - yy);
+            if (levels > 3) {
+                bs[9] = SH_C3_0 * y * (3.f * xx - yy); bs[10] = SH_C3_1 * xy * z; bs[11] = SH_C3_2 * y * (4.f * zz - xx - yy);
+                bs[12] = SH_C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy); bs[13] = SH_C3_4 * x * (4.f * zz - xx - yy);
+                bs[14] = SH_C3_5 * z * (xx - yy); bs[15] = SH_C3_6 * x * (xx - 3.f * yy);
+            }
+        }
+    }
+}
+
+struct ShArgs {
+    int P, M, levels;
+    const float* sh;          // [P, M, 3]
+    const float* positions;   // [P, 3] (camera mode) or NULL
+    const float* camera;      // [3] device (camera mode) or NULL
+    const float* directions;  // [P, 3] (direction mode) or NULL
+    float* colors;            // fwd out [P, 3]
+    const float* dL_dcolors;  // bwd in
+    float* dL_dsh;            // bwd out [P, M, 3] (every element written)
+    float* dL_dpositions;     // bwd out [P, 3] or NULL
+    float* dL_ddirections;    // bwd out [P, 3] or NULL
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(PRE_BLOCK) void k_sh_rgb(const ShArgs a)
+{
+    __shared__ float4 sh_lds[PRE_BLOCK * 12];
+    const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
+    const bool in_range = idx < a.P;
+    const int ncoef = a.levels * a.levels;
+    const bool staged = a.M == 16;
+    const size_t base4 = (size_t)blockIdx.x * PRE_BLOCK * 12, total4 = (size_t)a.P * 12;
+    float camx = 0.f, camy = 0.f, camz = 0.f;
+    if (a.camera) { camx = a.camera[0]; camy = a.camera[1]; camz = a.camera[2]; }
+    if (staged) {
+        const float4* s4 = reinterpret_cast<const float4*>(a.sh);
+#pragma unroll
+        for (int q = 0; q < 12; q++) { const size_t i = base4 + q * PRE_BLOCK + threadIdx.x; if (i < total4) sh_lds[q * PRE_BLOCK + threadIdx.x] = s4[i]; }
+        __syncthreads();
+    }
+    float shv[48];
+#pragma unroll
+    for (int q = 0; q < 48; q++) shv[q] = 0.f;
+    float x = 0.f, y = 0.f, z = 1.f, vx = 0.f, vy = 0.f, vz = 0.f, inv_len = 0.f;
+    if (in_range) {
+        if (staged) {
+#pragma unroll
+            for (int q = 0; q < 12; q++) {
+                if (q * 4 < ncoef * 3) { const float4 t = sh_lds[threadIdx.x * 12 + q]; shv[4 * q] = t.x; shv[4 * q + 1] = t.y; shv[4 * q + 2] = t.z; shv[4 * q + 3] = t.w; }
+            }
+        } else {
+            const float* sh = a.sh + (size_t)idx * a.M * 3;
+#pragma unroll
+            for (int q = 0; q < 48; q++) if (q < ncoef * 3) shv[q] = sh[q];
+        }
+        if (a.positions) {      // torch.nn.functional.normalize: v / max(|v|, 1e-12)
+            vx = a.positions[3 * (size_t)idx] - camx; vy = a.positions[3 * (size_t)idx + 1] - camy; vz = a.positions[3 * (size_t)idx + 2] - camz;
+            inv_len = 1.0f / fmaxf(sqrtf(vx * vx + vy * vy + vz * vz), 1e-12f);
+            x = vx * inv_len; y = vy * inv_len; z = vz * inv_len;
+        } else {
+            x = a.directions[3 * (size_t)idx]; y = a.directions[3 * (size_t)idx + 1]; z = a.directions[3 * (size_t)idx + 2];
+        }
+    }
+    float bs[16];
+    sh_basis(a.levels, x, y, z, bs);
+    float res[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        if (k < ncoef) { res[0] += bs[k] * shv[3 * k]; res[1] += bs[k] * shv[3 * k + 1]; res[2] += bs[k] * shv[3 * k + 2]; }
+    }
+    if (!BWD) {
+        if (in_range) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) a.colors[3 * (size_t)idx + c] = fmaxf(res[c] + 0.5f, 0.f);
+        }
+        return;
+    }
+    // ---- backward ----
+    float dRGB[3] = {0.f, 0.f, 0.f};
+    if (in_range) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) dRGB[c] = (res[c] + 0.5f >= 0.f) ? a.dL_dcolors[3 * (size_t)idx + c] : 0.f;   // clamp_min passes the gradient where x >= min
+    }
+    if (in_range && (a.dL_dpositions || a.dL_ddirections)) {
+        // d colour / d direction (cuda_rasterizer/backward.cu:60-123 polynomials), then through the normalisation
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+#define SH(k) shv[3 * (k) + c]
+            float dx_ = 0.f, dy_ = 0.f, dz_ = 0.f;
+            if (a.levels > 1) {
+                dx_ = -SH_C1 * SH(3); dy_ = -SH_C1 * SH(1); dz_ = SH_C1 * SH(2);
+                if (a.levels > 2) {
+                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                    dx_ += SH_C2_0 * y * SH(4) + SH_C2_2 * 2.f * -x * SH(6) + SH_C2_3 * z * SH(7) + SH_C2_4 * 2.f * x * SH(8);
+                    dy_ += SH_C2_0 * x * SH(4) + SH_C2_1 * z * SH(5) + SH_C2_2 * 2.f * -y * SH(6) + SH_C2_4 * 2.f * -y * SH(8);
+                    dz_ += SH_C2_1 * y * SH(5) + SH_C2_2 * 2.f * 2.f * z * SH(6) + SH_C2_3 * x * SH(7);
+                    if (a.levels > 3) {
+                        dx_ += SH_C3_0 * SH(9) * 3.f * 2.f * xy + SH_C3_1 * SH(10) * yz + SH_C3_2 * SH(11) * -2.f * xy + SH_C3_3 * SH(12) * -3.f * 2.f * xz +
+                               SH_C3_4 * SH(13) * (-3.f * xx + 4.f * zz - yy) + SH_C3_5 * SH(14) * 2.f * xz + SH_C3_6 * SH(15) * 3.f * (xx - yy);
+                        dy_ += SH_C3_0 * SH(9) * 3.f * (xx - yy) + SH_C3_1 * SH(10) * xz + SH_C3_2 * SH(11) * (-3.f * yy + 4.f * zz - xx) +
+                               SH_C3_3 * SH(12) * -3.f * 2.f * yz + SH_C3_4 * SH(13) * -2.f * xy + SH_C3_5 * SH(14) * -2.f * yz + SH_C3_6 * SH(15) * -3.f * 2.f * xy;
+                        dz_ += SH_C3_1 * SH(10) * xy + SH_C3_2 * SH(11) * 4.f * 2.f * yz + SH_C3_3 * SH(12) * 3.f * (2.f * zz - xx - yy) +
+                               SH_C3_4 * SH(13) * 4.f * 2.f * xz + SH_C3_5 * SH(14) * (xx - yy);
+                    }
+                }
+            }
+#undef SH
+            gx += dx_ * dRGB[c]; gy += dy_ * dRGB[c]; gz += dz_ * dRGB[c];
+        }
+        if (a.dL_ddirections) { a.dL_ddirections[3 * (size_t)idx] = gx; a.dL_ddirections[3 * (size_t)idx + 1] = gy; a.dL_ddirections[3 * (size_t)idx + 2] = gz; }
+        if (a.dL_dpositions) {   // d(v/|v|)/dv = (I - d d^T)/|v|   (the max(.,1e-12) branch has zero measure)
+            const float dot = x * gx + y * gy + z * gz;
+            a.dL_dpositions[3 * (size_t)idx] = (gx - x * dot) * inv_len;
+            a.dL_dpositions[3 * (size_t)idx + 1] = (gy - y * dot) * inv_len;
+            a.dL_dpositions[3 * (size_t)idx + 2] = (gz - z * dot) * inv_len;
+        }
+    }
+    // dL_dsh[k][c] = basis_k * dRGB[c], zeros above the active levels
+    if (staged) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 12; q++) {
+            float o[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) { const int i = 4 * q + t; o[t] = (i / 3 < ncoef ? bs[i / 3] : 0.f) * dRGB[i % 3]; }
+            sh_lds[threadIdx.x * 12 + q] = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        __syncthreads();
+        float4* d4 = reinterpret_cast<float4*>(a.dL_dsh);
+#pragma unroll
+        for (int q = 0; q < 12; q++) { const size_t i = base4 + q * PRE_BLOCK + threadIdx.x; if (i < total4) d4[i] = sh_lds[q * PRE_BLOCK + threadIdx.x]; }
+    } else if (in_range) {
+        float* dsh = a.dL_dsh + (size_t)idx * a.M * 3;
+        for (int k = 0; k < a.M; k++) {
+            const float ck = (k < 16 && k < ncoef) ? bs[k < 16 ? k : 0] : 0.f;
+            dsh[3 * k] = ck * dRGB[0]; dsh[3 * k + 1] = ck * dRGB[1]; dsh[3 * k + 2] = ck * dRGB[2];
+        }
+    }
+}
+
+void launch_sh_rgb(hipStream_t st, const ShArgs& a, bool backward)
+{
+    const dim3 grid((unsigned)n_blocks((size_t)a.P)), blk(PRE_BLOCK);
+    if (backward) hipLaunchKernelGGL((k_sh_rgb<true>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((k_sh_rgb<false>), grid, blk, 0, st, a);
+}
+
+}  // namespace tgs
+
+extern "C" {
+#include "../../include/tgs_raster.h"
+
+int tgs_sh_rgb_forward(void* stream, int P, int M, int levels, const float* sh, const float* positions, const float* camera_center,
+                       const float* directions, float* colors)
+{
+    if (P == 0) return TGS_OK;
+    if (P < 0 || levels < 1 || levels > 4 || M < levels * levels || M > 16 || !sh || !colors || ((positions && camera_center) == (directions != nullptr)))
+        return TGS_ERR_INVALID;
+    tgs::ShArgs a{};
+    a.P = P; a.M = M; a.levels = levels; a.sh = sh; a.positions = positions; a.camera = camera_center; a.directions = directions; a.colors = colors;
+    tgs::launch_sh_rgb((hipStream_t)stream, a, false);
+    return hipGetLastError() == hipSuccess ? TGS_OK : TGS_ERR_HIP;
+}
+
+int tgs_sh_rgb_backward(void* stream, int P, int M, int levels, const float* sh, const float* positions, const float* camera_center,
+                        const float* directions, const float* dL_dcolors, float* dL_dsh, float* dL_dpositions, float* dL_ddirections)
+{
+    if (P == 0) return TGS_OK;
+    if (P < 0 || levels < 1 || levels > 4 || M < levels * levels || M > 16 || !sh || !dL_dcolors || !dL_dsh ||
+        ((positions && camera_center) == (directions != nullptr)))
+        return TGS_ERR_INVALID;
+    tgs::ShArgs a{};
+    a.P = P; a.M = M; a.levels = levels; a.sh = sh; a.positions = positions; a.camera = camera_center; a.directions = directions;
+    a.dL_dcolors = dL_dcolors; a.dL_dsh = dL_dsh; a.dL_dpositions = positions ? dL_dpositions : nullptr; a.dL_ddirections = directions ? dL_ddirections : nullptr;
+    tgs::launch_sh_rgb((hipStream_t)stream, a, true);
+    return hipGetLastError() == hipSuccess ? TGS_OK : TGS_ERR_HIP;
+}
+}

@@ -1,0 +1,93 @@
+"""Fused SH -> RGB of the Gaussian colours outside the rasterizer ("next" row 1).
+
+Drop-in for the body of ``TetGS.get_points_rgb`` (Edit_core/tetgs_scene/tetgs_model.py:413-442), which every
+training step of the reference runs as ~25 element-wise PyTorch kernels plus their autograd:
+
+    render_directions = F.normalize(positions - camera_centers, dim=-1)          # or the given directions
+    shs_view = sh_coordinates[:, :sh_levels**2].transpose(-1, -2).view(-1, 3, sh_levels**2)
+    colors = torch.clamp_min(eval_sh(sh_levels - 1, shs_view, render_directions) + 0.5, 0.0).view(-1, 3)
+
+One HIP kernel forward, one backward (tgs_sh_rgb_forward / tgs_sh_rgb_backward in include/tgs_raster.h).
+HIP tensors only; there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from .diff_gaussian_rasterization import _C as _rast_c
+
+_lib = _rast_c._lib
+_lib.tgs_sh_rgb_forward.restype = C.c_int
+_lib.tgs_sh_rgb_forward.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5
+_lib.tgs_sh_rgb_backward.restype = C.c_int
+_lib.tgs_sh_rgb_backward.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 8
+
+
+def _check(t: torch.Tensor, name: str, dev) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"expected scalar type Float but found {t.dtype} for {name}")
+    if not t.is_cuda:
+        raise RuntimeError(f"sh_color (MI355X build) has no CPU path: {name} must be on a HIP device")
+    return t.to(dev).contiguous()
+
+
+class _SHColor(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sh_coordinates, positions, camera_center, directions, sh_levels):
+        dev = sh_coordinates.device
+        sh = _check(sh_coordinates, "sh_coordinates", dev)
+        P, M = int(sh.shape[0]), int(sh.shape[1])
+        pos = _check(positions, "positions", dev) if positions is not None else None
+        cam = _check(camera_center.reshape(-1), "camera_centers", dev) if camera_center is not None else None
+        dirs = _check(directions, "directions", dev) if directions is not None else None
+        colors = torch.empty((P, 3), dtype=torch.float32, device=dev)
+        p = lambda t: None if t is None else t.data_ptr()
+        with torch.cuda.device(dev):
+            r = _lib.tgs_sh_rgb_forward(torch.cuda.current_stream(dev).cuda_stream, P, M, int(sh_levels), p(sh), p(pos), p(cam), p(dirs), colors.data_ptr())
+        if r < 0:
+            raise RuntimeError(f"tgs_sh_rgb_forward failed (code {r})")
+        ctx.save_for_backward(sh, pos if pos is not None else torch.Tensor([]), cam if cam is not None else torch.Tensor([]),
+                              dirs if dirs is not None else torch.Tensor([]))
+        ctx.levels = int(sh_levels)
+        return colors
+
+    @staticmethod
+    def backward(ctx, grad_colors):
+        sh, pos, cam, dirs = ctx.saved_tensors
+        dev = sh.device
+        P, M = int(sh.shape[0]), int(sh.shape[1])
+        pos = pos if pos.numel() else None
+        cam = cam if cam.numel() else None
+        dirs = dirs if dirs.numel() else None
+        g = _check(grad_colors, "grad_colors", dev)
+        d_sh = torch.empty_like(sh)
+        d_pos = torch.empty_like(pos) if pos is not None else None
+        d_dir = torch.empty_like(dirs) if dirs is not None else None
+        p = lambda t: None if t is None else t.data_ptr()
+        with torch.cuda.device(dev):
+            r = _lib.tgs_sh_rgb_backward(torch.cuda.current_stream(dev).cuda_stream, P, M, ctx.levels, p(sh), p(pos), p(cam), p(dirs), g.data_ptr(),
+                                         d_sh.data_ptr(), p(d_pos), p(d_dir))
+        if r < 0:
+            raise RuntimeError(f"tgs_sh_rgb_backward failed (code {r})")
+        return d_sh, d_pos, None, d_dir, None
+
+
+def points_rgb(sh_coordinates: torch.Tensor, sh_levels: int, positions: Optional[torch.Tensor] = None,
+               camera_centers: Optional[torch.Tensor] = None, directions: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """colors[P,3] = clamp_min(eval_sh(sh_levels-1, sh_coordinates[:, :sh_levels**2], dirs) + 0.5, 0).
+
+    ``sh_coordinates`` is the [P, M, 3] tensor the reference keeps (``TetGS.sh_coordinates``); give either
+    ``positions`` + ``camera_centers`` ([3] or [1,3]) or unit ``directions`` -- get_points_rgb's two modes
+    (tetgs_model.py:424-429; neither -> ValueError like the reference)."""
+    if camera_centers is not None:
+        if positions is None:
+            raise ValueError("positions are required with camera_centers")
+        if camera_centers.numel() != 3:
+            raise ValueError("one camera centre ([3] or [1,3]) is supported")
+        return _SHColor.apply(sh_coordinates, positions, camera_centers, None, sh_levels)
+    if directions is not None:
+        return _SHColor.apply(sh_coordinates, None, None, directions, sh_levels)
+    raise ValueError("Either camera_centers or directions must be provided.")
