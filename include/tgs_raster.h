@@ -131,6 +131,14 @@ int tgs_sh_rgb_backward(void* stream, int P, int M, int levels, const float* sh,
                         const float* camera_center, const float* directions, const float* dL_dcolors,
                         float* dL_dsh, float* dL_dpositions, float* dL_ddirections);
 
+/* ---- "next" row 4: simple-knn ----
+ * distCUDA2 (Edit_core/thirdparties/simple-knn/spatial.cu:15-26 -> SimpleKNN::knn, simple_knn.cu:185-221):
+ * mean_dist2[i] = mean of the 3 smallest squared distances from points[i] to the other points (FLT_MAX terms, i.e.
+ * +inf, when fewer than 3 others exist, like the reference).  workspace: device scratch of
+ * tgs_dist2_workspace_bytes(P) bytes. */
+size_t tgs_dist2_workspace_bytes(int P);
+int tgs_dist2(void* stream, int P, const float* points, float* mean_dist2, void* workspace, size_t workspace_bytes);
+
 /* Test knob (process-wide): longest tile list that is depth-sorted inside LDS; longer lists take the
  * multi-workgroup global-memory path.  Power of two in [2, 8192]; default 8192. */
 int tgs_set_sort_lds_cap(unsigned cap);

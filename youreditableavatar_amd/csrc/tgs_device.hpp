@@ -348,6 +348,37 @@ __device__ __forceinline__ void wave_reduce36(const float (&v)[36], float (&r)[9
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bitonic network, all comparators ascending ("flip" + "disperse" form): because the larger key
+// always moves to the higher index, virtual +inf padding behind n never has to exist in memory.
+//   for k = 2,4,..,npad:  flip(k);  for j = k/4,..,1: disperse(j)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pair_flip(uint32_t t, uint32_t k, uint32_t& i, uint32_t& l)
+{
+    const uint32_t h = k >> 1, blk = t / h, off = t % h;
+    i = blk * k + off;
+    l = blk * k + (k - 1 - off);
+}
+__device__ __forceinline__ void pair_disperse(uint32_t t, uint32_t j, uint32_t& i, uint32_t& l)
+{
+    i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+    l = i + j;
+}
+__device__ __forceinline__ uint32_t next_pow2(uint32_t n)
+{
+    return n <= 1 ? 1u : 1u << (32 - __builtin_clz(n - 1));
+}
+
+template <typename KeyPtr>
+__device__ __forceinline__ void cmp_swap(KeyPtr keys, uint32_t i, uint32_t l, uint32_t n)
+{
+    if (l < n) {
+        const unsigned long long a = keys[i], c = keys[l];
+        if (a > c) { keys[i] = c; keys[l] = a; }
+    }
+}
+
+
 // SH basis constants (cuda_rasterizer/auxiliary.h:22-39)
 __device__ constexpr float SH_C0 = 0.28209479177387814f;
 __device__ constexpr float SH_C1 = 0.4886025119029199f;

@@ -344,35 +344,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_scatter(int P, const GeomState g,
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// bitonic network, all comparators ascending ("flip" + "disperse" form): because the larger key
-// always moves to the higher index, virtual +inf padding behind n never has to exist in memory.
-//   for k = 2,4,..,npad:  flip(k);  for j = k/4,..,1: disperse(j)
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void pair_flip(uint32_t t, uint32_t k, uint32_t& i, uint32_t& l)
-{
-    const uint32_t h = k >> 1, blk = t / h, off = t % h;
-    i = blk * k + off;
-    l = blk * k + (k - 1 - off);
-}
-__device__ __forceinline__ void pair_disperse(uint32_t t, uint32_t j, uint32_t& i, uint32_t& l)
-{
-    i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-    l = i + j;
-}
-__device__ __forceinline__ uint32_t next_pow2(uint32_t n)
-{
-    return n <= 1 ? 1u : 1u << (32 - __builtin_clz(n - 1));
-}
-
-template <typename KeyPtr>
-__device__ __forceinline__ void cmp_swap(KeyPtr keys, uint32_t i, uint32_t l, uint32_t n)
-{
-    if (l < n) {
-        const unsigned long long a = keys[i], c = keys[l];
-        if (a > c) { keys[i] = c; keys[l] = a; }
-    }
-}
+// (the bitonic network helpers pair_flip / pair_disperse / cmp_swap live in tgs_device.hpp)
 
 // Conservative 16-bit mask of the tile's 4x4 blocks of 4x4 pixels (bit by*4+bx) that a splat can reach with
 // alpha >= 1/255:  alpha = o*exp(power) >= 1/255  <=>  -power <= tau, tau = ln(255 o), where
