@@ -70,6 +70,21 @@ void prof_end_stage(hipStream_t st, int stage)
 }
 }  // namespace
 
+namespace tgs {
+int set_error(int code, const char* msg)
+{
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    return code;
+}
+int hip_status(const char* what)
+{
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return TGS_OK;
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return TGS_ERR_HIP;
+}
+}  // namespace tgs
+
 static int fail(int code, const char* fmt, ...)
 {
     va_list ap;

@@ -105,6 +105,10 @@ __host__ __device__ inline size_t bin_carve(BinState& b, char* base, size_t R)
     return (size_t)(p - base) + 256;
 }
 
+// host side (tgs_api.hip): record the message tgs_last_error() returns
+int set_error(int code, const char* msg);
+int hip_status(const char* what);            // hipGetLastError() -> TGS_OK / TGS_ERR_HIP (+ message)
+
 #ifdef __HIPCC__
 // ---------------------------------------------------------------------------------------------
 // wave64 primitives

@@ -2,7 +2,7 @@
 //
 // distCUDA2(points[P,3]) -> float[P]: mean of the 3 smallest squared distances to OTHER points
 // (Edit_core/thirdparties/simple-knn/spatial.cu:15-26, simple_knn.cu:185-221).  Same algorithm as the reference:
-// Morton order, boxes of 1024 consecutive points with their AABB, per point an upper bound from its 6 Morton
+// Morton order, boxes of 1024 consecutive points with their AABB, per point an upper bound from its Morton
 // neighbours, then every box whose AABB is not farther than the bound is scanned exhaustively -- so the result is the
 // exact 3-NN mean (up to fp32 rounding of the distances).  What differs is how it runs: the Morton sort is the same
 // all-ascending bitonic network as the tile sort (LDS for strides < 8192, no cub/thrust), box AABBs by wave
@@ -20,12 +20,13 @@ struct KnnWork {
     unsigned long long* keys;          // [P] morton << 32 | index
     float4* sorted;                    // [P] points in Morton order (xyz, bits(original index))
     float* boxes;                      // [nbox][6]
+    float* subs;                       // [nbox * 16][6] AABBs of the 64-point groups inside each box
 };
 __host__ __device__ inline size_t knn_carve(KnnWork& w, char* base, size_t P)
 {
     char* p = base;
     const size_t nblk = (P + 255) / 256, nbox = (P + KNN_BOX - 1) / KNN_BOX;
-    carve(p, w.partial, nblk * 6); carve(p, w.minmax, 8); carve(p, w.keys, P); carve(p, w.sorted, P); carve(p, w.boxes, nbox * 6);
+    carve(p, w.partial, nblk * 6); carve(p, w.minmax, 8); carve(p, w.keys, P); carve(p, w.sorted, P); carve(p, w.boxes, nbox * 6); carve(p, w.subs, nbox * 16 * 6);
     return (size_t)(p - base) + 256;
 }
 
@@ -142,13 +143,19 @@ __global__ __launch_bounds__(256) void k_knn_gather(int P, const float* __restri
     sorted[i] = make_float4(pts[3 * (size_t)id], pts[3 * (size_t)id + 1], pts[3 * (size_t)id + 2], __uint_as_float(id));
 }
 
-// boxMinMax (simple_knn.cu:78-117)
-__global__ __launch_bounds__(KNN_BOX) void k_knn_boxes(int P, const float4* __restrict__ sorted, float* boxes)
+// boxMinMax (simple_knn.cu:78-117), plus the AABB of every wave's 64 points (second level of the rejection test)
+__global__ __launch_bounds__(KNN_BOX) void k_knn_boxes(int P, const float4* __restrict__ sorted, float* boxes, float* subs)
 {
     const int i = blockIdx.x * KNN_BOX + threadIdx.x;
     const bool have = i < P;
     float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
     if (have) p = sorted[i];
+    {
+        float v[6] = {have ? p.x : FLT_MAX, have ? p.y : FLT_MAX, have ? p.z : FLT_MAX, have ? p.x : -FLT_MAX, have ? p.y : -FLT_MAX, have ? p.z : -FLT_MAX};
+#pragma unroll
+        for (int k = 0; k < 3; k++) { v[k] = wave_min_f(v[k]); v[3 + k] = wave_max_f(v[3 + k]); }
+        if ((threadIdx.x & 63) == 0) for (int k = 0; k < 6; k++) subs[6 * ((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) + k] = v[k];
+    }
     block_minmax<KNN_BOX>(p.x, p.y, p.z, have, boxes + 6 * (size_t)blockIdx.x);
 }
 
@@ -162,39 +169,53 @@ __device__ __forceinline__ void update3(float px, float py, float pz, float qx, 
     if (b2 > d) { b2 = d; }
 }
 
-// boxMeanDist (simple_knn.cu:147-183): one thread per point in Morton order, one wave decides per box
-__global__ __launch_bounds__(256) void k_knn_meandist(int P, const float4* __restrict__ sorted, const float* __restrict__ boxes, int nbox, float* __restrict__ out)
+// distBoxPoint (simple_knn.cu:119-130)
+__device__ __forceinline__ float dist_box_point(const float* __restrict__ bx, float px, float py, float pz)
+{
+    const float mnx = bx[0], mny = bx[1], mnz = bx[2], mxx = bx[3], mxy = bx[4], mxz = bx[5];   // wave-uniform: scalar loads
+    float dx = 0.f, dy = 0.f, dz = 0.f;
+    if (px < mnx || px > mxx) dx = fminf(fabsf(px - mnx), fabsf(px - mxx));
+    if (py < mny || py > mxy) dy = fminf(fabsf(py - mny), fabsf(py - mxy));
+    if (pz < mnz || pz > mxz) dz = fminf(fabsf(pz - mnz), fabsf(pz - mxz));
+    return dx * dx + dy * dy + dz * dz;
+}
+
+// boxMeanDist (simple_knn.cu:147-183).  One thread per point in Morton order; a wave is one 64-point group.  The
+// reference seeds a rejection radius from the 6 Morton neighbours and then scans every box it cannot reject; here the
+// wave first scans its own group and the two next to it (192 points, which already holds most true neighbours), then
+// applies the same conservative AABB test at two levels -- 1024-point boxes, then their 64-point groups -- against the
+// running third-best distance.  Every point is visited at most once, so the triple is the exact 3-NN set.
+__global__ __launch_bounds__(256) void k_knn_meandist(int P, const float4* __restrict__ sorted, const float* __restrict__ boxes,
+                                                      const float* __restrict__ subs, int nbox, float* __restrict__ out)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const bool have = idx < P;
     float4 me = make_float4(0.f, 0.f, 0.f, 0.f);
     if (have) me = sorted[idx];
     float b0 = FLT_MAX, b1 = FLT_MAX, b2 = FLT_MAX;
-    if (have) {
-        const int lo = max(0, idx - 3), hi = min(P - 1, idx + 3);
-        for (int i = lo; i <= hi; i++) {
-            if (i == idx) continue;
-            const float4 q = sorted[i];
-            update3(me.x, me.y, me.z, q.x, q.y, q.z, b0, b1, b2);
+    const int g_own = __builtin_amdgcn_readfirstlane(idx >> 6);          // this wave's group
+    const int nsub = (P + 63) >> 6;
+    const int g_lo = max(0, g_own - 1), g_hi = min(nsub - 1, g_own + 1);
+    {
+        const int i0 = g_lo << 6, i1 = min(P, (g_hi + 1) << 6);
+        for (int i = i0; i < i1; i++) {
+            const float4 q = sorted[i];                                  // wave-uniform address
+            if (have && i != idx) update3(me.x, me.y, me.z, q.x, q.y, q.z, b0, b1, b2);
         }
     }
-    const float reject = b2;
-    b0 = FLT_MAX; b1 = FLT_MAX; b2 = FLT_MAX;
     for (int b = 0; b < nbox; b++) {
-        const float* bx = boxes + 6 * (size_t)b;                       // wave-uniform address: scalar loads
-        const float mnx = bx[0], mny = bx[1], mnz = bx[2], mxx = bx[3], mxy = bx[4], mxz = bx[5];
-        // distBoxPoint (simple_knn.cu:119-130)
-        float dx = 0.f, dy = 0.f, dz = 0.f;
-        if (me.x < mnx || me.x > mxx) dx = fminf(fabsf(me.x - mnx), fabsf(me.x - mxx));
-        if (me.y < mny || me.y > mxy) dy = fminf(fabsf(me.y - mny), fabsf(me.y - mxy));
-        if (me.z < mnz || me.z > mxz) dz = fminf(fabsf(me.z - mnz), fabsf(me.z - mxz));
-        const float dist = dx * dx + dy * dy + dz * dz;
-        const bool want = have && !(dist > reject || dist > b2);
-        if (__builtin_amdgcn_ballot_w64(want) == 0) continue;          // nobody in this wave needs the box
-        const int i0 = b * KNN_BOX, i1 = min(P, i0 + KNN_BOX);
-        for (int i = i0; i < i1; i++) {
-            const float4 q = sorted[i];                                // wave-uniform address
-            if (want && i != idx) update3(me.x, me.y, me.z, q.x, q.y, q.z, b0, b1, b2);
+        const bool want = have && !(dist_box_point(boxes + 6 * (size_t)b, me.x, me.y, me.z) > b2);
+        if (__builtin_amdgcn_ballot_w64(want) == 0) continue;            // nobody in this wave needs the box
+        const int s0 = b * 16, s1 = min(nsub, s0 + 16);
+        for (int g = s0; g < s1; g++) {
+            if (g >= g_lo && g <= g_hi) continue;                        // already visited
+            const bool wg = want && !(dist_box_point(subs + 6 * (size_t)g, me.x, me.y, me.z) > b2);
+            if (__builtin_amdgcn_ballot_w64(wg) == 0) continue;
+            const int i0 = g << 6, i1 = min(P, i0 + 64);
+            for (int i = i0; i < i1; i++) {
+                const float4 q = sorted[i];
+                if (wg) update3(me.x, me.y, me.z, q.x, q.y, q.z, b0, b1, b2);
+            }
         }
     }
     if (have) out[__float_as_uint(me.w)] = (b0 + b1 + b2) / 3.0f;
@@ -216,9 +237,9 @@ int tgs_dist2(void* stream, int P, const float* points, float* mean_dist2, void*
     using namespace tgs;
     hipStream_t st = (hipStream_t)stream;
     if (P == 0) return TGS_OK;
-    if (P < 0 || !points || !mean_dist2 || !workspace) return TGS_ERR_INVALID;
+    if (P < 0 || !points || !mean_dist2 || !workspace) return set_error(TGS_ERR_INVALID, "tgs_dist2: P >= 0 and non-NULL points / mean_dist2 / workspace required");
     KnnWork w;
-    if (knn_carve(w, (char*)workspace, (size_t)P) > workspace_bytes) return TGS_ERR_INVALID;
+    if (knn_carve(w, (char*)workspace, (size_t)P) > workspace_bytes) return set_error(TGS_ERR_INVALID, "tgs_dist2: workspace smaller than tgs_dist2_workspace_bytes(P)");
     const int nblk = (P + 255) / 256, nbox = (P + KNN_BOX - 1) / KNN_BOX;
     hipLaunchKernelGGL(k_knn_minmax, dim3(nblk), dim3(256), 0, st, P, points, w.partial);
     hipLaunchKernelGGL(k_knn_minmax_final, dim3(1), dim3(256), 0, st, nblk, w.partial, w.minmax);
@@ -234,8 +255,8 @@ int tgs_dist2(void* stream, int P, const float* points, float* mean_dist2, void*
         hipLaunchKernelGGL(k_sort64_local, lgrid, dim3(256), (size_t)cap * 8, st, w.keys, n, k, cap);
     }
     hipLaunchKernelGGL(k_knn_gather, dim3(nblk), dim3(256), 0, st, P, points, w.keys, w.sorted);
-    hipLaunchKernelGGL(k_knn_boxes, dim3(nbox), dim3(KNN_BOX), 0, st, P, w.sorted, w.boxes);
-    hipLaunchKernelGGL(k_knn_meandist, dim3(nblk), dim3(256), 0, st, P, w.sorted, w.boxes, nbox, mean_dist2);
-    return hipGetLastError() == hipSuccess ? TGS_OK : TGS_ERR_HIP;
+    hipLaunchKernelGGL(k_knn_boxes, dim3(nbox), dim3(KNN_BOX), 0, st, P, w.sorted, w.boxes, w.subs);
+    hipLaunchKernelGGL(k_knn_meandist, dim3(nblk), dim3(256), 0, st, P, w.sorted, w.boxes, w.subs, nbox, mean_dist2);
+    return hip_status("tgs_dist2");
 }
 }

@@ -177,11 +177,11 @@ int tgs_sh_rgb_forward(void* stream, int P, int M, int levels, const float* sh, 
 {
     if (P == 0) return TGS_OK;
     if (P < 0 || levels < 1 || levels > 4 || M < levels * levels || M > 16 || !sh || !colors || ((positions && camera_center) == (directions != nullptr)))
-        return TGS_ERR_INVALID;
+        return tgs::set_error(TGS_ERR_INVALID, "tgs_sh_rgb_forward: levels in 1..4, levels^2 <= M <= 16, sh/colors non-NULL, and exactly one of (positions, camera_center) / directions");
     tgs::ShArgs a{};
     a.P = P; a.M = M; a.levels = levels; a.sh = sh; a.positions = positions; a.camera = camera_center; a.directions = directions; a.colors = colors;
     tgs::launch_sh_rgb((hipStream_t)stream, a, false);
-    return hipGetLastError() == hipSuccess ? TGS_OK : TGS_ERR_HIP;
+    return tgs::hip_status("tgs_sh_rgb_forward");
 }
 
 int tgs_sh_rgb_backward(void* stream, int P, int M, int levels, const float* sh, const float* positions, const float* camera_center,
@@ -190,11 +190,11 @@ int tgs_sh_rgb_backward(void* stream, int P, int M, int levels, const float* sh,
     if (P == 0) return TGS_OK;
     if (P < 0 || levels < 1 || levels > 4 || M < levels * levels || M > 16 || !sh || !dL_dcolors || !dL_dsh ||
         ((positions && camera_center) == (directions != nullptr)))
-        return TGS_ERR_INVALID;
+        return tgs::set_error(TGS_ERR_INVALID, "tgs_sh_rgb_backward: levels in 1..4, levels^2 <= M <= 16, sh/dL_dcolors/dL_dsh non-NULL, and exactly one of (positions, camera_center) / directions");
     tgs::ShArgs a{};
     a.P = P; a.M = M; a.levels = levels; a.sh = sh; a.positions = positions; a.camera = camera_center; a.directions = directions;
     a.dL_dcolors = dL_dcolors; a.dL_dsh = dL_dsh; a.dL_dpositions = positions ? dL_dpositions : nullptr; a.dL_ddirections = directions ? dL_ddirections : nullptr;
     tgs::launch_sh_rgb((hipStream_t)stream, a, true);
-    return hipGetLastError() == hipSuccess ? TGS_OK : TGS_ERR_HIP;
+    return tgs::hip_status("tgs_sh_rgb_backward");
 }
 }

@@ -48,7 +48,7 @@ class _SHColor(torch.autograd.Function):
         with torch.cuda.device(dev):
             r = _lib.tgs_sh_rgb_forward(torch.cuda.current_stream(dev).cuda_stream, P, M, int(sh_levels), p(sh), p(pos), p(cam), p(dirs), colors.data_ptr())
         if r < 0:
-            raise RuntimeError(f"tgs_sh_rgb_forward failed (code {r})")
+            raise _rast_c._err(r)
         ctx.save_for_backward(sh, pos if pos is not None else torch.Tensor([]), cam if cam is not None else torch.Tensor([]),
                               dirs if dirs is not None else torch.Tensor([]))
         ctx.levels = int(sh_levels)
@@ -71,7 +71,7 @@ class _SHColor(torch.autograd.Function):
             r = _lib.tgs_sh_rgb_backward(torch.cuda.current_stream(dev).cuda_stream, P, M, ctx.levels, p(sh), p(pos), p(cam), p(dirs), g.data_ptr(),
                                          d_sh.data_ptr(), p(d_pos), p(d_dir))
         if r < 0:
-            raise RuntimeError(f"tgs_sh_rgb_backward failed (code {r})")
+            raise _rast_c._err(r)
         return d_sh, d_pos, None, d_dir, None
 
 

@@ -30,5 +30,5 @@ def distCUDA2(points: torch.Tensor) -> torch.Tensor:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         r = _lib.tgs_dist2(torch.cuda.current_stream(dev).cuda_stream, P, pts.data_ptr(), means.data_ptr(), ws.data_ptr(), nbytes)
     if r < 0:
-        raise RuntimeError(f"tgs_dist2 failed (code {r})")
+        raise _rast_c._err(r)
     return means
