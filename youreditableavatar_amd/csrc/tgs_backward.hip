@@ -231,8 +231,9 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
     if (inside) { dpx0 = dL_dpix[pix_id]; dpx1 = dL_dpix[N + pix_id]; dpx2 = dL_dpix[2 * N + pix_id]; }
     float bg_dot_dpixel = 0.f;                              // backward.cu:533-535
     bg_dot_dpixel += bg[0] * dpx0; bg_dot_dpixel += bg[1] * dpx1; bg_dot_dpixel += bg[2] * dpx2;
-    float ar0 = 0.f, ar1 = 0.f, ar2 = 0.f;                  // accum_rec
-    float last_alpha = 0.f, lm0 = 0.f, lm1 = 0.f, lm2 = 0.f;   // last_alpha and last_alpha*last_color
+    float ar0 = 0.f, ar1 = 0.f, ar2 = 0.f;                  // accum_rec with (last_alpha, last_color) already applied
+    float vone = 1.0f, vzero = 0.0f;                        // identity elements, pinned to VGPRs for the DPP selects
+    asm volatile("" : "+v"(vone), "+v"(vzero));
     const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);   // backward.cu:460-461
 
     const uint32_t qmax = min(s.tile_qmax[tile], n);        // deepest position any pixel of the tile blended (k_render_fwd)
@@ -280,33 +281,15 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
                 if (__builtin_amdgcn_ballot_w64(valid) == 0) continue;
                 const float aeff = valid ? alpha : 0.f;     // a skipped entry is walked as alpha = 0, G = 0
                 const float Geff = valid ? G : 0.f;
-                // transmittance after each of the 4 entries: T / prod(1 - alpha), prefix product over the quad
-                const float Town = tgs_div(T, quad_prefix_product(1.f - aeff, e));
-                T = quad_bcast<3>(Town);
-                // accum_rec walk (backward.cu:516-518): ar <- la*lc + (1-la)*ar with (la, lc) of the PREVIOUS step
-                const float m0 = aeff * c0, m1 = aeff * c1, m2 = aeff * c2;
-                float a0own, a1own, a2own;
-                {   // step 0 uses the state left by the previous group
-                    const float om = 1.f - last_alpha;
-                    ar0 = lm0 + om * ar0; ar1 = lm1 + om * ar1; ar2 = lm2 + om * ar2;
-                    a0own = ar0; a1own = ar1; a2own = ar2;
-                }
-#define TGS_BWD_STEP(E)  /* steps 1..3 use (alpha, alpha*colour) of entry E-1, fetched by DPP inside the add */ \
-                {                                                                                              \
-                    const float om = 1.f - quad_bcast<E - 1>(aeff);                                            \
-                    ar0 *= om; ar1 *= om; ar2 *= om;                                                           \
-                    TGS_QUAD_BCAST_ADD(ar0, m0, E - 1); TGS_QUAD_BCAST_ADD(ar1, m1, E - 1); TGS_QUAD_BCAST_ADD(ar2, m2, E - 1); \
-                    if (e == E) { a0own = ar0; a1own = ar1; a2own = ar2; }                                     \
-                }
-                TGS_BWD_STEP(1) TGS_BWD_STEP(2) TGS_BWD_STEP(3)
-#undef TGS_BWD_STEP
-                last_alpha = quad_bcast<3>(aeff); lm0 = quad_bcast<3>(m0); lm1 = quad_bcast<3>(m1); lm2 = quad_bcast<3>(m2);
+                // the quad walks the pixel's state through the group's 4 entries (bwd_chain4, tgs_device.hpp)
+                float Town, inv_om, a0own, a1own, a2own;
+                bwd_chain4(aeff, c0, c1, c2, T, ar0, ar1, ar2, Town, inv_om, a0own, a1own, a2own, vone, vzero);
                 // this lane's (pixel, entry) gradient terms, backward.cu:507-555 (all zero for a skipped entry)
                 const float dchannel_dcolor = aeff * Town;
                 float dL_dalpha = 0.0f;
                 dL_dalpha += (c0 - a0own) * dpx0; dL_dalpha += (c1 - a1own) * dpx1; dL_dalpha += (c2 - a2own) * dpx2;
                 dL_dalpha *= Town;
-                dL_dalpha += tgs_div(-T_final, 1.f - alpha) * bg_dot_dpixel;
+                dL_dalpha -= T_final * inv_om * bg_dot_dpixel;             // -T_final / (1 - alpha) * bg_dot_dpixel
                 const float dL_dG = bb.y * dL_dalpha;
                 const float gdx = Geff * dx, gdy = Geff * dy;
                 const float dG_ddelx = -gdx * a.z - gdy * a.w;
@@ -319,13 +302,7 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
                 v[6] = -0.5f * gdx * dy * dL_dG;
                 v[7] = -0.5f * gdy * dy * dL_dG;
                 v[8] = Geff * dL_dalpha;
-#pragma unroll
-                for (int c = 0; c < NACC; c++) {
-                    float x = v[c];
-                    TGS_DPP_ADD(x, 0x124, 0xf);             // row_ror:4  } the 4 lanes of a row that share an entry slot
-                    TGS_DPP_ADD(x, 0x128, 0xf);             // row_ror:8  }
-                    v[c] = x;
-                }
+                row_stride4_sum9(v);                        // the 4 lanes of a row that share an entry slot
                 // fold the 4 rows: afterwards s0 rows 0..3 = components 0..3, s1 rows = components 4..7, s2 = component 8
                 const float q0 = swap16_add(v[0], v[1]), q1 = swap16_add(v[2], v[3]), q2 = swap16_add(v[4], v[5]), q3 = swap16_add(v[6], v[7]);
                 const float q4 = swap16_add(v[8], v[8]);

@@ -280,6 +280,90 @@ __device__ __forceinline__ float quad_bcast(float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), E * 0x55, 0xf, 0xf, false));
 }
 
+// ---------------------------------------------------------------------------------------------
+// Hand-scheduled DPP sequences.  hipcc keeps `v_mov_b32 tmp, 0; v_mov_b32_dpp tmp, x` in front of every consumer
+// that is not a plain VOP2 with the DPP value in src0 (selects, fma, fmac: 3 instructions where 1 is enough), and
+// both render kernels are bound by VALU issue, so the per-group chains are written out as ISA.  Hazards handled
+// by ordering / s_nop inside the blocks: a VGPR written by VALU needs 2 wait states before a DPP read, a v_rcp/v_exp
+// result 1 before any use (gfx940+).
+// ---------------------------------------------------------------------------------------------
+#define TGS_QP(E) " quad_perm:[" #E "," #E "," #E "," #E "] row_mask:0xf bank_mask:0xf\n\t"
+constexpr unsigned long long QUAD_LT1 = 0x1111111111111111ull;   // lanes with (lane & 3) < 1
+constexpr unsigned long long QUAD_LT2 = 0x3333333333333333ull;
+constexpr unsigned long long QUAD_LT3 = 0x7777777777777777ull;
+
+// Back-to-front walk of one pixel through the 4 entries held by the lanes of its quad (backward.cu:505-531).
+//   in : a = alpha of this lane's entry (0 for a skipped one), c0..2 its colour, T / r0..2 = transmittance and accum_rec
+//        state in front of the group (uniform over the quad)
+//   out: Town = T after this lane's entry, inv = 1/(1-a), o0..2 = accum_rec seen by this lane's entry; T / r0..2 advanced
+// Lane e applies entries 0..e-1 in order (o <- o*(1-a_k) + a_k*c_k: the reference's recurrence with one rounding per
+// step); lanes with e <= k take the identity (1, 0) for step k through v_cndmask_b32_dpp.
+__device__ __forceinline__ void bwd_chain4(float a, float c0, float c1, float c2, float& T, float& r0, float& r1, float& r2,
+                                           float& Town, float& inv, float& o0, float& o1, float& o2, float one, float zero)
+{
+    float om, m0, m1, m2, so, t0, t1, t2, q;
+    asm volatile(
+        "v_sub_f32 %[om], 1.0, %[a]\n\t"
+        "v_mul_f32 %[m0], %[a], %[c0]\n\t"
+        "v_mul_f32 %[m1], %[a], %[c1]\n\t"
+        "v_mul_f32 %[m2], %[a], %[c2]\n\t"
+        "s_mov_b64 vcc, %[lt1]\n\t"
+        "v_cndmask_b32_dpp %[q], %[om], %[one], vcc" TGS_QP(0)
+        "v_cndmask_b32_dpp %[t0], %[m0], %[zero], vcc" TGS_QP(0)
+        "v_cndmask_b32_dpp %[t1], %[m1], %[zero], vcc" TGS_QP(0)
+        "s_nop 0\n\t"
+        "v_cndmask_b32_dpp %[t2], %[m2], %[zero], vcc" TGS_QP(0)
+        "v_fma_f32 %[o0], %[r0], %[q], %[t0]\n\t"
+        "v_fma_f32 %[o1], %[r1], %[q], %[t1]\n\t"
+        "v_fma_f32 %[o2], %[r2], %[q], %[t2]\n\t"
+        "s_mov_b64 vcc, %[lt2]\n\t"
+        "v_cndmask_b32_dpp %[so], %[om], %[one], vcc" TGS_QP(1)
+        "v_cndmask_b32_dpp %[t0], %[m0], %[zero], vcc" TGS_QP(1)
+        "v_cndmask_b32_dpp %[t1], %[m1], %[zero], vcc" TGS_QP(1)
+        "v_cndmask_b32_dpp %[t2], %[m2], %[zero], vcc" TGS_QP(1)
+        "v_mul_f32 %[q], %[q], %[so]\n\t"
+        "v_fma_f32 %[o0], %[o0], %[so], %[t0]\n\t"
+        "v_fma_f32 %[o1], %[o1], %[so], %[t1]\n\t"
+        "v_fma_f32 %[o2], %[o2], %[so], %[t2]\n\t"
+        "s_mov_b64 vcc, %[lt3]\n\t"
+        "v_cndmask_b32_dpp %[so], %[om], %[one], vcc" TGS_QP(2)
+        "v_cndmask_b32_dpp %[t0], %[m0], %[zero], vcc" TGS_QP(2)
+        "v_cndmask_b32_dpp %[t1], %[m1], %[zero], vcc" TGS_QP(2)
+        "v_cndmask_b32_dpp %[t2], %[m2], %[zero], vcc" TGS_QP(2)
+        "v_mul_f32 %[q], %[q], %[so]\n\t"
+        "v_fma_f32 %[o0], %[o0], %[so], %[t0]\n\t"
+        "v_fma_f32 %[o1], %[o1], %[so], %[t1]\n\t"
+        "v_fma_f32 %[o2], %[o2], %[so], %[t2]\n\t"
+        "v_mul_f32 %[so], %[q], %[om]\n\t"               // prod_{k<=e} (1 - a_k)
+        "v_rcp_f32 %[so], %[so]\n\t"
+        "v_fma_f32 %[t0], %[o0], %[om], %[m0]\n\t"         // state behind this lane's own entry
+        "v_fma_f32 %[t1], %[o1], %[om], %[m1]\n\t"
+        "v_fma_f32 %[t2], %[o2], %[om], %[m2]\n\t"
+        "v_mul_f32 %[Town], %[T], %[so]\n\t"
+        "v_mul_f32 %[inv], %[q], %[so]\n\t"
+        "v_mov_b32_dpp %[r0], %[t0]" TGS_QP(3)
+        "v_mov_b32_dpp %[r1], %[t1]" TGS_QP(3)
+        "v_mov_b32_dpp %[r2], %[t2]" TGS_QP(3)
+        "v_mov_b32_dpp %[T], %[Town]" TGS_QP(3)
+        : [om] "=&v"(om), [m0] "=&v"(m0), [m1] "=&v"(m1), [m2] "=&v"(m2), [so] "=&v"(so), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
+          [q] "=&v"(q), [Town] "=&v"(Town), [inv] "=&v"(inv), [o0] "=&v"(o0), [o1] "=&v"(o1), [o2] "=&v"(o2),
+          [T] "+v"(T), [r0] "+v"(r0), [r1] "+v"(r1), [r2] "+v"(r2)
+        : [a] "v"(a), [c0] "v"(c0), [c1] "v"(c1), [c2] "v"(c2), [one] "v"(one), [zero] "v"(zero),
+          [lt1] "s"(QUAD_LT1), [lt2] "s"(QUAD_LT2), [lt3] "s"(QUAD_LT3)
+        : "vcc");
+}
+
+// x_i <- sum of x_i over the 4 lanes {l, l+4, l+8, l+12} of each row, for 9 values: 18 v_add_f32_dpp
+__device__ __forceinline__ void row_stride4_sum9(float (&v)[9])
+{
+#define TGS_ROR(I, N) "v_add_f32_dpp %" #I ", %" #I ", %" #I " row_ror:" #N " row_mask:0xf bank_mask:0xf\n\t"
+    asm volatile("s_nop 1\n\t"
+                 TGS_ROR(0, 4) TGS_ROR(1, 4) TGS_ROR(2, 4) TGS_ROR(3, 4) TGS_ROR(4, 4) TGS_ROR(5, 4) TGS_ROR(6, 4) TGS_ROR(7, 4) TGS_ROR(8, 4)
+                 TGS_ROR(0, 8) TGS_ROR(1, 8) TGS_ROR(2, 8) TGS_ROR(3, 8) TGS_ROR(4, 8) TGS_ROR(5, 8) TGS_ROR(6, 8) TGS_ROR(7, 8) TGS_ROR(8, 8)
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]));
+#undef TGS_ROR
+}
+
 #ifndef TGS_STAMPS
 #define TGS_STAMPS 0
 #endif
