@@ -231,6 +231,7 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
     if (inside) { dpx0 = dL_dpix[pix_id]; dpx1 = dL_dpix[N + pix_id]; dpx2 = dL_dpix[2 * N + pix_id]; }
     float bg_dot_dpixel = 0.f;                              // backward.cu:533-535
     bg_dot_dpixel += bg[0] * dpx0; bg_dot_dpixel += bg[1] * dpx1; bg_dot_dpixel += bg[2] * dpx2;
+    const float tfinal_bg = T_final * bg_dot_dpixel;
     float ar0 = 0.f, ar1 = 0.f, ar2 = 0.f;                  // accum_rec with (last_alpha, last_color) already applied
     float vone = 1.0f, vzero = 0.0f;                        // identity elements, pinned to VGPRs for the DPP selects
     asm volatile("" : "+v"(vone), "+v"(vzero));
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
     for (uint32_t i = threadIdx.x; i < NACC * (BCH + 1); i += BWD_THREADS) (&acc[0][0])[i] = 0.f;
     {
         const uint32_t cnt0 = min((uint32_t)BCH, qmax);
-        if (threadIdx.x < cnt0) { sA[threadIdx.x] = ra; sB[threadIdx.x] = rb; sC[threadIdx.x] = rc.x; sMask[threadIdx.x] = (unsigned short)__float_as_uint(rc.y); sSlot[0][threadIdx.x] = rs; }
+        if (threadIdx.x < cnt0) { stage_conic(ra, rb); sA[threadIdx.x] = ra; sB[threadIdx.x] = rb; sC[threadIdx.x] = rc.x; sMask[threadIdx.x] = (unsigned short)__float_as_uint(rc.y); sSlot[0][threadIdx.x] = rs; }
         if (threadIdx.x < BCH && qmax > BCH && threadIdx.x < qmax - BCH) {
             const uint32_t pos = rg.x + qmax - BCH - 1 - threadIdx.x;
             ra = b.recA[pos]; rb = b.recB[pos]; rc = b.recC[pos]; rs = b.slot[pos];
@@ -269,39 +270,36 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
 #pragma unroll 1
             for (uint32_t k = 0; k < nl; k += 4) {
                 const uint32_t j = lists[wv][k + e];
-                const float4 a = sA[j];
-                const float4 bb = sB[j];
+                const float4 a = sA[j];                     // mean2D, conic xx / xy pre-scaled for exp2 (stage_conic)
+                const float4 bb = sB[j];                    // conic yy pre-scaled, opacity, colour r g
                 const float c0 = bb.z, c1 = bb.w, c2 = sC[j];
                 const float dx = a.x - pixfx, dy = a.y - pixfy;
-                const float power = -0.5f * (a.z * dx * dx + bb.x * dy * dy) - a.w * dx * dy;
-                const float G = tgs_exp(power);
+                const float power2 = (a.z * dx + a.w * dy) * dx + (bb.x * dy) * dy;   // log2(e) * power of forward.cu:336
+                const float G = __builtin_amdgcn_exp2f(power2);
                 const float alpha = fminf(0.99f, bb.y * G);
-                // list position of slot j is qhi-1-j; "contributor >= last_contributor" skip of backward.cu:487
-                const bool valid = (qhi - 1 - j < last_contributor) && (j < cnt) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+                // list position of slot j is qhi-1-j; "contributor >= last_contributor" skip of backward.cu:487.  A padding
+                // entry (j == BNULL) has opacity 0 and fails the alpha test.
+                const bool valid = (qhi - 1 - j < last_contributor) && !(power2 > 0.0f) && !(alpha < 1.0f / 255.0f);
                 if (__builtin_amdgcn_ballot_w64(valid) == 0) continue;
                 const float aeff = valid ? alpha : 0.f;     // a skipped entry is walked as alpha = 0, G = 0
                 const float Geff = valid ? G : 0.f;
                 // the quad walks the pixel's state through the group's 4 entries (bwd_chain4, tgs_device.hpp)
                 float Town, inv_om, a0own, a1own, a2own;
                 bwd_chain4(aeff, c0, c1, c2, T, ar0, ar1, ar2, Town, inv_om, a0own, a1own, a2own, vone, vzero);
-                // this lane's (pixel, entry) gradient terms, backward.cu:507-555 (all zero for a skipped entry)
+                // this lane's (pixel, entry) terms, backward.cu:507-555 (all zero for a skipped entry).  Everything that is
+                // constant per entry -- opacity, the conic, -0.5, the ndc scale -- is applied once per entry at the flush
+                // (flush_row), so a lane only forms the moments of w = G * dL_dalpha over dx, dy.
                 const float dchannel_dcolor = aeff * Town;
-                float dL_dalpha = 0.0f;
-                dL_dalpha += (c0 - a0own) * dpx0; dL_dalpha += (c1 - a1own) * dpx1; dL_dalpha += (c2 - a2own) * dpx2;
-                dL_dalpha *= Town;
-                dL_dalpha -= T_final * inv_om * bg_dot_dpixel;             // -T_final / (1 - alpha) * bg_dot_dpixel
-                const float dL_dG = bb.y * dL_dalpha;
-                const float gdx = Geff * dx, gdy = Geff * dy;
-                const float dG_ddelx = -gdx * a.z - gdy * a.w;
-                const float dG_ddely = -gdy * bb.x - gdx * a.w;
+                float dL_dalpha = (c0 - a0own) * dpx0;
+                dL_dalpha += (c1 - a1own) * dpx1; dL_dalpha += (c2 - a2own) * dpx2;
+                dL_dalpha = dL_dalpha * Town - tfinal_bg * inv_om;      // ... + (-T_final / (1 - alpha)) * bg_dot_dpixel
+                const float w = Geff * dL_dalpha;
+                const float wdx = w * dx, wdy = w * dy;
                 float v[NACC];
                 v[0] = dchannel_dcolor * dpx0; v[1] = dchannel_dcolor * dpx1; v[2] = dchannel_dcolor * dpx2;
-                v[3] = dL_dG * dG_ddelx * ddelx_dx;
-                v[4] = dL_dG * dG_ddely * ddely_dy;
-                v[5] = -0.5f * gdx * dx * dL_dG;
-                v[6] = -0.5f * gdx * dy * dL_dG;
-                v[7] = -0.5f * gdy * dy * dL_dG;
-                v[8] = Geff * dL_dalpha;
+                v[3] = wdx; v[4] = wdy;
+                v[5] = wdx * dx; v[6] = wdx * dy; v[7] = wdy * dy;
+                v[8] = w;
                 row_stride4_sum9(v);                        // the 4 lanes of a row that share an entry slot
                 // fold the 4 rows: afterwards s0 rows 0..3 = components 0..3, s1 rows = components 4..7, s2 = component 8
                 const float q0 = swap16_add(v[0], v[1]), q1 = swap16_add(v[2], v[3]), q2 = swap16_add(v[4], v[5]), q3 = swap16_add(v[6], v[7]);
@@ -318,16 +316,20 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
         __syncthreads();                                    // every wave is done with the records and the accumulator of this round
         if (threadIdx.x < cnt) {                            // flush: one 48-B row per instance, then clear the column for the next round
             const uint32_t j = threadIdx.x;
+            // moments -> gradients (backward.cu:537-555): dL_dG = opacity * dL_dalpha, dG/ddel = -G (conic . d), conic terms * -0.5
+            const float4 a = sA[j]; const float4 bb = sB[j];
+            const float cxx = a.z * UNSCALE_CONIC, cxy = a.w * UNSCALE_CONIC_XY, cyy = bb.x * UNSCALE_CONIC, op = bb.y;
+            const float Sx = acc[3][j], Sy = acc[4][j];
             float4* row = b.slab + (size_t)sSlot[rnd][j] * SLAB_ROW;
-            row[0] = make_float4(acc[0][j], acc[1][j], acc[2][j], acc[3][j]);
-            row[1] = make_float4(acc[4][j], acc[5][j], acc[6][j], acc[7][j]);
+            row[0] = make_float4(acc[0][j], acc[1][j], acc[2][j], op * (-Sx * cxx - Sy * cxy) * ddelx_dx);
+            row[1] = make_float4(op * (-Sy * cyy - Sx * cxy) * ddely_dy, -0.5f * op * acc[5][j], -0.5f * op * acc[6][j], -0.5f * op * acc[7][j]);
             row[2] = make_float4(acc[8][j], 0.f, 0.f, 0.f);
 #pragma unroll
             for (int k = 0; k < NACC; k++) acc[k][j] = 0.f;
         }
         if (qhi > BCH) {                                    // stage the next round (its records were prefetched into registers)
             const uint32_t qn = qhi - BCH, cntn = min((uint32_t)BCH, qn);
-            if (threadIdx.x < cntn) { sA[threadIdx.x] = ra; sB[threadIdx.x] = rb; sC[threadIdx.x] = rc.x; sMask[threadIdx.x] = (unsigned short)__float_as_uint(rc.y); sSlot[rnd ^ 1][threadIdx.x] = rs; }
+            if (threadIdx.x < cntn) { stage_conic(ra, rb); sA[threadIdx.x] = ra; sB[threadIdx.x] = rb; sC[threadIdx.x] = rc.x; sMask[threadIdx.x] = (unsigned short)__float_as_uint(rc.y); sSlot[rnd ^ 1][threadIdx.x] = rs; }
             if (threadIdx.x < BCH && qn > BCH && threadIdx.x < qn - BCH) {
                 const uint32_t pos = rg.x + qn - BCH - 1 - threadIdx.x;
                 ra = b.recA[pos]; rb = b.recB[pos]; rc = b.recC[pos]; rs = b.slot[pos];

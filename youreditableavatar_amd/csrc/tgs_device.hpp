@@ -280,6 +280,16 @@ __device__ __forceinline__ float quad_bcast(float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), E * 0x55, 0xf, 0xf, false));
 }
 
+// Records staged into LDS by the render kernels carry the conic pre-scaled for one v_exp_f32:
+//   log2(e) * power = (A dx + B dy) dx + (C dy) dy   with A = -0.5 log2e conic.x, B = -log2e conic.y, C = -0.5 log2e conic.z
+// (forward.cu:336 `power = -0.5f * (con.x*d.x*d.x + con.z*d.y*d.y) - con.y*d.x*d.y`, d = mean - pixel as in this code).
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float UNSCALE_CONIC = -2.0f / LOG2E, UNSCALE_CONIC_XY = -1.0f / LOG2E;
+__device__ __forceinline__ void stage_conic(float4& ra, float4& rb)
+{
+    ra.z *= -0.5f * LOG2E; ra.w *= -LOG2E; rb.x *= -0.5f * LOG2E;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Hand-scheduled DPP sequences.  hipcc keeps `v_mov_b32 tmp, 0; v_mov_b32_dpp tmp, x` in front of every consumer
 // that is not a plain VOP2 with the DPP value in src0 (selects, fma, fmac: 3 instructions where 1 is enough), and
