@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--config", type=int, default=3, help="BASELINE.json config index (1-based); 3 = 500k/1080p/SH3")
     ap.add_argument("--mode", default="sh", choices=["sh", "precomp"])
     ap.add_argument("--views", type=int, default=64)
+    ap.add_argument("--sync-per-frame", action="store_true", help="reference protocol: read num_rendered back in every forward")
     ap.add_argument("--no-fused-accumulate", action="store_true", help="let autograd add each view's gradients in a separate pass")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to smoke-test the N>1 control flow)")
@@ -67,7 +68,7 @@ def main():
     N = world
 
     from youreditableavatar_amd import scenes
-    from youreditableavatar_amd.multiview import FlatGradients, rasterize_accumulate
+    from youreditableavatar_amd.multiview import FlatGradients, SyncFreeBatch, rasterize_accumulate
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _C
 
     cfg = dict(scenes.CONFIGS[a.config])
@@ -91,21 +92,22 @@ def main():
     if a.mode == "precomp":
         colors_pre = [None] * V
 
-    def frame(view):
+    fused = not (a.no_fused_accumulate or a.mode != "sh")
+
+    def rasterize(view, r_capacity=None):
         rs = settings[view]
         means2D = torch.zeros(P, 3, device=dev, requires_grad=True)
-        if a.no_fused_accumulate or a.mode != "sh":
-            rast = GaussianRasterizer(rs)
-        else:       # multi-view path: the backward adds into the flat gradient buffer directly (multiview.rasterize_accumulate)
-            rast = lambda **kw: rasterize_accumulate(rs, **kw)
-        if a.mode == "sh":
-            img, radii = rast(means3D=means3D, means2D=means2D, opacities=opac, shs=shs, scales=scales, rotations=rots)
+        if fused:   # multi-view path: the backward adds into the flat gradient buffer directly (multiview.rasterize_accumulate)
+            rast = lambda **kw: rasterize_accumulate(rs, r_capacity=r_capacity, return_meta=True, **kw)
         else:
-            if colors_pre[view] is None:
-                colors_pre[view] = g(scenes.sh_to_rgb_numpy(cloud["shs"], cloud["means3D"], cams[view].campos, D), True)
-            img, radii = rast(means3D=means3D, means2D=means2D, opacities=opac, colors_precomp=colors_pre[view], scales=scales, rotations=rots)
-        img.backward(dL)
-        return img
+            rast = GaussianRasterizer(rs)
+        if a.mode == "sh":
+            return rast(means3D=means3D, means2D=means2D, opacities=opac, shs=shs, scales=scales, rotations=rots)
+        if colors_pre[view] is None:
+            colors_pre[view] = g(scenes.sh_to_rgb_numpy(cloud["shs"], cloud["means3D"], cams[view].campos, D), True)
+        return rast(means3D=means3D, means2D=means2D, opacities=opac, colors_precomp=colors_pre[view], scales=scales, rotations=rots)
+
+    batch = SyncFreeBatch() if (fused and not a.sync_per_frame) else None
 
     VPG = a.views_per_gpu
 
@@ -133,16 +135,28 @@ def main():
 
     def step(s):
         flat.zero_()
-        for v in views_of(s):
-            frame(v)
+        if batch is not None:       # no host synchronisation per frame: one Meta read-back per step (multiview.SyncFreeBatch)
+            batch.run(views_of(s), rasterize, lambda v, img: dL)
+        else:
+            for v in views_of(s):
+                rasterize(v)[0].backward(dL)
         flat.all_reduce()
 
     for s in range(a.warmup):
         step(s)
     torch.cuda.synchronize()
+    # per-stage times: one untimed pass with events around every stage (each event costs queue time, so the timed
+    # region below keeps only the events of the dominant kernel -- the one the roofline object reports)
+    _C.profile_begin(max(a.warmup, 2) * VPG * 8 + 64)
+    for s in range(max(a.warmup, 2)):
+        step(s)
+    torch.cuda.synchronize()
+    prof_all = _C.profile_end()
+    kern = {k: (ms / max(n, 1)) for k, (ms, n) in prof_all.items() if n > 0}
+    dom = max(kern, key=kern.get) if kern else None
     if dist is not None:
         dist.barrier()
-    _C.profile_begin(a.steps * VPG * 8 + 64)
+    _C.profile_begin(a.steps * VPG + 64, stages=[dom] if dom else [])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for s in range(a.steps):
@@ -153,6 +167,8 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     prof = _C.profile_end()
+    if dom and prof[dom][1] > 0:
+        kern[dom] = prof[dom][0] / prof[dom][1]              # measured inside the timed region
 
     F_rank = sum(F_view[v] for s in range(a.steps) for v in views_of(s))
     R_rank = sum(R_view[v] for s in range(a.steps) for v in views_of(s))
@@ -171,8 +187,6 @@ def main():
         ms_per_step = elapsed / a.steps * 1e3
         value = F_tot / elapsed / 1e6
         # dominant kernel and its roofline (algorithmic bytes per launch: DESIGN.md "Roofline accounting")
-        kern = {k: (ms / max(n, 1)) for k, (ms, n) in prof.items() if n > 0}
-        dom = max(kern, key=kern.get) if kern else None
         Rm = R_rank / frames_rank
         Npix = W * H
         Cin = 12 * (D + 1) ** 2 if a.mode == "sh" else 12
@@ -201,6 +215,8 @@ def main():
             "config": {"workload": f"cfg{a.config}: {P} Gaussians, {W}x{H}, SH degree {D}, colour mode {a.mode}, {V}-view orbit, {VPG} frames per GPU per step",
                        "frames_per_step": N * VPG, "views_per_gpu_per_step": VPG, "fragments_per_frame": int(F_rank / frames_rank),
                        "instances_per_frame": int(Rm), "ms_per_frame_per_gpu": round(ms_per_step / VPG, 4),
+                       "host_sync": "one per step (SyncFreeBatch)" if batch is not None else "one per frame (reference protocol)",
+                       "frames_rerendered": batch.rejected if batch is not None else 0,
                        "parallelism": f"view-sharded dp{N}" + (", one RCCL all-reduce of the flat gradient buffer per step" if N > 1 else "")},
             "roofline": roof,
             "kernels_ms": {k: round(v, 4) for k, v in kern.items()},

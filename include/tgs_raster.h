@@ -63,6 +63,31 @@ int64_t tgs_forward(tgs_alloc_fn alloc, void* alloc_ctx, void* stream,
                     float tan_fovx, float tan_fovy, int prefiltered,
                     float* out_color, int* radii, int debug);
 
+/* Sync-free forward for callers that render many frames per step (multi-view batches).  Rasterizer::forward
+ * reads num_rendered back to size the binning buffer (rasterizer_impl.cu:280-281: the GPU idles while the host
+ * catches up); here the CALLER bounds it: the binning buffer is requested for r_capacity tile instances before
+ * anything runs, nothing is read back and the call returns r_capacity -- pass that as R to tgs_backward[_accumulate]
+ * and tgs_state_field.  A frame that needs more instances than r_capacity (or holds a tile list longer than the LDS
+ * sort, which needs host-sized launches) is REJECTED on the device: the kernels behind the scan do no work, out_color
+ * is the background, dL_dmean2D is zero, the other gradient outputs are left untouched (nothing is accumulated), and
+ * tgs_frame_status reports TGS_FRAME_REJECTED; render such a frame again with tgs_forward.  The prefiltered check
+ * (TGS_ERR_PREFILTERED) also moves to tgs_frame_status (TGS_FRAME_PREFILTERED). */
+int64_t tgs_forward_async(int64_t r_capacity, tgs_alloc_fn alloc, void* alloc_ctx, void* stream,
+                          int P, int D, int M,
+                          const float* background, int width, int height,
+                          const float* means3D, const float* shs, const float* colors_precomp,
+                          const float* opacities, const float* scales, float scale_modifier,
+                          const float* rotations, const float* cov3D_precomp,
+                          const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                          float tan_fovx, float tan_fovy, int prefiltered,
+                          float* out_color, int* radii, int debug);
+
+enum { TGS_FRAME_PREFILTERED = 1, TGS_FRAME_REJECTED = 2 };
+/* Synchronises `stream` and returns the frame's true num_rendered and its TGS_FRAME_* flags.  The same 64 bytes sit at
+ * the start of the image buffer (u64 num_rendered, u32 longest list, u32 overflow tiles, u32 flags, ...), so a batch
+ * can also gather them on the device and read them back once. */
+int tgs_frame_status(void* stream, const void* img_buffer, int64_t* num_rendered, int* flags);
+
 /* Gradient outputs need NOT be zero-initialised (the reference requires torch::zeros,
  * rasterize_points.cu:151-159); every element is written.  dL_dconic[P,4] is scratch.
  * dL_dsh may be NULL when M == 0, dL_dscale / dL_drot may be NULL when scales == NULL. */
@@ -118,6 +143,9 @@ enum {
 };
 int tgs_profile_begin(int max_records);
 int tgs_profile_end(double* ms_sum, int64_t* counts);
+/* Restrict the events to the stages whose bit (1u << TGS_STAGE_*) is set; default all.  Events cost a few microseconds of
+ * queue time each, so a throughput measurement keeps only the stage it reports. */
+void tgs_profile_stages(unsigned mask);
 
 /* ---- "next" row 1: the caller-side SH -> RGB of every training step, fused ----
  * Replaces TetGS.get_points_rgb (Edit_core/tetgs_scene/tetgs_model.py:413-442: F.normalize(positions - camera_center),

@@ -221,6 +221,108 @@ def test_fused_accumulate_equals_autograd_sum(gpu_device):
     assert util.rel_l2(a.cpu().numpy(), b.cpu().numpy()) <= 1e-6
 
 
+def test_sync_free_forward_matches_and_rejects(gpu_device):
+    """tgs_forward_async: with enough binning capacity the frame is the synchronous one bit for bit; with too little it
+    is rejected on the device -- background image, zero dL_dmeans2D, nothing accumulated -- and the status says so."""
+    from diff_gaussian_rasterization import _C
+    from youreditableavatar_amd import scenes
+    cloud = scenes.make_cloud(6000, 3, seed=43, scale_mult=3.0)
+    cam = scenes.orbit_camera(176, 112, azimuth_deg=30.0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(gpu_device)
+    e = torch.Tensor([])
+    args = (t(cam.bg), t(cloud["means3D"]), e, t(cloud["opacities"]), t(cloud["scales"]), t(cloud["rotations"]), 1.0, e, t(cam.viewmatrix),
+            t(cam.projmatrix), cam.tanfovx, cam.tanfovy, 112, 176, t(cloud["shs"]), 3, t(cam.campos), False, False)
+    R, color, radii, geom, binning, img = _C.rasterize_gaussians(*args)
+    assert R > 1000 and _C.frame_status(img) == (R, 0)
+    dL = t(scenes.upstream_gradient(176, 112))
+
+    def backward(R_, radii_, geom_, binning_, img_, into):
+        return _C.rasterize_gaussians_backward_accumulate(args[0], args[1], radii_, e, args[4], args[5], 1.0, e, args[8], args[9], cam.tanfovx,
+                                                          cam.tanfovy, dL, args[14], 3, args[16], geom_, R_, binning_, img_, False, into)
+
+    def zeros():
+        return dict(means3D=torch.zeros(6000, 3, device=gpu_device), opacities=torch.zeros(6000, 1, device=gpu_device),
+                    sh=torch.zeros(6000, 16, 3, device=gpu_device), scales=torch.zeros(6000, 3, device=gpu_device),
+                    rotations=torch.zeros(6000, 4, device=gpu_device))
+
+    _C.set_deterministic(True)
+    try:
+        ref = zeros()
+        g2d_ref = backward(R, radii, geom, binning, img, ref)
+        # roomy capacity: identical frame, true count in the Meta record
+        cap = R + 5000
+        R2, color2, radii2, geom2, binning2, img2 = _C.rasterize_gaussians(*args, r_capacity=cap)
+        assert R2 == cap
+        assert torch.equal(color2, color) and torch.equal(radii2, radii)
+        assert _C.decode_meta(_C.frame_meta(img2)) == (R, 0) and _C.frame_status(img2) == (R, 0)
+        got = zeros()
+        g2d = backward(R2, radii2, geom2, binning2, img2, got)
+        assert torch.equal(g2d, g2d_ref)
+        for k in ref:
+            assert torch.equal(got[k], ref[k]), k
+        # exact fit is accepted, one less is not
+        assert _C.frame_status(_C.rasterize_gaussians(*args, r_capacity=R)[5]) == (R, 0)
+        R3, color3, radii3, geom3, binning3, img3 = _C.rasterize_gaussians(*args, r_capacity=R - 1)
+        assert _C.frame_status(img3) == (R, _C.FRAME_REJECTED)
+        bg = t(cam.bg).view(3, 1, 1).expand(3, 112, 176)
+        assert torch.equal(color3, bg) and torch.equal(radii3, radii)
+        acc = zeros()
+        for v in acc.values():
+            v.fill_(7.0)
+        g2d3 = backward(R3, radii3, geom3, binning3, img3, acc)
+        assert torch.all(g2d3 == 0) and all(torch.all(v == 7.0) for v in acc.values())
+    finally:
+        _C.set_deterministic(False)
+
+
+def test_sync_free_batch_rerenders_rejected_views(gpu_device):
+    """multiview.SyncFreeBatch: one read-back per batch; views that outgrow the bound are rendered again, and the
+    accumulated gradients equal the per-frame-synchronised ones."""
+    from diff_gaussian_rasterization import _C
+    from youreditableavatar_amd import scenes
+    from youreditableavatar_amd.multiview import FlatGradients, SyncFreeBatch, rasterize_accumulate
+    cloud = scenes.make_cloud(6000, 3, seed=41, scale_mult=3.0)
+    cams = [scenes.orbit_camera(176, 112, azimuth_deg=a) for a in (0.0, 90.0, 200.0, 310.0)]
+    dL = torch.from_numpy(scenes.upstream_gradient(176, 112)).to(gpu_device)
+    names = ("means3D", "opacities", "scales", "rotations", "shs")
+    L = _leaves(cloud, gpu_device)
+    flat = FlatGradients([L[n] for n in names])
+    settings = [_settings(c, 3, gpu_device) for c in cams]
+    caps = []
+
+    def rasterize(v, cap):
+        caps.append(cap)
+        return rasterize_accumulate(settings[v], means3D=L["means3D"], means2D=torch.zeros(6000, 3, device=gpu_device, requires_grad=True),
+                                    opacities=L["opacities"], shs=L["shs"], scales=L["scales"], rotations=L["rotations"], r_capacity=cap,
+                                    return_meta=True)
+
+    _C.set_deterministic(True)
+    try:
+        flat.zero_()
+        for v in range(4):
+            rasterize(v, None)[0].backward(dL)
+        want, imgs_want = flat.flat.clone(), [rasterize(v, None)[0].detach().clone() for v in range(4)]
+        batch = SyncFreeBatch(headroom=1.25, granule=256)
+        flat.zero_(); caps.clear()
+        imgs = batch.run(range(4), rasterize, lambda v, img: dL)                  # first batch: no bound yet -> synchronous frames
+        assert caps == [None] * 4 and batch.bound is not None and torch.equal(flat.flat, want)
+        flat.zero_(); caps.clear()
+        imgs = batch.run(range(4), rasterize, lambda v, img: dL)                  # now sync-free
+        assert caps == [batch.capacity()] * 4 and batch.rejected == 0 and torch.equal(flat.flat, want)
+        assert all(torch.equal(a, b) for a, b in zip(imgs, imgs_want))
+        batch.bound = batch.bound // 3                                            # a bound some views no longer fit
+        small = batch.capacity()
+        flat.zero_(); caps.clear()
+        imgs = batch.run(range(4), rasterize, lambda v, img: dL)
+        assert batch.rejected >= 1 and caps[:4] == [small] * 4 and caps[4:] == [None] * batch.rejected
+        assert all(torch.equal(a, b) for a, b in zip(imgs, imgs_want))
+        # the re-rendered views are added after the others: same terms, different order
+        assert util.rel_l2(flat.flat.cpu().numpy(), want.cpu().numpy()) <= 1e-6
+        assert batch.capacity() > small
+    finally:
+        _C.set_deterministic(False)
+
+
 @pytest.mark.parametrize("levels", [1, 2, 3, 4])
 @pytest.mark.parametrize("M", [16, 9])
 def test_fused_sh_color_matches_reference(levels, M, gpu_device):

@@ -9,11 +9,12 @@
 
 namespace tgs {
 void launch_preprocess_fwd(hipStream_t, const FwdIn&, const CamParams&, const GeomState&, const ImgState&);
-void launch_scan(hipStream_t, const GeomState&, const ImgState&, uint32_t nblocks, uint32_t T, uint32_t sort_cap);
+void launch_scan(hipStream_t, const GeomState&, const ImgState&, uint32_t nblocks, uint32_t T, uint32_t sort_cap, unsigned long long r_capacity,
+                 int allow_overflow);
 void launch_scatter(hipStream_t, int P, const GeomState&, const ImgState&, const BinState&, uint32_t gx);
-void launch_tile_sort(hipStream_t, const GeomState&, const ImgState&, const BinState&, uint32_t gx, uint32_t T, uint32_t R,
-                      uint32_t max_count, uint32_t n_overflow, uint32_t n_nonempty, uint32_t n_heavy, uint32_t sort_cap);
-void launch_render_fwd(hipStream_t, const ImgState&, const BinState&, int W, int H, uint32_t gx, uint32_t T, uint32_t n_nonempty, const float* bg,
+void launch_tile_sort(hipStream_t, const GeomState&, const ImgState&, const BinState&, uint32_t gx, uint32_t T, uint64_t r_bound, const Meta* m,
+                      uint32_t sort_cap);
+void launch_render_fwd(hipStream_t, const ImgState&, const BinState&, int W, int H, uint32_t gx, uint32_t T, const Meta* m, const float* bg,
                        float* out_color);
 void launch_mark_visible(hipStream_t, int P, const float* means3D, const float* view, uint8_t* present);
 void launch_render_bwd(hipStream_t, const ImgState&, const BinState&, int W, int H, uint32_t gx, uint32_t T, const float* bg, const float* dL_dpix,
@@ -50,9 +51,11 @@ size_t g_prof_cap = 0;
 std::vector<ProfRec> g_prof;
 hipEvent_t g_prof_open = nullptr;
 
-void prof_begin_stage(hipStream_t st)
+unsigned g_prof_mask = ~0u;          // stages that get events (tgs_profile_stages)
+
+void prof_begin_stage(hipStream_t st, int stage)
 {
-    if (!g_prof_on) return;
+    if (!g_prof_on || !((g_prof_mask >> stage) & 1u)) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if (!g_prof_on || g_prof.size() >= g_prof_cap) { g_prof_open = nullptr; return; }
     if (hipEventCreate(&g_prof_open) != hipSuccess) { g_prof_open = nullptr; return; }
@@ -60,7 +63,7 @@ void prof_begin_stage(hipStream_t st)
 }
 void prof_end_stage(hipStream_t st, int stage)
 {
-    if (!g_prof_on) return;
+    if (!g_prof_on || !((g_prof_mask >> stage) & 1u)) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if (!g_prof_open) return;
     ProfRec r; r.stage = stage; r.e0 = g_prof_open; g_prof_open = nullptr;
@@ -101,7 +104,7 @@ static int fail(int code, const char* fmt, ...)
     } while (0)
 
 // the reference's CHECK_CUDA (auxiliary.h:166-173): in debug mode synchronise after every stage
-#define STAGE_BEGIN() prof_begin_stage(st)
+#define STAGE_BEGIN(id) prof_begin_stage(st, id)
 #define STAGE_CHECK(name, id)                                                                             \
     do {                                                                                                  \
         prof_end_stage(st, id);                                                                                                  \
@@ -156,6 +159,12 @@ int tgs_profile_begin(int max_records)
     return TGS_OK;
 }
 
+void tgs_profile_stages(unsigned mask)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_mask = mask;
+}
+
 int tgs_profile_end(double* ms_sum, int64_t* counts)
 {
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -173,12 +182,16 @@ int tgs_profile_end(double* ms_sum, int64_t* counts)
 }
 const char* tgs_last_error(void) { return g_err; }
 
-int64_t tgs_forward(tgs_alloc_fn alloc, void* alloc_ctx, void* stream, int P, int D, int M, const float* background, int width,
+// r_capacity < 0: the reference's protocol (read R back, then size the binning buffer).  r_capacity >= 0: sync-free --
+// the binning buffer is sized for r_capacity instances before anything runs and nothing is read back.
+static int64_t forward_impl(int64_t r_capacity, tgs_alloc_fn alloc, void* alloc_ctx, void* stream, int P, int D, int M, const float* background, int width,
                     int height, const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
                     const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
                     const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
                     int prefiltered, float* out_color, int* radii, int debug)
 {
+    const bool async = r_capacity >= 0;
+    if (r_capacity > 0x7fffffffll) return fail(TGS_ERR_INVALID, "r_capacity exceeds 2^31-1");
     hipStream_t st = (hipStream_t)stream;
     g_err[0] = 0;
     if (!alloc) return fail(TGS_ERR_INVALID, "alloc callback is NULL");
@@ -186,6 +199,13 @@ int64_t tgs_forward(tgs_alloc_fn alloc, void* alloc_ctx, void* stream, int P, in
     if (P == 0) {   // rasterize_points.cu:81: nothing runs, the image keeps its zero fill (empty inputs have no pointers to check)
         if (!out_color) return fail(TGS_ERR_INVALID, "NULL required pointer");
         HIP_TRY(hipMemsetAsync(out_color, 0, 3 * (size_t)width * height * sizeof(float), st));
+        if (async) {   // the caller still gets a (zeroed) Meta to query
+            ImgState s0;
+            const size_t bytes = img_carve(s0, nullptr, (size_t)width * height, (size_t)((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE));
+            char* ip = (char*)alloc(alloc_ctx, TGS_BUF_IMAGE, bytes);
+            if (!ip) return fail(TGS_ERR_ALLOC, "state buffer allocation failed");
+            HIP_TRY(hipMemsetAsync(ip, 0, 256, st));
+        }
         return 0;
     }
     if ((shs == nullptr) == (colors_precomp == nullptr)) return fail(TGS_ERR_INVALID, "provide exactly one of shs / colors_precomp");
@@ -221,37 +241,75 @@ int64_t tgs_forward(tgs_alloc_fn alloc, void* alloc_ctx, void* stream, int P, in
     uint64_t R = 0;
     Meta meta;
     memset(&meta, 0, sizeof(meta));
-    if (P > 0) {
-        STAGE_BEGIN();
-        launch_preprocess_fwd(st, in, cam, g, s);
-        STAGE_CHECK("preprocess", TGS_STAGE_PREPROCESS_FWD);
-        STAGE_BEGIN();
-        launch_scan(st, g, s, (uint32_t)n_blocks((size_t)P), (uint32_t)T, sort_cap);
-        STAGE_CHECK("scan", TGS_STAGE_SCAN);
+    STAGE_BEGIN(TGS_STAGE_PREPROCESS_FWD);
+    launch_preprocess_fwd(st, in, cam, g, s);
+    STAGE_CHECK("preprocess", TGS_STAGE_PREPROCESS_FWD);
+    STAGE_BEGIN(TGS_STAGE_SCAN);
+    launch_scan(st, g, s, (uint32_t)n_blocks((size_t)P), (uint32_t)T, sort_cap, async ? (unsigned long long)r_capacity : ~0ull, async ? 0 : 1);
+    STAGE_CHECK("scan", TGS_STAGE_SCAN);
+    if (!async) {
         // the one host synchronisation of the forward pass (rasterizer_impl.cu:280-281): R sizes the binning buffer
         HIP_TRY(hipMemcpyAsync(&meta, s.meta, sizeof(Meta), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         if (meta.error & 1u) return fail(TGS_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
         R = meta.R;
         if (R > 0x7fffffffull) return fail(TGS_ERR_TOO_MANY, "%llu tile instances exceed 2^31-1", (unsigned long long)R);
+    } else {
+        R = (uint64_t)r_capacity;
     }
     const size_t bin_bytes = bin_carve(b, nullptr, (size_t)R);
     char* bin_ptr = (char*)alloc(alloc_ctx, TGS_BUF_BINNING, bin_bytes);
     if (!bin_ptr) return fail(TGS_ERR_ALLOC, "binning buffer allocation failed");
     bin_carve(b, bin_ptr, (size_t)R);
+    const Meta* known = async ? nullptr : &meta;
 
     if (R > 0) {
-        STAGE_BEGIN();
+        STAGE_BEGIN(TGS_STAGE_SCATTER);
         launch_scatter(st, P, g, s, b, cam.gx);
         STAGE_CHECK("scatter", TGS_STAGE_SCATTER);
-        STAGE_BEGIN();
-        launch_tile_sort(st, g, s, b, cam.gx, (uint32_t)T, (uint32_t)R, meta.max_count, meta.n_overflow, meta.n_nonempty, meta.n_heavy, sort_cap);
+        STAGE_BEGIN(TGS_STAGE_TILE_SORT);
+        launch_tile_sort(st, g, s, b, cam.gx, (uint32_t)T, R, known, sort_cap);
         STAGE_CHECK("tile_sort", TGS_STAGE_TILE_SORT);
     }
-    STAGE_BEGIN();
-    launch_render_fwd(st, s, b, width, height, cam.gx, (uint32_t)T, meta.n_nonempty, background, out_color);
+    STAGE_BEGIN(TGS_STAGE_RENDER_FWD);
+    launch_render_fwd(st, s, b, width, height, cam.gx, (uint32_t)T, known, background, out_color);
     STAGE_CHECK("render", TGS_STAGE_RENDER_FWD);
     return (int64_t)R;
+}
+
+int64_t tgs_forward(tgs_alloc_fn alloc, void* alloc_ctx, void* stream, int P, int D, int M, const float* background, int width,
+                    int height, const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+                    const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                    const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
+                    int prefiltered, float* out_color, int* radii, int debug)
+{
+    return forward_impl(-1, alloc, alloc_ctx, stream, P, D, M, background, width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
+                        rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, radii, debug);
+}
+
+int64_t tgs_forward_async(int64_t r_capacity, tgs_alloc_fn alloc, void* alloc_ctx, void* stream, int P, int D, int M, const float* background,
+                          int width, int height, const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+                          const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                          const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
+                          int prefiltered, float* out_color, int* radii, int debug)
+{
+    if (r_capacity < 0) return fail(TGS_ERR_INVALID, "r_capacity must be >= 0");
+    return forward_impl(r_capacity, alloc, alloc_ctx, stream, P, D, M, background, width, height, means3D, shs, colors_precomp, opacities, scales,
+                        scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, radii, debug);
+}
+
+int tgs_frame_status(void* stream, const void* img_buffer, int64_t* num_rendered, int* flags)
+{
+    g_err[0] = 0;
+    if (!img_buffer || !num_rendered || !flags) return fail(TGS_ERR_INVALID, "NULL required pointer");
+    Meta meta;
+    ImgState s;
+    img_carve(s, (char*)img_buffer, 0, 0);                  // Meta is the first field of the image buffer
+    HIP_TRY(hipMemcpyAsync(&meta, s.meta, sizeof(Meta), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    *num_rendered = (int64_t)meta.R;
+    *flags = (int)meta.error;
+    return TGS_OK;
 }
 
 static int backward_impl(int accumulate, void* stream, int P, int D, int M, int64_t R, const float* background, int width, int height, const float* means3D,
@@ -285,13 +343,14 @@ static int backward_impl(int accumulate, void* stream, int P, int D, int M, int6
     in.dL_dmean2D = dL_dmean2D; in.dL_dconic = dL_dconic; in.dL_dopacity = dL_dopacity; in.dL_dcolor = dL_dcolor;
     in.dL_dmean3D = dL_dmean3D; in.dL_dcov3D = dL_dcov3D; in.dL_dsh = dL_dsh; in.dL_dscale = dL_dscale; in.dL_drot = dL_drot;
     in.accumulate = accumulate;
+    in.meta = s.meta;
 
     if (R > 0) {
-        STAGE_BEGIN();
+        STAGE_BEGIN(TGS_STAGE_RENDER_BWD);
         launch_render_bwd(st, s, b, width, height, cam.gx, (uint32_t)T, background, dL_dpix, deterministic_mode());
         STAGE_CHECK("render_bwd", TGS_STAGE_RENDER_BWD);
     }
-    STAGE_BEGIN();
+    STAGE_BEGIN(TGS_STAGE_PREPROCESS_BWD);
     launch_preprocess_bwd(st, in, cam, g, b);
     STAGE_CHECK("preprocess_bwd", TGS_STAGE_PREPROCESS_BWD);
     return TGS_OK;

@@ -29,6 +29,7 @@ __global__ __launch_bounds__(256) void k_render_bwd_det(const ImgState s, const 
     __shared__ QuadLists L;
     __shared__ uint32_t wmax[4];
 
+    if (frame_rejected(s)) return;
     const uint4 td = s.tile_desc[blockIdx.x];
     const uint32_t tile = td.x;
     const uint32_t tx = tile % gx, ty = tile / gx;
@@ -207,6 +208,7 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
     __shared__ unsigned short sMask[BCH];
     __shared__ __attribute__((aligned(16))) unsigned short lists[16][BCH + 8];   // one list per block (= per wave)
 
+    if (frame_rejected(s)) return;
     const uint4 td = s.tile_desc[blockIdx.x];
     const uint32_t tile = td.x;
     const uint32_t tx = tile % gx, ty = tile / gx;
@@ -347,6 +349,10 @@ template <bool HAS_SH, bool HAS_SCALE_ROT>
 __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, const CamParams cam, const GeomState g, const BinState b)
 {
     const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
+    if (in.meta && (in.meta->error & META_ERR_CAPACITY)) {              // rejected frame (tgs_forward_async): contributes nothing
+        if (idx < in.P) { in.dL_dmean2D[3 * idx] = 0.f; in.dL_dmean2D[3 * idx + 1] = 0.f; in.dL_dmean2D[3 * idx + 2] = 0.f; }
+        return;
+    }
     const ViewMat V = load_mat(cam.view), PM = load_mat(cam.proj);
     const float camx = cam.campos[0], camy = cam.campos[1], camz = cam.campos[2];
     // SH rows in, dL_dsh rows out: staged through LDS so that global memory sees 16 B per lane, fully coalesced

@@ -27,11 +27,13 @@ struct Meta {                 // lives at the start of the image buffer
     unsigned long long R;     // number of tile instances ("num_rendered")
     uint32_t max_count;       // longest tile list
     uint32_t n_overflow;      // tiles whose list is longer than SORT_LDS_CAP
-    uint32_t error;           // bit0: prefiltered Gaussian culled
+    uint32_t error;           // bit0: prefiltered Gaussian culled; bit1 (META_ERR_CAPACITY): frame rejected by tgs_forward_async
     uint32_t n_nonempty;      // tiles with at least one instance (they come first in tile_order)
     uint32_t n_heavy;         // tiles with >= 1024 instances (first in tile_order): sorted by 1024-thread workgroups
     uint32_t pad[9];
 };
+
+constexpr uint32_t META_ERR_CAPACITY = 2u;
 
 struct GeomState {
     // One 64-byte line per Gaussian with everything the per-tile gather needs (geomState.means2D,
@@ -374,6 +376,12 @@ __device__ __forceinline__ void row_stride4_sum9(float (&v)[9])
 #undef TGS_ROR
 }
 
+// A frame that tgs_forward_async could not fit into the caller's binning capacity: every kernel behind k_scan returns.
+__device__ __forceinline__ bool frame_rejected(const ImgState& s)
+{
+    return (__builtin_nontemporal_load(&s.meta->error) & META_ERR_CAPACITY) != 0u;
+}
+
 #ifndef TGS_STAMPS
 #define TGS_STAMPS 0
 #endif
@@ -571,6 +579,7 @@ struct BwdIn {
     const float* dL_dpix;
     float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot;
     int accumulate;   // 1: parameter gradients (all but dL_dmean2D / dL_dconic) are added to what the buffers hold
+    const Meta* meta; // the frame's Meta: a frame rejected by tgs_forward_async contributes nothing
 };
 
 }  // namespace tgs

@@ -194,7 +194,7 @@ __device__ __forceinline__ unsigned long long block_exscan_u64(unsigned long lon
     return base + inc - v;
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const ImgState s, uint32_t nblocks, uint32_t T, uint32_t sort_cap)
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const ImgState s, uint32_t nblocks, uint32_t T, uint32_t sort_cap, unsigned long long r_capacity, int allow_overflow)
 {
     __shared__ unsigned long long lds[SCAN_THREADS / WAVE];
     __shared__ uint32_t lds_max[SCAN_THREADS / WAVE];
@@ -213,7 +213,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const 
             for (int k = 0; k < SCAN_ITEMS; k++) { if (i0 + k < nblocks) g.block_sums[i0 + k] = (uint32_t)ex; ex += v[k]; }
             carry += tot;
         }
-        if (threadIdx.x == 0) s.meta->R = carry;
+        if (threadIdx.x == 0) {
+            s.meta->R = carry;
+            if (carry > r_capacity) atomicOr(&s.meta->error, META_ERR_CAPACITY);     // tgs_forward_async: the frame does not fit
+        }
     } else {
         // Tile pass.  One workgroup is latency bound, so every global access is issued 8-deep: the counters of a
         // super-chunk of 8192 tiles are pulled into LDS with 8 independent loads per thread, and the scan, the
@@ -279,6 +282,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const 
             for (int i = 0; i < SCAN_THREADS / WAVE; i++) m = lds_max[i] > m ? lds_max[i] : m;
             s.meta->max_count = m;
             s.meta->n_overflow = ovf_n;
+            if (ovf_n > 0 && !allow_overflow) atomicOr(&s.meta->error, META_ERR_CAPACITY);
         }
     }
 }
@@ -293,6 +297,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_scatter(int P, const GeomState g,
     __shared__ uint32_t qn;
     const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (frame_rejected(s)) return;
     if (threadIdx.x == 0) qn = 0;
     const uint32_t tiles = idx < P ? g.tiles_touched[idx] : 0u;
     const uint32_t inc = wave_iscan_u32(tiles, lane);
@@ -424,10 +429,15 @@ __device__ __forceinline__ void finalize_entry(unsigned long long key, uint32_t 
 
 // One workgroup per tile, visited in tile_order (longest lists first); lists of >= 1024 entries get 1024 threads.
 template <int NT>
-__global__ __launch_bounds__(NT) void k_tile_sort(const ImgState s, const BinState b, uint32_t first, uint32_t sort_cap)
+__global__ __launch_bounds__(NT) void k_tile_sort(const ImgState s, const BinState b, uint32_t sort_cap)
 {
     extern __shared__ unsigned long long lk[];
-    const uint4 td = s.tile_desc[first + blockIdx.x];
+    // the grid is an upper bound (exact after tgs_forward's read-back): heavy tiles come first in tile_order
+    if (frame_rejected(s)) return;
+    const uint32_t n_heavy = min(s.meta->n_heavy, s.meta->n_nonempty);
+    const uint32_t t = (NT == 1024 ? 0u : n_heavy) + blockIdx.x;
+    if (t >= (NT == 1024 ? n_heavy : s.meta->n_nonempty)) return;
+    const uint4 td = s.tile_desc[t];
     const uint2 rg = make_uint2(td.y, td.z);
     const uint32_t n = rg.y - rg.x;
     if (n < 2 || n > sort_cap) return;
@@ -447,10 +457,10 @@ __global__ __launch_bounds__(NT) void k_tile_sort(const ImgState s, const BinSta
 
 // One thread per sorted instance, evenly over all R of them: finds its tile by binary search in the (monotone)
 // range starts, gathers the Gaussian's 64-B line and writes the 40-B record, the block mask and the slab row.
-__global__ __launch_bounds__(256) void k_finalize(const GeomState g, const ImgState s, const BinState b, uint32_t gx, uint32_t T, uint32_t R)
+__global__ __launch_bounds__(256) void k_finalize(const GeomState g, const ImgState s, const BinState b, uint32_t gx, uint32_t T)
 {
     const uint32_t p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= R) return;
+    if (frame_rejected(s) || p >= (uint32_t)s.meta->R) return;
     uint32_t lo = 0, hi = T - 1;                            // last tile whose start is <= p (empty tiles before it share its start)
     while (lo < hi) {
         const uint32_t mid = (lo + hi + 1) >> 1;
@@ -527,6 +537,21 @@ constexpr int FWD_THREADS = 1024;
 constexpr int FCH = 512;                   // list entries staged per round
 constexpr int FNULL = FCH;                 // LDS slot of the null record
 
+// A tile nothing is blended into: C = 0, T = 1 -> background (forward.cu:366-373 with an empty range).  Also what a frame
+// rejected by tgs_forward_async renders, so its image is defined.
+__device__ __forceinline__ void fill_tile_background(const ImgState& s, uint32_t tile, uint32_t t, int W, int H, uint32_t gx,
+                                                     const float* __restrict__ bg, float* __restrict__ out_color)
+{
+    const int px = (tile % gx) * TILE + (t & 15), py = (tile / gx) * TILE + (t >> 4);
+    if (t == 0) s.tile_qmax[tile] = 0;
+    if (px < W && py < H) {
+        const size_t pix_id = (size_t)W * py + px, N = (size_t)W * H;
+        s.final_T[pix_id] = 1.0f;
+        s.n_contrib[pix_id] = 0;
+        out_color[pix_id] = bg[0]; out_color[N + pix_id] = bg[1]; out_color[2 * N + pix_id] = bg[2];
+    }
+}
+
 __global__ __launch_bounds__(FWD_THREADS) void k_render_fwd(const ImgState s, const BinState b, int W, int H, uint32_t gx,
                                                             const float* __restrict__ bg, float* __restrict__ out_color)
 {
@@ -538,7 +563,12 @@ __global__ __launch_bounds__(FWD_THREADS) void k_render_fwd(const ImgState s, co
     __shared__ uint32_t wave_alive[2][16];                 // double-buffered "this wave still has live pixels"
     __shared__ uint32_t wave_qmax[16];
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+    if (blockIdx.x >= s.meta->n_nonempty) return;
     const uint4 td = s.tile_desc[blockIdx.x];
+    if (frame_rejected(s)) {
+        if (threadIdx.x < 256) fill_tile_background(s, td.x, threadIdx.x, W, H, gx, bg, out_color);
+        return;
+    }
     const uint32_t tile = td.x;
     const uint32_t tx = tile % gx, ty = tile / gx;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -647,18 +677,12 @@ __global__ __launch_bounds__(FWD_THREADS) void k_render_fwd(const ImgState s, co
 }
 
 // tiles without any instance: background only (they sit at the end of tile_order)
-__global__ __launch_bounds__(256) void k_fill_empty(const ImgState s, int W, int H, uint32_t gx, uint32_t first, const float* __restrict__ bg,
+__global__ __launch_bounds__(256) void k_fill_empty(const ImgState s, int W, int H, uint32_t gx, uint32_t T, const float* __restrict__ bg,
                                                     float* __restrict__ out_color)
 {
-    const uint32_t tile = s.tile_desc[first + blockIdx.x].x;
-    const int px = (tile % gx) * TILE + (threadIdx.x & 15), py = (tile / gx) * TILE + (threadIdx.x >> 4);
-    if (threadIdx.x == 0) s.tile_qmax[tile] = 0;
-    if (px < W && py < H) {
-        const size_t pix_id = (size_t)W * py + px, N = (size_t)W * H;
-        s.final_T[pix_id] = 1.0f;
-        s.n_contrib[pix_id] = 0;
-        out_color[pix_id] = bg[0]; out_color[N + pix_id] = bg[1]; out_color[2 * N + pix_id] = bg[2];   // C + T*bg with C = 0, T = 1
-    }
+    const uint32_t t = s.meta->n_nonempty + blockIdx.x;     // empty tiles are the tail of tile_order
+    if (t >= T) return;
+    fill_tile_background(s, s.tile_desc[t].x, threadIdx.x, W, H, gx, bg, out_color);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -685,30 +709,37 @@ void launch_preprocess_fwd(hipStream_t st, const FwdIn& in, const CamParams& cam
     else if (sr) hipLaunchKernelGGL((k_preprocess_fwd<false, true>), grid, blk, 0, st, in, cam, g, s);
     else hipLaunchKernelGGL((k_preprocess_fwd<false, false>), grid, blk, 0, st, in, cam, g, s);
 }
-void launch_scan(hipStream_t st, const GeomState& g, const ImgState& s, uint32_t nblocks, uint32_t T, uint32_t sort_cap)
+void launch_scan(hipStream_t st, const GeomState& g, const ImgState& s, uint32_t nblocks, uint32_t T, uint32_t sort_cap, unsigned long long r_capacity,
+                 int allow_overflow)
 {
-    hipLaunchKernelGGL(k_scan, dim3(2), dim3(SCAN_THREADS), 0, st, g, s, nblocks, T, sort_cap);
+    hipLaunchKernelGGL(k_scan, dim3(2), dim3(SCAN_THREADS), 0, st, g, s, nblocks, T, sort_cap, r_capacity, allow_overflow);
 }
 void launch_scatter(hipStream_t st, int P, const GeomState& g, const ImgState& s, const BinState& b, uint32_t gx)
 {
     hipLaunchKernelGGL(k_scatter, dim3((unsigned)n_blocks(P)), dim3(PRE_BLOCK), 0, st, P, g, s, b, gx);
 }
 static uint32_t host_next_pow2(uint32_t n) { uint32_t p = 1; while (p < n) p <<= 1; return p; }
-void launch_tile_sort(hipStream_t st, const GeomState& g, const ImgState& s, const BinState& b, uint32_t gx, uint32_t T, uint32_t R,
-                      uint32_t max_count, uint32_t n_overflow, uint32_t n_nonempty, uint32_t n_heavy, uint32_t sort_cap)
+// Exact sizes (after the forward's read-back of Meta) or, with m == nullptr, upper bounds for the sync-free forward:
+// workgroups beyond the device-side counts return at once.
+void launch_tile_sort(hipStream_t st, const GeomState& g, const ImgState& s, const BinState& b, uint32_t gx, uint32_t T, uint64_t r_bound,
+                      const Meta* m, uint32_t sort_cap)
 {
+    const uint32_t max_count = m ? m->max_count : sort_cap;
     const uint32_t cap = max_count < sort_cap ? max_count : sort_cap;
     const size_t lds = (size_t)(cap ? cap : 1) * 8;
-    if (n_heavy > n_nonempty) n_heavy = n_nonempty;
-    if (n_heavy > 0) hipLaunchKernelGGL((k_tile_sort<1024>), dim3(n_heavy), dim3(1024), lds, st, s, b, 0u, sort_cap);
-    if (n_nonempty > n_heavy) {
+    const uint32_t nonempty = m ? m->n_nonempty : (uint32_t)(r_bound < T ? r_bound : T);
+    uint32_t heavy = m ? m->n_heavy : (uint32_t)(r_bound / 1024 < T ? r_bound / 1024 : T);
+    if (heavy > nonempty) heavy = nonempty;
+    const uint32_t light = m ? nonempty - heavy : nonempty;
+    if (heavy > 0) hipLaunchKernelGGL((k_tile_sort<1024>), dim3(heavy), dim3(1024), lds, st, s, b, sort_cap);
+    if (light > 0) {
         const uint32_t cap2 = cap < 1024u ? cap : 1024u;    // these lists are shorter than 1024
-        hipLaunchKernelGGL((k_tile_sort<256>), dim3(n_nonempty - n_heavy), dim3(256), (size_t)(cap2 ? cap2 : 1) * 8, st, s, b, n_heavy, sort_cap);
+        hipLaunchKernelGGL((k_tile_sort<256>), dim3(light), dim3(256), (size_t)(cap2 ? cap2 : 1) * 8, st, s, b, sort_cap);
     }
-    if (n_overflow > 0) {
+    if (m && m->n_overflow > 0) {
         // lists longer than sort_cap: sorted in global memory by many workgroups, LDS for strides < sort_cap
         const uint32_t npad = host_next_pow2(max_count);
-        const dim3 lgrid((npad + sort_cap - 1) / sort_cap, n_overflow), ggrid((npad / 2 + 255) / 256, n_overflow);
+        const dim3 lgrid((npad + sort_cap - 1) / sort_cap, m->n_overflow), ggrid((npad / 2 + 255) / 256, m->n_overflow);
         const size_t ldsb = (size_t)sort_cap * 8;
         hipLaunchKernelGGL(k_ovf_local, lgrid, dim3(256), ldsb, st, s, b, 0u, sort_cap);
         for (uint32_t k = sort_cap * 2; k <= npad; k <<= 1) {
@@ -717,13 +748,14 @@ void launch_tile_sort(hipStream_t st, const GeomState& g, const ImgState& s, con
             hipLaunchKernelGGL(k_ovf_local, lgrid, dim3(256), ldsb, st, s, b, k, sort_cap);
         }
     }
-    hipLaunchKernelGGL(k_finalize, dim3((R + 255) / 256), dim3(256), 0, st, g, s, b, gx, T, R);
+    if (r_bound > 0) hipLaunchKernelGGL(k_finalize, dim3((unsigned)((r_bound + 255) / 256)), dim3(256), 0, st, g, s, b, gx, T);
 }
-void launch_render_fwd(hipStream_t st, const ImgState& s, const BinState& b, int W, int H, uint32_t gx, uint32_t T, uint32_t n_nonempty,
+void launch_render_fwd(hipStream_t st, const ImgState& s, const BinState& b, int W, int H, uint32_t gx, uint32_t T, const Meta* m,
                        const float* bg, float* out_color)
 {
-    if (n_nonempty > 0) hipLaunchKernelGGL(k_render_fwd, dim3(n_nonempty), dim3(FWD_THREADS), 0, st, s, b, W, H, gx, bg, out_color);
-    if (T > n_nonempty) hipLaunchKernelGGL(k_fill_empty, dim3(T - n_nonempty), dim3(256), 0, st, s, W, H, gx, n_nonempty, bg, out_color);
+    const uint32_t nonempty = m ? m->n_nonempty : T, empty = m ? T - m->n_nonempty : T;
+    if (nonempty > 0) hipLaunchKernelGGL(k_render_fwd, dim3(nonempty), dim3(FWD_THREADS), 0, st, s, b, W, H, gx, bg, out_color);
+    if (empty > 0) hipLaunchKernelGGL(k_fill_empty, dim3(empty), dim3(256), 0, st, s, W, H, gx, T, bg, out_color);
 }
 void launch_mark_visible(hipStream_t st, int P, const float* means3D, const float* view, uint8_t* present)
 {

@@ -34,6 +34,10 @@ def _load() -> C.CDLL:
     lib.tgs_last_error.restype = C.c_char_p
     lib.tgs_forward.restype = C.c_int64
     lib.tgs_forward.argtypes = [vp, vp, vp, it, it, it, vp, it, it, vp, vp, vp, vp, vp, fl, vp, vp, vp, vp, vp, fl, fl, it, vp, vp, it]
+    lib.tgs_forward_async.restype = C.c_int64
+    lib.tgs_forward_async.argtypes = [C.c_int64] + lib.tgs_forward.argtypes
+    lib.tgs_frame_status.restype = it
+    lib.tgs_frame_status.argtypes = [vp, vp, C.POINTER(C.c_int64), C.POINTER(it)]
     lib.tgs_backward.restype = it
     lib.tgs_backward.argtypes = [vp, it, it, it, C.c_int64, vp, it, it, vp, vp, vp, vp, fl, vp, vp, vp, vp, vp, fl, fl, vp,
                                  vp, vp, vp, vp] + [vp] * 9 + [it]
@@ -51,6 +55,8 @@ def _load() -> C.CDLL:
     lib.tgs_selftest_reduce36.argtypes = [vp, vp, vp]
     lib.tgs_profile_begin.restype = it
     lib.tgs_profile_begin.argtypes = [it]
+    lib.tgs_profile_stages.restype = None
+    lib.tgs_profile_stages.argtypes = [C.c_uint]
     lib.tgs_profile_end.restype = it
     lib.tgs_profile_end.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     return lib
@@ -81,8 +87,11 @@ def selftest_reduce36(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def profile_begin(max_records: int = 100000) -> None:
-    """Bench instrumentation: hipEvents around every pipeline stage on the caller's stream (no syncs)."""
+def profile_begin(max_records: int = 100000, stages=None) -> None:
+    """Bench instrumentation: hipEvents around the pipeline stages (all, or the names in ``stages``) on the caller's
+    stream (no syncs)."""
+    mask = 0xffffffff if stages is None else sum(1 << STAGES.index(n) for n in stages)
+    _lib.tgs_profile_stages(mask)
     if _lib.tgs_profile_begin(int(max_records)) < 0:
         raise RuntimeError("profiling already active")
 
@@ -130,8 +139,13 @@ def _require_gpu(means3D: torch.Tensor) -> torch.device:
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                        prefiltered, debug) -> Tuple[int, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
-    """RasterizeGaussiansCUDA (rasterize_points.cu:35-115)."""
+                        prefiltered, debug, r_capacity: Optional[int] = None
+                        ) -> Tuple[int, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """RasterizeGaussiansCUDA (rasterize_points.cu:35-115).
+
+    ``r_capacity`` (extension, tgs_forward_async): render without the host read-back of num_rendered; the binning
+    buffer holds ``r_capacity`` instances and that number is returned in place of num_rendered.  Check the frame with
+    ``frame_status`` / ``frame_meta`` afterwards: a rejected frame renders as background and back-propagates nothing."""
     if means3D.dim() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     dev = _require_gpu(means3D)
@@ -153,13 +167,43 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                  cov=_dev_f32(cov3D_precomp, dev, "cov3D_precomp"), view=_dev_f32(viewmatrix, dev, "viewmatrix"),
                  proj=_dev_f32(projmatrix, dev, "projmatrix"), sh=_dev_f32(sh, dev, "sh"), campos=_dev_f32(campos, dev, "campos"))
         stream = torch.cuda.current_stream(dev).cuda_stream
-        r = _lib.tgs_forward(C.cast(cb, C.c_void_p), None, stream, P, int(degree), M, _p(t["bg"]), W, H, _p(t["means"]),
-                             _p(t["sh"]), _p(t["colors"]), _p(t["opac"]), _p(t["scales"]), float(scale_modifier), _p(t["rots"]),
-                             _p(t["cov"]), _p(t["view"]), _p(t["proj"]), _p(t["campos"]), float(tan_fovx), float(tan_fovy),
-                             int(bool(prefiltered)), out_color.data_ptr(), _p(radii) if P else None, int(bool(debug)))
+        args = (C.cast(cb, C.c_void_p), None, stream, P, int(degree), M, _p(t["bg"]), W, H, _p(t["means"]),
+                _p(t["sh"]), _p(t["colors"]), _p(t["opac"]), _p(t["scales"]), float(scale_modifier), _p(t["rots"]),
+                _p(t["cov"]), _p(t["view"]), _p(t["proj"]), _p(t["campos"]), float(tan_fovx), float(tan_fovy),
+                int(bool(prefiltered)), out_color.data_ptr(), _p(radii) if P else None, int(bool(debug)))
+        r = _lib.tgs_forward(*args) if r_capacity is None else _lib.tgs_forward_async(int(r_capacity), *args)
         if r < 0:
             raise _err(int(r))
     return int(r), out_color, radii, bufs[0], bufs[1], bufs[2]
+
+
+META_BYTES = 64
+FRAME_PREFILTERED, FRAME_REJECTED = 1, 2
+
+
+def frame_meta(image_buffer: torch.Tensor) -> torch.Tensor:
+    """The frame's 64-byte Meta record (a view of the image buffer, on the device): gather these for a batch of
+    sync-free frames and decode them on the host with ``decode_meta`` after ONE copy."""
+    return image_buffer[:META_BYTES]
+
+
+def decode_meta(meta_bytes: torch.Tensor) -> Tuple[int, int]:
+    """64 Meta bytes on the host -> (num_rendered, flags)."""
+    import struct
+    raw = bytes(meta_bytes.cpu().numpy().tobytes())
+    R, _max_count, _n_overflow, flags = struct.unpack_from("<QIII", raw, 0)
+    return int(R), int(flags)
+
+
+def frame_status(image_buffer: torch.Tensor) -> Tuple[int, int]:
+    """tgs_frame_status: synchronises the current stream; -> (true num_rendered, TGS_FRAME_* flags)."""
+    dev = image_buffer.device
+    R, fl = C.c_int64(0), C.c_int(0)
+    with torch.cuda.device(dev):
+        r = _lib.tgs_frame_status(torch.cuda.current_stream(dev).cuda_stream, image_buffer.data_ptr(), C.byref(R), C.byref(fl))
+    if r < 0:
+        raise _err(int(r))
+    return int(R.value), int(fl.value)
 
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,

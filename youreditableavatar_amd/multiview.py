@@ -87,21 +87,23 @@ class _RasterizeAccumulate(torch.autograd.Function):
     buffer (e.g. from FlatGradients); ``means2D`` keeps its ordinary per-view gradient."""
 
     @staticmethod
-    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings, r_capacity):
         from .diff_gaussian_rasterization import _C
         rs = raster_settings
         num_rendered, color, radii, geom, binning, img = _C.rasterize_gaussians(
             rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix, rs.projmatrix,
-            rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
-        ctx.rs, ctx.num_rendered = rs, num_rendered
+            rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug,
+            r_capacity=r_capacity)
+        ctx.rs, ctx.num_rendered = rs, num_rendered         # sync-free: the binning capacity (what the buffers are carved for)
         ctx.leaves = dict(means3D=means3D, sh=sh, colors_precomp=colors_precomp, opacities=opacities, scales=scales, rotations=rotations,
                           cov3D_precomp=cov3Ds_precomp)
         ctx.save_for_backward(radii, geom, binning, img)
-        ctx.mark_non_differentiable(radii)
-        return color, radii
+        meta = _C.frame_meta(img) if img.numel() else torch.zeros(_C.META_BYTES, dtype=torch.uint8, device=color.device)
+        ctx.mark_non_differentiable(radii, meta)
+        return color, radii, meta
 
     @staticmethod
-    def backward(ctx, grad_out_color, _grad_radii):
+    def backward(ctx, grad_out_color, _grad_radii, _grad_meta=None):
         from .diff_gaussian_rasterization import _C
         rs, L = ctx.rs, ctx.leaves
         radii, geom, binning, img = ctx.saved_tensors
@@ -115,13 +117,87 @@ class _RasterizeAccumulate(torch.autograd.Function):
             rs.bg, L["means3D"].detach(), radii, L["colors_precomp"].detach(), L["scales"].detach(), L["rotations"].detach(), rs.scale_modifier,
             L["cov3D_precomp"].detach(), rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, L["sh"].detach(), rs.sh_degree,
             rs.campos, geom, ctx.num_rendered, binning, img, rs.debug, into)
-        return None, g2d, None, None, None, None, None, None, None
+        return None, g2d, None, None, None, None, None, None, None, None
 
 
 def rasterize_accumulate(raster_settings, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                         cov3D_precomp=None):
-    """``GaussianRasterizer(raster_settings)(...)`` with fused gradient accumulation (HIP device only)."""
+                         cov3D_precomp=None, r_capacity: Optional[int] = None, return_meta: bool = False):
+    """``GaussianRasterizer(raster_settings)(...)`` with fused gradient accumulation (HIP device only).
+
+    ``r_capacity``: render sync-free (tgs_forward_async) with room for that many tile instances -- use through
+    ``SyncFreeBatch``, which checks every frame afterwards and re-renders rejected ones.  ``return_meta`` appends the
+    frame's 64-byte Meta record (device tensor, see ``_C.decode_meta``)."""
     e = torch.Tensor([])
-    return _RasterizeAccumulate.apply(means3D, means2D, e if shs is None else shs, e if colors_precomp is None else colors_precomp, opacities,
-                                      e if scales is None else scales, e if rotations is None else rotations,
-                                      e if cov3D_precomp is None else cov3D_precomp, raster_settings)
+    color, radii, meta = _RasterizeAccumulate.apply(
+        means3D, means2D, e if shs is None else shs, e if colors_precomp is None else colors_precomp, opacities,
+        e if scales is None else scales, e if rotations is None else rotations, e if cov3D_precomp is None else cov3D_precomp,
+        raster_settings, r_capacity)
+    return (color, radii, meta) if (return_meta or r_capacity is not None) else (color, radii)
+
+
+class SyncFreeBatch:
+    """Renders the views of one step without a host synchronisation per frame.
+
+    The reference's forward reads num_rendered back for every frame (rasterizer_impl.cu:280-281) and so does
+    ``GaussianRasterizer``; between that read-back and the next launches the GPU idles.  A batch knows better: the
+    instance count of a view changes slowly from step to step, so the binning buffer is sized from the counts seen so
+    far (times ``headroom``) and nothing is read back until the batch is done.  Then ONE copy fetches every frame's
+    Meta record; a frame that did not fit rendered as background and accumulated nothing (it was rejected on the
+    device), and is rendered again with the synchronous forward, which also raises the bound.  Results are those of
+    the synchronous path: only the binning capacity differs.
+
+    ``rasterize(v, r_capacity)`` renders view ``v`` with ``rasterize_accumulate(..., r_capacity=r_capacity,
+    return_meta=True)`` and returns its ``(image, radii, meta)``; ``upstream(v, image)`` returns dL/d image (it runs
+    again for a re-rendered view)."""
+
+    def __init__(self, headroom: float = 1.25, granule: int = 1 << 16):
+        self.headroom, self.granule = float(headroom), int(granule)
+        self.bound: Optional[int] = None        # largest num_rendered seen (decays slowly)
+        self.rejected = 0                       # frames re-rendered so far
+        self._host: Optional[torch.Tensor] = None
+
+    def capacity(self) -> Optional[int]:
+        if self.bound is None:
+            return None
+        c = int(self.bound * self.headroom) + 1
+        return min(0x7fffffff, (c + self.granule - 1) // self.granule * self.granule)
+
+    def run(self, views: Iterable[int], rasterize: Callable, upstream: Callable[[int, torch.Tensor], torch.Tensor]) -> List[torch.Tensor]:
+        from .diff_gaussian_rasterization import _C
+        views = list(views)
+        images: List[torch.Tensor] = []
+        metas: List[torch.Tensor] = []
+        cap = self.capacity()
+        if not views:
+            return images
+        ready = None
+        for k, v in enumerate(views):
+            img, _radii, meta = rasterize(v, cap)
+            metas.append(meta)
+            if k == len(views) - 1:
+                # every Meta record is final once its forward is enqueued: start the read-back NOW, in front of the last
+                # backward, so the host learns the verdict while the GPU is still busy
+                stacked = torch.stack(metas)
+                if self._host is None or self._host.shape != stacked.shape:
+                    self._host = torch.empty(stacked.shape, dtype=torch.uint8, pin_memory=True)
+                self._host.copy_(stacked, non_blocking=True)
+                ready = torch.cuda.Event()
+                ready.record()
+            img.backward(upstream(v, img.detach()))
+            images.append(img.detach())
+        ready.synchronize()                                 # the one host wait of the batch
+        host = self._host
+        seen = 0
+        for i, v in enumerate(views):
+            R, flags = _C.decode_meta(host[i])
+            if flags & _C.FRAME_PREFILTERED:
+                raise RuntimeError("Point is filtered although prefiltered is set. This shouldn't happen!")
+            if flags & _C.FRAME_REJECTED:
+                self.rejected += 1
+                img, _radii, meta = rasterize(v, None)      # synchronous forward: sizes its buffers from the true count
+                img.backward(upstream(v, img.detach()))
+                images[i] = img.detach()
+                R, _ = _C.decode_meta(meta)
+            seen = max(seen, R)
+        self.bound = seen if self.bound is None else max(seen, int(self.bound * 0.95))
+        return images
