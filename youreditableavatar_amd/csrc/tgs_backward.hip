@@ -248,20 +248,30 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
         row[0] = make_float4(0.f, 0.f, 0.f, 0.f); row[1] = make_float4(0.f, 0.f, 0.f, 0.f); row[2] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 
-    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
-    float2 rc = make_float2(0.f, 0.f);
-    uint32_t rs = 0;
-    if (threadIdx.x < BCH && threadIdx.x < qmax) { const uint32_t pos = rg.x + qmax - 1 - threadIdx.x; ra = b.recA[pos]; rb = b.recB[pos]; rc = b.recC[pos]; rs = b.slot[pos]; }
+    // Register-staged prefetch of the next round, split over the two halves of the workgroup so that it costs 6 VGPRs, not 11
+    // (64 VGPRs keep two workgroups per CU): thread t < BCH carries recA + recC of entry t, thread BCH + t recB + slot.
+    const uint32_t ht = threadIdx.x & (BCH - 1);
+    const bool upper = threadIdx.x >= BCH;
+    float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint2 r2 = make_uint2(0u, 0u);
+    auto fetch = [&](uint32_t pos) {
+        if (!upper) { r4 = b.recA[pos]; const float2 c = b.recC[pos]; r2 = make_uint2(__float_as_uint(c.x), __float_as_uint(c.y)); }
+        else { r4 = b.recB[pos]; r2.x = b.slot[pos]; }
+    };
+    auto stage = [&](int buf) {
+        uint32_t h = ht;
+        asm volatile("" : "+v"(h));                        // keeps the five LDS addresses from being hoisted into (spilled) VGPRs
+        if (!upper) { stage_conic_a(r4); sA[h] = r4; sC[h] = __uint_as_float(r2.x); sMask[h] = (unsigned short)r2.y; }
+        else { stage_conic_b(r4); sB[h] = r4; sSlot[buf][h] = r2.x; }
+    };
+    if (ht < qmax) fetch(rg.x + qmax - 1 - ht);
 
     // Two barriers per round: [compute r] | flush r + zero its accumulator column + stage r+1 | [compute r+1] ...
     for (uint32_t i = threadIdx.x; i < NACC * (BCH + 1); i += BWD_THREADS) (&acc[0][0])[i] = 0.f;
     {
         const uint32_t cnt0 = min((uint32_t)BCH, qmax);
-        if (threadIdx.x < cnt0) { stage_conic(ra, rb); sA[threadIdx.x] = ra; sB[threadIdx.x] = rb; sC[threadIdx.x] = rc.x; sMask[threadIdx.x] = (unsigned short)__float_as_uint(rc.y); sSlot[0][threadIdx.x] = rs; }
-        if (threadIdx.x < BCH && qmax > BCH && threadIdx.x < qmax - BCH) {
-            const uint32_t pos = rg.x + qmax - BCH - 1 - threadIdx.x;
-            ra = b.recA[pos]; rb = b.recB[pos]; rc = b.recC[pos]; rs = b.slot[pos];
-        }
+        if (ht < cnt0) stage(0);
+        if (qmax > BCH && ht < qmax - BCH) fetch(rg.x + qmax - BCH - 1 - ht);
     }
     __syncthreads();
     int rnd = 0;
@@ -331,11 +341,8 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
         }
         if (qhi > BCH) {                                    // stage the next round (its records were prefetched into registers)
             const uint32_t qn = qhi - BCH, cntn = min((uint32_t)BCH, qn);
-            if (threadIdx.x < cntn) { stage_conic(ra, rb); sA[threadIdx.x] = ra; sB[threadIdx.x] = rb; sC[threadIdx.x] = rc.x; sMask[threadIdx.x] = (unsigned short)__float_as_uint(rc.y); sSlot[rnd ^ 1][threadIdx.x] = rs; }
-            if (threadIdx.x < BCH && qn > BCH && threadIdx.x < qn - BCH) {
-                const uint32_t pos = rg.x + qn - BCH - 1 - threadIdx.x;
-                ra = b.recA[pos]; rb = b.recB[pos]; rc = b.recC[pos]; rs = b.slot[pos];
-            }
+            if (ht < cntn) stage(rnd ^ 1);
+            if (qn > BCH && ht < qn - BCH) fetch(rg.x + qn - BCH - 1 - ht);
             __syncthreads();
         }
     }

@@ -287,10 +287,8 @@ __device__ __forceinline__ float quad_bcast(float v)
 // (forward.cu:336 `power = -0.5f * (con.x*d.x*d.x + con.z*d.y*d.y) - con.y*d.x*d.y`, d = mean - pixel as in this code).
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float UNSCALE_CONIC = -2.0f / LOG2E, UNSCALE_CONIC_XY = -1.0f / LOG2E;
-__device__ __forceinline__ void stage_conic(float4& ra, float4& rb)
-{
-    ra.z *= -0.5f * LOG2E; ra.w *= -LOG2E; rb.x *= -0.5f * LOG2E;
-}
+__device__ __forceinline__ void stage_conic_a(float4& ra) { ra.z *= -0.5f * LOG2E; ra.w *= -LOG2E; }
+__device__ __forceinline__ void stage_conic_b(float4& rb) { rb.x *= -0.5f * LOG2E; }
 
 // ---------------------------------------------------------------------------------------------
 // Hand-scheduled DPP sequences.  hipcc keeps `v_mov_b32 tmp, 0; v_mov_b32_dpp tmp, x` in front of every consumer
@@ -313,56 +311,78 @@ constexpr unsigned long long QUAD_LT3 = 0x7777777777777777ull;
 __device__ __forceinline__ void bwd_chain4(float a, float c0, float c1, float c2, float& T, float& r0, float& r1, float& r2,
                                            float& Town, float& inv, float& o0, float& o1, float& o2, float one, float zero)
 {
-    float om, m0, m1, m2, so, t0, t1, t2, q;
+    float om, m0, m1, m2, so, t, q;
+#define TGS_STEP(K, LT, SRC0, SRC1, SRC2, QINIT)                                              \
+        "s_mov_b64 vcc, %[" #LT "]\n\t"                                                       \
+        "v_cndmask_b32_dpp %[so], %[om], %[one], vcc" TGS_QP(K)                               \
+        "v_cndmask_b32_dpp %[t], %[m0], %[zero], vcc" TGS_QP(K)                               \
+        QINIT                                                                                 \
+        "v_fma_f32 %[o0], %[" #SRC0 "], %[so], %[t]\n\t"                                      \
+        "v_cndmask_b32_dpp %[t], %[m1], %[zero], vcc" TGS_QP(K)                               \
+        "v_fma_f32 %[o1], %[" #SRC1 "], %[so], %[t]\n\t"                                      \
+        "v_cndmask_b32_dpp %[t], %[m2], %[zero], vcc" TGS_QP(K)                               \
+        "v_fma_f32 %[o2], %[" #SRC2 "], %[so], %[t]\n\t"
     asm volatile(
         "v_sub_f32 %[om], 1.0, %[a]\n\t"
         "v_mul_f32 %[m0], %[a], %[c0]\n\t"
         "v_mul_f32 %[m1], %[a], %[c1]\n\t"
         "v_mul_f32 %[m2], %[a], %[c2]\n\t"
-        "s_mov_b64 vcc, %[lt1]\n\t"
-        "v_cndmask_b32_dpp %[q], %[om], %[one], vcc" TGS_QP(0)
-        "v_cndmask_b32_dpp %[t0], %[m0], %[zero], vcc" TGS_QP(0)
-        "v_cndmask_b32_dpp %[t1], %[m1], %[zero], vcc" TGS_QP(0)
-        "s_nop 0\n\t"
-        "v_cndmask_b32_dpp %[t2], %[m2], %[zero], vcc" TGS_QP(0)
-        "v_fma_f32 %[o0], %[r0], %[q], %[t0]\n\t"
-        "v_fma_f32 %[o1], %[r1], %[q], %[t1]\n\t"
-        "v_fma_f32 %[o2], %[r2], %[q], %[t2]\n\t"
-        "s_mov_b64 vcc, %[lt2]\n\t"
-        "v_cndmask_b32_dpp %[so], %[om], %[one], vcc" TGS_QP(1)
-        "v_cndmask_b32_dpp %[t0], %[m0], %[zero], vcc" TGS_QP(1)
-        "v_cndmask_b32_dpp %[t1], %[m1], %[zero], vcc" TGS_QP(1)
-        "v_cndmask_b32_dpp %[t2], %[m2], %[zero], vcc" TGS_QP(1)
-        "v_mul_f32 %[q], %[q], %[so]\n\t"
-        "v_fma_f32 %[o0], %[o0], %[so], %[t0]\n\t"
-        "v_fma_f32 %[o1], %[o1], %[so], %[t1]\n\t"
-        "v_fma_f32 %[o2], %[o2], %[so], %[t2]\n\t"
-        "s_mov_b64 vcc, %[lt3]\n\t"
-        "v_cndmask_b32_dpp %[so], %[om], %[one], vcc" TGS_QP(2)
-        "v_cndmask_b32_dpp %[t0], %[m0], %[zero], vcc" TGS_QP(2)
-        "v_cndmask_b32_dpp %[t1], %[m1], %[zero], vcc" TGS_QP(2)
-        "v_cndmask_b32_dpp %[t2], %[m2], %[zero], vcc" TGS_QP(2)
-        "v_mul_f32 %[q], %[q], %[so]\n\t"
-        "v_fma_f32 %[o0], %[o0], %[so], %[t0]\n\t"
-        "v_fma_f32 %[o1], %[o1], %[so], %[t1]\n\t"
-        "v_fma_f32 %[o2], %[o2], %[so], %[t2]\n\t"
+        TGS_STEP(0, lt1, r0, r1, r2, "v_mov_b32 %[q], %[so]\n\t")
+        TGS_STEP(1, lt2, o0, o1, o2, "v_mul_f32 %[q], %[q], %[so]\n\t")
+        TGS_STEP(2, lt3, o0, o1, o2, "v_mul_f32 %[q], %[q], %[so]\n\t")
         "v_mul_f32 %[so], %[q], %[om]\n\t"               // prod_{k<=e} (1 - a_k)
         "v_rcp_f32 %[so], %[so]\n\t"
-        "v_fma_f32 %[t0], %[o0], %[om], %[m0]\n\t"         // state behind this lane's own entry
-        "v_fma_f32 %[t1], %[o1], %[om], %[m1]\n\t"
-        "v_fma_f32 %[t2], %[o2], %[om], %[m2]\n\t"
+        "v_fma_f32 %[t], %[o0], %[om], %[m0]\n\t"          // state behind this lane's own entry, channel by channel
+        "v_fma_f32 %[m0], %[o1], %[om], %[m1]\n\t"
+        "v_fma_f32 %[m1], %[o2], %[om], %[m2]\n\t"
         "v_mul_f32 %[Town], %[T], %[so]\n\t"
         "v_mul_f32 %[inv], %[q], %[so]\n\t"
-        "v_mov_b32_dpp %[r0], %[t0]" TGS_QP(3)
-        "v_mov_b32_dpp %[r1], %[t1]" TGS_QP(3)
-        "v_mov_b32_dpp %[r2], %[t2]" TGS_QP(3)
+        "v_mov_b32_dpp %[r0], %[t]" TGS_QP(3)
+        "v_mov_b32_dpp %[r1], %[m0]" TGS_QP(3)
+        "v_mov_b32_dpp %[r2], %[m1]" TGS_QP(3)
         "v_mov_b32_dpp %[T], %[Town]" TGS_QP(3)
-        : [om] "=&v"(om), [m0] "=&v"(m0), [m1] "=&v"(m1), [m2] "=&v"(m2), [so] "=&v"(so), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
+        : [om] "=&v"(om), [m0] "=&v"(m0), [m1] "=&v"(m1), [m2] "=&v"(m2), [so] "=&v"(so), [t] "=&v"(t),
           [q] "=&v"(q), [Town] "=&v"(Town), [inv] "=&v"(inv), [o0] "=&v"(o0), [o1] "=&v"(o1), [o2] "=&v"(o2),
           [T] "+v"(T), [r0] "+v"(r0), [r1] "+v"(r1), [r2] "+v"(r2)
         : [a] "v"(a), [c0] "v"(c0), [c1] "v"(c1), [c2] "v"(c2), [one] "v"(one), [zero] "v"(zero),
           [lt1] "s"(QUAD_LT1), [lt2] "s"(QUAD_LT2), [lt3] "s"(QUAD_LT3)
         : "vcc");
+#undef TGS_STEP
+}
+
+// Front-to-back walk of one pixel through the 4 entries of its quad (forward.cu:344-357): p = 1 - alpha of this lane's
+// entry (1 for a skipped one), T = transmittance in front of the group (uniform over the quad).
+//   y = T * p_0 * ... * p_{e-1}  (transmittance in front of this lane's entry, the reference's left-to-right products),
+//   x = y * p_e                   (the reference's test_T).
+__device__ __forceinline__ void fwd_chain4(float p, float T, float& y, float& x, float one)
+{
+    asm volatile(
+        "s_mov_b64 vcc, %[lt1]\n\t"
+        "s_nop 0\n\t"
+        "v_cndmask_b32_dpp %[y], %[p], %[one], vcc" TGS_QP(0)
+        "s_mov_b64 vcc, %[lt2]\n\t"
+        "v_cndmask_b32_dpp %[x], %[p], %[one], vcc" TGS_QP(1)
+        "v_mul_f32 %[y], %[T], %[y]\n\t"
+        "v_mul_f32 %[y], %[y], %[x]\n\t"
+        "s_mov_b64 vcc, %[lt3]\n\t"
+        "v_cndmask_b32_dpp %[x], %[p], %[one], vcc" TGS_QP(2)
+        "v_mul_f32 %[y], %[y], %[x]\n\t"
+        "v_mul_f32 %[x], %[y], %[p]\n\t"
+        : [y] "=&v"(y), [x] "=&v"(x)
+        : [p] "v"(p), [T] "v"(T), [one] "v"(one), [lt1] "s"(QUAD_LT1), [lt2] "s"(QUAD_LT2), [lt3] "s"(QUAD_LT3)
+        : "vcc");
+}
+// c <- max of c over the quad; x3 <- x of the quad's lane 3
+__device__ __forceinline__ void quad_max_bcast3(float& c, float x, float& x3)
+{
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %[c], %[c], %[c] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %[x3], %[x]" TGS_QP(3)
+        "s_nop 0\n\t"
+        "v_max_f32_dpp %[c], %[c], %[c] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        : [c] "+v"(c), [x3] "=&v"(x3)
+        : [x] "v"(x));
 }
 
 // x_i <- sum of x_i over the 4 lanes {l, l+4, l+8, l+12} of each row, for 9 values: 18 v_add_f32_dpp

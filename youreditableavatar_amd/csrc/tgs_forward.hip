@@ -552,7 +552,7 @@ __device__ __forceinline__ void fill_tile_background(const ImgState& s, uint32_t
     }
 }
 
-__global__ __launch_bounds__(FWD_THREADS) void k_render_fwd(const ImgState s, const BinState b, int W, int H, uint32_t gx,
+__global__ __launch_bounds__(FWD_THREADS, 8) void k_render_fwd(const ImgState s, const BinState b, int W, int H, uint32_t gx,
                                                             const float* __restrict__ bg, float* __restrict__ out_color)
 {
     __shared__ float4 sA[FCH + 1];
@@ -581,14 +581,23 @@ __global__ __launch_bounds__(FWD_THREADS) void k_render_fwd(const ImgState s, co
     set_wave_priority(rg.y - rg.x);
     stamp(s, tile, 0);
     bool done = !inside;                                   // per pixel; identical in the 4 lanes of a quad
+    float vone = 1.0f;                                     // pinned to a VGPR for the DPP selects
+    asm volatile("" : "+v"(vone));
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;          // C: this lane's share (entries of slot e)
     uint32_t last_contributor = 0;
     if (threadIdx.x == 0) { sA[FNULL] = make_float4(0.f, 0.f, 0.f, 0.f); sB[FNULL] = make_float4(0.f, 0.f, 0.f, 0.f); sC[FNULL] = 0.f; }
 
-    // register-staged prefetch of the next round (global loads stay in flight under the compute)
-    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
-    float2 rc = make_float2(0.f, 0.f);
-    if (threadIdx.x < FCH && rg.x + threadIdx.x < rg.y) { ra = b.recA[rg.x + threadIdx.x]; rb = b.recB[rg.x + threadIdx.x]; rc = b.recC[rg.x + threadIdx.x]; }
+    // Register-staged prefetch of the next round (global loads stay in flight under the compute), split over the two halves
+    // of the workgroup to stay inside 64 VGPRs: thread t < FCH carries recA + recC of entry t, thread FCH + t carries recB.
+    const uint32_t ht = threadIdx.x & (FCH - 1);
+    const bool upper = threadIdx.x >= FCH;
+    float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float2 r2 = make_float2(0.f, 0.f);
+    auto fetch = [&](uint32_t pos) {
+        if (!upper) { r4 = b.recA[pos]; r2 = b.recC[pos]; }
+        else r4 = b.recB[pos];
+    };
+    if (rg.x + ht < rg.y) fetch(rg.x + ht);
 
     bool wave_live = __builtin_amdgcn_ballot_w64(!done) != 0;
     int round = 0;
@@ -603,43 +612,43 @@ __global__ __launch_bounds__(FWD_THREADS) void k_render_fwd(const ImgState s, co
             if (((f0.x | f0.y | f0.z | f0.w) | (f1.x | f1.y | f1.z | f1.w) | (f2.x | f2.y | f2.z | f2.w) | (f3.x | f3.y | f3.z | f3.w)) == 0u) break;
         }
         const uint32_t cnt = min((uint32_t)FCH, rg.y - base);
-        if (threadIdx.x < cnt) { sA[threadIdx.x] = ra; sB[threadIdx.x] = rb; sC[threadIdx.x] = rc.x; sMask[threadIdx.x] = (unsigned short)__float_as_uint(rc.y); }
-        __syncthreads();
-        if (threadIdx.x < FCH) {
-            const uint32_t nxt = base + FCH + threadIdx.x;
-            if (nxt < rg.y) { ra = b.recA[nxt]; rb = b.recB[nxt]; rc = b.recC[nxt]; }
+        if (ht < cnt) {
+            if (!upper) { stage_conic_a(r4); sA[ht] = r4; sC[ht] = r2.x; sMask[ht] = (unsigned short)__float_as_uint(r2.y); }
+            else { stage_conic_b(r4); sB[ht] = r4; }
         }
+        __syncthreads();
+        if (base + FCH + ht < rg.y) fetch(base + FCH + ht);
         const uint32_t cbase = base - rg.x + 1;
         {
             const uint32_t n = wave_live ? build_own_list<FCH>(lists[wv], sMask, cnt, wv, lane, FNULL) : 0u;
 #pragma unroll 1
             for (uint32_t k = 0; k < n; k += 4) {               // 4 list entries per pass, only those that can reach this block
                 const uint32_t j = lists[wv][k + e];
-                const float4 a = sA[j];
-                const float4 bb = sB[j];
+                const float4 a = sA[j];                        // mean2D, conic xx / xy pre-scaled for exp2 (stage_conic)
+                const float4 bb = sB[j];                       // conic yy pre-scaled, opacity, colour r g
                 const float cc = sC[j];
                 const float dx = a.x - pixfx, dy = a.y - pixfy;
-                const float power = -0.5f * (a.z * dx * dx + bb.x * dy * dy) - a.w * dx * dy;
-                const float alpha = fminf(0.99f, bb.y * tgs_exp(power));
-                const bool live = !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+                const float power2 = (a.z * dx + a.w * dy) * dx + (bb.x * dy) * dy;    // log2(e) * power of forward.cu:336
+                const float alpha = fminf(0.99f, bb.y * __builtin_amdgcn_exp2f(power2));
+                // forward.cu:337-343 skips; a finished pixel skips everything (a padding entry has opacity 0)
+                const bool live = !done && !(power2 > 0.0f) && !(alpha < 1.0f / 255.0f);
                 const float pown = live ? 1.f - alpha : 1.0f;   // a skipped entry leaves T alone
-                // the pixel's transmittance chain over the group's 4 entries, in list order (all 4 lanes of the quad agree)
-                bool alive = !done;
-                const float t0 = T;
-                const float x0 = t0 * quad_bcast<0>(pown); const bool ok0 = alive && !(x0 < 0.0001f); const float t1 = ok0 ? x0 : t0; alive = ok0;
-                const float x1 = t1 * quad_bcast<1>(pown); const bool ok1 = alive && !(x1 < 0.0001f); const float t2 = ok1 ? x1 : t1; alive = ok1;
-                const float x2 = t2 * quad_bcast<2>(pown); const bool ok2 = alive && !(x2 < 0.0001f); const float t3 = ok2 ? x2 : t2; alive = ok2;
-                const float x3 = t3 * quad_bcast<3>(pown); const bool ok3 = alive && !(x3 < 0.0001f); const float t4 = ok3 ? x3 : t3; alive = ok3;
-                const float Tb = e == 0 ? t0 : e == 1 ? t1 : e == 2 ? t2 : t3;
-                const bool okown = e == 0 ? ok0 : e == 1 ? ok1 : e == 2 ? ok2 : ok3;
-                const bool upd = live && okown;
-                const float w = upd ? alpha * Tb : 0.f;
+                // The pixel's transmittance over the group's 4 entries, in list order.  The products never grow, so once an
+                // entry fails `test_T < 0.0001` (forward.cu:345-350) every later live entry fails too: a lane only needs
+                // its own test, and T stops at the value in front of the first failing entry = the largest such value.
+                float y, x, x3;
+                fwd_chain4(pown, T, y, x, vone);
+                const bool fail = live && (x < 0.0001f);
+                const bool upd = live && !fail;
+                float cand = fail ? y : -1.0f;
+                quad_max_bcast3(cand, x, x3);
+                const float w = upd ? alpha * y : 0.f;
                 C0 += bb.z * w; C1 += bb.w * w; C2 += cc * w;
                 last_contributor = upd ? cbase + j : last_contributor;
-                T = t4;
-                const bool newly_done = !alive && !done;
-                done = !alive;
-                if (__builtin_amdgcn_ballot_w64(newly_done) != 0 && __builtin_amdgcn_ballot_w64(!done) == 0) { wave_live = false; break; }
+                const bool stop = cand >= 0.0f;                 // some entry of the group ended the pixel
+                T = stop ? cand : x3;
+                done = done || stop;
+                if (__builtin_amdgcn_ballot_w64(!done) == 0) { wave_live = false; break; }
             }
         }
     }
