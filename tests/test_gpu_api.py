@@ -275,7 +275,8 @@ def test_sync_free_forward_matches_and_rejects(gpu_device):
         _C.set_deterministic(False)
 
 
-def test_sync_free_batch_rerenders_rejected_views(gpu_device):
+@pytest.mark.parametrize("streams", [1, 2])
+def test_sync_free_batch_rerenders_rejected_views(streams, gpu_device):
     """multiview.SyncFreeBatch: one read-back per batch; views that outgrow the bound are rendered again, and the
     accumulated gradients equal the per-frame-synchronised ones."""
     from diff_gaussian_rasterization import _C
@@ -302,7 +303,7 @@ def test_sync_free_batch_rerenders_rejected_views(gpu_device):
         for v in range(4):
             rasterize(v, None)[0].backward(dL)
         want, imgs_want = flat.flat.clone(), [rasterize(v, None)[0].detach().clone() for v in range(4)]
-        batch = SyncFreeBatch(headroom=1.25, granule=256)
+        batch = SyncFreeBatch(headroom=1.25, granule=256, streams=streams)
         flat.zero_(); caps.clear()
         imgs = batch.run(range(4), rasterize, lambda v, img: dL)                  # first batch: no bound yet -> synchronous frames
         assert caps == [None] * 4 and batch.bound is not None and torch.equal(flat.flat, want)

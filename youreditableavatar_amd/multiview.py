@@ -150,11 +150,13 @@ class SyncFreeBatch:
     return_meta=True)`` and returns its ``(image, radii, meta)``; ``upstream(v, image)`` returns dL/d image (it runs
     again for a re-rendered view)."""
 
-    def __init__(self, headroom: float = 1.25, granule: int = 1 << 16):
+    def __init__(self, headroom: float = 1.25, granule: int = 1 << 16, streams: int = 2):
         self.headroom, self.granule = float(headroom), int(granule)
         self.bound: Optional[int] = None        # largest num_rendered seen (decays slowly)
         self.rejected = 0                       # frames re-rendered so far
+        self.streams = max(1, int(streams))     # 2: consecutive views alternate between two HIP streams (see run)
         self._host: Optional[torch.Tensor] = None
+        self._side = {}
 
     def capacity(self) -> Optional[int]:
         if self.bound is None:
@@ -163,6 +165,11 @@ class SyncFreeBatch:
         return min(0x7fffffff, (c + self.granule - 1) // self.granule * self.granule)
 
     def run(self, views: Iterable[int], rasterize: Callable, upstream: Callable[[int, torch.Tensor], torch.Tensor]) -> List[torch.Tensor]:
+        """Renders and back-propagates ``views``; returns their images.
+
+        With ``streams=2`` view k runs on stream k % 2, so the forward of view k+1 (binning: L2 atomics and HBM) shares
+        the GPU with the backward of view k (VALU bound).  The backwards stay ordered among themselves -- they add into
+        the same gradient buffers -- and the calling stream waits for everything before ``run`` returns."""
         from .diff_gaussian_rasterization import _C
         views = list(views)
         images: List[torch.Tensor] = []
@@ -170,21 +177,53 @@ class SyncFreeBatch:
         cap = self.capacity()
         if not views:
             return images
+        main = torch.cuda.current_stream()
+        lanes = [main]
+        if self.streams > 1 and cap is not None and len(views) > 1:
+            key = main.device
+            if key not in self._side:
+                self._side[key] = torch.cuda.Stream(device=key)
+            lanes.append(self._side[key])
+            start = torch.cuda.Event()
+            start.record(main)
+            lanes[1].wait_event(start)                      # whatever the caller enqueued before (e.g. zeroing the gradients)
         ready = None
+        fwd_done = [None] * len(lanes)
+        prev_bwd = None
         for k, v in enumerate(views):
-            img, _radii, meta = rasterize(v, cap)
-            metas.append(meta)
-            if k == len(views) - 1:
-                # every Meta record is final once its forward is enqueued: start the read-back NOW, in front of the last
-                # backward, so the host learns the verdict while the GPU is still busy
-                stacked = torch.stack(metas)
-                if self._host is None or self._host.shape != stacked.shape:
-                    self._host = torch.empty(stacked.shape, dtype=torch.uint8, pin_memory=True)
-                self._host.copy_(stacked, non_blocking=True)
-                ready = torch.cuda.Event()
-                ready.record()
-            img.backward(upstream(v, img.detach()))
+            st = lanes[k % len(lanes)]
+            with torch.cuda.stream(st):
+                img, _radii, meta = rasterize(v, cap)
+                metas.append(meta)
+                if len(lanes) > 1:
+                    fwd_done[k % len(lanes)] = torch.cuda.Event()
+                    fwd_done[k % len(lanes)].record(st)
+                if k == len(views) - 1:
+                    # every Meta record is final once its forward has run: start the read-back NOW, in front of the last
+                    # backward, so the host learns the verdict while the GPU is still busy
+                    for i, ev in enumerate(fwd_done):
+                        if ev is not None and lanes[i] is not st:
+                            st.wait_event(ev)
+                    for m in metas:
+                        m.record_stream(st)
+                    stacked = torch.stack(metas)
+                    if self._host is None or self._host.shape != stacked.shape:
+                        self._host = torch.empty(stacked.shape, dtype=torch.uint8, pin_memory=True)
+                    self._host.copy_(stacked, non_blocking=True)
+                    ready = torch.cuda.Event()
+                    ready.record(st)
+                grad = upstream(v, img.detach())
+                if prev_bwd is not None and len(lanes) > 1:
+                    st.wait_event(prev_bwd)                 # gradient accumulation is read-modify-write: one backward at a time
+                img.backward(grad)
+                if len(lanes) > 1:
+                    prev_bwd = torch.cuda.Event()
+                    prev_bwd.record(st)
+                    if st is not main:
+                        img.record_stream(main)
             images.append(img.detach())
+        if len(lanes) > 1:
+            main.wait_event(prev_bwd)                       # the last backward is behind every other kernel of the batch
         ready.synchronize()                                 # the one host wait of the batch
         host = self._host
         seen = 0
