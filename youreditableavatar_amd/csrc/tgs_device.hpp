@@ -30,7 +30,8 @@ struct Meta {                 // lives at the start of the image buffer
     uint32_t error;           // bit0: prefiltered Gaussian culled; bit1 (META_ERR_CAPACITY): frame rejected by tgs_forward_async
     uint32_t n_nonempty;      // tiles with at least one instance (they come first in tile_order)
     uint32_t n_heavy;         // tiles with >= 1024 instances (first in tile_order): sorted by 1024-thread workgroups
-    uint32_t pad[9];
+    uint32_t n_mid;           // tiles with >= 128 instances (heavy ones included); the rest are sorted one wave per tile
+    uint32_t pad[8];
 };
 
 constexpr uint32_t META_ERR_CAPACITY = 2u;
@@ -503,6 +504,38 @@ __device__ __forceinline__ void cmp_swap(KeyPtr keys, uint32_t i, uint32_t l, ui
         if (a > c) { keys[i] = c; keys[l] = a; }
     }
 }
+
+// Steps of the network that stay inside one aligned chunk of SORT_CHUNK = 128 keys are run by ONE wave (64 pairs per
+// step, one per lane) without workgroup barriers: LDS instructions of a wave execute in order, so the next step's
+// reads see this step's writes.
+constexpr uint32_t SORT_CHUNK = 128;
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+template <typename KeyPtr>
+__device__ __forceinline__ void wave_chunk_disperse(KeyPtr lk, uint32_t base, uint32_t n, uint32_t lane, uint32_t j0)
+{
+#pragma unroll 1
+    for (uint32_t j = j0; j > 0; j >>= 1) { uint32_t i, l; pair_disperse(lane, j, i, l); cmp_swap(lk, base + i, base + l, n); wave_sync(); }
+}
+// full network k = 2..kmax (kmax <= SORT_CHUNK) on keys [base, base + kmax)
+template <typename KeyPtr>
+__device__ __forceinline__ void wave_chunk_sort(KeyPtr lk, uint32_t base, uint32_t n, uint32_t lane, uint32_t kmax)
+{
+#pragma unroll 1
+    for (uint32_t k = 2; k <= kmax; k <<= 1) {
+        if (lane < (kmax >> 1)) { uint32_t i, l; pair_flip(lane, k, i, l); cmp_swap(lk, base + i, base + l, n); }
+        wave_sync();
+#pragma unroll 1
+        for (uint32_t j = k >> 2; j > 0; j >>= 1) {
+            if (lane < (kmax >> 1)) { uint32_t i, l; pair_disperse(lane, j, i, l); cmp_swap(lk, base + i, base + l, n); }
+            wave_sync();
+        }
+    }
+}
+
 
 
 // SH basis constants (cuda_rasterizer/auxiliary.h:22-39)

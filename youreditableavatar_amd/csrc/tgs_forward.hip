@@ -257,7 +257,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const 
             __syncthreads();
         }
         // tiles by descending list length (power-of-two buckets; order inside a bucket does not matter)
-        if (threadIdx.x == 0) { uint32_t acc = 0; for (int b2 = 33; b2-- > 0;) { const uint32_t h = hist[b2]; hist[b2] = acc; if (b2 == 1) s.meta->n_nonempty = acc + h; if (b2 == 11) s.meta->n_heavy = acc + h; acc += h; } }
+        if (threadIdx.x == 0) { uint32_t acc = 0; for (int b2 = 33; b2-- > 0;) { const uint32_t h = hist[b2]; hist[b2] = acc; if (b2 == 1) s.meta->n_nonempty = acc + h; if (b2 == 11) s.meta->n_heavy = acc + h; if (b2 == 8) s.meta->n_mid = acc + h; acc += h; } }
         __syncthreads();
         for (uint32_t sc = 0; sc < T; sc += SC) {
             const uint32_t n = min(SC, T - sc);
@@ -427,16 +427,19 @@ __device__ __forceinline__ void finalize_entry(unsigned long long key, uint32_t 
     b.slot[pos] = __float_as_uint(p2.w) + (ty - miny) * (maxx - minx) + (tx - minx);
 }
 
-// One workgroup per tile, visited in tile_order (longest lists first); lists of >= 1024 entries get 1024 threads.
+// Per-tile sort in LDS, tiles visited in tile_order (longest lists first).  Three classes by list length n:
+//   n >= 1024 : one 1024-thread workgroup per tile  } all steps that stay inside an aligned 128-key chunk are run by one
+//   n >= 128  : one 256-thread workgroup per tile   } wave without workgroup barriers (21 barriers instead of 78 at 4096 keys)
+//   n <  128  : one WAVE per tile, four tiles per workgroup, no barrier at all
+// The grids are upper bounds (exact after tgs_forward's read-back).
 template <int NT>
 __global__ __launch_bounds__(NT) void k_tile_sort(const ImgState s, const BinState b, uint32_t sort_cap)
 {
     extern __shared__ unsigned long long lk[];
-    // the grid is an upper bound (exact after tgs_forward's read-back): heavy tiles come first in tile_order
     if (frame_rejected(s)) return;
-    const uint32_t n_heavy = min(s.meta->n_heavy, s.meta->n_nonempty);
+    const uint32_t n_heavy = min(s.meta->n_heavy, s.meta->n_nonempty), n_mid = min(max(s.meta->n_mid, n_heavy), s.meta->n_nonempty);
     const uint32_t t = (NT == 1024 ? 0u : n_heavy) + blockIdx.x;
-    if (t >= (NT == 1024 ? n_heavy : s.meta->n_nonempty)) return;
+    if (t >= (NT == 1024 ? n_heavy : n_mid)) return;
     const uint4 td = s.tile_desc[t];
     const uint2 rg = make_uint2(td.y, td.z);
     const uint32_t n = rg.y - rg.x;
@@ -444,15 +447,39 @@ __global__ __launch_bounds__(NT) void k_tile_sort(const ImgState s, const BinSta
     for (uint32_t i = threadIdx.x; i < n; i += NT) lk[i] = b.keys[rg.x + i];
     __syncthreads();
     const uint32_t npad = next_pow2(n), half = npad >> 1;
-    for (uint32_t k = 2; k <= npad; k <<= 1) {
-        for (uint32_t t = threadIdx.x; t < half; t += NT) { uint32_t i, l; pair_flip(t, k, i, l); cmp_swap(lk, i, l, n); }
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr uint32_t W = NT / 64;
+    for (uint32_t c = wv * SORT_CHUNK; c < n; c += W * SORT_CHUNK) wave_chunk_sort(lk, c, n, lane, min(SORT_CHUNK, npad));
+    __syncthreads();
+    for (uint32_t k = 2 * SORT_CHUNK; k <= npad; k <<= 1) {
+        for (uint32_t p = threadIdx.x; p < half; p += NT) { uint32_t i, l; pair_flip(p, k, i, l); cmp_swap(lk, i, l, n); }
         __syncthreads();
-        for (uint32_t j = k >> 2; j > 0; j >>= 1) {
-            for (uint32_t t = threadIdx.x; t < half; t += NT) { uint32_t i, l; pair_disperse(t, j, i, l); cmp_swap(lk, i, l, n); }
+        for (uint32_t j = k >> 2; j >= SORT_CHUNK; j >>= 1) {
+            for (uint32_t p = threadIdx.x; p < half; p += NT) { uint32_t i, l; pair_disperse(p, j, i, l); cmp_swap(lk, i, l, n); }
             __syncthreads();
         }
+        for (uint32_t c = wv * SORT_CHUNK; c < n; c += W * SORT_CHUNK) wave_chunk_disperse(lk, c, n, lane, SORT_CHUNK >> 1);
+        __syncthreads();
     }
     for (uint32_t i = threadIdx.x; i < n; i += NT) b.keys[rg.x + i] = lk[i];
+}
+
+__global__ __launch_bounds__(256) void k_tile_sort_small(const ImgState s, const BinState b, uint32_t sort_cap)
+{
+    __shared__ unsigned long long lk4[4][SORT_CHUNK];
+    if (frame_rejected(s)) return;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t n_heavy = min(s.meta->n_heavy, s.meta->n_nonempty), n_mid = min(max(s.meta->n_mid, n_heavy), s.meta->n_nonempty);
+    const uint32_t t = n_mid + blockIdx.x * 4 + wv;
+    if (t >= s.meta->n_nonempty) return;                    // wave-uniform: no workgroup barrier below
+    const uint4 td = s.tile_desc[t];
+    const uint32_t n = td.z - td.y;
+    if (n < 2 || n > sort_cap || n > SORT_CHUNK) return;    // (n < 128 by the class boundary in k_scan)
+    unsigned long long* lk = lk4[wv];
+    for (uint32_t i = lane; i < n; i += 64) lk[i] = b.keys[td.y + i];
+    wave_sync();
+    wave_chunk_sort(lk, 0u, n, lane, next_pow2(n));
+    for (uint32_t i = lane; i < n; i += 64) b.keys[td.y + i] = lk[i];
 }
 
 // One thread per sorted instance, evenly over all R of them: finds its tile by binary search in the (monotone)
@@ -738,13 +765,17 @@ void launch_tile_sort(hipStream_t st, const GeomState& g, const ImgState& s, con
     const size_t lds = (size_t)(cap ? cap : 1) * 8;
     const uint32_t nonempty = m ? m->n_nonempty : (uint32_t)(r_bound < T ? r_bound : T);
     uint32_t heavy = m ? m->n_heavy : (uint32_t)(r_bound / 1024 < T ? r_bound / 1024 : T);
+    uint32_t mid = m ? m->n_mid : (uint32_t)(r_bound / 128 < T ? r_bound / 128 : T);     // tiles with >= 128 instances, heavy ones included
     if (heavy > nonempty) heavy = nonempty;
-    const uint32_t light = m ? nonempty - heavy : nonempty;
+    if (mid < heavy) mid = heavy;
+    if (mid > nonempty) mid = nonempty;
+    const uint32_t small = m ? nonempty - mid : nonempty;
     if (heavy > 0) hipLaunchKernelGGL((k_tile_sort<1024>), dim3(heavy), dim3(1024), lds, st, s, b, sort_cap);
-    if (light > 0) {
+    if (mid > (m ? heavy : 0u)) {
         const uint32_t cap2 = cap < 1024u ? cap : 1024u;    // these lists are shorter than 1024
-        hipLaunchKernelGGL((k_tile_sort<256>), dim3(light), dim3(256), (size_t)(cap2 ? cap2 : 1) * 8, st, s, b, sort_cap);
+        hipLaunchKernelGGL((k_tile_sort<256>), dim3(m ? mid - heavy : mid), dim3(256), (size_t)(cap2 ? cap2 : 1) * 8, st, s, b, sort_cap);
     }
+    if (small > 0) hipLaunchKernelGGL(k_tile_sort_small, dim3((small + 3) / 4), dim3(256), 0, st, s, b, sort_cap);
     if (m && m->n_overflow > 0) {
         // lists longer than sort_cap: sorted in global memory by many workgroups, LDS for strides < sort_cap
         const uint32_t npad = host_next_pow2(max_count);

@@ -181,12 +181,14 @@ class SyncFreeBatch:
         lanes = [main]
         if self.streams > 1 and cap is not None and len(views) > 1:
             key = main.device
-            if key not in self._side:
-                self._side[key] = torch.cuda.Stream(device=key)
-            lanes.append(self._side[key])
+            side = self._side.setdefault(key, [])
+            while len(side) < min(self.streams, len(views)) - 1:
+                side.append(torch.cuda.Stream(device=key))
+            lanes += side[:min(self.streams, len(views)) - 1]
             start = torch.cuda.Event()
             start.record(main)
-            lanes[1].wait_event(start)                      # whatever the caller enqueued before (e.g. zeroing the gradients)
+            for st in lanes[1:]:
+                st.wait_event(start)                        # whatever the caller enqueued before (e.g. zeroing the gradients)
         ready = None
         fwd_done = [None] * len(lanes)
         prev_bwd = None
