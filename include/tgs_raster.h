@@ -167,6 +167,15 @@ int tgs_sh_rgb_backward(void* stream, int P, int M, int levels, const float* sh,
 size_t tgs_dist2_workspace_bytes(int P);
 int tgs_dist2(void* stream, int P, const float* points, float* mean_dist2, void* workspace, size_t workspace_bytes);
 
+/* ---- "next" row 2: the trainers' photometric loss ----
+ * loss = (1 - dssim_factor) * l1_loss(img, gt) + dssim_factor * (1 - ssim(img, gt)), window 11, sigma 1.5, zero padding
+ * (Edit_core/utils/loss_utils.py:17-18 and :39-63, composed as in tetgs_texture/refine.py:245-247), over
+ * `planes` = batch x channels image planes of height x width.  out3[0] = loss, out3[1] = ssim, out3[2] = l1 (device
+ * floats); dL_dimg (may be NULL) receives d loss / d img.  dssim_factor 1 / 0 give 1 - ssim / l1 and their gradients. */
+size_t tgs_l1_ssim_workspace_bytes(int planes, int height, int width);
+int tgs_l1_ssim(void* stream, int planes, int height, int width, const float* img, const float* gt, float dssim_factor,
+                float* out3, float* dL_dimg, void* workspace, size_t workspace_bytes);
+
 /* Test knob (process-wide): longest tile list that is depth-sorted inside LDS; longer lists take the
  * multi-workgroup global-memory path.  Power of two in [2, 8192]; default 8192. */
 int tgs_set_sort_lds_cap(unsigned cap);

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libtgs_raster.so")
-SOURCES = ["tgs_forward.hip", "tgs_backward.hip", "tgs_api.hip", "tgs_shcolor.hip", "tgs_knn.hip"]
+SOURCES = ["tgs_forward.hip", "tgs_backward.hip", "tgs_api.hip", "tgs_shcolor.hip", "tgs_knn.hip", "tgs_loss.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 # experiment knobs, e.g. TGS_DEFINES="-DTGS_FAST_MATH=0" python -m youreditableavatar_amd.build --force
@@ -56,7 +56,7 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
             print(r.stderr, file=sys.stderr)
         return obj
 
-    with ThreadPoolExecutor(max_workers=5) as ex:
+    with ThreadPoolExecutor(max_workers=6) as ex:
         objs = list(ex.map(compile_one, SOURCES))
     cmd = [cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -1,0 +1,194 @@
+// tgs_loss.hip -- the trainers' photometric loss, value and gradient, in two passes over the image ("next" row 2).
+//
+//   loss = (1 - f) * mean|pred - gt| + f * (1 - mean(ssim_map(pred, gt)))          f = dssim_factor
+// (Edit_core/utils/loss_utils.py:17-18, :39-63 composed as in tetgs_texture/refine.py:245-247).  The reference builds
+// the SSIM statistics with five zero-padded depthwise 11x11 convolutions plus ~15 element-wise kernels and lets
+// autograd run them backwards; here
+//   k_ssim_stats : one 32x16 tile of one image plane per workgroup; pred and gt tiles (+5 halo, zeros outside) in LDS,
+//                  separable 11-tap Gaussian of (x, y, x^2, y^2, xy) -> ssim_map, its three partial derivatives with
+//                  respect to the windowed statistics, and the workgroup's partial sums of ssim_map and |x - y|;
+//   k_loss_reduce: fixed-order sum of the partials -> loss, ssim, l1 (no float atomics: reproducible);
+//   k_ssim_grad  : the adjoint of the same separable window applied to the three derivative maps
+//                  d loss / d x(p) = gl * sign(x - y) + gs * (conv(dM1)(p) + 2 x(p) conv(dX2)(p) + y(p) conv(dXY)(p)).
+// Both image passes are bound by HBM: 2 planes read + 3 written, then 5 read + 1 written (4 B each).
+#include "tgs_device.hpp"
+#include <cmath>
+
+namespace tgs {
+
+constexpr int LW = 32, LH = 16, LR = 5;                 // tile width / height, window radius
+constexpr int LTW = LW + 2 * LR, LTH = LH + 2 * LR;     // 42 x 26 with halo
+
+struct LossWin { float w[2 * LR + 1]; };
+
+// global [planes, H, W] plane -> LDS tile with halo, zeros outside the image (conv2d padding, loss_utils.py:46)
+__device__ __forceinline__ void load_tile(float (*dst)[LTW + 1], const float* __restrict__ src, int H, int W, int x0, int y0)
+{
+    for (int i = threadIdx.x; i < LTW * LTH; i += 256) {
+        const int r = i / LTW, c = i % LTW, gx = x0 + c - LR, gy = y0 + r - LR;
+        dst[r][c] = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? src[(size_t)gy * W + gx] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ssim_stats(int H, int W, const float* __restrict__ img, const float* __restrict__ gt, LossWin win,
+                                                   float* __restrict__ dM1, float* __restrict__ dX2, float* __restrict__ dXY, float2* __restrict__ partial)
+{
+    __shared__ float sx[LTH][LTW + 1], sy[LTH][LTW + 1];
+    __shared__ float h[5][LTH][LW + 1];
+    __shared__ float2 red[4];
+    const int x0 = blockIdx.x * LW, y0 = blockIdx.y * LH;
+    const size_t plane = (size_t)blockIdx.z * H * W;
+    load_tile(sx, img + plane, H, W, x0, y0);
+    load_tile(sy, gt + plane, H, W, x0, y0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < LTH * LW; i += 256) {     // horizontal pass
+        const int r = i / LW, c = i % LW;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+#pragma unroll
+        for (int k = 0; k <= 2 * LR; k++) {
+            const float x = sx[r][c + k], y = sy[r][c + k], wx = win.w[k] * x, wy = win.w[k] * y;
+            a0 += wx; a1 += wy; a2 += wx * x; a3 += wy * y; a4 += wx * y;
+        }
+        h[0][r][c] = a0; h[1][r][c] = a1; h[2][r][c] = a2; h[3][r][c] = a3; h[4][r][c] = a4;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    float s_map = 0.f, s_l1 = 0.f;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        const int o = ty + 8 * half, gx = x0 + tx, gy = y0 + o;
+        float m1 = 0.f, m2 = 0.f, X2 = 0.f, Y2 = 0.f, XY = 0.f;
+#pragma unroll
+        for (int k = 0; k <= 2 * LR; k++) {
+            const float w = win.w[k];
+            m1 += w * h[0][o + k][tx]; m2 += w * h[1][o + k][tx]; X2 += w * h[2][o + k][tx]; Y2 += w * h[3][o + k][tx]; XY += w * h[4][o + k][tx];
+        }
+        if (gx < W && gy < H) {
+            // loss_utils.py:49-58
+            const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+            const float m11 = m1 * m1, m22 = m2 * m2, m12 = m1 * m2;
+            const float s1 = X2 - m11, s2 = Y2 - m22, s12 = XY - m12;
+            const float N1 = 2.f * m12 + C1, N2 = 2.f * s12 + C2, D1 = m11 + m22 + C1, D2 = s1 + s2 + C2;
+            const float iD1 = 1.f / D1, iD2 = 1.f / D2, q = iD1 * iD2;
+            const float map = N1 * N2 * q;
+            // map as a function of the windowed statistics (m1, X2, XY); sigma1_sq = X2 - m1^2, sigma12 = XY - m1 m2
+            const size_t at = plane + (size_t)gy * W + gx;
+            dM1[at] = 2.f * q * (m2 * (N2 - N1) - m1 * map * (D2 - D1));
+            dX2[at] = -map * iD2;
+            dXY[at] = 2.f * N1 * q;
+            s_map += map;
+            s_l1 += fabsf(sx[o + LR][tx + LR] - sy[o + LR][tx + LR]);
+        }
+    }
+    s_map = wave_sum(s_map); s_l1 = wave_sum(s_l1);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = make_float2(s_map, s_l1);
+    __syncthreads();
+    if (threadIdx.x == 0)
+        partial[(size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] =
+            make_float2((red[0].x + red[1].x) + (red[2].x + red[3].x), (red[0].y + red[1].y) + (red[2].y + red[3].y));
+}
+
+// out[0] = loss, out[1] = ssim, out[2] = l1; sums in double, fixed order
+__global__ __launch_bounds__(1024) void k_loss_reduce(int n, const float2* __restrict__ partial, double inv_count, float f, float* __restrict__ out)
+{
+    __shared__ double rm[16], rl[16];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < n; i += 1024) { const float2 p = partial[i]; a += (double)p.x; b += (double)p.y; }
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+    if ((threadIdx.x & 63) == 0) { rm[threadIdx.x >> 6] = a; rl[threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double sm = 0.0, sl = 0.0;
+        for (int i = 0; i < 16; i++) { sm += rm[i]; sl += rl[i]; }
+        const double ssim = sm * inv_count, l1 = sl * inv_count;
+        out[0] = (float)((1.0 - (double)f) * l1 + (double)f * (1.0 - ssim));
+        out[1] = (float)ssim;
+        out[2] = (float)l1;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ssim_grad(int H, int W, const float* __restrict__ img, const float* __restrict__ gt, LossWin win,
+                                                  const float* __restrict__ dM1, const float* __restrict__ dX2, const float* __restrict__ dXY,
+                                                  float gs, float gl, float* __restrict__ grad)
+{
+    __shared__ float t[3][LTH][LTW + 1];
+    __shared__ float h[3][LTH][LW + 1];
+    const int x0 = blockIdx.x * LW, y0 = blockIdx.y * LH;
+    const size_t plane = (size_t)blockIdx.z * H * W;
+    load_tile(t[0], dM1 + plane, H, W, x0, y0);
+    load_tile(t[1], dX2 + plane, H, W, x0, y0);
+    load_tile(t[2], dXY + plane, H, W, x0, y0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < LTH * LW; i += 256) {
+        const int r = i / LW, c = i % LW;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int k = 0; k <= 2 * LR; k++) { const float w = win.w[k]; a0 += w * t[0][r][c + k]; a1 += w * t[1][r][c + k]; a2 += w * t[2][r][c + k]; }
+        h[0][r][c] = a0; h[1][r][c] = a1; h[2][r][c] = a2;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        const int o = ty + 8 * half, gx = x0 + tx, gy = y0 + o;
+        if (gx >= W || gy >= H) continue;
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int k = 0; k <= 2 * LR; k++) { const float w = win.w[k]; c0 += w * h[0][o + k][tx]; c1 += w * h[1][o + k][tx]; c2 += w * h[2][o + k][tx]; }
+        const size_t at = plane + (size_t)gy * W + gx;
+        const float x = img[at], y = gt[at], d = x - y;
+        const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);         // torch's abs backward: 0 at 0
+        grad[at] = gl * sgn + gs * (c0 + 2.f * x * c1 + y * c2);
+    }
+}
+
+static LossWin make_window()
+{
+    // loss_utils.py:23-25: exp in double, stored fp32, normalised in fp32
+    LossWin w;
+    float sum = 0.f;
+    for (int i = 0; i <= 2 * LR; i++) { w.w[i] = (float)std::exp(-(double)((i - LR) * (i - LR)) / (2.0 * 1.5 * 1.5)); sum += w.w[i]; }
+    for (int i = 0; i <= 2 * LR; i++) w.w[i] /= sum;
+    return w;
+}
+
+}  // namespace tgs
+
+extern "C" {
+#include "../../include/tgs_raster.h"
+
+size_t tgs_l1_ssim_workspace_bytes(int planes, int height, int width)
+{
+    if (planes <= 0 || height <= 0 || width <= 0) return 0;
+    const size_t n = (size_t)planes * height * width;
+    const size_t blocks = (size_t)planes * ((height + tgs::LH - 1) / tgs::LH) * ((width + tgs::LW - 1) / tgs::LW);
+    return 3 * n * sizeof(float) + blocks * sizeof(float2) + 1024;
+}
+
+int tgs_l1_ssim(void* stream, int planes, int height, int width, const float* img, const float* gt, float dssim_factor, float* out3,
+                float* dL_dimg, void* workspace, size_t workspace_bytes)
+{
+    using namespace tgs;
+    hipStream_t st = (hipStream_t)stream;
+    if (planes <= 0 || height <= 0 || width <= 0 || !img || !gt || !out3 || !workspace)
+        return set_error(TGS_ERR_INVALID, "tgs_l1_ssim: positive sizes and non-NULL img / gt / out3 / workspace required");
+    if (workspace_bytes < tgs_l1_ssim_workspace_bytes(planes, height, width))
+        return set_error(TGS_ERR_INVALID, "tgs_l1_ssim: workspace smaller than tgs_l1_ssim_workspace_bytes()");
+    const size_t n = (size_t)planes * height * width;
+    const dim3 grid((width + LW - 1) / LW, (height + LH - 1) / LH, planes);
+    if (grid.y > 65535u || grid.z > 65535u) return set_error(TGS_ERR_INVALID, "tgs_l1_ssim: image too large");
+    float* dM1 = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    float* dX2 = dM1 + n;
+    float* dXY = dX2 + n;
+    float2* partial = (float2*)(dXY + n);
+    const LossWin win = make_window();
+    const int nblk = (int)(grid.x * grid.y * grid.z);
+    hipLaunchKernelGGL(k_ssim_stats, grid, dim3(256), 0, st, height, width, img, gt, win, dM1, dX2, dXY, partial);
+    hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(1024), 0, st, nblk, partial, 1.0 / (double)n, dssim_factor, out3);
+    if (dL_dimg) {
+        const float gs = (float)(-(double)dssim_factor / (double)n), gl = (float)((1.0 - (double)dssim_factor) / (double)n);
+        hipLaunchKernelGGL(k_ssim_grad, grid, dim3(256), 0, st, height, width, img, gt, win, dM1, dX2, dXY, gs, gl, dL_dimg);
+    }
+    return hip_status("tgs_l1_ssim");
+}
+}
