@@ -206,9 +206,16 @@ def main():
         roof = None
         if dom:
             t_dom = dom_timed if dom_timed else kern[dom]
+            traffic = None      # HBM bytes per launch from the PMC passes committed under profiles/ (same workload, collected offline)
+            try:
+                pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_d_hbm_counters.json")))
+                if a.config in (3, 4) and a.mode == "sh":
+                    traffic = next(v["hbm_bytes_est"] for k, v in pmc["kernels"].items() if k.startswith("tgs::k_" + dom))
+            except (OSError, StopIteration, KeyError, ValueError):
+                traffic = None
             ach = alg[dom] / (t_dom * 1e-3) / 1e9
             roof = {"kernel": "k_" + dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "avg_launch_ms": round(t_dom, 4),
+                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "avg_launch_ms": round(t_dom, 4),
                     "avg_launch_ms_alone": round(kern[dom], 4), "algorithmic_bytes_per_launch": int(alg[dom])}
         k_P = (430 + 3 * Cin) if a.mode == "sh" else 412
         B_alg = k_P * P + 124 * Rm + 40 * Npix
