@@ -158,7 +158,7 @@ def main():
         batch.streams = a.streams
     prof_all = _C.profile_end()
     kern = {k: (ms / max(n, 1)) for k, (ms, n) in prof_all.items() if n > 0}
-    dom = max(kern, key=kern.get) if kern else None
+    dom = max(kern, key=lambda k: prof_all[k][0]) if kern else None          # most time per step (a batched kernel runs once per step)
     if dist is not None:
         dist.barrier()
     _C.profile_begin(a.steps * VPG + 64, stages=[dom] if dom else [])
@@ -203,6 +203,8 @@ def main():
             "render_bwd": 44 * Rm + 20 * Npix + 36 * Rm,
             "preprocess_bwd": (36 * Rm) + ((107 + Cin) + (40 + Cin) + 56 + 36) * P if a.mode == "sh" else (36 * Rm) + (92 + 40 + 56 + 36) * P,
         }
+        if batch is not None and batch.deferred:   # one launch for the VPG views of the step: shared rows once, per-view state VPG times
+            alg["preprocess_bwd"] = VPG * (36 * Rm + (24 + 1 + 4 + 4 + 4 + 12) * P) + (40 + Cin + 2 * (44 + Cin)) * P
         roof = None
         if dom:
             t_dom = dom_timed if dom_timed else kern[dom]
@@ -229,6 +231,7 @@ def main():
                        "instances_per_frame": int(Rm), "ms_per_frame_per_gpu": round(ms_per_step / VPG, 4),
                        "host_sync": "one per step (SyncFreeBatch)" if batch is not None else "one per frame (reference protocol)",
                        "streams": batch.streams if batch is not None else 1,
+                       "per_gaussian_backward": "one pass per step (tgs_backward_batch)" if (batch is not None and batch.deferred) else "one pass per view",
                        "frames_rerendered": batch.rejected if batch is not None else 0,
                        "parallelism": f"view-sharded dp{N}" + (", one RCCL all-reduce of the flat gradient buffer per step" if N > 1 else "")},
             "roofline": roof,

@@ -167,6 +167,32 @@ int tgs_sh_rgb_backward(void* stream, int P, int M, int levels, const float* sh,
 size_t tgs_dist2_workspace_bytes(int P);
 int tgs_dist2(void* stream, int P, const float* points, float* mean_dist2, void* workspace, size_t workspace_bytes);
 
+/* ---- Batched backward (multi-view steps) ----
+ * Rasterizer::backward runs its per-Gaussian half (computeCov2DCUDA + preprocessCUDA of backward.cu) once per view; with
+ * in-place accumulation that is 192 B of SH read plus 192 B of dL_dsh read AND written per Gaussian per view.  A batch
+ * splits the backward: tgs_backward_render does the per-pixel half of one view (tile partials stay in that view's
+ * binning buffer), and ONE tgs_backward_batch call then does the per-Gaussian half for all views, reading the
+ * view-independent inputs once and storing (accumulate = 0) or adding (accumulate = 1) the summed parameter gradients
+ * once.  Per-view outputs: dL_dmean2D[P,3] and, on the colors_precomp path (shs == NULL), dL_dcolor[P,3].
+ * A view rejected by tgs_forward_async contributes nothing (its dL_dmean2D is zero). */
+typedef struct {
+    int width, height;
+    float tan_fovx, tan_fovy;
+    const float *viewmatrix, *projmatrix, *campos;
+    const int* radii;
+    const void *geom_buffer, *binning_buffer, *img_buffer;
+    int64_t R;                 /* what tgs_forward / tgs_forward_async returned for this view */
+    float* dL_dmean2D;
+    float* dL_dcolor;          /* NULL on the SH path */
+} tgs_view_t;
+int tgs_backward_render(void* stream, int P, int64_t R, const float* background, int width, int height,
+                        const void* binning_buffer, const void* img_buffer, const float* dL_dpix);
+int tgs_backward_batch(void* stream, int P, int D, int M, int n_views, const tgs_view_t* views,
+                       const float* means3D, const float* shs, const float* scales, float scale_modifier,
+                       const float* rotations, const float* cov3D_precomp,
+                       float* dL_dopacity, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                       float* dL_dscale, float* dL_drot, int accumulate);
+
 /* ---- "next" row 2: the trainers' photometric loss ----
  * loss = (1 - dssim_factor) * l1_loss(img, gt) + dssim_factor * (1 - ssim(img, gt)), window 11, sigma 1.5, zero padding
  * (Edit_core/utils/loss_utils.py:17-18 and :39-63, composed as in tetgs_texture/refine.py:245-247), over

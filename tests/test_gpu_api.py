@@ -275,8 +275,9 @@ def test_sync_free_forward_matches_and_rejects(gpu_device):
         _C.set_deterministic(False)
 
 
+@pytest.mark.parametrize("deferred", [False, True])
 @pytest.mark.parametrize("streams", [1, 2])
-def test_sync_free_batch_rerenders_rejected_views(streams, gpu_device):
+def test_sync_free_batch_rerenders_rejected_views(streams, deferred, gpu_device):
     """multiview.SyncFreeBatch: one read-back per batch; views that outgrow the bound are rendered again, and the
     accumulated gradients equal the per-frame-synchronised ones."""
     from diff_gaussian_rasterization import _C
@@ -303,13 +304,15 @@ def test_sync_free_batch_rerenders_rejected_views(streams, gpu_device):
         for v in range(4):
             rasterize(v, None)[0].backward(dL)
         want, imgs_want = flat.flat.clone(), [rasterize(v, None)[0].detach().clone() for v in range(4)]
-        batch = SyncFreeBatch(headroom=1.25, granule=256, streams=streams)
+        batch = SyncFreeBatch(headroom=1.25, granule=256, streams=streams, deferred=deferred)
         flat.zero_(); caps.clear()
         imgs = batch.run(range(4), rasterize, lambda v, img: dL)                  # first batch: no bound yet -> synchronous frames
         assert caps == [None] * 4 and batch.bound is not None and torch.equal(flat.flat, want)
         flat.zero_(); caps.clear()
         imgs = batch.run(range(4), rasterize, lambda v, img: dL)                  # now sync-free
-        assert caps == [batch.capacity()] * 4 and batch.rejected == 0 and torch.equal(flat.flat, want)
+        # the batched per-Gaussian pass sums the views in registers before it touches the gradient buffers
+        assert caps == [batch.capacity()] * 4 and batch.rejected == 0
+        assert torch.equal(flat.flat, want) if not deferred else util.rel_l2(flat.flat.cpu().numpy(), want.cpu().numpy()) <= 1e-6
         assert all(torch.equal(a, b) for a, b in zip(imgs, imgs_want))
         batch.bound = batch.bound // 3                                            # a bound some views no longer fit
         small = batch.capacity()
@@ -377,3 +380,52 @@ def test_fused_sh_color_feeds_the_rasterizer(gpu_device):
     assert util.rel_l2(img.detach().cpu().numpy(), ref["color"]) <= 1e-4
     assert util.rel_l2(L["shs"].grad.cpu().numpy(), ref["dL_dsh"]) <= 1e-4
     assert util.rel_l2(L["means3D"].grad.cpu().numpy(), ref["dL_dmeans3D"]) <= 2e-4
+
+
+def test_batched_backward_equals_per_view_backward(gpu_device):
+    """tgs_backward_render + tgs_backward_batch (one per-Gaussian pass for all views) == tgs_backward per view, summed;
+    per-view dL_dmeans2D identical; more views than one launch holds (BATCH_VIEWS = 8)."""
+    from diff_gaussian_rasterization import _C
+    from youreditableavatar_amd import scenes
+    P = 5000
+    cloud = scenes.make_cloud(P, 3, seed=47, scale_mult=3.0)
+    cams = [scenes.orbit_camera(176, 112, azimuth_deg=a) for a in np.linspace(0, 330, 11)]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(gpu_device)
+    e = torch.Tensor([])
+    means, opac, scales, rots, shs = t(cloud["means3D"]), t(cloud["opacities"]), t(cloud["scales"]), t(cloud["rotations"]), t(cloud["shs"])
+    dL = t(scenes.upstream_gradient(176, 112))
+    _C.set_deterministic(True)
+    try:
+        want = dict(means3D=torch.zeros(P, 3, device=gpu_device), opacities=torch.zeros(P, 1, device=gpu_device), sh=torch.zeros(P, 16, 3, device=gpu_device),
+                    scales=torch.zeros(P, 3, device=gpu_device), rotations=torch.zeros(P, 4, device=gpu_device))
+        views, want2d = [], []
+        for cam in cams:
+            bg, vm, pm, cp = t(cam.bg), t(cam.viewmatrix), t(cam.projmatrix), t(cam.campos)
+            R, color, radii, geom, binning, img = _C.rasterize_gaussians(bg, means, e, opac, scales, rots, 1.0, e, vm, pm, cam.tanfovx, cam.tanfovy, 112, 176, shs,
+                                                                       3, cp, False, False)
+            g = _C.rasterize_gaussians_backward(bg, means, radii, e, scales, rots, 1.0, e, vm, pm, cam.tanfovx, cam.tanfovy, dL, shs, 3, cp, geom, R, binning,
+                                                img, False)
+            d2d, _dcol, dop, dm3, _dcov, dsh, dsc, drot = g
+            want2d.append(d2d)
+            for k, v in (("means3D", dm3), ("opacities", dop), ("sh", dsh), ("scales", dsc), ("rotations", drot)):
+                want[k] += v
+            # fresh state for the split path (the one-view backward above consumed nothing, but keep the two paths apart)
+            R, color, radii, geom, binning, img = _C.rasterize_gaussians(bg, means, e, opac, scales, rots, 1.0, e, vm, pm, cam.tanfovx, cam.tanfovy, 112, 176, shs,
+                                                                       3, cp, False, False)
+            _C.rasterize_gaussians_backward_render(bg, dL, R, binning, img, P)
+            views.append(dict(viewmatrix=vm, projmatrix=pm, campos=cp, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, image_height=112, image_width=176, radii=radii,
+                              geom=geom, binning=binning, img=img, R=R))
+        got = {k: torch.full_like(v, 3.0) for k, v in want.items()}      # accumulate=False must overwrite
+        outs = _C.rasterize_gaussians_backward_batch(views, means, shs, 3, scales, rots, 1.0, e, got, accumulate=False)
+        for (g2d, _), w in zip(outs, want2d):
+            assert torch.equal(g2d, w)
+        for k in want:     # same terms, other association: views 0-7 are summed in registers, 8-10 added as a second partial sum
+            assert util.rel_l2(got[k].cpu().numpy(), want[k].cpu().numpy()) <= 1e-5, k
+        again = {k: v.clone() for k, v in got.items()}
+        _C.rasterize_gaussians_backward_batch(views[:3], means, shs, 3, scales, rots, 1.0, e, again, accumulate=True)
+        three = {k: torch.zeros_like(v) for k, v in got.items()}
+        _C.rasterize_gaussians_backward_batch(views[:3], means, shs, 3, scales, rots, 1.0, e, three, accumulate=False)
+        for k in want:
+            assert util.rel_l2(again[k].cpu().numpy(), (got[k] + three[k]).cpu().numpy()) <= 1e-6, k
+    finally:
+        _C.set_deterministic(False)

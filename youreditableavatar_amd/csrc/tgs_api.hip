@@ -20,6 +20,7 @@ void launch_mark_visible(hipStream_t, int P, const float* means3D, const float* 
 void launch_render_bwd(hipStream_t, const ImgState&, const BinState&, int W, int H, uint32_t gx, uint32_t T, const float* bg, const float* dL_dpix,
                        bool deterministic);
 void launch_preprocess_bwd(hipStream_t, const BwdIn&, const CamParams&, const GeomState&, const BinState&);
+void launch_preprocess_bwd_batch(hipStream_t, const BwdIn&, const BatchViews&);
 void launch_selftest_reduce36(hipStream_t, const float* in, float* out);
 }  // namespace tgs
 
@@ -378,6 +379,71 @@ int tgs_backward_accumulate(void* stream, int P, int D, int M, int64_t R, const 
     return backward_impl(1, stream, P, D, M, R, background, width, height, means3D, shs, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp,
                          viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer, img_buffer, dL_dpix, dL_dmean2D,
                          dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug);
+}
+
+int tgs_backward_render(void* stream, int P, int64_t R, const float* background, int width, int height, const void* binning_buffer,
+                        const void* img_buffer, const float* dL_dpix)
+{
+    hipStream_t st = (hipStream_t)stream;
+    g_err[0] = 0;
+    const int debug = 0;
+    if (P == 0) return TGS_OK;
+    if (P < 0 || R < 0 || width <= 0 || height <= 0) return fail(TGS_ERR_INVALID, "bad sizes");
+    if (!background || !binning_buffer || !img_buffer || !dL_dpix) return fail(TGS_ERR_INVALID, "NULL required pointer");
+    const uint32_t gx = (uint32_t)((width + TILE - 1) / TILE), gy = (uint32_t)((height + TILE - 1) / TILE);
+    ImgState s; BinState b;
+    img_carve(s, (char*)img_buffer, (size_t)width * height, (size_t)gx * gy);
+    bin_carve(b, (char*)binning_buffer, (size_t)R);
+    if (R > 0) {
+        STAGE_BEGIN(TGS_STAGE_RENDER_BWD);
+        launch_render_bwd(st, s, b, width, height, gx, gx * gy, background, dL_dpix, deterministic_mode());
+        STAGE_CHECK("render_bwd", TGS_STAGE_RENDER_BWD);
+    }
+    return TGS_OK;
+}
+
+int tgs_backward_batch(void* stream, int P, int D, int M, int n_views, const tgs_view_t* views, const float* means3D, const float* shs,
+                       const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp, float* dL_dopacity,
+                       float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int accumulate)
+{
+    hipStream_t st = (hipStream_t)stream;
+    g_err[0] = 0;
+    const int debug = 0;
+    if (P == 0 || n_views == 0) return TGS_OK;
+    if (P < 0 || n_views < 0 || !views) return fail(TGS_ERR_INVALID, "bad sizes");
+    const bool has_sh = shs != nullptr, has_sr = scales != nullptr && rotations != nullptr;
+    if (has_sr == (cov3D_precomp != nullptr)) return fail(TGS_ERR_INVALID, "provide exactly one of (scales, rotations) / cov3D_precomp");
+    if (has_sh && (D < 0 || D > 3 || M < (D + 1) * (D + 1))) return fail(TGS_ERR_INVALID, "SH degree %d needs M >= %d (M=%d)", D, (D + 1) * (D + 1), M);
+    if (!means3D || !dL_dopacity || !dL_dmean3D || (has_sh && !dL_dsh) || (has_sr && (!dL_dscale || !dL_drot)) || (!has_sr && !dL_dcov3D))
+        return fail(TGS_ERR_INVALID, "NULL required pointer");
+    BwdIn in;
+    memset(&in, 0, sizeof(in));
+    in.P = P; in.D = D; in.M = M; in.means3D = means3D; in.shs = shs; in.scales = scales; in.rotations = rotations; in.cov3D_precomp = cov3D_precomp;
+    in.dL_dopacity = dL_dopacity; in.dL_dmean3D = dL_dmean3D; in.dL_dcov3D = has_sr ? nullptr : dL_dcov3D; in.dL_dsh = dL_dsh;
+    in.dL_dscale = has_sr ? dL_dscale : nullptr; in.dL_drot = has_sr ? dL_drot : nullptr;
+    for (int v0 = 0; v0 < n_views; v0 += BATCH_VIEWS) {
+        BatchViews bv;
+        memset(&bv, 0, sizeof(bv));
+        bv.n = n_views - v0 < BATCH_VIEWS ? n_views - v0 : BATCH_VIEWS;
+        for (int k = 0; k < bv.n; k++) {
+            const tgs_view_t& w = views[v0 + k];
+            if (w.width <= 0 || w.height <= 0 || w.R < 0 || !w.viewmatrix || !w.projmatrix || !w.campos || !w.radii || !w.geom_buffer ||
+                !w.binning_buffer || !w.img_buffer || !w.dL_dmean2D || (!has_sh && !w.dL_dcolor))
+                return fail(TGS_ERR_INVALID, "view %d: bad sizes or NULL required pointer", v0 + k);
+            BatchView& o = bv.v[k];
+            o.cam = make_cam(w.viewmatrix, w.projmatrix, w.campos, w.tan_fovx, w.tan_fovy, scale_modifier, w.width, w.height);
+            ImgState s;
+            geom_carve(o.g, (char*)w.geom_buffer, (size_t)P, has_sh, has_sr);
+            img_carve(s, (char*)w.img_buffer, (size_t)w.width * w.height, (size_t)o.cam.gx * o.cam.gy);
+            bin_carve(o.b, (char*)w.binning_buffer, (size_t)w.R);
+            o.meta = s.meta; o.radii = w.radii; o.dL_dmean2D = w.dL_dmean2D; o.dL_dcolor = has_sh ? nullptr : w.dL_dcolor;
+        }
+        in.accumulate = (accumulate || v0 > 0) ? 1 : 0;       // later chunks add to what the first one stored
+        STAGE_BEGIN(TGS_STAGE_PREPROCESS_BWD);
+        launch_preprocess_bwd_batch(st, in, bv);
+        STAGE_CHECK("preprocess_bwd_batch", TGS_STAGE_PREPROCESS_BWD);
+    }
+    return TGS_OK;
 }
 
 int tgs_mark_visible(void* stream, int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present)

@@ -350,8 +350,274 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_preprocess_bwd
+// Per-Gaussian half of the backward for ONE view (computeCov2DCUDA backward.cu:144-274, preprocessCUDA :346-396,
+// computeCov3D :278-341, computeColorFromSH :20-139), shared by k_preprocess_bwd (one view per launch) and
+// k_preprocess_bwd_batch (all views of a batch per launch).
 // ---------------------------------------------------------------------------------------------
+struct GaussIn { float mx, my, mz, s0, s1, s2, qr, qx, qy, qz; };
+struct GaussTerms {
+    float a[NACC];                 // sums of the tile partials: colour rgb, mean2D xy, conic xx xy yy, opacity
+    float dmean[3], dcov[6], dscale[3], drot[4];
+    float coef[16], dRGB[3];       // dL_dsh[k][c] = coef[k] * dRGB[c]
+};
+
+template <bool HAS_SH, bool HAS_SCALE_ROT, typename ShRow>
+__device__ __forceinline__ void pergauss_terms(int idx, bool live, int D, const ShRow& sh, const BwdIn& in, const float* __restrict__ cov3D_precomp,
+                                               const CamParams& cam, const ViewMat& V, const ViewMat& PM, float camx, float camy, float camz,
+                                               const GeomState& g, const BinState& b, GaussTerms& t)
+{
+    float (&a)[NACC] = t.a;
+    float (&dmean)[3] = t.dmean; float (&dcov)[6] = t.dcov; float (&dscale)[3] = t.dscale; float (&drot)[4] = t.drot;
+    float (&coef)[16] = t.coef; float (&dRGB)[3] = t.dRGB;
+#pragma unroll
+    for (int k = 0; k < NACC; k++) a[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { dmean[k] = 0.f; dscale[k] = 0.f; dRGB[k] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < 6; k++) dcov[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) drot[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; k++) coef[k] = 0.f;
+    if (!live) return;
+    const size_t i3 = 3 * (size_t)idx;
+    const float mx = in.means3D[i3], my = in.means3D[i3 + 1], mz = in.means3D[i3 + 2];
+    {
+        // sum of this Gaussian's tile partials, fixed order
+        const uint32_t tiles = g.tiles_touched[idx];
+        const float4* row = b.slab + (size_t)g.offsets[idx] * SLAB_ROW;
+        for (uint32_t k = 0; k < tiles; k++, row += SLAB_ROW) {
+            const float4 r0 = row[0], r1 = row[1], r2 = row[2];
+            a[0] += r0.x; a[1] += r0.y; a[2] += r0.z; a[3] += r0.w; a[4] += r1.x; a[5] += r1.y; a[6] += r1.z; a[7] += r1.w; a[8] += r2.x;
+        }
+
+        // ---- computeCov2DCUDA (backward.cu:144-274) ----
+        float cov3d[6];
+        const float* csrc = HAS_SCALE_ROT ? (g.cov3D + 6 * (size_t)idx) : (cov3D_precomp + 6 * (size_t)idx);
+#pragma unroll
+        for (int i = 0; i < 6; i++) cov3d[i] = csrc[i];
+        const Cov2D c2 = compute_cov2d(mx, my, mz, cov3d, cam, V);
+        const float limx = 1.3f * cam.tan_fovx, limy = 1.3f * cam.tan_fovy;
+        const float x_grad_mul = (c2.txtz < -limx || c2.txtz > limx) ? 0.f : 1.f;
+        const float y_grad_mul = (c2.tytz < -limy || c2.tytz > limy) ? 0.f : 1.f;
+        const float ca = c2.cov.m[0][0] + 0.3f, cb = c2.cov.m[0][1], cc = c2.cov.m[1][1] + 0.3f;
+        const float dLc0 = a[5], dLc1 = a[6], dLc2 = a[7];    // dL_dconic .x .y .w
+        const float denom = ca * cc - cb * cb;
+        float dL_da = 0, dL_db = 0, dL_dc = 0;
+        const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+#define Tm(c_, r_) c2.T.m[c_][r_]
+        if (denom2inv != 0) {
+            dL_da = denom2inv * (-cc * cc * dLc0 + 2 * cb * cc * dLc1 + (denom - ca * cc) * dLc2);
+            dL_dc = denom2inv * (-ca * ca * dLc2 + 2 * ca * cb * dLc1 + (denom - ca * cc) * dLc0);
+            dL_db = denom2inv * 2 * (cb * cc * dLc0 - (denom + 2 * cb * cb) * dLc1 + ca * cb * dLc2);
+            dcov[0] = (Tm(0, 0) * Tm(0, 0) * dL_da + Tm(0, 0) * Tm(1, 0) * dL_db + Tm(1, 0) * Tm(1, 0) * dL_dc);
+            dcov[3] = (Tm(0, 1) * Tm(0, 1) * dL_da + Tm(0, 1) * Tm(1, 1) * dL_db + Tm(1, 1) * Tm(1, 1) * dL_dc);
+            dcov[5] = (Tm(0, 2) * Tm(0, 2) * dL_da + Tm(0, 2) * Tm(1, 2) * dL_db + Tm(1, 2) * Tm(1, 2) * dL_dc);
+            dcov[1] = 2 * Tm(0, 0) * Tm(0, 1) * dL_da + (Tm(0, 0) * Tm(1, 1) + Tm(0, 1) * Tm(1, 0)) * dL_db + 2 * Tm(1, 0) * Tm(1, 1) * dL_dc;
+            dcov[2] = 2 * Tm(0, 0) * Tm(0, 2) * dL_da + (Tm(0, 0) * Tm(1, 2) + Tm(0, 2) * Tm(1, 0)) * dL_db + 2 * Tm(1, 0) * Tm(1, 2) * dL_dc;
+            dcov[4] = 2 * Tm(0, 2) * Tm(0, 1) * dL_da + (Tm(0, 1) * Tm(1, 2) + Tm(0, 2) * Tm(1, 1)) * dL_db + 2 * Tm(1, 1) * Tm(1, 2) * dL_dc;
+        }
+#define Vk(c_, r_) c2.Vrk.m[c_][r_]
+        const float dL_dT00 = 2 * (Tm(0, 0) * Vk(0, 0) + Tm(0, 1) * Vk(0, 1) + Tm(0, 2) * Vk(0, 2)) * dL_da + (Tm(1, 0) * Vk(0, 0) + Tm(1, 1) * Vk(0, 1) + Tm(1, 2) * Vk(0, 2)) * dL_db;
+        const float dL_dT01 = 2 * (Tm(0, 0) * Vk(1, 0) + Tm(0, 1) * Vk(1, 1) + Tm(0, 2) * Vk(1, 2)) * dL_da + (Tm(1, 0) * Vk(1, 0) + Tm(1, 1) * Vk(1, 1) + Tm(1, 2) * Vk(1, 2)) * dL_db;
+        const float dL_dT02 = 2 * (Tm(0, 0) * Vk(2, 0) + Tm(0, 1) * Vk(2, 1) + Tm(0, 2) * Vk(2, 2)) * dL_da + (Tm(1, 0) * Vk(2, 0) + Tm(1, 1) * Vk(2, 1) + Tm(1, 2) * Vk(2, 2)) * dL_db;
+        const float dL_dT10 = 2 * (Tm(1, 0) * Vk(0, 0) + Tm(1, 1) * Vk(0, 1) + Tm(1, 2) * Vk(0, 2)) * dL_dc + (Tm(0, 0) * Vk(0, 0) + Tm(0, 1) * Vk(0, 1) + Tm(0, 2) * Vk(0, 2)) * dL_db;
+        const float dL_dT11 = 2 * (Tm(1, 0) * Vk(1, 0) + Tm(1, 1) * Vk(1, 1) + Tm(1, 2) * Vk(1, 2)) * dL_dc + (Tm(0, 0) * Vk(1, 0) + Tm(0, 1) * Vk(1, 1) + Tm(0, 2) * Vk(1, 2)) * dL_db;
+        const float dL_dT12 = 2 * (Tm(1, 0) * Vk(2, 0) + Tm(1, 1) * Vk(2, 1) + Tm(1, 2) * Vk(2, 2)) * dL_dc + (Tm(0, 0) * Vk(2, 0) + Tm(0, 1) * Vk(2, 1) + Tm(0, 2) * Vk(2, 2)) * dL_db;
+#undef Vk
+#undef Tm
+#define Wg(c_, r_) c2.W.m[c_][r_]
+        const float dL_dJ00 = Wg(0, 0) * dL_dT00 + Wg(0, 1) * dL_dT01 + Wg(0, 2) * dL_dT02;
+        const float dL_dJ02 = Wg(2, 0) * dL_dT00 + Wg(2, 1) * dL_dT01 + Wg(2, 2) * dL_dT02;
+        const float dL_dJ11 = Wg(1, 0) * dL_dT10 + Wg(1, 1) * dL_dT11 + Wg(1, 2) * dL_dT12;
+        const float dL_dJ12 = Wg(2, 0) * dL_dT10 + Wg(2, 1) * dL_dT11 + Wg(2, 2) * dL_dT12;
+#undef Wg
+        const float tz = 1.f / c2.tz, tz2 = tz * tz, tz3 = tz2 * tz;
+        const float h_x = cam.focal_x, h_y = cam.focal_y;
+        const float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
+        const float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
+        const float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * c2.tx) * tz3 * dL_dJ02 + (2 * h_y * c2.ty) * tz3 * dL_dJ12;
+        const float* vm = V.m;                                  // transformVec4x3Transpose (auxiliary.h:89-97)
+        dmean[0] = vm[0] * dL_dtx + vm[1] * dL_dty + vm[2] * dL_dtz;
+        dmean[1] = vm[4] * dL_dtx + vm[5] * dL_dty + vm[6] * dL_dtz;
+        dmean[2] = vm[8] * dL_dtx + vm[9] * dL_dty + vm[10] * dL_dtz;
+
+        // ---- preprocessCUDA backward (backward.cu:346-396) ----
+        const float* proj = PM.m;
+        const float m_hom_w = proj[3] * mx + proj[7] * my + proj[11] * mz + proj[15];
+        const float m_w = 1.0f / (m_hom_w + 0.0000001f);
+        const float mul1 = (proj[0] * mx + proj[4] * my + proj[8] * mz + proj[12]) * m_w * m_w;
+        const float mul2 = (proj[1] * mx + proj[5] * my + proj[9] * mz + proj[13]) * m_w * m_w;
+        const float g2x = a[3], g2y = a[4];
+        dmean[0] += (proj[0] * m_w - proj[3] * mul1) * g2x + (proj[1] * m_w - proj[3] * mul2) * g2y;
+        dmean[1] += (proj[4] * m_w - proj[7] * mul1) * g2x + (proj[5] * m_w - proj[7] * mul2) * g2y;
+        dmean[2] += (proj[8] * m_w - proj[11] * mul1) * g2x + (proj[9] * m_w - proj[11] * mul2) * g2y;
+
+        if (HAS_SCALE_ROT) {
+            // computeCov3D backward (backward.cu:278-341)
+            const float s0 = in.scales[i3], s1 = in.scales[i3 + 1], s2 = in.scales[i3 + 2];
+            const float4 q = reinterpret_cast<const float4*>(in.rotations)[idx];
+            const float r = q.x, x = q.y, y = q.z, z = q.w;
+            const mat3 R = quat_to_R(r, x, y, z);
+            const float sx = cam.scale_modifier * s0, sy = cam.scale_modifier * s1, sz = cam.scale_modifier * s2;
+            const mat3 S = m3make(sx, 0.f, 0.f, 0.f, sy, 0.f, 0.f, 0.f, sz);
+            const mat3 Mx = m3mul(S, R);
+            const mat3 dSig = m3make(dcov[0], 0.5f * dcov[1], 0.5f * dcov[2], 0.5f * dcov[1], dcov[3], 0.5f * dcov[4], 0.5f * dcov[2], 0.5f * dcov[4], dcov[5]);
+            mat3 M2;
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+#pragma unroll
+                for (int w = 0; w < 3; w++) M2.m[c][w] = 2.0f * Mx.m[c][w];
+            const mat3 dM = m3mul(M2, dSig);
+            const mat3 Rt = m3t(R);
+            mat3 dMt = m3t(dM);
+            dscale[0] = Rt.m[0][0] * dMt.m[0][0] + Rt.m[0][1] * dMt.m[0][1] + Rt.m[0][2] * dMt.m[0][2];
+            dscale[1] = Rt.m[1][0] * dMt.m[1][0] + Rt.m[1][1] * dMt.m[1][1] + Rt.m[1][2] * dMt.m[1][2];
+            dscale[2] = Rt.m[2][0] * dMt.m[2][0] + Rt.m[2][1] * dMt.m[2][1] + Rt.m[2][2] * dMt.m[2][2];
+#pragma unroll
+            for (int w = 0; w < 3; w++) { dMt.m[0][w] *= sx; dMt.m[1][w] *= sy; dMt.m[2][w] *= sz; }
+#define A(c_, w_) dMt.m[c_][w_]
+            drot[0] = 2 * z * (A(0, 1) - A(1, 0)) + 2 * y * (A(2, 0) - A(0, 2)) + 2 * x * (A(1, 2) - A(2, 1));
+            drot[1] = 2 * y * (A(1, 0) + A(0, 1)) + 2 * z * (A(2, 0) + A(0, 2)) + 2 * r * (A(1, 2) - A(2, 1)) - 4 * x * (A(2, 2) + A(1, 1));
+            drot[2] = 2 * x * (A(1, 0) + A(0, 1)) + 2 * r * (A(2, 0) - A(0, 2)) + 2 * z * (A(1, 2) + A(2, 1)) - 4 * y * (A(2, 2) + A(0, 0));
+            drot[3] = 2 * r * (A(0, 1) - A(1, 0)) + 2 * x * (A(2, 0) + A(0, 2)) + 2 * y * (A(1, 2) + A(2, 1)) - 4 * z * (A(1, 1) + A(0, 0));
+#undef A
+        }
+    }
+    if (HAS_SH) {
+            asm volatile("" ::: "memory");            // keep the 48 SH reads below from being hoisted over the covariance math (VGPR pressure)
+            const uint32_t cl = g.clamped[idx];
+            dRGB[0] = a[0] * ((cl & 1u) ? 0.f : 1.f);
+            dRGB[1] = a[1] * ((cl & 2u) ? 0.f : 1.f);
+            dRGB[2] = a[2] * ((cl & 4u) ? 0.f : 1.f);
+            const float ox = mx - camx, oy = my - camy, oz = mz - camz;
+            const float len = sqrtf(ox * ox + oy * oy + oz * oz);
+            const float x = ox / len, y = oy / len, z = oz / len;
+            float gxv[3] = {0.f, 0.f, 0.f}, gyv[3] = {0.f, 0.f, 0.f}, gzv[3] = {0.f, 0.f, 0.f};
+#define SH(k) sh(3 * (k) + c)
+            coef[0] = SH_C0;
+            if (D > 0) {
+                coef[1] = -SH_C1 * y; coef[2] = SH_C1 * z; coef[3] = -SH_C1 * x;
+#pragma unroll
+                for (int c = 0; c < 3; c++) { gxv[c] = -SH_C1 * SH(3); gyv[c] = -SH_C1 * SH(1); gzv[c] = SH_C1 * SH(2); }
+                if (D > 1) {
+                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                    coef[4] = SH_C2_0 * xy; coef[5] = SH_C2_1 * yz; coef[6] = SH_C2_2 * (2.f * zz - xx - yy); coef[7] = SH_C2_3 * xz; coef[8] = SH_C2_4 * (xx - yy);
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        gxv[c] += SH_C2_0 * y * SH(4) + SH_C2_2 * 2.f * -x * SH(6) + SH_C2_3 * z * SH(7) + SH_C2_4 * 2.f * x * SH(8);
+                        gyv[c] += SH_C2_0 * x * SH(4) + SH_C2_1 * z * SH(5) + SH_C2_2 * 2.f * -y * SH(6) + SH_C2_4 * 2.f * -y * SH(8);
+                        gzv[c] += SH_C2_1 * y * SH(5) + SH_C2_2 * 2.f * 2.f * z * SH(6) + SH_C2_3 * x * SH(7);
+                    }
+                    if (D > 2) {
+                        coef[9] = SH_C3_0 * y * (3.f * xx - yy); coef[10] = SH_C3_1 * xy * z; coef[11] = SH_C3_2 * y * (4.f * zz - xx - yy);
+                        coef[12] = SH_C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy); coef[13] = SH_C3_4 * x * (4.f * zz - xx - yy);
+                        coef[14] = SH_C3_5 * z * (xx - yy); coef[15] = SH_C3_6 * x * (xx - 3.f * yy);
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+                            gxv[c] += (SH_C3_0 * SH(9) * 3.f * 2.f * xy + SH_C3_1 * SH(10) * yz + SH_C3_2 * SH(11) * -2.f * xy +
+                                       SH_C3_3 * SH(12) * -3.f * 2.f * xz + SH_C3_4 * SH(13) * (-3.f * xx + 4.f * zz - yy) +
+                                       SH_C3_5 * SH(14) * 2.f * xz + SH_C3_6 * SH(15) * 3.f * (xx - yy));
+                            gyv[c] += (SH_C3_0 * SH(9) * 3.f * (xx - yy) + SH_C3_1 * SH(10) * xz + SH_C3_2 * SH(11) * (-3.f * yy + 4.f * zz - xx) +
+                                       SH_C3_3 * SH(12) * -3.f * 2.f * yz + SH_C3_4 * SH(13) * -2.f * xy + SH_C3_5 * SH(14) * -2.f * yz +
+                                       SH_C3_6 * SH(15) * -3.f * 2.f * xy);
+                            gzv[c] += (SH_C3_1 * SH(10) * xy + SH_C3_2 * SH(11) * 4.f * 2.f * yz + SH_C3_3 * SH(12) * 3.f * (2.f * zz - xx - yy) +
+                                       SH_C3_4 * SH(13) * 4.f * 2.f * xz + SH_C3_5 * SH(14) * (xx - yy));
+                        }
+                    }
+                }
+            }
+#undef SH
+            const float ddx = gxv[0] * dRGB[0] + gxv[1] * dRGB[1] + gxv[2] * dRGB[2];
+            const float ddy = gyv[0] * dRGB[0] + gyv[1] * dRGB[1] + gyv[2] * dRGB[2];
+            const float ddz = gzv[0] * dRGB[0] + gzv[1] * dRGB[1] + gzv[2] * dRGB[2];
+            // dnormvdv (auxiliary.h:107-117)
+            const float sum2 = ox * ox + oy * oy + oz * oz;
+            const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+            dmean[0] += ((+sum2 - ox * ox) * ddx - oy * ox * ddy - oz * ox * ddz) * invsum32;
+            dmean[1] += (-ox * oy * ddx + (sum2 - oy * oy) * ddy - oz * oy * ddz) * invsum32;
+            dmean[2] += (-ox * oz * ddx - oy * oz * ddy + (sum2 - oz * oz) * ddz) * invsum32;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_preprocess_bwd: one view per launch
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ GaussIn load_gauss(const BwdIn& in, int idx, bool has_scale_rot)
+{
+    GaussIn gi;
+    const size_t i3 = 3 * (size_t)idx;
+    gi.mx = in.means3D[i3]; gi.my = in.means3D[i3 + 1]; gi.mz = in.means3D[i3 + 2];
+    gi.s0 = gi.s1 = gi.s2 = 0.f; gi.qr = gi.qx = gi.qy = gi.qz = 0.f;
+    if (has_scale_rot) {
+        gi.s0 = in.scales[i3]; gi.s1 = in.scales[i3 + 1]; gi.s2 = in.scales[i3 + 2];
+        const float4 q = reinterpret_cast<const float4*>(in.rotations)[idx];
+        gi.qr = q.x; gi.qx = q.y; gi.qy = q.z; gi.qz = q.w;
+    }
+    return gi;
+}
+
+// the parameter gradients of one Gaussian: stored, or added to what the buffers hold (accumulate)
+__device__ __forceinline__ void store_param_grads(const BwdIn& in, int idx, float dopacity, const float (&dcolor)[3], const float (&dmean)[3], const float (&dcov)[6],
+                                                  const float (&dscale)[3], const float (&drot)[4])
+{
+    const size_t i3 = 3 * (size_t)idx;
+    if (in.accumulate) {
+        // fused gradient accumulation of a multi-view batch (youreditableavatar_amd/multiview.py): += on the parameter gradients
+        in.dL_dopacity[idx] += dopacity;
+        if (in.dL_dcolor) { in.dL_dcolor[i3] += dcolor[0]; in.dL_dcolor[i3 + 1] += dcolor[1]; in.dL_dcolor[i3 + 2] += dcolor[2]; }   // NULL: intermediate on the SH path
+        in.dL_dmean3D[i3] += dmean[0]; in.dL_dmean3D[i3 + 1] += dmean[1]; in.dL_dmean3D[i3 + 2] += dmean[2];
+        if (in.dL_dcov3D) {                                                                                         // NULL: intermediate on the scale/rot path
+#pragma unroll
+            for (int i = 0; i < 6; i++) in.dL_dcov3D[6 * (size_t)idx + i] += dcov[i];
+        }
+        if (in.dL_dscale) { in.dL_dscale[i3] += dscale[0]; in.dL_dscale[i3 + 1] += dscale[1]; in.dL_dscale[i3 + 2] += dscale[2]; }
+        if (in.dL_drot) { float4 p = reinterpret_cast<float4*>(in.dL_drot)[idx]; p.x += drot[0]; p.y += drot[1]; p.z += drot[2]; p.w += drot[3]; reinterpret_cast<float4*>(in.dL_drot)[idx] = p; }
+        return;
+    }
+    in.dL_dopacity[idx] = dopacity;
+    if (in.dL_dcolor) { in.dL_dcolor[i3] = dcolor[0]; in.dL_dcolor[i3 + 1] = dcolor[1]; in.dL_dcolor[i3 + 2] = dcolor[2]; }
+    in.dL_dmean3D[i3] = dmean[0]; in.dL_dmean3D[i3 + 1] = dmean[1]; in.dL_dmean3D[i3 + 2] = dmean[2];
+    if (in.dL_dcov3D) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) in.dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
+    }
+    if (in.dL_dscale) { in.dL_dscale[i3] = dscale[0]; in.dL_dscale[i3 + 1] = dscale[1]; in.dL_dscale[i3 + 2] = dscale[2]; }
+    if (in.dL_drot) reinterpret_cast<float4*>(in.dL_drot)[idx] = make_float4(drot[0], drot[1], drot[2], drot[3]);
+}
+
+// dL_dsh rows of the workgroup, 48 values per thread in `o48` (M == 16): through LDS so that global memory sees 16 B per lane
+template <typename Row48>
+__device__ __forceinline__ void store_sh_rows_staged(const BwdIn& in, float4* sh_lds, const Row48& o48)
+{
+    const size_t base4 = (size_t)blockIdx.x * PRE_BLOCK * 12, total4 = (size_t)in.P * 12;
+    __syncthreads();                                       // every thread has consumed its SH row
+#pragma unroll
+    for (int q = 0; q < 12; q++) sh_lds[threadIdx.x * 12 + q] = make_float4(o48(4 * q), o48(4 * q + 1), o48(4 * q + 2), o48(4 * q + 3));
+    __syncthreads();
+    float4* d4 = reinterpret_cast<float4*>(in.dL_dsh);
+#pragma unroll
+    for (int q = 0; q < 12; q++) {
+        const size_t i = base4 + q * PRE_BLOCK + threadIdx.x;
+        if (i < total4) {
+            float4 o = sh_lds[q * PRE_BLOCK + threadIdx.x];
+            if (in.accumulate) { const float4 p = d4[i]; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+            d4[i] = o;
+        }
+    }
+}
+__device__ __forceinline__ void load_sh_rows_staged(const BwdIn& in, float4* sh_lds)
+{
+    const size_t base4 = (size_t)blockIdx.x * PRE_BLOCK * 12, total4 = (size_t)in.P * 12;
+    const float4* s4 = reinterpret_cast<const float4*>(in.shs);
+#pragma unroll
+    for (int q = 0; q < 12; q++) { const size_t i = base4 + q * PRE_BLOCK + threadIdx.x; if (i < total4) sh_lds[q * PRE_BLOCK + threadIdx.x] = s4[i]; }
+    __syncthreads();
+}
+
+// (The one-view kernel keeps its own copy of the math of pergauss_terms: routed through the shared function hipcc
+// allocates 172 VGPRs instead of 132 -- 2 resident waves per SIMD instead of 3 -- and the kernel takes 120 us instead
+// of 98.  tests/test_gpu_api.py::test_batched_backward_equals_per_view_backward keeps the two in step.)
 template <bool HAS_SH, bool HAS_SCALE_ROT>
 __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, const CamParams cam, const GeomState g, const BinState b)
 {
@@ -616,6 +882,76 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
     if (in.dL_drot) reinterpret_cast<float4*>(in.dL_drot)[idx] = make_float4(drot[0], drot[1], drot[2], drot[3]);
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_preprocess_bwd_batch: the per-Gaussian half for ALL views of a batch in one launch.  The view-independent inputs
+// (mean, scale, rotation, the 192-B SH row) are read once and the parameter gradients -- dL_dsh above all: 192 B read +
+// 192 B written per Gaussian per view in the one-view kernel's += mode -- are accumulated in registers over the views
+// and stored (or added) once.  Per view only the view's own state is touched: pack line, tile partials, radii, flags.
+// ---------------------------------------------------------------------------------------------
+template <bool HAS_SH, bool HAS_SCALE_ROT>
+__global__ __launch_bounds__(PRE_BLOCK, 2) void k_preprocess_bwd_batch(const BwdIn in, const BatchViews views)
+{
+    const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
+    __shared__ float4 sh_lds[HAS_SH ? PRE_BLOCK * 12 : 1];
+    const bool sh_staged = HAS_SH && in.M == 16;
+    if (sh_staged) load_sh_rows_staged(in, sh_lds);
+    const bool in_range = idx < in.P;
+    const float* sh_row = sh_staged ? reinterpret_cast<const float*>(&sh_lds[threadIdx.x * 12]) : (HAS_SH ? in.shs + (size_t)(in_range ? idx : 0) * in.M * 3 : nullptr);
+    float o48[48];                                         // dL_dsh row accumulated over the views (dead code without SH)
+#pragma unroll
+    for (int i = 0; i < 48; i++) o48[i] = 0.f;
+    float dopacity = 0.f, dmean[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dscale[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int v = 0; v < views.n; v++) {
+        const BatchView& vw = views.v[v];
+        const bool rejected = (vw.meta->error & META_ERR_CAPACITY) != 0u;       // tgs_forward_async could not fit this frame: it contributes nothing
+        const bool live = in_range && !rejected && vw.radii[idx] > 0;
+        GaussTerms t;
+        if (__builtin_amdgcn_ballot_w64(live) != 0) {
+            const ViewMat V = load_mat(vw.cam.view), PM = load_mat(vw.cam.proj);
+            pergauss_terms<HAS_SH, HAS_SCALE_ROT>(idx, live, in.D, [&](int i) { return sh_row[i]; }, in, in.cov3D_precomp, vw.cam, V, PM, vw.cam.campos[0], vw.cam.campos[1],
+                                                  vw.cam.campos[2], vw.g, vw.b, t);
+        } else {
+            t.a[0] = t.a[1] = t.a[2] = t.a[3] = t.a[4] = 0.f;
+        }
+        if (in_range) {
+            const size_t i3 = 3 * (size_t)idx;
+            vw.dL_dmean2D[i3] = live ? t.a[3] : 0.f; vw.dL_dmean2D[i3 + 1] = live ? t.a[4] : 0.f; vw.dL_dmean2D[i3 + 2] = 0.f;
+            if (!HAS_SH && vw.dL_dcolor) { vw.dL_dcolor[i3] = live ? t.a[0] : 0.f; vw.dL_dcolor[i3 + 1] = live ? t.a[1] : 0.f; vw.dL_dcolor[i3 + 2] = live ? t.a[2] : 0.f; }
+        }
+        if (live) {
+            dopacity += t.a[8];
+#pragma unroll
+            for (int k = 0; k < 3; k++) { dmean[k] += t.dmean[k]; dscale[k] += t.dscale[k]; }
+#pragma unroll
+            for (int k = 0; k < 6; k++) dcov[k] += t.dcov[k];
+#pragma unroll
+            for (int k = 0; k < 4; k++) drot[k] += t.drot[k];
+            if (HAS_SH) {
+#pragma unroll
+                for (int i = 0; i < 48; i++) o48[i] += t.coef[i / 3] * t.dRGB[i % 3];
+            }
+        }
+    }
+    if (HAS_SH) {
+        if (sh_staged) store_sh_rows_staged(in, sh_lds, [&](int i) { return o48[i]; });
+        else if (in_range) {
+            float* dsh = in.dL_dsh + (size_t)idx * in.M * 3;
+            for (int i = 0; i < in.M * 3; i++) {
+                float o = 0.f;
+#pragma unroll
+                for (int j = 0; j < 48; j++) o = (i == j) ? o48[j] : o;           // no dynamic indexing: keeps the accumulators in registers
+                dsh[i] = (in.accumulate ? dsh[i] : 0.f) + o;
+            }
+        }
+    }
+    if (!in_range) return;
+    const float nocolor[3] = {0.f, 0.f, 0.f};
+    BwdIn shared = in;
+    shared.dL_dcolor = nullptr;                              // per-view colours have per-view gradients (BatchView::dL_dcolor)
+    store_param_grads(shared, idx, dopacity, nocolor, dmean, dcov, dscale, drot);
+}
+
 // hardware self-test of wave_reduce36: in[64][36] -> out[4][9] (row e, component k)
 __global__ void k_selftest_reduce36(const float* in, float* out)
 {
@@ -647,6 +983,16 @@ void launch_preprocess_bwd(hipStream_t st, const BwdIn& in, const CamParams& cam
     else if (sh) hipLaunchKernelGGL((k_preprocess_bwd<true, false>), grid, blk, 0, st, in, cam, g, b);
     else if (sr) hipLaunchKernelGGL((k_preprocess_bwd<false, true>), grid, blk, 0, st, in, cam, g, b);
     else hipLaunchKernelGGL((k_preprocess_bwd<false, false>), grid, blk, 0, st, in, cam, g, b);
+}
+
+void launch_preprocess_bwd_batch(hipStream_t st, const BwdIn& in, const BatchViews& views)
+{
+    const dim3 grid((unsigned)n_blocks(in.P)), blk(PRE_BLOCK);
+    const bool sh = in.shs != nullptr, sr = in.scales != nullptr;
+    if (sh && sr) hipLaunchKernelGGL((k_preprocess_bwd_batch<true, true>), grid, blk, 0, st, in, views);
+    else if (sh) hipLaunchKernelGGL((k_preprocess_bwd_batch<true, false>), grid, blk, 0, st, in, views);
+    else if (sr) hipLaunchKernelGGL((k_preprocess_bwd_batch<false, true>), grid, blk, 0, st, in, views);
+    else hipLaunchKernelGGL((k_preprocess_bwd_batch<false, false>), grid, blk, 0, st, in, views);
 }
 
 }  // namespace tgs

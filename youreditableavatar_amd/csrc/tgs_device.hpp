@@ -635,4 +635,17 @@ struct BwdIn {
     const Meta* meta; // the frame's Meta: a frame rejected by tgs_forward_async contributes nothing
 };
 
+// One view of a batch for k_preprocess_bwd_batch: everything that differs between the views (kernel argument)
+constexpr int BATCH_VIEWS = 8;
+struct BatchView {
+    CamParams cam;
+    GeomState g;
+    BinState b;
+    const Meta* meta;
+    const int* radii;
+    float* dL_dmean2D;   // [P,3] of this view
+    float* dL_dcolor;    // [P,3] of this view (colors_precomp path) or nullptr
+};
+struct BatchViews { int n; BatchView v[BATCH_VIEWS]; };
+
 }  // namespace tgs

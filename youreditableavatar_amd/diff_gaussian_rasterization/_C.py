@@ -43,6 +43,10 @@ def _load() -> C.CDLL:
                                  vp, vp, vp, vp] + [vp] * 9 + [it]
     lib.tgs_backward_accumulate.restype = it
     lib.tgs_backward_accumulate.argtypes = lib.tgs_backward.argtypes
+    lib.tgs_backward_render.restype = it
+    lib.tgs_backward_render.argtypes = [vp, it, C.c_int64, vp, it, it, vp, vp, vp]
+    lib.tgs_backward_batch.restype = it
+    lib.tgs_backward_batch.argtypes = [vp, it, it, it, it, vp, vp, vp, vp, fl, vp, vp, vp, vp, vp, vp, vp, vp, it]
     lib.tgs_mark_visible.restype = it
     lib.tgs_mark_visible.argtypes = [vp, it, vp, vp, vp, vp]
     lib.tgs_state_field.restype = C.c_int64
@@ -285,6 +289,78 @@ def rasterize_gaussians_backward_accumulate(background, means3D, radii, colors, 
         if r < 0:
             raise _err(int(r))
     return dL_dmeans2D
+
+
+class _ViewT(C.Structure):
+    """tgs_view_t (include/tgs_raster.h)"""
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("tan_fovx", C.c_float), ("tan_fovy", C.c_float),
+                ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p), ("radii", C.c_void_p),
+                ("geom_buffer", C.c_void_p), ("binning_buffer", C.c_void_p), ("img_buffer", C.c_void_p), ("R", C.c_int64),
+                ("dL_dmean2D", C.c_void_p), ("dL_dcolor", C.c_void_p)]
+
+
+def rasterize_gaussians_backward_render(background, dL_dout_color, R, binningBuffer, imageBuffer, P) -> None:
+    """tgs_backward_render: the per-pixel half of one view's backward; the tile partials stay in ``binningBuffer`` for
+    ``rasterize_gaussians_backward_batch``."""
+    dev = _require_gpu(dL_dout_color)
+    H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
+    with torch.cuda.device(dev):
+        bg, dL = _dev_f32(background, dev, "background"), _dev_f32(dL_dout_color, dev, "dL_dout_color")
+        r = _lib.tgs_backward_render(torch.cuda.current_stream(dev).cuda_stream, int(P), int(R), _p(bg), W, H, binningBuffer.data_ptr(),
+                                     imageBuffer.data_ptr(), _p(dL))
+    if r < 0:
+        raise _err(int(r))
+
+
+def rasterize_gaussians_backward_batch(views, means3D, sh, degree, scales, rotations, scale_modifier, cov3D_precomp, into, accumulate=True):
+    """tgs_backward_batch: the per-Gaussian half for all ``views`` of a batch in one pass.
+
+    ``views``: dicts with keys viewmatrix, projmatrix, campos, tanfovx, tanfovy, image_height, image_width, radii, geom, binning, img,
+    R (and colors=True on the colors_precomp path).  Parameter gradients are stored (``accumulate=False``) or added into the tensors
+    of ``into`` (keys: means3D, opacities, and sh, scales + rotations | cov3D_precomp).  Returns, per view, dL_dmeans2D[P,3]
+    (and dL_dcolors[P,3] on the colors_precomp path)."""
+    dev = _require_gpu(means3D)
+    P = int(means3D.size(0))
+    M = int(sh.size(1)) if (sh is not None and sh.dim() > 1 and sh.size(0) != 0) else 0
+    has_sh = M > 0
+    outs = []
+    if P == 0 or not views:
+        return outs
+    with torch.cuda.device(dev):
+        t = dict(means=_dev_f32(means3D, dev, "means3D"), sh=_dev_f32(sh, dev, "sh") if has_sh else None, scales=_dev_f32(scales, dev, "scales"),
+                 rots=_dev_f32(rotations, dev, "rotations"), cov=_dev_f32(cov3D_precomp, dev, "cov3D_precomp"))
+        has_sr = t["scales"] is not None
+        arr = (_ViewT * len(views))()
+        keep = []
+        for i, v in enumerate(views):
+            vm, pm, cp = _dev_f32(v["viewmatrix"], dev, "viewmatrix"), _dev_f32(v["projmatrix"], dev, "projmatrix"), _dev_f32(v["campos"], dev, "campos")
+            radii = v["radii"].contiguous()
+            g2d = torch.empty((P, 3), dtype=torch.float32, device=dev)
+            gcol = None if has_sh else torch.empty((P, 3), dtype=torch.float32, device=dev)
+            keep += [vm, pm, cp, radii]
+            a = arr[i]
+            a.width, a.height, a.tan_fovx, a.tan_fovy = int(v["image_width"]), int(v["image_height"]), float(v["tanfovx"]), float(v["tanfovy"])
+            a.viewmatrix, a.projmatrix, a.campos, a.radii = vm.data_ptr(), pm.data_ptr(), cp.data_ptr(), radii.data_ptr()
+            a.geom_buffer, a.binning_buffer, a.img_buffer, a.R = v["geom"].data_ptr(), v["binning"].data_ptr(), v["img"].data_ptr(), int(v["R"])
+            a.dL_dmean2D, a.dL_dcolor = g2d.data_ptr(), (gcol.data_ptr() if gcol is not None else None)
+            outs.append((g2d, gcol))
+
+        def dst(name, shape):
+            g = into.get(name)
+            if g is None:
+                raise RuntimeError(f"rasterize_gaussians_backward_batch: no gradient buffer for {name}")
+            if g.dtype != torch.float32 or g.device != dev or not g.is_contiguous() or tuple(g.shape) != shape:
+                raise RuntimeError(f"gradient buffer for {name} must be a contiguous fp32 tensor of shape {shape} on {dev}")
+            return g.data_ptr()
+
+        r = _lib.tgs_backward_batch(torch.cuda.current_stream(dev).cuda_stream, P, int(degree), M, len(views), C.cast(arr, C.c_void_p), _p(t["means"]),
+                                    _p(t["sh"]), _p(t["scales"]), float(scale_modifier), _p(t["rots"]), _p(t["cov"]), dst("opacities", (P, 1)),
+                                    dst("means3D", (P, 3)), None if has_sr else dst("cov3D_precomp", (P, 6)), dst("sh", (P, M, 3)) if has_sh else None,
+                                    dst("scales", (P, 3)) if has_sr else None, dst("rotations", (P, 4)) if has_sr else None, 1 if accumulate else 0)
+        del keep
+    if r < 0:
+        raise _err(int(r))
+    return outs
 
 
 def mark_visible(means3D, viewmatrix, projmatrix) -> torch.Tensor:

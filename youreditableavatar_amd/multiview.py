@@ -80,6 +80,56 @@ def render_batch_sharded(render_view: Callable[[int], torch.Tensor], upstream: C
     return list(mine)
 
 
+class DeferredBackward:
+    """Collects the views of a batch whose backward has only run its per-pixel half (tgs_backward_render); ``finish`` runs
+    the per-Gaussian half for all of them in one pass (tgs_backward_batch) and adds the result into the parameters'
+    ``.grad`` buffers.  Reading the SH rows and read-modify-writing ``dL_dsh`` once per batch instead of once per view
+    removes about two thirds of that pass's memory traffic."""
+
+    def __init__(self):
+        self.views: List[dict] = []
+        self.leaves = None
+        self.meta = None            # (sh_degree, scale_modifier)
+
+    def add(self, rs, leaves, radii, geom, binning, img, R, means2D):
+        key = tuple((k, t.data_ptr(), tuple(t.shape)) for k, t in leaves.items())
+        if self.leaves is None:
+            self.leaves, self._key, self.meta = leaves, key, (rs.sh_degree, rs.scale_modifier)
+        elif key != self._key or self.meta != (rs.sh_degree, rs.scale_modifier):
+            raise RuntimeError("DeferredBackward: all views of a batch must render the same parameter tensors with the same SH degree / scale modifier")
+        self.views.append(dict(viewmatrix=rs.viewmatrix, projmatrix=rs.projmatrix, campos=rs.campos, tanfovx=rs.tanfovx, tanfovy=rs.tanfovy,
+                               image_height=rs.image_height, image_width=rs.image_width, radii=radii, geom=geom, binning=binning, img=img, R=R,
+                               means2D=means2D))
+
+    def finish(self) -> None:
+        from .diff_gaussian_rasterization import _C
+        if not self.views:
+            return
+        L = self.leaves
+        if L["colors_precomp"].numel():
+            raise RuntimeError("DeferredBackward supports the SH path (per-view colours have per-view gradients)")
+        into = {}
+        for name, t in L.items():
+            if t.numel() and t.requires_grad:
+                if not t.is_leaf or t.grad is None:
+                    raise RuntimeError(f"rasterize_accumulate: {name} must be a leaf parameter with an allocated .grad (see FlatGradients)")
+                into[name] = t.grad
+        st = torch.cuda.current_stream()
+        for v in self.views:                                 # buffers that were allocated on another stream of the batch
+            for k in ("radii", "geom", "binning", "img"):
+                v[k].record_stream(st)
+        outs = _C.rasterize_gaussians_backward_batch(self.views, L["means3D"].detach(), L["sh"].detach(), self.meta[0], L["scales"].detach(),
+                                                     L["rotations"].detach(), self.meta[1], L["cov3D_precomp"].detach(), into, accumulate=True)
+        for v, (g2d, _gcol) in zip(self.views, outs):
+            m = v["means2D"]
+            if m is not None and m.requires_grad:
+                m.grad = g2d if m.grad is None else m.grad + g2d
+        self.views = []
+
+
+_collector: Optional[DeferredBackward] = None       # set by SyncFreeBatch.run while it renders its views
+
+
 class _RasterizeAccumulate(torch.autograd.Function):
     """Rasterizer call for multi-view batches: identical forward; the backward ADDS the parameter gradients
     straight into the ``.grad`` tensors of the leaf parameters (tgs_backward_accumulate) instead of returning them
@@ -95,6 +145,8 @@ class _RasterizeAccumulate(torch.autograd.Function):
             rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug,
             r_capacity=r_capacity)
         ctx.rs, ctx.num_rendered = rs, num_rendered         # sync-free: the binning capacity (what the buffers are carved for)
+        ctx.collector = _collector if (r_capacity is not None and colors_precomp.numel() == 0) else None
+        ctx.means2D = means2D
         ctx.leaves = dict(means3D=means3D, sh=sh, colors_precomp=colors_precomp, opacities=opacities, scales=scales, rotations=rotations,
                           cov3D_precomp=cov3Ds_precomp)
         ctx.save_for_backward(radii, geom, binning, img)
@@ -107,6 +159,11 @@ class _RasterizeAccumulate(torch.autograd.Function):
         from .diff_gaussian_rasterization import _C
         rs, L = ctx.rs, ctx.leaves
         radii, geom, binning, img = ctx.saved_tensors
+        if ctx.collector is not None:
+            # batch mode: only the per-pixel half now; DeferredBackward.finish does the per-Gaussian half for all views at once
+            _C.rasterize_gaussians_backward_render(rs.bg, grad_out_color, ctx.num_rendered, binning, img, L["means3D"].size(0))
+            ctx.collector.add(rs, L, radii, geom, binning, img, ctx.num_rendered, ctx.means2D)
+            return None, None, None, None, None, None, None, None, None, None
         into = {}
         for name, t in L.items():
             if t.numel() and t.requires_grad:
@@ -150,11 +207,12 @@ class SyncFreeBatch:
     return_meta=True)`` and returns its ``(image, radii, meta)``; ``upstream(v, image)`` returns dL/d image (it runs
     again for a re-rendered view)."""
 
-    def __init__(self, headroom: float = 1.25, granule: int = 1 << 16, streams: int = 2):
+    def __init__(self, headroom: float = 1.25, granule: int = 1 << 16, streams: int = 2, deferred: bool = True):
         self.headroom, self.granule = float(headroom), int(granule)
         self.bound: Optional[int] = None        # largest num_rendered seen (decays slowly)
         self.rejected = 0                       # frames re-rendered so far
         self.streams = max(1, int(streams))     # 2: consecutive views alternate between two HIP streams (see run)
+        self.deferred = bool(deferred)          # one per-Gaussian backward pass for the whole batch (DeferredBackward)
         self._host: Optional[torch.Tensor] = None
         self._side = {}
 
@@ -192,10 +250,17 @@ class SyncFreeBatch:
         ready = None
         fwd_done = [None] * len(lanes)
         prev_bwd = None
+        global _collector
+        collector = DeferredBackward() if (self.deferred and cap is not None) else None
+        last_on_lane = [None] * len(lanes)
         for k, v in enumerate(views):
             st = lanes[k % len(lanes)]
             with torch.cuda.stream(st):
-                img, _radii, meta = rasterize(v, cap)
+                _collector = collector                      # picked up by rasterize_accumulate's forward
+                try:
+                    img, _radii, meta = rasterize(v, cap)
+                finally:
+                    _collector = None
                 metas.append(meta)
                 if len(lanes) > 1:
                     fwd_done[k % len(lanes)] = torch.cuda.Event()
@@ -215,17 +280,22 @@ class SyncFreeBatch:
                     ready = torch.cuda.Event()
                     ready.record(st)
                 grad = upstream(v, img.detach())
-                if prev_bwd is not None and len(lanes) > 1:
+                if collector is None and prev_bwd is not None and len(lanes) > 1:
                     st.wait_event(prev_bwd)                 # gradient accumulation is read-modify-write: one backward at a time
                 img.backward(grad)
                 if len(lanes) > 1:
                     prev_bwd = torch.cuda.Event()
                     prev_bwd.record(st)
+                    last_on_lane[k % len(lanes)] = prev_bwd
                     if st is not main:
                         img.record_stream(main)
             images.append(img.detach())
         if len(lanes) > 1:
-            main.wait_event(prev_bwd)                       # the last backward is behind every other kernel of the batch
+            for ev in (last_on_lane if collector is not None else [prev_bwd]):
+                if ev is not None:
+                    main.wait_event(ev)                     # chained backwards: the last one is behind every other kernel of the batch
+        if collector is not None:
+            collector.finish()                              # the per-Gaussian half of every view, one pass, on the calling stream
         ready.synchronize()                                 # the one host wait of the batch
         host = self._host
         seen = 0
