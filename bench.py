@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--config", type=int, default=3, help="BASELINE.json config index (1-based); 3 = 500k/1080p/SH3")
     ap.add_argument("--mode", default="sh", choices=["sh", "precomp"])
     ap.add_argument("--views", type=int, default=64)
-    ap.add_argument("--streams", type=int, default=2, help="HIP streams the views of a step alternate between (SyncFreeBatch)")
+    ap.add_argument("--streams", type=int, default=4, help="HIP streams the views of a step alternate between (SyncFreeBatch)")
     ap.add_argument("--sync-per-frame", action="store_true", help="reference protocol: read num_rendered back in every forward")
     ap.add_argument("--no-fused-accumulate", action="store_true", help="let autograd add each view's gradients in a separate pass")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")

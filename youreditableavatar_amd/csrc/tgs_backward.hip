@@ -354,6 +354,42 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
 // computeCov3D :278-341, computeColorFromSH :20-139), shared by k_preprocess_bwd (one view per launch) and
 // k_preprocess_bwd_batch (all views of a batch per launch).
 // ---------------------------------------------------------------------------------------------
+// a[0..8] <- sum of this Gaussian's tile partials (its slab rows are contiguous).  A splat on few tiles is summed by its own
+// lane in tile order; one on >= SLAB_COOP tiles -- a per-lane loop of thousands of dependent iterations otherwise, the
+// tail of the whole kernel on scenes with oversized splats -- is summed by the whole wave: lane l takes rows l, l + 64, ...
+// and the nine totals are formed with wave_sum.  Fixed order either way.  Call from convergent code.
+constexpr uint32_t SLAB_COOP = 128;
+__device__ __forceinline__ void slab_sum(bool live, int idx, const GeomState& g, const BinState& b, float (&a)[NACC])
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t tiles = live ? g.tiles_touched[idx] : 0u, off = live ? g.offsets[idx] : 0u;
+#pragma unroll
+    for (int c = 0; c < NACC; c++) a[c] = 0.f;
+    unsigned long long big = __builtin_amdgcn_ballot_w64(tiles >= SLAB_COOP);
+    while (big) {
+        const int src = __builtin_ctzll(big);
+        big &= big - 1;
+        const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)tiles, src), o = (uint32_t)__builtin_amdgcn_readlane((int)off, src);
+        float p[NACC];
+#pragma unroll
+        for (int c = 0; c < NACC; c++) p[c] = 0.f;
+        for (uint32_t k = lane; k < n; k += 64) {
+            const float4* row = b.slab + (size_t)(o + k) * SLAB_ROW;
+            const float4 r0 = row[0], r1 = row[1], r2 = row[2];
+            p[0] += r0.x; p[1] += r0.y; p[2] += r0.z; p[3] += r0.w; p[4] += r1.x; p[5] += r1.y; p[6] += r1.z; p[7] += r1.w; p[8] += r2.x;
+        }
+#pragma unroll
+        for (int c = 0; c < NACC; c++) { const float tot = wave_sum(p[c]); if (lane == src) a[c] = tot; }
+    }
+    if (tiles < SLAB_COOP) {
+        const float4* row = b.slab + (size_t)off * SLAB_ROW;
+        for (uint32_t k = 0; k < tiles; k++, row += SLAB_ROW) {
+            const float4 r0 = row[0], r1 = row[1], r2 = row[2];
+            a[0] += r0.x; a[1] += r0.y; a[2] += r0.z; a[3] += r0.w; a[4] += r1.x; a[5] += r1.y; a[6] += r1.z; a[7] += r1.w; a[8] += r2.x;
+        }
+    }
+}
+
 struct GaussIn { float mx, my, mz, s0, s1, s2, qr, qx, qy, qz; };
 struct GaussTerms {
     float a[NACC];                 // sums of the tile partials: colour rgb, mean2D xy, conic xx xy yy, opacity
@@ -369,8 +405,7 @@ __device__ __forceinline__ void pergauss_terms(int idx, bool live, int D, const 
     float (&a)[NACC] = t.a;
     float (&dmean)[3] = t.dmean; float (&dcov)[6] = t.dcov; float (&dscale)[3] = t.dscale; float (&drot)[4] = t.drot;
     float (&coef)[16] = t.coef; float (&dRGB)[3] = t.dRGB;
-#pragma unroll
-    for (int k = 0; k < NACC; k++) a[k] = 0.f;
+    slab_sum(live, idx, g, b, a);                          // convergent: the wave helps its splats that touch many tiles
 #pragma unroll
     for (int k = 0; k < 3; k++) { dmean[k] = 0.f; dscale[k] = 0.f; dRGB[k] = 0.f; }
 #pragma unroll
@@ -383,14 +418,6 @@ __device__ __forceinline__ void pergauss_terms(int idx, bool live, int D, const 
     const size_t i3 = 3 * (size_t)idx;
     const float mx = in.means3D[i3], my = in.means3D[i3 + 1], mz = in.means3D[i3 + 2];
     {
-        // sum of this Gaussian's tile partials, fixed order
-        const uint32_t tiles = g.tiles_touched[idx];
-        const float4* row = b.slab + (size_t)g.offsets[idx] * SLAB_ROW;
-        for (uint32_t k = 0; k < tiles; k++, row += SLAB_ROW) {
-            const float4 r0 = row[0], r1 = row[1], r2 = row[2];
-            a[0] += r0.x; a[1] += r0.y; a[2] += r0.z; a[3] += r0.w; a[4] += r1.x; a[5] += r1.y; a[6] += r1.z; a[7] += r1.w; a[8] += r2.x;
-        }
-
         // ---- computeCov2DCUDA (backward.cu:144-274) ----
         float cov3d[6];
         const float* csrc = HAS_SCALE_ROT ? (g.cov3D + 6 * (size_t)idx) : (cov3D_precomp + 6 * (size_t)idx);
@@ -650,14 +677,8 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
     const bool live = in_range && in.radii[idx] > 0;        // backward.cu:156,367
     float mx = 0.f, my = 0.f, mz = 0.f;
     float dRGB[3] = {0.f, 0.f, 0.f};
+    slab_sum(live, idx, g, b, a);                           // sum of this Gaussian's tile partials (wave-cooperative for big splats)
     if (live) {
-        // sum of this Gaussian's tile partials, fixed order
-        const uint32_t tiles = g.tiles_touched[idx];
-        const float4* row = b.slab + (size_t)g.offsets[idx] * SLAB_ROW;
-        for (uint32_t k = 0; k < tiles; k++, row += SLAB_ROW) {
-            const float4 r0 = row[0], r1 = row[1], r2 = row[2];
-            a[0] += r0.x; a[1] += r0.y; a[2] += r0.z; a[3] += r0.w; a[4] += r1.x; a[5] += r1.y; a[6] += r1.z; a[7] += r1.w; a[8] += r2.x;
-        }
         mx = in.means3D[i3]; my = in.means3D[i3 + 1]; mz = in.means3D[i3 + 2];
 
         // ---- computeCov2DCUDA (backward.cu:144-274) ----

@@ -191,12 +191,18 @@ def frame_meta(image_buffer: torch.Tensor) -> torch.Tensor:
     return image_buffer[:META_BYTES]
 
 
-def decode_meta(meta_bytes: torch.Tensor) -> Tuple[int, int]:
-    """64 Meta bytes on the host -> (num_rendered, flags)."""
+def decode_meta_full(meta_bytes: torch.Tensor) -> Tuple[int, int, int, int]:
+    """64 Meta bytes on the host -> (num_rendered, flags, longest tile list, tiles beyond the LDS sort)."""
     import struct
     raw = bytes(meta_bytes.cpu().numpy().tobytes())
-    R, _max_count, _n_overflow, flags = struct.unpack_from("<QIII", raw, 0)
-    return int(R), int(flags)
+    R, max_count, n_overflow, flags = struct.unpack_from("<QIII", raw, 0)
+    return int(R), int(flags), int(max_count), int(n_overflow)
+
+
+def decode_meta(meta_bytes: torch.Tensor) -> Tuple[int, int]:
+    """64 Meta bytes on the host -> (num_rendered, flags)."""
+    R, flags, _m, _o = decode_meta_full(meta_bytes)
+    return R, flags
 
 
 def frame_status(image_buffer: torch.Tensor) -> Tuple[int, int]:

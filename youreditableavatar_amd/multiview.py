@@ -207,7 +207,7 @@ class SyncFreeBatch:
     return_meta=True)`` and returns its ``(image, radii, meta)``; ``upstream(v, image)`` returns dL/d image (it runs
     again for a re-rendered view)."""
 
-    def __init__(self, headroom: float = 1.25, granule: int = 1 << 16, streams: int = 2, deferred: bool = True):
+    def __init__(self, headroom: float = 1.25, granule: int = 1 << 16, streams: int = 4, deferred: bool = True):
         self.headroom, self.granule = float(headroom), int(granule)
         self.bound: Optional[int] = None        # largest num_rendered seen (decays slowly)
         self.rejected = 0                       # frames re-rendered so far
@@ -215,9 +215,10 @@ class SyncFreeBatch:
         self.deferred = bool(deferred)          # one per-Gaussian backward pass for the whole batch (DeferredBackward)
         self._host: Optional[torch.Tensor] = None
         self._side = {}
+        self._cooldown = 0                      # batches to render synchronously after a tile list outgrew the LDS sort
 
     def capacity(self) -> Optional[int]:
-        if self.bound is None:
+        if self.bound is None or self._cooldown > 0:
             return None
         c = int(self.bound * self.headroom) + 1
         return min(0x7fffffff, (c + self.granule - 1) // self.granule * self.granule)
@@ -225,9 +226,12 @@ class SyncFreeBatch:
     def run(self, views: Iterable[int], rasterize: Callable, upstream: Callable[[int, torch.Tensor], torch.Tensor]) -> List[torch.Tensor]:
         """Renders and back-propagates ``views``; returns their images.
 
-        With ``streams=2`` view k runs on stream k % 2, so the forward of view k+1 (binning: L2 atomics and HBM) shares
-        the GPU with the backward of view k (VALU bound).  The backwards stay ordered among themselves -- they add into
-        the same gradient buffers -- and the calling stream waits for everything before ``run`` returns."""
+        View k runs on stream k mod ``streams``: the forward of one view (binning: L2 atomics and HBM) shares the GPU with
+        the render kernels of others (VALU bound), and every kernel's tail is filled by somebody else's work.  With
+        ``deferred`` (default) a view's backward only runs its per-pixel half; the per-Gaussian half of all views is ONE
+        pass at the end (``DeferredBackward``), so the streams never wait for each other.  Without it the backwards are
+        chained by events, because each adds into the same gradient buffers.  The calling stream waits for everything
+        before ``run`` returns."""
         from .diff_gaussian_rasterization import _C
         views = list(views)
         images: List[torch.Tensor] = []
@@ -299,8 +303,14 @@ class SyncFreeBatch:
         ready.synchronize()                                 # the one host wait of the batch
         host = self._host
         seen = 0
+        if self._cooldown > 0:
+            self._cooldown -= 1
         for i, v in enumerate(views):
-            R, flags = _C.decode_meta(host[i])
+            R, flags, _longest, n_overflow = _C.decode_meta_full(host[i])
+            if n_overflow > 0 and cap is not None:
+                # tile lists longer than the LDS sort need host-sized launches: the sync-free forward rejects such frames every
+                # time, so render synchronously for a while before trying again
+                self._cooldown = 16
             if flags & _C.FRAME_PREFILTERED:
                 raise RuntimeError("Point is filtered although prefiltered is set. This shouldn't happen!")
             if flags & _C.FRAME_REJECTED:
