@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--mode", default="sh", choices=["sh", "precomp"])
     ap.add_argument("--views", type=int, default=64)
     ap.add_argument("--streams", type=int, default=4, help="HIP streams the views of a step alternate between (SyncFreeBatch)")
+    ap.add_argument("--per-view-calls", action="store_true", help="drive every view through autograd (SyncFreeBatch.run) instead of the whole-batch path (run_views)")
     ap.add_argument("--sync-per-frame", action="store_true", help="reference protocol: read num_rendered back in every forward")
     ap.add_argument("--no-fused-accumulate", action="store_true", help="let autograd add each view's gradients in a separate pass")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -136,7 +137,10 @@ def main():
 
     def step(s):
         flat.zero_()
-        if batch is not None:       # no host synchronisation per frame: one Meta read-back per step (multiview.SyncFreeBatch)
+        if batch is not None and not a.per_view_calls:
+            # three native calls per step (forward of all views, per-pixel backward of all views, one per-Gaussian backward), one Meta read-back
+            batch.run_views([settings[v] for v in views_of(s)], means3D, opac, shs, scales, rots, lambda images: dL)
+        elif batch is not None:     # the same through autograd, view by view
             batch.run(views_of(s), rasterize, lambda v, img: dL)
         else:
             for v in views_of(s):
@@ -230,6 +234,7 @@ def main():
                        "frames_per_step": N * VPG, "views_per_gpu_per_step": VPG, "fragments_per_frame": int(F_rank / frames_rank),
                        "instances_per_frame": int(Rm), "ms_per_frame_per_gpu": round(ms_per_step / VPG, 4),
                        "host_sync": "one per step (SyncFreeBatch)" if batch is not None else "one per frame (reference protocol)",
+                       "native_calls": ("3 per step (run_views)" if not a.per_view_calls else "per view, through autograd") if batch is not None else "per view",
                        "streams": batch.streams if batch is not None else 1,
                        "per_gaussian_backward": "one pass per step (tgs_backward_batch)" if (batch is not None and batch.deferred) else "one pass per view",
                        "frames_rerendered": batch.rejected if batch is not None else 0,

@@ -184,7 +184,24 @@ typedef struct {
     int64_t R;                 /* what tgs_forward / tgs_forward_async returned for this view */
     float* dL_dmean2D;
     float* dL_dcolor;          /* NULL on the SH path */
+    /* used by the *_views entry points only (NULL / 0 elsewhere) */
+    const float* background;   /* [3] */
+    float* out_color;          /* [3,H,W] */
+    int* radii_out;            /* [P], written by tgs_forward_views (the same memory `radii` points to) */
+    const float* dL_dpix;      /* [3,H,W] */
+    size_t geom_bytes, binning_bytes, img_bytes;   /* capacities of the three caller-allocated state buffers */
 } tgs_view_t;
+/* Whole-batch entry points: one call enqueues the forward (or the per-pixel backward) of every view, view k on
+ * streams[k % n_streams], with state buffers the CALLER allocated up front (tgs_state_sizes) -- no allocation callback, no
+ * read-back, one trip through the host language per batch instead of several per view.  tgs_forward_views is
+ * tgs_forward_async per view (SH path or shared colors_precomp); it fills views[k].R.  The caller orders the streams
+ * against its own work (events) and checks every frame afterwards (tgs_frame_status / the Meta records). */
+void tgs_state_sizes(int P, int width, int height, int has_sh, int has_scale_rot, int64_t r_capacity, size_t sizes3[3]);
+int tgs_forward_views(void* const* streams, int n_streams, int64_t r_capacity, int P, int D, int M,
+                      const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+                      const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                      int prefiltered, int n_views, tgs_view_t* views);
+int tgs_backward_render_views(void* const* streams, int n_streams, int P, int n_views, const tgs_view_t* views);
 int tgs_backward_render(void* stream, int P, int64_t R, const float* background, int width, int height,
                         const void* binning_buffer, const void* img_buffer, const float* dL_dpix);
 int tgs_backward_batch(void* stream, int P, int D, int M, int n_views, const tgs_view_t* views,

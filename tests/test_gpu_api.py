@@ -429,3 +429,60 @@ def test_batched_backward_equals_per_view_backward(gpu_device):
             assert util.rel_l2(again[k].cpu().numpy(), (got[k] + three[k]).cpu().numpy()) <= 1e-6, k
     finally:
         _C.set_deterministic(False)
+
+
+@pytest.mark.parametrize("streams", [1, 3])
+def test_run_views_whole_batch_path(streams, gpu_device):
+    """SyncFreeBatch.run_views (tgs_forward_views / tgs_backward_render_views / tgs_backward_batch: three native calls per
+    batch) == the per-view path: images, per-view dL/d means2D, accumulated parameter gradients; rejected views are redone."""
+    from diff_gaussian_rasterization import _C
+    from youreditableavatar_amd import scenes
+    from youreditableavatar_amd.multiview import FlatGradients, SyncFreeBatch, rasterize_accumulate
+    P = 6000
+    cloud = scenes.make_cloud(P, 3, seed=41, scale_mult=3.0)
+    cams = [scenes.orbit_camera(176, 112, azimuth_deg=a) for a in (0.0, 70.0, 140.0, 210.0, 300.0)]
+    dLs = torch.stack([torch.from_numpy(scenes.upstream_gradient(176, 112, seed=50 + i)) for i in range(5)]).to(gpu_device)
+    names = ("means3D", "opacities", "scales", "rotations", "shs")
+    L = _leaves(cloud, gpu_device)
+    flat = FlatGradients([L[n] for n in names])
+    settings = [_settings(c, 3, gpu_device) for c in cams]
+    _C.set_deterministic(True)
+    try:
+        flat.zero_()
+        want_img, want_2d = [], []
+        for v in range(5):
+            m2 = torch.zeros(P, 3, device=gpu_device, requires_grad=True)
+            img, _ = rasterize_accumulate(settings[v], means3D=L["means3D"], means2D=m2, opacities=L["opacities"], shs=L["shs"], scales=L["scales"],
+                                          rotations=L["rotations"])
+            img.backward(dLs[v])
+            want_img.append(img.detach().clone()); want_2d.append(m2.grad.clone())
+        want = flat.flat.clone()
+        batch = SyncFreeBatch(granule=256, streams=streams)
+        calls = []
+
+        def upstream(images):
+            calls.append(images.shape)
+            return dLs
+
+        run = lambda: batch.run_views(settings, L["means3D"], L["opacities"], L["shs"], L["scales"], L["rotations"], upstream)
+        for rep in range(3):                                # first batch: synchronous (learns the bound); then the whole-batch path, twice (pool reuse)
+            flat.zero_()
+            imgs = run()
+            assert tuple(imgs.shape) == (5, 3, 112, 176)
+            assert all(torch.equal(imgs[v], want_img[v]) for v in range(5)), rep
+            assert all(torch.equal(batch.viewspace_grads[v], want_2d[v]) for v in range(5)), rep
+            assert util.rel_l2(flat.flat.cpu().numpy(), want.cpu().numpy()) <= 2e-5, rep     # two compilations of the same fp32 math (fma contraction): scales / rotations differ by ~5e-6
+        assert batch.rejected == 0 and len(calls) == 3
+        batch.bound = batch.bound // 3                      # some views no longer fit: rejected on the device, rendered again
+        flat.zero_()
+        imgs = run()
+        assert batch.rejected >= 1
+        assert all(torch.equal(imgs[v], want_img[v]) for v in range(5))
+        assert all(torch.equal(batch.viewspace_grads[v], want_2d[v]) for v in range(5))
+        assert util.rel_l2(flat.flat.cpu().numpy(), want.cpu().numpy()) <= 2e-5
+        # one gradient image for all views
+        flat.zero_()
+        run2 = batch.run_views(settings, L["means3D"], L["opacities"], L["shs"], L["scales"], L["rotations"], lambda images: dLs[0])
+        assert torch.isfinite(flat.flat).all() and flat.flat.abs().max() > 0
+    finally:
+        _C.set_deterministic(False)

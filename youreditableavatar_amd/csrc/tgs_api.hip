@@ -381,6 +381,57 @@ int tgs_backward_accumulate(void* stream, int P, int D, int M, int64_t R, const 
                          dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug);
 }
 
+void tgs_state_sizes(int P, int width, int height, int has_sh, int has_scale_rot, int64_t r_capacity, size_t sizes3[3])
+{
+    GeomState g; ImgState s; BinState b;
+    const size_t gx = (size_t)((width + TILE - 1) / TILE), gy = (size_t)((height + TILE - 1) / TILE);
+    sizes3[TGS_BUF_GEOM] = geom_carve(g, nullptr, (size_t)(P > 0 ? P : 0), has_sh != 0, has_scale_rot != 0);
+    sizes3[TGS_BUF_BINNING] = bin_carve(b, nullptr, (size_t)(r_capacity > 0 ? r_capacity : 0));
+    sizes3[TGS_BUF_IMAGE] = img_carve(s, nullptr, (size_t)width * height, gx * gy);
+}
+
+// allocation "callback" of the *_views entry points: hands out the caller's preset buffers
+static void* alloc_preset(void* ctx, int which, size_t bytes)
+{
+    const tgs_view_t* v = (const tgs_view_t*)ctx;
+    if (which == TGS_BUF_GEOM) return bytes <= v->geom_bytes ? const_cast<void*>(v->geom_buffer) : nullptr;
+    if (which == TGS_BUF_BINNING) return bytes <= v->binning_bytes ? const_cast<void*>(v->binning_buffer) : nullptr;
+    if (which == TGS_BUF_IMAGE) return bytes <= v->img_bytes ? const_cast<void*>(v->img_buffer) : nullptr;
+    return nullptr;
+}
+
+int tgs_forward_views(void* const* streams, int n_streams, int64_t r_capacity, int P, int D, int M, const float* means3D, const float* shs,
+                      const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                      const float* cov3D_precomp, int prefiltered, int n_views, tgs_view_t* views)
+{
+    g_err[0] = 0;
+    if (n_views == 0) return TGS_OK;
+    if (!streams || n_streams <= 0 || n_views < 0 || !views || r_capacity < 0) return fail(TGS_ERR_INVALID, "bad arguments");
+    for (int k = 0; k < n_views; k++) {
+        tgs_view_t& v = views[k];
+        if (!v.geom_buffer || !v.binning_buffer || !v.img_buffer || !v.out_color || !v.background)
+            return fail(TGS_ERR_INVALID, "view %d: NULL required pointer", k);
+        const int64_t r = forward_impl(r_capacity, alloc_preset, &v, streams[k % n_streams], P, D, M, v.background, v.width, v.height, means3D, shs,
+                                       colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, v.viewmatrix, v.projmatrix, v.campos,
+                                       v.tan_fovx, v.tan_fovy, prefiltered, v.out_color, v.radii_out, 0);
+        if (r < 0) return (int)r;
+        v.R = r;
+    }
+    return TGS_OK;
+}
+
+int tgs_backward_render_views(void* const* streams, int n_streams, int P, int n_views, const tgs_view_t* views)
+{
+    if (n_views == 0) return TGS_OK;
+    if (!streams || n_streams <= 0 || n_views < 0 || !views) return fail(TGS_ERR_INVALID, "bad arguments");
+    for (int k = 0; k < n_views; k++) {
+        const tgs_view_t& v = views[k];
+        const int r = tgs_backward_render(streams[k % n_streams], P, v.R, v.background, v.width, v.height, v.binning_buffer, v.img_buffer, v.dL_dpix);
+        if (r < 0) return r;
+    }
+    return TGS_OK;
+}
+
 int tgs_backward_render(void* stream, int P, int64_t R, const float* background, int width, int height, const void* binning_buffer,
                         const void* img_buffer, const float* dL_dpix)
 {

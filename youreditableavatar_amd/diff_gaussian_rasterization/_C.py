@@ -43,6 +43,12 @@ def _load() -> C.CDLL:
                                  vp, vp, vp, vp] + [vp] * 9 + [it]
     lib.tgs_backward_accumulate.restype = it
     lib.tgs_backward_accumulate.argtypes = lib.tgs_backward.argtypes
+    lib.tgs_state_sizes.restype = None
+    lib.tgs_state_sizes.argtypes = [it, it, it, it, it, C.c_int64, C.POINTER(C.c_size_t)]
+    lib.tgs_forward_views.restype = it
+    lib.tgs_forward_views.argtypes = [vp, it, C.c_int64, it, it, it, vp, vp, vp, vp, vp, fl, vp, vp, it, it, vp]
+    lib.tgs_backward_render_views.restype = it
+    lib.tgs_backward_render_views.argtypes = [vp, it, it, it, vp]
     lib.tgs_backward_render.restype = it
     lib.tgs_backward_render.argtypes = [vp, it, C.c_int64, vp, it, it, vp, vp, vp]
     lib.tgs_backward_batch.restype = it
@@ -302,7 +308,44 @@ class _ViewT(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("tan_fovx", C.c_float), ("tan_fovy", C.c_float),
                 ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p), ("radii", C.c_void_p),
                 ("geom_buffer", C.c_void_p), ("binning_buffer", C.c_void_p), ("img_buffer", C.c_void_p), ("R", C.c_int64),
-                ("dL_dmean2D", C.c_void_p), ("dL_dcolor", C.c_void_p)]
+                ("dL_dmean2D", C.c_void_p), ("dL_dcolor", C.c_void_p),
+                ("background", C.c_void_p), ("out_color", C.c_void_p), ("radii_out", C.c_void_p), ("dL_dpix", C.c_void_p),
+                ("geom_bytes", C.c_size_t), ("binning_bytes", C.c_size_t), ("img_bytes", C.c_size_t)]
+
+
+ViewArray = lambda n: (_ViewT * n)()
+
+
+def state_sizes(P: int, width: int, height: int, has_sh: bool, has_scale_rot: bool, r_capacity: int) -> Tuple[int, int, int]:
+    """tgs_state_sizes -> bytes of the (geometry, binning, image) state buffers of one view."""
+    out = (C.c_size_t * 3)()
+    _lib.tgs_state_sizes(int(P), int(width), int(height), int(bool(has_sh)), int(bool(has_scale_rot)), int(r_capacity), out)
+    return int(out[0]), int(out[1]), int(out[2])
+
+
+def forward_views(stream_handles, r_capacity, P, D, M, means3D, shs, opacities, scales, scale_modifier, rotations, views, n_views) -> None:
+    """tgs_forward_views on prepared device pointers (ints) and a filled ``ViewArray``."""
+    arr = (C.c_void_p * len(stream_handles))(*stream_handles)
+    r = _lib.tgs_forward_views(arr, len(stream_handles), int(r_capacity), int(P), int(D), int(M), means3D, shs, None, opacities, scales,
+                               float(scale_modifier), rotations, None, 0, int(n_views), C.cast(views, C.c_void_p))
+    if r < 0:
+        raise _err(int(r))
+
+
+def backward_render_views(stream_handles, P, views, n_views) -> None:
+    arr = (C.c_void_p * len(stream_handles))(*stream_handles)
+    r = _lib.tgs_backward_render_views(arr, len(stream_handles), int(P), int(n_views), C.cast(views, C.c_void_p))
+    if r < 0:
+        raise _err(int(r))
+
+
+def backward_batch_raw(stream, P, D, M, views, n_views, means3D, shs, scales, scale_modifier, rotations, dL_dopacity, dL_dmean3D, dL_dsh, dL_dscale,
+                       dL_drot, accumulate) -> None:
+    """tgs_backward_batch on prepared device pointers (SH + scales/rotations path)."""
+    r = _lib.tgs_backward_batch(stream, int(P), int(D), int(M), int(n_views), C.cast(views, C.c_void_p), means3D, shs, scales, float(scale_modifier),
+                                rotations, None, dL_dopacity, dL_dmean3D, None, dL_dsh, dL_dscale, dL_drot, 1 if accumulate else 0)
+    if r < 0:
+        raise _err(int(r))
 
 
 def rasterize_gaussians_backward_render(background, dL_dout_color, R, binningBuffer, imageBuffer, P) -> None:
