@@ -222,7 +222,10 @@ def main():
             ach = alg[dom] / (t_dom * 1e-3) / 1e9
             roof = {"kernel": "k_" + dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "avg_launch_ms": round(t_dom, 4),
-                    "avg_launch_ms_alone": round(kern[dom], 4), "algorithmic_bytes_per_launch": int(alg[dom])}
+                    "avg_launch_ms_alone": round(kern[dom], 4), "algorithmic_bytes_per_launch": int(alg[dom]),
+                    # in the timed region up to `streams` launches of this kernel share the GPU, which stretches each of them; alone = one-stream pass
+                    "achieved_alone": round(alg[dom] / (kern[dom] * 1e-3) / 1e9, 2), "frac_alone": round(alg[dom] / (kern[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "concurrent_streams": batch.streams if batch is not None else 1}
         k_P = (430 + 3 * Cin) if a.mode == "sh" else 412
         B_alg = k_P * P + 124 * Rm + 40 * Npix
         out = {
