@@ -133,3 +133,36 @@ def test_sh_color_requires_gpu_and_a_mode():
         sh_color.points_rgb(torch.zeros(4, 16, 3), 4, positions=torch.zeros(4, 3))
     with pytest.raises(RuntimeError, match="no CPU path"):
         sh_color.points_rgb(torch.zeros(4, 16, 3), 4, directions=torch.zeros(4, 3))
+
+
+def test_sync_free_batch_capacity_policy():
+    """Host logic of multiview.SyncFreeBatch: no bound -> synchronous; headroom and granule rounding; slow decay; cooldown."""
+    from youreditableavatar_amd.multiview import SyncFreeBatch
+    b = SyncFreeBatch(headroom=1.25, granule=1 << 16)
+    assert b.capacity() is None and b.streams == 4 and b.deferred
+    b.bound = 960_000
+    cap = b.capacity()
+    assert cap % (1 << 16) == 0 and 960_000 * 1.25 < cap <= 960_000 * 1.25 + (1 << 16)
+    b.bound = 1 << 40
+    assert b.capacity() == 0x7fffffff                       # the ABI's limit on tile instances
+    b.bound = 1000
+    b._cooldown = 2                                         # after a list outgrew the LDS sort: synchronous for a while
+    assert b.capacity() is None
+    b._cooldown = 0
+    assert b.capacity() == 1 << 16
+
+
+def test_deferred_backward_rejects_mixed_batches():
+    import torch
+    from youreditableavatar_amd.multiview import DeferredBackward
+    from youreditableavatar_amd.diff_gaussian_rasterization import GaussianRasterizationSettings
+    z = torch.zeros
+    rs = lambda deg: GaussianRasterizationSettings(image_height=8, image_width=8, tanfovx=1.0, tanfovy=1.0, bg=z(3), scale_modifier=1.0, viewmatrix=z(4, 4),
+                                                    projmatrix=z(4, 4), sh_degree=deg, campos=z(3), prefiltered=False, debug=False)
+    leaves = dict(means3D=z(4, 3), sh=z(4, 16, 3), colors_precomp=z(0), opacities=z(4, 1), scales=z(4, 3), rotations=z(4, 4), cov3D_precomp=z(0))
+    d = DeferredBackward()
+    d.add(rs(3), leaves, z(4), z(1), z(1), z(1), 0, None)
+    with pytest.raises(RuntimeError):
+        d.add(rs(2), leaves, z(4), z(1), z(1), z(1), 0, None)                      # another SH degree
+    with pytest.raises(RuntimeError):
+        d.add(rs(3), dict(leaves, means3D=z(4, 3)), z(4), z(1), z(1), z(1), 0, None)   # another parameter tensor
