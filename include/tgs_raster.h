@@ -202,6 +202,9 @@ int tgs_forward_views(void* const* streams, int n_streams, int64_t r_capacity, i
                       const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
                       int prefiltered, int n_views, tgs_view_t* views);
 int tgs_backward_render_views(void* const* streams, int n_streams, int P, int n_views, const tgs_view_t* views);
+/* Knob (process-wide): views per launch of the per-Gaussian forward stage inside tgs_forward_views (1..8, default 1).  Groups
+ * read the SH rows once per group; measured, that does not pay when the views overlap on several streams. */
+void tgs_set_forward_group(int views_per_launch);
 int tgs_backward_render(void* stream, int P, int64_t R, const float* background, int width, int height,
                         const void* binning_buffer, const void* img_buffer, const float* dL_dpix);
 int tgs_backward_batch(void* stream, int P, int D, int M, int n_views, const tgs_view_t* views,

@@ -431,8 +431,8 @@ def test_batched_backward_equals_per_view_backward(gpu_device):
         _C.set_deterministic(False)
 
 
-@pytest.mark.parametrize("streams", [1, 3])
-def test_run_views_whole_batch_path(streams, gpu_device):
+@pytest.mark.parametrize("streams,group", [(1, 1), (3, 1), (2, 4)])
+def test_run_views_whole_batch_path(streams, group, gpu_device):
     """SyncFreeBatch.run_views (tgs_forward_views / tgs_backward_render_views / tgs_backward_batch: three native calls per
     batch) == the per-view path: images, per-view dL/d means2D, accumulated parameter gradients; rejected views are redone."""
     from diff_gaussian_rasterization import _C
@@ -447,6 +447,7 @@ def test_run_views_whole_batch_path(streams, gpu_device):
     flat = FlatGradients([L[n] for n in names])
     settings = [_settings(c, 3, gpu_device) for c in cams]
     _C.set_deterministic(True)
+    _C.set_forward_group(group)             # > 1: k_preprocess_fwd_batch serves several views per launch
     try:
         flat.zero_()
         want_img, want_2d = [], []
@@ -486,3 +487,4 @@ def test_run_views_whole_batch_path(streams, gpu_device):
         assert torch.isfinite(flat.flat).all() and flat.flat.abs().max() > 0
     finally:
         _C.set_deterministic(False)
+        _C.set_forward_group(1)

@@ -9,6 +9,7 @@
 
 namespace tgs {
 void launch_preprocess_fwd(hipStream_t, const FwdIn&, const CamParams&, const GeomState&, const ImgState&);
+void launch_preprocess_fwd_batch(hipStream_t, const FwdIn&, const FwdViews&);
 void launch_scan(hipStream_t, const GeomState&, const ImgState&, uint32_t nblocks, uint32_t T, uint32_t sort_cap, unsigned long long r_capacity,
                  int allow_overflow);
 void launch_scatter(hipStream_t, int P, const GeomState&, const ImgState&, const BinState&, uint32_t gx);
@@ -33,6 +34,7 @@ static thread_local char g_err[512] = "";
 // -1: not set by the API -> environment variable TGS_DETERMINISTIC decides (default 0)
 static std::atomic<int> g_deterministic{-1};
 static std::atomic<uint32_t> g_sort_cap{SORT_LDS_CAP};
+static std::atomic<int> g_fwd_group{1};
 static bool deterministic_mode()
 {
     const int v = g_deterministic.load(std::memory_order_relaxed);
@@ -133,6 +135,11 @@ extern "C" {
 
 int tgs_abi_version(void) { return TGS_ABI_VERSION; }
 
+void tgs_set_forward_group(int views_per_launch)
+{
+    g_fwd_group.store(views_per_launch < 1 ? 1 : (views_per_launch > BATCH_VIEWS ? BATCH_VIEWS : views_per_launch), std::memory_order_relaxed);
+}
+
 int tgs_set_sort_lds_cap(unsigned cap)
 {
     if (cap < 2 || cap > SORT_LDS_CAP || (cap & (cap - 1))) return fail(TGS_ERR_INVALID, "sort cap must be a power of two in [2, %u]", SORT_LDS_CAP);
@@ -185,7 +192,7 @@ const char* tgs_last_error(void) { return g_err; }
 
 // r_capacity < 0: the reference's protocol (read R back, then size the binning buffer).  r_capacity >= 0: sync-free --
 // the binning buffer is sized for r_capacity instances before anything runs and nothing is read back.
-static int64_t forward_impl(int64_t r_capacity, tgs_alloc_fn alloc, void* alloc_ctx, void* stream, int P, int D, int M, const float* background, int width,
+static int64_t forward_impl(int preprocessed, int64_t r_capacity, tgs_alloc_fn alloc, void* alloc_ctx, void* stream, int P, int D, int M, const float* background, int width,
                     int height, const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
                     const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
                     const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
@@ -232,7 +239,8 @@ static int64_t forward_impl(int64_t r_capacity, tgs_alloc_fn alloc, void* alloc_
     img_carve(s, img_ptr, N, T);
 
     // meta + ranges + tile_count are contiguous at the head of the image buffer: one memset
-    HIP_TRY(hipMemsetAsync(img_ptr, 0, (size_t)((char*)s.cursor - img_ptr), st));
+    // (preprocessed: tgs_forward_views has cleared them and run the per-Gaussian stage for all views at once)
+    if (!preprocessed) HIP_TRY(hipMemsetAsync(img_ptr, 0, (size_t)((char*)s.cursor - img_ptr), st));
 
     FwdIn in;
     in.P = P; in.D = D; in.M = M; in.means3D = means3D; in.shs = shs; in.colors_precomp = colors_precomp; in.opacities = opacities;
@@ -242,9 +250,11 @@ static int64_t forward_impl(int64_t r_capacity, tgs_alloc_fn alloc, void* alloc_
     uint64_t R = 0;
     Meta meta;
     memset(&meta, 0, sizeof(meta));
-    STAGE_BEGIN(TGS_STAGE_PREPROCESS_FWD);
-    launch_preprocess_fwd(st, in, cam, g, s);
-    STAGE_CHECK("preprocess", TGS_STAGE_PREPROCESS_FWD);
+    if (!preprocessed) {
+        STAGE_BEGIN(TGS_STAGE_PREPROCESS_FWD);
+        launch_preprocess_fwd(st, in, cam, g, s);
+        STAGE_CHECK("preprocess", TGS_STAGE_PREPROCESS_FWD);
+    }
     STAGE_BEGIN(TGS_STAGE_SCAN);
     launch_scan(st, g, s, (uint32_t)n_blocks((size_t)P), (uint32_t)T, sort_cap, async ? (unsigned long long)r_capacity : ~0ull, async ? 0 : 1);
     STAGE_CHECK("scan", TGS_STAGE_SCAN);
@@ -284,7 +294,7 @@ int64_t tgs_forward(tgs_alloc_fn alloc, void* alloc_ctx, void* stream, int P, in
                     const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
                     int prefiltered, float* out_color, int* radii, int debug)
 {
-    return forward_impl(-1, alloc, alloc_ctx, stream, P, D, M, background, width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
+    return forward_impl(0, -1, alloc, alloc_ctx, stream, P, D, M, background, width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
                         rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, radii, debug);
 }
 
@@ -295,7 +305,7 @@ int64_t tgs_forward_async(int64_t r_capacity, tgs_alloc_fn alloc, void* alloc_ct
                           int prefiltered, float* out_color, int* radii, int debug)
 {
     if (r_capacity < 0) return fail(TGS_ERR_INVALID, "r_capacity must be >= 0");
-    return forward_impl(r_capacity, alloc, alloc_ctx, stream, P, D, M, background, width, height, means3D, shs, colors_precomp, opacities, scales,
+    return forward_impl(0, r_capacity, alloc, alloc_ctx, stream, P, D, M, background, width, height, means3D, shs, colors_precomp, opacities, scales,
                         scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, radii, debug);
 }
 
@@ -407,15 +417,70 @@ int tgs_forward_views(void* const* streams, int n_streams, int64_t r_capacity, i
     g_err[0] = 0;
     if (n_views == 0) return TGS_OK;
     if (!streams || n_streams <= 0 || n_views < 0 || !views || r_capacity < 0) return fail(TGS_ERR_INVALID, "bad arguments");
-    for (int k = 0; k < n_views; k++) {
-        tgs_view_t& v = views[k];
-        if (!v.geom_buffer || !v.binning_buffer || !v.img_buffer || !v.out_color || !v.background)
-            return fail(TGS_ERR_INVALID, "view %d: NULL required pointer", k);
-        const int64_t r = forward_impl(r_capacity, alloc_preset, &v, streams[k % n_streams], P, D, M, v.background, v.width, v.height, means3D, shs,
-                                       colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, v.viewmatrix, v.projmatrix, v.campos,
-                                       v.tan_fovx, v.tan_fovy, prefiltered, v.out_color, v.radii_out, 0);
-        if (r < 0) return (int)r;
-        v.R = r;
+    const int debug = 0;
+    const bool has_sh = shs != nullptr, has_sr = scales != nullptr && rotations != nullptr;
+    // views that can share the per-Gaussian stage: same model, the usual case (P > 0, all pointers there; the rest is
+    // validated by forward_impl below)
+    // Views per launch of the shared per-Gaussian stage (tgs_set_forward_group; default 1 = every view runs its own).  More
+    // views per launch read the SH rows fewer times (0.57 ms for 8 views against 8 x 0.106), but the views of a group start
+    // their remaining stages together and the launch itself is bound by the L2 atomic units with the CUs mostly idle;
+    // measured at 4 streams the forward phase is 0.249 / 0.255 / 0.262 / 0.259 ms per frame for groups of 1 / 2 / 4 / 8.
+    const int group = g_fwd_group.load(std::memory_order_relaxed);
+    const bool batched = group > 1 && n_views > 1 && P > 0 && means3D && opacities && ((shs == nullptr) != (colors_precomp == nullptr)) && (has_sr != (cov3D_precomp != nullptr)) &&
+                         (!has_sh || (D >= 0 && D <= 3 && M >= (D + 1) * (D + 1)));
+    for (int v0 = 0; v0 < n_views; v0 += group) {
+        const int nv = n_views - v0 < group ? n_views - v0 : group;
+        hipStream_t st0 = (hipStream_t)streams[v0 % n_streams];
+        hipEvent_t pre_done = nullptr;
+        for (int k = 0; k < nv; k++) {
+            const tgs_view_t& v = views[v0 + k];
+            if (!v.geom_buffer || !v.binning_buffer || !v.img_buffer || !v.out_color || !v.background || !v.viewmatrix || !v.projmatrix || !v.campos ||
+                v.width <= 0 || v.height <= 0)
+                return fail(TGS_ERR_INVALID, "view %d: bad sizes or NULL required pointer", v0 + k);
+        }
+        if (batched) {
+            FwdIn in;
+            memset(&in, 0, sizeof(in));
+            in.P = P; in.D = D; in.M = M; in.means3D = means3D; in.shs = shs; in.colors_precomp = colors_precomp; in.opacities = opacities;
+            in.scales = scales; in.rotations = rotations; in.cov3D_precomp = cov3D_precomp; in.prefiltered = prefiltered;
+            FwdViews fv;
+            memset(&fv, 0, sizeof(fv));
+            fv.n = nv;
+            for (int k = 0; k < nv; k++) {
+                const tgs_view_t& v = views[v0 + k];
+                FwdView& o = fv.v[k];
+                o.cam = make_cam(v.viewmatrix, v.projmatrix, v.campos, v.tan_fovx, v.tan_fovy, scale_modifier, v.width, v.height);
+                if (o.cam.gx > 65535u || o.cam.gy > 65535u) return fail(TGS_ERR_INVALID, "image too large");
+                const size_t N = (size_t)v.width * v.height, T = (size_t)o.cam.gx * o.cam.gy;
+                if (geom_carve(o.g, nullptr, (size_t)P, has_sh, has_sr) > v.geom_bytes || img_carve(o.s, nullptr, N, T) > v.img_bytes)
+                    return fail(TGS_ERR_ALLOC, "view %d: state buffers smaller than tgs_state_sizes()", v0 + k);
+                geom_carve(o.g, (char*)v.geom_buffer, (size_t)P, has_sh, has_sr);
+                img_carve(o.s, (char*)v.img_buffer, N, T);
+                o.radii = v.radii_out;
+                HIP_TRY(hipMemsetAsync((void*)v.img_buffer, 0, (size_t)((char*)o.s.cursor - (char*)v.img_buffer), st0));
+            }
+            {
+                hipStream_t st = st0;
+                STAGE_BEGIN(TGS_STAGE_PREPROCESS_FWD);
+                launch_preprocess_fwd_batch(st, in, fv);
+                STAGE_CHECK("preprocess_batch", TGS_STAGE_PREPROCESS_FWD);
+            }
+            if (n_streams > 1) {
+                HIP_TRY(hipEventCreateWithFlags(&pre_done, hipEventDisableTiming));
+                HIP_TRY(hipEventRecord(pre_done, st0));
+            }
+        }
+        for (int k = 0; k < nv; k++) {
+            tgs_view_t& v = views[v0 + k];
+            hipStream_t st = (hipStream_t)streams[(v0 + k) % n_streams];
+            if (pre_done && st != st0) HIP_TRY(hipStreamWaitEvent(st, pre_done, 0));
+            const int64_t r = forward_impl(batched ? 1 : 0, r_capacity, alloc_preset, &v, st, P, D, M, v.background, v.width, v.height, means3D, shs, colors_precomp,
+                                           opacities, scales, scale_modifier, rotations, cov3D_precomp, v.viewmatrix, v.projmatrix, v.campos, v.tan_fovx, v.tan_fovy,
+                                           prefiltered, v.out_color, v.radii_out, 0);
+            if (r < 0) { if (pre_done) (void)hipEventDestroy(pre_done); return (int)r; }
+            v.R = r;
+        }
+        if (pre_done) (void)hipEventDestroy(pre_done);
     }
     return TGS_OK;
 }

@@ -647,5 +647,13 @@ struct BatchView {
     float* dL_dcolor;    // [P,3] of this view (colors_precomp path) or nullptr
 };
 struct BatchViews { int n; BatchView v[BATCH_VIEWS]; };
+// One view of a batch for k_preprocess_fwd_batch
+struct FwdView {
+    CamParams cam;
+    GeomState g;
+    ImgState s;
+    int* radii;
+};
+struct FwdViews { int n; FwdView v[BATCH_VIEWS]; };
 
 }  // namespace tgs

@@ -22,25 +22,15 @@ namespace tgs {
 // ---------------------------------------------------------------------------------------------
 // k_preprocess_fwd
 // ---------------------------------------------------------------------------------------------
+// One Gaussian of one view: projection, EWA covariance, SH colour, tile rectangle, the 64-B pack line, and the per-tile
+// instance count whose returned values are the instance's ranks.  Shared by the one-view and the all-views kernel.
 template <bool HAS_SH, bool HAS_SCALE_ROT>
-__global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd(const FwdIn in, const CamParams cam, const GeomState g,
-                                                              const ImgState s)
+__device__ __forceinline__ uint32_t preprocess_fwd_one(const FwdIn& in, int* __restrict__ radii, const CamParams& cam, const GeomState& g, const ImgState& s,
+                                                       const float4* sh_lds, bool sh_staged, int idx)
 {
-    const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
     uint32_t tiles = 0;
     const ViewMat V = load_mat(cam.view), PM = load_mat(cam.proj);      // uniform -> scalar loads, before any store
     const float camx = cam.campos[0], camy = cam.campos[1], camz = cam.campos[2];
-    // SH rows of the workgroup's 256 Gaussians (M = 16: 192 B each, 48 KB in all) are fetched with fully coalesced
-    // 16-B-per-lane loads into LDS; a per-thread walk over its own 192-B row would touch 64 lines per instruction.
-    __shared__ float4 sh_lds[HAS_SH ? PRE_BLOCK * 12 : 1];
-    const bool sh_staged = HAS_SH && in.M == 16;
-    if (sh_staged) {
-        const float4* s4 = reinterpret_cast<const float4*>(in.shs);
-        const size_t base4 = (size_t)blockIdx.x * PRE_BLOCK * 12, total4 = (size_t)in.P * 12;
-#pragma unroll
-        for (int q = 0; q < 12; q++) { const size_t i = base4 + q * PRE_BLOCK + threadIdx.x; if (i < total4) sh_lds[q * PRE_BLOCK + threadIdx.x] = s4[i]; }
-        __syncthreads();
-    }
     if (idx < in.P) {
         int my_radius_i = 0;
         uint32_t minx = 0, miny = 0, maxx = 0, maxy = 0;
@@ -162,16 +152,62 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd(const FwdIn in, co
                 }
             }
         }
-        if (in.radii) in.radii[idx] = my_radius_i;
+        if (radii) radii[idx] = my_radius_i;
         g.tiles_touched[idx] = tiles;
         g.rect[idx] = make_ushort4((unsigned short)minx, (unsigned short)miny, (unsigned short)maxx, (unsigned short)maxy);
     }
-    // per-block sum of tiles_touched (first level of the offsets scan)
+    return tiles;
+}
+
+// per-block sum of tiles_touched (first level of the offsets scan)
+__device__ __forceinline__ void block_sum_tiles(uint32_t tiles, uint32_t* __restrict__ block_sums)
+{
     __shared__ uint32_t wsum[PRE_BLOCK / WAVE];
     const uint32_t w = wave_sum_u32(tiles);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = w;
     __syncthreads();
-    if (threadIdx.x == 0) g.block_sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// SH rows of the workgroup's 256 Gaussians (M = 16: 192 B each, 48 KB in all) are fetched with fully coalesced
+// 16-B-per-lane loads into LDS; a per-thread walk over its own 192-B row would touch 64 lines per instruction.
+__device__ __forceinline__ void stage_sh_rows(const FwdIn& in, float4* sh_lds)
+{
+    const float4* s4 = reinterpret_cast<const float4*>(in.shs);
+    const size_t base4 = (size_t)blockIdx.x * PRE_BLOCK * 12, total4 = (size_t)in.P * 12;
+#pragma unroll
+    for (int q = 0; q < 12; q++) { const size_t i = base4 + q * PRE_BLOCK + threadIdx.x; if (i < total4) sh_lds[q * PRE_BLOCK + threadIdx.x] = s4[i]; }
+    __syncthreads();
+}
+
+template <bool HAS_SH, bool HAS_SCALE_ROT>
+__global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd(const FwdIn in, const CamParams cam, const GeomState g,
+                                                              const ImgState s)
+{
+    const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
+    __shared__ float4 sh_lds[HAS_SH ? PRE_BLOCK * 12 : 1];
+    const bool sh_staged = HAS_SH && in.M == 16;
+    if (sh_staged) stage_sh_rows(in, sh_lds);
+    const uint32_t tiles = preprocess_fwd_one<HAS_SH, HAS_SCALE_ROT>(in, in.radii, cam, g, s, sh_lds, sh_staged, idx);
+    block_sum_tiles(tiles, g.block_sums);
+}
+
+// All views of a batch in one launch (tgs_forward_views): the 192-B SH row -- 80 % of what the kernel reads -- is
+// staged once and every view then projects, colours and counts from it.
+template <bool HAS_SH, bool HAS_SCALE_ROT>
+__global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd_batch(const FwdIn in, const FwdViews views)
+{
+    const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
+    __shared__ float4 sh_lds[HAS_SH ? PRE_BLOCK * 12 : 1];
+    const bool sh_staged = HAS_SH && in.M == 16;
+    if (sh_staged) stage_sh_rows(in, sh_lds);
+#pragma unroll 1
+    for (int v = 0; v < views.n; v++) {
+        const FwdView& vw = views.v[v];
+        const uint32_t tiles = preprocess_fwd_one<HAS_SH, HAS_SCALE_ROT>(in, vw.radii, vw.cam, vw.g, vw.s, sh_lds, sh_staged, idx);
+        block_sum_tiles(tiles, vw.g.block_sums);
+        __syncthreads();                                   // wsum is reused by the next view
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -744,6 +780,15 @@ void launch_preprocess_fwd(hipStream_t st, const FwdIn& in, const CamParams& cam
     else if (sh) hipLaunchKernelGGL((k_preprocess_fwd<true, false>), grid, blk, 0, st, in, cam, g, s);
     else if (sr) hipLaunchKernelGGL((k_preprocess_fwd<false, true>), grid, blk, 0, st, in, cam, g, s);
     else hipLaunchKernelGGL((k_preprocess_fwd<false, false>), grid, blk, 0, st, in, cam, g, s);
+}
+void launch_preprocess_fwd_batch(hipStream_t st, const FwdIn& in, const FwdViews& views)
+{
+    const dim3 grid((unsigned)n_blocks(in.P)), blk(PRE_BLOCK);
+    const bool sh = in.colors_precomp == nullptr, sr = in.cov3D_precomp == nullptr;
+    if (sh && sr) hipLaunchKernelGGL((k_preprocess_fwd_batch<true, true>), grid, blk, 0, st, in, views);
+    else if (sh) hipLaunchKernelGGL((k_preprocess_fwd_batch<true, false>), grid, blk, 0, st, in, views);
+    else if (sr) hipLaunchKernelGGL((k_preprocess_fwd_batch<false, true>), grid, blk, 0, st, in, views);
+    else hipLaunchKernelGGL((k_preprocess_fwd_batch<false, false>), grid, blk, 0, st, in, views);
 }
 void launch_scan(hipStream_t st, const GeomState& g, const ImgState& s, uint32_t nblocks, uint32_t T, uint32_t sort_cap, unsigned long long r_capacity,
                  int allow_overflow)

@@ -59,6 +59,8 @@ def _load() -> C.CDLL:
     lib.tgs_state_field.argtypes = [vp, C.c_char_p, it, it, it, C.c_int64, it, it, vp, vp, vp, vp, C.c_size_t]
     lib.tgs_set_sort_lds_cap.restype = it
     lib.tgs_set_sort_lds_cap.argtypes = [C.c_uint]
+    lib.tgs_set_forward_group.restype = None
+    lib.tgs_set_forward_group.argtypes = [it]
     lib.tgs_set_deterministic.restype = None
     lib.tgs_set_deterministic.argtypes = [it]
     lib.tgs_selftest_reduce36.restype = it
@@ -80,6 +82,11 @@ def set_sort_lds_cap(cap: int) -> None:
     """Test knob: tile lists longer than ``cap`` (power of two <= 8192) take the global-memory sort path."""
     if _lib.tgs_set_sort_lds_cap(int(cap)) < 0:
         raise _err(-1)
+
+
+def set_forward_group(views_per_launch: int) -> None:
+    """Views per launch of the per-Gaussian forward stage inside forward_views (1..8; default 1)."""
+    _lib.tgs_set_forward_group(int(views_per_launch))
 
 
 def set_deterministic(on: bool) -> None:
