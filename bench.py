@@ -136,11 +136,14 @@ def main():
     flat = FlatGradients(params)            # parameter .grad tensors are views of one buffer: one collective per step
 
     def step(s):
-        flat.zero_()
         if batch is not None and not a.per_view_calls:
-            # three native calls per step (forward of all views, per-pixel backward of all views, one per-Gaussian backward), one Meta read-back
-            batch.run_views([settings[v] for v in views_of(s)], means3D, opac, shs, scales, rots, lambda images: dL)
-        elif batch is not None:     # the same through autograd, view by view
+            # three native calls per step (forward of all views, per-pixel backward of all views, one per-Gaussian backward), one Meta read-back;
+            # the one per-Gaussian pass of the step STORES the gradients, so the flat buffer needs no zeroing
+            batch.run_views([settings[v] for v in views_of(s)], means3D, opac, shs, scales, rots, lambda images: dL, accumulate=False)
+            flat.all_reduce()
+            return
+        flat.zero_()
+        if batch is not None:       # the same through autograd, view by view
             batch.run(views_of(s), rasterize, lambda v, img: dL)
         else:
             for v in views_of(s):

@@ -481,6 +481,10 @@ def test_run_views_whole_batch_path(streams, group, gpu_device):
         assert all(torch.equal(imgs[v], want_img[v]) for v in range(5))
         assert all(torch.equal(batch.viewspace_grads[v], want_2d[v]) for v in range(5))
         assert util.rel_l2(flat.flat.cpu().numpy(), want.cpu().numpy()) <= 2e-5
+        # accumulate=False stores: whatever the buffers held is gone
+        flat.flat.fill_(5.0)
+        batch.run_views(settings, L["means3D"], L["opacities"], L["shs"], L["scales"], L["rotations"], upstream, accumulate=False)
+        assert util.rel_l2(flat.flat.cpu().numpy(), want.cpu().numpy()) <= 2e-5
         # one gradient image for all views
         flat.zero_()
         run2 = batch.run_views(settings, L["means3D"], L["opacities"], L["shs"], L["scales"], L["rotations"], lambda images: dLs[0])

@@ -231,12 +231,13 @@ class SyncFreeBatch:
     # launch time per frame -- as much as the GPU needs for the frame once the views overlap on several streams.
     # ------------------------------------------------------------------------------------------------------------------
     def run_views(self, settings: Sequence, means3D: torch.Tensor, opacities: torch.Tensor, shs: torch.Tensor, scales: torch.Tensor,
-                  rotations: torch.Tensor, upstream_batch: Callable[[torch.Tensor], torch.Tensor]) -> torch.Tensor:
+                  rotations: torch.Tensor, upstream_batch: Callable[[torch.Tensor], torch.Tensor], accumulate: bool = True) -> torch.Tensor:
         """Renders the views described by ``settings`` (GaussianRasterizationSettings, same image size, SH degree and scale
         modifier) of one Gaussian model (leaf parameters with allocated ``.grad``, SH colours, scales + rotations), calls
         ``upstream_batch(images[V,3,H,W]) -> dL/d images`` ([V,3,H,W], or [3,H,W] for all views) ONCE, and adds the
-        gradients of all views into the parameters' ``.grad``.  Returns the images -- a view of a buffer the next call
-        reuses; ``self.viewspace_grads`` [V,P,3] holds dL/d means2D per view."""
+        gradients of all views into the parameters' ``.grad`` (``accumulate=False``: overwrites them instead -- the
+        step then needs no zeroing pass and the batch kernel no read of the old values).  Returns the images -- a view
+        of a buffer the next call reuses; ``self.viewspace_grads`` [V,P,3] holds dL/d means2D per view."""
         from .diff_gaussian_rasterization import _C
         V = len(settings)
         rs0 = settings[0]
@@ -274,6 +275,9 @@ class SyncFreeBatch:
             return dL if dL.dim() == 3 else dL[v]
 
         if cap is None:                                     # no bound yet (or cooling down after an LDS-sort overflow): synchronous frames
+            if not accumulate:
+                for t in params.values():
+                    t.grad.zero_()
             states = per_view_fallback(range(V), None)
             images = torch.stack([states[v][1] for v in range(V)])
             dL = upstream_batch(images)
@@ -347,7 +351,7 @@ class SyncFreeBatch:
             join()
             _C.backward_batch_raw(main.cuda_stream, P, D, M, arr, V, means3D.data_ptr(), shs.data_ptr(), scales.data_ptr(), rs0.scale_modifier,
                                   rotations.data_ptr(), opacities.grad.data_ptr(), means3D.grad.data_ptr(), shs.grad.data_ptr(), scales.grad.data_ptr(),
-                                  rotations.grad.data_ptr(), True)
+                                  rotations.grad.data_ptr(), accumulate)
         self.viewspace_grads = pool["g2d"]
         ready.synchronize()                                 # the one host wait of the batch
         seen = 0
