@@ -118,19 +118,27 @@ def main():
         b0 = step * N * VPG + rank * VPG
         return [(b0 + i) % V for i in range(VPG)]
 
-    # fragment / instance counts of the views this rank will time (outside the timed region)
+    # fragment / instance counts of the views this rank will time (outside the timed region).  F = sum of n_contrib as the
+    # REFERENCE's state defines it (positions in the full 3-sigma-rectangle lists), so instance pruning is off
+    # for this count; R_binned is what the timed path really bins.
     used = sorted({v for s in range(a.steps) for v in views_of(s)})
-    F_view, R_view = {}, {}
+    F_view, R_view, Rb_view = {}, {}, {}
     empty = torch.Tensor([])
-    for v in used:
-        rs = settings[v]
-        R, color, radii, geom, binning, img = _C.rasterize_gaussians(rs.bg, means3D.detach(), empty, opac.detach(), scales.detach(), rots.detach(), 1.0,
-                                                                   empty, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, H, W, shs.detach(), D,
-                                                                   rs.campos, False, False)
-        nc = _C.state_field("n_contrib", P, W, H, R, True, True, geom, binning, img)
-        F_view[v] = int(nc.to(torch.int64).sum().item())
-        R_view[v] = int(R)
-        del geom, binning, img, color, radii, nc
+    for prune in (False, True):
+        _C.set_instance_pruning(prune)
+        for v in used:
+            rs = settings[v]
+            R, color, radii, geom, binning, img = _C.rasterize_gaussians(rs.bg, means3D.detach(), empty, opac.detach(), scales.detach(), rots.detach(), 1.0,
+                                                                       empty, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, H, W, shs.detach(), D,
+                                                                       rs.campos, False, False)
+            if prune:
+                Rb_view[v] = int(R)
+            else:
+                nc = _C.state_field("n_contrib", P, W, H, R, True, True, geom, binning, img)
+                F_view[v] = int(nc.to(torch.int64).sum().item())
+                R_view[v] = int(R)
+                del nc
+            del geom, binning, img, color, radii
     torch.cuda.synchronize()
 
     flat = FlatGradients(params)            # parameter .grad tensors are views of one buffer: one collective per step
@@ -238,7 +246,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"cfg{a.config}: {P} Gaussians, {W}x{H}, SH degree {D}, colour mode {a.mode}, {V}-view orbit, {VPG} frames per GPU per step",
                        "frames_per_step": N * VPG, "views_per_gpu_per_step": VPG, "fragments_per_frame": int(F_rank / frames_rank),
-                       "instances_per_frame": int(Rm), "ms_per_frame_per_gpu": round(ms_per_step / VPG, 4),
+                       "instances_per_frame": int(Rm), "instances_binned_per_frame": int(sum(Rb_view[v] for s in range(a.steps) for v in views_of(s)) / frames_rank), "ms_per_frame_per_gpu": round(ms_per_step / VPG, 4),
                        "host_sync": "one per step (SyncFreeBatch)" if batch is not None else "one per frame (reference protocol)",
                        "native_calls": ("3 per step (run_views)" if not a.per_view_calls else "per view, through autograd") if batch is not None else "per view",
                        "streams": batch.streams if batch is not None else 1,

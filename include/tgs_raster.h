@@ -202,6 +202,11 @@ int tgs_forward_views(void* const* streams, int n_streams, int64_t r_capacity, i
                       const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
                       int prefiltered, int n_views, tgs_view_t* views);
 int tgs_backward_render_views(void* const* streams, int n_streams, int P, int n_views, const tgs_view_t* views);
+/* Knob (process-wide, default on): a splat gets no tile instance in a tile of its 3-sigma rectangle where it stays below
+ * alpha = 1/255 on every pixel (the reference creates the instance, rasterizer_impl.cu:98-109, and skips it pixel by pixel,
+ * forward.cu:340-343).  Images and gradients do not change; num_rendered and the internal n_contrib (a list position) do.
+ * Off = the reference's instance lists, e.g. to count fragments the way the reference's state defines them. */
+void tgs_set_instance_pruning(int on);
 /* Knob (process-wide): views per launch of the per-Gaussian forward stage inside tgs_forward_views (1..8, default 1).  Groups
  * read the SH rows once per group; measured, that does not pay when the views overlap on several streams. */
 void tgs_set_forward_group(int views_per_launch);

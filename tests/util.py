@@ -120,47 +120,94 @@ def hip_run(inp: dict, dL: Optional[np.ndarray] = None, device="cuda:0", debug=F
     return out
 
 
+def _alpha_max_in_tile(ref: dict, ids: np.ndarray, tile: int, gx: int) -> np.ndarray:
+    """max over the 256 pixel centres of a tile of the alpha each Gaussian of ``ids`` would get there (float64;
+    forward.cu:333-343: power > 0 and alpha < 1/255 are skipped)"""
+    m2 = np.asarray(ref["means2D"], np.float64).reshape(-1, 2)[ids]
+    co = np.asarray(ref["conic_opacity"], np.float64).reshape(-1, 4)[ids]
+    px = (tile % gx) * 16 + np.arange(16, dtype=np.float64)
+    py = (tile // gx) * 16 + np.arange(16, dtype=np.float64)
+    dx = m2[:, 0, None, None] - px[None, None, :]
+    dy = m2[:, 1, None, None] - py[None, :, None]
+    power = -0.5 * (co[:, 0, None, None] * dx * dx + co[:, 2, None, None] * dy * dy) - co[:, 1, None, None] * dx * dy
+    alpha = np.where(power > 0, 0.0, np.minimum(0.99, co[:, 3, None, None] * np.exp(np.minimum(power, 0.0))))
+    return alpha.reshape(len(ids), -1).max(axis=1)
+
+
 def check_point_lists(mine: dict, ref: dict, rep: dict):
-    """Per-tile lists: same members in every tile, and sorted by (my own fp32 depth, index).  Exact
-    equality with the reference order is required wherever the depths agree bitwise; a last-bit
-    difference in view-space z (FMA contraction) may legitimately swap two near-coincident entries."""
+    """Per-tile lists.  The HIP path gives a splat no instance in a tile of its 3-sigma rectangle where it stays below
+    alpha = 1/255 on every pixel (the reference creates the instance and skips it pixel by pixel, forward.cu:340-343), so
+    a tile's list must be the reference's list minus entries that provably cannot contribute, in the same order: sorted by
+    (my own fp32 depth, index), and equal to the reference order wherever the depths agree bitwise (a last-bit difference
+    in view-space z -- FMA contraction -- may legitimately swap two near-coincident entries)."""
     a, b = np.asarray(mine["point_list"]), np.asarray(ref["point_list"])
-    if np.array_equal(a, b):
-        rep["lists_equal"] = 1.0
-        return
-    rg = np.asarray(ref["ranges"]).reshape(-1, 2)
-    mrg = np.asarray(mine["ranges"]).reshape(-1, 2)
-    ne = rg[:, 1] > rg[:, 0]
-    assert np.array_equal(mrg[ne], rg[ne]), "tile ranges differ"
+    rg = np.asarray(ref["ranges"]).reshape(-1, 2).astype(np.int64)
+    mrg = np.asarray(mine["ranges"]).reshape(-1, 2).astype(np.int64)
+    H, W = ref["n_contrib"].shape
+    gx = (W + 15) // 16
     dm = np.asarray(mine["depths"]).view(np.uint32).astype(np.uint64)
     dr = np.asarray(ref["depths"]).view(np.uint32).astype(np.uint64)
-    for s0, s1 in rg[ne]:
-        la, lb = a[s0:s1], b[s0:s1]
-        if np.array_equal(la, lb):
+    dropped = same = 0
+    for t in range(rg.shape[0]):
+        lb = b[rg[t, 0]:rg[t, 1]]
+        la = a[mrg[t, 0]:mrg[t, 1]] if mrg[t, 1] > mrg[t, 0] else a[:0]
+        if len(lb) == 0:
+            assert len(la) == 0, "an instance in a tile the reference leaves empty"
             continue
-        assert np.array_equal(np.sort(la), np.sort(lb)), "a tile's list has different members"
+        keep = np.isin(lb, la)
+        assert len(la) == int(keep.sum()) and np.array_equal(np.sort(la), np.sort(lb[keep])), "a tile's list is not a subset of the reference's"
+        gone = lb[~keep]
+        if len(gone):
+            amax = _alpha_max_in_tile(ref, gone, t, gx)
+            assert np.all(amax < (1.0 / 255.0) * (1.0 - 1e-3)), f"tile {t}: dropped an instance that reaches alpha {amax.max():.6f}"
+            dropped += len(gone)
+        lbk = lb[keep]
+        if np.array_equal(la, lbk):
+            same += len(la)
+            continue
         ka = (dm[la] << np.uint64(32)) | la.astype(np.uint64)
         assert np.all(ka[1:] > ka[:-1]), "a tile's list is not sorted by (depth, index)"
-        diff = la != lb
+        diff = la != lbk
         assert np.all(dm[la[diff]] != dr[la[diff]]) or np.all(np.abs(dm[la[diff]].astype(np.int64) - dr[la[diff]].astype(np.int64)) <= 2), \
             "order differs although depths agree"
-    rep["lists_equal"] = float((a == b).mean())
+        same += int((~diff).sum())
+    assert int(mine["num_rendered"]) == len(b) - dropped == len(a), "num_rendered is not the reference's minus the non-contributing instances"
+    rep["lists_equal"] = same / len(a) if len(a) else 1.0
+    rep["instances_dropped"] = dropped / max(len(b), 1)
     assert rep["lists_equal"] > 0.99
+    if "tiles_touched" in mine and "tiles_touched" in ref:
+        tm, tr = np.asarray(mine["tiles_touched"]).astype(np.int64), np.asarray(ref["tiles_touched"]).astype(np.int64)
+        assert np.all(tm <= tr) and tm.sum() == len(a)
+
+
+def last_contributor_ids(d: dict) -> np.ndarray:
+    """Gaussian id of the last entry blended into each pixel (-1: none) from n_contrib, ranges and point_list."""
+    nc = np.asarray(d["n_contrib"]).astype(np.int64)
+    H, W = nc.shape
+    gx = (W + 15) // 16
+    start = np.asarray(d["ranges"]).reshape(-1, 2).astype(np.int64)[:, 0]
+    yy, xx = np.mgrid[0:H, 0:W]
+    tile = (yy // 16) * gx + xx // 16
+    pl = np.asarray(d["point_list"]).astype(np.int64)
+    pos = np.clip(start[tile] + nc - 1, 0, max(len(pl) - 1, 0))
+    return np.where(nc > 0, pl[pos] if len(pl) else -1, -1)
 
 
 def compare(mine: dict, ref: dict, golden_out: Optional[dict] = None, nc_frac: float = 0.999, check_lists: bool = True):
     """Asserts the SURVEY.md section 8d parity bar; returns {tensor: rel_l2} for reporting."""
     H, W = ref["n_contrib"].shape
     rep = {}
-    assert int(mine["num_rendered"]) == int(ref["num_rendered"]), "num_rendered differs"
+    assert int(mine["num_rendered"]) <= int(ref["num_rendered"]), "more instances than the reference"   # exact relation: check_point_lists
     vis = np.asarray(ref["radii"]) > 0
     assert np.array_equal(np.asarray(mine["radii"]), np.asarray(ref["radii"])), "radii differ"
     if check_lists and "point_list" in mine:
         check_point_lists(mine, ref, rep)
-    if "n_contrib" in mine:
-        frac = float((mine["n_contrib"] == ref["n_contrib"]).mean())
+    if "n_contrib" in mine and "point_list" in mine and "point_list" in ref:
+        # n_contrib counts list positions, and the lists here lack the reference's non-contributing instances: compare WHO the
+        # last contributor of every pixel is
+        frac = float((last_contributor_ids(mine) == last_contributor_ids(ref)).mean())
         rep["n_contrib_equal"] = frac
-        assert frac >= nc_frac, f"n_contrib equal on {frac:.5f} of pixels"
+        assert frac >= nc_frac, f"last contributor equal on {frac:.5f} of pixels"
     e = rel_l2(mine["color"], ref["color"]); rep["color"] = e
     assert e <= REL_TOL, f"color rel-L2 {e:.3e}"
     # Against the oracle (not a fixture) the cancellation-prone tensors are checked in two steps, because the map

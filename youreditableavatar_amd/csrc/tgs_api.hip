@@ -35,6 +35,7 @@ static thread_local char g_err[512] = "";
 static std::atomic<int> g_deterministic{-1};
 static std::atomic<uint32_t> g_sort_cap{SORT_LDS_CAP};
 static std::atomic<int> g_fwd_group{1};
+static std::atomic<int> g_prune{1};
 static bool deterministic_mode()
 {
     const int v = g_deterministic.load(std::memory_order_relaxed);
@@ -134,6 +135,8 @@ static CamParams make_cam(const float* view, const float* proj, const float* cam
 extern "C" {
 
 int tgs_abi_version(void) { return TGS_ABI_VERSION; }
+
+void tgs_set_instance_pruning(int on) { g_prune.store(on ? 1 : 0, std::memory_order_relaxed); }
 
 void tgs_set_forward_group(int views_per_launch)
 {
@@ -245,7 +248,7 @@ static int64_t forward_impl(int preprocessed, int64_t r_capacity, tgs_alloc_fn a
     FwdIn in;
     in.P = P; in.D = D; in.M = M; in.means3D = means3D; in.shs = shs; in.colors_precomp = colors_precomp; in.opacities = opacities;
     in.scales = scales; in.rotations = rotations; in.cov3D_precomp = cov3D_precomp; in.background = background;
-    in.prefiltered = prefiltered; in.out_color = out_color; in.radii = radii;
+    in.prefiltered = prefiltered; in.out_color = out_color; in.radii = radii; in.prune = g_prune.load(std::memory_order_relaxed);
 
     uint64_t R = 0;
     Meta meta;
@@ -443,6 +446,7 @@ int tgs_forward_views(void* const* streams, int n_streams, int64_t r_capacity, i
             memset(&in, 0, sizeof(in));
             in.P = P; in.D = D; in.M = M; in.means3D = means3D; in.shs = shs; in.colors_precomp = colors_precomp; in.opacities = opacities;
             in.scales = scales; in.rotations = rotations; in.cov3D_precomp = cov3D_precomp; in.prefiltered = prefiltered;
+            in.prune = g_prune.load(std::memory_order_relaxed);
             FwdViews fv;
             memset(&fv, 0, sizeof(fv));
             fv.n = nv;
@@ -597,6 +601,7 @@ int64_t tgs_state_field(void* stream, const char* field, int P, int width, int h
     else if (!strcmp(field, "tiles_touched")) { src = g.tiles_touched; count = (size_t)P; }
     else if (!strcmp(field, "tile_order")) { src = s.tile_order; count = T; }
     else if (!strcmp(field, "stamps")) { src = s.stamps; count = 4 * T; esz = 8; }
+    else if (!strcmp(field, "block_masks")) { src = (const char*)b.recC + 4; count = (size_t)R; esz = 4; stride = 8; rows = (size_t)R; }   // 16-bit culling mask per sorted instance
     else if (!strcmp(field, "point_list")) { src = b.keys; count = (size_t)R; esz = 4; stride = 8; rows = (size_t)R; }   // low 32 bits of each sorted key
     else return fail(TGS_ERR_INVALID, "unknown field %s", field);
     const size_t total = stride ? rows * esz : count * esz;

@@ -624,6 +624,7 @@ struct FwdIn {
     int prefiltered;
     float* out_color;
     int* radii;
+    int prune;        // 1 (default): rectangle tiles the splat cannot reach with alpha >= 1/255 get no instance (tgs_set_instance_pruning)
 };
 struct BwdIn {
     int P, D, M;

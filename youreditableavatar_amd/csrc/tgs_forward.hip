@@ -22,6 +22,67 @@ namespace tgs {
 // ---------------------------------------------------------------------------------------------
 // k_preprocess_fwd
 // ---------------------------------------------------------------------------------------------
+// Conservative 16-bit mask of the tile's 4x4 blocks of 4x4 pixels (bit by*4+bx) that a splat can reach with
+// alpha >= 1/255:  alpha = o*exp(power) >= 1/255  <=>  -power <= tau, tau = ln(255 o), where
+// -power = f(d) = 1/2 (A dx^2 + C dy^2) + B dx dy is the conic's quadratic form in d = pixel - mean.
+// Stage 1: bounding box of the level set f <= tau (|dx| <= sqrt(2 tau C/det), |dy| <= sqrt(2 tau A/det)), separable.
+// Stage 2, for the blocks that survive: the exact minimum of the convex f over the block's pixel rectangle
+// (0 if the mean is inside; otherwise on one of the 4 edges, a clamped 1-D parabola each).
+// The exact per-pixel tests of forward.cu:336-343 stay in the render kernels, so a conservative mask only removes
+// work, never a contribution (margins: +0.01 on tau plus 0.1 % on f).  NaNs and non-convex conics keep every block.
+__device__ __forceinline__ float conic_min_on_edge(float dfix, float lo, float hi, float Pfix, float Pvar, float B, float mB_over_Pvar)
+{
+    // minimise 1/2 Pfix dfix^2 + B dfix t + 1/2 Pvar t^2 over t in [lo, hi]; the stationary point is t = -B dfix / Pvar
+    const float t = fminf(hi, fmaxf(lo, dfix * mB_over_Pvar));
+    return 0.5f * (Pfix * dfix * dfix + Pvar * t * t) + B * dfix * t;
+}
+__device__ __forceinline__ uint32_t block_mask(float2 xy, float4 co, uint32_t tx, uint32_t ty)
+{
+    const float o255 = 255.0f * co.w;
+    if (o255 < 0.999f) return 0u;                       // alpha <= o < 1/255 for every pixel (G <= 1)
+    const float tau = fmaxf(logf(o255), 0.f) + 0.01f;
+    const float A = co.x, B = co.y, Cc = co.z;
+    const float det = A * Cc - B * B;
+    const bool convex = det > 0.f && A > 0.f && Cc > 0.f;
+    float hx = 3.0e38f, hy = 3.0e38f;
+    if (convex) {
+        hx = sqrtf(2.f * tau * Cc / det) * 1.001f + 0.01f;
+        hy = sqrtf(2.f * tau * A / det) * 1.001f + 0.01f;
+    }
+    const float x0 = (float)(tx * TILE), y0 = (float)(ty * TILE);
+    uint32_t mx = 0, my = 0;                            // 4-bit column / row masks; the box test is separable
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float lo_x = x0 + (float)(4 * k), lo_y = y0 + (float)(4 * k);
+        if (!((xy.x + hx < lo_x) || (xy.x - hx > lo_x + 3.f))) mx |= 1u << k;
+        if (!((xy.y + hy < lo_y) || (xy.y - hy > lo_y + 3.f))) my |= 1u << k;
+    }
+    uint32_t m = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) if ((my >> r) & 1u) m |= mx << (4 * r);
+    if (!convex || m == 0u) return m;
+    const float tau_x = tau * 1.001f;
+    const float rC = -B / Cc, rA = -B / A;
+    uint32_t keep = 0;
+#pragma unroll
+    for (int blk = 0; blk < 16; blk++) {
+        if (!((m >> blk) & 1u)) continue;
+        // block rectangle in d = pixel - mean coordinates
+        const float xl = x0 + (float)(4 * (blk & 3)) - xy.x, xh = xl + 3.f;
+        const float yl = y0 + (float)(4 * (blk >> 2)) - xy.y, yh = yl + 3.f;
+        float fmin_ = 0.f;
+        if (!(xl <= 0.f && xh >= 0.f && yl <= 0.f && yh >= 0.f)) {
+            const float e0 = conic_min_on_edge(xl, yl, yh, A, Cc, B, rC), e1 = conic_min_on_edge(xh, yl, yh, A, Cc, B, rC);
+            const float e2 = conic_min_on_edge(yl, xl, xh, Cc, A, B, rA), e3 = conic_min_on_edge(yh, xl, xh, Cc, A, B, rA);
+            fmin_ = fminf(fminf(e0, e1), fminf(e2, e3));
+        }
+        if (!(fmin_ > tau_x)) keep |= 1u << blk;
+    }
+    return keep;
+}
+
+constexpr uint32_t RANK_DEAD = 0xffffffffu;   // rank slot of a rectangle tile the splat cannot reach with alpha >= 1/255: no instance
+
 // One Gaussian of one view: projection, EWA covariance, SH colour, tile rectangle, the 64-B pack line, and the per-tile
 // instance count whose returned values are the instance's ranks.  Shared by the one-view and the all-views kernel.
 template <bool HAS_SH, bool HAS_SCALE_ROT>
@@ -139,12 +200,25 @@ __device__ __forceinline__ uint32_t preprocess_fwd_one(const FwdIn& in, int* __r
                     // Per-tile instance count (replaces the tile half of the reference's 64-bit sort keys).  A splat on <= 4 tiles
                     // (almost all) takes its rank inside each tile from the same atomic, so k_scatter needs no second atomic pass.
                     if (tiles <= (uint32_t)RANK_TILES) {
-                        uint32_t rk[RANK_TILES] = {0u, 0u, 0u, 0u};
-                        const uint32_t rw = maxx - minx;
+                        // The 3-sigma square over-covers: a tile of the rectangle where the splat stays below alpha = 1/255 everywhere
+                        // (the same conservative test that masks the 4x4 blocks for the render kernels, so nothing that could be
+                        // blended is lost) gets no instance at all -- no count, no key, no sort, no record (about a fifth of them).
+                        uint32_t rk[RANK_TILES] = {RANK_DEAD, RANK_DEAD, RANK_DEAD, RANK_DEAD};
+                        const uint32_t rw = maxx - minx, area = tiles;
+                        const float opac = in.opacities[idx];
+                        uint32_t live = 0;
 #pragma unroll
-                        for (int k = 0; k < RANK_TILES; k++)       // constant indices: rk stays in registers
-                            if ((uint32_t)k < tiles) rk[k] = atomicAdd(&s.tile_count[(size_t)((miny + k / rw) * cam.gx + minx + k % rw) * CSTRIDE], 1u);
+                        for (int k = 0; k < RANK_TILES; k++) {     // constant indices: rk stays in registers
+                            if ((uint32_t)k < area) {
+                                const uint32_t tx = minx + k % rw, ty = miny + k / rw;
+                                if (!in.prune || block_mask(make_float2(pix, piy), make_float4(conx, cony, conz, opac), tx, ty) != 0u) {
+                                    rk[k] = atomicAdd(&s.tile_count[(size_t)(ty * cam.gx + tx) * CSTRIDE], 1u);
+                                    live++;
+                                }
+                            }
+                        }
                         pk[3] = make_float4(__uint_as_float(rk[0]), __uint_as_float(rk[1]), __uint_as_float(rk[2]), __uint_as_float(rk[3]));
+                        tiles = live;
                     } else {
                         for (uint32_t ty = miny; ty < maxy; ty++)
                             for (uint32_t tx = minx; tx < maxx; tx++) atomicAdd(&s.tile_count[(size_t)(ty * cam.gx + tx) * CSTRIDE + 1], 1u);
@@ -348,17 +422,16 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_scatter(int P, const GeomState g,
 
     if (tiles > 0) {
         const unsigned long long key = ((unsigned long long)__float_as_uint(g.depth[idx]) << 32) | (uint32_t)idx;
-        if (tiles <= (uint32_t)RANK_TILES) {
+        const ushort4 r = g.rect[idx];
+        const uint32_t rw = (uint32_t)r.z - r.x, area = rw * ((uint32_t)r.w - r.y);      // tiles <= area: dead tiles of small rectangles have no instance
+        if (area <= (uint32_t)RANK_TILES) {
             // position = start of the tile's segment + the rank taken in k_preprocess_fwd: no atomic
-            const ushort4 r = g.rect[idx];
             const float4 rk4 = g.pack[4 * (size_t)idx + 3];
             const uint32_t rk[RANK_TILES] = {__float_as_uint(rk4.x), __float_as_uint(rk4.y), __float_as_uint(rk4.z), __float_as_uint(rk4.w)};
-            const uint32_t rw = (uint32_t)r.z - r.x;
 #pragma unroll
             for (int k = 0; k < RANK_TILES; k++)
-                if ((uint32_t)k < tiles) b.keys[s.ranges[(r.y + k / rw) * gx + r.x + k % rw].x + rk[k]] = key;
-        } else if (tiles <= (uint32_t)COOP_TILES) {
-            const ushort4 r = g.rect[idx];
+                if ((uint32_t)k < area && rk[k] != RANK_DEAD) b.keys[s.ranges[(r.y + k / rw) * gx + r.x + k % rw].x + rk[k]] = key;
+        } else if (area <= (uint32_t)COOP_TILES) {
             for (uint32_t ty = r.y; ty < r.w; ty++)
                 for (uint32_t tx = r.x; tx < r.z; tx++) {
                     uint32_t* line = s.tile_count + (size_t)(ty * gx + tx) * CSTRIDE;
@@ -387,65 +460,6 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_scatter(int P, const GeomState g,
 
 // (the bitonic network helpers pair_flip / pair_disperse / cmp_swap live in tgs_device.hpp)
 
-// Conservative 16-bit mask of the tile's 4x4 blocks of 4x4 pixels (bit by*4+bx) that a splat can reach with
-// alpha >= 1/255:  alpha = o*exp(power) >= 1/255  <=>  -power <= tau, tau = ln(255 o), where
-// -power = f(d) = 1/2 (A dx^2 + C dy^2) + B dx dy is the conic's quadratic form in d = pixel - mean.
-// Stage 1: bounding box of the level set f <= tau (|dx| <= sqrt(2 tau C/det), |dy| <= sqrt(2 tau A/det)), separable.
-// Stage 2, for the blocks that survive: the exact minimum of the convex f over the block's pixel rectangle
-// (0 if the mean is inside; otherwise on one of the 4 edges, a clamped 1-D parabola each).
-// The exact per-pixel tests of forward.cu:336-343 stay in the render kernels, so a conservative mask only removes
-// work, never a contribution (margins: +0.01 on tau plus 0.1 % on f).  NaNs and non-convex conics keep every block.
-__device__ __forceinline__ float conic_min_on_edge(float dfix, float lo, float hi, float Pfix, float Pvar, float B, float mB_over_Pvar)
-{
-    // minimise 1/2 Pfix dfix^2 + B dfix t + 1/2 Pvar t^2 over t in [lo, hi]; the stationary point is t = -B dfix / Pvar
-    const float t = fminf(hi, fmaxf(lo, dfix * mB_over_Pvar));
-    return 0.5f * (Pfix * dfix * dfix + Pvar * t * t) + B * dfix * t;
-}
-__device__ __forceinline__ uint32_t block_mask(float2 xy, float4 co, uint32_t tx, uint32_t ty)
-{
-    const float o255 = 255.0f * co.w;
-    if (o255 < 0.999f) return 0u;                       // alpha <= o < 1/255 for every pixel (G <= 1)
-    const float tau = fmaxf(logf(o255), 0.f) + 0.01f;
-    const float A = co.x, B = co.y, Cc = co.z;
-    const float det = A * Cc - B * B;
-    const bool convex = det > 0.f && A > 0.f && Cc > 0.f;
-    float hx = 3.0e38f, hy = 3.0e38f;
-    if (convex) {
-        hx = sqrtf(2.f * tau * Cc / det) * 1.001f + 0.01f;
-        hy = sqrtf(2.f * tau * A / det) * 1.001f + 0.01f;
-    }
-    const float x0 = (float)(tx * TILE), y0 = (float)(ty * TILE);
-    uint32_t mx = 0, my = 0;                            // 4-bit column / row masks; the box test is separable
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const float lo_x = x0 + (float)(4 * k), lo_y = y0 + (float)(4 * k);
-        if (!((xy.x + hx < lo_x) || (xy.x - hx > lo_x + 3.f))) mx |= 1u << k;
-        if (!((xy.y + hy < lo_y) || (xy.y - hy > lo_y + 3.f))) my |= 1u << k;
-    }
-    uint32_t m = 0;
-#pragma unroll
-    for (int r = 0; r < 4; r++) if ((my >> r) & 1u) m |= mx << (4 * r);
-    if (!convex || m == 0u) return m;
-    const float tau_x = tau * 1.001f;
-    const float rC = -B / Cc, rA = -B / A;
-    uint32_t keep = 0;
-#pragma unroll
-    for (int blk = 0; blk < 16; blk++) {
-        if (!((m >> blk) & 1u)) continue;
-        // block rectangle in d = pixel - mean coordinates
-        const float xl = x0 + (float)(4 * (blk & 3)) - xy.x, xh = xl + 3.f;
-        const float yl = y0 + (float)(4 * (blk >> 2)) - xy.y, yh = yl + 3.f;
-        float fmin_ = 0.f;
-        if (!(xl <= 0.f && xh >= 0.f && yl <= 0.f && yh >= 0.f)) {
-            const float e0 = conic_min_on_edge(xl, yl, yh, A, Cc, B, rC), e1 = conic_min_on_edge(xh, yl, yh, A, Cc, B, rC);
-            const float e2 = conic_min_on_edge(yl, xl, xh, Cc, A, B, rA), e3 = conic_min_on_edge(yh, xl, xh, Cc, A, B, rA);
-            fmin_ = fminf(fminf(e0, e1), fminf(e2, e3));
-        }
-        if (!(fmin_ > tau_x)) keep |= 1u << blk;
-    }
-    return keep;
-}
-
 // gathers the per-instance record of sorted entry i of a tile (what renderCUDA fetches per entry:
 // forward.cu:315-321,355 and backward.cu:470-480)
 __device__ __forceinline__ void finalize_entry(unsigned long long key, uint32_t pos, uint32_t tile, uint32_t gx, const GeomState& g,
@@ -455,12 +469,22 @@ __device__ __forceinline__ void finalize_entry(unsigned long long key, uint32_t 
     const float4* pk = g.pack + 4 * (size_t)id;               // one 64-B line per Gaussian
     const float4 p0 = pk[0], p1 = pk[1], p2 = pk[2];
     const uint32_t rmin = __float_as_uint(p2.y), rmax = __float_as_uint(p2.z);
-    const uint32_t minx = rmin & 0xffffu, miny = rmin >> 16, maxx = rmax & 0xffffu;
+    const uint32_t minx = rmin & 0xffffu, miny = rmin >> 16, maxx = rmax & 0xffffu, maxy = rmax >> 16;
     const uint32_t tx = tile % gx, ty = tile / gx;
     b.recA[pos] = p0;
     b.recB[pos] = p1;
     b.recC[pos] = make_float2(p2.x, __uint_as_float(block_mask(make_float2(p0.x, p0.y), make_float4(p0.z, p0.w, p1.x, p1.y), tx, ty)));
-    b.slot[pos] = __float_as_uint(p2.w) + (ty - miny) * (maxx - minx) + (tx - minx);
+    // row of this instance in the gradient slab: the Gaussian's rows are its LIVE tiles in rectangle order
+    const uint32_t rw = maxx - minx, k = (ty - miny) * rw + (tx - minx);
+    uint32_t ord = k;
+    if (rw * (maxy - miny) <= (uint32_t)RANK_TILES) {
+        const float4 p3 = pk[3];
+        const uint32_t rk[RANK_TILES] = {__float_as_uint(p3.x), __float_as_uint(p3.y), __float_as_uint(p3.z), __float_as_uint(p3.w)};
+        ord = 0;
+#pragma unroll
+        for (int j = 0; j < RANK_TILES; j++) if ((uint32_t)j < k && rk[j] != RANK_DEAD) ord++;
+    }
+    b.slot[pos] = __float_as_uint(p2.w) + ord;
 }
 
 // Per-tile sort in LDS, tiles visited in tile_order (longest lists first).  Three classes by list length n:

@@ -59,6 +59,8 @@ def _load() -> C.CDLL:
     lib.tgs_state_field.argtypes = [vp, C.c_char_p, it, it, it, C.c_int64, it, it, vp, vp, vp, vp, C.c_size_t]
     lib.tgs_set_sort_lds_cap.restype = it
     lib.tgs_set_sort_lds_cap.argtypes = [C.c_uint]
+    lib.tgs_set_instance_pruning.restype = None
+    lib.tgs_set_instance_pruning.argtypes = [it]
     lib.tgs_set_forward_group.restype = None
     lib.tgs_set_forward_group.argtypes = [it]
     lib.tgs_set_deterministic.restype = None
@@ -82,6 +84,12 @@ def set_sort_lds_cap(cap: int) -> None:
     """Test knob: tile lists longer than ``cap`` (power of two <= 8192) take the global-memory sort path."""
     if _lib.tgs_set_sort_lds_cap(int(cap)) < 0:
         raise _err(-1)
+
+
+def set_instance_pruning(on: bool) -> None:
+    """False: keep the reference's tile instances (every tile of the 3-sigma rectangle); True (default): drop those that cannot
+    reach alpha >= 1/255 anywhere in the tile.  Same images and gradients either way."""
+    _lib.tgs_set_instance_pruning(1 if on else 0)
 
 
 def set_forward_group(views_per_launch: int) -> None:
@@ -433,7 +441,7 @@ def mark_visible(means3D, viewmatrix, projmatrix) -> torch.Tensor:
     return present
 
 
-_FIELD_DTYPES = {"n_contrib": torch.int32, "final_T": torch.float32, "ranges": torch.int32, "point_list": torch.int32,
+_FIELD_DTYPES = {"n_contrib": torch.int32, "final_T": torch.float32, "ranges": torch.int32, "point_list": torch.int32, "block_masks": torch.int32,
                  "means2D": torch.float32, "depths": torch.float32, "conic_opacity": torch.float32, "rgb": torch.float32,
                  "tiles_touched": torch.int32, "tile_order": torch.int32, "stamps": torch.int64}
 
@@ -443,7 +451,7 @@ def state_field(name: str, P: int, width: int, height: int, R: int, has_sh: bool
     """Test/bench introspection of the opaque state buffers (tgs_state_field)."""
     dev = geomBuffer.device
     T = ((width + 15) // 16) * ((height + 15) // 16)
-    count = {"n_contrib": width * height, "final_T": width * height, "ranges": 2 * T, "point_list": R, "means2D": 2 * P,
+    count = {"n_contrib": width * height, "final_T": width * height, "ranges": 2 * T, "point_list": R, "block_masks": R, "means2D": 2 * P,
              "depths": P, "conic_opacity": 4 * P, "rgb": 3 * P, "tiles_touched": P, "tile_order": T, "stamps": 4 * T}[name]
     out = torch.empty((count,), dtype=_FIELD_DTYPES[name], device=dev)
     with torch.cuda.device(dev):
