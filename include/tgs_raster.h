@@ -190,6 +190,7 @@ typedef struct {
     int* radii_out;            /* [P], written by tgs_forward_views (the same memory `radii` points to) */
     const float* dL_dpix;      /* [3,H,W] */
     size_t geom_bytes, binning_bytes, img_bytes;   /* capacities of the three caller-allocated state buffers */
+    const float* colors_precomp;  /* [P,3] colours of THIS view (tgs_forward_views; overrides the shared argument) or NULL */
 } tgs_view_t;
 /* Whole-batch entry points: one call enqueues the forward (or the per-pixel backward) of every view, view k on
  * streams[k % n_streams], with state buffers the CALLER allocated up front (tgs_state_sizes) -- no allocation callback, no

@@ -492,3 +492,47 @@ def test_run_views_whole_batch_path(streams, group, gpu_device):
     finally:
         _C.set_deterministic(False)
         _C.set_forward_group(1)
+
+
+def test_run_views_with_per_view_colors(gpu_device):
+    """run_views(colors_precomp=[V,P,3]) -- the reference's training mode, colours evaluated by the caller per view -- against the
+    per-view path: images, dL/d colours per view, accumulated parameter gradients; fused SH->RGB in front of it reproduces the
+    SH-in-rasterizer gradients end to end."""
+    from diff_gaussian_rasterization import _C
+    from youreditableavatar_amd import scenes, sh_color
+    from youreditableavatar_amd.multiview import FlatGradients, SyncFreeBatch, rasterize_accumulate
+    P = 5000
+    cloud = scenes.make_cloud(P, 3, seed=43, scale_mult=3.0)
+    cams = [scenes.orbit_camera(176, 112, azimuth_deg=a) for a in (10.0, 100.0, 190.0, 280.0)]
+    V = len(cams)
+    dLs = torch.stack([torch.from_numpy(scenes.upstream_gradient(176, 112, seed=60 + i)) for i in range(V)]).to(gpu_device)
+    L = _leaves(cloud, gpu_device)
+    names = ("means3D", "opacities", "scales", "rotations", "shs")
+    flat = FlatGradients([L[n] for n in names])
+    settings = [_settings(c, 3, gpu_device) for c in cams]
+    campos = [torch.from_numpy(np.ascontiguousarray(c.campos, np.float32)).to(gpu_device).view(1, 3) for c in cams]
+    _C.set_deterministic(True)
+    try:
+        # (a) SH inside the rasterizer: the reference result for all parameter gradients
+        batch_sh = SyncFreeBatch(granule=256)
+        for _ in range(2):
+            flat.zero_()
+            imgs_sh = batch_sh.run_views(settings, L["means3D"], L["opacities"], L["shs"], L["scales"], L["rotations"], lambda im: dLs).clone()
+        want = flat.flat.clone()
+        # (b) colours by the fused SH->RGB op per view, rasterizer in colors_precomp mode, colour gradients handed back to the op
+        batch = SyncFreeBatch(granule=256)
+        for rep in range(3):                                # synchronous first, then the whole-batch path (twice: pool reuse)
+            flat.zero_()
+            cols = [sh_color.points_rgb(L["shs"], 4, positions=L["means3D"], camera_centers=campos[v]) for v in range(V)]
+            colors = torch.stack([c.detach() for c in cols])
+            imgs = batch.run_views(settings, L["means3D"], L["opacities"], None, L["scales"], L["rotations"], lambda im: dLs, colors_precomp=colors)
+            assert tuple(batch.color_grads.shape) == (V, P, 3)
+            for v in range(V):
+                cols[v].backward(batch.color_grads[v])      # adds dL/d sh and the view-direction part of dL/d means3D
+            assert util.rel_l2(imgs.cpu().numpy(), imgs_sh.cpu().numpy()) <= 1e-6, rep
+            assert util.rel_l2(flat.flat.cpu().numpy(), want.cpu().numpy()) <= 2e-5, rep
+        assert batch.rejected == 0
+        with pytest.raises(RuntimeError):
+            batch.run_views(settings, L["means3D"], L["opacities"], L["shs"], L["scales"], L["rotations"], lambda im: dLs, colors_precomp=colors)
+    finally:
+        _C.set_deterministic(False)

@@ -429,7 +429,10 @@ int tgs_forward_views(void* const* streams, int n_streams, int64_t r_capacity, i
     // their remaining stages together and the launch itself is bound by the L2 atomic units with the CUs mostly idle;
     // measured at 4 streams the forward phase is 0.249 / 0.255 / 0.262 / 0.259 ms per frame for groups of 1 / 2 / 4 / 8.
     const int group = g_fwd_group.load(std::memory_order_relaxed);
-    const bool batched = group > 1 && n_views > 1 && P > 0 && means3D && opacities && ((shs == nullptr) != (colors_precomp == nullptr)) && (has_sr != (cov3D_precomp != nullptr)) &&
+    bool per_view_colors = false;
+    for (int k = 0; k < n_views; k++) per_view_colors = per_view_colors || views[k].colors_precomp != nullptr;
+    if (per_view_colors && shs) return fail(TGS_ERR_INVALID, "provide exactly one of shs / colors_precomp");
+    const bool batched = !per_view_colors && group > 1 && n_views > 1 && P > 0 && means3D && opacities && ((shs == nullptr) != (colors_precomp == nullptr)) && (has_sr != (cov3D_precomp != nullptr)) &&
                          (!has_sh || (D >= 0 && D <= 3 && M >= (D + 1) * (D + 1)));
     for (int v0 = 0; v0 < n_views; v0 += group) {
         const int nv = n_views - v0 < group ? n_views - v0 : group;
@@ -478,7 +481,8 @@ int tgs_forward_views(void* const* streams, int n_streams, int64_t r_capacity, i
             tgs_view_t& v = views[v0 + k];
             hipStream_t st = (hipStream_t)streams[(v0 + k) % n_streams];
             if (pre_done && st != st0) HIP_TRY(hipStreamWaitEvent(st, pre_done, 0));
-            const int64_t r = forward_impl(batched ? 1 : 0, r_capacity, alloc_preset, &v, st, P, D, M, v.background, v.width, v.height, means3D, shs, colors_precomp,
+            const int64_t r = forward_impl(batched ? 1 : 0, r_capacity, alloc_preset, &v, st, P, D, M, v.background, v.width, v.height, means3D, shs,
+                                           v.colors_precomp ? v.colors_precomp : colors_precomp,
                                            opacities, scales, scale_modifier, rotations, cov3D_precomp, v.viewmatrix, v.projmatrix, v.campos, v.tan_fovx, v.tan_fovy,
                                            prefiltered, v.out_color, v.radii_out, 0);
             if (r < 0) { if (pre_done) (void)hipEventDestroy(pre_done); return (int)r; }

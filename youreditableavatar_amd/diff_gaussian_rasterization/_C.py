@@ -325,7 +325,7 @@ class _ViewT(C.Structure):
                 ("geom_buffer", C.c_void_p), ("binning_buffer", C.c_void_p), ("img_buffer", C.c_void_p), ("R", C.c_int64),
                 ("dL_dmean2D", C.c_void_p), ("dL_dcolor", C.c_void_p),
                 ("background", C.c_void_p), ("out_color", C.c_void_p), ("radii_out", C.c_void_p), ("dL_dpix", C.c_void_p),
-                ("geom_bytes", C.c_size_t), ("binning_bytes", C.c_size_t), ("img_bytes", C.c_size_t)]
+                ("geom_bytes", C.c_size_t), ("binning_bytes", C.c_size_t), ("img_bytes", C.c_size_t), ("colors_precomp", C.c_void_p)]
 
 
 ViewArray = lambda n: (_ViewT * n)()
@@ -356,9 +356,10 @@ def backward_render_views(stream_handles, P, views, n_views) -> None:
 
 def backward_batch_raw(stream, P, D, M, views, n_views, means3D, shs, scales, scale_modifier, rotations, dL_dopacity, dL_dmean3D, dL_dsh, dL_dscale,
                        dL_drot, accumulate) -> None:
-    """tgs_backward_batch on prepared device pointers (SH + scales/rotations path)."""
+    """tgs_backward_batch on prepared device pointers (scales/rotations path; ``shs`` None: per-view colours, their gradients go to
+    the views' dL_dcolor)."""
     r = _lib.tgs_backward_batch(stream, int(P), int(D), int(M), int(n_views), C.cast(views, C.c_void_p), means3D, shs, scales, float(scale_modifier),
-                                rotations, None, dL_dopacity, dL_dmean3D, None, dL_dsh, dL_dscale, dL_drot, 1 if accumulate else 0)
+                                rotations, None, dL_dopacity, dL_dmean3D, None, dL_dsh if shs else None, dL_dscale, dL_drot, 1 if accumulate else 0)
     if r < 0:
         raise _err(int(r))
 

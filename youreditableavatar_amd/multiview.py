@@ -218,6 +218,7 @@ class SyncFreeBatch:
         self._cooldown = 0                      # batches to render synchronously after a tile list outgrew the LDS sort
         self._pool = None
         self.viewspace_grads: Optional[torch.Tensor] = None
+        self.color_grads: Optional[torch.Tensor] = None      # run_views with colors_precomp: dL/d colours per view [V,P,3]
 
     def capacity(self) -> Optional[int]:
         if self.bound is None or self._cooldown > 0:
@@ -231,22 +232,37 @@ class SyncFreeBatch:
     # launch time per frame -- as much as the GPU needs for the frame once the views overlap on several streams.
     # ------------------------------------------------------------------------------------------------------------------
     def run_views(self, settings: Sequence, means3D: torch.Tensor, opacities: torch.Tensor, shs: torch.Tensor, scales: torch.Tensor,
-                  rotations: torch.Tensor, upstream_batch: Callable[[torch.Tensor], torch.Tensor], accumulate: bool = True) -> torch.Tensor:
+                  rotations: torch.Tensor, upstream_batch: Callable[[torch.Tensor], torch.Tensor], accumulate: bool = True,
+                  colors_precomp: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Renders the views described by ``settings`` (GaussianRasterizationSettings, same image size, SH degree and scale
         modifier) of one Gaussian model (leaf parameters with allocated ``.grad``, SH colours, scales + rotations), calls
         ``upstream_batch(images[V,3,H,W]) -> dL/d images`` ([V,3,H,W], or [3,H,W] for all views) ONCE, and adds the
         gradients of all views into the parameters' ``.grad`` (``accumulate=False``: overwrites them instead -- the
         step then needs no zeroing pass and the batch kernel no read of the old values).  Returns the images -- a view
-        of a buffer the next call reuses; ``self.viewspace_grads`` [V,P,3] holds dL/d means2D per view."""
+        of a buffer the next call reuses; ``self.viewspace_grads`` [V,P,3] holds dL/d means2D per view.
+
+        ``colors_precomp`` [V,P,3] (float32, with ``shs=None``): the reference's training mode -- colours evaluated by the caller
+        per view (``compute_color_in_rasterizer=False``, tetgs_model.py:524-537; e.g. ``sh_color.points_rgb``); their
+        gradients come back in ``self.color_grads`` [V,P,3] for the caller's ``colors.backward(batch.color_grads)``."""
         from .diff_gaussian_rasterization import _C
         V = len(settings)
         rs0 = settings[0]
         P, H, W, D = int(means3D.size(0)), int(rs0.image_height), int(rs0.image_width), int(rs0.sh_degree)
-        params = dict(means3D=means3D, opacities=opacities, sh=shs, scales=scales, rotations=rotations)
+        precomp = colors_precomp is not None
+        if precomp == (shs is not None):
+            raise RuntimeError("run_views: provide exactly one of shs / colors_precomp")
+        params = dict(means3D=means3D, opacities=opacities, scales=scales, rotations=rotations)
+        if precomp:
+            colors_precomp = colors_precomp.detach()
+            if not (colors_precomp.is_cuda and colors_precomp.dtype == torch.float32 and colors_precomp.is_contiguous()
+                    and tuple(colors_precomp.shape) == (V, int(means3D.size(0)), 3)):
+                raise RuntimeError("run_views: colors_precomp must be a contiguous float32 GPU tensor [V,P,3]")
+        else:
+            params["sh"] = shs
         for name, t in params.items():
             if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.is_leaf and t.grad is not None and t.grad.is_contiguous()):
                 raise RuntimeError(f"run_views: {name} must be a contiguous float32 leaf parameter on the GPU with an allocated .grad (see FlatGradients)")
-        M = int(shs.size(1))
+        M = 0 if precomp else int(shs.size(1))
         cap = self.capacity()
         dev = means3D.device
 
@@ -256,9 +272,10 @@ class SyncFreeBatch:
             out = {}
             for v in idx:
                 rs = settings[v]
-                R, color, radii, geom, binning, img = _C.rasterize_gaussians(rs.bg, means3D.detach(), e, opacities.detach(), scales.detach(), rotations.detach(),
-                                                                           rs.scale_modifier, e, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, H, W,
-                                                                           shs.detach(), D, rs.campos, rs.prefiltered, rs.debug)
+                R, color, radii, geom, binning, img = _C.rasterize_gaussians(rs.bg, means3D.detach(), colors_precomp[v] if precomp else e, opacities.detach(),
+                                                                           scales.detach(), rotations.detach(), rs.scale_modifier, e, rs.viewmatrix, rs.projmatrix,
+                                                                           rs.tanfovx, rs.tanfovy, H, W, e if precomp else shs.detach(), D, rs.campos,
+                                                                           rs.prefiltered, rs.debug)
                 out[v] = (R, color, radii, geom, binning, img)
             return out
 
@@ -266,14 +283,20 @@ class SyncFreeBatch:
             rs = settings[v]
             e = torch.Tensor([])
             R, color, radii, geom, binning, img = state
-            into = dict(means3D=means3D.grad, opacities=opacities.grad, sh=shs.grad, scales=scales.grad, rotations=rotations.grad)
-            return _C.rasterize_gaussians_backward_accumulate(rs.bg, means3D.detach(), radii, e, scales.detach(), rotations.detach(), rs.scale_modifier, e,
-                                                              rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, g, shs.detach(), D, rs.campos, geom, R,
-                                                              binning, img, rs.debug, into)
+            into = dict(means3D=means3D.grad, opacities=opacities.grad, scales=scales.grad, rotations=rotations.grad)
+            if precomp:
+                gcol[v].zero_()
+                into["colors_precomp"] = gcol[v]             # per-view colours: their gradient is this view's alone
+            else:
+                into["sh"] = shs.grad
+            return _C.rasterize_gaussians_backward_accumulate(rs.bg, means3D.detach(), radii, colors_precomp[v] if precomp else e, scales.detach(),
+                                                              rotations.detach(), rs.scale_modifier, e, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, g,
+                                                              e if precomp else shs.detach(), D, rs.campos, geom, R, binning, img, rs.debug, into)
 
         def grad_of(dL, v):
             return dL if dL.dim() == 3 else dL[v]
 
+        gcol = torch.empty((V, P, 3), dtype=torch.float32, device=dev) if (precomp and cap is None) else None
         if cap is None:                                     # no bound yet (or cooling down after an LDS-sort overflow): synchronous frames
             if not accumulate:
                 for t in params.values():
@@ -283,6 +306,7 @@ class SyncFreeBatch:
             dL = upstream_batch(images)
             g2d = [per_view_backward(v, states[v], grad_of(dL, v)) for v in range(V)]
             self.viewspace_grads = torch.stack(g2d)
+            self.color_grads = gcol
             seen = max(states[v][0] for v in range(V))
             if self._cooldown > 0:
                 self._cooldown -= 1
@@ -290,15 +314,17 @@ class SyncFreeBatch:
             return images
 
         # ---- pooled state: one tensor per kind for all views, reused from step to step
-        key = (P, H, W, V, M, cap, dev)
+        key = (P, H, W, V, M, cap, dev, precomp)
         if self._pool is None or self._pool["key"] != key:
-            gb, bb, ib = _C.state_sizes(P, W, H, True, True, cap)
+            gb, bb, ib = _C.state_sizes(P, W, H, not precomp, True, cap)
             al = lambda n: (n + 255) // 256 * 256
             z = lambda *shape, dt=torch.float32: torch.empty(shape, dtype=dt, device=dev)
             self._pool = dict(key=key, images=z(V, 3, H, W), radii=z(V, P, dt=torch.int32), g2d=z(V, P, 3), geom=z(V, al(gb), dt=torch.uint8),
                               binning=z(V, al(bb), dt=torch.uint8), img=z(V, al(ib), dt=torch.uint8), sizes=(gb, bb, ib), arr=_C.ViewArray(V),
+                              gcol=z(V, P, 3) if precomp else None,
                               host=torch.empty((V, _C.META_BYTES), dtype=torch.uint8, pin_memory=True))
         pool = self._pool
+        gcol = pool["gcol"]
         arr = pool["arr"]
         gb, bb, ib = pool["sizes"]
         for v, rs in enumerate(settings):
@@ -310,7 +336,9 @@ class SyncFreeBatch:
             a.radii = a.radii_out = pool["radii"][v].data_ptr()
             a.geom_buffer, a.binning_buffer, a.img_buffer = pool["geom"][v].data_ptr(), pool["binning"][v].data_ptr(), pool["img"][v].data_ptr()
             a.geom_bytes, a.binning_bytes, a.img_bytes = gb, bb, ib
-            a.out_color, a.dL_dmean2D, a.dL_dcolor, a.dL_dpix = pool["images"][v].data_ptr(), pool["g2d"][v].data_ptr(), None, None
+            a.out_color, a.dL_dmean2D, a.dL_dpix = pool["images"][v].data_ptr(), pool["g2d"][v].data_ptr(), None
+            a.dL_dcolor = gcol[v].data_ptr() if precomp else None
+            a.colors_precomp = colors_precomp[v].data_ptr() if precomp else None
         main = torch.cuda.current_stream(dev)
         side = self._side.setdefault(dev, [])
         n_lanes = max(1, min(self.streams, V))
@@ -333,8 +361,8 @@ class SyncFreeBatch:
 
         with torch.cuda.device(dev):
             fork()
-            _C.forward_views(handles, cap, P, D, M, means3D.data_ptr(), shs.data_ptr(), opacities.data_ptr(), scales.data_ptr(), rs0.scale_modifier,
-                             rotations.data_ptr(), arr, V)
+            _C.forward_views(handles, cap, P, D, M, means3D.data_ptr(), None if precomp else shs.data_ptr(), opacities.data_ptr(), scales.data_ptr(),
+                             rs0.scale_modifier, rotations.data_ptr(), arr, V)
             join()
             pool["host"].copy_(pool["img"][:, :_C.META_BYTES], non_blocking=True)      # the verdict travels while the GPU works on
             ready = torch.cuda.Event()
@@ -349,10 +377,11 @@ class SyncFreeBatch:
             fork()
             _C.backward_render_views(handles, P, arr, V)
             join()
-            _C.backward_batch_raw(main.cuda_stream, P, D, M, arr, V, means3D.data_ptr(), shs.data_ptr(), scales.data_ptr(), rs0.scale_modifier,
-                                  rotations.data_ptr(), opacities.grad.data_ptr(), means3D.grad.data_ptr(), shs.grad.data_ptr(), scales.grad.data_ptr(),
-                                  rotations.grad.data_ptr(), accumulate)
+            _C.backward_batch_raw(main.cuda_stream, P, D, M, arr, V, means3D.data_ptr(), None if precomp else shs.data_ptr(), scales.data_ptr(),
+                                  rs0.scale_modifier, rotations.data_ptr(), opacities.grad.data_ptr(), means3D.grad.data_ptr(),
+                                  None if precomp else shs.grad.data_ptr(), scales.grad.data_ptr(), rotations.grad.data_ptr(), accumulate)
         self.viewspace_grads = pool["g2d"]
+        self.color_grads = gcol
         ready.synchronize()                                 # the one host wait of the batch
         seen = 0
         if self._cooldown > 0:
