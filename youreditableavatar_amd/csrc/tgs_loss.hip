@@ -4,7 +4,7 @@
 // (Edit_core/utils/loss_utils.py:17-18, :39-63 composed as in tetgs_texture/refine.py:245-247).  The reference builds
 // the SSIM statistics with five zero-padded depthwise 11x11 convolutions plus ~15 element-wise kernels and lets
 // autograd run them backwards; here
-//   k_ssim_stats : one 32x16 tile of one image plane per workgroup; pred and gt tiles (+5 halo, zeros outside) in LDS,
+//   k_ssim_stats : one 32x32 tile of one image plane per workgroup; pred and gt tiles (+5 halo, zeros outside) in LDS,
 //                  separable 11-tap Gaussian of (x, y, x^2, y^2, xy) -> ssim_map, its three partial derivatives with
 //                  respect to the windowed statistics, and the workgroup's partial sums of ssim_map and |x - y|;
 //   k_loss_reduce: fixed-order sum of the partials -> loss, ssim, l1 (no float atomics: reproducible);
@@ -16,10 +16,12 @@
 
 namespace tgs {
 
-constexpr int LW = 32, LH = 16, LR = 5;                 // tile width / height, window radius
-constexpr int LTW = LW + 2 * LR, LTH = LH + 2 * LR;     // 42 x 26 with halo
+constexpr int LW = 32, LH = 32, LR = 5;                 // tile width / height, window radius
+constexpr int LTW = LW + 2 * LR, LTH = LH + 2 * LR;     // 42 x 42 with halo
+constexpr int NTAP = 2 * LR + 1;
+constexpr int STRIP = 4;                                // outputs per thread and pass: 14 inputs serve 4 outputs
 
-struct LossWin { float w[2 * LR + 1]; };
+struct LossWin { float w[NTAP]; };
 
 // global [planes, H, W] plane -> LDS tile with halo, zeros outside the image (conv2d padding, loss_utils.py:46)
 __device__ __forceinline__ void load_tile(float (*dst)[LTW + 1], const float* __restrict__ src, int H, int W, int x0, int y0)
@@ -27,6 +29,61 @@ __device__ __forceinline__ void load_tile(float (*dst)[LTW + 1], const float* __
     for (int i = threadIdx.x; i < LTW * LTH; i += 256) {
         const int r = i / LTW, c = i % LTW, gx = x0 + c - LR, gy = y0 + r - LR;
         dst[r][c] = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? src[(size_t)gy * W + gx] : 0.f;
+    }
+}
+
+// Horizontal pass of NMAP maps: work item = (row, strip of 4 columns); the 14 inputs of a strip are read once.
+// `load(r, c, v)` fills v[NMAP] with the map values at tile position (r, c).
+template <int NMAP, typename Load>
+__device__ __forceinline__ void hpass(float (*h)[LTH][LW + 1], const LossWin& win, Load load)
+{
+    for (int i = threadIdx.x; i < LTH * (LW / STRIP); i += 256) {
+        const int r = i / (LW / STRIP), c0 = (i % (LW / STRIP)) * STRIP;
+        float acc[STRIP][NMAP];
+#pragma unroll
+        for (int o = 0; o < STRIP; o++)
+#pragma unroll
+            for (int m = 0; m < NMAP; m++) acc[o][m] = 0.f;
+#pragma unroll
+        for (int k = 0; k < NTAP + STRIP - 1; k++) {
+            float v[NMAP];
+            load(r, c0 + k, v);
+#pragma unroll
+            for (int o = 0; o < STRIP; o++) {
+                if (k - o >= 0 && k - o < NTAP) {
+                    const float w = win.w[k - o];
+#pragma unroll
+                    for (int m = 0; m < NMAP; m++) acc[o][m] += w * v[m];
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < STRIP; o++)
+#pragma unroll
+            for (int m = 0; m < NMAP; m++) h[m][r][c0 + o] = acc[o][m];
+    }
+}
+// Vertical pass: thread (tx, ty) produces rows 4 ty .. 4 ty + 3 of column tx from 14 rows of h
+template <int NMAP>
+__device__ __forceinline__ void vpass(const float (*h)[LTH][LW + 1], const LossWin& win, int tx, int ty, float (&out)[STRIP][NMAP])
+{
+#pragma unroll
+    for (int o = 0; o < STRIP; o++)
+#pragma unroll
+        for (int m = 0; m < NMAP; m++) out[o][m] = 0.f;
+#pragma unroll
+    for (int k = 0; k < NTAP + STRIP - 1; k++) {
+        float v[NMAP];
+#pragma unroll
+        for (int m = 0; m < NMAP; m++) v[m] = h[m][STRIP * ty + k][tx];
+#pragma unroll
+        for (int o = 0; o < STRIP; o++) {
+            if (k - o >= 0 && k - o < NTAP) {
+                const float w = win.w[k - o];
+#pragma unroll
+                for (int m = 0; m < NMAP; m++) out[o][m] += w * v[m];
+            }
+        }
     }
 }
 
@@ -41,30 +98,18 @@ __global__ __launch_bounds__(256) void k_ssim_stats(int H, int W, const float* _
     load_tile(sx, img + plane, H, W, x0, y0);
     load_tile(sy, gt + plane, H, W, x0, y0);
     __syncthreads();
-    for (int i = threadIdx.x; i < LTH * LW; i += 256) {     // horizontal pass
-        const int r = i / LW, c = i % LW;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
-#pragma unroll
-        for (int k = 0; k <= 2 * LR; k++) {
-            const float x = sx[r][c + k], y = sy[r][c + k], wx = win.w[k] * x, wy = win.w[k] * y;
-            a0 += wx; a1 += wy; a2 += wx * x; a3 += wy * y; a4 += wx * y;
-        }
-        h[0][r][c] = a0; h[1][r][c] = a1; h[2][r][c] = a2; h[3][r][c] = a3; h[4][r][c] = a4;
-    }
+    hpass<5>(h, win, [&](int r, int c, float (&v)[5]) { const float x = sx[r][c], y = sy[r][c]; v[0] = x; v[1] = y; v[2] = x * x; v[3] = y * y; v[4] = x * y; });
     __syncthreads();
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    float st[STRIP][5];
+    vpass<5>(h, win, tx, ty, st);
     float s_map = 0.f, s_l1 = 0.f;
 #pragma unroll
-    for (int half = 0; half < 2; half++) {
-        const int o = ty + 8 * half, gx = x0 + tx, gy = y0 + o;
-        float m1 = 0.f, m2 = 0.f, X2 = 0.f, Y2 = 0.f, XY = 0.f;
-#pragma unroll
-        for (int k = 0; k <= 2 * LR; k++) {
-            const float w = win.w[k];
-            m1 += w * h[0][o + k][tx]; m2 += w * h[1][o + k][tx]; X2 += w * h[2][o + k][tx]; Y2 += w * h[3][o + k][tx]; XY += w * h[4][o + k][tx];
-        }
+    for (int o = 0; o < STRIP; o++) {
+        const int row = STRIP * ty + o, gx = x0 + tx, gy = y0 + row;
         if (gx < W && gy < H) {
             // loss_utils.py:49-58
+            const float m1 = st[o][0], m2 = st[o][1], X2 = st[o][2], Y2 = st[o][3], XY = st[o][4];
             const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
             const float m11 = m1 * m1, m22 = m2 * m2, m12 = m1 * m2;
             const float s1 = X2 - m11, s2 = Y2 - m22, s12 = XY - m12;
@@ -77,7 +122,7 @@ __global__ __launch_bounds__(256) void k_ssim_stats(int H, int W, const float* _
             dX2[at] = -map * iD2;
             dXY[at] = 2.f * N1 * q;
             s_map += map;
-            s_l1 += fabsf(sx[o + LR][tx + LR] - sy[o + LR][tx + LR]);
+            s_l1 += fabsf(sx[row + LR][tx + LR] - sy[row + LR][tx + LR]);
         }
     }
     s_map = wave_sum(s_map); s_l1 = wave_sum(s_l1);
@@ -119,26 +164,19 @@ __global__ __launch_bounds__(256) void k_ssim_grad(int H, int W, const float* __
     load_tile(t[1], dX2 + plane, H, W, x0, y0);
     load_tile(t[2], dXY + plane, H, W, x0, y0);
     __syncthreads();
-    for (int i = threadIdx.x; i < LTH * LW; i += 256) {
-        const int r = i / LW, c = i % LW;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-#pragma unroll
-        for (int k = 0; k <= 2 * LR; k++) { const float w = win.w[k]; a0 += w * t[0][r][c + k]; a1 += w * t[1][r][c + k]; a2 += w * t[2][r][c + k]; }
-        h[0][r][c] = a0; h[1][r][c] = a1; h[2][r][c] = a2;
-    }
+    hpass<3>(h, win, [&](int r, int c, float (&v)[3]) { v[0] = t[0][r][c]; v[1] = t[1][r][c]; v[2] = t[2][r][c]; });
     __syncthreads();
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    float cv[STRIP][3];
+    vpass<3>(h, win, tx, ty, cv);
 #pragma unroll
-    for (int half = 0; half < 2; half++) {
-        const int o = ty + 8 * half, gx = x0 + tx, gy = y0 + o;
+    for (int o = 0; o < STRIP; o++) {
+        const int gx = x0 + tx, gy = y0 + STRIP * ty + o;
         if (gx >= W || gy >= H) continue;
-        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
-#pragma unroll
-        for (int k = 0; k <= 2 * LR; k++) { const float w = win.w[k]; c0 += w * h[0][o + k][tx]; c1 += w * h[1][o + k][tx]; c2 += w * h[2][o + k][tx]; }
         const size_t at = plane + (size_t)gy * W + gx;
         const float x = img[at], y = gt[at], d = x - y;
         const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);         // torch's abs backward: 0 at 0
-        grad[at] = gl * sgn + gs * (c0 + 2.f * x * c1 + y * c2);
+        grad[at] = gl * sgn + gs * (cv[o][0] + 2.f * x * cv[o][1] + y * cv[o][2]);
     }
 }
 
