@@ -338,11 +338,11 @@ def state_sizes(P: int, width: int, height: int, has_sh: bool, has_scale_rot: bo
     return int(out[0]), int(out[1]), int(out[2])
 
 
-def forward_views(stream_handles, r_capacity, P, D, M, means3D, shs, opacities, scales, scale_modifier, rotations, views, n_views) -> None:
+def forward_views(stream_handles, r_capacity, P, D, M, means3D, shs, opacities, scales, scale_modifier, rotations, views, n_views, prefiltered=False) -> None:
     """tgs_forward_views on prepared device pointers (ints) and a filled ``ViewArray``."""
     arr = (C.c_void_p * len(stream_handles))(*stream_handles)
     r = _lib.tgs_forward_views(arr, len(stream_handles), int(r_capacity), int(P), int(D), int(M), means3D, shs, None, opacities, scales,
-                               float(scale_modifier), rotations, None, 0, int(n_views), C.cast(views, C.c_void_p))
+                               float(scale_modifier), rotations, None, int(bool(prefiltered)), int(n_views), C.cast(views, C.c_void_p))
     if r < 0:
         raise _err(int(r))
 

@@ -328,8 +328,9 @@ class SyncFreeBatch:
         arr = pool["arr"]
         gb, bb, ib = pool["sizes"]
         for v, rs in enumerate(settings):
-            if (int(rs.image_height), int(rs.image_width), int(rs.sh_degree)) != (H, W, D) or rs.scale_modifier != rs0.scale_modifier:
-                raise RuntimeError("run_views: all views of a batch share image size, SH degree and scale modifier")
+            if (int(rs.image_height), int(rs.image_width), int(rs.sh_degree)) != (H, W, D) or rs.scale_modifier != rs0.scale_modifier or \
+                    bool(rs.prefiltered) != bool(rs0.prefiltered):
+                raise RuntimeError("run_views: all views of a batch share image size, SH degree, scale modifier and the prefiltered flag")
             a = arr[v]
             a.width, a.height, a.tan_fovx, a.tan_fovy = W, H, float(rs.tanfovx), float(rs.tanfovy)
             a.viewmatrix, a.projmatrix, a.campos, a.background = rs.viewmatrix.data_ptr(), rs.projmatrix.data_ptr(), rs.campos.data_ptr(), rs.bg.data_ptr()
@@ -362,7 +363,7 @@ class SyncFreeBatch:
         with torch.cuda.device(dev):
             fork()
             _C.forward_views(handles, cap, P, D, M, means3D.data_ptr(), None if precomp else shs.data_ptr(), opacities.data_ptr(), scales.data_ptr(),
-                             rs0.scale_modifier, rotations.data_ptr(), arr, V)
+                             rs0.scale_modifier, rotations.data_ptr(), arr, V, prefiltered=rs0.prefiltered)
             join()
             pool["host"].copy_(pool["img"][:, :_C.META_BYTES], non_blocking=True)      # the verdict travels while the GPU works on
             ready = torch.cuda.Event()
