@@ -166,6 +166,10 @@ int tgs_sh_rgb_backward(void* stream, int P, int M, int levels, const float* sh,
  * tgs_dist2_workspace_bytes(P) bytes. */
 size_t tgs_dist2_workspace_bytes(int P);
 int tgs_dist2(void* stream, int P, const float* points, float* mean_dist2, void* workspace, size_t workspace_bytes);
+/* The K (<= 32) nearest neighbours of every point among the same points, itself included: what the reference asks of its
+ * third-party knn_points(points[None], points[None], K) (tetgs_scene/tetgs_model.py:6 import; :36 with K = 4, :180 with K = 16).  dists[P,K] squared
+ * distances ascending (FLT_MAX and index -1 where P < K), idx[P,K] int64.  Same workspace as tgs_dist2. */
+int tgs_knn_self(void* stream, int P, int K, const float* points, float* dists, long long* idx, void* workspace, size_t workspace_bytes);
 
 /* ---- Batched backward (multi-view steps) ----
  * Rasterizer::backward runs its per-Gaussian half (computeCov2DCUDA + preprocessCUDA of backward.cu) once per view; with

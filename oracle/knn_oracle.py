@@ -44,3 +44,24 @@ def dist2_kdtree(points: np.ndarray) -> np.ndarray:
     _, idx = cKDTree(pts.astype(np.float64)).query(pts.astype(np.float64), k=4)
     d = np.sort(_d2_f32(pts[:, None, :], pts[idx]), axis=1)[:, 1:4]       # drop one zero: the point itself
     return ((d[:, 0] + d[:, 1]).astype(np.float32) + d[:, 2]).astype(np.float32) / np.float32(3.0)
+
+
+def knn_self_bruteforce(points: np.ndarray, K: int):
+    """pytorch3d.ops.knn_points(p[None], p[None], K) as used at tetgs_scene/tetgs_model.py:36,180 (not importable here: pytorch3d
+    is absent): squared distances in fp32, ascending, the point itself included; -> (dists [P,K], idx [P,K]).  Ties may come in
+    any order, so compare indices through the distances they give."""
+    pts = np.ascontiguousarray(points, dtype=np.float32)
+    P = pts.shape[0]
+    d_out = np.full((P, K), FLT_MAX, np.float32)
+    i_out = np.full((P, K), -1, np.int64)
+    step = max(1, (1 << 24) // max(P, 1))
+    for s in range(0, P, step):
+        e = min(P, s + step)
+        d = _d2_f32(pts[s:e, None, :], pts[None, :, :])
+        k = min(K, P)
+        part = np.argpartition(d, k - 1, axis=1)[:, :k]
+        dd = np.take_along_axis(d, part, 1)
+        order = np.argsort(dd, axis=1, kind="stable")
+        d_out[s:e, :k] = np.take_along_axis(dd, order, 1)
+        i_out[s:e, :k] = np.take_along_axis(part, order, 1)
+    return d_out, i_out

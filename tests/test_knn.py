@@ -82,3 +82,46 @@ def test_gpu_full_size_against_kdtree():
     pts = np.ascontiguousarray(pts, np.float32)
     got, want = _hip(pts), knn_oracle.dist2_kdtree(pts)
     np.testing.assert_allclose(got, want, rtol=2e-6, atol=0)
+
+
+def test_knn_oracle_self_query():
+    pts = clouds()["uniform_5000"][:600]
+    d, i = knn_oracle.knn_self_bruteforce(pts, 4)
+    assert np.all(d[:, 0] == 0) and np.all(i[:, 0] == np.arange(600)) and np.all(np.diff(d, axis=1) >= 0)
+    from scipy.spatial import cKDTree
+    dk, _ = cKDTree(pts.astype(np.float64)).query(pts.astype(np.float64), k=4)
+    np.testing.assert_allclose(d, (dk ** 2).astype(np.float32), rtol=1e-5, atol=1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,K", [("uniform_5000", 4), ("clustered_6000", 16), ("duplicates_3000", 4), ("flat_2049", 9), ("uniform_5000", 32)])
+def test_gpu_knn_points_self(name, K):
+    """knn_points(p, p, K) of the reference's scale initialisation (K = 4) and neighbour tracking (K = 16)"""
+    from youreditableavatar_amd.knn import knn_points_self
+    pts = clouds()[name]
+    want_d, _ = knn_oracle.knn_self_bruteforce(pts, K)
+    out = knn_points_self(torch.from_numpy(pts).cuda()[None], K)
+    d, i = out.dists[0].cpu().numpy(), out.idx[0].cpu().numpy()
+    assert out.dists.shape == (1, len(pts), K) and out.idx.dtype == torch.int64
+    np.testing.assert_allclose(d, want_d, rtol=2e-6, atol=0)
+    # the indices are neighbours at exactly those distances (ties may be ordered differently)
+    diff = pts[i] - pts[:, None, :]
+    np.testing.assert_allclose((diff * diff).sum(-1), d, rtol=2e-6, atol=1e-12)
+    assert np.all(d[:, 0] == 0)
+    for row in i[:: max(1, len(pts) // 50)]:
+        assert len(set(row.tolist())) == K
+
+
+@pytest.mark.gpu
+def test_gpu_knn_fewer_points_than_k_and_scale_init():
+    from youreditableavatar_amd.knn import knn_points_self
+    pts = torch.tensor([[0.0, 0, 0], [1, 0, 0], [0, 3, 0]], device="cuda")
+    out = knn_points_self(pts, 4)
+    assert out.idx.shape == (3, 4) and torch.all(out.idx[:, 3] == -1) and torch.all(out.dists[:, 3] > 1e38)
+    assert out.dists[0].tolist()[:3] == [0.0, 1.0, 9.0] and out.idx[0].tolist()[:3] == [0, 1, 2]
+    # the reference's scale initialisation (tetgs_model.py:36-46) on top of it
+    cloud = torch.from_numpy(clouds()["uniform_5000"]).cuda()
+    knn = knn_points_self(cloud[None], K=4)
+    radiuses = torch.sqrt(knn.dists[..., 1:]).mean(-1, keepdim=True).clamp_min(0.0000001)
+    want_d, _ = knn_oracle.knn_self_bruteforce(cloud.cpu().numpy(), 4)
+    np.testing.assert_allclose(radiuses[0, :, 0].cpu().numpy(), np.sqrt(want_d[:, 1:]).mean(-1), rtol=1e-5)

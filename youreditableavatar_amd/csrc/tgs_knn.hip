@@ -221,6 +221,64 @@ __global__ __launch_bounds__(256) void k_knn_meandist(int P, const float4* __res
     if (have) out[__float_as_uint(me.w)] = (b0 + b1 + b2) / 3.0f;
 }
 
+// ---------------------------------------------------------------------------------------------
+// K nearest neighbours of every point among the same points, the point itself included (distance 0, first) -- what the
+// reference asks of pytorch3d: knn_points(points[None], points[None], K) at tetgs_scene/tetgs_model.py:36 (K = 4, scale
+// initialisation) and :180 (K = knn_to_track = 16, neighbour tracking).  Same Morton order / box / group rejection as
+// k_knn_meandist; the K best (squared distance, index) pairs are kept ascending in registers.
+// ---------------------------------------------------------------------------------------------
+template <int K>
+__device__ __forceinline__ void insert_k(float d, uint32_t id, float (&bd)[K], uint32_t (&bi)[K])
+{
+    if (!(d < bd[K - 1])) return;
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        if (d < bd[j]) { const float td = bd[j]; const uint32_t ti = bi[j]; bd[j] = d; bi[j] = id; d = td; id = ti; }
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void k_knn_kbest(int P, int Kout, const float4* __restrict__ sorted, const float* __restrict__ boxes,
+                                                   const float* __restrict__ subs, int nbox, float* __restrict__ dists, long long* __restrict__ idx_out)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const bool have = idx < P;
+    float4 me = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (have) me = sorted[idx];
+    float bd[K];
+    uint32_t bi[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) { bd[j] = FLT_MAX; bi[j] = 0xffffffffu; }
+    const int g_own = __builtin_amdgcn_readfirstlane(idx >> 6);
+    const int nsub = (P + 63) >> 6;
+    const int g_lo = max(0, g_own - 1), g_hi = min(nsub - 1, g_own + 1);
+    auto visit = [&](int i0, int i1, bool want) {
+        for (int i = i0; i < i1; i++) {
+            const float4 q = sorted[i];                                  // wave-uniform address
+            const float dx = q.x - me.x, dy = q.y - me.y, dz = q.z - me.z;
+            if (want) insert_k<K>(dx * dx + dy * dy + dz * dz, __float_as_uint(q.w), bd, bi);
+        }
+    };
+    visit(g_lo << 6, min(P, (g_hi + 1) << 6), have);
+    for (int b = 0; b < nbox; b++) {
+        const bool want = have && !(dist_box_point(boxes + 6 * (size_t)b, me.x, me.y, me.z) > bd[K - 1]);
+        if (__builtin_amdgcn_ballot_w64(want) == 0) continue;
+        const int s0 = b * 16, s1 = min(nsub, s0 + 16);
+        for (int g = s0; g < s1; g++) {
+            if (g >= g_lo && g <= g_hi) continue;
+            const bool wg = want && !(dist_box_point(subs + 6 * (size_t)g, me.x, me.y, me.z) > bd[K - 1]);
+            if (__builtin_amdgcn_ballot_w64(wg) == 0) continue;
+            visit(g << 6, min(P, (g << 6) + 64), wg);
+        }
+    }
+    if (have) {
+        const size_t o = (size_t)__float_as_uint(me.w) * Kout;
+#pragma unroll
+        for (int j = 0; j < K; j++)
+            if (j < Kout) { dists[o + j] = bd[j]; idx_out[o + j] = bi[j] == 0xffffffffu ? -1ll : (long long)bi[j]; }
+    }
+}
+
 }  // namespace tgs
 
 extern "C" {
@@ -232,15 +290,13 @@ size_t tgs_dist2_workspace_bytes(int P)
     return tgs::knn_carve(w, nullptr, (size_t)(P > 0 ? P : 0));
 }
 
-int tgs_dist2(void* stream, int P, const float* points, float* mean_dist2, void* workspace, size_t workspace_bytes)
+// Morton order, boxes and groups of `points` into the workspace (shared by tgs_dist2 and tgs_knn_self)
+static int knn_prepare(hipStream_t st, int P, const float* points, void* workspace, size_t workspace_bytes, tgs::KnnWork& w, int& nbox)
 {
     using namespace tgs;
-    hipStream_t st = (hipStream_t)stream;
-    if (P == 0) return TGS_OK;
-    if (P < 0 || !points || !mean_dist2 || !workspace) return set_error(TGS_ERR_INVALID, "tgs_dist2: P >= 0 and non-NULL points / mean_dist2 / workspace required");
-    KnnWork w;
-    if (knn_carve(w, (char*)workspace, (size_t)P) > workspace_bytes) return set_error(TGS_ERR_INVALID, "tgs_dist2: workspace smaller than tgs_dist2_workspace_bytes(P)");
-    const int nblk = (P + 255) / 256, nbox = (P + KNN_BOX - 1) / KNN_BOX;
+    if (knn_carve(w, (char*)workspace, (size_t)P) > workspace_bytes) return set_error(TGS_ERR_INVALID, "k-NN workspace smaller than tgs_dist2_workspace_bytes(P)");
+    const int nblk = (P + 255) / 256;
+    nbox = (P + KNN_BOX - 1) / KNN_BOX;
     hipLaunchKernelGGL(k_knn_minmax, dim3(nblk), dim3(256), 0, st, P, points, w.partial);
     hipLaunchKernelGGL(k_knn_minmax_final, dim3(1), dim3(256), 0, st, nblk, w.partial, w.minmax);
     hipLaunchKernelGGL(k_knn_morton, dim3(nblk), dim3(256), 0, st, P, points, w.minmax, w.keys);
@@ -256,7 +312,39 @@ int tgs_dist2(void* stream, int P, const float* points, float* mean_dist2, void*
     }
     hipLaunchKernelGGL(k_knn_gather, dim3(nblk), dim3(256), 0, st, P, points, w.keys, w.sorted);
     hipLaunchKernelGGL(k_knn_boxes, dim3(nbox), dim3(KNN_BOX), 0, st, P, w.sorted, w.boxes, w.subs);
-    hipLaunchKernelGGL(k_knn_meandist, dim3(nblk), dim3(256), 0, st, P, w.sorted, w.boxes, w.subs, nbox, mean_dist2);
+    return TGS_OK;
+}
+
+int tgs_dist2(void* stream, int P, const float* points, float* mean_dist2, void* workspace, size_t workspace_bytes)
+{
+    using namespace tgs;
+    hipStream_t st = (hipStream_t)stream;
+    if (P == 0) return TGS_OK;
+    if (P < 0 || !points || !mean_dist2 || !workspace) return set_error(TGS_ERR_INVALID, "tgs_dist2: P >= 0 and non-NULL points / mean_dist2 / workspace required");
+    KnnWork w;
+    int nbox = 0;
+    const int r = knn_prepare(st, P, points, workspace, workspace_bytes, w, nbox);
+    if (r < 0) return r;
+    hipLaunchKernelGGL(k_knn_meandist, dim3((P + 255) / 256), dim3(256), 0, st, P, w.sorted, w.boxes, w.subs, nbox, mean_dist2);
     return hip_status("tgs_dist2");
+}
+
+int tgs_knn_self(void* stream, int P, int K, const float* points, float* dists, long long* idx, void* workspace, size_t workspace_bytes)
+{
+    using namespace tgs;
+    hipStream_t st = (hipStream_t)stream;
+    if (P == 0 || K == 0) return TGS_OK;
+    if (P < 0 || K < 0 || K > 32 || !points || !dists || !idx || !workspace)
+        return set_error(TGS_ERR_INVALID, "tgs_knn_self: P >= 0, 0 <= K <= 32 and non-NULL points / dists / idx / workspace required");
+    KnnWork w;
+    int nbox = 0;
+    const int r = knn_prepare(st, P, points, workspace, workspace_bytes, w, nbox);
+    if (r < 0) return r;
+    const dim3 grid((P + 255) / 256), blk(256);
+    if (K <= 4) hipLaunchKernelGGL((k_knn_kbest<4>), grid, blk, 0, st, P, K, w.sorted, w.boxes, w.subs, nbox, dists, idx);
+    else if (K <= 8) hipLaunchKernelGGL((k_knn_kbest<8>), grid, blk, 0, st, P, K, w.sorted, w.boxes, w.subs, nbox, dists, idx);
+    else if (K <= 16) hipLaunchKernelGGL((k_knn_kbest<16>), grid, blk, 0, st, P, K, w.sorted, w.boxes, w.subs, nbox, dists, idx);
+    else hipLaunchKernelGGL((k_knn_kbest<32>), grid, blk, 0, st, P, K, w.sorted, w.boxes, w.subs, nbox, dists, idx);
+    return hip_status("tgs_knn_self");
 }
 }
