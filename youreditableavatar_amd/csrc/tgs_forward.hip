@@ -81,6 +81,26 @@ __device__ __forceinline__ uint32_t block_mask(float2 xy, float4 co, uint32_t tx
     return keep;
 }
 
+// Can the splat reach alpha >= 1/255 anywhere in tile (tx, ty)?  The same two stages as block_mask on ONE rectangle -- the hull of
+// the tile's pixel centres, a superset of its 16 block rectangles -- with the same margins: never "no" where a block says "yes".
+__device__ __forceinline__ bool tile_reachable(float2 xy, float4 co, uint32_t tx, uint32_t ty)
+{
+    const float o255 = 255.0f * co.w;
+    if (o255 < 0.999f) return false;
+    const float tau = fmaxf(logf(o255), 0.f) + 0.01f;
+    const float A = co.x, B = co.y, Cc = co.z;
+    const float det = A * Cc - B * B;
+    if (!(det > 0.f && A > 0.f && Cc > 0.f)) return true;              // NaNs and non-convex conics keep everything
+    const float hx = sqrtf(2.f * tau * Cc / det) * 1.001f + 0.01f, hy = sqrtf(2.f * tau * A / det) * 1.001f + 0.01f;
+    const float xl = (float)(tx * TILE) - xy.x, xh = xl + (float)(TILE - 1), yl = (float)(ty * TILE) - xy.y, yh = yl + (float)(TILE - 1);
+    if (hx < xl || -hx > xh || hy < yl || -hy > yh) return false;       // bounding box of the level set misses the tile
+    if (xl <= 0.f && xh >= 0.f && yl <= 0.f && yh >= 0.f) return true;  // the mean is inside
+    const float rC = -B / Cc, rA = -B / A;
+    const float e0 = conic_min_on_edge(xl, yl, yh, A, Cc, B, rC), e1 = conic_min_on_edge(xh, yl, yh, A, Cc, B, rC);
+    const float e2 = conic_min_on_edge(yl, xl, xh, Cc, A, B, rA), e3 = conic_min_on_edge(yh, xl, xh, Cc, A, B, rA);
+    return !(fminf(fminf(e0, e1), fminf(e2, e3)) > tau * 1.001f);
+}
+
 constexpr uint32_t RANK_DEAD = 0xffffffffu;   // rank slot of a rectangle tile the splat cannot reach with alpha >= 1/255: no instance
 
 // One Gaussian of one view: projection, EWA covariance, SH colour, tile rectangle, the 64-B pack line, and the per-tile
@@ -201,8 +221,8 @@ __device__ __forceinline__ uint32_t preprocess_fwd_one(const FwdIn& in, int* __r
                     // (almost all) takes its rank inside each tile from the same atomic, so k_scatter needs no second atomic pass.
                     if (tiles <= (uint32_t)RANK_TILES) {
                         // The 3-sigma square over-covers: a tile of the rectangle where the splat stays below alpha = 1/255 everywhere
-                        // (the same conservative test that masks the 4x4 blocks for the render kernels, so nothing that could be
-                        // blended is lost) gets no instance at all -- no count, no key, no sort, no record (about a fifth of them).
+                        // (tile_reachable: the conservative test that masks the 4x4 blocks for the render kernels, applied to the whole
+                        // tile, so nothing that could be blended is lost) gets no instance at all -- no count, no key, no sort, no record (about a fifth of them).
                         uint32_t rk[RANK_TILES] = {RANK_DEAD, RANK_DEAD, RANK_DEAD, RANK_DEAD};
                         const uint32_t rw = maxx - minx, area = tiles;
                         const float opac = in.opacities[idx];
@@ -211,7 +231,7 @@ __device__ __forceinline__ uint32_t preprocess_fwd_one(const FwdIn& in, int* __r
                         for (int k = 0; k < RANK_TILES; k++) {     // constant indices: rk stays in registers
                             if ((uint32_t)k < area) {
                                 const uint32_t tx = minx + k % rw, ty = miny + k / rw;
-                                if (!in.prune || block_mask(make_float2(pix, piy), make_float4(conx, cony, conz, opac), tx, ty) != 0u) {
+                                if (!in.prune || tile_reachable(make_float2(pix, piy), make_float4(conx, cony, conz, opac), tx, ty)) {
                                     rk[k] = atomicAdd(&s.tile_count[(size_t)(ty * cam.gx + tx) * CSTRIDE], 1u);
                                     live++;
                                 }
