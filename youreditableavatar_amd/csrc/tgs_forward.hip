@@ -64,9 +64,8 @@ __device__ __forceinline__ uint32_t block_mask(float2 xy, float4 co, uint32_t tx
     const float tau_x = tau * 1.001f;
     const float rC = -B / Cc, rA = -B / A;
     uint32_t keep = 0;
-#pragma unroll
-    for (int blk = 0; blk < 16; blk++) {
-        if (!((m >> blk) & 1u)) continue;
+    for (uint32_t rest = m; rest != 0u; rest &= rest - 1u) {           // only the blocks the box test left (a wave runs as many rounds as its busiest lane has)
+        const int blk = __builtin_ctz(rest);
         // block rectangle in d = pixel - mean coordinates
         const float xl = x0 + (float)(4 * (blk & 3)) - xy.x, xh = xl + 3.f;
         const float yl = y0 + (float)(4 * (blk >> 2)) - xy.y, yh = yl + 3.f;
