@@ -659,7 +659,7 @@ __device__ __forceinline__ void fill_tile_background(const ImgState& s, uint32_t
 }
 
 __global__ __launch_bounds__(FWD_THREADS, 8) void k_render_fwd(const ImgState s, const BinState b, int W, int H, uint32_t gx,
-                                                            const float* __restrict__ bg, float* __restrict__ out_color)
+                                                            const float* __restrict__ bg, float* __restrict__ out_color, int fill_tail)
 {
     __shared__ float4 sA[FCH + 1];
     __shared__ float4 sB[FCH + 1];
@@ -669,8 +669,11 @@ __global__ __launch_bounds__(FWD_THREADS, 8) void k_render_fwd(const ImgState s,
     __shared__ uint32_t wave_alive[2][16];                 // double-buffered "this wave still has live pixels"
     __shared__ uint32_t wave_qmax[16];
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-    if (blockIdx.x >= s.meta->n_nonempty) return;
     const uint4 td = s.tile_desc[blockIdx.x];
+    if (blockIdx.x >= s.meta->n_nonempty) {                // grid = all tiles (sync-free forward): the empty ones are the tail of tile_order
+        if (fill_tail && threadIdx.x < 256) fill_tile_background(s, td.x, threadIdx.x, W, H, gx, bg, out_color);
+        return;
+    }
     if (frame_rejected(s)) {
         if (threadIdx.x < 256) fill_tile_background(s, td.x, threadIdx.x, W, H, gx, bg, out_color);
         return;
@@ -881,8 +884,12 @@ void launch_tile_sort(hipStream_t st, const GeomState& g, const ImgState& s, con
 void launch_render_fwd(hipStream_t st, const ImgState& s, const BinState& b, int W, int H, uint32_t gx, uint32_t T, const Meta* m,
                        const float* bg, float* out_color)
 {
-    const uint32_t nonempty = m ? m->n_nonempty : T, empty = m ? T - m->n_nonempty : T;
-    if (nonempty > 0) hipLaunchKernelGGL(k_render_fwd, dim3(nonempty), dim3(FWD_THREADS), 0, st, s, b, W, H, gx, bg, out_color);
+    if (!m) {   // sync-free: one launch over all tiles; workgroups behind the non-empty ones write the background of the empty tiles
+        hipLaunchKernelGGL(k_render_fwd, dim3(T), dim3(FWD_THREADS), 0, st, s, b, W, H, gx, bg, out_color, 1);
+        return;
+    }
+    const uint32_t nonempty = m->n_nonempty, empty = T - m->n_nonempty;
+    if (nonempty > 0) hipLaunchKernelGGL(k_render_fwd, dim3(nonempty), dim3(FWD_THREADS), 0, st, s, b, W, H, gx, bg, out_color, 0);
     if (empty > 0) hipLaunchKernelGGL(k_fill_empty, dim3(empty), dim3(256), 0, st, s, W, H, gx, T, bg, out_color);
 }
 void launch_mark_visible(hipStream_t st, int P, const float* means3D, const float* view, uint8_t* present)
