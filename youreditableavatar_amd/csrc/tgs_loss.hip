@@ -4,7 +4,8 @@
 // (Edit_core/utils/loss_utils.py:17-18, :39-63 composed as in tetgs_texture/refine.py:245-247).  The reference builds
 // the SSIM statistics with five zero-padded depthwise 11x11 convolutions plus ~15 element-wise kernels and lets
 // autograd run them backwards; here
-//   k_ssim_stats : one 32x32 tile of one image plane per workgroup; pred and gt tiles (+5 halo, zeros outside) in LDS,
+//   k_ssim_stats : a workgroup walks 4 vertically adjacent 32x32 tiles of one image plane (the next tile's loads in flight under
+//                  the current tile's arithmetic); pred and gt tiles (+5 halo, zeros outside) in LDS,
 //                  separable 11-tap Gaussian of (x, y, x^2, y^2, xy) -> ssim_map, its three partial derivatives with
 //                  respect to the windowed statistics, and the workgroup's partial sums of ssim_map and |x - y|;
 //   k_loss_reduce: fixed-order sum of the partials -> loss, ssim, l1 (no float atomics: reproducible);
@@ -23,14 +24,27 @@ constexpr int STRIP = 4;                                // outputs per thread an
 
 struct LossWin { float w[NTAP]; };
 
-// global [planes, H, W] plane -> LDS tile with halo, zeros outside the image (conv2d padding, loss_utils.py:46)
-__device__ __forceinline__ void load_tile(float (*dst)[LTW + 1], const float* __restrict__ src, int H, int W, int x0, int y0)
+// global [planes, H, W] plane -> LDS tile with halo, zeros outside the image (conv2d padding, loss_utils.py:46), in two
+// steps so that the loads of the NEXT tile are in flight while the current one is convolved: fetch into registers
+// (7 values per thread and map), commit to LDS one iteration later.
+constexpr int LPT = (LTW * LTH + 255) / 256;            // tile elements per thread
+__device__ __forceinline__ void fetch_tile(float (&v)[LPT], const float* __restrict__ src, int H, int W, int x0, int y0)
 {
-    for (int i = threadIdx.x; i < LTW * LTH; i += 256) {
-        const int r = i / LTW, c = i % LTW, gx = x0 + c - LR, gy = y0 + r - LR;
-        dst[r][c] = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? src[(size_t)gy * W + gx] : 0.f;
+#pragma unroll
+    for (int k = 0; k < LPT; k++) {
+        const int i = threadIdx.x + 256 * k, r = i / LTW, c = i - r * LTW, gx = x0 + c - LR, gy = y0 + r - LR;
+        v[k] = (i < LTW * LTH && gx >= 0 && gx < W && gy >= 0 && gy < H) ? src[(size_t)gy * W + gx] : 0.f;
     }
 }
+__device__ __forceinline__ void commit_tile(float (*dst)[LTW + 1], const float (&v)[LPT])
+{
+#pragma unroll
+    for (int k = 0; k < LPT; k++) {
+        const int i = threadIdx.x + 256 * k, r = i / LTW, c = i - r * LTW;
+        if (i < LTW * LTH) dst[r][c] = v[k];
+    }
+}
+constexpr int LTY = 4;                                   // tiles a workgroup walks down a column of the image
 
 // Horizontal pass of NMAP maps: work item = (row, strip of 4 columns); the 14 inputs of a strip are read once.
 // `load(r, c, v)` fills v[NMAP] with the map values at tile position (r, c).
@@ -93,37 +107,49 @@ __global__ __launch_bounds__(256) void k_ssim_stats(int H, int W, const float* _
     __shared__ float sx[LTH][LTW + 1], sy[LTH][LTW + 1];
     __shared__ float h[5][LTH][LW + 1];
     __shared__ float2 red[4];
-    const int x0 = blockIdx.x * LW, y0 = blockIdx.y * LH;
+    const int x0 = blockIdx.x * LW;
     const size_t plane = (size_t)blockIdx.z * H * W;
-    load_tile(sx, img + plane, H, W, x0, y0);
-    load_tile(sy, gt + plane, H, W, x0, y0);
-    __syncthreads();
-    hpass<5>(h, win, [&](int r, int c, float (&v)[5]) { const float x = sx[r][c], y = sy[r][c]; v[0] = x; v[1] = y; v[2] = x * x; v[3] = y * y; v[4] = x * y; });
-    __syncthreads();
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    float st[STRIP][5];
-    vpass<5>(h, win, tx, ty, st);
     float s_map = 0.f, s_l1 = 0.f;
-#pragma unroll
-    for (int o = 0; o < STRIP; o++) {
-        const int row = STRIP * ty + o, gx = x0 + tx, gy = y0 + row;
-        if (gx < W && gy < H) {
-            // loss_utils.py:49-58
-            const float m1 = st[o][0], m2 = st[o][1], X2 = st[o][2], Y2 = st[o][3], XY = st[o][4];
-            const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
-            const float m11 = m1 * m1, m22 = m2 * m2, m12 = m1 * m2;
-            const float s1 = X2 - m11, s2 = Y2 - m22, s12 = XY - m12;
-            const float N1 = 2.f * m12 + C1, N2 = 2.f * s12 + C2, D1 = m11 + m22 + C1, D2 = s1 + s2 + C2;
-            const float iD1 = 1.f / D1, iD2 = 1.f / D2, q = iD1 * iD2;
-            const float map = N1 * N2 * q;
-            // map as a function of the windowed statistics (m1, X2, XY); sigma1_sq = X2 - m1^2, sigma12 = XY - m1 m2
-            const size_t at = plane + (size_t)gy * W + gx;
-            dM1[at] = 2.f * q * (m2 * (N2 - N1) - m1 * map * (D2 - D1));
-            dX2[at] = -map * iD2;
-            dXY[at] = 2.f * N1 * q;
-            s_map += map;
-            s_l1 += fabsf(sx[row + LR][tx + LR] - sy[row + LR][tx + LR]);
+    float vx[LPT], vy[LPT];
+    fetch_tile(vx, img + plane, H, W, x0, blockIdx.y * LTY * LH);
+    fetch_tile(vy, gt + plane, H, W, x0, blockIdx.y * LTY * LH);
+    for (int it = 0; it < LTY; it++) {
+        const int y0 = (blockIdx.y * LTY + it) * LH;
+        if (y0 >= H) break;                                  // uniform
+        commit_tile(sx, vx);
+        commit_tile(sy, vy);
+        __syncthreads();
+        if (it + 1 < LTY && y0 + LH < H) {                   // next tile's loads fly under this tile's arithmetic
+            fetch_tile(vx, img + plane, H, W, x0, y0 + LH);
+            fetch_tile(vy, gt + plane, H, W, x0, y0 + LH);
         }
+        hpass<5>(h, win, [&](int r, int c, float (&v)[5]) { const float x = sx[r][c], y = sy[r][c]; v[0] = x; v[1] = y; v[2] = x * x; v[3] = y * y; v[4] = x * y; });
+        __syncthreads();
+        float st[STRIP][5];
+        vpass<5>(h, win, tx, ty, st);
+#pragma unroll
+        for (int o = 0; o < STRIP; o++) {
+            const int row = STRIP * ty + o, gx = x0 + tx, gy = y0 + row;
+            if (gx < W && gy < H) {
+                // loss_utils.py:49-58
+                const float m1 = st[o][0], m2 = st[o][1], X2 = st[o][2], Y2 = st[o][3], XY = st[o][4];
+                const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+                const float m11 = m1 * m1, m22 = m2 * m2, m12 = m1 * m2;
+                const float s1 = X2 - m11, s2 = Y2 - m22, s12 = XY - m12;
+                const float N1 = 2.f * m12 + C1, N2 = 2.f * s12 + C2, D1 = m11 + m22 + C1, D2 = s1 + s2 + C2;
+                const float iD1 = 1.f / D1, iD2 = 1.f / D2, q = iD1 * iD2;
+                const float map = N1 * N2 * q;
+                // map as a function of the windowed statistics (m1, X2, XY); sigma1_sq = X2 - m1^2, sigma12 = XY - m1 m2
+                const size_t at = plane + (size_t)gy * W + gx;
+                dM1[at] = 2.f * q * (m2 * (N2 - N1) - m1 * map * (D2 - D1));
+                dX2[at] = -map * iD2;
+                dXY[at] = 2.f * N1 * q;
+                s_map += map;
+                s_l1 += fabsf(sx[row + LR][tx + LR] - sy[row + LR][tx + LR]);
+            }
+        }
+        __syncthreads();                                     // sx / sy / h are rewritten by the next tile
     }
     s_map = wave_sum(s_map); s_l1 = wave_sum(s_l1);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = make_float2(s_map, s_l1);
@@ -158,25 +184,39 @@ __global__ __launch_bounds__(256) void k_ssim_grad(int H, int W, const float* __
 {
     __shared__ float t[3][LTH][LTW + 1];
     __shared__ float h[3][LTH][LW + 1];
-    const int x0 = blockIdx.x * LW, y0 = blockIdx.y * LH;
+    const int x0 = blockIdx.x * LW;
     const size_t plane = (size_t)blockIdx.z * H * W;
-    load_tile(t[0], dM1 + plane, H, W, x0, y0);
-    load_tile(t[1], dX2 + plane, H, W, x0, y0);
-    load_tile(t[2], dXY + plane, H, W, x0, y0);
-    __syncthreads();
-    hpass<3>(h, win, [&](int r, int c, float (&v)[3]) { v[0] = t[0][r][c]; v[1] = t[1][r][c]; v[2] = t[2][r][c]; });
-    __syncthreads();
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    float cv[STRIP][3];
-    vpass<3>(h, win, tx, ty, cv);
+    float v0[LPT], v1[LPT], v2[LPT];
+    fetch_tile(v0, dM1 + plane, H, W, x0, blockIdx.y * LTY * LH);
+    fetch_tile(v1, dX2 + plane, H, W, x0, blockIdx.y * LTY * LH);
+    fetch_tile(v2, dXY + plane, H, W, x0, blockIdx.y * LTY * LH);
+    for (int it = 0; it < LTY; it++) {
+        const int y0 = (blockIdx.y * LTY + it) * LH;
+        if (y0 >= H) break;                                  // uniform
+        commit_tile(t[0], v0);
+        commit_tile(t[1], v1);
+        commit_tile(t[2], v2);
+        __syncthreads();
+        if (it + 1 < LTY && y0 + LH < H) {
+            fetch_tile(v0, dM1 + plane, H, W, x0, y0 + LH);
+            fetch_tile(v1, dX2 + plane, H, W, x0, y0 + LH);
+            fetch_tile(v2, dXY + plane, H, W, x0, y0 + LH);
+        }
+        hpass<3>(h, win, [&](int r, int c, float (&v)[3]) { v[0] = t[0][r][c]; v[1] = t[1][r][c]; v[2] = t[2][r][c]; });
+        __syncthreads();
+        float cv[STRIP][3];
+        vpass<3>(h, win, tx, ty, cv);
 #pragma unroll
-    for (int o = 0; o < STRIP; o++) {
-        const int gx = x0 + tx, gy = y0 + STRIP * ty + o;
-        if (gx >= W || gy >= H) continue;
-        const size_t at = plane + (size_t)gy * W + gx;
-        const float x = img[at], y = gt[at], d = x - y;
-        const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);         // torch's abs backward: 0 at 0
-        grad[at] = gl * sgn + gs * (cv[o][0] + 2.f * x * cv[o][1] + y * cv[o][2]);
+        for (int o = 0; o < STRIP; o++) {
+            const int gx = x0 + tx, gy = y0 + STRIP * ty + o;
+            if (gx >= W || gy >= H) continue;
+            const size_t at = plane + (size_t)gy * W + gx;
+            const float x = img[at], y = gt[at], d = x - y;
+            const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);         // torch's abs backward: 0 at 0
+            grad[at] = gl * sgn + gs * (cv[o][0] + 2.f * x * cv[o][1] + y * cv[o][2]);
+        }
+        __syncthreads();
     }
 }
 
@@ -199,7 +239,7 @@ size_t tgs_l1_ssim_workspace_bytes(int planes, int height, int width)
 {
     if (planes <= 0 || height <= 0 || width <= 0) return 0;
     const size_t n = (size_t)planes * height * width;
-    const size_t blocks = (size_t)planes * ((height + tgs::LH - 1) / tgs::LH) * ((width + tgs::LW - 1) / tgs::LW);
+    const size_t blocks = (size_t)planes * ((height + tgs::LH * tgs::LTY - 1) / (tgs::LH * tgs::LTY)) * ((width + tgs::LW - 1) / tgs::LW);
     return 3 * n * sizeof(float) + blocks * sizeof(float2) + 1024;
 }
 
@@ -213,7 +253,7 @@ int tgs_l1_ssim(void* stream, int planes, int height, int width, const float* im
     if (workspace_bytes < tgs_l1_ssim_workspace_bytes(planes, height, width))
         return set_error(TGS_ERR_INVALID, "tgs_l1_ssim: workspace smaller than tgs_l1_ssim_workspace_bytes()");
     const size_t n = (size_t)planes * height * width;
-    const dim3 grid((width + LW - 1) / LW, (height + LH - 1) / LH, planes);
+    const dim3 grid((width + LW - 1) / LW, (height + LH * LTY - 1) / (LH * LTY), planes);
     if (grid.y > 65535u || grid.z > 65535u) return set_error(TGS_ERR_INVALID, "tgs_l1_ssim: image too large");
     float* dM1 = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     float* dX2 = dM1 + n;
