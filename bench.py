@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--mode", default="sh", choices=["sh", "precomp"])
     ap.add_argument("--views", type=int, default=64)
     ap.add_argument("--streams", type=int, default=4, help="HIP streams the views of a step alternate between (SyncFreeBatch)")
+    ap.add_argument("--loss", action="store_true", help="upstream gradient from the fused L1+SSIM loss against fixed target images (a training "
+                    "step's image-space work) instead of a fixed dL/d image; not the headline metric")
     ap.add_argument("--per-view-calls", action="store_true", help="drive every view through autograd (SyncFreeBatch.run) instead of the whole-batch path (run_views)")
     ap.add_argument("--sync-per-frame", action="store_true", help="reference protocol: read num_rendered back in every forward")
     ap.add_argument("--no-fused-accumulate", action="store_true", help="let autograd add each view's gradients in a separate pass")
@@ -143,11 +145,17 @@ def main():
 
     flat = FlatGradients(params)            # parameter .grad tensors are views of one buffer: one collective per step
 
+    upstream_batch = lambda images: dL
+    if a.loss:
+        from youreditableavatar_amd.loss import l1_ssim_value_and_grad
+        targets = torch.rand(VPG, 3, H, W, device=dev)         # stand-ins for the ground-truth images of the step's views
+        upstream_batch = lambda images: l1_ssim_value_and_grad(images, targets)[1]
+
     def step(s):
         if batch is not None and not a.per_view_calls:
             # three native calls per step (forward of all views, per-pixel backward of all views, one per-Gaussian backward), one Meta read-back;
             # the one per-Gaussian pass of the step STORES the gradients, so the flat buffer needs no zeroing
-            batch.run_views([settings[v] for v in views_of(s)], means3D, opac, shs, scales, rots, lambda images: dL, accumulate=False)
+            batch.run_views([settings[v] for v in views_of(s)], means3D, opac, shs, scales, rots, upstream_batch, accumulate=False)
             flat.all_reduce()
             return
         flat.zero_()
@@ -248,6 +256,7 @@ def main():
                        "frames_per_step": N * VPG, "views_per_gpu_per_step": VPG, "fragments_per_frame": int(F_rank / frames_rank),
                        "instances_per_frame": int(Rm), "instances_binned_per_frame": int(sum(Rb_view[v] for s in range(a.steps) for v in views_of(s)) / frames_rank), "ms_per_frame_per_gpu": round(ms_per_step / VPG, 4),
                        "host_sync": "one per step (SyncFreeBatch)" if batch is not None else "one per frame (reference protocol)",
+                       "upstream": "fused L1+SSIM loss against target images (tgs_l1_ssim)" if a.loss else "fixed dL/d image",
                        "native_calls": ("3 per step (run_views)" if not a.per_view_calls else "per view, through autograd") if batch is not None else "per view",
                        "streams": batch.streams if batch is not None else 1,
                        "per_gaussian_backward": "one pass per step (tgs_backward_batch)" if (batch is not None and batch.deferred) else "one pass per view",
