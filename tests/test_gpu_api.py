@@ -536,3 +536,44 @@ def test_run_views_with_per_view_colors(gpu_device):
             batch.run_views(settings, L["means3D"], L["opacities"], L["shs"], L["scales"], L["rotations"], lambda im: dLs, colors_precomp=colors)
     finally:
         _C.set_deterministic(False)
+
+
+def test_run_views_at_the_benchmark_configuration(gpu_device):
+    """BASELINE config 3/4 at full size (500k Gaussians, 1920x1080, SH 3, 8 views on 4 streams): the whole-batch path bench.py
+    times against the per-view synchronous path (reference protocol) -- images bit-equal, per-view dL/d means2D and the
+    accumulated parameter gradients within the stated fp32 tolerance."""
+    from diff_gaussian_rasterization import _C
+    from youreditableavatar_amd import scenes
+    from youreditableavatar_amd.multiview import FlatGradients, SyncFreeBatch, rasterize_accumulate
+    cfg = scenes.CONFIGS[3]
+    P, W, H, D = cfg["P"], cfg["width"], cfg["height"], cfg["sh_degree"]
+    cloud = scenes.make_cloud(P, D, cfg["seed"])
+    V = 8
+    cams = [scenes.orbit_camera(W, H, azimuth_deg=k * 360.0 / 64) for k in range(V)]
+    dL = torch.from_numpy(scenes.upstream_gradient(W, H, seed=cfg["seed"] + 1000)).to(gpu_device)
+    L = _leaves(cloud, gpu_device)
+    names = ("means3D", "opacities", "scales", "rotations", "shs")
+    flat = FlatGradients([L[n] for n in names])
+    settings = [_settings(c, D, gpu_device) for c in cams]
+    flat.zero_()
+    want_img, want_2d = [], []
+    for v in range(V):
+        m2 = torch.zeros(P, 3, device=gpu_device, requires_grad=True)
+        img, _ = rasterize_accumulate(settings[v], means3D=L["means3D"], means2D=m2, opacities=L["opacities"], shs=L["shs"], scales=L["scales"],
+                                      rotations=L["rotations"])
+        img.backward(dL)
+        want_img.append(img.detach().clone()); want_2d.append(m2.grad.clone())
+    want = flat.flat.clone()
+    batch = SyncFreeBatch()
+    for rep in range(3):
+        imgs = batch.run_views(settings, L["means3D"], L["opacities"], L["shs"], L["scales"], L["rotations"], lambda im: dL, accumulate=False)
+    assert batch.rejected == 0 and batch.capacity() is not None
+    for v in range(V):
+        assert torch.equal(imgs[v], want_img[v]), v
+        assert util.rel_l2(batch.viewspace_grads[v].cpu().numpy(), want_2d[v].cpu().numpy()) <= 1e-5, v   # in-tile summation order (LDS atomics)
+    off = 0
+    for n in names:
+        k = L[n].numel()
+        e = util.rel_l2(flat.flat[off:off + k].cpu().numpy(), want[off:off + k].cpu().numpy())
+        assert e <= 1e-4, (n, e)
+        off += k
