@@ -82,6 +82,22 @@ int64_t tgs_forward_async(int64_t r_capacity, tgs_alloc_fn alloc, void* alloc_ct
                           float tan_fovx, float tan_fovy, int prefiltered,
                           float* out_color, int* radii, int debug);
 
+/* Rasterizer::forward with the read-back taken off the critical path: the caller passes the instance count it expects (e.g. last
+ * frame's, with headroom); the binning buffer is requested for r_guess instances, Meta is copied to the host right behind the scan,
+ * every later stage is enqueued WITHOUT waiting for it, and only then the host waits for that copy.  If the frame does not fit, the
+ * stages behind the scan (which returned at once) run again with the exact sizes, like tgs_forward -- the result is always the
+ * complete frame.  *num_rendered = the true count; the RETURN value is what the binning buffer is carved for (r_guess, or the true
+ * count after the retry): pass that as R to tgs_backward / tgs_state_field. */
+int64_t tgs_forward_speculative(int64_t r_guess, int64_t* num_rendered, tgs_alloc_fn alloc, void* alloc_ctx, void* stream,
+                                int P, int D, int M,
+                                const float* background, int width, int height,
+                                const float* means3D, const float* shs, const float* colors_precomp,
+                                const float* opacities, const float* scales, float scale_modifier,
+                                const float* rotations, const float* cov3D_precomp,
+                                const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                                float tan_fovx, float tan_fovy, int prefiltered,
+                                float* out_color, int* radii, int debug);
+
 enum { TGS_FRAME_PREFILTERED = 1, TGS_FRAME_REJECTED = 2 };
 /* Synchronises `stream` and returns the frame's true num_rendered and its TGS_FRAME_* flags.  The same 64 bytes sit at
  * the start of the image buffer (u64 num_rendered, u32 longest list, u32 overflow tiles, u32 flags, ...), so a batch

@@ -577,3 +577,33 @@ def test_run_views_at_the_benchmark_configuration(gpu_device):
         e = util.rel_l2(flat.flat[off:off + k].cpu().numpy(), want[off:off + k].cpu().numpy())
         assert e <= 1e-4, (n, e)
         off += k
+
+
+def test_speculative_forward_is_the_complete_frame(gpu_device):
+    """tgs_forward_speculative: with a fitting guess and with a guess that is far too small (retry with exact sizes) the image,
+    radii, true count and all gradients equal the plain synchronous call."""
+    from diff_gaussian_rasterization import _C
+    from youreditableavatar_amd import scenes
+    cloud = scenes.make_cloud(6000, 3, seed=45, scale_mult=3.0)
+    cam = scenes.orbit_camera(176, 112, azimuth_deg=60.0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(gpu_device)
+    e = torch.Tensor([])
+    args = (t(cam.bg), t(cloud["means3D"]), e, t(cloud["opacities"]), t(cloud["scales"]), t(cloud["rotations"]), 1.0, e, t(cam.viewmatrix),
+            t(cam.projmatrix), cam.tanfovx, cam.tanfovy, 112, 176, t(cloud["shs"]), 3, t(cam.campos), False, False)
+    dL = t(scenes.upstream_gradient(176, 112))
+    _C.set_deterministic(True)
+    try:
+        R, color, radii, geom, binning, img = _C.rasterize_gaussians(*args)
+        bw = lambda R_, radii_, geom_, binning_, img_: _C.rasterize_gaussians_backward(args[0], args[1], radii_, e, args[4], args[5], 1.0, e, args[8], args[9],
+                                                                                     cam.tanfovx, cam.tanfovy, dL, args[14], 3, args[16], geom_, R_, binning_, img_, False)
+        want = bw(R, radii, geom, binning, img)
+        for guess in (R + 7000, R, max(R // 10, 1), 0):
+            carve, color2, radii2, geom2, binning2, img2, true_R = _C.rasterize_gaussians(*args, r_guess=guess)
+            assert true_R == R and carve == (guess if guess >= R else R), guess
+            assert torch.equal(color2, color) and torch.equal(radii2, radii), guess
+            assert _C.frame_status(img2) == (R, 0)
+            got = bw(carve, radii2, geom2, binning2, img2)
+            for a, b in zip(got, want):
+                assert torch.equal(a, b), guess
+    finally:
+        _C.set_deterministic(False)

@@ -193,9 +193,21 @@ int tgs_profile_end(double* ms_sum, int64_t* counts)
 }
 const char* tgs_last_error(void) { return g_err; }
 
+// pinned Meta staging + event of the speculative forward, one per host thread
+struct SpecSlot { Meta* meta; hipEvent_t ready; };
+static SpecSlot* spec_slot()
+{
+    thread_local SpecSlot slot = {nullptr, nullptr};
+    if (!slot.meta) {
+        if (hipHostMalloc((void**)&slot.meta, sizeof(Meta), hipHostMallocDefault) != hipSuccess) { slot.meta = nullptr; return nullptr; }
+        if (hipEventCreateWithFlags(&slot.ready, hipEventDisableTiming) != hipSuccess) { (void)hipHostFree(slot.meta); slot.meta = nullptr; return nullptr; }
+    }
+    return &slot;
+}
+
 // r_capacity < 0: the reference's protocol (read R back, then size the binning buffer).  r_capacity >= 0: sync-free --
 // the binning buffer is sized for r_capacity instances before anything runs and nothing is read back.
-static int64_t forward_impl(int preprocessed, int64_t r_capacity, tgs_alloc_fn alloc, void* alloc_ctx, void* stream, int P, int D, int M, const float* background, int width,
+static int64_t forward_impl(int preprocessed, int64_t r_capacity, int64_t* speculative_true_R, tgs_alloc_fn alloc, void* alloc_ctx, void* stream, int P, int D, int M, const float* background, int width,
                     int height, const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
                     const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
                     const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
@@ -261,6 +273,15 @@ static int64_t forward_impl(int preprocessed, int64_t r_capacity, tgs_alloc_fn a
     STAGE_BEGIN(TGS_STAGE_SCAN);
     launch_scan(st, g, s, (uint32_t)n_blocks((size_t)P), (uint32_t)T, sort_cap, async ? (unsigned long long)r_capacity : ~0ull, async ? 0 : 1);
     STAGE_CHECK("scan", TGS_STAGE_SCAN);
+    SpecSlot* spec = nullptr;
+    if (async && speculative_true_R) {
+        // speculative synchronous forward: Meta travels to the host NOW, the remaining stages are enqueued against the guessed
+        // capacity without waiting, and only then the host waits for this copy -- the GPU never idles behind the read-back
+        spec = spec_slot();
+        if (!spec) return fail(TGS_ERR_HIP, "pinned staging for the speculative forward could not be allocated");
+        HIP_TRY(hipMemcpyAsync(spec->meta, s.meta, sizeof(Meta), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipEventRecord(spec->ready, st));
+    }
     if (!async) {
         // the one host synchronisation of the forward pass (rasterizer_impl.cu:280-281): R sizes the binning buffer
         HIP_TRY(hipMemcpyAsync(&meta, s.meta, sizeof(Meta), hipMemcpyDeviceToHost, st));
@@ -288,6 +309,29 @@ static int64_t forward_impl(int preprocessed, int64_t r_capacity, tgs_alloc_fn a
     STAGE_BEGIN(TGS_STAGE_RENDER_FWD);
     launch_render_fwd(st, s, b, width, height, cam.gx, (uint32_t)T, known, background, out_color);
     STAGE_CHECK("render", TGS_STAGE_RENDER_FWD);
+    if (spec) {
+        HIP_TRY(hipEventSynchronize(spec->ready));
+        meta = *spec->meta;
+        if (meta.error & 1u) return fail(TGS_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
+        if (meta.R > 0x7fffffffull) return fail(TGS_ERR_TOO_MANY, "%llu tile instances exceed 2^31-1", (unsigned long long)meta.R);
+        *speculative_true_R = (int64_t)meta.R;
+        if (meta.error & META_ERR_CAPACITY) {
+            // the guess was too small (or a list needs the host-sized overflow sort): every kernel behind the scan returned at
+            // once; clear the flag and run those stages again with the exact sizes, as tgs_forward does
+            HIP_TRY(hipMemsetAsync(&s.meta->error, 0, sizeof(uint32_t), st));
+            R = meta.R;
+            const size_t exact_bytes = bin_carve(b, nullptr, (size_t)R);
+            char* exact_ptr = (char*)alloc(alloc_ctx, TGS_BUF_BINNING, exact_bytes);
+            if (!exact_ptr) return fail(TGS_ERR_ALLOC, "binning buffer allocation failed");
+            bin_carve(b, exact_ptr, (size_t)R);
+            if (R > 0) {
+                launch_scatter(st, P, g, s, b, cam.gx);
+                launch_tile_sort(st, g, s, b, cam.gx, (uint32_t)T, R, &meta, sort_cap);
+            }
+            launch_render_fwd(st, s, b, width, height, cam.gx, (uint32_t)T, &meta, background, out_color);
+            HIP_TRY(hipGetLastError());
+        }
+    }
     return (int64_t)R;
 }
 
@@ -297,7 +341,7 @@ int64_t tgs_forward(tgs_alloc_fn alloc, void* alloc_ctx, void* stream, int P, in
                     const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
                     int prefiltered, float* out_color, int* radii, int debug)
 {
-    return forward_impl(0, -1, alloc, alloc_ctx, stream, P, D, M, background, width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
+    return forward_impl(0, -1, nullptr, alloc, alloc_ctx, stream, P, D, M, background, width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
                         rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, radii, debug);
 }
 
@@ -308,8 +352,21 @@ int64_t tgs_forward_async(int64_t r_capacity, tgs_alloc_fn alloc, void* alloc_ct
                           int prefiltered, float* out_color, int* radii, int debug)
 {
     if (r_capacity < 0) return fail(TGS_ERR_INVALID, "r_capacity must be >= 0");
-    return forward_impl(0, r_capacity, alloc, alloc_ctx, stream, P, D, M, background, width, height, means3D, shs, colors_precomp, opacities, scales,
+    return forward_impl(0, r_capacity, nullptr, alloc, alloc_ctx, stream, P, D, M, background, width, height, means3D, shs, colors_precomp, opacities, scales,
                         scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, radii, debug);
+}
+
+int64_t tgs_forward_speculative(int64_t r_guess, int64_t* num_rendered, tgs_alloc_fn alloc, void* alloc_ctx, void* stream, int P, int D, int M,
+                                const float* background, int width, int height, const float* means3D, const float* shs, const float* colors_precomp,
+                                const float* opacities, const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                                const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
+                                int prefiltered, float* out_color, int* radii, int debug)
+{
+    if (r_guess < 0 || !num_rendered) return fail(TGS_ERR_INVALID, "r_guess must be >= 0 and num_rendered non-NULL");
+    *num_rendered = 0;
+    return forward_impl(0, r_guess, num_rendered, alloc, alloc_ctx, stream, P, D, M, background, width, height, means3D, shs, colors_precomp, opacities,
+                        scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, radii,
+                        debug);
 }
 
 int tgs_frame_status(void* stream, const void* img_buffer, int64_t* num_rendered, int* flags)
@@ -481,7 +538,7 @@ int tgs_forward_views(void* const* streams, int n_streams, int64_t r_capacity, i
             tgs_view_t& v = views[v0 + k];
             hipStream_t st = (hipStream_t)streams[(v0 + k) % n_streams];
             if (pre_done && st != st0) HIP_TRY(hipStreamWaitEvent(st, pre_done, 0));
-            const int64_t r = forward_impl(batched ? 1 : 0, r_capacity, alloc_preset, &v, st, P, D, M, v.background, v.width, v.height, means3D, shs,
+            const int64_t r = forward_impl(batched ? 1 : 0, r_capacity, nullptr, alloc_preset, &v, st, P, D, M, v.background, v.width, v.height, means3D, shs,
                                            v.colors_precomp ? v.colors_precomp : colors_precomp,
                                            opacities, scales, scale_modifier, rotations, cov3D_precomp, v.viewmatrix, v.projmatrix, v.campos, v.tan_fovx, v.tan_fovy,
                                            prefiltered, v.out_color, v.radii_out, 0);

@@ -36,6 +36,8 @@ def _load() -> C.CDLL:
     lib.tgs_forward.argtypes = [vp, vp, vp, it, it, it, vp, it, it, vp, vp, vp, vp, vp, fl, vp, vp, vp, vp, vp, fl, fl, it, vp, vp, it]
     lib.tgs_forward_async.restype = C.c_int64
     lib.tgs_forward_async.argtypes = [C.c_int64] + lib.tgs_forward.argtypes
+    lib.tgs_forward_speculative.restype = C.c_int64
+    lib.tgs_forward_speculative.argtypes = [C.c_int64, C.POINTER(C.c_int64)] + lib.tgs_forward.argtypes
     lib.tgs_frame_status.restype = it
     lib.tgs_frame_status.argtypes = [vp, vp, C.POINTER(C.c_int64), C.POINTER(it)]
     lib.tgs_backward.restype = it
@@ -164,13 +166,17 @@ def _require_gpu(means3D: torch.Tensor) -> torch.device:
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                        prefiltered, debug, r_capacity: Optional[int] = None
+                        prefiltered, debug, r_capacity: Optional[int] = None, r_guess: Optional[int] = None
                         ) -> Tuple[int, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     """RasterizeGaussiansCUDA (rasterize_points.cu:35-115).
 
     ``r_capacity`` (extension, tgs_forward_async): render without the host read-back of num_rendered; the binning
     buffer holds ``r_capacity`` instances and that number is returned in place of num_rendered.  Check the frame with
-    ``frame_status`` / ``frame_meta`` afterwards: a rejected frame renders as background and back-propagates nothing."""
+    ``frame_status`` / ``frame_meta`` afterwards: a rejected frame renders as background and back-propagates nothing.
+
+    ``r_guess`` (extension, tgs_forward_speculative): the complete frame like the plain call, but the stages behind the scan are
+    enqueued against the guessed instance count while the read-back is in flight (they run again if the guess was too small).
+    Returns a 7-tuple then: the value to pass as ``R`` to the backward / ``state_field`` first, the true num_rendered last."""
     if means3D.dim() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     dev = _require_gpu(means3D)
@@ -196,9 +202,15 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                 _p(t["sh"]), _p(t["colors"]), _p(t["opac"]), _p(t["scales"]), float(scale_modifier), _p(t["rots"]),
                 _p(t["cov"]), _p(t["view"]), _p(t["proj"]), _p(t["campos"]), float(tan_fovx), float(tan_fovy),
                 int(bool(prefiltered)), out_color.data_ptr(), _p(radii) if P else None, int(bool(debug)))
-        r = _lib.tgs_forward(*args) if r_capacity is None else _lib.tgs_forward_async(int(r_capacity), *args)
+        true_R = C.c_int64(0)
+        if r_guess is not None:
+            r = _lib.tgs_forward_speculative(int(r_guess), C.byref(true_R), *args)
+        else:
+            r = _lib.tgs_forward(*args) if r_capacity is None else _lib.tgs_forward_async(int(r_capacity), *args)
         if r < 0:
             raise _err(int(r))
+    if r_guess is not None:
+        return int(r), out_color, radii, bufs[0], bufs[1], bufs[2], int(true_R.value)
     return int(r), out_color, radii, bufs[0], bufs[1], bufs[2]
 
 
