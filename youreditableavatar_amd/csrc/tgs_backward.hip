@@ -390,7 +390,6 @@ __device__ __forceinline__ void slab_sum(bool live, int idx, const GeomState& g,
     }
 }
 
-struct GaussIn { float mx, my, mz, s0, s1, s2, qr, qx, qy, qz; };
 struct GaussTerms {
     float a[NACC];                 // sums of the tile partials: colour rgb, mean2D xy, conic xx xy yy, opacity
     float dmean[3], dcov[6], dscale[3], drot[4];
@@ -570,20 +569,6 @@ __device__ __forceinline__ void pergauss_terms(int idx, bool live, int D, const 
 // ---------------------------------------------------------------------------------------------
 // k_preprocess_bwd: one view per launch
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ GaussIn load_gauss(const BwdIn& in, int idx, bool has_scale_rot)
-{
-    GaussIn gi;
-    const size_t i3 = 3 * (size_t)idx;
-    gi.mx = in.means3D[i3]; gi.my = in.means3D[i3 + 1]; gi.mz = in.means3D[i3 + 2];
-    gi.s0 = gi.s1 = gi.s2 = 0.f; gi.qr = gi.qx = gi.qy = gi.qz = 0.f;
-    if (has_scale_rot) {
-        gi.s0 = in.scales[i3]; gi.s1 = in.scales[i3 + 1]; gi.s2 = in.scales[i3 + 2];
-        const float4 q = reinterpret_cast<const float4*>(in.rotations)[idx];
-        gi.qr = q.x; gi.qx = q.y; gi.qy = q.z; gi.qz = q.w;
-    }
-    return gi;
-}
-
 // the parameter gradients of one Gaussian: stored, or added to what the buffers hold (accumulate)
 __device__ __forceinline__ void store_param_grads(const BwdIn& in, int idx, float dopacity, const float (&dcolor)[3], const float (&dmean)[3], const float (&dcov)[6],
                                                   const float (&dscale)[3], const float (&drot)[4])
