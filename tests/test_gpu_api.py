@@ -1,5 +1,7 @@
 """GPU: the public drop-in API (GaussianRasterizer + autograd) the way tetgs_scene calls it, edge cases,
 and the BASELINE.json configurations at full size against the CPU oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -607,3 +609,14 @@ def test_speculative_forward_is_the_complete_frame(gpu_device):
                 assert torch.equal(a, b), guess
     finally:
         _C.set_deterministic(False)
+
+
+def test_example_training_loop_converges(gpu_device):
+    """examples/train_views.py: cameras once -> run_views -> fused loss for all views -> batched backward -> Adam; the loss falls."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("train_views", os.path.join(util.ROOT, "examples", "train_views.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    vals = mod.run(steps=25, P=8000, W=192, H=128, V=6, log=lambda *_: None)
+    assert len(vals) == 25 and all(np.isfinite(vals))
+    assert vals[-1] < 0.6 * vals[0], (vals[0], vals[-1])
