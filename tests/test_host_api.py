@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import GOLDEN_DIR
+from tests.util import GOLDEN_DIR, ROOT
 
 
 def test_settings_tuple_matches_reference_field_order():
@@ -166,3 +166,22 @@ def test_deferred_backward_rejects_mixed_batches():
         d.add(rs(2), leaves, z(4), z(1), z(1), z(1), 0, None)                      # another SH degree
     with pytest.raises(RuntimeError):
         d.add(rs(3), dict(leaves, means3D=z(4, 3)), z(4), z(1), z(1), z(1), 0, None)   # another parameter tensor
+
+
+def test_bench_contract_is_parseable_without_a_gpu():
+    """bench.py: the driver's flags exist, the defaults are N=1 and a run of minutes, and the JSON line carries the contract's keys
+    (checked on the source: running it needs the MI355X)."""
+    import ast
+    import subprocess
+    import sys
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    ast.parse(src)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0
+    for flag in ("--gpus", "--steps", "--warmup", "--views-per-gpu", "--streams", "--sync-per-frame", "--no-cpu"):
+        assert flag in out.stdout, flag
+    for key in ('"metric"', '"value"', '"unit"', '"n_gpus"', '"steps"', '"warmup"', '"ms_per_step"', '"higher_is_better"', '"scaling"', '"vs_baseline"', '"dtype"',
+                '"data"', '"config"', '"workload"', '"roofline"', '"bound"', '"achieved"', '"peak"', '"frac"', '"traffic"', '"cpu_baseline"', '"cores"', '"kind"',
+                '"sample"'):
+        assert key in src, key
+    assert "from oracle" in src and "cpu_baseline" in src          # the oracle is used for the reported CPU baseline only
