@@ -71,3 +71,61 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
            [vp(0)] * 5 + [ctypes.c_float(1.0)] + [vp(0)] * 5 + [ctypes.c_float(1.0), ctypes.c_float(1.0), ctypes.c_int(0), vp(0), vp(0), ctypes.c_int(0)]
     r = lib.tgs_forward(*args)
     assert r == -1 and b"alloc" in lib.tgs_last_error()
+
+
+def test_argument_validation_needs_no_gpu():
+    """Every entry point rejects bad arguments with TGS_ERR_INVALID and a message before it touches the device."""
+    lib = ctypes.CDLL(lib_path())
+    vp, it, i64, fl, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
+    lib.tgs_last_error.restype = ctypes.c_char_p
+    INVALID = -1
+
+    def msg():
+        return (lib.tgs_last_error() or b"").decode()
+
+    lib.tgs_forward.restype = i64
+    lib.tgs_forward.argtypes = [vp, vp, vp, it, it, it, vp, it, it, vp, vp, vp, vp, vp, fl, vp, vp, vp, vp, vp, fl, fl, it, vp, vp, it]
+    assert lib.tgs_forward(None, None, None, 10, 0, 0, None, 64, 64, None, None, None, None, None, 1.0, None, None, None, None, None, 1.0, 1.0, 0, None, None, 0) == INVALID
+    assert "alloc" in msg()
+    lib.tgs_forward_async.restype = i64
+    lib.tgs_forward_async.argtypes = [i64] + lib.tgs_forward.argtypes
+    assert lib.tgs_forward_async(-5, None, None, None, 10, 0, 0, None, 64, 64, None, None, None, None, None, 1.0, None, None, None, None, None, 1.0, 1.0, 0, None, None, 0) == INVALID
+    lib.tgs_backward_render.restype = it
+    lib.tgs_backward_render.argtypes = [vp, it, i64, vp, it, it, vp, vp, vp]
+    assert lib.tgs_backward_render(None, 10, 5, None, 64, 64, None, None, None) == INVALID and "NULL" in msg()
+    assert lib.tgs_backward_render(None, 0, 0, None, 64, 64, None, None, None) == 0          # P == 0: nothing to do
+    lib.tgs_backward_batch.restype = it
+    lib.tgs_backward_batch.argtypes = [vp, it, it, it, it, vp, vp, vp, vp, fl, vp, vp, vp, vp, vp, vp, vp, vp, it]
+    assert lib.tgs_backward_batch(None, 10, 3, 16, 2, None, None, None, None, 1.0, None, None, None, None, None, None, None, None, 0) == INVALID
+    lib.tgs_forward_views.restype = it
+    lib.tgs_forward_views.argtypes = [vp, it, i64, it, it, it, vp, vp, vp, vp, vp, fl, vp, vp, it, it, vp]
+    assert lib.tgs_forward_views(None, 0, 100, 10, 3, 16, None, None, None, None, None, 1.0, None, None, 0, 2, None) == INVALID
+    lib.tgs_dist2.restype = it
+    lib.tgs_dist2.argtypes = [vp, it, vp, vp, vp, sz]
+    assert lib.tgs_dist2(None, -1, None, None, None, 0) == INVALID and "tgs_dist2" in msg()
+    assert lib.tgs_dist2(None, 0, None, None, None, 0) == 0
+    lib.tgs_knn_self.restype = it
+    lib.tgs_knn_self.argtypes = [vp, it, it, vp, vp, vp, vp, sz]
+    assert lib.tgs_knn_self(None, 10, 33, None, None, None, None, 0) == INVALID and "tgs_knn_self" in msg()
+    lib.tgs_l1_ssim.restype = it
+    lib.tgs_l1_ssim.argtypes = [vp, it, it, it, vp, vp, fl, vp, vp, vp, sz]
+    assert lib.tgs_l1_ssim(None, 0, 8, 8, None, None, 0.2, None, None, None, 0) == INVALID and "tgs_l1_ssim" in msg()
+    lib.tgs_sh_rgb_forward.restype = it
+    lib.tgs_sh_rgb_forward.argtypes = [vp, it, it, it, vp, vp, vp, vp, vp]
+    assert lib.tgs_sh_rgb_forward(None, 10, 16, 5, None, None, None, None, None) == INVALID and "levels" in msg()
+    lib.tgs_set_sort_lds_cap.restype = it
+    lib.tgs_set_sort_lds_cap.argtypes = [ctypes.c_uint]
+    assert lib.tgs_set_sort_lds_cap(3) < 0 and lib.tgs_set_sort_lds_cap(8192) == 0
+    # host-only size queries
+    lib.tgs_state_sizes.restype = None
+    lib.tgs_state_sizes.argtypes = [it, it, it, it, it, i64, ctypes.POINTER(sz)]
+    a, b = (sz * 3)(), (sz * 3)()
+    lib.tgs_state_sizes(500000, 1920, 1080, 1, 1, 1_000_000, a)
+    lib.tgs_state_sizes(500000, 1920, 1080, 1, 1, 2_000_000, b)
+    assert a[0] == b[0] > 500000 * 64 and a[2] == b[2] > 1920 * 1080 * 8 and b[1] > a[1] >= 1_000_000 * 100
+    lib.tgs_dist2_workspace_bytes.restype = sz
+    lib.tgs_dist2_workspace_bytes.argtypes = [it]
+    assert lib.tgs_dist2_workspace_bytes(1000) > 1000 * 24
+    lib.tgs_l1_ssim_workspace_bytes.restype = sz
+    lib.tgs_l1_ssim_workspace_bytes.argtypes = [it, it, it]
+    assert lib.tgs_l1_ssim_workspace_bytes(3, 1080, 1920) >= 3 * 3 * 1080 * 1920 * 4 and lib.tgs_l1_ssim_workspace_bytes(0, 8, 8) == 0
