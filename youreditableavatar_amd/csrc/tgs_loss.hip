@@ -28,21 +28,42 @@ struct LossWin { float w[NTAP]; };
 // steps so that the loads of the NEXT tile are in flight while the current one is convolved: fetch into registers
 // (7 values per thread and map), commit to LDS one iteration later.
 constexpr int LPT = (LTW * LTH + 255) / 256;            // tile elements per thread
-__device__ __forceinline__ void fetch_tile(float (&v)[LPT], const float* __restrict__ src, int H, int W, int x0, int y0)
+// The (row, column) of a thread's LPT tile elements never change while a workgroup walks down its column of tiles, so the
+// index arithmetic (a division by 42 per element) is done once: global offset inside the tile's rows, LDS offset, and whether
+// the element exists / lies inside the image horizontally.
+struct TileSlots {
+    int goff[LPT];      // r * W + (x0 + c - LR), or -1 when there is no element or it is outside the image in x
+    int row[LPT];       // r
+    int lds[LPT];       // r * (LTW + 1) + c, or -1 when there is no element
+};
+__device__ __forceinline__ TileSlots make_slots(int W, int x0)
 {
+    TileSlots t;
 #pragma unroll
     for (int k = 0; k < LPT; k++) {
-        const int i = threadIdx.x + 256 * k, r = i / LTW, c = i - r * LTW, gx = x0 + c - LR, gy = y0 + r - LR;
-        v[k] = (i < LTW * LTH && gx >= 0 && gx < W && gy >= 0 && gy < H) ? src[(size_t)gy * W + gx] : 0.f;
+        const int i = threadIdx.x + 256 * k, r = i / LTW, c = i - r * LTW, gx = x0 + c - LR;
+        const bool exists = i < LTW * LTH;
+        t.row[k] = r;
+        t.lds[k] = exists ? r * (LTW + 1) + c : -1;
+        t.goff[k] = (exists && gx >= 0 && gx < W) ? r * W + gx : -1;
+    }
+    return t;
+}
+__device__ __forceinline__ void fetch_tile(float (&v)[LPT], const TileSlots& t, const float* __restrict__ src, int H, int W, int y0)
+{
+    const float* base = src + (ptrdiff_t)(y0 - LR) * W;
+#pragma unroll
+    for (int k = 0; k < LPT; k++) {
+        const int gy = y0 + t.row[k] - LR;
+        v[k] = (t.goff[k] >= 0 && gy >= 0 && gy < H) ? base[t.goff[k]] : 0.f;
     }
 }
-__device__ __forceinline__ void commit_tile(float (*dst)[LTW + 1], const float (&v)[LPT])
+__device__ __forceinline__ void commit_tile(float (*dst)[LTW + 1], const TileSlots& t, const float (&v)[LPT])
 {
+    float* d = &dst[0][0];
 #pragma unroll
-    for (int k = 0; k < LPT; k++) {
-        const int i = threadIdx.x + 256 * k, r = i / LTW, c = i - r * LTW;
-        if (i < LTW * LTH) dst[r][c] = v[k];
-    }
+    for (int k = 0; k < LPT; k++)
+        if (t.lds[k] >= 0) d[t.lds[k]] = v[k];
 }
 constexpr int LTY = 4;                                   // tiles a workgroup walks down a column of the image
 
@@ -112,17 +133,18 @@ __global__ __launch_bounds__(256) void k_ssim_stats(int H, int W, const float* _
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     float s_map = 0.f, s_l1 = 0.f;
     float vx[LPT], vy[LPT];
-    fetch_tile(vx, img + plane, H, W, x0, blockIdx.y * LTY * LH);
-    fetch_tile(vy, gt + plane, H, W, x0, blockIdx.y * LTY * LH);
+    const TileSlots slots = make_slots(W, x0);
+    fetch_tile(vx, slots, img + plane, H, W, blockIdx.y * LTY * LH);
+    fetch_tile(vy, slots, gt + plane, H, W, blockIdx.y * LTY * LH);
     for (int it = 0; it < LTY; it++) {
         const int y0 = (blockIdx.y * LTY + it) * LH;
         if (y0 >= H) break;                                  // uniform
-        commit_tile(sx, vx);
-        commit_tile(sy, vy);
+        commit_tile(sx, slots, vx);
+        commit_tile(sy, slots, vy);
         __syncthreads();
         if (it + 1 < LTY && y0 + LH < H) {                   // next tile's loads fly under this tile's arithmetic
-            fetch_tile(vx, img + plane, H, W, x0, y0 + LH);
-            fetch_tile(vy, gt + plane, H, W, x0, y0 + LH);
+            fetch_tile(vx, slots, img + plane, H, W, y0 + LH);
+            fetch_tile(vy, slots, gt + plane, H, W, y0 + LH);
         }
         hpass<5>(h, win, [&](int r, int c, float (&v)[5]) { const float x = sx[r][c], y = sy[r][c]; v[0] = x; v[1] = y; v[2] = x * x; v[3] = y * y; v[4] = x * y; });
         __syncthreads();
@@ -188,20 +210,21 @@ __global__ __launch_bounds__(256) void k_ssim_grad(int H, int W, const float* __
     const size_t plane = (size_t)blockIdx.z * H * W;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     float v0[LPT], v1[LPT], v2[LPT];
-    fetch_tile(v0, dM1 + plane, H, W, x0, blockIdx.y * LTY * LH);
-    fetch_tile(v1, dX2 + plane, H, W, x0, blockIdx.y * LTY * LH);
-    fetch_tile(v2, dXY + plane, H, W, x0, blockIdx.y * LTY * LH);
+    const TileSlots slots = make_slots(W, x0);
+    fetch_tile(v0, slots, dM1 + plane, H, W, blockIdx.y * LTY * LH);
+    fetch_tile(v1, slots, dX2 + plane, H, W, blockIdx.y * LTY * LH);
+    fetch_tile(v2, slots, dXY + plane, H, W, blockIdx.y * LTY * LH);
     for (int it = 0; it < LTY; it++) {
         const int y0 = (blockIdx.y * LTY + it) * LH;
         if (y0 >= H) break;                                  // uniform
-        commit_tile(t[0], v0);
-        commit_tile(t[1], v1);
-        commit_tile(t[2], v2);
+        commit_tile(t[0], slots, v0);
+        commit_tile(t[1], slots, v1);
+        commit_tile(t[2], slots, v2);
         __syncthreads();
         if (it + 1 < LTY && y0 + LH < H) {
-            fetch_tile(v0, dM1 + plane, H, W, x0, y0 + LH);
-            fetch_tile(v1, dX2 + plane, H, W, x0, y0 + LH);
-            fetch_tile(v2, dXY + plane, H, W, x0, y0 + LH);
+            fetch_tile(v0, slots, dM1 + plane, H, W, y0 + LH);
+            fetch_tile(v1, slots, dX2 + plane, H, W, y0 + LH);
+            fetch_tile(v2, slots, dXY + plane, H, W, y0 + LH);
         }
         hpass<3>(h, win, [&](int r, int c, float (&v)[3]) { v[0] = t[0][r][c]; v[1] = t[1][r][c]; v[2] = t[2][r][c]; });
         __syncthreads();
