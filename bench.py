@@ -4,9 +4,11 @@
 Workload (BASELINE.json configs[2]/[3]): 500k Gaussians, 1920x1080, SH degree 3 evaluated inside the
 rasterizer, orbit cameras of the 64-view batch.  A *step* = one data-parallel batch: every GPU renders
 ``--views-per-gpu`` (default 8 = 64 views / 8 GPUs) frames, each one forward + one backward of the
-rasterizer through the public drop-in API (GaussianRasterizer + autograd) with the upstream gradient
-supplied, accumulating the per-Gaussian gradients in one flat buffer; at N > 1 the step ends with ONE
-RCCL all-reduce of that buffer (236 B/Gaussian).  Per-GPU work is fixed as N grows (weak scaling).
+rasterizer with the upstream gradient supplied, through multiview.SyncFreeBatch.run_views (three native calls
+per step, no host synchronisation per frame, views on four HIP streams, one per-Gaussian backward pass for the
+batch; ``--per-view-calls`` / ``--sync-per-frame`` select the autograd path / the reference's protocol), the
+per-Gaussian gradients of all views landing in one flat buffer; at N > 1 the step ends with ONE RCCL
+all-reduce of that buffer (236 B/Gaussian).  Per-GPU work is fixed as N grows (weak scaling).
 Metric numerator: F = sum over pixels of n_contrib, counted per view outside the
 timed region.  Inputs are resident in HBM before the timed region starts.
 
@@ -20,6 +22,7 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this driver
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
