@@ -1,0 +1,35 @@
+"""How much of the render kernels' lane work is useful, by culling granularity (config 3, view 0): for every tile instance
+count the pixels with alpha >= 1/255, and the 4x4 blocks / 2x2 quadrants that contain at least one such pixel."""
+import sys, os, numpy as np, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from youreditableavatar_amd import scenes
+from diff_gaussian_rasterization import _C
+dev = torch.device("cuda", 0)
+cfg = scenes.CONFIGS[3]; P, W, H, D = cfg["P"], cfg["width"], cfg["height"], cfg["sh_degree"]
+cloud = scenes.make_cloud(P, D, cfg["seed"])
+g = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
+e = torch.Tensor([])
+c = scenes.orbit_camera(W, H, azimuth_deg=0.0)
+R, color, radii, geom, binning, img = _C.rasterize_gaussians(g(c.bg), g(cloud["means3D"]), e, g(cloud["opacities"]), g(cloud["scales"]), g(cloud["rotations"]), 1.0, e,
+    g(c.viewmatrix), g(c.projmatrix), c.tanfovx, c.tanfovy, H, W, g(cloud["shs"]), D, g(c.campos), False, False)
+f = lambda n: _C.state_field(n, P, W, H, R, True, True, geom, binning, img)
+pl = f("point_list").long(); rg = f("ranges").view(-1, 2).long(); m2 = f("means2D").view(-1, 2); co = f("conic_opacity").view(-1, 4)
+gx = (W + 15) // 16
+lens = rg[:, 1] - rg[:, 0]
+tile_of = torch.repeat_interleave(torch.arange(rg.shape[0], device=dev), lens)          # instances are stored tile-major
+px = torch.arange(16, device=dev, dtype=torch.float32)
+tot_px = tot_blk = tot_quad = 0
+for s in range(0, R, 1 << 18):
+    ids, t = pl[s:s + (1 << 18)], tile_of[s:s + (1 << 18)]
+    x0, y0 = ((t % gx) * 16).float(), ((t // gx) * 16).float()
+    dx = m2[ids, 0, None, None] - (x0[:, None, None] + px[None, None, :])
+    dy = m2[ids, 1, None, None] - (y0[:, None, None] + px[None, :, None])
+    q = co[ids]
+    power = -0.5 * (q[:, 0, None, None] * dx * dx + q[:, 2, None, None] * dy * dy) - q[:, 1, None, None] * dx * dy
+    alive = (power <= 0) & (torch.minimum(torch.tensor(0.99, device=dev), q[:, 3, None, None] * torch.exp(power)) >= 1.0 / 255.0)   # [n,16(y),16(x)]
+    tot_px += int(alive.sum())
+    tot_blk += int(alive.view(-1, 4, 4, 4, 4).any(dim=4).any(dim=2).sum())
+    tot_quad += int(alive.view(-1, 8, 2, 8, 2).any(dim=4).any(dim=2).sum())
+print(f"instances {R}; alive (pixel, instance) pairs {tot_px}")
+print(f"4x4 blocks touched {tot_blk} -> {16 * tot_blk} lane-pairs processed, {tot_px / (16 * tot_blk) * 100:.1f} % useful")
+print(f"2x2 quadrants touched {tot_quad} -> {4 * tot_quad} lane-pairs, {tot_px / (4 * tot_quad) * 100:.1f} % useful; ratio 4x4 / 2x2 = {16 * tot_blk / (4 * tot_quad):.2f}")
