@@ -19,6 +19,8 @@ lens = rg[:, 1] - rg[:, 0]
 tile_of = torch.repeat_interleave(torch.arange(rg.shape[0], device=dev), lens)          # instances are stored tile-major
 px = torch.arange(16, device=dev, dtype=torch.float32)
 tot_px = tot_blk = tot_quad = 0
+T = rg.shape[0]
+nb = torch.zeros(T, 16, device=dev, dtype=torch.long); nq = torch.zeros(T, 64, device=dev, dtype=torch.long)
 for s in range(0, R, 1 << 18):
     ids, t = pl[s:s + (1 << 18)], tile_of[s:s + (1 << 18)]
     x0, y0 = ((t % gx) * 16).float(), ((t // gx) * 16).float()
@@ -30,6 +32,21 @@ for s in range(0, R, 1 << 18):
     tot_px += int(alive.sum())
     tot_blk += int(alive.view(-1, 4, 4, 4, 4).any(dim=4).any(dim=2).sum())
     tot_quad += int(alive.view(-1, 8, 2, 8, 2).any(dim=4).any(dim=2).sum())
+    nb.index_add_(0, t, alive.view(-1, 4, 4, 4, 4).any(dim=4).any(dim=2).view(-1, 16).long())
+    # quadrant index = block * 4 + quadrant-in-block
+    qa = alive.view(-1, 4, 2, 2, 4, 2, 2).any(dim=6).any(dim=3)             # [n, by, qy, bx, qx]
+    nq.index_add_(0, t, qa.permute(0, 1, 3, 2, 4).reshape(-1, 64).long())
 print(f"instances {R}; alive (pixel, instance) pairs {tot_px}")
 print(f"4x4 blocks touched {tot_blk} -> {16 * tot_blk} lane-pairs processed, {tot_px / (16 * tot_blk) * 100:.1f} % useful")
 print(f"2x2 quadrants touched {tot_quad} -> {4 * tot_quad} lane-pairs, {tot_px / (4 * tot_quad) * 100:.1f} % useful; ratio 4x4 / 2x2 = {16 * tot_blk / (4 * tot_quad):.2f}")
+
+# wave passes of the render kernels (4 entries per pass; single staging round assumed, early termination ignored)
+c4 = lambda n: (n + 3) // 4
+cur = c4(nb)                                              # [T,16] passes of each wave now
+new = c4(nq).view(T, 16, 4).max(dim=2).values            # each 16-lane row walks its own quadrant's list
+print(f"wave passes: block lists {int(cur.sum())}, quadrant lists {int(new.sum())}  ({cur.sum() / new.sum():.2f}x)")
+crit_cur, crit_new = cur.max(dim=1).values, new.max(dim=1).values
+print(f"critical path per tile (slowest wave), summed: {int(crit_cur.sum())} -> {int(crit_new.sum())}  ({crit_cur.sum() / crit_new.sum():.2f}x)")
+top = torch.argsort(lens, descending=True)[:256]
+print(f"256 longest tiles: passes {int(cur[top].sum())} -> {int(new[top].sum())} ({cur[top].sum() / new[top].sum():.2f}x); slowest wave {int(crit_cur[top].sum())} -> {int(crit_new[top].sum())} ({crit_cur[top].sum() / crit_new[top].sum():.2f}x)")
+print(f"sum_q n_q / n_b over blocks: {nq.sum() / nb.sum():.2f}; blocks whose 4 quadrant lists exceed 2x512 entries: {int((nq.view(T,16,4).sum(2) > 1000).sum())}")

@@ -194,7 +194,10 @@ __global__ __launch_bounds__(256) void k_render_bwd_det(const ImgState s, const 
 // (bitwise reproducible) at about 2.5x the time; tgs_set_deterministic(1) selects it.
 // ---------------------------------------------------------------------------------------------
 constexpr int BWD_THREADS = 1024;
-constexpr int BCH = 512;                   // list entries per round
+#ifndef TGS_BCH
+#define TGS_BCH 384
+#endif
+constexpr int BCH = TGS_BCH;               // list entries per round
 constexpr int BNULL = BCH;
 
 __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s, const BinState b, int W, int H, uint32_t gx,
@@ -203,19 +206,21 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
     __shared__ float4 sA[BCH + 1];
     __shared__ float4 sB[BCH + 1];
     __shared__ float sC[BCH + 1];
-    __shared__ uint32_t sSlot[2][BCH];                       // double-buffered: the flush of round r overlaps the staging of r+1
-    __shared__ float acc[NACC][BCH + 1];                   // per-round sums; column BNULL swallows the padding entries
-    __shared__ unsigned short sMask[BCH];
-    __shared__ __attribute__((aligned(16))) unsigned short lists[16][BCH + 8];   // one list per block (= per wave)
+    __shared__ uint32_t sSlot[2][BCH];                     // double-buffered, like sFl: the flush of round r overlaps the staging of r+1,
+    __shared__ float2 sFl[2][BCH];                         // and these are written by the OTHER half of the workgroup: (conic yy, opacity) for the flush
+    __shared__ double acc[NACC][BCH + 1];                  // per-round sums (f64: ds_add_f64 runs ~20x the rate of ds_add_f32 on gfx950); column BNULL swallows the padding entries
+    __shared__ uint2 sQ[BCH];                              // quadrant masks of the staged entries
+    __shared__ __attribute__((aligned(16))) unsigned short lists[16][BCH + 8];   // one list per block (= per wave): slot | quadrant nibble << 10
+    __shared__ __attribute__((aligned(16))) unsigned short qlists[16][4][QL_ROW]; // per wave: the current chunk's four quadrant lists
 
     if (frame_rejected(s)) return;
     const uint4 td = s.tile_desc[blockIdx.x];
     const uint32_t tile = td.x;
     const uint32_t tx = tile % gx, ty = tile / gx;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int pp = lane >> 2, e = lane & 3;
-    const int px = tx * TILE + (wv & 3) * 4 + (pp & 3);
-    const int py = ty * TILE + (wv >> 2) * 4 + (pp >> 2);
+    const int qd = lane >> 4, pq = (lane >> 2) & 3, e = lane & 3;   // DPP row = 2x2 quadrant of the block, pixel of the quadrant, entry slot
+    const int px = tx * TILE + (wv & 3) * 4 + (qd & 1) * 2 + (pq & 1);
+    const int py = ty * TILE + (wv >> 2) * 4 + (qd >> 1) * 2 + (pq >> 1);
     const bool inside = px < W && py < H;
     const float pixfx = (float)px, pixfy = (float)py;
     const uint2 rg = make_uint2(td.y, td.z);
@@ -249,25 +254,25 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
     }
 
     // Register-staged prefetch of the next round, split over the two halves of the workgroup so that it costs 6 VGPRs, not 11
-    // (64 VGPRs keep two workgroups per CU): thread t < BCH carries recA + recC of entry t, thread BCH + t recB + slot.
-    const uint32_t ht = threadIdx.x & (BCH - 1);
+    // (64 VGPRs keep two workgroups per CU): thread t < BCH carries recA + the quadrant mask of entry t, thread BCH + t recB + recC + slot.
     const bool upper = threadIdx.x >= BCH;
+    const uint32_t ht = threadIdx.x < 2 * BCH ? (upper ? threadIdx.x - BCH : threadIdx.x) : 0xffffffffu;   // (threads beyond 2 BCH stage nothing)
     float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
     uint2 r2 = make_uint2(0u, 0u);
     auto fetch = [&](uint32_t pos) {
-        if (!upper) { r4 = b.recA[pos]; const float2 c = b.recC[pos]; r2 = make_uint2(__float_as_uint(c.x), __float_as_uint(c.y)); }
-        else { r4 = b.recB[pos]; r2.x = b.slot[pos]; }
+        if (!upper) { r4 = b.recA[pos]; r2 = b.qmask[pos]; }
+        else { r4 = b.recB[pos]; r2 = make_uint2(__float_as_uint(b.recC[pos].x), b.slot[pos]); }
     };
     auto stage = [&](int buf) {
         uint32_t h = ht;
         asm volatile("" : "+v"(h));                        // keeps the five LDS addresses from being hoisted into (spilled) VGPRs
-        if (!upper) { stage_conic_a(r4); sA[h] = r4; sC[h] = __uint_as_float(r2.x); sMask[h] = (unsigned short)r2.y; }
-        else { stage_conic_b(r4); sB[h] = r4; sSlot[buf][h] = r2.x; }
+        if (!upper) { stage_conic_a(r4); sA[h] = r4; sQ[h] = r2; }
+        else { sFl[buf][h] = make_float2(r4.x, r4.y); stage_conic_b(r4); sB[h] = r4; sC[h] = __uint_as_float(r2.x); sSlot[buf][h] = r2.y; }
     };
     if (ht < qmax) fetch(rg.x + qmax - 1 - ht);
 
     // Two barriers per round: [compute r] | flush r + zero its accumulator column + stage r+1 | [compute r+1] ...
-    for (uint32_t i = threadIdx.x; i < NACC * (BCH + 1); i += BWD_THREADS) (&acc[0][0])[i] = 0.f;
+    for (uint32_t i = threadIdx.x; i < NACC * (BCH + 1); i += BWD_THREADS) (&acc[0][0])[i] = 0.0;
     {
         const uint32_t cnt0 = min((uint32_t)BCH, qmax);
         if (ht < cnt0) stage(0);
@@ -278,10 +283,14 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
     for (uint32_t qhi = qmax; qhi > 0; qhi = qhi > BCH ? qhi - BCH : 0, rnd ^= 1) {
         const uint32_t cnt = min((uint32_t)BCH, qhi);
         {
-            const uint32_t nl = build_own_list<BCH>(lists[wv], sMask, cnt, wv, lane, BNULL);
+            const uint32_t nl = build_own_list_q<BCH>(lists[wv], sQ, cnt, wv, lane);
+            const unsigned short* myq = &qlists[wv][qd][e];
 #pragma unroll 1
-            for (uint32_t k = 0; k < nl; k += 4) {
-                const uint32_t j = lists[wv][k + e];
+            for (uint32_t c0 = 0; c0 < nl; c0 += QCH) {
+            const uint32_t nq = build_chunk_quadrant_lists(qlists[wv], lists[wv], c0, nl, lane, BNULL);
+#pragma unroll 1
+            for (uint32_t k = 0; k < nq; k += 4) {          // 4 entries of its own quadrant list per row and pass
+                const uint32_t j = myq[k];
                 const float4 a = sA[j];                     // mean2D, conic xx / xy pre-scaled for exp2 (stage_conic)
                 const float4 bb = sB[j];                    // conic yy pre-scaled, opacity, colour r g
                 const float c0 = bb.z, c1 = bb.w, c2 = sC[j];
@@ -312,32 +321,34 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
                 v[3] = wdx; v[4] = wdy;
                 v[5] = wdx * dx; v[6] = wdx * dy; v[7] = wdy * dy;
                 v[8] = w;
-                row_stride4_sum9(v);                        // the 4 lanes of a row that share an entry slot
-                // fold the 4 rows: afterwards s0 rows 0..3 = components 0..3, s1 rows = components 4..7, s2 = component 8
-                const float q0 = swap16_add(v[0], v[1]), q1 = swap16_add(v[2], v[3]), q2 = swap16_add(v[4], v[5]), q3 = swap16_add(v[6], v[7]);
-                const float q4 = swap16_add(v[8], v[8]);
-                const float s0 = swap32_add(q0, q1), s1 = swap32_add(q2, q3), s2 = swap32_add(q4, q4);
-                if ((lane & 15) < 4) {                      // lane l of row r: entry slot l (its own j), component r / 4+r / 8
-                    const int row = lane >> 4;
-                    atomicAdd(&acc[row][j], s0);
-                    atomicAdd(&acc[4 + row][j], s1);
-                    if (row == 0) atomicAdd(&acc[8][j], s2);
-                }
+                row_stride4_sum9(v);                        // the quadrant's 4 pixels: the 4 lanes of the row that share an entry slot
+                // every row adds for its own entries: lane (pixel i, slot e) takes components i, 4 + i (and 8 if i == 0) of entry j
+                const float s0 = pq == 0 ? v[0] : pq == 1 ? v[1] : pq == 2 ? v[2] : v[3];
+                const float s1 = pq == 0 ? v[4] : pq == 1 ? v[5] : pq == 2 ? v[6] : v[7];
+#ifdef TGS_EXP_NOATOM
+                asm volatile("" :: "v"(s0), "v"(s1), "v"(v[8]));
+#else
+                atomicAdd(&acc[pq][j], (double)s0);
+                atomicAdd(&acc[4 + pq][j], (double)s1);
+                if (pq == 0) atomicAdd(&acc[8][j], (double)v[8]);
+#endif
+            }
             }
         }
         __syncthreads();                                    // every wave is done with the records and the accumulator of this round
         if (threadIdx.x < cnt) {                            // flush: one 48-B row per instance, then clear the column for the next round
             const uint32_t j = threadIdx.x;
             // moments -> gradients (backward.cu:537-555): dL_dG = opacity * dL_dalpha, dG/ddel = -G (conic . d), conic terms * -0.5
-            const float4 a = sA[j]; const float4 bb = sB[j];
-            const float cxx = a.z * UNSCALE_CONIC, cxy = a.w * UNSCALE_CONIC_XY, cyy = bb.x * UNSCALE_CONIC, op = bb.y;
-            const float Sx = acc[3][j], Sy = acc[4][j];
+            // (sA[j] is restaged by this same thread below; sB[j] by thread BCH + j, possibly already: hence sFl)
+            const float4 a = sA[j]; const float2 fl = sFl[rnd][j];
+            const float cxx = a.z * UNSCALE_CONIC, cxy = a.w * UNSCALE_CONIC_XY, cyy = fl.x, op = fl.y;
+            const float Sx = (float)acc[3][j], Sy = (float)acc[4][j];
             float4* row = b.slab + (size_t)sSlot[rnd][j] * SLAB_ROW;
-            row[0] = make_float4(acc[0][j], acc[1][j], acc[2][j], op * (-Sx * cxx - Sy * cxy) * ddelx_dx);
-            row[1] = make_float4(op * (-Sy * cyy - Sx * cxy) * ddely_dy, -0.5f * op * acc[5][j], -0.5f * op * acc[6][j], -0.5f * op * acc[7][j]);
-            row[2] = make_float4(acc[8][j], 0.f, 0.f, 0.f);
+            row[0] = make_float4((float)acc[0][j], (float)acc[1][j], (float)acc[2][j], op * (-Sx * cxx - Sy * cxy) * ddelx_dx);
+            row[1] = make_float4(op * (-Sy * cyy - Sx * cxy) * ddely_dy, -0.5f * op * (float)acc[5][j], -0.5f * op * (float)acc[6][j], -0.5f * op * (float)acc[7][j]);
+            row[2] = make_float4((float)acc[8][j], 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int k = 0; k < NACC; k++) acc[k][j] = 0.f;
+            for (int k = 0; k < NACC; k++) acc[k][j] = 0.0;
         }
         if (qhi > BCH) {                                    // stage the next round (its records were prefetched into registers)
             const uint32_t qn = qhi - BCH, cntn = min((uint32_t)BCH, qn);

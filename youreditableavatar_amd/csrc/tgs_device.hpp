@@ -71,6 +71,7 @@ struct BinState {
     float4* recB;             //                              conic.z, opacity, r, g
     float2* recC;             //                              b, bits(gaussian idx)
     uint32_t* slot;           // offsets[g] + ordinal of this tile in g's rectangle (gradient slab row)
+    uint2* qmask;             // 64-bit mask of the tile's 2x2-pixel quadrants the splat reaches: bit 4*block + quadrant
     float4* slab;             // backward scratch: SLAB_ROW float4 (9 sums + padding) per instance, Gaussian-major rows
 };
 
@@ -104,7 +105,7 @@ __host__ __device__ inline size_t img_carve(ImgState& s, char* base, size_t N, s
 __host__ __device__ inline size_t bin_carve(BinState& b, char* base, size_t R)
 {
     char* p = base;
-    carve(p, b.keys, R); carve(p, b.recA, R); carve(p, b.recB, R); carve(p, b.recC, R); carve(p, b.slot, R); carve(p, b.slab, (size_t)SLAB_ROW * R);
+    carve(p, b.keys, R); carve(p, b.recA, R); carve(p, b.recB, R); carve(p, b.recC, R); carve(p, b.slot, R); carve(p, b.qmask, R); carve(p, b.slab, (size_t)SLAB_ROW * R);
     return (size_t)(p - base) + 256;
 }
 
@@ -258,6 +259,50 @@ __device__ __forceinline__ uint32_t build_own_list(unsigned short* list, const u
     }
     if (lane < 4) list[base + lane] = (unsigned short)null_slot;
     return base;
+}
+
+// ---- quadrant culling of the default render kernels -------------------------------------------------------------------
+// A wave owns a 4x4-pixel block; each of its four 16-lane DPP rows owns one 2x2-pixel quadrant of the block (4 pixels x 4
+// entry slots) and walks ITS OWN list: the entries whose splat reaches alpha >= 1/255 on one of the quadrant's pixels
+// (BinState::qmask).  Two levels: build_own_list_q compacts the staged round into the block's list (entries that reach any
+// quadrant, each with its 4-bit quadrant nibble), then every chunk of 64 block entries is split into the four quadrant lists
+// (build_chunk_quadrant_lists) and the wave runs max_q ceil(n_q / 4) passes over them.
+constexpr int QCH = 64;                    // block-list entries split per chunk
+constexpr int QL_ROW = QCH + 8;            // one quadrant list: <= 64 entries + null padding up to the longest list of the chunk
+template <int CH>
+__device__ __forceinline__ uint32_t build_own_list_q(unsigned short* list, const uint2* qmasks, uint32_t cnt, int blk, int lane)
+{
+    uint32_t base = 0;
+    const uint32_t* half = reinterpret_cast<const uint32_t*>(qmasks) + (blk >> 3);
+    const uint32_t sh = 4u * (uint32_t)(blk & 7);
+#pragma unroll 1
+    for (uint32_t k0 = 0; k0 < cnt; k0 += 64) {            // (rolled: unrolled, the 8 slot addresses are hoisted into VGPRs the render loops need)
+        const uint32_t slot = k0 + lane;
+        const uint32_t nib = slot < cnt ? (half[2 * slot] >> sh) & 15u : 0u;
+        const bool on = nib != 0u;
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(on);
+        if (on) list[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (unsigned short)(slot | (nib << 10));
+        base += (uint32_t)__builtin_popcountll(bal);
+    }
+    return base;
+}
+// quadrant lists of block-list entries [c0, min(c0 + 64, n)); returns the longest list's length
+__device__ __forceinline__ uint32_t build_chunk_quadrant_lists(unsigned short (*ql)[QL_ROW], const unsigned short* list, uint32_t c0, uint32_t n, int lane,
+                                                              int null_slot)
+{
+    const uint32_t ent = c0 + lane < n ? list[c0 + lane] : 0u;
+    const uint32_t nib = ent >> 10, slot = ent & 1023u;
+    uint32_t nmax = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const bool on = (nib >> q) & 1u;
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(on);
+        const uint32_t cq = (uint32_t)__builtin_popcountll(bal);
+        if (on) ql[q][__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (unsigned short)slot;
+        if (cq + lane < (uint32_t)QL_ROW) ql[q][cq + lane] = (unsigned short)null_slot;      // short lists idle on the null record
+        nmax = max(nmax, cq);
+    }
+    return nmax;
 }
 
 // 16-bit block mask -> 4-bit quadrant mask (quadrant q: bit0 = right half, bit1 = lower half)

@@ -80,6 +80,68 @@ __device__ __forceinline__ uint32_t block_mask(float2 xy, float4 co, uint32_t tx
     return keep;
 }
 
+// 64-bit mask of the tile's 2x2-pixel quadrants (bit 4*block + quadrant, quadrant = 2*(lower half) + (right half) of the 4x4
+// block) holding a pixel the splat reaches with alpha >= 1/255.  Stage 1 as in block_mask; stage 2 evaluates the conic at the
+// 16 pixel centres of every block the box test left (same margins).  NaNs and non-convex conics keep every quadrant.
+__device__ __forceinline__ unsigned long long quadrant_mask(float2 xy, float4 co, uint32_t tx, uint32_t ty)
+{
+    const float o255 = 255.0f * co.w;
+    if (o255 < 0.999f) return 0ull;
+    const float tau = fmaxf(logf(o255), 0.f) + 0.01f;
+    const float A = co.x, B = co.y, Cc = co.z;
+    const float det = A * Cc - B * B;
+    const bool convex = det > 0.f && A > 0.f && Cc > 0.f;
+    float hx = 3.0e38f, hy = 3.0e38f;
+    if (convex) {
+        hx = sqrtf(2.f * tau * Cc / det) * 1.001f + 0.01f;
+        hy = sqrtf(2.f * tau * A / det) * 1.001f + 0.01f;
+    }
+    const float x0 = (float)(tx * TILE), y0 = (float)(ty * TILE);
+    uint32_t mx = 0, my = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float lo_x = x0 + (float)(4 * k), lo_y = y0 + (float)(4 * k);
+        if (!((xy.x + hx < lo_x) || (xy.x - hx > lo_x + 3.f))) mx |= 1u << k;
+        if (!((xy.y + hy < lo_y) || (xy.y - hy > lo_y + 3.f))) my |= 1u << k;
+    }
+    uint32_t m = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) if ((my >> r) & 1u) m |= mx << (4 * r);
+    unsigned long long keep = 0ull;
+    const float tau_x = tau * 1.001f, hA = 0.5f * A, hC = 0.5f * Cc;
+    for (uint32_t rest = m; rest != 0u; rest &= rest - 1u) {
+        const int blk = __builtin_ctz(rest);
+        uint32_t nib = 15u;
+        if (convex) {
+            const float xl = x0 + (float)(4 * (blk & 3)) - xy.x, yl = y0 + (float)(4 * (blk >> 2)) - xy.y;
+            nib = 0u;
+#pragma unroll
+            for (int iy = 0; iy < 4; iy++) {
+                const float dy = yl + (float)iy, gB = B * dy, hh = hC * dy * dy;
+#pragma unroll
+                for (int ix = 0; ix < 4; ix++) {
+                    const float dx = xl + (float)ix;
+                    const float f = (hA * dx + gB) * dx + hh;
+                    if (!(f > tau_x)) nib |= 1u << ((iy >> 1) * 2 + (ix >> 1));
+                }
+            }
+        }
+        keep |= (unsigned long long)nib << (4 * blk);
+    }
+    return keep;
+}
+// the 4x4 blocks with a live quadrant
+__device__ __forceinline__ uint32_t blocks_of_quadrants(unsigned long long qm)
+{
+    unsigned long long t = qm | (qm >> 1);
+    t |= t >> 2;
+    t &= 0x1111111111111111ull;                          // bit 4*blk = any quadrant of blk
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) m |= (uint32_t)((t >> (4 * k)) & 1ull) << k;
+    return m;
+}
+
 // Can the splat reach alpha >= 1/255 anywhere in tile (tx, ty)?  The same two stages as block_mask on ONE rectangle -- the hull of
 // the tile's pixel centres, a superset of its 16 block rectangles -- with the same margins: never "no" where a block says "yes".
 __device__ __forceinline__ bool tile_reachable(float2 xy, float4 co, uint32_t tx, uint32_t ty)
@@ -492,7 +554,9 @@ __device__ __forceinline__ void finalize_entry(unsigned long long key, uint32_t 
     const uint32_t tx = tile % gx, ty = tile / gx;
     b.recA[pos] = p0;
     b.recB[pos] = p1;
-    b.recC[pos] = make_float2(p2.x, __uint_as_float(block_mask(make_float2(p0.x, p0.y), make_float4(p0.z, p0.w, p1.x, p1.y), tx, ty)));
+    const unsigned long long qm = quadrant_mask(make_float2(p0.x, p0.y), make_float4(p0.z, p0.w, p1.x, p1.y), tx, ty);
+    b.recC[pos] = make_float2(p2.x, __uint_as_float(blocks_of_quadrants(qm)));
+    b.qmask[pos] = make_uint2((uint32_t)qm, (uint32_t)(qm >> 32));
     // row of this instance in the gradient slab: the Gaussian's rows are its LIVE tiles in rectangle order
     const uint32_t rw = maxx - minx, k = (ty - miny) * rw + (tx - minx);
     uint32_t ord = k;
@@ -664,8 +728,9 @@ __global__ __launch_bounds__(FWD_THREADS, 8) void k_render_fwd(const ImgState s,
     __shared__ float4 sA[FCH + 1];
     __shared__ float4 sB[FCH + 1];
     __shared__ float sC[FCH + 1];
-    __shared__ unsigned short sMask[FCH];
-    __shared__ __attribute__((aligned(16))) unsigned short lists[16][FCH + 8];   // one list per block (= per wave)
+    __shared__ uint2 sQ[FCH];                              // quadrant masks of the staged entries
+    __shared__ __attribute__((aligned(16))) unsigned short lists[16][FCH + 8];   // one list per block (= per wave): slot | quadrant nibble << 10
+    __shared__ __attribute__((aligned(16))) unsigned short qlists[16][4][QL_ROW]; // per wave: the current chunk's four quadrant lists
     __shared__ uint32_t wave_alive[2][16];                 // double-buffered "this wave still has live pixels"
     __shared__ uint32_t wave_qmax[16];
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
@@ -681,9 +746,9 @@ __global__ __launch_bounds__(FWD_THREADS, 8) void k_render_fwd(const ImgState s,
     const uint32_t tile = td.x;
     const uint32_t tx = tile % gx, ty = tile / gx;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int pp = lane >> 2, e = lane & 3;                // pixel of the block, entry slot of the group
-    const int px = tx * TILE + (wv & 3) * 4 + (pp & 3);
-    const int py = ty * TILE + (wv >> 2) * 4 + (pp >> 2);
+    const int qd = lane >> 4, pq = (lane >> 2) & 3, e = lane & 3;   // DPP row = 2x2 quadrant of the block, pixel of the quadrant, entry slot of the group
+    const int px = tx * TILE + (wv & 3) * 4 + (qd & 1) * 2 + (pq & 1);
+    const int py = ty * TILE + (wv >> 2) * 4 + (qd >> 1) * 2 + (pq >> 1);
     const bool inside = px < W && py < H;
     const float pixfx = (float)px, pixfy = (float)py;
     const uint2 rg = make_uint2(td.y, td.z);
@@ -697,14 +762,14 @@ __global__ __launch_bounds__(FWD_THREADS, 8) void k_render_fwd(const ImgState s,
     if (threadIdx.x == 0) { sA[FNULL] = make_float4(0.f, 0.f, 0.f, 0.f); sB[FNULL] = make_float4(0.f, 0.f, 0.f, 0.f); sC[FNULL] = 0.f; }
 
     // Register-staged prefetch of the next round (global loads stay in flight under the compute), split over the two halves
-    // of the workgroup to stay inside 64 VGPRs: thread t < FCH carries recA + recC of entry t, thread FCH + t carries recB.
+    // of the workgroup to stay inside 64 VGPRs: thread t < FCH carries recA + recC of entry t, thread FCH + t recB + the quadrant mask.
     const uint32_t ht = threadIdx.x & (FCH - 1);
     const bool upper = threadIdx.x >= FCH;
     float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float2 r2 = make_float2(0.f, 0.f);
+    uint2 r2 = make_uint2(0u, 0u);
     auto fetch = [&](uint32_t pos) {
-        if (!upper) { r4 = b.recA[pos]; r2 = b.recC[pos]; }
-        else r4 = b.recB[pos];
+        if (!upper) { r4 = b.recA[pos]; r2.x = __float_as_uint(b.recC[pos].x); }
+        else { r4 = b.recB[pos]; r2 = b.qmask[pos]; }
     };
     if (rg.x + ht < rg.y) fetch(rg.x + ht);
 
@@ -722,17 +787,21 @@ __global__ __launch_bounds__(FWD_THREADS, 8) void k_render_fwd(const ImgState s,
         }
         const uint32_t cnt = min((uint32_t)FCH, rg.y - base);
         if (ht < cnt) {
-            if (!upper) { stage_conic_a(r4); sA[ht] = r4; sC[ht] = r2.x; sMask[ht] = (unsigned short)__float_as_uint(r2.y); }
-            else { stage_conic_b(r4); sB[ht] = r4; }
+            if (!upper) { stage_conic_a(r4); sA[ht] = r4; sC[ht] = __uint_as_float(r2.x); }
+            else { stage_conic_b(r4); sB[ht] = r4; sQ[ht] = r2; }
         }
         __syncthreads();
         if (base + FCH + ht < rg.y) fetch(base + FCH + ht);
         const uint32_t cbase = base - rg.x + 1;
         {
-            const uint32_t n = wave_live ? build_own_list<FCH>(lists[wv], sMask, cnt, wv, lane, FNULL) : 0u;
+            const uint32_t n = wave_live ? build_own_list_q<FCH>(lists[wv], sQ, cnt, wv, lane) : 0u;
+            const unsigned short* myq = &qlists[wv][qd][e];
 #pragma unroll 1
-            for (uint32_t k = 0; k < n; k += 4) {               // 4 list entries per pass, only those that can reach this block
-                const uint32_t j = lists[wv][k + e];
+            for (uint32_t c0 = 0; c0 < n && wave_live; c0 += QCH) {
+            const uint32_t nq = build_chunk_quadrant_lists(qlists[wv], lists[wv], c0, n, lane, FNULL);
+#pragma unroll 1
+            for (uint32_t k = 0; k < nq; k += 4) {              // 4 entries of its own quadrant list per row and pass
+                const uint32_t j = myq[k];
                 const float4 a = sA[j];                        // mean2D, conic xx / xy pre-scaled for exp2 (stage_conic)
                 const float4 bb = sB[j];                       // conic yy pre-scaled, opacity, colour r g
                 const float cc = sC[j];
@@ -758,6 +827,7 @@ __global__ __launch_bounds__(FWD_THREADS, 8) void k_render_fwd(const ImgState s,
                 T = stop ? cand : x3;
                 done = done || stop;
                 if (__builtin_amdgcn_ballot_w64(!done) == 0) { wave_live = false; break; }
+            }
             }
         }
     }
