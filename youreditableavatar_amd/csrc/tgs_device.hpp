@@ -71,7 +71,7 @@ struct BinState {
     float4* recB;             //                              conic.z, opacity, r, g
     float2* recC;             //                              b, bits(gaussian idx)
     uint32_t* slot;           // offsets[g] + ordinal of this tile in g's rectangle (gradient slab row)
-    uint2* qmask;             // 64-bit mask of the tile's 2x2-pixel quadrants the splat reaches: bit 4*block + quadrant
+    uint2* qmask;             // 64-bit mask of the tile's 8x8 grid of 2x2-pixel quadrants the splat reaches: bit 8*row + column
     float4* slab;             // backward scratch: SLAB_ROW float4 (9 sums + padding) per instance, Gaussian-major rows
 };
 
@@ -273,12 +273,14 @@ template <int CH>
 __device__ __forceinline__ uint32_t build_own_list_q(unsigned short* list, const uint2* qmasks, uint32_t cnt, int blk, int lane)
 {
     uint32_t base = 0;
+    // block (bx, by) = blk: quadrant rows 2 by, 2 by + 1 and columns 2 bx, 2 bx + 1 of the 8x8 grid -> nibble bit 2*(lower) + (right)
     const uint32_t* half = reinterpret_cast<const uint32_t*>(qmasks) + (blk >> 3);
-    const uint32_t sh = 4u * (uint32_t)(blk & 7);
+    const uint32_t sh = 16u * (uint32_t)((blk >> 2) & 1) + 2u * (uint32_t)(blk & 3);
 #pragma unroll 1
     for (uint32_t k0 = 0; k0 < cnt; k0 += 64) {            // (rolled: unrolled, the 8 slot addresses are hoisted into VGPRs the render loops need)
         const uint32_t slot = k0 + lane;
-        const uint32_t nib = slot < cnt ? (half[2 * slot] >> sh) & 15u : 0u;
+        const uint32_t w = slot < cnt ? half[2 * slot] >> sh : 0u;
+        const uint32_t nib = (w & 3u) | ((w >> 6) & 12u);
         const bool on = nib != 0u;
         const unsigned long long bal = __builtin_amdgcn_ballot_w64(on);
         if (on) list[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (unsigned short)(slot | (nib << 10));

@@ -80,65 +80,50 @@ __device__ __forceinline__ uint32_t block_mask(float2 xy, float4 co, uint32_t tx
     return keep;
 }
 
-// 64-bit mask of the tile's 2x2-pixel quadrants (bit 4*block + quadrant, quadrant = 2*(lower half) + (right half) of the 4x4
-// block) holding a pixel the splat reaches with alpha >= 1/255.  Stage 1 as in block_mask; stage 2 evaluates the conic at the
-// 16 pixel centres of every block the box test left (same margins).  NaNs and non-convex conics keep every quadrant.
+// 64-bit mask of the tile's 8x8 grid of 2x2-pixel quadrants (bit 8*R + C: quadrant row R, quadrant column C) that hold a pixel the
+// splat reaches with alpha >= 1/255, i.e. with f(d) <= tau (block_mask above; same margins).  Per pixel row the pixels with
+// f <= tau are an interval in x -- f is a convex parabola in dx for fixed dy -- so 16 square roots give the exact pixel footprint
+// (widened by 0.01 px), without a loop whose trip count differs between lanes.  NaNs and non-convex conics keep every quadrant.
 __device__ __forceinline__ unsigned long long quadrant_mask(float2 xy, float4 co, uint32_t tx, uint32_t ty)
 {
     const float o255 = 255.0f * co.w;
-    if (o255 < 0.999f) return 0ull;
-    const float tau = fmaxf(logf(o255), 0.f) + 0.01f;
+    if (o255 < 0.999f) return 0ull;                     // alpha <= o < 1/255 for every pixel (G <= 1)
+    const float tau = (fmaxf(logf(o255), 0.f) + 0.01f) * 1.001f;
     const float A = co.x, B = co.y, Cc = co.z;
-    const float det = A * Cc - B * B;
-    const bool convex = det > 0.f && A > 0.f && Cc > 0.f;
-    float hx = 3.0e38f, hy = 3.0e38f;
-    if (convex) {
-        hx = sqrtf(2.f * tau * Cc / det) * 1.001f + 0.01f;
-        hy = sqrtf(2.f * tau * A / det) * 1.001f + 0.01f;
-    }
-    const float x0 = (float)(tx * TILE), y0 = (float)(ty * TILE);
-    uint32_t mx = 0, my = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const float lo_x = x0 + (float)(4 * k), lo_y = y0 + (float)(4 * k);
-        if (!((xy.x + hx < lo_x) || (xy.x - hx > lo_x + 3.f))) mx |= 1u << k;
-        if (!((xy.y + hy < lo_y) || (xy.y - hy > lo_y + 3.f))) my |= 1u << k;
-    }
-    uint32_t m = 0;
-#pragma unroll
-    for (int r = 0; r < 4; r++) if ((my >> r) & 1u) m |= mx << (4 * r);
+    if (!(A * Cc - B * B > 0.f && A > 0.f && Cc > 0.f)) return ~0ull;
+    // f = 1/2 A dx^2 + (B dy) dx + 1/2 C dy^2 <= tau  <=>  dx in [(-B dy - s) / A, (-B dy + s) / A], s^2 = (B dy)^2 - A (C dy^2 - 2 tau)
+    const float rA = 1.0f / A;
+    const float ox = xy.x - (float)(tx * TILE), y0 = (float)(ty * TILE) - xy.y;       // mean relative to the tile; first row relative to the mean
     unsigned long long keep = 0ull;
-    const float tau_x = tau * 1.001f, hA = 0.5f * A, hC = 0.5f * Cc;
-    for (uint32_t rest = m; rest != 0u; rest &= rest - 1u) {
-        const int blk = __builtin_ctz(rest);
-        uint32_t nib = 15u;
-        if (convex) {
-            const float xl = x0 + (float)(4 * (blk & 3)) - xy.x, yl = y0 + (float)(4 * (blk >> 2)) - xy.y;
-            nib = 0u;
 #pragma unroll
-            for (int iy = 0; iy < 4; iy++) {
-                const float dy = yl + (float)iy, gB = B * dy, hh = hC * dy * dy;
+    for (int R = 0; R < 8; R++) {
+        uint32_t m8 = 0;
 #pragma unroll
-                for (int ix = 0; ix < 4; ix++) {
-                    const float dx = xl + (float)ix;
-                    const float f = (hA * dx + gB) * dx + hh;
-                    if (!(f > tau_x)) nib |= 1u << ((iy >> 1) * 2 + (ix >> 1));
-                }
-            }
+        for (int h = 0; h < 2; h++) {
+            const float dy = y0 + (float)(2 * R + h), gB = B * dy;
+            const float disc = gB * gB - A * (Cc * dy * dy - 2.f * tau);
+            if (disc < 0.f) continue;                   // the row misses the footprint (a NaN falls through and keeps the row)
+            const float sq = sqrtf(disc);
+            const float lo = fmaxf(ox + (-gB - sq) * rA - 0.01f, 0.f), hi = fminf(ox + (-gB + sq) * rA + 0.01f, 15.f);   // pixel columns of the tile
+            const int il = (int)ceilf(lo), ih = (int)floorf(hi);
+            if (il > ih) continue;
+            m8 |= ((2u << (ih >> 1)) - 1u) & ~((1u << (il >> 1)) - 1u);
         }
-        keep |= (unsigned long long)nib << (4 * blk);
+        keep |= (unsigned long long)m8 << (8 * R);
     }
     return keep;
 }
-// the 4x4 blocks with a live quadrant
+// the 4x4 blocks (bit 4*by + bx) with a live quadrant
 __device__ __forceinline__ uint32_t blocks_of_quadrants(unsigned long long qm)
 {
-    unsigned long long t = qm | (qm >> 1);
-    t |= t >> 2;
-    t &= 0x1111111111111111ull;                          // bit 4*blk = any quadrant of blk
     uint32_t m = 0;
 #pragma unroll
-    for (int k = 0; k < 16; k++) m |= (uint32_t)((t >> (4 * k)) & 1ull) << k;
+    for (int by = 0; by < 4; by++) {
+        const uint32_t rp = (uint32_t)(qm >> (16 * by)) & 0xffffu;
+        uint32_t c = (rp | (rp >> 8)) & 0xffu;          // the block row's two quadrant rows
+        c = (c | (c >> 1)) & 0x55u;                     // pairs of quadrant columns
+        m |= ((c & 1u) | ((c >> 1) & 2u) | ((c >> 2) & 4u) | ((c >> 3) & 8u)) << (4 * by);
+    }
     return m;
 }
 
