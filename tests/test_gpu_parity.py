@@ -146,6 +146,37 @@ def test_instance_pruning_off_gives_the_reference_lists(gpu_device):
         assert util.rel_l2(full[k], pruned[k]) <= 2e-5, k
 
 
+@pytest.mark.parametrize("name", ["g01_sh3_scale_rot", "g09_giant_splat", "g13_dense_2k"])
+def test_quadrant_masks_are_conservative(name, gpu_device):
+    """The render kernels visit an entry only in the 2x2-pixel quadrants its 64-bit mask names (k_finalize, bit 8*row + column of the
+    tile's 8x8 quadrant grid): every pixel where the entry passes the reference's tests (forward.cu:336-343, evaluated in float64 on the
+    kernel's own means2D / conic_opacity) must lie in a named quadrant.  Also reports how tight the masks are."""
+    inp, gold = util.load_golden(name)
+    mine = util.hip_run(inp)
+    W, H = int(inp["image_width"]), int(inp["image_height"])
+    gx = (W + 15) // 16
+    rg = mine["ranges"].astype(np.int64)
+    pl, qm = mine["point_list"].astype(np.int64), mine["quad_masks"]
+    m2, co = mine["means2D"].astype(np.float64), mine["conic_opacity"].astype(np.float64)
+    named = alive_total = missed = 0
+    for tile in np.nonzero(rg[:, 1] > rg[:, 0])[0]:
+        ids = pl[rg[tile, 0]:rg[tile, 1]]
+        px = (tile % gx) * 16 + np.arange(16, dtype=np.float64)
+        py = (tile // gx) * 16 + np.arange(16, dtype=np.float64)
+        dx = m2[ids, 0, None, None] - px[None, None, :]
+        dy = m2[ids, 1, None, None] - py[None, :, None]
+        power = -0.5 * (co[ids, 0, None, None] * dx * dx + co[ids, 2, None, None] * dy * dy) - co[ids, 1, None, None] * dx * dy
+        alpha = np.minimum(0.99, co[ids, 3, None, None] * np.exp(np.minimum(power, 0.0)))
+        alive = (power <= 0) & (alpha >= 1.0 / 255.0)                                   # [n, y, x]
+        alive_q = alive.reshape(-1, 8, 2, 8, 2).any(axis=(2, 4)).reshape(-1, 64)        # [n, 8*row + column]
+        bits = ((qm[rg[tile, 0]:rg[tile, 1], None] >> np.arange(64, dtype=np.uint64)[None, :]) & np.uint64(1)).astype(bool)
+        missed += int((alive_q & ~bits).sum())
+        named += int(bits.sum()); alive_total += int(alive_q.sum())
+    print(name, f"quadrants named {named}, with a live pixel {alive_total} ({alive_total / max(named, 1):.3f})")
+    assert missed == 0, f"{missed} quadrants with a contributing pixel are not in the mask"
+    assert alive_total >= 0.9 * named                    # and the masks are tight: a quadrant is named only near the footprint
+
+
 @pytest.mark.parametrize("seed", [11, 12, 14, 15, 16, 17])   # seed 13: one radius lands on the other side of ceil() than in the oracle (DESIGN.md 3)
 def test_random_small_scenes_vs_oracle(seed, gpu_device):
     """A slice of tests/tools/fuzz_vs_oracle.py with fixed seeds: random sizes (not multiples of 16), SH degrees, scale multipliers,

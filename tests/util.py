@@ -108,6 +108,7 @@ def hip_run(inp: dict, dL: Optional[np.ndarray] = None, device="cuda:0", debug=F
         out["depths"] = f("depths")
         out["conic_opacity"] = f("conic_opacity").reshape(-1, 4)
         out["tiles_touched"] = f("tiles_touched").astype(np.uint32)
+        out["quad_masks"] = f("quad_masks").astype(np.uint64)
         if has_sh:
             out["rgb"] = f("rgb").reshape(-1, 3)
     if dL is not None:

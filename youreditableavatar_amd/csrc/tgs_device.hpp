@@ -222,45 +222,6 @@ __device__ __forceinline__ void build_quad_lists(QuadLists& L, uint32_t qm, int 
     }
 }
 
-// 16-block variant (4x4 blocks of 4x4 pixels): one compute wave per block, staged by STG staging waves
-template <int STG>
-struct alignas(16) BlockLists {
-    unsigned short idx[16][STG][QL_STRIDE];   // [block][staging wave][k]
-    uint32_t cnt[16][STG];
-};
-template <int STG>
-__device__ __forceinline__ void build_block_lists(BlockLists<STG>& L, uint32_t bm, int sw, int lane, int null_slot = RNULL)
-{
-#pragma unroll
-    for (int q = 0; q < 16; q++) {
-        const bool on = (bm >> q) & 1u;
-        const unsigned long long bal = __builtin_amdgcn_ballot_w64(on);
-        const uint32_t n = (uint32_t)__builtin_popcountll(bal);
-        const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-        if (on) L.idx[q][sw][pos] = (unsigned short)threadIdx.x;
-        if (lane < RUNROLL) L.idx[q][sw][n + lane] = (unsigned short)null_slot;
-        if (lane == 0) L.cnt[q][sw] = n;
-    }
-}
-// Per-wave list of the staged slots whose splat can reach the wave's block, in slot order, padded with `null_slot`
-// to a multiple of 4.  Each compute wave builds its OWN list from the staged 16-bit masks (CH/64 ballots and an
-// in-wave running base), so no list is shared between waves and one round yields one contiguous list per block.
-template <int CH>
-__device__ __forceinline__ uint32_t build_own_list(unsigned short* list, const unsigned short* masks, uint32_t cnt, int blk, int lane, int null_slot)
-{
-    uint32_t base = 0;
-#pragma unroll
-    for (int k = 0; k < CH / 64; k++) {
-        const uint32_t slot = k * 64 + lane;
-        const bool on = slot < cnt && ((masks[slot] >> blk) & 1u);
-        const unsigned long long bal = __builtin_amdgcn_ballot_w64(on);
-        if (on) list[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (unsigned short)slot;
-        base += (uint32_t)__builtin_popcountll(bal);
-    }
-    if (lane < 4) list[base + lane] = (unsigned short)null_slot;
-    return base;
-}
-
 // ---- quadrant culling of the default render kernels -------------------------------------------------------------------
 // A wave owns a 4x4-pixel block; each of its four 16-lane DPP rows owns one 2x2-pixel quadrant of the block (4 pixels x 4
 // entry slots) and walks ITS OWN list: the entries whose splat reaches alpha >= 1/255 on one of the quadrant's pixels
@@ -312,24 +273,6 @@ __device__ __forceinline__ uint32_t block_to_quadrant_mask(uint32_t m)
 {
     return ((m & 0x0033u) ? 1u : 0u) | ((m & 0x00CCu) ? 2u : 0u) | ((m & 0x3300u) ? 4u : 0u) | ((m & 0xCC00u) ? 8u : 0u);
 }
-// inclusive prefix product over the 4 lanes of each quad (lane e: x_0 * ... * x_e); e = lane & 3
-__device__ __forceinline__ float quad_prefix_product(float x, int e)
-{
-    const float y1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x90, 0xf, 0xf, false));   // quad_perm [0,0,1,2]
-    x *= (e == 0) ? 1.0f : y1;                            // x_e * x_{e-1}
-    const float y2 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x44, 0xf, 0xf, false));   // quad_perm [0,1,0,1]
-    return x * ((e < 2) ? 1.0f : y2);
-}
-// x + (value of lane quad base + E): one v_add_f32 with a DPP source
-#define TGS_QUAD_BCAST_ADD(x, y, E) \
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y), (E) * 0x55, 0xf, 0xf, false))
-// value of lane (quad base + E) broadcast to the 4 lanes of each quad
-template <int E>
-__device__ __forceinline__ float quad_bcast(float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), E * 0x55, 0xf, 0xf, false));
-}
-
 // Records staged into LDS by the render kernels carry the conic pre-scaled for one v_exp_f32:
 //   log2(e) * power = (A dx + B dy) dx + (C dy) dy   with A = -0.5 log2e conic.x, B = -log2e conic.y, C = -0.5 log2e conic.z
 // (forward.cu:336 `power = -0.5f * (con.x*d.x*d.x + con.z*d.y*d.y) - con.y*d.x*d.y`, d = mean - pixel as in this code).

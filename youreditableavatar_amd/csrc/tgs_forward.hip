@@ -22,66 +22,20 @@ namespace tgs {
 // ---------------------------------------------------------------------------------------------
 // k_preprocess_fwd
 // ---------------------------------------------------------------------------------------------
-// Conservative 16-bit mask of the tile's 4x4 blocks of 4x4 pixels (bit by*4+bx) that a splat can reach with
-// alpha >= 1/255:  alpha = o*exp(power) >= 1/255  <=>  -power <= tau, tau = ln(255 o), where
-// -power = f(d) = 1/2 (A dx^2 + C dy^2) + B dx dy is the conic's quadratic form in d = pixel - mean.
-// Stage 1: bounding box of the level set f <= tau (|dx| <= sqrt(2 tau C/det), |dy| <= sqrt(2 tau A/det)), separable.
-// Stage 2, for the blocks that survive: the exact minimum of the convex f over the block's pixel rectangle
-// (0 if the mean is inside; otherwise on one of the 4 edges, a clamped 1-D parabola each).
+// Culling masks.  A splat reaches a pixel with alpha >= 1/255 iff  alpha = o*exp(power) >= 1/255  <=>  -power <= tau,
+// tau = ln(255 o), where -power = f(d) = 1/2 (A dx^2 + C dy^2) + B dx dy is the conic's quadratic form in d = pixel - mean.
 // The exact per-pixel tests of forward.cu:336-343 stay in the render kernels, so a conservative mask only removes
-// work, never a contribution (margins: +0.01 on tau plus 0.1 % on f).  NaNs and non-convex conics keep every block.
+// work, never a contribution (margins: +0.01 on tau plus 0.1 % on f).  NaNs and non-convex conics keep everything.
+// minimum of f over one edge of a rectangle (tile_reachable): a clamped 1-D parabola
 __device__ __forceinline__ float conic_min_on_edge(float dfix, float lo, float hi, float Pfix, float Pvar, float B, float mB_over_Pvar)
 {
     // minimise 1/2 Pfix dfix^2 + B dfix t + 1/2 Pvar t^2 over t in [lo, hi]; the stationary point is t = -B dfix / Pvar
     const float t = fminf(hi, fmaxf(lo, dfix * mB_over_Pvar));
     return 0.5f * (Pfix * dfix * dfix + Pvar * t * t) + B * dfix * t;
 }
-__device__ __forceinline__ uint32_t block_mask(float2 xy, float4 co, uint32_t tx, uint32_t ty)
-{
-    const float o255 = 255.0f * co.w;
-    if (o255 < 0.999f) return 0u;                       // alpha <= o < 1/255 for every pixel (G <= 1)
-    const float tau = fmaxf(logf(o255), 0.f) + 0.01f;
-    const float A = co.x, B = co.y, Cc = co.z;
-    const float det = A * Cc - B * B;
-    const bool convex = det > 0.f && A > 0.f && Cc > 0.f;
-    float hx = 3.0e38f, hy = 3.0e38f;
-    if (convex) {
-        hx = sqrtf(2.f * tau * Cc / det) * 1.001f + 0.01f;
-        hy = sqrtf(2.f * tau * A / det) * 1.001f + 0.01f;
-    }
-    const float x0 = (float)(tx * TILE), y0 = (float)(ty * TILE);
-    uint32_t mx = 0, my = 0;                            // 4-bit column / row masks; the box test is separable
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const float lo_x = x0 + (float)(4 * k), lo_y = y0 + (float)(4 * k);
-        if (!((xy.x + hx < lo_x) || (xy.x - hx > lo_x + 3.f))) mx |= 1u << k;
-        if (!((xy.y + hy < lo_y) || (xy.y - hy > lo_y + 3.f))) my |= 1u << k;
-    }
-    uint32_t m = 0;
-#pragma unroll
-    for (int r = 0; r < 4; r++) if ((my >> r) & 1u) m |= mx << (4 * r);
-    if (!convex || m == 0u) return m;
-    const float tau_x = tau * 1.001f;
-    const float rC = -B / Cc, rA = -B / A;
-    uint32_t keep = 0;
-    for (uint32_t rest = m; rest != 0u; rest &= rest - 1u) {           // only the blocks the box test left (a wave runs as many rounds as its busiest lane has)
-        const int blk = __builtin_ctz(rest);
-        // block rectangle in d = pixel - mean coordinates
-        const float xl = x0 + (float)(4 * (blk & 3)) - xy.x, xh = xl + 3.f;
-        const float yl = y0 + (float)(4 * (blk >> 2)) - xy.y, yh = yl + 3.f;
-        float fmin_ = 0.f;
-        if (!(xl <= 0.f && xh >= 0.f && yl <= 0.f && yh >= 0.f)) {
-            const float e0 = conic_min_on_edge(xl, yl, yh, A, Cc, B, rC), e1 = conic_min_on_edge(xh, yl, yh, A, Cc, B, rC);
-            const float e2 = conic_min_on_edge(yl, xl, xh, Cc, A, B, rA), e3 = conic_min_on_edge(yh, xl, xh, Cc, A, B, rA);
-            fmin_ = fminf(fminf(e0, e1), fminf(e2, e3));
-        }
-        if (!(fmin_ > tau_x)) keep |= 1u << blk;
-    }
-    return keep;
-}
 
 // 64-bit mask of the tile's 8x8 grid of 2x2-pixel quadrants (bit 8*R + C: quadrant row R, quadrant column C) that hold a pixel the
-// splat reaches with alpha >= 1/255, i.e. with f(d) <= tau (block_mask above; same margins).  Per pixel row the pixels with
+// splat reaches with alpha >= 1/255, i.e. with f(d) <= tau (above).  Per pixel row the pixels with
 // f <= tau are an interval in x -- f is a convex parabola in dx for fixed dy -- so 16 square roots give the exact pixel footprint
 // (widened by 0.01 px), without a loop whose trip count differs between lanes.  NaNs and non-convex conics keep every quadrant.
 __device__ __forceinline__ unsigned long long quadrant_mask(float2 xy, float4 co, uint32_t tx, uint32_t ty)
@@ -127,8 +81,10 @@ __device__ __forceinline__ uint32_t blocks_of_quadrants(unsigned long long qm)
     return m;
 }
 
-// Can the splat reach alpha >= 1/255 anywhere in tile (tx, ty)?  The same two stages as block_mask on ONE rectangle -- the hull of
-// the tile's pixel centres, a superset of its 16 block rectangles -- with the same margins: never "no" where a block says "yes".
+// Can the splat reach alpha >= 1/255 anywhere in tile (tx, ty)?  Two stages on the hull of the tile's pixel centres: the bounding
+// box of the level set f <= tau (|dx| <= sqrt(2 tau C/det), |dy| <= sqrt(2 tau A/det)), then the exact minimum of the convex f
+// over the rectangle (0 if the mean is inside, otherwise on one of the 4 edges).  Same margins as quadrant_mask, and the rectangle
+// contains every pixel: never "no" where a quadrant says "yes".
 __device__ __forceinline__ bool tile_reachable(float2 xy, float4 co, uint32_t tx, uint32_t ty)
 {
     const float o255 = 255.0f * co.w;

@@ -456,7 +456,7 @@ def mark_visible(means3D, viewmatrix, projmatrix) -> torch.Tensor:
 
 _FIELD_DTYPES = {"n_contrib": torch.int32, "final_T": torch.float32, "ranges": torch.int32, "point_list": torch.int32, "block_masks": torch.int32,
                  "means2D": torch.float32, "depths": torch.float32, "conic_opacity": torch.float32, "rgb": torch.float32,
-                 "tiles_touched": torch.int32, "tile_order": torch.int32, "stamps": torch.int64}
+                 "tiles_touched": torch.int32, "tile_order": torch.int32, "stamps": torch.int64, "quad_masks": torch.int64}
 
 
 def state_field(name: str, P: int, width: int, height: int, R: int, has_sh: bool, has_scale_rot: bool,
@@ -464,7 +464,7 @@ def state_field(name: str, P: int, width: int, height: int, R: int, has_sh: bool
     """Test/bench introspection of the opaque state buffers (tgs_state_field)."""
     dev = geomBuffer.device
     T = ((width + 15) // 16) * ((height + 15) // 16)
-    count = {"n_contrib": width * height, "final_T": width * height, "ranges": 2 * T, "point_list": R, "block_masks": R, "means2D": 2 * P,
+    count = {"n_contrib": width * height, "final_T": width * height, "ranges": 2 * T, "point_list": R, "block_masks": R, "quad_masks": R, "means2D": 2 * P,
              "depths": P, "conic_opacity": 4 * P, "rgb": 3 * P, "tiles_touched": P, "tile_order": T, "stamps": 4 * T}[name]
     out = torch.empty((count,), dtype=_FIELD_DTYPES[name], device=dev)
     with torch.cuda.device(dev):
