@@ -50,3 +50,29 @@ print(f"critical path per tile (slowest wave), summed: {int(crit_cur.sum())} -> 
 top = torch.argsort(lens, descending=True)[:256]
 print(f"256 longest tiles: passes {int(cur[top].sum())} -> {int(new[top].sum())} ({cur[top].sum() / new[top].sum():.2f}x); slowest wave {int(crit_cur[top].sum())} -> {int(crit_new[top].sum())} ({crit_cur[top].sum() / crit_new[top].sum():.2f}x)")
 print(f"sum_q n_q / n_b over blocks: {nq.sum() / nb.sum():.2f}; blocks whose 4 quadrant lists exceed 2x512 entries: {int((nq.view(T,16,4).sum(2) > 1000).sum())}")
+
+# ---- backward: how many list entries lie behind the last contributor of a block / quadrant (they are walked up to the tile's qmax today)
+nc = f("n_contrib").view(H, W).long()
+Hp, Wp = (H + 15) // 16 * 16, gx * 16
+ncp = torch.zeros(Hp, Wp, device=dev, dtype=torch.long); ncp[:H, :W] = nc
+tq = ncp.view(Hp // 16, 16, gx, 16).permute(0, 2, 1, 3).reshape(-1, 16, 16)               # [T, y, x]
+tile_qmax = tq.reshape(T, -1).max(dim=1).values
+blk_max = tq.view(T, 4, 4, 4, 4).permute(0, 1, 3, 2, 4).reshape(T, 16, 16).max(dim=2).values           # [T, block]
+quad_max = tq.view(T, 8, 2, 8, 2).permute(0, 1, 3, 2, 4).reshape(T, 64, 4).max(dim=2).values           # [T, 8*row + col]
+pos_in_tile = torch.arange(R, device=dev) - rg[tile_of, 0]                                             # list position of every instance
+cnt_tile = cnt_blk = cnt_quad_tile = cnt_quad = 0
+for s in range(0, R, 1 << 18):
+    ids, t, pos = pl[s:s + (1 << 18)], tile_of[s:s + (1 << 18)], pos_in_tile[s:s + (1 << 18)]
+    x0, y0 = ((t % gx) * 16).float(), ((t // gx) * 16).float()
+    dx = m2[ids, 0, None, None] - (x0[:, None, None] + px[None, None, :])
+    dy = m2[ids, 1, None, None] - (y0[:, None, None] + px[None, :, None])
+    q = co[ids]
+    power = -0.5 * (q[:, 0, None, None] * dx * dx + q[:, 2, None, None] * dy * dy) - q[:, 1, None, None] * dx * dy
+    alive = (power <= 0) & (torch.minimum(torch.tensor(0.99, device=dev), q[:, 3, None, None] * torch.exp(power)) >= 1.0 / 255.0)
+    ab = alive.view(-1, 4, 4, 4, 4).any(dim=4).any(dim=2).view(-1, 16)                      # [n, block]
+    aq = alive.view(-1, 8, 2, 8, 2).any(dim=4).any(dim=2).view(-1, 64)                      # [n, quadrant (raster)]
+    in_tile = (pos < tile_qmax[t])[:, None]
+    cnt_tile += int((ab & in_tile).sum()); cnt_blk += int((ab & (pos[:, None] < blk_max[t])).sum())
+    cnt_quad_tile += int((aq & in_tile).sum()); cnt_quad += int((aq & (pos[:, None] < quad_max[t])).sum())
+print(f"backward, (block, entry) pairs in front of the tile's qmax {cnt_tile}, in front of the block's own last contributor {cnt_blk} ({cnt_blk / cnt_tile:.3f})")
+print(f"backward, (quadrant, entry) pairs in front of the tile's qmax {cnt_quad_tile}, in front of the quadrant's own last contributor {cnt_quad} ({cnt_quad / cnt_quad_tile:.3f})")

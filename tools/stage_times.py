@@ -4,7 +4,7 @@ from youreditableavatar_amd import scenes
 from diff_gaussian_rasterization import _C
 dev = torch.device("cuda", 0)
 cfg = scenes.CONFIGS[3]; P, W, H, D = cfg["P"], cfg["width"], cfg["height"], cfg["sh_degree"]
-cloud = scenes.make_cloud(P, D, cfg["seed"])
+cloud = scenes.make_cloud(P, D, cfg["seed"], scale_mult=float(sys.argv[1]) if len(sys.argv) > 1 else 1.0)
 g = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
 e = torch.Tensor([])
 c = scenes.orbit_camera(W, H, azimuth_deg=0.0)

@@ -194,6 +194,9 @@ __global__ __launch_bounds__(256) void k_render_bwd_det(const ImgState s, const 
 // (bitwise reproducible) at about 2.5x the time; tgs_set_deterministic(1) selects it.
 // ---------------------------------------------------------------------------------------------
 constexpr int BWD_THREADS = 1024;
+#ifndef TGS_BWD_BOUNDED
+#define TGS_BWD_BOUNDED true
+#endif
 #ifndef TGS_BCH
 #define TGS_BCH 384
 #endif
@@ -245,6 +248,14 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
     const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);   // backward.cu:460-461
 
     const uint32_t qmax = min(s.tile_qmax[tile], n);        // deepest position any pixel of the tile blended (k_render_fwd)
+    uint32_t qlast[4];                                      // the same per quadrant of this wave's block (wave-uniform)
+    {
+        uint32_t m = last_contributor;                      // max over the row's 4 pixels (lanes 4 apart), then one lane per row
+        m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x124, 0xf, 0xf, false));     // row_ror:4
+        m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x128, 0xf, 0xf, false));     // row_ror:8
+#pragma unroll
+        for (int q = 0; q < 4; q++) qlast[q] = (uint32_t)__builtin_amdgcn_readlane((int)m, 16 * q);
+    }
     __syncthreads();                                        // the null record is in LDS
 
     // rows of the never-visited tail are zero
@@ -287,7 +298,7 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
             const unsigned short* myq = &qlists[wv][qd][e];
 #pragma unroll 1
             for (uint32_t c0 = 0; c0 < nl; c0 += QCH) {
-            const uint32_t nq = build_chunk_quadrant_lists(qlists[wv], lists[wv], c0, nl, lane, BNULL);
+            const uint32_t nq = build_chunk_quadrant_lists<TGS_BWD_BOUNDED>(qlists[wv], lists[wv], c0, nl, lane, BNULL, qhi - 1, qlast);
 #pragma unroll 1
             for (uint32_t k = 0; k < nq; k += 4) {          // 4 entries of its own quadrant list per row and pass
                 const uint32_t j = myq[k];

@@ -55,7 +55,7 @@ struct ImgState {
     Meta* meta;
     uint2* ranges;            // per tile [start, end)              (imgState.ranges)
     uint32_t* tile_count;     // per tile, one 64-B line (CSTRIDE words): [0] instances of splats touching <= RANK_TILES tiles
-                              // (their ranks are taken in k_preprocess_fwd), [1] instances of larger splats, [2] scatter cursor of those
+                              // (their ranks are taken in k_preprocess_fwd), [1] instances of larger splats, [2] k_scatter's cursor for those: an absolute list position, primed by k_scan
     uint32_t* cursor;         // (unused, kept for layout stability)
     uint32_t* ovf_tiles;      // list of overflow tiles
     uint32_t* tile_order;     // tiles by descending list length: render kernels start the long lists first
@@ -249,16 +249,20 @@ __device__ __forceinline__ uint32_t build_own_list_q(unsigned short* list, const
     }
     return base;
 }
-// quadrant lists of block-list entries [c0, min(c0 + 64, n)); returns the longest list's length
+// quadrant lists of block-list entries [c0, min(c0 + 64, n)); returns the longest list's length.  BOUNDED (backward): an entry whose
+// list position top - slot is not in front of the quadrant's deepest last contributor (bound[q]) is left out -- no pixel of the
+// quadrant blended it (backward.cu:487).
+template <bool BOUNDED = false>
 __device__ __forceinline__ uint32_t build_chunk_quadrant_lists(unsigned short (*ql)[QL_ROW], const unsigned short* list, uint32_t c0, uint32_t n, int lane,
-                                                              int null_slot)
+                                                              int null_slot, uint32_t top = 0u, const uint32_t* bound = nullptr)
 {
     const uint32_t ent = c0 + lane < n ? list[c0 + lane] : 0u;
     const uint32_t nib = ent >> 10, slot = ent & 1023u;
     uint32_t nmax = 0;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        const bool on = (nib >> q) & 1u;
+        bool on = (nib >> q) & 1u;
+        if (BOUNDED) on = on && (top - slot < bound[q]);
         const unsigned long long bal = __builtin_amdgcn_ballot_w64(on);
         const uint32_t cq = (uint32_t)__builtin_popcountll(bal);
         if (on) ql[q][__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (unsigned short)slot;

@@ -355,6 +355,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const 
         // longest-list search and the length histogram then run out of LDS.
         constexpr uint32_t SC = SCAN_THREADS * 8;
         __shared__ uint32_t lc[SC];
+        __shared__ uint32_t lc0[SC];                        // the share of splats on <= RANK_TILES tiles (they hold their ranks already)
         __shared__ uint32_t hist[34];
         if (threadIdx.x == 0) ovf_n = 0;
         if (threadIdx.x < 34) hist[threadIdx.x] = 0;
@@ -363,11 +364,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const 
         uint32_t mx = 0;
         for (uint32_t sc = 0; sc < T; sc += SC) {
             const uint32_t n = min(SC, T - sc);
-            uint32_t v[8];
+            uint32_t v[8], v0[8];
 #pragma unroll
-            for (int k = 0; k < 8; k++) { const uint32_t i = k * SCAN_THREADS + threadIdx.x; if (i < n) { const uint2 c2 = *reinterpret_cast<const uint2*>(&s.tile_count[(size_t)(sc + i) * CSTRIDE]); v[k] = c2.x + c2.y; } else v[k] = 0u; }
+            for (int k = 0; k < 8; k++) { const uint32_t i = k * SCAN_THREADS + threadIdx.x; if (i < n) { const uint2 c2 = *reinterpret_cast<const uint2*>(&s.tile_count[(size_t)(sc + i) * CSTRIDE]); v[k] = c2.x + c2.y; v0[k] = c2.x; } else { v[k] = 0u; v0[k] = 0u; } }
 #pragma unroll
-            for (int k = 0; k < 8; k++) lc[k * SCAN_THREADS + threadIdx.x] = v[k];
+            for (int k = 0; k < 8; k++) { lc[k * SCAN_THREADS + threadIdx.x] = v[k]; lc0[k * SCAN_THREADS + threadIdx.x] = v0[k]; }
             __syncthreads();
             unsigned long long sum = 0;
             const uint32_t i0 = threadIdx.x * 8;
@@ -380,6 +381,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const 
                 if (i0 + k < n) {
                     const uint32_t t = sc + i0 + k;
                     s.ranges[t] = make_uint2((uint32_t)ex, (uint32_t)(ex + v[k]));
+                    // cursor of the larger splats (k_scatter): they follow the ranked instances of the small ones
+                    if (v[k] != lc0[i0 + k]) s.tile_count[(size_t)t * CSTRIDE + 2] = (uint32_t)ex + lc0[i0 + k];
                     if (v[k] > sort_cap) s.ovf_tiles[atomicAdd(&ovf_n, 1u)] = t;
                     atomicAdd(&hist[v[k] ? 32 - __builtin_clz(v[k]) : 0], 1u);
                 }
@@ -427,6 +430,12 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_scatter(int P, const GeomState g,
     __shared__ uint32_t wtot[PRE_BLOCK / WAVE];
     __shared__ uint32_t queue[PRE_BLOCK];
     __shared__ uint32_t qn;
+    __shared__ uint32_t mid_excl[PRE_BLOCK / WAVE][WAVE];
+    __shared__ unsigned long long mid_keys[PRE_BLOCK / WAVE][WAVE];
+    __shared__ uint2 mid_rects[PRE_BLOCK / WAVE][WAVE];
+    uint32_t mid_area = 0;
+    unsigned long long mid_key = 0;
+    uint2 mid_rect = make_uint2(0u, 1u);
     const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (frame_rejected(s)) return;
@@ -454,13 +463,32 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_scatter(int P, const GeomState g,
             for (int k = 0; k < RANK_TILES; k++)
                 if ((uint32_t)k < area && rk[k] != RANK_DEAD) b.keys[s.ranges[(r.y + k / rw) * gx + r.x + k % rw].x + rk[k]] = key;
         } else if (area <= (uint32_t)COOP_TILES) {
-            for (uint32_t ty = r.y; ty < r.w; ty++)
-                for (uint32_t tx = r.x; tx < r.z; tx++) {
-                    uint32_t* line = s.tile_count + (size_t)(ty * gx + tx) * CSTRIDE;
-                    b.keys[s.ranges[ty * gx + tx].x + line[0] + atomicAdd(&line[2], 1u)] = key;
-                }
+            mid_area = area;                                // emitted below by the whole wave
+            mid_key = key;
+            mid_rect = make_uint2((uint32_t)r.x | ((uint32_t)r.y << 16), rw);
         } else {
             queue[atomicAdd(&qn, 1u)] = (uint32_t)idx;
+        }
+    }
+    // Splats on 5..COOP_TILES tiles: their (splat, tile) pairs are spread over the wave's lanes, 64 pairs per step, so that the
+    // 64 cursor atomics of a step are in flight together.  (One lane walking its own rectangle waits for every returned cursor
+    // before the next store: ~2 us per tile, the whole kernel's duration at larger splats -- 487 us at 4x the scales of config 3.)
+    {
+        const uint32_t incl = wave_iscan_u32(mid_area, lane), total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (total > 0) {                                    // wave-uniform
+            mid_excl[wv][lane] = incl - mid_area;
+            mid_keys[wv][lane] = mid_key;
+            mid_rects[wv][lane] = mid_rect;
+            wave_sync();
+            for (uint32_t w = lane; w < total; w += 64) {
+                uint32_t lo = 0, hi = 63;                   // owner: the last lane whose first pair is <= w (lanes without pairs share their successor's start)
+#pragma unroll
+                for (int it = 0; it < 6; it++) { const uint32_t mid = (lo + hi + 1) >> 1; if (mid_excl[wv][mid] <= w) lo = mid; else hi = mid - 1; }
+                const uint2 rc = mid_rects[wv][lo];
+                const uint32_t k = w - mid_excl[wv][lo], rw2 = rc.y;
+                const uint32_t ky = k / rw2, tx = (rc.x & 0xffffu) + (k - ky * rw2), ty = (rc.x >> 16) + ky;
+                b.keys[atomicAdd(&s.tile_count[(size_t)(ty * gx + tx) * CSTRIDE + 2], 1u)] = mid_keys[wv][lo];      // (cursor primed by k_scan)
+            }
         }
     }
     __syncthreads();
@@ -474,8 +502,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_scatter(int P, const GeomState g,
         const unsigned long long key = ((unsigned long long)__float_as_uint(g.depth[id]) << 32) | id;
         for (uint32_t k = threadIdx.x; k < n; k += PRE_BLOCK) {
             const uint32_t ty = r.y + k / w, tx = r.x + k % w;
-            uint32_t* line = s.tile_count + (size_t)(ty * gx + tx) * CSTRIDE;
-            b.keys[s.ranges[ty * gx + tx].x + line[0] + atomicAdd(&line[2], 1u)] = key;
+            b.keys[atomicAdd(&s.tile_count[(size_t)(ty * gx + tx) * CSTRIDE + 2], 1u)] = key;
         }
     }
 }
