@@ -468,20 +468,23 @@ def test_run_views_whole_batch_path(streams, group, gpu_device):
             return dLs
 
         run = lambda: batch.run_views(settings, L["means3D"], L["opacities"], L["shs"], L["scales"], L["rotations"], upstream)
+        # group == 1: the very same kernels as the per-view path -> bitwise.  group > 1: the per-Gaussian forward comes from the all-views
+        # kernel, a second compilation of the same fp32 math (fma contraction differs: conics agree to the last bit or two)
+        same = torch.equal if group == 1 else (lambda a, b: util.rel_l2(a.cpu().numpy(), b.cpu().numpy()) <= 2e-6)
         for rep in range(3):                                # first batch: synchronous (learns the bound); then the whole-batch path, twice (pool reuse)
             flat.zero_()
             imgs = run()
             assert tuple(imgs.shape) == (5, 3, 112, 176)
-            assert all(torch.equal(imgs[v], want_img[v]) for v in range(5)), rep
-            assert all(torch.equal(batch.viewspace_grads[v], want_2d[v]) for v in range(5)), rep
+            assert all(same(imgs[v], want_img[v]) for v in range(5)), rep
+            assert all(same(batch.viewspace_grads[v], want_2d[v]) for v in range(5)), rep
             assert util.rel_l2(flat.flat.cpu().numpy(), want.cpu().numpy()) <= 2e-5, rep     # two compilations of the same fp32 math (fma contraction): scales / rotations differ by ~5e-6
         assert batch.rejected == 0 and len(calls) == 3
         batch.bound = batch.bound // 3                      # some views no longer fit: rejected on the device, rendered again
         flat.zero_()
         imgs = run()
         assert batch.rejected >= 1
-        assert all(torch.equal(imgs[v], want_img[v]) for v in range(5))
-        assert all(torch.equal(batch.viewspace_grads[v], want_2d[v]) for v in range(5))
+        assert all(same(imgs[v], want_img[v]) for v in range(5))
+        assert all(same(batch.viewspace_grads[v], want_2d[v]) for v in range(5))
         assert util.rel_l2(flat.flat.cpu().numpy(), want.cpu().numpy()) <= 2e-5
         # accumulate=False stores: whatever the buffers held is gone
         flat.flat.fill_(5.0)

@@ -41,7 +41,8 @@ struct GeomState {
     // .conic_opacity, .rgb of the reference, plus the tile rectangle and the slab offset):
     //   pack[4g+0] = (x, y, conic.x, conic.y)   pack[4g+1] = (conic.z, opacity, r, g)
     //   pack[4g+2] = (b, bits(minx | miny<<16), bits(maxx | maxy<<16), bits(offset))
-    //   pack[4g+3] = in-tile ranks of its (<= RANK_TILES) instances, row-major over the rectangle
+    //   pack[4g+3] = in-tile ranks of its (<= RANK_TILES) instances, row-major over the rectangle; for a rectangle of 5..COOP_TILES
+    //                tiles the 64-bit mask of its live tiles instead (.x low word, .y high word)
     float4* pack;
     float* depth;             // view-space z                       (geomState.depths)
     float* cov3D;             // 6 floats, scale/rot path only      (geomState.cov3D)

@@ -241,6 +241,19 @@ __device__ __forceinline__ uint32_t preprocess_fwd_one(const FwdIn& in, int* __r
                         }
                         pk[3] = make_float4(__uint_as_float(rk[0]), __uint_as_float(rk[1]), __uint_as_float(rk[2]), __uint_as_float(rk[3]));
                         tiles = live;
+                    } else if (tiles <= (uint32_t)COOP_TILES) {
+                        // 5..64 tiles: the same pruning, the live tiles as a 64-bit mask over the rectangle (row-major) in the rank slots
+                        const float opac = in.opacities[idx];
+                        unsigned long long live_mask = 0ull;
+                        uint32_t k = 0;
+                        for (uint32_t ty = miny; ty < maxy; ty++)
+                            for (uint32_t tx = minx; tx < maxx; tx++, k++)
+                                if (!in.prune || tile_reachable(make_float2(pix, piy), make_float4(conx, cony, conz, opac), tx, ty)) {
+                                    atomicAdd(&s.tile_count[(size_t)(ty * cam.gx + tx) * CSTRIDE + 1], 1u);
+                                    live_mask |= 1ull << k;
+                                }
+                        pk[3] = make_float4(__uint_as_float((uint32_t)live_mask), __uint_as_float((uint32_t)(live_mask >> 32)), 0.f, 0.f);
+                        tiles = (uint32_t)__builtin_popcountll(live_mask);
                     } else {
                         for (uint32_t ty = miny; ty < maxy; ty++)
                             for (uint32_t tx = minx; tx < maxx; tx++) atomicAdd(&s.tile_count[(size_t)(ty * cam.gx + tx) * CSTRIDE + 1], 1u);
@@ -433,6 +446,8 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_scatter(int P, const GeomState g,
     __shared__ uint32_t mid_excl[PRE_BLOCK / WAVE][WAVE];
     __shared__ unsigned long long mid_keys[PRE_BLOCK / WAVE][WAVE];
     __shared__ uint2 mid_rects[PRE_BLOCK / WAVE][WAVE];
+    __shared__ unsigned long long mid_lives[PRE_BLOCK / WAVE][WAVE];
+    unsigned long long mid_live = 0;
     uint32_t mid_area = 0;
     unsigned long long mid_key = 0;
     uint2 mid_rect = make_uint2(0u, 1u);
@@ -466,6 +481,8 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_scatter(int P, const GeomState g,
             mid_area = area;                                // emitted below by the whole wave
             mid_key = key;
             mid_rect = make_uint2((uint32_t)r.x | ((uint32_t)r.y << 16), rw);
+            const float4 lm = g.pack[4 * (size_t)idx + 3];  // live tiles of the rectangle (k_preprocess_fwd)
+            mid_live = (unsigned long long)__float_as_uint(lm.x) | ((unsigned long long)__float_as_uint(lm.y) << 32);
         } else {
             queue[atomicAdd(&qn, 1u)] = (uint32_t)idx;
         }
@@ -479,6 +496,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_scatter(int P, const GeomState g,
             mid_excl[wv][lane] = incl - mid_area;
             mid_keys[wv][lane] = mid_key;
             mid_rects[wv][lane] = mid_rect;
+            mid_lives[wv][lane] = mid_live;
             wave_sync();
             for (uint32_t w = lane; w < total; w += 64) {
                 uint32_t lo = 0, hi = 63;                   // owner: the last lane whose first pair is <= w (lanes without pairs share their successor's start)
@@ -486,6 +504,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_scatter(int P, const GeomState g,
                 for (int it = 0; it < 6; it++) { const uint32_t mid = (lo + hi + 1) >> 1; if (mid_excl[wv][mid] <= w) lo = mid; else hi = mid - 1; }
                 const uint2 rc = mid_rects[wv][lo];
                 const uint32_t k = w - mid_excl[wv][lo], rw2 = rc.y;
+                if (!((mid_lives[wv][lo] >> k) & 1ull)) continue;     // a tile of the rectangle the splat cannot reach: no instance
                 const uint32_t ky = k / rw2, tx = (rc.x & 0xffffu) + (k - ky * rw2), ty = (rc.x >> 16) + ky;
                 b.keys[atomicAdd(&s.tile_count[(size_t)(ty * gx + tx) * CSTRIDE + 2], 1u)] = mid_keys[wv][lo];      // (cursor primed by k_scan)
             }
@@ -528,12 +547,17 @@ __device__ __forceinline__ void finalize_entry(unsigned long long key, uint32_t 
     // row of this instance in the gradient slab: the Gaussian's rows are its LIVE tiles in rectangle order
     const uint32_t rw = maxx - minx, k = (ty - miny) * rw + (tx - minx);
     uint32_t ord = k;
-    if (rw * (maxy - miny) <= (uint32_t)RANK_TILES) {
+    const uint32_t area = rw * (maxy - miny);
+    if (area <= (uint32_t)RANK_TILES) {
         const float4 p3 = pk[3];
         const uint32_t rk[RANK_TILES] = {__float_as_uint(p3.x), __float_as_uint(p3.y), __float_as_uint(p3.z), __float_as_uint(p3.w)};
         ord = 0;
 #pragma unroll
         for (int j = 0; j < RANK_TILES; j++) if ((uint32_t)j < k && rk[j] != RANK_DEAD) ord++;
+    } else if (area <= (uint32_t)COOP_TILES) {
+        const float4 p3 = pk[3];                            // 64-bit mask of the rectangle's live tiles
+        const unsigned long long live = (unsigned long long)__float_as_uint(p3.x) | ((unsigned long long)__float_as_uint(p3.y) << 32);
+        ord = (uint32_t)__builtin_popcountll(live & ((1ull << k) - 1ull));
     }
     b.slot[pos] = __float_as_uint(p2.w) + ord;
 }
