@@ -24,7 +24,7 @@ bad_px = np.argwhere(lc_m != lc_r)
 print("pixels with another last contributor:", len(bad_px), bad_px[:5].tolist())
 dT = np.abs(mine["final_T"] - ref["final_T"].reshape(H, W))
 print("final_T max abs diff", dT.max(), "at", np.unravel_index(dT.argmax(), dT.shape))
-for k in ("dL_dmeans2D", "dL_dconic", "dL_dopacity", "dL_dcolors"):
+for k in ("dL_dmeans2D", "dL_dconic", "dL_dopacity", "dL_dcolors", "dL_dscales", "dL_drotations", "dL_dmeans3D"):
     a = np.asarray(mine[k], np.float64).reshape(P, -1); b = np.asarray(ref[k], np.float64).reshape(P, -1)[:, :a.shape[1]]
     d = ((a - b) ** 2).sum(1)
     order = np.argsort(-d)[:4]

@@ -76,3 +76,38 @@ for s in range(0, R, 1 << 18):
     cnt_quad_tile += int((aq & in_tile).sum()); cnt_quad += int((aq & (pos[:, None] < quad_max[t])).sum())
 print(f"backward, (block, entry) pairs in front of the tile's qmax {cnt_tile}, in front of the block's own last contributor {cnt_blk} ({cnt_blk / cnt_tile:.3f})")
 print(f"backward, (quadrant, entry) pairs in front of the tile's qmax {cnt_quad_tile}, in front of the quadrant's own last contributor {cnt_quad} ({cnt_quad / cnt_quad_tile:.3f})")
+
+# ---- passes of the forward kernel as built (512-entry rounds, 64-entry chunks of the block list) against other chunk sizes
+AB = torch.zeros(R, 16, dtype=torch.bool, device=dev); AQ = torch.zeros(R, 64, dtype=torch.bool, device=dev)
+for s in range(0, R, 1 << 18):
+    ids, t = pl[s:s + (1 << 18)], tile_of[s:s + (1 << 18)]
+    x0, y0 = ((t % gx) * 16).float(), ((t // gx) * 16).float()
+    dx = m2[ids, 0, None, None] - (x0[:, None, None] + px[None, None, :])
+    dy = m2[ids, 1, None, None] - (y0[:, None, None] + px[None, :, None])
+    q = co[ids]
+    power = -0.5 * (q[:, 0, None, None] * dx * dx + q[:, 2, None, None] * dy * dy) - q[:, 1, None, None] * dx * dy
+    alive = (power <= 0) & (torch.minimum(torch.tensor(0.99, device=dev), q[:, 3, None, None] * torch.exp(power)) >= 1.0 / 255.0)
+    AB[s:s + (1 << 18)] = alive.view(-1, 4, 4, 4, 4).any(dim=4).any(dim=2).view(-1, 16)
+    AQ[s:s + (1 << 18)] = alive.view(-1, 4, 2, 2, 4, 2, 2).any(dim=6).any(dim=3).permute(0, 1, 3, 2, 4).reshape(-1, 64)    # block*4 + quadrant
+rnd = pos_in_tile // 512
+seg = tile_of * 8 + rnd                                   # (tile, round) segment of every instance (rounds < 8 here)
+assert int(rnd.max()) < 8
+cs = torch.cumsum(AB.long(), dim=0)                       # running count per block over all instances
+first = torch.zeros(int(seg.max()) + 2, dtype=torch.long, device=dev)
+segstart = torch.ones(R, dtype=torch.bool, device=dev); segstart[1:] = seg[1:] != seg[:-1]
+start_idx = torch.nonzero(segstart).squeeze(1)
+base = torch.zeros(R, 16, dtype=torch.long, device=dev)
+base_vals = cs[start_idx] - AB[start_idx].long()          # count before the segment's first instance
+seg_id = torch.cumsum(segstart.long(), 0) - 1
+rank = cs - AB.long() - base_vals[seg_id]                 # rank of the instance in its block's list of this round
+for ch in (64, 128, 4096):
+    chunk = rank // ch                                    # [R,16]
+    nchunk = int(chunk.max()) + 1
+    key = (seg_id[:, None] * 16 + torch.arange(16, device=dev)[None, :]) * nchunk + chunk          # [R,16]
+    tot = torch.zeros((int(seg_id.max()) + 1) * 16 * nchunk, 4, dtype=torch.long, device=dev)
+    for qd in range(4):
+        m = AQ.view(R, 16, 4)[:, :, qd] & AB
+        tot[:, qd].index_add_(0, key[m], torch.ones(int(m.sum()), dtype=torch.long, device=dev))
+    passes = ((tot + 3) // 4).max(dim=1).values.sum()
+    print(f"forward passes with {ch}-entry chunks of the block list: {int(passes)}")
+print(f"ideal (every row always busy): {int((AQ.view(R,16,4) & AB[:, :, None]).sum()) // 16}")
