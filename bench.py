@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--config", type=int, default=3, help="BASELINE.json config index (1-based); 3 = 500k/1080p/SH3")
     ap.add_argument("--mode", default="sh", choices=["sh", "precomp"])
     ap.add_argument("--views", type=int, default=64)
+    ap.add_argument("--batch-upstream", action="store_true", help="dL/d images from ONE call on all images of the step (the streams meet between forwards and backwards) instead of per view on the view's stream")
     ap.add_argument("--streams", type=int, default=4, help="HIP streams the views of a step alternate between (SyncFreeBatch)")
     ap.add_argument("--loss", action="store_true", help="upstream gradient from the fused L1+SSIM loss against fixed target images (a training "
                     "step's image-space work) instead of a fixed dL/d image; not the headline metric")
@@ -148,17 +149,21 @@ def main():
 
     flat = FlatGradients(params)            # parameter .grad tensors are views of one buffer: one collective per step
 
-    upstream_batch = lambda images: dL
+    # dL/d image per view, evaluated on the view's own stream (run_views(upstream_view=...)); --batch-upstream: one call for all views
+    upstream_batch, upstream_view = None, (lambda v, image: dL)
     if a.loss:
         from youreditableavatar_amd.loss import l1_ssim_value_and_grad
         targets = torch.rand(VPG, 3, H, W, device=dev)         # stand-ins for the ground-truth images of the step's views
-        upstream_batch = lambda images: l1_ssim_value_and_grad(images, targets)[1]
+        upstream_view = lambda v, image: l1_ssim_value_and_grad(image[None], targets[v:v + 1])[1][0]
+    if a.batch_upstream:
+        upstream_view = None
+        upstream_batch = (lambda images: l1_ssim_value_and_grad(images, targets)[1]) if a.loss else (lambda images: dL)
 
     def step(s):
         if batch is not None and not a.per_view_calls:
             # three native calls per step (forward of all views, per-pixel backward of all views, one per-Gaussian backward), one Meta read-back;
             # the one per-Gaussian pass of the step STORES the gradients, so the flat buffer needs no zeroing
-            batch.run_views([settings[v] for v in views_of(s)], means3D, opac, shs, scales, rots, upstream_batch, accumulate=False)
+            batch.run_views([settings[v] for v in views_of(s)], means3D, opac, shs, scales, rots, upstream_batch, accumulate=False, upstream_view=upstream_view)
             flat.all_reduce()
             return
         flat.zero_()

@@ -499,6 +499,56 @@ def test_run_views_whole_batch_path(streams, group, gpu_device):
         _C.set_forward_group(1)
 
 
+@pytest.mark.parametrize("streams", [1, 3])
+def test_run_views_per_view_upstream(streams, gpu_device):
+    """run_views(upstream_view=...): the loss of each view is taken on the view's own stream and its backward follows without the
+    streams meeting in between -- same images, per-view dL/d means2D and parameter gradients as with one upstream_batch call;
+    a rejected view is redone with its own upstream call."""
+    from diff_gaussian_rasterization import _C
+    from youreditableavatar_amd import scenes
+    from youreditableavatar_amd.multiview import FlatGradients, SyncFreeBatch
+    P = 5000
+    cloud = scenes.make_cloud(P, 2, seed=43, scale_mult=2.0)
+    cams = [scenes.orbit_camera(160, 96, azimuth_deg=a) for a in (10.0, 80.0, 150.0, 220.0, 290.0)]
+    targets = torch.rand(5, 3, 96, 160, device=gpu_device)
+    names = ("means3D", "opacities", "scales", "rotations", "shs")
+    L = _leaves(cloud, gpu_device)
+    flat = FlatGradients([L[n] for n in names])
+    settings = [_settings(c, 2, gpu_device) for c in cams]
+    grad_view = lambda v, image: 2.0 * (image - targets[v]) / image.numel()              # d/d image of the mean squared error of one view
+    grad_batch = lambda images: 2.0 * (images - targets) / images[0].numel()
+    _C.set_deterministic(True)
+    try:
+        ref = SyncFreeBatch(granule=256, streams=streams)
+        for rep in range(2):
+            flat.zero_()
+            want_img = ref.run_views(settings, L["means3D"], L["opacities"], L["shs"], L["scales"], L["rotations"], grad_batch).clone()
+        want, want_2d = flat.flat.clone(), ref.viewspace_grads.clone()
+        batch = SyncFreeBatch(granule=256, streams=streams)
+        seen = []
+        def upstream(v, image):
+            seen.append(v)
+            return grad_view(v, image)
+        for rep in range(3):                                # synchronous first batch, then the pipelined path twice
+            flat.zero_()
+            del seen[:]
+            imgs = batch.run_views(settings, L["means3D"], L["opacities"], L["shs"], L["scales"], L["rotations"], None, upstream_view=upstream)
+            assert sorted(seen) == [0, 1, 2, 3, 4]
+            assert torch.equal(imgs, want_img), rep
+            assert torch.equal(batch.viewspace_grads, want_2d), rep
+            assert util.rel_l2(flat.flat.cpu().numpy(), want.cpu().numpy()) <= 1e-6, rep
+        batch.bound = batch.bound // 3                      # rejected on the device, rendered again
+        flat.zero_()
+        imgs = batch.run_views(settings, L["means3D"], L["opacities"], L["shs"], L["scales"], L["rotations"], None, upstream_view=upstream)
+        assert batch.rejected >= 1
+        assert torch.equal(imgs, want_img) and torch.equal(batch.viewspace_grads, want_2d)
+        assert util.rel_l2(flat.flat.cpu().numpy(), want.cpu().numpy()) <= 2e-5
+        with pytest.raises(RuntimeError):
+            batch.run_views(settings, L["means3D"], L["opacities"], L["shs"], L["scales"], L["rotations"], grad_batch, upstream_view=upstream)
+    finally:
+        _C.set_deterministic(False)
+
+
 def test_run_views_with_per_view_colors(gpu_device):
     """run_views(colors_precomp=[V,P,3]) -- the reference's training mode, colours evaluated by the caller per view -- against the
     per-view path: images, dL/d colours per view, accumulated parameter gradients; fused SH->RGB in front of it reproduces the

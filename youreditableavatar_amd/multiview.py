@@ -232,14 +232,21 @@ class SyncFreeBatch:
     # launch time per frame -- as much as the GPU needs for the frame once the views overlap on several streams.
     # ------------------------------------------------------------------------------------------------------------------
     def run_views(self, settings: Sequence, means3D: torch.Tensor, opacities: torch.Tensor, shs: torch.Tensor, scales: torch.Tensor,
-                  rotations: torch.Tensor, upstream_batch: Callable[[torch.Tensor], torch.Tensor], accumulate: bool = True,
-                  colors_precomp: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  rotations: torch.Tensor, upstream_batch: Optional[Callable[[torch.Tensor], torch.Tensor]], accumulate: bool = True,
+                  colors_precomp: Optional[torch.Tensor] = None,
+                  upstream_view: Optional[Callable[[int, torch.Tensor], torch.Tensor]] = None) -> torch.Tensor:
         """Renders the views described by ``settings`` (GaussianRasterizationSettings, same image size, SH degree and scale
         modifier) of one Gaussian model (leaf parameters with allocated ``.grad``, SH colours, scales + rotations), calls
         ``upstream_batch(images[V,3,H,W]) -> dL/d images`` ([V,3,H,W], or [3,H,W] for all views) ONCE, and adds the
         gradients of all views into the parameters' ``.grad`` (``accumulate=False``: overwrites them instead -- the
         step then needs no zeroing pass and the batch kernel no read of the old values).  Returns the images -- a view
         of a buffer the next call reuses; ``self.viewspace_grads`` [V,P,3] holds dL/d means2D per view.
+
+        ``upstream_view(v, image[3,H,W]) -> dL/d image`` instead of ``upstream_batch`` (pass ``None`` for that): for losses that are
+        sums over the views (the reference's are: refine.py:245-247 takes the loss of one image).  It is called per view under the
+        HIP stream that view runs on, so a view's backward follows its own forward and loss without any cross-stream wait -- the
+        streams meet only before the per-Gaussian pass (two event round trips per step instead of four, each ~20-40 us of idle
+        GPU on this platform, and no phase boundary where every stream drains).
 
         ``colors_precomp`` [V,P,3] (float32, with ``shs=None``): the reference's training mode -- colours evaluated by the caller
         per view (``compute_color_in_rasterizer=False``, tetgs_model.py:524-537; e.g. ``sh_color.points_rgb``); their
@@ -249,6 +256,10 @@ class SyncFreeBatch:
         rs0 = settings[0]
         P, H, W, D = int(means3D.size(0)), int(rs0.image_height), int(rs0.image_width), int(rs0.sh_degree)
         precomp = colors_precomp is not None
+        if (upstream_batch is None) == (upstream_view is None):
+            raise RuntimeError("run_views: provide exactly one of upstream_batch / upstream_view")
+        if upstream_batch is None:
+            upstream_batch = lambda images: torch.stack([upstream_view(v, images[v]) for v in range(images.size(0))])   # the synchronous paths
         if precomp == (shs is not None):
             raise RuntimeError("run_views: provide exactly one of shs / colors_precomp")
         params = dict(means3D=means3D, opacities=opacities, scales=scales, rotations=rotations)
@@ -360,22 +371,45 @@ class SyncFreeBatch:
                 ev.record(st)
                 main.wait_event(ev)
 
+        def check(dL):
+            if dL.dtype != torch.float32 or not dL.is_cuda or dL.shape[-3:] != pool["images"].shape[-3:]:
+                raise RuntimeError("upstream must return a float32 GPU tensor [V,3,H,W] or [3,H,W]")
+            return dL.contiguous()
+
         with torch.cuda.device(dev):
             fork()
             _C.forward_views(handles, cap, P, D, M, means3D.data_ptr(), None if precomp else shs.data_ptr(), opacities.data_ptr(), scales.data_ptr(),
                              rs0.scale_modifier, rotations.data_ptr(), arr, V, prefiltered=rs0.prefiltered)
-            join()
-            pool["host"].copy_(pool["img"][:, :_C.META_BYTES], non_blocking=True)      # the verdict travels while the GPU works on
-            ready = torch.cuda.Event()
-            ready.record(main)
             images = pool["images"]
-            dL = upstream_batch(images)
-            if dL.dtype != torch.float32 or not dL.is_cuda or dL.shape[-3:] != images.shape[-3:]:
-                raise RuntimeError("upstream_batch must return a float32 GPU tensor [V,3,H,W] or [3,H,W]")
-            dL = dL.contiguous()
-            for v in range(V):
-                arr[v].dL_dpix = grad_of(dL, v).data_ptr()
-            fork()
+            if upstream_view is None:
+                join()
+                pool["host"].copy_(pool["img"][:, :_C.META_BYTES], non_blocking=True)      # the verdict travels while the GPU works on
+                ready = [torch.cuda.Event()]
+                ready[0].record(main)
+                dL = check(upstream_batch(images))
+                for v in range(V):
+                    arr[v].dL_dpix = grad_of(dL, v).data_ptr()
+                fork()
+            else:
+                # every lane: the verdicts of its views leave for the host, then loss and backward of each view follow on the same stream
+                ready, dLs = [], []
+                for l, st in enumerate(lanes):
+                    with torch.cuda.stream(st):
+                        for v in range(l, V, n_lanes):
+                            pool["host"][v].copy_(pool["img"][v, :_C.META_BYTES], non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record(st)
+                        ready.append(ev)
+                        for v in range(l, V, n_lanes):
+                            g = check(upstream_view(v, images[v]))
+                            if g.dim() != 3:
+                                raise RuntimeError("upstream_view must return [3,H,W]")
+                            g.record_stream(st)
+                            dLs.append((v, g))
+                dL = torch.empty(0)
+                for v, g in dLs:
+                    arr[v].dL_dpix = g.data_ptr()
+                self._keep = dLs                                 # (alive until the next batch)
             _C.backward_render_views(handles, P, arr, V)
             join()
             _C.backward_batch_raw(main.cuda_stream, P, D, M, arr, V, means3D.data_ptr(), None if precomp else shs.data_ptr(), scales.data_ptr(),
@@ -383,7 +417,8 @@ class SyncFreeBatch:
                                   None if precomp else shs.grad.data_ptr(), scales.grad.data_ptr(), rotations.grad.data_ptr(), accumulate)
         self.viewspace_grads = pool["g2d"]
         self.color_grads = gcol
-        ready.synchronize()                                 # the one host wait of the batch
+        for ev in ready:
+            ev.synchronize()                                # the one host wait of the batch (long past by now: the GPU is in the backwards)
         seen = 0
         if self._cooldown > 0:
             self._cooldown -= 1
@@ -402,9 +437,9 @@ class SyncFreeBatch:
             states = per_view_fallback(redo, dL)
             for v in redo:
                 images[v].copy_(states[v][1])
-            dL2 = upstream_batch(images) if redo else dL    # the gradient images depend on the re-rendered frames
+            dL2 = upstream_batch(images).contiguous() if upstream_view is None else None    # the gradient images depend on the re-rendered frames
             for v in redo:
-                pool["g2d"][v].copy_(per_view_backward(v, states[v], grad_of(dL2.contiguous(), v)))
+                pool["g2d"][v].copy_(per_view_backward(v, states[v], grad_of(dL2, v) if dL2 is not None else check(upstream_view(v, images[v]))))
                 seen = max(seen, states[v][0])
         self.bound = max(seen, int(self.bound * 0.95))
         return images
