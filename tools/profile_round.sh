@@ -1,6 +1,7 @@
 set -x
+# usage (on the GPU box, via gpurun): bash tools/profile_round.sh [name]  -> gpurun_out/<name>/{bench_default.json, rp4/, rp1/, pmc_fetch/, pmc_write/}
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r01_i
+O=$R/gpurun_out/${1:-r01_j}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
