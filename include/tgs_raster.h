@@ -142,7 +142,9 @@ int tgs_mark_visible(void* stream, int P, const float* means3D, const float* vie
 /* Introspection of a finished forward pass (tests, bench): copies are enqueued on `stream`.
  * field: "n_contrib" (u32[H*W]), "final_T" (f32[H*W]), "ranges" (u32[2*T]), "point_list" (u32[R]),
  * "means2D" (f32[2P]), "depths" (f32[P]), "conic_opacity" (f32[4P]), "rgb" (f32[3P], SH path only),
- * "tiles_touched" (u32[P]).  dst is a device pointer with room for the whole field.
+ * "tiles_touched" (u32[P]), "block_masks" (u32[R]: 4x4 blocks of the instance's tile it can reach, bit 4*by + bx), "quad_masks"
+ * (u64[R]: the same per 2x2-pixel quadrant, bit 8*row + column of the tile's 8x8 quadrant grid), "tile_order" (u32[T]).
+ * dst is a device pointer with room for the whole field.
  * Returns the element count or a negative error. */
 int64_t tgs_state_field(void* stream, const char* field, int P, int width, int height, int64_t R,
                         int has_sh, int has_scale_rot,
