@@ -168,6 +168,25 @@ def test_baseline_config_full_size_vs_oracle(cfg, gpu_device):
     print(cfg, {k: f"{v:.2e}" for k, v in rep.items()})
 
 
+@pytest.mark.parametrize("scale_mult", [4.0, 8.0])
+def test_large_splats_full_size_vs_oracle(scale_mult, gpu_device):
+    """Config 2's cloud (100k Gaussians, 800x800, SH3) with the scales multiplied: most splats now cover 5..64 tiles (the wave-cooperative
+    k_scatter path, instance pruning through the 64-bit live-tile mask, slab rows by popcount) and some more than 64 (workgroup
+    path) -- the full parity bar against the CPU oracle, lists included."""
+    from youreditableavatar_amd import scenes
+    cfg = scenes.CONFIGS[2]
+    cloud = scenes.make_cloud(cfg["P"], cfg["sh_degree"], cfg["seed"], scale_mult=scale_mult)
+    cam = scenes.orbit_camera(cfg["width"], cfg["height"], azimuth_deg=25.0)
+    inp = util.scene_input(cloud, cam)
+    dL = scenes.upstream_gradient(cfg["width"], cfg["height"], seed=9)
+    mine = util.hip_run(inp, dL)
+    ref = util.oracle_run(inp, dL)
+    tt = ref["tiles_touched"]
+    assert ((tt > 4) & (tt <= 64)).mean() > 0.2 and (scale_mult < 8 or (tt > 64).sum() > 100)      # the paths are really taken
+    rep = util.compare(mine, ref)
+    print(scale_mult, mine["num_rendered"], ref["num_rendered"], {k: f"{v:.2e}" for k, v in rep.items() if k in ("color", "instances_dropped", "n_contrib_equal", "dL_dmeans2D")})
+
+
 def test_config5_overflow_stress_properties(gpu_device):
     """Config 5 (2M Gaussians, 2048x2048, 1 % flat 1e-8 splats, 1000 oversized splats): size-independent properties
     at full size -- sorted lists, range bookkeeping, n_contrib bounds, finite outputs, linearity of the backward in dL."""
