@@ -181,16 +181,19 @@ __global__ __launch_bounds__(256) void k_render_bwd_det(const ImgState s, const 
 
 // ---------------------------------------------------------------------------------------------
 // k_render_bwd (default): same geometry as k_render_fwd -- 16 waves per tile, one wave per 4x4-pixel
-// block, 64 lanes = 16 pixels x 4 consecutive list entries (back to front).  Every lane evaluates its
-// own (pixel, entry) pair; the 4 lanes of a quad walk the pixel's sequential state (T, accum_rec,
-// last_alpha, last_color of backward.cu:505-531) through the group's 4 entries with DPP quad
-// broadcasts and each lane keeps the state of its own step; a skipped entry is walked as alpha = 0,
-// which leaves T and every later accum_rec value bit-identical to not visiting it
+// block, every 16-lane row one 2x2-pixel quadrant walking its own list (back to front), 4 pixels x 4
+// consecutive entries per row and pass.  Every lane evaluates its own (pixel, entry) pair; the 4 lanes
+// of a quad walk the pixel's sequential state (T, accum_rec, last_alpha, last_color of
+// backward.cu:505-531) through the group's 4 entries with DPP quad broadcasts and each lane keeps the
+// state of its own step; a skipped entry is walked as alpha = 0, which leaves T and every later
+// accum_rec value bit-identical to not visiting it
 // (acc' = la*lc + (1-la)*acc, (la,lc) <- (0,c);  next: 0*c + 1*acc' = acc').
-// The nine per-entry sums over the block's 16 pixels are formed with DPP row rotations and
-// v_permlane16/32_swap (34 operations per 4 entries), then added to the tile's per-round accumulator
-// in LDS with ds_add_f32: up to 16 waves add to one entry, so the in-tile summation order -- and the
-// last bit of a gradient -- can vary run to run.  k_render_bwd_det above keeps a fixed order
+// The nine per-entry sums over the quadrant's 4 pixels are formed with DPP row rotations (18
+// v_add_f32_dpp), then every row adds them to the tile's per-round accumulator in LDS -- in f64:
+// ds_add_f32 is a per-lane loop on gfx950 (~3 clk per active lane), ds_add_f64 runs at the rate of a
+// plain LDS access (tools/microbench/lds_atomic_rate.hip).  Up to 64 adds meet in one entry, so the
+// in-tile summation order can vary run to run, but the f32 terms are summed in f64 and rounded once at
+// the flush: differences are rare last-bit events.  k_render_bwd_det above keeps a fixed order
 // (bitwise reproducible) at about 2.5x the time; tgs_set_deterministic(1) selects it.
 // ---------------------------------------------------------------------------------------------
 constexpr int BWD_THREADS = 1024;

@@ -7,8 +7,10 @@
 //                                                                   (cub InclusiveSum, identifyTileRanges)
 //   [host reads R, longest list]                                     (the reference's D2H copy, :280-281)
 //   k_scatter          every instance goes straight to its tile's segment              (duplicateWithKeys)
-//   k_tile_sort        per-tile sort by (depth, index) inside LDS + gather of the       (cub SortPairs)
-//                      per-instance records; lists longer than SORT_LDS_CAP take the k_ovf_* path
+//   k_tile_sort*       per-tile sort by (depth, index) inside LDS; lists longer than       (cub SortPairs)
+//                      SORT_LDS_CAP take the k_ovf_* path
+//   k_finalize         gather of the per-instance records in sorted order + the 64-bit quadrant mask of each
+//                      instance (which 2x2-pixel quadrants of its tile the splat reaches)   (forward.cu:315-321)
 //   k_render_fwd       front-to-back compositing, one 16x16 tile per workgroup           (forward.cu:261-374)
 //
 // The reference sorts 64-bit (tile|depth) keys globally with a 6-pass radix sort (12 B x R per pass);
@@ -682,20 +684,19 @@ __global__ __launch_bounds__(256) void k_ovf_global(const ImgState s, const BinS
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_render_fwd: one 16x16 tile per 256-thread workgroup; each of the 4 waves owns an 8x8 pixel
-// quadrant so that a wave's 64 pixels are spatially compact (whole-wave skips of small splats).
-// The tile's records are staged through LDS in rounds of 256 and read back as broadcasts.
-// ---------------------------------------------------------------------------------------------
 // k_render_fwd: one 16x16 tile per 1024-thread workgroup = 16 waves, one wave per 4x4-pixel block.
-// Inside a wave the 64 lanes are 16 pixels x 4 CONSECUTIVE list entries: every lane evaluates one
-// (pixel, entry) pair -- conic power, exp, alpha -- and the four lanes of a quad then walk the
-// transmittance chain of their pixel together (DPP quad broadcasts of 1-alpha), so one pass of the
-// loop retires four entries of the front-to-back order with the sequential semantics of
-// forward.cu:325-362 intact (T is multiplied in list order; the first entry that would push T below
-// 1e-4 stops the pixel and is not blended).
-// Why: the kernel's duration is the longest tile list times the per-entry latency of the waves that
-// own it (work per tile is tiny against the chip), so a tile is spread over 16 waves, long lists are
-// visited first (tile_order) at raised priority, and the per-entry dependent chain is 1/4 as long.
+// Inside a wave every 16-lane DPP row is one 2x2-pixel quadrant of the block: 4 pixels x 4 CONSECUTIVE
+// entries of the quadrant's OWN list (the entries whose 64-bit quadrant mask names it; tgs_device.hpp
+// "quadrant culling").  Every lane evaluates one (pixel, entry) pair -- conic power, exp, alpha -- and
+// the four lanes of a quad then walk the transmittance chain of their pixel together (DPP quad
+// broadcasts of 1-alpha), so one pass of the loop retires four entries of each quadrant's list with the
+// sequential semantics of forward.cu:325-362 intact (T is multiplied in list order; the first entry that
+// would push T below 1e-4 stops the pixel and is not blended).  The quad chains never leave the quad, so
+// the four rows may walk four different lists in one instruction stream.
+// Why: both render kernels are bound by VALU issue, and only the lanes inside the splat's alpha >= 1/255
+// footprint do useful work -- 33 % of them when a wave's 16 pixels all took the block's entries, 64 %
+// quadrant by quadrant (tools/culling_potential.py).  A tile is spread over 16 waves and long lists are
+// visited first (tile_order) because a kernel ends when its longest list does.
 constexpr int FWD_THREADS = 1024;
 constexpr int FCH = 512;                   // list entries staged per round
 constexpr int FNULL = FCH;                 // LDS slot of the null record
