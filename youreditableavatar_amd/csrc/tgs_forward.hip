@@ -565,59 +565,80 @@ __device__ __forceinline__ void finalize_entry(unsigned long long key, uint32_t 
     b.slot[pos] = __float_as_uint(p2.w) + ord;
 }
 
-// Per-tile sort in LDS, tiles visited in tile_order (longest lists first).  Three classes by list length n:
-//   n >= 1024 : one 1024-thread workgroup per tile  } all steps that stay inside an aligned 128-key chunk are run by one
-//   n >= 128  : one 256-thread workgroup per tile   } wave without workgroup barriers (21 barriers instead of 78 at 4096 keys)
-//   n <  128  : one WAVE per tile, four tiles per workgroup, no barrier at all
-// The grids are upper bounds (exact after tgs_forward's read-back).
+// Per-tile sort in LDS, tiles visited in tile_order (longest lists first).  Three classes by list length n, all in ONE launch of
+// 1024-thread workgroups (the classes are latency bound on their longest lists; launched one after the other their critical paths add up:
+// 25 + 20 + 7 us at config 3, 28 us together):
+//   n >= 1024 : one workgroup per tile                 } all steps that stay inside an aligned 128-key chunk are run by one
+//   n >= 128  : four tiles per workgroup, 256 threads  } wave without workgroup barriers (21 barriers instead of 78 at 4096 keys)
+//               each; the four run the network of the longest of them so that every thread meets the same barriers -- on a
+//               sorted list the extra all-ascending steps exchange nothing
+//   n <  128  : one WAVE per tile, sixteen tiles per workgroup, no barrier at all
+// The grid is an upper bound per class (exact after tgs_forward's read-back); the tile indices come from Meta.
+// sorts keys [0, n) of lk with NT threads (tid in [0, NT)) that all call this; npad_loop >= next_pow2(n): the merge sizes to run
 template <int NT>
-__global__ __launch_bounds__(NT) void k_tile_sort(const ImgState s, const BinState b, uint32_t sort_cap)
+__device__ __forceinline__ void sort_tile_lds(unsigned long long* lk, uint32_t tid, uint32_t n, uint32_t npad_loop)
 {
-    extern __shared__ unsigned long long lk[];
-    if (frame_rejected(s)) return;
-    const uint32_t n_heavy = min(s.meta->n_heavy, s.meta->n_nonempty), n_mid = min(max(s.meta->n_mid, n_heavy), s.meta->n_nonempty);
-    const uint32_t t = (NT == 1024 ? 0u : n_heavy) + blockIdx.x;
-    if (t >= (NT == 1024 ? n_heavy : n_mid)) return;
-    const uint4 td = s.tile_desc[t];
-    const uint2 rg = make_uint2(td.y, td.z);
-    const uint32_t n = rg.y - rg.x;
-    if (n < 2 || n > sort_cap) return;
-    for (uint32_t i = threadIdx.x; i < n; i += NT) lk[i] = b.keys[rg.x + i];
-    __syncthreads();
-    const uint32_t npad = next_pow2(n), half = npad >> 1;
-    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t half = npad_loop >> 1;
+    const uint32_t lane = tid & 63, wv = tid >> 6;
     constexpr uint32_t W = NT / 64;
-    for (uint32_t c = wv * SORT_CHUNK; c < n; c += W * SORT_CHUNK) wave_chunk_sort(lk, c, n, lane, min(SORT_CHUNK, npad));
+    for (uint32_t c = wv * SORT_CHUNK; c < n; c += W * SORT_CHUNK) wave_chunk_sort(lk, c, n, lane, min(SORT_CHUNK, npad_loop));
     __syncthreads();
-    for (uint32_t k = 2 * SORT_CHUNK; k <= npad; k <<= 1) {
-        for (uint32_t p = threadIdx.x; p < half; p += NT) { uint32_t i, l; pair_flip(p, k, i, l); cmp_swap(lk, i, l, n); }
+    for (uint32_t k = 2 * SORT_CHUNK; k <= npad_loop; k <<= 1) {
+        for (uint32_t p = tid; p < half; p += NT) { uint32_t i, l; pair_flip(p, k, i, l); cmp_swap(lk, i, l, n); }
         __syncthreads();
         for (uint32_t j = k >> 2; j >= SORT_CHUNK; j >>= 1) {
-            for (uint32_t p = threadIdx.x; p < half; p += NT) { uint32_t i, l; pair_disperse(p, j, i, l); cmp_swap(lk, i, l, n); }
+            for (uint32_t p = tid; p < half; p += NT) { uint32_t i, l; pair_disperse(p, j, i, l); cmp_swap(lk, i, l, n); }
             __syncthreads();
         }
         for (uint32_t c = wv * SORT_CHUNK; c < n; c += W * SORT_CHUNK) wave_chunk_disperse(lk, c, n, lane, SORT_CHUNK >> 1);
         __syncthreads();
     }
-    for (uint32_t i = threadIdx.x; i < n; i += NT) b.keys[rg.x + i] = lk[i];
 }
 
-__global__ __launch_bounds__(256) void k_tile_sort_small(const ImgState s, const BinState b, uint32_t sort_cap)
+__global__ __launch_bounds__(1024) void k_tile_sort(const ImgState s, const BinState b, uint32_t sort_cap, uint32_t heavy_blocks, uint32_t mid_blocks)
 {
-    __shared__ unsigned long long lk4[4][SORT_CHUNK];
+    extern __shared__ unsigned long long lk[];
+    __shared__ uint32_t grp_npad[4];
     if (frame_rejected(s)) return;
+    const uint32_t n_nonempty = s.meta->n_nonempty;
+    const uint32_t n_heavy = min(s.meta->n_heavy, n_nonempty), n_mid = min(max(s.meta->n_mid, n_heavy), n_nonempty);
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t n_heavy = min(s.meta->n_heavy, s.meta->n_nonempty), n_mid = min(max(s.meta->n_mid, n_heavy), s.meta->n_nonempty);
-    const uint32_t t = n_mid + blockIdx.x * 4 + wv;
-    if (t >= s.meta->n_nonempty) return;                    // wave-uniform: no workgroup barrier below
-    const uint4 td = s.tile_desc[t];
-    const uint32_t n = td.z - td.y;
-    if (n < 2 || n > sort_cap || n > SORT_CHUNK) return;    // (n < 128 by the class boundary in k_scan)
-    unsigned long long* lk = lk4[wv];
-    for (uint32_t i = lane; i < n; i += 64) lk[i] = b.keys[td.y + i];
-    wave_sync();
-    wave_chunk_sort(lk, 0u, n, lane, next_pow2(n));
-    for (uint32_t i = lane; i < n; i += 64) b.keys[td.y + i] = lk[i];
+    if (blockIdx.x < heavy_blocks) {
+        const uint32_t t = blockIdx.x;
+        if (t >= n_heavy) return;
+        const uint4 td = s.tile_desc[t];
+        const uint32_t n = td.z - td.y;
+        if (n < 2 || n > sort_cap) return;                  // (longer lists: k_ovf_*)
+        for (uint32_t i = threadIdx.x; i < n; i += 1024) lk[i] = b.keys[td.y + i];
+        __syncthreads();
+        sort_tile_lds<1024>(lk, threadIdx.x, n, next_pow2(n));
+        for (uint32_t i = threadIdx.x; i < n; i += 1024) b.keys[td.y + i] = lk[i];
+    } else if (blockIdx.x < heavy_blocks + mid_blocks) {
+        const uint32_t grp = threadIdx.x >> 8, tid = threadIdx.x & 255u;
+        const uint32_t t = n_heavy + (blockIdx.x - heavy_blocks) * 4 + grp;
+        if (n_heavy + (blockIdx.x - heavy_blocks) * 4 >= n_mid) return;          // the whole workgroup is behind the class
+        uint32_t n = 0, start = 0;
+        if (t < n_mid) { const uint4 td = s.tile_desc[t]; start = td.y; n = td.z - td.y; }
+        if (n > 1024u || n > sort_cap) n = 0;               // (cannot happen by the class boundary; keeps the LDS segment safe)
+        unsigned long long* seg = lk + grp * 1024;
+        for (uint32_t i = tid; i < n; i += 256) seg[i] = b.keys[start + i];
+        if (tid == 0) grp_npad[grp] = n < 2 ? 2u : next_pow2(n);
+        __syncthreads();
+        const uint32_t npad_wg = max(max(grp_npad[0], grp_npad[1]), max(grp_npad[2], grp_npad[3]));
+        sort_tile_lds<256>(seg, tid, n, npad_wg);
+        for (uint32_t i = tid; i < n; i += 256) b.keys[start + i] = seg[i];
+    } else {
+        const uint32_t t = n_mid + (blockIdx.x - heavy_blocks - mid_blocks) * 16 + wv;
+        if (t >= n_nonempty) return;                        // wave-uniform: no workgroup barrier below
+        const uint4 td = s.tile_desc[t];
+        const uint32_t n = td.z - td.y;
+        if (n < 2 || n > sort_cap || n > SORT_CHUNK) return;    // (n < 128 by the class boundary in k_scan)
+        unsigned long long* seg = lk + wv * SORT_CHUNK;
+        for (uint32_t i = lane; i < n; i += 64) seg[i] = b.keys[td.y + i];
+        wave_sync();
+        wave_chunk_sort(seg, 0u, n, lane, next_pow2(n));
+        for (uint32_t i = lane; i < n; i += 64) b.keys[td.y + i] = seg[i];
+    }
 }
 
 // One thread per sorted instance, evenly over all R of them: finds its tile by binary search in the (monotone)
@@ -925,12 +946,16 @@ void launch_tile_sort(hipStream_t st, const GeomState& g, const ImgState& s, con
     if (mid < heavy) mid = heavy;
     if (mid > nonempty) mid = nonempty;
     const uint32_t small = m ? nonempty - mid : nonempty;
-    if (heavy > 0) hipLaunchKernelGGL((k_tile_sort<1024>), dim3(heavy), dim3(1024), lds, st, s, b, sort_cap);
-    if (mid > (m ? heavy : 0u)) {
-        const uint32_t cap2 = cap < 1024u ? cap : 1024u;    // these lists are shorter than 1024
-        hipLaunchKernelGGL((k_tile_sort<256>), dim3(m ? mid - heavy : mid), dim3(256), (size_t)(cap2 ? cap2 : 1) * 8, st, s, b, sort_cap);
+    {
+        const uint32_t mid_only = m ? mid - heavy : mid;    // (without the read-back both classes are bounded on their own)
+        const uint32_t mid_blocks = (mid_only + 3) / 4, small_blocks = (small + 15) / 16;
+        size_t bytes = 0;                                   // LDS for the largest class present: keys of one heavy tile / 4 x 1024 / 16 x 128
+        if (heavy > 0) bytes = lds;
+        if (mid_blocks > 0 && bytes < 4 * 1024 * 8) bytes = 4 * 1024 * 8;
+        if (small_blocks > 0 && bytes < 16 * SORT_CHUNK * 8) bytes = 16 * SORT_CHUNK * 8;
+        if (heavy + mid_blocks + small_blocks > 0)
+            hipLaunchKernelGGL(k_tile_sort, dim3(heavy + mid_blocks + small_blocks), dim3(1024), bytes, st, s, b, sort_cap, heavy, mid_blocks);
     }
-    if (small > 0) hipLaunchKernelGGL(k_tile_sort_small, dim3((small + 3) / 4), dim3(256), 0, st, s, b, sort_cap);
     if (m && m->n_overflow > 0) {
         // lists longer than sort_cap: sorted in global memory by many workgroups, LDS for strides < sort_cap
         const uint32_t npad = host_next_pow2(max_count);
