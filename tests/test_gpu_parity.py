@@ -146,6 +146,34 @@ def test_instance_pruning_off_gives_the_reference_lists(gpu_device):
         assert util.rel_l2(full[k], pruned[k]) <= 2e-5, k
 
 
+def test_instance_pruning_off_with_large_splats(gpu_device):
+    """The same switch on a scene whose splats mostly cover 5..64 tiles (64-bit live-tile masks, wave-cooperative k_scatter) and
+    some more than 64: with pruning off every tile of every rectangle has its instance -- num_rendered, tiles_touched and the tile
+    ranges equal the oracle's (the reference's definition); with pruning on the lists are the oracle's minus non-contributors."""
+    from diff_gaussian_rasterization import _C
+    from youreditableavatar_amd import scenes
+    cloud = scenes.make_cloud(20_000, 2, seed=97, scale_mult=4.0, n_oversized=5, oversize=20.0)
+    cam = scenes.orbit_camera(320, 208, azimuth_deg=65.0)
+    inp = util.scene_input(cloud, cam)
+    dL = scenes.upstream_gradient(320, 208, seed=4)
+    ref = util.oracle_run(inp, dL)
+    tt = ref["tiles_touched"]
+    assert ((tt > 4) & (tt <= 64)).sum() > 2000 and (tt > 64).sum() >= 5
+    pruned = util.hip_run(inp, dL)
+    util.compare(pruned, ref)
+    _C.set_instance_pruning(False)
+    try:
+        full = util.hip_run(inp, dL)
+    finally:
+        _C.set_instance_pruning(True)
+    assert full["num_rendered"] == ref["num_rendered"] > pruned["num_rendered"]
+    assert np.array_equal(full["tiles_touched"], ref["tiles_touched"])
+    assert np.array_equal(full["ranges"].reshape(-1, 2), ref["ranges"].reshape(-1, 2))
+    assert util.rel_l2(full["color"], pruned["color"]) <= 1e-6
+    for k in util.GRAD_KEYS:
+        assert util.rel_l2(full[k], pruned[k]) <= 5e-5, k
+
+
 @pytest.mark.parametrize("name", ["g01_sh3_scale_rot", "g09_giant_splat", "g13_dense_2k"])
 def test_quadrant_masks_are_conservative(name, gpu_device):
     """The render kernels visit an entry only in the 2x2-pixel quadrants its 64-bit mask names (k_finalize, bit 8*row + column of the
