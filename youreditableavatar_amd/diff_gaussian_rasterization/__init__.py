@@ -9,6 +9,8 @@ from __future__ import annotations
 
 from typing import NamedTuple
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -50,6 +52,10 @@ def _call_native(fn, args, debug: bool, dump_name: str, what: str):
         raise
 
 
+_SPECULATE = os.environ.get("TGS_SPECULATIVE_FORWARD", "1") != "0"
+_last_count = {}
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
@@ -58,7 +64,19 @@ class _RasterizeGaussians(torch.autograd.Function):
         args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
                 rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree, rs.campos,
                 rs.prefiltered, rs.debug)
-        num_rendered, color, radii, geom, binning, img = _call_native(_C.rasterize_gaussians, args, rs.debug, "snapshot_fw.dump", "forward")
+        # The forward reads num_rendered back like the reference (rasterizer_impl.cu:280-281), but does not wait for it before it
+        # enqueues the stages behind the scan: they run against last call's count + headroom (tgs_forward_speculative; a frame that
+        # needs more repeats them with the exact sizes).  num_rendered below is what the binning buffer is carved for.
+        key = (int(means3D.shape[0]), int(rs.image_height), int(rs.image_width), means3D.device)
+        guess = _last_count.get(key) if _SPECULATE else None
+        if guess is not None:
+            num_rendered, color, radii, geom, binning, img, true_R = _call_native(
+                lambda *a: _C.rasterize_gaussians(*a, r_guess=guess), args, rs.debug, "snapshot_fw.dump", "forward")
+        else:
+            num_rendered, color, radii, geom, binning, img = _call_native(_C.rasterize_gaussians, args, rs.debug, "snapshot_fw.dump", "forward")
+            true_R = num_rendered
+        if _SPECULATE:
+            _last_count[key] = (int(true_R * 1.15) + 65535) // 65536 * 65536
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img)
