@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--config", type=int, default=3, help="BASELINE.json config index (1-based); 3 = 500k/1080p/SH3")
     ap.add_argument("--mode", default="sh", choices=["sh", "precomp"])
     ap.add_argument("--views", type=int, default=64)
+    ap.add_argument("--split-streams", action="store_true", help="half of the streams bin, the other half composite (SyncFreeBatch(split=True))")
     ap.add_argument("--batch-upstream", action="store_true", help="dL/d images from ONE call on all images of the step (the streams meet between forwards and backwards) instead of per view on the view's stream")
     ap.add_argument("--streams", type=int, default=4, help="HIP streams the views of a step alternate between (SyncFreeBatch)")
     ap.add_argument("--loss", action="store_true", help="upstream gradient from the fused L1+SSIM loss against fixed target images (a training "
@@ -115,7 +116,7 @@ def main():
             colors_pre[view] = g(scenes.sh_to_rgb_numpy(cloud["shs"], cloud["means3D"], cams[view].campos, D), True)
         return rast(means3D=means3D, means2D=means2D, opacities=opac, colors_precomp=colors_pre[view], scales=scales, rotations=rots)
 
-    batch = SyncFreeBatch(streams=a.streams) if (fused and not a.sync_per_frame) else None
+    batch = SyncFreeBatch(streams=a.streams, split=a.split_streams) if (fused and not a.sync_per_frame) else None
 
     VPG = a.views_per_gpu
 

@@ -230,6 +230,11 @@ int tgs_backward_render_views(void* const* streams, int n_streams, int P, int n_
  * forward.cu:340-343).  Images and gradients do not change; num_rendered and the internal n_contrib (a list position) do.
  * Off = the reference's instance lists, e.g. to count fragments the way the reference's state defines them. */
 void tgs_set_instance_pruning(int on);
+/* Experiment knob (per calling thread): tgs_forward_views puts k_render_fwd of view k on streams[k mod n] -- behind an event on the
+ * view's own stream -- so that binning (L2 atomics, latency) and compositing (VALU) of different views run on streams of their own.
+ * n = 0 restores one stream per view. */
+int tgs_set_render_streams(void* const* streams, int n);
+
 /* Knob (process-wide): views per launch of the per-Gaussian forward stage inside tgs_forward_views (1..8, default 1).  Groups
  * read the SH rows once per group; measured, that does not pay when the views overlap on several streams. */
 void tgs_set_forward_group(int views_per_launch);

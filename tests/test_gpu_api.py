@@ -518,8 +518,8 @@ def test_run_views_whole_batch_path(streams, group, gpu_device):
         _C.set_forward_group(1)
 
 
-@pytest.mark.parametrize("streams", [1, 3])
-def test_run_views_per_view_upstream(streams, gpu_device):
+@pytest.mark.parametrize("streams,split", [(1, False), (3, False), (4, True)])
+def test_run_views_per_view_upstream(streams, split, gpu_device):
     """run_views(upstream_view=...): the loss of each view is taken on the view's own stream and its backward follows without the
     streams meeting in between -- same images, per-view dL/d means2D and parameter gradients as with one upstream_batch call;
     a rejected view is redone with its own upstream call."""
@@ -543,7 +543,7 @@ def test_run_views_per_view_upstream(streams, gpu_device):
             flat.zero_()
             want_img = ref.run_views(settings, L["means3D"], L["opacities"], L["shs"], L["scales"], L["rotations"], grad_batch).clone()
         want, want_2d = flat.flat.clone(), ref.viewspace_grads.clone()
-        batch = SyncFreeBatch(granule=256, streams=streams)
+        batch = SyncFreeBatch(granule=256, streams=streams, split=split)     # split: two streams bin, two composite
         seen = []
         def upstream(v, image):
             seen.append(v)

@@ -207,6 +207,10 @@ static SpecSlot* spec_slot()
 
 // r_capacity < 0: the reference's protocol (read R back, then size the binning buffer).  r_capacity >= 0: sync-free --
 // the binning buffer is sized for r_capacity instances before anything runs and nothing is read back.
+// tgs_set_render_streams: k_render_fwd of view k goes to render stream k mod n (behind an event on the view's own stream)
+static thread_local std::vector<hipStream_t> t_render_streams;
+static thread_local hipStream_t t_render_stream = nullptr;
+
 static int64_t forward_impl(int preprocessed, int64_t r_capacity, int64_t* speculative_true_R, tgs_alloc_fn alloc, void* alloc_ctx, void* stream, int P, int D, int M, const float* background, int width,
                     int height, const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
                     const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
@@ -306,8 +310,17 @@ static int64_t forward_impl(int preprocessed, int64_t r_capacity, int64_t* specu
         launch_tile_sort(st, g, s, b, cam.gx, (uint32_t)T, R, known, sort_cap);
         STAGE_CHECK("tile_sort", TGS_STAGE_TILE_SORT);
     }
+    hipStream_t rst = st;
+    if (t_render_stream && t_render_stream != st && !spec) {     // binning and compositing on different streams (tgs_set_render_streams)
+        hipEvent_t binned;
+        HIP_TRY(hipEventCreateWithFlags(&binned, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(binned, st));
+        HIP_TRY(hipStreamWaitEvent(t_render_stream, binned, 0));
+        (void)hipEventDestroy(binned);
+        rst = t_render_stream;
+    }
     STAGE_BEGIN(TGS_STAGE_RENDER_FWD);
-    launch_render_fwd(st, s, b, width, height, cam.gx, (uint32_t)T, known, background, out_color);
+    launch_render_fwd(rst, s, b, width, height, cam.gx, (uint32_t)T, known, background, out_color);
     STAGE_CHECK("render", TGS_STAGE_RENDER_FWD);
     if (spec) {
         HIP_TRY(hipEventSynchronize(spec->ready));
@@ -470,6 +483,13 @@ static void* alloc_preset(void* ctx, int which, size_t bytes)
     return nullptr;
 }
 
+int tgs_set_render_streams(void* const* streams, int n)
+{
+    t_render_streams.clear();
+    for (int i = 0; i < n && streams; i++) t_render_streams.push_back((hipStream_t)streams[i]);
+    return TGS_OK;
+}
+
 int tgs_forward_views(void* const* streams, int n_streams, int64_t r_capacity, int P, int D, int M, const float* means3D, const float* shs,
                       const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier, const float* rotations,
                       const float* cov3D_precomp, int prefiltered, int n_views, tgs_view_t* views)
@@ -538,6 +558,8 @@ int tgs_forward_views(void* const* streams, int n_streams, int64_t r_capacity, i
             tgs_view_t& v = views[v0 + k];
             hipStream_t st = (hipStream_t)streams[(v0 + k) % n_streams];
             if (pre_done && st != st0) HIP_TRY(hipStreamWaitEvent(st, pre_done, 0));
+            t_render_stream = t_render_streams.empty() ? nullptr : t_render_streams[(size_t)(v0 + k) % t_render_streams.size()];
+            struct Reset { ~Reset() { t_render_stream = nullptr; } } reset_render_stream;
             const int64_t r = forward_impl(batched ? 1 : 0, r_capacity, nullptr, alloc_preset, &v, st, P, D, M, v.background, v.width, v.height, means3D, shs,
                                            v.colors_precomp ? v.colors_precomp : colors_precomp,
                                            opacities, scales, scale_modifier, rotations, cov3D_precomp, v.viewmatrix, v.projmatrix, v.campos, v.tan_fovx, v.tan_fovy,

@@ -48,6 +48,8 @@ def _load() -> C.CDLL:
     lib.tgs_state_sizes.restype = None
     lib.tgs_state_sizes.argtypes = [it, it, it, it, it, C.c_int64, C.POINTER(C.c_size_t)]
     lib.tgs_forward_views.restype = it
+    lib.tgs_set_render_streams.restype = it
+    lib.tgs_set_render_streams.argtypes = [vp, it]
     lib.tgs_forward_views.argtypes = [vp, it, C.c_int64, it, it, it, vp, vp, vp, vp, vp, fl, vp, vp, it, it, vp]
     lib.tgs_backward_render_views.restype = it
     lib.tgs_backward_render_views.argtypes = [vp, it, it, it, vp]
@@ -357,6 +359,12 @@ def forward_views(stream_handles, r_capacity, P, D, M, means3D, shs, opacities, 
                                float(scale_modifier), rotations, None, int(bool(prefiltered)), int(n_views), C.cast(views, C.c_void_p))
     if r < 0:
         raise _err(int(r))
+
+
+def set_render_streams(stream_handles) -> None:
+    """tgs_set_render_streams: later forward_views calls of this thread put k_render_fwd of view k on stream_handles[k mod n] ([] resets)."""
+    arr = (C.c_void_p * max(1, len(stream_handles)))(*stream_handles)
+    _lib.tgs_set_render_streams(arr, len(stream_handles))
 
 
 def backward_render_views(stream_handles, P, views, n_views) -> None:

@@ -213,12 +213,15 @@ class SyncFreeBatch:
     return_meta=True)`` and returns its ``(image, radii, meta)``; ``upstream(v, image)`` returns dL/d image (it runs
     again for a re-rendered view)."""
 
-    def __init__(self, headroom: float = 1.25, granule: int = 1 << 16, streams: int = 4, deferred: bool = True):
+    def __init__(self, headroom: float = 1.25, granule: int = 1 << 16, streams: int = 4, deferred: bool = True, split: bool = False):
         self.headroom, self.granule = float(headroom), int(granule)
         self.bound: Optional[int] = None        # largest num_rendered seen (decays slowly)
         self.rejected = 0                       # frames re-rendered so far
         self.streams = max(1, int(streams))     # 2: consecutive views alternate between two HIP streams (see run)
         self.deferred = bool(deferred)          # one per-Gaussian backward pass for the whole batch (DeferredBackward)
+        # run_views(upstream_view=...): half of the streams bin (per-Gaussian forward .. finalize), the other half composite
+        # (k_render_fwd, the loss, k_render_bwd): kernels bound by the L2 atomics / by latency next to kernels bound by VALU issue
+        self.split = bool(split)
         self._host: Optional[torch.Tensor] = None
         self._side = {}
         self._cooldown = 0                      # batches to render synchronously after a tile list outgrew the LDS sort
@@ -383,9 +386,15 @@ class SyncFreeBatch:
             return dL.contiguous()
 
         with torch.cuda.device(dev):
+            split = self.split and upstream_view is not None and n_lanes >= 4
+            bin_lanes, ren_lanes = (lanes[:n_lanes // 2], lanes[n_lanes // 2:]) if split else (lanes, lanes)
             fork()
-            _C.forward_views(handles, cap, P, D, M, means3D.data_ptr(), None if precomp else shs.data_ptr(), opacities.data_ptr(), scales.data_ptr(),
-                             rs0.scale_modifier, rotations.data_ptr(), arr, V, prefiltered=rs0.prefiltered)
+            _C.set_render_streams([st.cuda_stream for st in ren_lanes] if split else [])
+            try:
+                _C.forward_views([st.cuda_stream for st in bin_lanes], cap, P, D, M, means3D.data_ptr(), None if precomp else shs.data_ptr(), opacities.data_ptr(),
+                                 scales.data_ptr(), rs0.scale_modifier, rotations.data_ptr(), arr, V, prefiltered=rs0.prefiltered)
+            finally:
+                _C.set_render_streams([])
             images = pool["images"]
             if upstream_view is None:
                 join()
@@ -399,14 +408,16 @@ class SyncFreeBatch:
             else:
                 # every lane: the verdicts of its views leave for the host, then loss and backward of each view follow on the same stream
                 ready, dLs = [], []
-                for l, st in enumerate(lanes):
+                for l, st in enumerate(bin_lanes):
                     with torch.cuda.stream(st):
-                        for v in range(l, V, n_lanes):
+                        for v in range(l, V, len(bin_lanes)):
                             pool["host"][v].copy_(pool["img"][v, :_C.META_BYTES], non_blocking=True)
                         ev = torch.cuda.Event()
                         ev.record(st)
                         ready.append(ev)
-                        for v in range(l, V, n_lanes):
+                for l, st in enumerate(ren_lanes):
+                    with torch.cuda.stream(st):
+                        for v in range(l, V, len(ren_lanes)):
                             g = check(upstream_view(v, images[v]))
                             if g.dim() != 3:
                                 raise RuntimeError("upstream_view must return [3,H,W]")
@@ -416,7 +427,7 @@ class SyncFreeBatch:
                 for v, g in dLs:
                     arr[v].dL_dpix = g.data_ptr()
                 self._keep = dLs                                 # (alive until the next batch)
-            _C.backward_render_views(handles, P, arr, V)
+            _C.backward_render_views([st.cuda_stream for st in ren_lanes] if upstream_view is not None else handles, P, arr, V)
             join()
             _C.backward_batch_raw(main.cuda_stream, P, D, M, arr, V, means3D.data_ptr(), None if precomp else shs.data_ptr(), scales.data_ptr(),
                                   rs0.scale_modifier, rotations.data_ptr(), opacities.grad.data_ptr(), means3D.grad.data_ptr(),
