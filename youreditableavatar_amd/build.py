@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
-LIB = os.path.join(LIBDIR, "libtgs_raster.so")
+LIB = os.path.join(LIBDIR, os.environ.get("TGS_LIB_NAME", "libtgs_raster.so"))       # TGS_LIB_NAME: build a variant next to the default one
 SOURCES = ["tgs_forward.hip", "tgs_backward.hip", "tgs_api.hip", "tgs_shcolor.hip", "tgs_knn.hip", "tgs_loss.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]

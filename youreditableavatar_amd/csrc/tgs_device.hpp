@@ -279,6 +279,20 @@ __device__ __forceinline__ uint32_t block_to_quadrant_mask(uint32_t m)
 {
     return ((m & 0x0033u) ? 1u : 0u) | ((m & 0x00CCu) ? 2u : 0u) | ((m & 0x3300u) ? 4u : 0u) | ((m & 0xCC00u) ? 8u : 0u);
 }
+// 16-B loads / stores of data that is touched once per launch (SH rows, gradient rows): the non-temporal hint keeps them from
+// displacing what later kernels gather from L2 (pack lines, counters, records)
+typedef float tgs_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_load4(const float4* p)
+{
+    const tgs_v4f t = __builtin_nontemporal_load(reinterpret_cast<const tgs_v4f*>(p));
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ void nt_store4(float4* p, float4 v)
+{
+    tgs_v4f t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<tgs_v4f*>(p));
+}
+
 // Records staged into LDS by the render kernels carry the conic pre-scaled for one v_exp_f32:
 //   log2(e) * power = (A dx + B dy) dx + (C dy) dy   with A = -0.5 log2e conic.x, B = -log2e conic.y, C = -0.5 log2e conic.z
 // (forward.cu:336 `power = -0.5f * (con.x*d.x*d.x + con.z*d.y*d.y) - con.y*d.x*d.y`, d = mean - pixel as in this code).

@@ -288,7 +288,7 @@ __device__ __forceinline__ void stage_sh_rows(const FwdIn& in, float4* sh_lds)
     const float4* s4 = reinterpret_cast<const float4*>(in.shs);
     const size_t base4 = (size_t)blockIdx.x * PRE_BLOCK * 12, total4 = (size_t)in.P * 12;
 #pragma unroll
-    for (int q = 0; q < 12; q++) { const size_t i = base4 + q * PRE_BLOCK + threadIdx.x; if (i < total4) { typedef float v4f __attribute__((ext_vector_type(4))); const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(&s4[i])); sh_lds[q * PRE_BLOCK + threadIdx.x] = make_float4(t.x, t.y, t.z, t.w); } }
+    for (int q = 0; q < 12; q++) { const size_t i = base4 + q * PRE_BLOCK + threadIdx.x; if (i < total4) sh_lds[q * PRE_BLOCK + threadIdx.x] = nt_load4(&s4[i]); }
     __syncthreads();
 }
 

@@ -16,7 +16,7 @@ import torch
 
 from .. import build as _build
 
-_LIB_PATH = _build.LIB
+_LIB_PATH = os.environ.get("TGS_LIBRARY") or _build.LIB       # TGS_LIBRARY: another build of the same ABI (A/B measurements on one box)
 
 
 def _load() -> C.CDLL:
