@@ -36,8 +36,8 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--views-per-gpu", type=int, default=8, help="frames each GPU renders per step (64-view batch / 8 GPUs)")
     ap.add_argument("--config", type=int, default=3, help="BASELINE.json config index (1-based); 3 = 500k/1080p/SH3")
     ap.add_argument("--mode", default="sh", choices=["sh", "precomp"])
