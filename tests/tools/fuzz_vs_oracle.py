@@ -18,5 +18,18 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 24):
         print(it, P, W, H, D, sm, f"R={mine['num_rendered']}/{ref['num_rendered']}", "ok", {k: f"{v:.1e}" for k, v in rep.items() if k in ("color", "lists_equal", "instances_dropped", "n_contrib_equal")})
     except AssertionError as e:
         bad += 1
-        print(it, P, W, H, D, sm, "FAIL", str(e)[:200])
+        # where does the difference sit?  (one Gaussian / one pixel = a threshold flip or an ill-conditioned splat, not a defect)
+        note = ""
+        try:
+            dT = np.abs(np.asarray(mine["final_T"], np.float64) - np.asarray(ref["final_T"], np.float64).reshape(np.asarray(mine["final_T"]).shape))
+            conc = {}
+            for k in ("dL_dmeans2D", "dL_dconic", "dL_dscales", "dL_drotations"):
+                if k in mine and k in ref:
+                    a = np.asarray(mine[k], np.float64).reshape(P, -1); b = np.asarray(ref[k], np.float64).reshape(P, -1)[:, :a.shape[1]]
+                    d = ((a - b) ** 2).sum(1)
+                    conc[k] = float(d.max() / max(d.sum(), 1e-300))
+            note = f" | pixels with |dT| > 1e-3: {int((dT > 1e-3).sum())}, share of the squared error in ONE Gaussian: " + ", ".join(f"{k} {v:.2f}" for k, v in conc.items())
+        except Exception as ex:
+            note = f" | (no diagnosis: {ex})"
+        print(it, P, W, H, D, sm, "FAIL", str(e)[:120] + note)
 print("failures", bad)
