@@ -183,9 +183,9 @@ __global__ __launch_bounds__(256) void k_render_bwd_det(const ImgState s, const 
 // k_render_bwd (default): same geometry as k_render_fwd -- 16 waves per tile, one wave per 4x4-pixel
 // block, every 16-lane row one 2x2-pixel quadrant walking its own list (back to front), 4 pixels x 4
 // consecutive entries per row and pass.  Every lane evaluates its own (pixel, entry) pair; the 4 lanes
-// of a quad walk the pixel's sequential state (T, accum_rec, last_alpha, last_color of
-// backward.cu:505-531) through the group's 4 entries with DPP quad broadcasts and each lane keeps the
-// state of its own step; a skipped entry is walked as alpha = 0, which leaves T and every later
+// of a quad walk the pixel's sequential state (T and dL_dpixel . accum_rec -- the one scalar of
+// backward.cu:505-531's three accum_rec channels that dL_dalpha needs; bwd_chain4s) through the group's 4
+// entries with DPP quad broadcasts and each lane keeps the state of its own step; a skipped entry is walked as alpha = 0, which leaves T and every later
 // accum_rec value bit-identical to not visiting it
 // (acc' = la*lc + (1-la)*acc, (la,lc) <- (0,c);  next: 0*c + 1*acc' = acc').
 // The nine per-entry sums over the quadrant's 4 pixels are formed with DPP row rotations (18
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
     float bg_dot_dpixel = 0.f;                              // backward.cu:533-535
     bg_dot_dpixel += bg[0] * dpx0; bg_dot_dpixel += bg[1] * dpx1; bg_dot_dpixel += bg[2] * dpx2;
     const float tfinal_bg = T_final * bg_dot_dpixel;
-    float ar0 = 0.f, ar1 = 0.f, ar2 = 0.f;                  // accum_rec with (last_alpha, last_color) already applied
+    float arA = 0.f;                                        // dL_dpixel . accum_rec with (last_alpha, last_color) already applied (bwd_chain4s)
     float vone = 1.0f, vzero = 0.0f;                        // identity elements, pinned to VGPRs for the DPP selects
     asm volatile("" : "+v"(vone), "+v"(vzero));
     const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);   // backward.cu:460-461
@@ -318,15 +318,16 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
                 if (__builtin_amdgcn_ballot_w64(valid) == 0) continue;
                 const float aeff = valid ? alpha : 0.f;     // a skipped entry is walked as alpha = 0, G = 0
                 const float Geff = valid ? G : 0.f;
-                // the quad walks the pixel's state through the group's 4 entries (bwd_chain4, tgs_device.hpp)
-                float Town, inv_om, a0own, a1own, a2own;
-                bwd_chain4(aeff, c0, c1, c2, T, ar0, ar1, ar2, Town, inv_om, a0own, a1own, a2own, vone, vzero);
+                // the quad walks the pixel's state through the group's 4 entries (bwd_chain4s, tgs_device.hpp)
+                float Town, inv_om, Aown;
+                float sdot = c0 * dpx0;
+                sdot += c1 * dpx1; sdot += c2 * dpx2;               // dL_dpixel . colour of this entry
+                bwd_chain4s(aeff, sdot, T, arA, Town, inv_om, Aown, vone, vzero);
                 // this lane's (pixel, entry) terms, backward.cu:507-555 (all zero for a skipped entry).  Everything that is
                 // constant per entry -- opacity, the conic, -0.5, the ndc scale -- is applied once per entry at the flush
                 // (flush_row), so a lane only forms the moments of w = G * dL_dalpha over dx, dy.
                 const float dchannel_dcolor = aeff * Town;
-                float dL_dalpha = (c0 - a0own) * dpx0;
-                dL_dalpha += (c1 - a1own) * dpx1; dL_dalpha += (c2 - a2own) * dpx2;
+                float dL_dalpha = sdot - Aown;                     // sum_ch (c_ch - accum_rec_ch) * dL_dpixel_ch
                 dL_dalpha = dL_dalpha * Town - tfinal_bg * inv_om;      // ... + (-T_final / (1 - alpha)) * bg_dot_dpixel
                 const float w = Geff * dL_dalpha;
                 const float wdx = w * dx, wdy = w * dy;
