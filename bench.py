@@ -242,7 +242,7 @@ def main():
             t_dom = dom_timed if dom_timed else kern[dom]
             traffic = None      # HBM bytes per launch from the PMC passes committed under profiles/ (same workload, collected offline)
             try:
-                pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_m_hbm_counters.json")))
+                pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_n_hbm_counters.json")))
                 if a.config in (3, 4) and a.mode == "sh":
                     traffic = next(v["hbm_bytes_est"] for k, v in pmc["kernels"].items() if k.startswith("tgs::k_" + dom))
             except (OSError, StopIteration, KeyError, ValueError):
