@@ -27,9 +27,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
-
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
@@ -54,15 +51,42 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to smoke-test the N>1 control flow)")
     ap.add_argument("--same-device", action="store_true", help="testing only: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--cpu-frames", type=int, default=3)
+    ap.add_argument("--grad-chunks", type=int, default=4, help="N > 1: the step's per-Gaussian pass runs in this many Gaussian ranges and each range's all-reduce "
+                    "starts behind its launch (1 = one blocking all-reduce behind the whole pass)")
     return ap.parse_args()
+
+
+def launch_ranks(a) -> int:
+    """``python bench.py --gpus N`` (N > 1) outside a launcher: start N ranks -- one process per GPU -- as a CHILD
+    ``python -m torch.distributed.run`` with the same arguments, relay what rank 0 prints, return the child's exit code.
+    Runs before anything in this process imports torch or touches the GPU; never exec()s."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a))
+    global np, torch
+    import numpy as np
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dev_index = 0 if (world == 1 or a.same_device) else local_rank
+    n_devices = torch.cuda.device_count()
+    if dev_index >= n_devices:
+        raise SystemExit(f"bench.py: rank {rank} needs cuda:{dev_index} but this node has {n_devices} GPU(s) (--same-device --backend gloo: "
+                         "control-flow smoke test of N ranks on one GPU)")
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(dev_index)
@@ -160,12 +184,26 @@ def main():
         upstream_view = None
         upstream_batch = (lambda images: l1_ssim_value_and_grad(images, targets)[1]) if a.loss else (lambda images: dL)
 
+    chunks = max(1, a.grad_chunks) if (dist is not None) else 1
+    pending = []
+
+    def reduce_range(first, count):
+        pending.extend(flat.all_reduce_rows(first, count))      # asynchronous, behind the launch that made this range final
+
     def step(s):
         if batch is not None and not a.per_view_calls:
             # three native calls per step (forward of all views, per-pixel backward of all views, one per-Gaussian backward), one Meta read-back;
-            # the one per-Gaussian pass of the step STORES the gradients, so the flat buffer needs no zeroing
-            batch.run_views([settings[v] for v in views_of(s)], means3D, opac, shs, scales, rots, upstream_batch, accumulate=False, upstream_view=upstream_view)
-            flat.all_reduce()
+            # the one per-Gaussian pass of the step STORES the gradients, so the flat buffer needs no zeroing.  N > 1: that pass runs range by
+            # range and every range's all-reduce (RCCL, its own stream) runs beside the pass over the next one.
+            if chunks > 1:
+                batch.run_views([settings[v] for v in views_of(s)], means3D, opac, shs, scales, rots, upstream_batch, accumulate=False, upstream_view=upstream_view,
+                                grad_chunks=chunks, on_chunk=reduce_range)
+                for w in pending:
+                    w.wait()
+                pending.clear()
+            else:
+                batch.run_views([settings[v] for v in views_of(s)], means3D, opac, shs, scales, rots, upstream_batch, accumulate=False, upstream_view=upstream_view)
+                flat.all_reduce()
             return
         flat.zero_()
         if batch is not None:       # the same through autograd, view by view
@@ -270,7 +308,10 @@ def main():
                        "streams": batch.streams if batch is not None else 1,
                        "per_gaussian_backward": "one pass per step (tgs_backward_batch)" if (batch is not None and batch.deferred) else "one pass per view",
                        "frames_rerendered": batch.rejected if batch is not None else 0,
-                       "parallelism": f"view-sharded dp{N}" + (", one RCCL all-reduce of the flat gradient buffer per step" if N > 1 else "")},
+                       "parallelism": f"view-sharded dp{N}: {N} rank(s) x 1 GPU, torch.distributed world size {dist.get_world_size() if dist is not None else 1} "
+                                      f"(backend {a.backend if N > 1 else 'none'}), {n_devices} GPU(s) visible per node"
+                                      + ((f", gradient all-reduce in {chunks} Gaussian ranges overlapped with the per-Gaussian pass" if (chunks > 1 and batch is not None and not a.per_view_calls)
+                                          else ", one all-reduce of the flat gradient buffer per step") if N > 1 else "")},
             "roofline": roof,
             "kernels_ms": {k: round(v, 4) for k, v in kern.items()},      # each kernel alone on the GPU (one-stream pass before the timed region)
             "frame_algorithmic_bytes": int(B_alg),

@@ -245,6 +245,14 @@ int tgs_backward_batch(void* stream, int P, int D, int M, int n_views, const tgs
                        const float* rotations, const float* cov3D_precomp,
                        float* dL_dopacity, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
                        float* dL_dscale, float* dL_drot, int accumulate);
+/* The same pass restricted to Gaussians [first, first + count): first and first + count multiples of 256 (or first + count == P).
+ * A data-parallel step runs it range by range so that the all-reduce of one range's gradients (RCCL, on its own stream) overlaps
+ * the pass over the next range; every output element of the range is final when the call's kernels are. */
+int tgs_backward_batch_range(void* stream, int P, int D, int M, int n_views, const tgs_view_t* views,
+                             const float* means3D, const float* shs, const float* scales, float scale_modifier,
+                             const float* rotations, const float* cov3D_precomp,
+                             float* dL_dopacity, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                             float* dL_dscale, float* dL_drot, int accumulate, int first, int count);
 
 /* ---- "next" row 2: the trainers' photometric loss ----
  * loss = (1 - dssim_factor) * l1_loss(img, gt) + dssim_factor * (1 - ssim(img, gt)), window 11, sigma 1.5, zero padding

@@ -1,0 +1,126 @@
+"""GPU: the N > 1 control flow on ONE device -- two ranks over gloo that both use cuda:0 (the 1-GPU box has no second GPU
+for RCCL; the collective calls, their order and the sharding are the ones the 8-GPU run makes).
+
+* bench.py --gpus 2 starts two ranks itself (a child ``torch.distributed.run``) and reports n_gpus 2;
+* sum over the shards of a view-sharded step == the unsharded step ON THE HIP PATH, with the per-Gaussian pass split into
+  Gaussian ranges whose all-reduces start behind each range (SyncFreeBatch.run_views(grad_chunks, on_chunk) +
+  FlatGradients.all_reduce_rows), including a step in which one rank has to render a rejected view again.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+ROOT = util.ROOT
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+@pytest.mark.timeout(900)
+def test_bench_starts_two_ranks(gpu_device):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-device", "--config", "2", "--steps", "2",
+                        "--warmup", "2", "--views-per-gpu", "4", "--no-cpu"], capture_output=True, text=True, timeout=800, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["config"]["frames_per_step"] == 8
+    assert "world size 2" in out["config"]["parallelism"] and "Gaussian ranges" in out["config"]["parallelism"]
+    assert out["value"] > 0 and out["config"]["frames_rerendered"] == 0
+
+
+_WORKER = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["TGS_ROOT"])
+from youreditableavatar_amd import scenes
+from youreditableavatar_amd.multiview import FlatGradients, SyncFreeBatch, shard_views
+from diff_gaussian_rasterization import GaussianRasterizationSettings, _C
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+if world > 1:
+    dist.init_process_group("gloo")
+dev = torch.device("cuda:0")
+P, W, H, D, V = 7000, 208, 144, 2, 6
+cloud = scenes.make_cloud(P, D, seed=77, scale_mult=3.0)
+t = lambda a, rg=False: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev).requires_grad_(rg)
+names = ("means3D", "opacities", "scales", "rotations", "shs")
+L = {n: t(cloud[n], True) for n in names}
+flat = FlatGradients([L[n] for n in names])
+cams = [scenes.orbit_camera(W, H, azimuth_deg=a) for a in np.linspace(0.0, 300.0, V)]
+settings = [GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=c.tanfovx, tanfovy=c.tanfovy, bg=t(c.bg), scale_modifier=1.0,
+                                          viewmatrix=t(c.viewmatrix), projmatrix=t(c.projmatrix), sh_degree=D, campos=t(c.campos), prefiltered=False, debug=False)
+            for c in cams]
+dLs = [t(scenes.upstream_gradient(W, H, seed=300 + v)) for v in range(V)]
+mine = list(shard_views(V, rank, world))
+_C.set_deterministic(True)
+batch = SyncFreeBatch(granule=256, streams=2)
+pending, calls = [], []
+def on_chunk(first, count):
+    calls.append((first, count))
+    pending.extend(flat.all_reduce_rows(first, count))
+res = {}
+for step in range(4):
+    if step == 3 and rank == world - 1:
+        batch.bound = batch.bound // 3          # this rank has to render views again in this step; the other one does not
+    calls.clear()
+    batch.run_views([settings[v] for v in mine], L["means3D"], L["opacities"], L["shs"], L["scales"], L["rotations"], None, accumulate=False,
+                    upstream_view=lambda i, img: dLs[mine[i]], grad_chunks=3, on_chunk=on_chunk)
+    for w in pending:
+        w.wait()
+    pending.clear()
+    torch.cuda.synchronize()
+    res[f"flat{step}"] = flat.flat.cpu().numpy().copy()
+    res[f"calls{step}"] = np.asarray(calls)
+res["rejected"] = np.asarray(batch.rejected)
+np.savez(os.environ["TGS_OUT"] + f".{rank}.npz", **res)
+if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+"""
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_step_on_the_hip_path_equals_unsharded(gpu_device, tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    out = str(tmp_path / "res")
+
+    def launch(world):
+        port = _free_port()
+        procs = []
+        for rank in range(world):
+            env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       TGS_ROOT=ROOT, TGS_OUT=out + f"_w{world}", HSA_ENABLE_IPC_MODE_LEGACY="0")
+            procs.append(subprocess.Popen([sys.executable, str(script)], env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        for p in procs:
+            so, se = p.communicate(timeout=600)
+            assert p.returncode == 0, se[-3000:]
+        return [np.load(out + f"_w{world}.{r}.npz") for r in range(world)]
+
+    one = launch(1)[0]
+    two = launch(2)
+    for step in range(4):
+        want = one[f"flat{step}"]
+        assert np.abs(want).max() > 0
+        for r in range(2):
+            got = two[r][f"flat{step}"]
+            # every rank holds the whole batch's gradient: the same numbers as the unsharded step up to the order of the fp32 sums
+            # (the one-process run adds 6 views in registers, two ranks add 3 + 3 and then the two partial sums)
+            assert util.rel_l2(got, want) <= 2e-6, (step, r)
+        assert np.array_equal(two[0][f"flat{step}"], two[1][f"flat{step}"])
+        # the same ranges in the same order on both ranks (collectives pair up), also when one of them had to render views again
+        assert np.array_equal(two[0][f"calls{step}"], two[1][f"calls{step}"]) and len(two[0][f"calls{step}"]) == 3
+    assert int(two[1]["rejected"]) >= 1 and int(two[0]["rejected"]) == 0

@@ -111,3 +111,53 @@ def test_flat_gradients_are_views():
     assert fg.flat.tolist() == [2.0] * 6 + [0.0, 1.0, 2.0, 3.0]
     assert a.grad.data_ptr() == fg.flat.data_ptr()
     assert fg.all_reduce() is None          # no process group: no-op
+
+
+def _rows_step(rank, world, port, out_q):
+    """every rank fills its flat buffer with rank-dependent values and reduces it range by range (FlatGradients.all_reduce_rows)"""
+    from youreditableavatar_amd import multiview
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    P = 1000
+    params = [torch.zeros(P, 3, requires_grad=True), torch.zeros(P, 1, requires_grad=True), torch.zeros(P, 16, 3, requires_grad=True)]
+    fg = multiview.FlatGradients(params)
+    g = torch.Generator().manual_seed(7 + rank)
+    fg.flat.copy_(torch.randn(fg.flat.numel(), generator=g))
+    mine = fg.flat.clone()
+    works = []
+    for first in range(0, P, 256):                       # ranges of 256 Gaussians, the last one ragged
+        works += fg.all_reduce_rows(first, min(256, P - first))
+    for w in works:
+        w.wait()
+    out_q.put((rank, mine.numpy(), fg.flat.clone().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_all_reduce_by_gaussian_ranges_equals_one_all_reduce():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rows_step, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(2)], key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    total = res[0][1] + res[1][1]
+    for _rank, _mine, reduced in res:
+        assert np.array_equal(reduced, total)           # every element reduced exactly once
+
+
+def test_row_slices_cover_the_flat_buffer_once():
+    from youreditableavatar_amd.multiview import FlatGradients
+    P = 700
+    params = [torch.zeros(P, 3, requires_grad=True), torch.zeros(P, 1, requires_grad=True), torch.zeros(P, 4, 3, requires_grad=True)]
+    fg = FlatGradients(params)
+    for first in range(0, P, 256):
+        for t in fg.row_slices(first, min(256, P - first)):
+            t += 1
+    assert torch.all(fg.flat == 1)
+    assert fg.all_reduce_rows(0, P) == []       # no process group: nothing to wait for

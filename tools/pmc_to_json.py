@@ -1,14 +1,27 @@
-"""FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh -> profiles/<name>_hbm_counters.json (+ the bench lines and rocprof summaries):
-python tools/pmc_to_json.py gpurun_out/r01_j r01_j "state description" """
-import csv, json, collections, shutil, sys, os
+"""Counter passes of tools/profile_round.sh -> profiles/<name>_hbm_counters.json, profiles/<name>_sq_counters.json (+ the bench lines, rocprof
+summaries and the VALU microbenchmark):   python tools/pmc_to_json.py gpurun_out/r02_a r02_a "state description" """
+import csv, json, collections, glob, shutil, sys, os
 O, name, what = sys.argv[1].rstrip("/") + "/", sys.argv[2], sys.argv[3]
 P = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
+
+
+def rows(d):
+    f = glob.glob(O + d + "/**/*counter_collection.csv", recursive=True)
+    return list(csv.DictReader(open(f[0]))) if f else []
+
+
+def kname(r):
+    return r["Kernel_Name"].replace("void ", "").split("(")[0]
+
+
 def load(d, counter):
     agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(O + d + "/pmc_counter_collection.csv")):
+    for r in rows(d):
         if r["Counter_Name"] == counter:
-            agg[r["Kernel_Name"].replace("void ", "").split("(")[0]].append(float(r["Counter_Value"]))
+            agg[kname(r)].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in agg.items()}
+
+
 f, w = load("pmc_fetch", "FETCH_SIZE"), load("pmc_write", "WRITE_SIZE")
 out = {"note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over tools/pmc_workload.py (4 frames forward+backward, cfg3: 500k Gaussians, "
                "1080p, SH3, fused accumulation through the one-view kernels, one stream; " + what + "); KB per launch as reported. FETCH_SIZE under-reports 16-B-per-lane "
@@ -18,9 +31,41 @@ for k in sorted(set(f) | set(w)):
         out["kernels"][k] = {"FETCH_SIZE_KB_per_launch": round(f.get(k, 0.0), 1), "WRITE_SIZE_KB_per_launch": round(w.get(k, 0.0), 1),
                              "hbm_bytes_est": int((2 * f.get(k, 0.0) + w.get(k, 0.0)) * 1024)}
 json.dump(out, open(f"{P}/{name}_hbm_counters.json", "w"), indent=1)
+
+# SQ passes: per kernel, per launch averages + the launch duration seen in the same pass (dispatch timestamps of the counter CSV)
+sq = {"note": "rocprofv3 --kernel-trace --pmc <8 SQ counters> (two passes: pmc_sq, pmc_sq2) over tools/pmc_workload.py (4 frames forward+backward of cfg3 through the "
+              "one-view kernels, one stream: every kernel alone on the GPU; " + what + "). Per launch averages. SQ_INSTS_* count wave-instructions; SQ_WAVE_CYCLES / "
+              "SQ_WAIT_* / SQ_ACTIVE_INST_* / SQ_BUSY_CYCLES count quad-cycles (4 shader cycles) summed over waves (MI355X_MICROARCH.md, cycle constants). "
+              "us_in_pass = average dispatch duration inside the counter pass (profiled passes run at a lower clock). valu_rate_G_per_s = SQ_INSTS_VALU / duration.",
+      "kernels": {}}
+for d in ("pmc_sq", "pmc_sq2"):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    dur = collections.defaultdict(dict)
+    for r in rows(d):
+        k = kname(r)
+        if "tgs" not in k:
+            continue
+        agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        dur[k][r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    for k, cs in agg.items():
+        e = sq["kernels"].setdefault(k, {})
+        for c, v in cs.items():
+            e[c] = round(sum(v) / len(v), 1)
+        e["us_in_pass_" + d] = round(sum(dur[k].values()) / len(dur[k]), 2)
+        e["launches_" + d] = len(dur[k])
+for k, e in sq["kernels"].items():
+    if "SQ_INSTS_VALU" in e and e.get("us_in_pass_pmc_sq"):
+        e["valu_rate_G_per_s"] = round(e["SQ_INSTS_VALU"] / e["us_in_pass_pmc_sq"] / 1e3, 1)
+    if e.get("SQ_WAVE_CYCLES"):
+        e["wait_any_frac_of_wave_cycles"] = round(e.get("SQ_WAIT_ANY", 0.0) / e["SQ_WAVE_CYCLES"], 3)
+json.dump(sq, open(f"{P}/{name}_sq_counters.json", "w"), indent=1)
+
 for src, dst in (("bench_default.json", "bench_default.json"), ("bench_under_rocprof.json", "bench_under_rocprof.json"),
                  ("bench_under_rocprof_one_stream.json", "bench_under_rocprof_one_stream.json"), ("rp4/rp_kernel_stats.csv", "kernel_stats.csv"),
-                 ("rp1/rp_kernel_stats.csv", "kernel_stats_one_stream.csv")):
-    shutil.copy(O + src, f"{P}/{name}_{dst}")
+                 ("rp1/rp_kernel_stats.csv", "kernel_stats_one_stream.csv"), ("valu_issue_rate.txt", "valu_issue_rate.txt")):
+    if os.path.exists(O + src):
+        shutil.copy(O + src, f"{P}/{name}_{dst}")
 for k, v in out["kernels"].items():
+    print(k, v)
+for k, v in sq["kernels"].items():
     print(k, v)

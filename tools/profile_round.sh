@@ -1,7 +1,10 @@
 set -x
-# usage (on the GPU box, via gpurun): bash tools/profile_round.sh [name]  -> gpurun_out/<name>/{bench_default.json, rp4/, rp1/, pmc_fetch/, pmc_write/}
+# usage (on the GPU box, via gpurun): bash tools/profile_round.sh [name]
+#   -> gpurun_out/<name>/{bench_default.json, rp4/, rp1/, pmc_fetch/, pmc_write/, pmc_sq/, pmc_sq2/, valu_issue_rate.txt}
+# Counter passes never share a run with trace domains other than --kernel-trace (MI355X_MICROARCH.md, rocprofv3 PMC slots: 8 SQ counters or
+# FETCH_SIZE (3 TCC slots) or WRITE_SIZE (2) per pass).
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/${1:-r01_j}
+O=$R/gpurun_out/${1:-r02_a}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
@@ -9,5 +12,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/rp4 -o rp -- python3 
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/rp1 -o rp -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu --streams 1 > $O/bench_under_rocprof_one_stream.json 2> $O/rp1.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o pmc -- python3 $R/tools/pmc_workload.py 4 > $O/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o pmc -- python3 $R/tools/pmc_workload.py 4 > $O/pmc_write.log 2>&1
-ls -R $O | head -40
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES --output-format csv -d $O/pmc_sq -o pmc -- python3 $R/tools/pmc_workload.py 4 > $O/pmc_sq.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM TCC_EA0_ATOMIC_sum --output-format csv -d $O/pmc_sq2 -o pmc -- python3 $R/tools/pmc_workload.py 4 > $O/pmc_sq2.log 2>&1
+(cd $R/tools/microbench && ./valu_issue_rate) > $O/valu_issue_rate.txt 2>&1
+ls -R $O | head -60
 tail -c 600 $O/bench_default.json

@@ -428,6 +428,7 @@ static int backward_impl(int accumulate, void* stream, int P, int D, int M, int6
     in.dL_dmean3D = dL_dmean3D; in.dL_dcov3D = dL_dcov3D; in.dL_dsh = dL_dsh; in.dL_dscale = dL_dscale; in.dL_drot = dL_drot;
     in.accumulate = accumulate;
     in.meta = s.meta;
+    in.block0 = 0; in.nblocks = 0;
 
     if (R > 0) {
         STAGE_BEGIN(TGS_STAGE_RENDER_BWD);
@@ -609,11 +610,21 @@ int tgs_backward_batch(void* stream, int P, int D, int M, int n_views, const tgs
                        const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp, float* dL_dopacity,
                        float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int accumulate)
 {
+    return tgs_backward_batch_range(stream, P, D, M, n_views, views, means3D, shs, scales, scale_modifier, rotations, cov3D_precomp, dL_dopacity, dL_dmean3D,
+                                    dL_dcov3D, dL_dsh, dL_dscale, dL_drot, accumulate, 0, P);
+}
+
+int tgs_backward_batch_range(void* stream, int P, int D, int M, int n_views, const tgs_view_t* views, const float* means3D, const float* shs,
+                             const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp, float* dL_dopacity,
+                             float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int accumulate, int first, int count)
+{
     hipStream_t st = (hipStream_t)stream;
     g_err[0] = 0;
     const int debug = 0;
-    if (P == 0 || n_views == 0) return TGS_OK;
+    if (P == 0 || n_views == 0 || count == 0) return TGS_OK;
     if (P < 0 || n_views < 0 || !views) return fail(TGS_ERR_INVALID, "bad sizes");
+    if (first < 0 || count < 0 || first % PRE_BLOCK != 0 || (long long)first + count > P || ((first + count) % PRE_BLOCK != 0 && first + count != P))
+        return fail(TGS_ERR_INVALID, "Gaussian range [%d, %d + %d) must start and end on multiples of %d (or end at P = %d)", first, first, count, PRE_BLOCK, P);
     const bool has_sh = shs != nullptr, has_sr = scales != nullptr && rotations != nullptr;
     if (has_sr == (cov3D_precomp != nullptr)) return fail(TGS_ERR_INVALID, "provide exactly one of (scales, rotations) / cov3D_precomp");
     if (has_sh && (D < 0 || D > 3 || M < (D + 1) * (D + 1))) return fail(TGS_ERR_INVALID, "SH degree %d needs M >= %d (M=%d)", D, (D + 1) * (D + 1), M);
@@ -624,6 +635,7 @@ int tgs_backward_batch(void* stream, int P, int D, int M, int n_views, const tgs
     in.P = P; in.D = D; in.M = M; in.means3D = means3D; in.shs = shs; in.scales = scales; in.rotations = rotations; in.cov3D_precomp = cov3D_precomp;
     in.dL_dopacity = dL_dopacity; in.dL_dmean3D = dL_dmean3D; in.dL_dcov3D = has_sr ? nullptr : dL_dcov3D; in.dL_dsh = dL_dsh;
     in.dL_dscale = has_sr ? dL_dscale : nullptr; in.dL_drot = has_sr ? dL_drot : nullptr;
+    in.block0 = first / PRE_BLOCK; in.nblocks = (int)n_blocks((size_t)count);
     for (int v0 = 0; v0 < n_views; v0 += BATCH_VIEWS) {
         BatchViews bv;
         memset(&bv, 0, sizeof(bv));

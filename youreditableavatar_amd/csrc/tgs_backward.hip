@@ -626,9 +626,9 @@ __device__ __forceinline__ void store_param_grads(const BwdIn& in, int idx, floa
 
 // dL_dsh rows of the workgroup, 48 values per thread in `o48` (M == 16): through LDS so that global memory sees 16 B per lane
 template <typename Row48>
-__device__ __forceinline__ void store_sh_rows_staged(const BwdIn& in, float4* sh_lds, const Row48& o48)
+__device__ __forceinline__ void store_sh_rows_staged(const BwdIn& in, float4* sh_lds, const Row48& o48, uint32_t blk)
 {
-    const size_t base4 = (size_t)blockIdx.x * PRE_BLOCK * 12, total4 = (size_t)in.P * 12;
+    const size_t base4 = (size_t)blk * PRE_BLOCK * 12, total4 = (size_t)in.P * 12;
     __syncthreads();                                       // every thread has consumed its SH row
 #pragma unroll
     for (int q = 0; q < 12; q++) sh_lds[threadIdx.x * 12 + q] = make_float4(o48(4 * q), o48(4 * q + 1), o48(4 * q + 2), o48(4 * q + 3));
@@ -644,9 +644,9 @@ __device__ __forceinline__ void store_sh_rows_staged(const BwdIn& in, float4* sh
         }
     }
 }
-__device__ __forceinline__ void load_sh_rows_staged(const BwdIn& in, float4* sh_lds)
+__device__ __forceinline__ void load_sh_rows_staged(const BwdIn& in, float4* sh_lds, uint32_t blk)
 {
-    const size_t base4 = (size_t)blockIdx.x * PRE_BLOCK * 12, total4 = (size_t)in.P * 12;
+    const size_t base4 = (size_t)blk * PRE_BLOCK * 12, total4 = (size_t)in.P * 12;
     const float4* s4 = reinterpret_cast<const float4*>(in.shs);
 #pragma unroll
     for (int q = 0; q < 12; q++) { const size_t i = base4 + q * PRE_BLOCK + threadIdx.x; if (i < total4) sh_lds[q * PRE_BLOCK + threadIdx.x] = s4[i]; }
@@ -923,10 +923,11 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
 template <bool HAS_SH, bool HAS_SCALE_ROT>
 __global__ __launch_bounds__(PRE_BLOCK, 2) void k_preprocess_bwd_batch(const BwdIn in, const BatchViews views)
 {
-    const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
+    const uint32_t blk = (uint32_t)in.block0 + blockIdx.x;  // a launch may cover a range of Gaussians only (tgs_backward_batch_range)
+    const int idx = (int)(blk * PRE_BLOCK + threadIdx.x);
     __shared__ float4 sh_lds[HAS_SH ? PRE_BLOCK * 12 : 1];
     const bool sh_staged = HAS_SH && in.M == 16;
-    if (sh_staged) load_sh_rows_staged(in, sh_lds);
+    if (sh_staged) load_sh_rows_staged(in, sh_lds, blk);
     const bool in_range = idx < in.P;
     const float* sh_row = sh_staged ? reinterpret_cast<const float*>(&sh_lds[threadIdx.x * 12]) : (HAS_SH ? in.shs + (size_t)(in_range ? idx : 0) * in.M * 3 : nullptr);
     float o48[48];                                         // dL_dsh row accumulated over the views (dead code without SH)
@@ -966,7 +967,7 @@ __global__ __launch_bounds__(PRE_BLOCK, 2) void k_preprocess_bwd_batch(const Bwd
         }
     }
     if (HAS_SH) {
-        if (sh_staged) store_sh_rows_staged(in, sh_lds, [&](int i) { return o48[i]; });
+        if (sh_staged) store_sh_rows_staged(in, sh_lds, [&](int i) { return o48[i]; }, blk);
         else if (in_range) {
             float* dsh = in.dL_dsh + (size_t)idx * in.M * 3;
             for (int i = 0; i < in.M * 3; i++) {
@@ -1019,7 +1020,7 @@ void launch_preprocess_bwd(hipStream_t st, const BwdIn& in, const CamParams& cam
 
 void launch_preprocess_bwd_batch(hipStream_t st, const BwdIn& in, const BatchViews& views)
 {
-    const dim3 grid((unsigned)n_blocks(in.P)), blk(PRE_BLOCK);
+    const dim3 grid((unsigned)(in.nblocks > 0 ? in.nblocks : n_blocks(in.P))), blk(PRE_BLOCK);
     const bool sh = in.shs != nullptr, sr = in.scales != nullptr;
     if (sh && sr) hipLaunchKernelGGL((k_preprocess_bwd_batch<true, true>), grid, blk, 0, st, in, views);
     else if (sh) hipLaunchKernelGGL((k_preprocess_bwd_batch<true, false>), grid, blk, 0, st, in, views);

@@ -636,6 +636,7 @@ struct BwdIn {
     float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot;
     int accumulate;   // 1: parameter gradients (all but dL_dmean2D / dL_dconic) are added to what the buffers hold
     const Meta* meta; // the frame's Meta: a frame rejected by tgs_forward_async contributes nothing
+    int block0, nblocks;   // k_preprocess_bwd_batch only: first PRE_BLOCK-sized block of Gaussians and how many this launch covers (0: all)
 };
 
 // One view of a batch for k_preprocess_bwd_batch: everything that differs between the views (kernel argument)

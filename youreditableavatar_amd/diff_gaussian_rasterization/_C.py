@@ -57,6 +57,8 @@ def _load() -> C.CDLL:
     lib.tgs_backward_render.argtypes = [vp, it, C.c_int64, vp, it, it, vp, vp, vp]
     lib.tgs_backward_batch.restype = it
     lib.tgs_backward_batch.argtypes = [vp, it, it, it, it, vp, vp, vp, vp, fl, vp, vp, vp, vp, vp, vp, vp, vp, it]
+    lib.tgs_backward_batch_range.restype = it
+    lib.tgs_backward_batch_range.argtypes = lib.tgs_backward_batch.argtypes + [it, it]
     lib.tgs_mark_visible.restype = it
     lib.tgs_mark_visible.argtypes = [vp, it, vp, vp, vp, vp]
     lib.tgs_state_field.restype = C.c_int64
@@ -375,11 +377,12 @@ def backward_render_views(stream_handles, P, views, n_views) -> None:
 
 
 def backward_batch_raw(stream, P, D, M, views, n_views, means3D, shs, scales, scale_modifier, rotations, dL_dopacity, dL_dmean3D, dL_dsh, dL_dscale,
-                       dL_drot, accumulate) -> None:
-    """tgs_backward_batch on prepared device pointers (scales/rotations path; ``shs`` None: per-view colours, their gradients go to
-    the views' dL_dcolor)."""
-    r = _lib.tgs_backward_batch(stream, int(P), int(D), int(M), int(n_views), C.cast(views, C.c_void_p), means3D, shs, scales, float(scale_modifier),
-                                rotations, None, dL_dopacity, dL_dmean3D, None, dL_dsh if shs else None, dL_dscale, dL_drot, 1 if accumulate else 0)
+                       dL_drot, accumulate, first: int = 0, count: Optional[int] = None) -> None:
+    """tgs_backward_batch[_range] on prepared device pointers (scales/rotations path; ``shs`` None: per-view colours, their gradients go to
+    the views' dL_dcolor).  ``first`` / ``count``: only Gaussians [first, first + count) (multiples of 256, or ending at P)."""
+    r = _lib.tgs_backward_batch_range(stream, int(P), int(D), int(M), int(n_views), C.cast(views, C.c_void_p), means3D, shs, scales, float(scale_modifier),
+                                      rotations, None, dL_dopacity, dL_dmean3D, None, dL_dsh if shs else None, dL_dscale, dL_drot, 1 if accumulate else 0,
+                                      int(first), int(P - first if count is None else count))
     if r < 0:
         raise _err(int(r))
 

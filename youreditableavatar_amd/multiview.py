@@ -58,6 +58,32 @@ class FlatGradients:
             return None
         return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
 
+    def row_slices(self, first: int, count: int) -> List[torch.Tensor]:
+        """The pieces of ``flat`` that hold the gradients of Gaussians [first, first + count): one contiguous slice per parameter
+        (every parameter is [P, ...] row-major, so a range of Gaussians is a range of rows)."""
+        out, off = [], 0
+        for p in self.params:
+            row = p.numel() // max(int(p.shape[0]), 1)
+            out.append(self.flat[off + first * row: off + (first + count) * row])
+            off += p.numel()
+        return out
+
+    def all_reduce_rows(self, first: int, count: int, group=None):
+        """Asynchronous sum over ranks of the gradients of Gaussians [first, first + count) -- one coalesced collective over the
+        parameters' slices (a single RCCL group launch), enqueued behind whatever the current stream holds, so it runs beside the kernels
+        that follow (the per-Gaussian pass over the next range, ``SyncFreeBatch.run_views(grad_chunks=..., on_chunk=...)``).  Returns the
+        handles to ``wait()`` on before the gradients are used (empty without a process group)."""
+        if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+            return []
+        pieces = [t for t in self.row_slices(first, count) if t.numel()]
+        try:
+            with dist._coalescing_manager(group=group, async_ops=True) as cm:
+                for t in pieces:
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            return [cm]
+        except (AttributeError, RuntimeError, ValueError):      # a backend without coalescing: one collective per slice
+            return [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True) for t in pieces]
+
 
 def render_batch_sharded(render_view: Callable[[int], torch.Tensor], upstream: Callable[[int, torch.Tensor], torch.Tensor],
                          num_views: int, grads: FlatGradients, group=None, rank: Optional[int] = None,
@@ -243,7 +269,8 @@ class SyncFreeBatch:
     def run_views(self, settings: Sequence, means3D: torch.Tensor, opacities: torch.Tensor, shs: torch.Tensor, scales: torch.Tensor,
                   rotations: torch.Tensor, upstream_batch: Optional[Callable[[torch.Tensor], torch.Tensor]], accumulate: bool = True,
                   colors_precomp: Optional[torch.Tensor] = None,
-                  upstream_view: Optional[Callable[[int, torch.Tensor], torch.Tensor]] = None) -> torch.Tensor:
+                  upstream_view: Optional[Callable[[int, torch.Tensor], torch.Tensor]] = None, grad_chunks: int = 1,
+                  on_chunk: Optional[Callable[[int, int], None]] = None) -> torch.Tensor:
         """Renders the views described by ``settings`` (GaussianRasterizationSettings, same image size, SH degree and scale
         modifier) of one Gaussian model (leaf parameters with allocated ``.grad``, SH colours, scales + rotations), calls
         ``upstream_batch(images[V,3,H,W]) -> dL/d images`` ([V,3,H,W], or [3,H,W] for all views) ONCE, and adds the
@@ -259,7 +286,12 @@ class SyncFreeBatch:
 
         ``colors_precomp`` [V,P,3] (float32, with ``shs=None``): the reference's training mode -- colours evaluated by the caller
         per view (``compute_color_in_rasterizer=False``, tetgs_model.py:524-537; e.g. ``sh_color.points_rgb``); their
-        gradients come back in ``self.color_grads`` [V,P,3] for the caller's ``colors.backward(batch.color_grads)``."""
+        gradients come back in ``self.color_grads`` [V,P,3] for the caller's ``colors.backward(batch.color_grads)``.
+
+        ``grad_chunks`` / ``on_chunk(first, count)``: the step's one per-Gaussian pass runs as ``grad_chunks`` launches over consecutive
+        ranges of Gaussians, and ``on_chunk`` is called right behind each launch (on the calling stream) -- the parameter gradients of
+        Gaussians [first, first + count) are final once that launch is: a data-parallel step starts their all-reduce there
+        (``FlatGradients.all_reduce_rows``) while the next range is still being computed."""
         from .diff_gaussian_rasterization import _C
         V = len(settings)
         rs0 = settings[0]
@@ -285,6 +317,9 @@ class SyncFreeBatch:
         M = 0 if precomp else int(shs.size(1))
         cap = self.capacity()
         dev = means3D.device
+        n_chunks = max(1, min(int(grad_chunks), (P + 255) // 256))
+        per = ((P + n_chunks - 1) // n_chunks + 255) // 256 * 256
+        ranges = [(first, min(per, P - first)) for first in range(0, P, per)]      # the same on every rank: multiples of 256 Gaussians
 
         def per_view_fallback(idx: Sequence[int], dL):
             # synchronous forward + in-place backward through the general path (first batch, rejected views, cooldown)
@@ -331,6 +366,8 @@ class SyncFreeBatch:
             if self._cooldown > 0:
                 self._cooldown -= 1
             self.bound = seen if self.bound is None else max(seen, int(self.bound * 0.95))
+            for first, count in (ranges if on_chunk is not None else []):
+                on_chunk(first, count)
             return images
 
         # ---- pooled state: one tensor per kind for all views, reused from step to step
@@ -429,26 +466,38 @@ class SyncFreeBatch:
                 self._keep = dLs                                 # (alive until the next batch)
             _C.backward_render_views([st.cuda_stream for st in ren_lanes] if upstream_view is not None else handles, P, arr, V)
             join()
-            _C.backward_batch_raw(main.cuda_stream, P, D, M, arr, V, means3D.data_ptr(), None if precomp else shs.data_ptr(), scales.data_ptr(),
-                                  rs0.scale_modifier, rotations.data_ptr(), opacities.grad.data_ptr(), means3D.grad.data_ptr(),
-                                  None if precomp else shs.grad.data_ptr(), scales.grad.data_ptr(), rotations.grad.data_ptr(), accumulate)
+            def verdict():
+                """waits for the Meta records (the one host wait of the batch: they left right behind the forwards) -> (views to render again, largest count)"""
+                for ev in ready:
+                    ev.synchronize()
+                seen, redo = 0, []
+                for v in range(V):
+                    R, flags, _longest, n_overflow = _C.decode_meta_full(pool["host"][v])
+                    if n_overflow > 0 and (flags & _C.FRAME_REJECTED):
+                        self._cooldown = 16
+                    if flags & _C.FRAME_PREFILTERED:
+                        raise RuntimeError("Point is filtered although prefiltered is set. This shouldn't happen!")
+                    if flags & _C.FRAME_REJECTED:
+                        redo.append(v)
+                    seen = max(seen, R)
+                return redo, seen
+
+            # With on_chunk the verdict is read BEFORE the per-Gaussian pass is enqueued (the GPU still has the per-pixel backwards in its
+            # queues): a range may only be handed out as final when no view has to be rendered again.
+            known = verdict() if on_chunk is not None else None
+            eager = known is not None and not known[0]
+            # the one per-Gaussian pass of the step, range by range: a range's gradients are final behind its launch
+            for first, count in ranges:
+                _C.backward_batch_raw(main.cuda_stream, P, D, M, arr, V, means3D.data_ptr(), None if precomp else shs.data_ptr(), scales.data_ptr(),
+                                      rs0.scale_modifier, rotations.data_ptr(), opacities.grad.data_ptr(), means3D.grad.data_ptr(),
+                                      None if precomp else shs.grad.data_ptr(), scales.grad.data_ptr(), rotations.grad.data_ptr(), accumulate, first, count)
+                if eager:
+                    on_chunk(first, count)
         self.viewspace_grads = pool["g2d"]
         self.color_grads = gcol
-        for ev in ready:
-            ev.synchronize()                                # the one host wait of the batch (long past by now: the GPU is in the backwards)
-        seen = 0
         if self._cooldown > 0:
             self._cooldown -= 1
-        redo = []
-        for v in range(V):
-            R, flags, _longest, n_overflow = _C.decode_meta_full(pool["host"][v])
-            if n_overflow > 0:
-                self._cooldown = 16
-            if flags & _C.FRAME_PREFILTERED:
-                raise RuntimeError("Point is filtered although prefiltered is set. This shouldn't happen!")
-            if flags & _C.FRAME_REJECTED:
-                redo.append(v)
-            seen = max(seen, R)
+        redo, seen = known if known is not None else verdict()
         if redo:
             self.rejected += len(redo)
             states = per_view_fallback(redo, dL)
@@ -458,6 +507,9 @@ class SyncFreeBatch:
             for v in redo:
                 pool["g2d"][v].copy_(per_view_backward(v, states[v], grad_of(dL2, v) if dL2 is not None else check(upstream_view(v, images[v]))))
                 seen = max(seen, states[v][0])
+        if on_chunk is not None and not eager:
+            for first, count in ranges:     # the same calls in the same order as on a rank that had nothing to render again (collectives must pair up)
+                on_chunk(first, count)
         self.bound = max(seen, int(self.bound * 0.95))
         return images
 
