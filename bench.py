@@ -106,7 +106,7 @@ def main():
 
     cfg = dict(scenes.CONFIGS[a.config])
     P, W, H, D = cfg["P"], cfg["width"], cfg["height"], cfg["sh_degree"]
-    cloud = scenes.make_cloud(P, D, cfg["seed"], tiny_fraction=cfg.get("tiny_fraction", 0.0), n_oversized=cfg.get("n_oversized", 0))
+    cloud = scenes.config_cloud(a.config)
     dL_np = scenes.upstream_gradient(W, H, seed=cfg["seed"] + 1000)
     V = a.views
     cams = [scenes.orbit_camera(W, H, azimuth_deg=k * 360.0 / V) for k in range(V)]

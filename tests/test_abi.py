@@ -129,3 +129,36 @@ def test_argument_validation_needs_no_gpu():
     lib.tgs_l1_ssim_workspace_bytes.restype = sz
     lib.tgs_l1_ssim_workspace_bytes.argtypes = [it, it, it]
     assert lib.tgs_l1_ssim_workspace_bytes(3, 1080, 1920) >= 3 * 3 * 1080 * 1920 * 4 and lib.tgs_l1_ssim_workspace_bytes(0, 8, 8) == 0
+
+
+def test_compiled_extension_module_exports_the_reference_names():
+    """The reference's `_C` is a compiled pybind module with three functions (ext.cpp:15-19); so is ours: built by plain g++ from
+    csrc/tgs_torch_ext.cpp, linked against libtgs_raster.so (the C ABI does the work) and torch, and what `_C` hands out."""
+    import inspect
+    from youreditableavatar_amd import build
+    path = build.build_torch_ext()
+    assert os.path.basename(path).startswith("_Cext") and path.endswith(".so")
+    out = subprocess.run(["ldd", path], capture_output=True, text=True).stdout
+    assert "libtgs_raster.so" in out and "libtorch" in out and "tgs_oracle" not in out
+    from diff_gaussian_rasterization import _C
+    for name in ("rasterize_gaussians", "rasterize_gaussians_backward", "mark_visible"):
+        fn = getattr(_C, name)
+        assert inspect.isbuiltin(fn) and fn is getattr(_C._ext, name), f"_C.{name} must be the compiled function"
+    doc = _C.rasterize_gaussians.__doc__
+    for arg in ("background", "means3D", "colors", "opacity", "scales", "rotations", "scale_modifier", "cov3D_precomp", "viewmatrix", "projmatrix", "tan_fovx",
+                "tan_fovy", "image_height", "image_width", "sh", "degree", "campos", "prefiltered", "debug"):
+        assert arg in doc                      # positional order of rasterize_points.h:18-38
+    src = open(os.path.join(ROOT, "youreditableavatar_amd", "csrc", "tgs_torch_ext.cpp")).read()
+    assert "__global__" not in src and "hipLaunchKernel" not in src      # glue only: no kernel outside the C-ABI library
+
+
+def test_compiled_extension_rejects_cpu_tensors_loudly():
+    import torch
+    from diff_gaussian_rasterization import _C
+    z = torch.zeros(3)
+    with pytest.raises(RuntimeError, match="means3D must have dimensions"):
+        _C.rasterize_gaussians(z, z, z, z, z, z, 1.0, z, z, z, 1.0, 1.0, 4, 4, z, 0, z, False, False)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        _C.rasterize_gaussians(z, torch.zeros(5, 3), z, z, z, z, 1.0, z, z, z, 1.0, 1.0, 4, 4, z, 0, z, False, False)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        _C.mark_visible(torch.zeros(5, 3), torch.eye(4), torch.eye(4))

@@ -165,6 +165,7 @@ def test_baseline_config_full_size_vs_oracle(cfg, gpu_device):
     mine = util.hip_run(inp, dL)
     ref = util.oracle_run(inp, dL)
     rep = util.compare(mine, ref)
+    util.record_parity(f"cfg{cfg}", rep, extra=dict(num_rendered=int(mine["num_rendered"]), num_rendered_reference=int(ref["num_rendered"])))
     print(cfg, {k: f"{v:.2e}" for k, v in rep.items()})
 
 
@@ -187,9 +188,12 @@ def test_large_splats_full_size_vs_oracle(scale_mult, gpu_device):
     print(scale_mult, mine["num_rendered"], ref["num_rendered"], {k: f"{v:.2e}" for k, v in rep.items() if k in ("color", "instances_dropped", "n_contrib_equal", "dL_dmeans2D")})
 
 
-def test_config5_overflow_stress_properties(gpu_device):
-    """Config 5 (2M Gaussians, 2048x2048, 1 % flat 1e-8 splats, 1000 oversized splats): size-independent properties
-    at full size -- sorted lists, range bookkeeping, n_contrib bounds, finite outputs, linearity of the backward in dL."""
+def test_config5_overflow_stress_vs_oracle(gpu_device):
+    """Config 5 (2M Gaussians, 2048x2048, 1 % flat 1e-8 splats, 1000 oversized splats, 20 000 splats piled into one tile) at FULL size
+    against the CPU oracle -- and what the config is for: a tile list beyond the LDS sort (n_overflow > 0, longest list > 8192),
+    sorted on the device by k_tile_sort's overflow workers.  Plus size-independent properties: sorted lists, range bookkeeping,
+    n_contrib bounds, finite outputs, linearity of the backward in dL."""
+    from diff_gaussian_rasterization import _C
     from youreditableavatar_amd import scenes
     cloud, cams, dL = scenes.config_scene(5)
     inp = util.scene_input(cloud, cams[0])
@@ -197,6 +201,7 @@ def test_config5_overflow_stress_properties(gpu_device):
     P, H, W = 2_000_000, 2048, 2048
     rg = a["ranges"].astype(np.int64)
     lens = rg[:, 1] - rg[:, 0]
+    assert lens.max() > 8192 and int((lens > 8192).sum()) >= 1                              # the overflow sort really ran
     assert lens.sum() == a["num_rendered"] == int(a["tiles_touched"].astype(np.int64).sum())
     assert np.all(a["n_contrib"].reshape(H // 16, 16, W // 16, 16).max(axis=(1, 3)).reshape(-1) <= lens)
     # every list is sorted by (depth, index)
@@ -209,6 +214,14 @@ def test_config5_overflow_stress_properties(gpu_device):
     b = util.hip_run(inp, 2.0 * dL, introspect=False)                                      # backward is linear in the upstream gradient
     for k in ("dL_dmeans3D", "dL_dopacity", "dL_dsh"):
         assert util.rel_l2(b[k], 2.0 * a[k]) <= 1e-5, k
+    del b
+    ref = util.oracle_run(inp, dL)                                                         # the full parity bar, lists included
+    rlens = ref["ranges"][:, 1].astype(np.int64) - ref["ranges"][:, 0]
+    assert rlens.max() >= 20_000
+    rep = util.compare(a, ref)
+    util.record_parity("cfg5", rep, extra=dict(longest_list=int(lens.max()), lists_beyond_lds_sort=int((lens > 8192).sum()), num_rendered=int(a["num_rendered"]),
+                                               num_rendered_reference=int(ref["num_rendered"])))
+    print(5, {k: f"{v:.2e}" for k, v in rep.items()})
 
 
 def test_fused_accumulate_equals_autograd_sum(gpu_device):
@@ -292,6 +305,11 @@ def test_sync_free_forward_matches_and_rejects(gpu_device):
             v.fill_(7.0)
         g2d3 = backward(R3, radii3, geom3, binning3, img3, acc)
         assert torch.all(g2d3 == 0) and all(torch.all(v == 7.0) for v in acc.values())
+        # the plain (non-accumulating) backward of a rejected frame writes every output: zeros, never uninitialised memory
+        torch.empty(1 << 22, device=gpu_device).fill_(float("nan"))     # poison what the allocator hands out next
+        outs = _C.rasterize_gaussians_backward(args[0], args[1], radii3, e, args[4], args[5], 1.0, e, args[8], args[9], cam.tanfovx, cam.tanfovy, dL,
+                                               args[14], 3, args[16], geom3, R3, binning3, img3, False)
+        assert len(outs) == 8 and all(torch.all(o == 0) for o in outs)
     finally:
         _C.set_deterministic(False)
 
@@ -516,6 +534,47 @@ def test_run_views_whole_batch_path(streams, group, gpu_device):
     finally:
         _C.set_deterministic(False)
         _C.set_forward_group(1)
+
+
+def test_run_views_with_a_list_beyond_the_lds_sort(gpu_device):
+    """The sync-free batch path on a scene whose longest tile list (> 16k entries) does not fit the LDS sort: the frame is NOT rejected
+    (the overflow is sorted on the device by k_tile_sort's workers, no host-sized launch), nothing is rendered again, no cooldown,
+    and images / accumulated gradients equal the synchronous per-view path -- which in turn is checked against the oracle in
+    tests/test_gpu_parity.py::test_real_overflow_lists_vs_oracle."""
+    from diff_gaussian_rasterization import _C
+    from youreditableavatar_amd import scenes
+    from youreditableavatar_amd.multiview import FlatGradients, SyncFreeBatch, rasterize_accumulate
+    n_blob, P = 20_000, 23_000
+    cloud = scenes.concentrate(scenes.make_cloud(P, 1, seed=91, scale_mult=2.0), n_blob, centre=(0.01, -0.01, 0.0), sigma=0.003)
+    W, H = 208, 144
+    cams = [scenes.orbit_camera(W, H, azimuth_deg=a) for a in (0.0, 95.0, 200.0)]
+    dLs = torch.stack([torch.from_numpy(scenes.upstream_gradient(W, H, seed=60 + i)) for i in range(3)]).to(gpu_device)
+    names = ("means3D", "opacities", "scales", "rotations", "shs")
+    L = _leaves(cloud, gpu_device)
+    flat = FlatGradients([L[n] for n in names])
+    settings = [_settings(c, 1, gpu_device) for c in cams]
+    _C.set_deterministic(True)
+    try:
+        flat.zero_()
+        want_img = []
+        for v in range(3):
+            m2 = torch.zeros(P, 3, device=gpu_device, requires_grad=True)
+            img, _ = rasterize_accumulate(settings[v], means3D=L["means3D"], means2D=m2, opacities=L["opacities"], shs=L["shs"], scales=L["scales"],
+                                          rotations=L["rotations"])
+            img.backward(dLs[v])
+            want_img.append(img.detach().clone())
+        want = flat.flat.clone()
+        batch = SyncFreeBatch(granule=256, streams=2)
+        for rep in range(3):                                # first batch synchronous (learns the bound), then sync-free twice
+            imgs = batch.run_views(settings, L["means3D"], L["opacities"], L["shs"], L["scales"], L["rotations"], lambda images: dLs, accumulate=False)
+            assert all(torch.equal(imgs[v], want_img[v]) for v in range(3)), rep
+            assert util.rel_l2(flat.flat.cpu().numpy(), want.cpu().numpy()) <= 2e-5, rep
+        assert batch.rejected == 0 and batch._cooldown == 0 and batch.capacity() is not None
+        longest = max(_C.decode_meta_full(batch._pool["host"][v])[2] for v in range(3))
+        n_ovf = max(_C.decode_meta_full(batch._pool["host"][v])[3] for v in range(3))
+        assert longest > 16384 and n_ovf >= 1              # the sync-free frames really held an overflow list
+    finally:
+        _C.set_deterministic(False)
 
 
 @pytest.mark.parametrize("streams,split", [(1, False), (3, False), (4, True)])

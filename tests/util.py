@@ -194,6 +194,21 @@ def last_contributor_ids(d: dict) -> np.ndarray:
     return np.where(nc > 0, pl[pos] if len(pl) else -1, -1)
 
 
+def record_parity(name: str, rep: dict, extra: Optional[dict] = None) -> None:
+    """Appends the achieved rel-L2 per tensor of one comparison to gpurun_out/parity.json (merged back from the GPU box; the round's
+    copy is tracked as profiles/parity_rNN.json)."""
+    import json
+    out_dir = os.path.join(os.environ.get("GRAFT_REPO_ROOT", ROOT), "gpurun_out")
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        path = os.path.join(out_dir, "parity.json")
+        data = json.load(open(path)) if os.path.exists(path) else {}
+        data[name] = {k: (float(f"{v:.4g}") if isinstance(v, float) else v) for k, v in {**rep, **(extra or {})}.items()}
+        json.dump(data, open(path, "w"), indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
 def compare(mine: dict, ref: dict, golden_out: Optional[dict] = None, nc_frac: float = 0.999, check_lists: bool = True):
     """Asserts the SURVEY.md section 8d parity bar; returns {tensor: rel_l2} for reporting."""
     H, W = ref["n_contrib"].shape
@@ -234,7 +249,7 @@ def compare(mine: dict, ref: dict, golden_out: Optional[dict] = None, nc_frac: f
             if split and k in NOISY:
                 e2 = rel_l2(a, pg[k]); rep[k + "|own_inputs"] = e2
                 assert e2 <= tol, f"{k} (per-Gaussian half on own inputs) rel-L2 {e2:.3e} > {tol:.1e}"
-                assert e <= 20 * tol, f"{k} rel-L2 {e:.3e} (sanity bound {20 * tol:.1e})"
+                assert e <= 3 * tol, f"{k} rel-L2 {e:.3e} (direct comparison, bound {3 * tol:.1e})"
             else:
                 assert e <= tol, f"{k} rel-L2 {e:.3e} > {tol:.1e}"
             assert np.all(a[~vis] == 0), f"{k}: culled Gaussians must have zero gradient"

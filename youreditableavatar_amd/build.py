@@ -65,5 +65,49 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+EXT_SRC = os.path.join(CSRC, "tgs_torch_ext.cpp")
+EXT_NAME = "_Cext"
+EXT_DIR = os.path.join(HERE, "diff_gaussian_rasterization")
+
+
+def ext_path() -> str:
+    import sysconfig
+    return os.path.join(EXT_DIR, EXT_NAME + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def build_torch_ext(force: bool = False, verbose: bool = False) -> str:
+    """The compiled `_C` glue (csrc/tgs_torch_ext.cpp: torch::Tensor <-> C ABI, pybind11) -- plain g++ against the torch and pybind11
+    headers, linked to libtgs_raster.so (rpath $ORIGIN/../lib) and the torch libraries; host code only.  Replaces the reference's
+    CUDAExtension recipe (setup.py:17-34) without hipify."""
+    lib = build_native(force=force, verbose=verbose)
+    out = ext_path()
+    deps = [EXT_SRC, os.path.join(HERE, "..", "include", "tgs_raster.h")]
+    if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+        return out
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension as ce
+    cxx = os.environ.get("CXX") or shutil.which("g++") or "g++"
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    inc = [f"-I{p}" for p in ce.include_paths()] + [f"-I{sysconfig.get_paths()['include']}", f"-I{rocm}/include"]
+    try:
+        import pybind11
+        inc.append(f"-I{pybind11.get_include()}")
+    except ImportError:
+        pass                                             # torch ships pybind11 headers as well
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", f"-DTORCH_EXTENSION_NAME={EXT_NAME}", "-DTORCH_API_INCLUDE_EXTENSION_H",
+           "-Wno-deprecated-declarations", *inc, EXT_SRC, "-o", out, f"-L{LIBDIR}", f"-l:{os.path.basename(lib)}", f"-L{tlib}", "-ltorch_python", "-ltorch",
+           "-ltorch_cpu", "-ltorch_hip", "-lc10", "-lc10_hip", "-Wl,-rpath,$ORIGIN/../lib", f"-Wl,-rpath,{tlib}"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"building {EXT_NAME} failed:\n{r.stdout}\n{r.stderr}")
+    return out
+
+
 if __name__ == "__main__":
     print(build_native(force="--force" in sys.argv, verbose=True))
+    print(build_torch_ext(force="--force" in sys.argv, verbose=True))

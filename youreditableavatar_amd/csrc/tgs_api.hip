@@ -193,11 +193,16 @@ int tgs_profile_end(double* ms_sum, int64_t* counts)
 }
 const char* tgs_last_error(void) { return g_err; }
 
-// pinned Meta staging + event of the speculative forward, one per host thread
+// pinned Meta staging + event of the speculative forward: one per host thread AND device (an event belongs to the device that was
+// current when it was created; a thread that renders on cuda:0 and then on cuda:1 gets a slot for each)
 struct SpecSlot { Meta* meta; hipEvent_t ready; };
 static SpecSlot* spec_slot()
 {
-    thread_local SpecSlot slot = {nullptr, nullptr};
+    thread_local std::vector<SpecSlot> slots;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return nullptr;
+    if ((size_t)dev >= slots.size()) slots.resize((size_t)dev + 1, SpecSlot{nullptr, nullptr});
+    SpecSlot& slot = slots[(size_t)dev];
     if (!slot.meta) {
         if (hipHostMalloc((void**)&slot.meta, sizeof(Meta), hipHostMallocDefault) != hipSuccess) { slot.meta = nullptr; return nullptr; }
         if (hipEventCreateWithFlags(&slot.ready, hipEventDisableTiming) != hipSuccess) { (void)hipHostFree(slot.meta); slot.meta = nullptr; return nullptr; }

@@ -661,7 +661,20 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
 {
     const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
     if (in.meta && (in.meta->error & META_ERR_CAPACITY)) {              // rejected frame (tgs_forward_async): contributes nothing
-        if (idx < in.P) { in.dL_dmean2D[3 * idx] = 0.f; in.dL_dmean2D[3 * idx + 1] = 0.f; in.dL_dmean2D[3 * idx + 2] = 0.f; }
+        if (idx < in.P) {
+            const size_t j3 = 3 * (size_t)idx;
+            in.dL_dmean2D[j3] = 0.f; in.dL_dmean2D[j3 + 1] = 0.f; in.dL_dmean2D[j3 + 2] = 0.f;
+            if (!in.accumulate) {                                       // tgs_backward promises that every output element is written: zeros
+                reinterpret_cast<float4*>(in.dL_dconic)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+                in.dL_dopacity[idx] = 0.f;
+                if (in.dL_dcolor) { in.dL_dcolor[j3] = 0.f; in.dL_dcolor[j3 + 1] = 0.f; in.dL_dcolor[j3 + 2] = 0.f; }
+                in.dL_dmean3D[j3] = 0.f; in.dL_dmean3D[j3 + 1] = 0.f; in.dL_dmean3D[j3 + 2] = 0.f;
+                if (in.dL_dcov3D) for (int i = 0; i < 6; i++) in.dL_dcov3D[6 * (size_t)idx + i] = 0.f;
+                if (in.dL_dscale) { in.dL_dscale[j3] = 0.f; in.dL_dscale[j3 + 1] = 0.f; in.dL_dscale[j3 + 2] = 0.f; }
+                if (in.dL_drot) reinterpret_cast<float4*>(in.dL_drot)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (HAS_SH && in.dL_dsh) for (int i = 0; i < 3 * in.M; i++) in.dL_dsh[(size_t)idx * in.M * 3 + i] = 0.f;
+            }
+        }
         return;
     }
     const ViewMat V = load_mat(cam.view), PM = load_mat(cam.proj);

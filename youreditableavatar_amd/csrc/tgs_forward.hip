@@ -433,7 +433,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const 
             for (int i = 0; i < SCAN_THREADS / WAVE; i++) m = lds_max[i] > m ? lds_max[i] : m;
             s.meta->max_count = m;
             s.meta->n_overflow = ovf_n;
-            if (ovf_n > 0 && !allow_overflow) atomicOr(&s.meta->error, META_ERR_CAPACITY);
+            (void)allow_overflow;                       // lists beyond the LDS sort are handled on the device (k_tile_sort's overflow workers): no rejection
         }
     }
 }
@@ -595,7 +595,102 @@ __device__ __forceinline__ void sort_tile_lds(unsigned long long* lk, uint32_t t
     }
 }
 
-__global__ __launch_bounds__(1024) void k_tile_sort(const ImgState s, const BinState b, uint32_t sort_cap, uint32_t heavy_blocks, uint32_t mid_blocks)
+// ---- overflow path: lists longer than the LDS sort (sort_cap keys), sorted in global memory by OVF_WORKERS workgroups of the SAME launch ----
+// The reference sorts any R globally (rasterizer_impl.cu:303-308).  Here the rare list that does not fit LDS runs the same all-ascending
+// bitonic network in global memory, LDS for the strides below `cap`: the last OVF_WORKERS workgroups of k_tile_sort's grid walk the
+// network step by step with a grid barrier between steps (a counter in the frame's Meta, zeroed with it).  They read n_overflow on the device
+// and return at once when there is nothing to do, so the sync-free forward needs neither host-sized launches nor a rejection, and a frame
+// with ordinary lists pays nothing.  Visibility between workgroups (other CUs, other XCDs' L2): release fence -> counter -> acquire fence
+// by one lane, workgroup barriers around it (MI355X_MICROARCH.md, correctness boundaries).
+constexpr uint32_t OVF_WORKERS = 128;
+constexpr uint32_t OVF_THREADS = 1024;
+
+__device__ __forceinline__ void ovf_grid_barrier(uint32_t* ctr, uint32_t& phase, uint32_t nwg)
+{
+    __syncthreads();                                        // every wave's stores are issued ...
+    if (threadIdx.x == 0) {
+        __threadfence();                                    // ... and made visible device-wide (release)
+        atomicAdd(ctr, 1u);
+        const uint32_t target = (phase + 1u) * nwg;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(8);
+        __threadfence();                                    // acquire: later loads see the other workgroups' stores
+    }
+    phase++;
+    __syncthreads();
+}
+
+// k_only == 0: full network for k = 2..cap on the aligned block `blk` of cap keys of overflow tile `ot`;
+// k_only  > 0: only the disperse steps j = cap/2..1 of merge size k_only.
+__device__ __forceinline__ void ovf_local(const ImgState& s, const BinState& b, unsigned long long* lk, uint32_t ot, uint32_t blk, uint32_t k_only, uint32_t cap)
+{
+    const uint32_t tile = s.ovf_tiles[ot];
+    const uint2 rg = s.ranges[tile];
+    const uint32_t n = rg.y - rg.x;
+    const uint32_t b0 = blk * cap;
+    if (b0 >= n) return;                                    // (uniform over the workgroup)
+    if (k_only > next_pow2(n)) return;
+    const uint32_t m = min(cap, n - b0);                    // real keys in this block
+    unsigned long long* gk = b.keys + rg.x + b0;
+    for (uint32_t i = threadIdx.x; i < m; i += OVF_THREADS) lk[i] = gk[i];
+    __syncthreads();
+    const uint32_t half = cap >> 1;
+    if (k_only == 0) {
+        for (uint32_t k = 2; k <= cap; k <<= 1) {
+            for (uint32_t t = threadIdx.x; t < half; t += OVF_THREADS) { uint32_t i, l; pair_flip(t, k, i, l); cmp_swap(lk, i, l, m); }
+            __syncthreads();
+            for (uint32_t j = k >> 2; j > 0; j >>= 1) {
+                for (uint32_t t = threadIdx.x; t < half; t += OVF_THREADS) { uint32_t i, l; pair_disperse(t, j, i, l); cmp_swap(lk, i, l, m); }
+                __syncthreads();
+            }
+        }
+    } else {
+        for (uint32_t j = cap >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = threadIdx.x; t < half; t += OVF_THREADS) { uint32_t i, l; pair_disperse(t, j, i, l); cmp_swap(lk, i, l, m); }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < m; i += OVF_THREADS) gk[i] = lk[i];
+    __syncthreads();                                        // lk is reused by the workgroup's next item
+}
+
+// OVF_THREADS comparators of overflow tile `ot`, starting at comparator c0; flip != 0: flip step of merge size k, else disperse step of distance j
+__device__ __forceinline__ void ovf_global(const ImgState& s, const BinState& b, uint32_t ot, uint32_t c0, uint32_t k, uint32_t j, int flip)
+{
+    const uint32_t tile = s.ovf_tiles[ot];
+    const uint2 rg = s.ranges[tile];
+    const uint32_t n = rg.y - rg.x, npad = next_pow2(n);
+    const uint32_t t = c0 + threadIdx.x;
+    if (k > npad || t >= (npad >> 1)) return;
+    uint32_t i, l;
+    if (flip) pair_flip(t, k, i, l); else pair_disperse(t, j, i, l);
+    cmp_swap(b.keys + rg.x, i, l, n);
+}
+
+__device__ __forceinline__ void ovf_worker(const ImgState& s, const BinState& b, unsigned long long* lk, uint32_t w, uint32_t nw, uint32_t cap)
+{
+    const uint32_t n_ovf = s.meta->n_overflow;              // written by k_scan, the same for every worker
+    if (n_ovf == 0) return;
+    const uint32_t npad = next_pow2(s.meta->max_count);     // >= 2 cap: the longest list is longer than cap
+    uint32_t* ctr = &s.meta->pad[0];
+    uint32_t phase = 0;
+    const uint32_t bpt = npad / cap;                        // aligned blocks of cap keys per (padded) list
+    const uint32_t cpt = max(1u, (npad >> 1) / OVF_THREADS); // chunks of OVF_THREADS comparators per list
+    for (uint32_t it = w; it < n_ovf * bpt; it += nw) ovf_local(s, b, lk, it / bpt, it % bpt, 0u, cap);
+    ovf_grid_barrier(ctr, phase, nw);
+    for (uint32_t k = cap * 2; k <= npad; k <<= 1) {
+        for (uint32_t it = w; it < n_ovf * cpt; it += nw) ovf_global(s, b, it / cpt, (it % cpt) * OVF_THREADS, k, 0u, 1);
+        ovf_grid_barrier(ctr, phase, nw);
+        for (uint32_t j = k >> 2; j >= cap; j >>= 1) {
+            for (uint32_t it = w; it < n_ovf * cpt; it += nw) ovf_global(s, b, it / cpt, (it % cpt) * OVF_THREADS, k, j, 0);
+            ovf_grid_barrier(ctr, phase, nw);
+        }
+        for (uint32_t it = w; it < n_ovf * bpt; it += nw) ovf_local(s, b, lk, it / bpt, it % bpt, k, cap);
+        ovf_grid_barrier(ctr, phase, nw);
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_tile_sort(const ImgState s, const BinState b, uint32_t sort_cap, uint32_t heavy_blocks, uint32_t mid_blocks,
+                                                    uint32_t small_blocks, uint32_t ovf_blocks)
 {
     extern __shared__ unsigned long long lk[];
     __shared__ uint32_t grp_npad[4];
@@ -603,6 +698,10 @@ __global__ __launch_bounds__(1024) void k_tile_sort(const ImgState s, const BinS
     const uint32_t n_nonempty = s.meta->n_nonempty;
     const uint32_t n_heavy = min(s.meta->n_heavy, n_nonempty), n_mid = min(max(s.meta->n_mid, n_heavy), n_nonempty);
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (blockIdx.x >= heavy_blocks + mid_blocks + small_blocks) {          // the grid's tail: workers of the lists beyond the LDS sort
+        ovf_worker(s, b, lk, blockIdx.x - (heavy_blocks + mid_blocks + small_blocks), ovf_blocks, sort_cap);
+        return;
+    }
     if (blockIdx.x < heavy_blocks) {
         const uint32_t t = blockIdx.x;
         if (t >= n_heavy) return;
@@ -653,55 +752,6 @@ __global__ __launch_bounds__(256) void k_finalize(const GeomState g, const ImgSt
         if (s.ranges[mid].x <= p) lo = mid; else hi = mid - 1;
     }
     finalize_entry(b.keys[p], p, lo, gx, g, b);
-}
-
-// ---- overflow path: lists longer than SORT_LDS_CAP, sorted in global memory by many workgroups ----
-// grid = (ceil(npad_max / cap), n_overflow); cap = power of two <= SORT_LDS_CAP (the LDS block of keys)
-__global__ __launch_bounds__(256) void k_ovf_local(const ImgState s, const BinState b, uint32_t k_only, uint32_t cap)
-{
-    // k_only == 0: full network for k = 2..cap on each aligned block of cap keys;
-    // k_only  > 0: only the disperse steps j = cap/2..1 of merge size k_only.
-    extern __shared__ unsigned long long lk[];
-    const uint32_t tile = s.ovf_tiles[blockIdx.y];
-    const uint2 rg = s.ranges[tile];
-    const uint32_t n = rg.y - rg.x;
-    const uint32_t b0 = blockIdx.x * cap;
-    if (b0 >= n) return;
-    if (k_only > next_pow2(n)) return;
-    const uint32_t m = min(cap, n - b0);                   // real keys in this block
-    unsigned long long* gk = b.keys + rg.x + b0;
-    for (uint32_t i = threadIdx.x; i < m; i += 256) lk[i] = gk[i];
-    __syncthreads();
-    const uint32_t half = cap >> 1;
-    if (k_only == 0) {
-        for (uint32_t k = 2; k <= cap; k <<= 1) {
-            for (uint32_t t = threadIdx.x; t < half; t += 256) { uint32_t i, l; pair_flip(t, k, i, l); cmp_swap(lk, i, l, m); }
-            __syncthreads();
-            for (uint32_t j = k >> 2; j > 0; j >>= 1) {
-                for (uint32_t t = threadIdx.x; t < half; t += 256) { uint32_t i, l; pair_disperse(t, j, i, l); cmp_swap(lk, i, l, m); }
-                __syncthreads();
-            }
-        }
-    } else {
-        for (uint32_t j = cap >> 1; j > 0; j >>= 1) {
-            for (uint32_t t = threadIdx.x; t < half; t += 256) { uint32_t i, l; pair_disperse(t, j, i, l); cmp_swap(lk, i, l, m); }
-            __syncthreads();
-        }
-    }
-    for (uint32_t i = threadIdx.x; i < m; i += 256) gk[i] = lk[i];
-}
-
-// one comparator per thread; flip != 0: flip step of merge size k, else disperse step of distance j
-__global__ __launch_bounds__(256) void k_ovf_global(const ImgState s, const BinState b, uint32_t k, uint32_t j, int flip)
-{
-    const uint32_t tile = s.ovf_tiles[blockIdx.y];
-    const uint2 rg = s.ranges[tile];
-    const uint32_t n = rg.y - rg.x, npad = next_pow2(n);
-    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    if (k > npad || t >= (npad >> 1)) return;
-    uint32_t i, l;
-    if (flip) pair_flip(t, k, i, l); else pair_disperse(t, j, i, l);
-    cmp_swap(b.keys + rg.x, i, l, n);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -953,20 +1003,13 @@ void launch_tile_sort(hipStream_t st, const GeomState& g, const ImgState& s, con
         if (heavy > 0) bytes = lds;
         if (mid_blocks > 0 && bytes < 4 * 1024 * 8) bytes = 4 * 1024 * 8;
         if (small_blocks > 0 && bytes < 16 * SORT_CHUNK * 8) bytes = 16 * SORT_CHUNK * 8;
-        if (heavy + mid_blocks + small_blocks > 0)
-            hipLaunchKernelGGL(k_tile_sort, dim3(heavy + mid_blocks + small_blocks), dim3(1024), bytes, st, s, b, sort_cap, heavy, mid_blocks);
-    }
-    if (m && m->n_overflow > 0) {
-        // lists longer than sort_cap: sorted in global memory by many workgroups, LDS for strides < sort_cap
-        const uint32_t npad = host_next_pow2(max_count);
-        const dim3 lgrid((npad + sort_cap - 1) / sort_cap, m->n_overflow), ggrid((npad / 2 + 255) / 256, m->n_overflow);
-        const size_t ldsb = (size_t)sort_cap * 8;
-        hipLaunchKernelGGL(k_ovf_local, lgrid, dim3(256), ldsb, st, s, b, 0u, sort_cap);
-        for (uint32_t k = sort_cap * 2; k <= npad; k <<= 1) {
-            hipLaunchKernelGGL(k_ovf_global, ggrid, dim3(256), 0, st, s, b, k, 0u, 1);
-            for (uint32_t j = k >> 2; j >= sort_cap; j >>= 1) hipLaunchKernelGGL(k_ovf_global, ggrid, dim3(256), 0, st, s, b, k, j, 0);
-            hipLaunchKernelGGL(k_ovf_local, lgrid, dim3(256), ldsb, st, s, b, k, sort_cap);
-        }
+        // workers for lists longer than sort_cap: none when the host knows there is no such list, otherwise (and always without the
+        // read-back) OVF_WORKERS workgroups at the end of the grid -- they return at once when Meta says n_overflow == 0
+        const uint32_t ovf_blocks = (m && m->n_overflow == 0) ? 0u : OVF_WORKERS;
+        if (ovf_blocks > 0 && bytes < (size_t)sort_cap * 8) bytes = (size_t)sort_cap * 8;
+        if (heavy + mid_blocks + small_blocks + ovf_blocks > 0)
+            hipLaunchKernelGGL(k_tile_sort, dim3(heavy + mid_blocks + small_blocks + ovf_blocks), dim3(1024), bytes, st, s, b, sort_cap, heavy, mid_blocks,
+                               small_blocks, ovf_blocks);
     }
     if (r_bound > 0) hipLaunchKernelGGL(k_finalize, dim3((unsigned)((r_bound + 255) / 256)), dim3(256), 0, st, g, s, b, gx, T);
 }

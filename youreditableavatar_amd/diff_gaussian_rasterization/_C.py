@@ -1,10 +1,12 @@
-"""``_C`` -- the native-extension surface of the reference package, served by libtgs_raster.so.
+"""``_C`` -- the native-extension surface of the reference package.
 
-Mirrors the three pybind11 exports of the reference (diff-gaussian-rasterization/ext.cpp:15-19,
-signatures rasterize_points.h:18-67) with identical positional arguments and return tuples, but is
-a thin ctypes binding over the C ABI in include/tgs_raster.h: torch supplies device memory and the
-current HIP stream, nothing else.  There is NO CPU fallback -- if the HIP library cannot be loaded,
-importing this module raises, and tensors that are not on a HIP device are rejected.
+The three pybind11 exports of the reference (diff-gaussian-rasterization/ext.cpp:15-19, signatures
+rasterize_points.h:18-67) -- ``rasterize_gaussians``, ``rasterize_gaussians_backward``, ``mark_visible`` -- are served by the COMPILED
+module ``_Cext`` (csrc/tgs_torch_ext.cpp: pybind11 + torch::Tensor glue over the C ABI of include/tgs_raster.h, built by plain g++),
+with identical positional arguments and return tuples; this file loads it and fails loudly when it (or libtgs_raster.so) cannot be
+built or loaded.  The batch / introspection / test entry points that have no counterpart in the reference are thin ctypes bindings of the
+same C ABI.  Torch supplies device memory and the current HIP stream, nothing else.  There is NO CPU fallback: tensors that are not on a
+HIP device are rejected.
 """
 from __future__ import annotations
 
@@ -20,13 +22,14 @@ _LIB_PATH = os.environ.get("TGS_LIBRARY") or _build.LIB       # TGS_LIBRARY: ano
 
 
 def _load() -> C.CDLL:
-    if not os.path.exists(_LIB_PATH):
+    if "TGS_LIBRARY" not in os.environ:
         try:
-            _build.build_native()
+            _build.build_native()       # no-op when the library is newer than csrc/*.hip and tgs_raster.h: never run stale kernels
         except Exception as e:  # loud: no silent fallback
-            raise ImportError(f"libtgs_raster.so is missing and could not be built ({e}); run "
-                              f"`python -c 'import __graft_entry__ as g; g.build()'` on a ROCm machine") from e
-    lib = C.CDLL(_LIB_PATH)
+            if not os.path.exists(_LIB_PATH):
+                raise ImportError(f"libtgs_raster.so is missing and could not be built ({e}); run "
+                                  f"`python -c 'import __graft_entry__ as g; g.build()'` on a ROCm machine") from e
+    lib = C.CDLL(_LIB_PATH, mode=C.RTLD_GLOBAL)        # the compiled _Cext resolves its tgs_* symbols against this very library
     vp, fl, it = C.c_void_p, C.c_float, C.c_int
     lib.tgs_abi_version.restype = it
     if lib.tgs_abi_version() != 1:
@@ -83,6 +86,24 @@ def _load() -> C.CDLL:
 
 
 _lib = _load()
+
+
+def _load_ext():
+    """The compiled glue module.  Built on demand (g++, ~40 s) when missing or older than its source; an ImportError otherwise."""
+    import importlib
+    try:
+        _build.build_torch_ext()
+    except Exception as e:
+        if not os.path.exists(_build.ext_path()):
+            raise ImportError(f"the compiled _C extension ({_build.EXT_NAME}) is missing and could not be built ({e}); run "
+                              f"`python -c 'import __graft_entry__ as g; g.build()'`") from e
+    ext = importlib.import_module(__package__ + "." + _build.EXT_NAME)
+    if ext.abi_version() != 1:
+        raise ImportError("compiled _C extension: ABI version mismatch")
+    return ext
+
+
+_ext = _load_ext()
 STAGES = ("preprocess_fwd", "scan", "scatter", "tile_sort", "render_fwd", "render_bwd", "preprocess_bwd")
 
 
@@ -168,11 +189,12 @@ def _require_gpu(means3D: torch.Tensor) -> torch.device:
     return means3D.device
 
 
-def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
-                        viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                        prefiltered, debug, r_capacity: Optional[int] = None, r_guess: Optional[int] = None
-                        ) -> Tuple[int, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
-    """RasterizeGaussiansCUDA (rasterize_points.cu:35-115).
+def _rasterize_gaussians_ctypes(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                                viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+                                prefiltered, debug, r_capacity: Optional[int] = None, r_guess: Optional[int] = None
+                                ) -> Tuple[int, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """RasterizeGaussiansCUDA (rasterize_points.cu:35-115) over ctypes -- kept for A/B measurements of the host cost
+    (``TGS_CTYPES_GLUE=1``); the module-level ``rasterize_gaussians`` is the compiled one (csrc/tgs_torch_ext.cpp).
 
     ``r_capacity`` (extension, tgs_forward_async): render without the host read-back of num_rendered; the binning
     buffer holds ``r_capacity`` instances and that number is returned in place of num_rendered.  Check the frame with
@@ -253,10 +275,10 @@ def frame_status(image_buffer: torch.Tensor) -> Tuple[int, int]:
     return int(R.value), int(fl.value)
 
 
-def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
-                                 viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos,
-                                 geomBuffer, R, binningBuffer, imageBuffer, debug, _with_conic=False):
-    """RasterizeGaussiansBackwardCUDA (rasterize_points.cu:117-196); return order of :195.
+def _rasterize_gaussians_backward_ctypes(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
+                                         viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos,
+                                         geomBuffer, R, binningBuffer, imageBuffer, debug, _with_conic=False):
+    """RasterizeGaussiansBackwardCUDA (rasterize_points.cu:117-196) over ctypes (see _rasterize_gaussians_ctypes); return order of :195.
     ``_with_conic`` (tests only) appends the scratch tensor dL_dconic[P,2,2]."""
     dev = _require_gpu(means3D)
     P = int(means3D.size(0))
@@ -451,8 +473,8 @@ def rasterize_gaussians_backward_batch(views, means3D, sh, degree, scales, rotat
     return outs
 
 
-def mark_visible(means3D, viewmatrix, projmatrix) -> torch.Tensor:
-    """markVisible (rasterize_points.cu:198-217)."""
+def _mark_visible_ctypes(means3D, viewmatrix, projmatrix) -> torch.Tensor:
+    """markVisible (rasterize_points.cu:198-217) over ctypes."""
     dev = _require_gpu(means3D)
     P = int(means3D.size(0))
     with torch.cuda.device(dev):
@@ -485,3 +507,13 @@ def state_field(name: str, P: int, width: int, height: int, R: int, has_sh: bool
     if r < 0:
         raise _err(int(r))
     return out
+
+
+# The reference's three exports (ext.cpp:15-19): the compiled module's functions, positional signatures of rasterize_points.h:18-67
+# (+ the keyword-only extensions r_capacity / r_guess / _with_conic documented in csrc/tgs_torch_ext.cpp).
+if os.environ.get("TGS_CTYPES_GLUE") == "1":        # A/B of the host cost only
+    rasterize_gaussians, rasterize_gaussians_backward, mark_visible = _rasterize_gaussians_ctypes, _rasterize_gaussians_backward_ctypes, _mark_visible_ctypes
+else:
+    rasterize_gaussians = _ext.rasterize_gaussians
+    rasterize_gaussians_backward = _ext.rasterize_gaussians_backward
+    mark_visible = _ext.mark_visible

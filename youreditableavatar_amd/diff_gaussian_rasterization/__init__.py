@@ -53,7 +53,40 @@ def _call_native(fn, args, debug: bool, dump_name: str, what: str):
 
 
 _SPECULATE = os.environ.get("TGS_SPECULATIVE_FORWARD", "1") != "0"
-_last_count = {}
+
+
+class _Speculation:
+    """Instance-count guesses of the speculative forward (tgs_forward_speculative), per (P, H, W, device).
+
+    The guess is a slowly decaying maximum of the counts seen (trainers sample views in random order -- refine.py:257-266 -- so the last
+    call's count alone misses on every small-to-large transition, and a miss enqueues scatter / sort / render twice) plus 15 % headroom.
+    Three misses in a row switch speculation off for that key for the next 64 calls (e.g. frames that need the host-sized overflow
+    sort, which always miss)."""
+
+    HEADROOM, DECAY, MAX_MISSES, COOLDOWN, GRANULE = 1.15, 0.97, 3, 64, 65536
+
+    def __init__(self):
+        self.state = {}
+
+    def guess(self, key):
+        st = self.state.get(key)
+        if st is None:
+            return None
+        if st[2] > 0:                       # cooling down after repeated misses
+            st[2] -= 1
+            return None
+        return (int(st[0] * self.HEADROOM) + self.GRANULE - 1) // self.GRANULE * self.GRANULE
+
+    def update(self, key, true_count, guess):
+        st = self.state.setdefault(key, [0, 0, 0])            # [bound, consecutive misses, calls left without speculation]
+        st[0] = max(int(true_count), int(st[0] * self.DECAY))
+        if guess is not None:
+            st[1] = st[1] + 1 if true_count > guess else 0
+            if st[1] >= self.MAX_MISSES:
+                st[1], st[2] = 0, self.COOLDOWN
+
+
+_speculation = _Speculation()
 
 
 class _RasterizeGaussians(torch.autograd.Function):
@@ -68,7 +101,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         # enqueues the stages behind the scan: they run against last call's count + headroom (tgs_forward_speculative; a frame that
         # needs more repeats them with the exact sizes).  num_rendered below is what the binning buffer is carved for.
         key = (int(means3D.shape[0]), int(rs.image_height), int(rs.image_width), means3D.device)
-        guess = _last_count.get(key) if _SPECULATE else None
+        guess = _speculation.guess(key) if _SPECULATE else None
         if guess is not None:
             num_rendered, color, radii, geom, binning, img, true_R = _call_native(
                 lambda *a: _C.rasterize_gaussians(*a, r_guess=guess), args, rs.debug, "snapshot_fw.dump", "forward")
@@ -76,7 +109,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             num_rendered, color, radii, geom, binning, img = _call_native(_C.rasterize_gaussians, args, rs.debug, "snapshot_fw.dump", "forward")
             true_R = num_rendered
         if _SPECULATE:
-            _last_count[key] = (int(true_R * 1.15) + 65535) // 65536 * 65536
+            _speculation.update(key, true_R, guess)
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img)

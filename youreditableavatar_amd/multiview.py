@@ -168,14 +168,14 @@ class _RasterizeAccumulate(torch.autograd.Function):
         rs = raster_settings
         from . import diff_gaussian_rasterization as dgr
         key = (int(means3D.shape[0]), int(rs.image_height), int(rs.image_width), means3D.device)
-        guess = dgr._last_count.get(key) if (dgr._SPECULATE and r_capacity is None) else None      # like GaussianRasterizer: read-back off the critical path
+        guess = dgr._speculation.guess(key) if (dgr._SPECULATE and r_capacity is None) else None      # like GaussianRasterizer: read-back off the critical path
         out = _C.rasterize_gaussians(
             rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix, rs.projmatrix,
             rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug,
             r_capacity=r_capacity, r_guess=guess)
         num_rendered, color, radii, geom, binning, img = out[:6]
         if dgr._SPECULATE and r_capacity is None:
-            dgr._last_count[key] = (int((out[6] if guess is not None else num_rendered) * 1.15) + 65535) // 65536 * 65536
+            dgr._speculation.update(key, out[6] if guess is not None else num_rendered, guess)
         ctx.rs, ctx.num_rendered = rs, num_rendered         # sync-free: the binning capacity (what the buffers are carved for)
         ctx.collector = _collector if (r_capacity is not None and colors_precomp.numel() == 0) else None
         ctx.means2D = means2D

@@ -128,6 +128,18 @@ def make_cloud(P: int, sh_degree: int = 3, seed: int = 1234, scale_mult: float =
             "shs": f32(sh), "sh_degree": sh_degree}
 
 
+def concentrate(cloud: Dict[str, np.ndarray], n: int, centre=(0.0, 0.0, 0.0), sigma: float = 0.004, seed: int = 5,
+                opacity=(0.004, 0.02)) -> Dict[str, np.ndarray]:
+    """Moves the first ``n`` Gaussians of ``cloud`` into a blob of standard deviation ``sigma`` around ``centre`` and makes them
+    faint -- thousands of splats whose centres fall into ONE 16x16 tile: a tile list far beyond the LDS sort budget (8192
+    entries), the case the reference's global radix sort handles like any other (rasterizer_impl.cu:303-308)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in cloud.items()}
+    out["means3D"][:n] = (np.asarray(centre, np.float64) + sigma * rng.standard_normal((n, 3))).astype(np.float32)
+    out["opacities"][:n, 0] = rng.uniform(opacity[0], opacity[1], n).astype(np.float32)
+    return out
+
+
 def upstream_gradient(width: int, height: int, seed: int = 99) -> np.ndarray:
     """dL/d out_color ~ N(0,1)/(3HW)."""
     rng = np.random.Generator(np.random.PCG64(seed))
@@ -165,15 +177,25 @@ CONFIGS = {
     2: dict(P=100_000, width=800, height=800, sh_degree=3, views=1, seed=1236),
     3: dict(P=500_000, width=1920, height=1080, sh_degree=3, views=1, seed=1237),
     4: dict(P=500_000, width=1920, height=1080, sh_degree=3, views=64, seed=1238),
+    # "tile-overflow stress": SURVEY.md 8d's 1000 oversized splats (scale x50, ~100 tiles each) put only ~6 extra entries into a tile, so
+    # on their own no list comes near the LDS sort budget; 20 000 faint splats piled into one tile make the config do what it is named for
     5: dict(P=2_000_000, width=2048, height=2048, sh_degree=3, views=8, seed=1239,
-            tiny_fraction=0.01, n_oversized=1000),
+            tiny_fraction=0.01, n_oversized=1000, n_pileup=20_000),
 }
+
+
+def config_cloud(index: int) -> Dict[str, np.ndarray]:
+    """The Gaussian cloud of a BASELINE.json config (bench.py and the tests build the same one)."""
+    c = CONFIGS[index]
+    cloud = make_cloud(c["P"], c["sh_degree"], c["seed"], tiny_fraction=c.get("tiny_fraction", 0.0), n_oversized=c.get("n_oversized", 0))
+    if c.get("n_pileup", 0):
+        cloud = concentrate(cloud, c["n_pileup"], centre=(0.01, -0.01, 0.3), sigma=0.0015, seed=c["seed"] + 7)
+    return cloud
 
 
 def config_scene(index: int):
     """Returns (cloud dict, [Camera per view], upstream gradient) for a BASELINE.json config."""
     c = CONFIGS[index]
-    cloud = make_cloud(c["P"], c["sh_degree"], c["seed"], tiny_fraction=c.get("tiny_fraction", 0.0),
-                       n_oversized=c.get("n_oversized", 0))
+    cloud = config_cloud(index)
     cams = [orbit_camera(c["width"], c["height"], azimuth_deg=k * 360.0 / c["views"]) for k in range(c["views"])]
     return cloud, cams, upstream_gradient(c["width"], c["height"], seed=c["seed"] + 1000)
