@@ -28,6 +28,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# VALU issue peak: 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction (MI355X_MICROARCH.md, cycle constants: v_fma_f32 2 cyc/SIMD)
+VALU_PEAK_GWIPS = 1228.8
+# measured with tools/microbench/valu_issue_rate.hip (profiles/r02_a_valu_issue_rate.txt), 8 waves per SIMD: independent v_fma_f32, and the
+# render loops' mix (6 fma/mul + 1 DPP + 1 transcendental per 8: DPP operations issue at half rate, v_exp_f32 at a quarter)
+VALU_MEASURED_FMA_GWIPS = 955.5
+VALU_MEASURED_MIX_GWIPS = 628.4
+PROFILE_SET = "r02_a"          # profiles/<set>_{hbm,sq}_counters.json: the PMC passes the roofline object quotes (tools/profile_round.sh)
 
 
 def parse():
@@ -51,6 +58,8 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to smoke-test the N>1 control flow)")
     ap.add_argument("--same-device", action="store_true", help="testing only: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--cpu-frames", type=int, default=3)
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads (drop-in API per frame, the trainers' protocol at 2048x2048, grown splats, "
+                    "alive-pair count) that are reported beside the headline at N = 1")
     ap.add_argument("--grad-chunks", type=int, default=4, help="N > 1: the step's per-Gaussian pass runs in this many Gaussian ranges and each range's all-reduce "
                     "starts behind its launch (1 = one blocking all-reduce behind the whole pass)")
     return ap.parse_args()
@@ -277,21 +286,43 @@ def main():
             alg["preprocess_bwd"] = VPG * (36 * Rm + (24 + 1 + 4 + 4 + 4 + 12) * P) + (40 + Cin + 2 * (44 + Cin)) * P
         roof = None
         if dom:
-            t_dom = dom_timed if dom_timed else kern[dom]
-            traffic = None      # HBM bytes per launch from the PMC passes committed under profiles/ (same workload, collected offline)
-            try:
-                pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_n_hbm_counters.json")))
-                if a.config in (3, 4) and a.mode == "sh":
+            # Dominant kernel = most time per step.  Its duration is measured LIVE with HIP events on the launch stream, in the one-stream pass
+            # above where the kernel has the GPU to itself (in the timed region up to `streams` launches share the GPU and stretch each other:
+            # avg_launch_ms_in_timed_region).  What it is priced against depends on what bounds it: the render kernels are bound by vector
+            # instruction issue (SQ counters), so achieved = wave-instructions per launch / duration against the chip's
+            # VALU issue peak; the HBM figures stay beside it.  Instruction counts and HBM traffic per launch are PMC measurements of the same
+            # workload committed under profiles/ (collected offline: counter passes cannot run inside a timed benchmark).
+            prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+            traffic, valu_insts = None, None
+            if a.config in (3, 4) and a.mode == "sh":
+                try:
+                    pmc = json.load(open(os.path.join(prof_dir, PROFILE_SET + "_hbm_counters.json")))
                     traffic = next(v["hbm_bytes_est"] for k, v in pmc["kernels"].items() if k.startswith("tgs::k_" + dom))
-            except (OSError, StopIteration, KeyError, ValueError):
-                traffic = None
-            ach = alg[dom] / (t_dom * 1e-3) / 1e9
-            roof = {"kernel": "k_" + dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "avg_launch_ms": round(t_dom, 4),
-                    "avg_launch_ms_alone": round(kern[dom], 4), "algorithmic_bytes_per_launch": int(alg[dom]),
-                    # in the timed region up to `streams` launches of this kernel share the GPU, which stretches each of them; alone = one-stream pass
-                    "achieved_alone": round(alg[dom] / (kern[dom] * 1e-3) / 1e9, 2), "frac_alone": round(alg[dom] / (kern[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                    "concurrent_streams": batch.streams if batch is not None else 1}
+                    sq = json.load(open(os.path.join(prof_dir, PROFILE_SET + "_sq_counters.json")))
+                    valu_insts = next(v["SQ_INSTS_VALU"] for k, v in sq["kernels"].items() if k.startswith("tgs::k_" + dom))
+                except (OSError, StopIteration, KeyError, ValueError):
+                    pass
+            Rb = sum(Rb_view[v] for s in range(a.steps) for v in views_of(s)) / frames_rank     # instances the timed path really bins
+            alg_b = dict(alg)
+            alg_b["render_fwd"] = 48 * Rb + 20 * Npix
+            alg_b["render_bwd"] = (48 + 4 + 48) * Rb + 20 * Npix          # records + quadrant mask + slot in, one 48-B slab row out; pixels in
+            t_alone = kern[dom]
+            hbm = {"algorithmic_bytes_per_launch": int(alg_b.get(dom, alg[dom])), "achieved_GBps": round(alg_b.get(dom, alg[dom]) / (t_alone * 1e-3) / 1e9, 2),
+                   "frac_of_8TBps": round(alg_b.get(dom, alg[dom]) / (t_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "instances": int(Rb)}
+            if dom in ("render_fwd", "render_bwd") and valu_insts:
+                ach = valu_insts / (t_alone * 1e-3) / 1e9
+                roof = {"kernel": "k_" + dom, "bound": "valu", "achieved": round(ach, 1), "peak": VALU_PEAK_GWIPS, "unit": "G wave-instr/s",
+                        "frac": round(ach / VALU_PEAK_GWIPS, 4), "traffic": traffic,
+                        "avg_launch_ms": round(t_alone, 4), "duration": "kernel alone on the GPU (one-stream pass of this run, HIP events on the launch stream)",
+                        "avg_launch_ms_in_timed_region": round(dom_timed, 4) if dom_timed else None, "concurrent_streams": batch.streams if batch is not None else 1,
+                        "valu_instructions_per_launch": int(valu_insts), "counters": PROFILE_SET + "_sq_counters.json",
+                        "peak_measured_v_fma_f32": VALU_MEASURED_FMA_GWIPS, "peak_measured_render_mix": VALU_MEASURED_MIX_GWIPS,
+                        "frac_of_measured_render_mix": round(ach / VALU_MEASURED_MIX_GWIPS, 4), "hbm": hbm}
+            else:
+                roof = {"kernel": "k_" + dom, "bound": "hbm", "achieved": hbm["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm["frac_of_8TBps"],
+                        "traffic": traffic, "avg_launch_ms": round(t_alone, 4), "duration": "kernel alone on the GPU (one-stream pass of this run, HIP events on the launch stream)",
+                        "avg_launch_ms_in_timed_region": round(dom_timed, 4) if dom_timed else None, "algorithmic_bytes_per_launch": hbm["algorithmic_bytes_per_launch"],
+                        "concurrent_streams": batch.streams if batch is not None else 1}
         k_P = (430 + 3 * Cin) if a.mode == "sh" else 412
         B_alg = k_P * P + 124 * Rm + 40 * Npix
         out = {
@@ -319,11 +350,126 @@ def main():
             "other_rates": {"Minstances/s": round(R_tot / elapsed / 1e6, 2), "Mpixels/s": round(Npix * frames_rank * N / elapsed / 1e6, 2),
                             "MGaussians/s": round(P * frames_rank * N / elapsed / 1e6, 2), "frames/s": round(frames_rank * N / elapsed, 1)},
         }
+        if N == 1 and not a.no_secondary and a.mode == "sh" and batch is not None and not a.per_view_calls:
+            del batch                                        # (its pooled state: ~2 GB)
+            torch.cuda.empty_cache()
+            out["secondary"] = secondary_workloads(a, cloud, dev, D, W, H, out["config"]["ms_per_frame_per_gpu"])
+            out["config"]["dropin_ms_per_frame"] = out["secondary"]["dropin_api"]["ms_per_frame"]
         if N == 1 and not a.no_cpu:
             out["cpu_baseline"] = cpu_baseline(cloud, cams[0], dL_np, a)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def secondary_workloads(a, cloud, dev, D, W, H, headline_ms):
+    """Reported beside the headline, never as it (N = 1, outside the timed region, a few seconds in all):
+
+    * ``dropin_api``: one view per step through the UNCHANGED reference API -- ``GaussianRasterizer(settings)(...)`` + ``image.backward(dL)``, SH
+      colours evaluated in the rasterizer, one read-back of num_rendered per frame taken off the critical path (tgs_forward_speculative) --
+      what a caller that swaps the package and changes nothing else gets per frame (the headline is the 8-view batch API).
+    * ``trainer_protocol``: what the reference's trainers run per optimisation step (tetgs_texture/paint_2dgs.py:159-166, refine_3dgs.py:165-166,
+      tetgs_scene/tetgs_model.py:524-537,605-614, refine.py:245-247): 2048 x 2048, colours from SH OUTSIDE the rasterizer (sh_color.points_rgb,
+      ``colors_precomp``), the L1 + SSIM loss between forward and backward, one random view per step, everything through autograd.
+    * ``grown_splats``: the headline batch path with every splat 4x / 8x larger (most splats on 5..64 tiles).
+    * ``alive_pairs``: (pixel, list entry) pairs of view 0 with alpha >= 1/255 -- what the render kernels actually blend; the fragment metric
+      F = sum n_contrib also counts the entries a pixel walks past."""
+    import math
+    from youreditableavatar_amd import scenes
+    from youreditableavatar_amd.loss import l1_ssim_loss
+    from youreditableavatar_amd.multiview import FlatGradients, SyncFreeBatch
+    from youreditableavatar_amd.sh_color import points_rgb
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _C
+    P = cloud["means3D"].shape[0]
+    g = lambda x, rg=False: torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev).requires_grad_(rg)
+
+    def settings_for(w, h, deg, n):
+        out = []
+        for k in range(n):
+            c = scenes.orbit_camera(w, h, azimuth_deg=(k * 137.5) % 360.0)          # golden-angle sequence: consecutive views far apart, like a shuffled camera list
+            out.append(GaussianRasterizationSettings(image_height=h, image_width=w, tanfovx=c.tanfovx, tanfovy=c.tanfovy, bg=g(c.bg), scale_modifier=1.0,
+                                                     viewmatrix=g(c.viewmatrix), projmatrix=g(c.projmatrix), sh_degree=deg, campos=g(c.campos), prefiltered=False,
+                                                     debug=False))
+        return out
+
+    def timed(fn, n, warm):
+        for i in range(warm):
+            fn(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            fn(warm + i)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    res = {}
+    leaves = {k: g(cloud[k], True) for k in ("means3D", "opacities", "scales", "rotations", "shs")}
+    # ---- the unchanged drop-in API, one view per step
+    S = settings_for(W, H, D, 16)
+    dL = g(scenes.upstream_gradient(W, H, seed=4321))
+
+    def dropin(i):
+        m2 = torch.zeros(P, 3, device=dev, requires_grad=True)
+        img, _radii = GaussianRasterizer(S[i % len(S)])(means3D=leaves["means3D"], means2D=m2, opacities=leaves["opacities"], shs=leaves["shs"],
+                                                        scales=leaves["scales"], rotations=leaves["rotations"])
+        img.backward(dL)
+    res["dropin_api"] = {"ms_per_frame": round(timed(dropin, 60, 20), 4), "what": f"GaussianRasterizer + autograd, one view per step, {W}x{H}, SH degree {D} in the rasterizer",
+                         "vs_headline_batch_path": round(timed(dropin, 20, 0) / headline_ms, 2)}
+    # ---- the trainers' protocol at 2048 x 2048
+    TW = TH = 2048
+    gt = torch.rand(3, TH, TW, device=dev)
+    tp = {}
+    for deg in (0, 3):
+        S2 = settings_for(TW, TH, deg, 16)
+
+        def train_step(i, S2=S2, deg=deg):
+            rs = S2[i % len(S2)]
+            for t in leaves.values():
+                t.grad = None
+            colors = points_rgb(leaves["shs"], deg + 1, positions=leaves["means3D"], camera_centers=rs.campos)
+            m2 = torch.zeros(P, 3, device=dev, requires_grad=True)
+            img, _radii = GaussianRasterizer(rs)(means3D=leaves["means3D"], means2D=m2, opacities=leaves["opacities"], colors_precomp=colors,
+                                                 scales=leaves["scales"], rotations=leaves["rotations"])
+            l1_ssim_loss(img, gt, 0.2).backward()
+        tp[f"sh{deg}"] = round(timed(train_step, 30, 10), 4)
+    res["trainer_protocol"] = {"ms_per_step": tp, "what": f"{P} Gaussians, 2048x2048, one view per step: sh_color.points_rgb -> GaussianRasterizer(colors_precomp) -> "
+                               "l1_ssim_loss -> backward, all through autograd (SH degree 0: the inpainting stage, 16 800 of the reference's ~22 800 rasterizer iterations; 3: refinement)"}
+    del gt
+    # ---- grown splats through the headline path
+    gs = {}
+    for mult in (4.0, 8.0):
+        big = {k: (g(cloud[k] * (mult if k == "scales" else 1.0), True)) for k in ("means3D", "opacities", "scales", "rotations", "shs")}
+        FlatGradients([big[k] for k in ("means3D", "opacities", "scales", "rotations", "shs")])
+        b2 = SyncFreeBatch(streams=a.streams)
+        S3 = settings_for(W, H, D, 8)
+        ms = timed(lambda i: b2.run_views(S3, big["means3D"], big["opacities"], big["shs"], big["scales"], big["rotations"], None, accumulate=False,
+                                          upstream_view=lambda v, image: dL), 6, 3) / len(S3)
+        gs[f"x{int(mult)}"] = {"ms_per_frame": round(ms, 4), "frames_rerendered": b2.rejected}
+        del b2, big
+        torch.cuda.empty_cache()
+    res["grown_splats"] = gs
+    # ---- alive (pixel, entry) pairs of view 0
+    rs = S[0]
+    e = torch.Tensor([])
+    R, _c, _r, geom, binning, img = _C.rasterize_gaussians(rs.bg, leaves["means3D"].detach(), e, leaves["opacities"].detach(), leaves["scales"].detach(),
+                                                          leaves["rotations"].detach(), 1.0, e, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, H, W,
+                                                          leaves["shs"].detach(), D, rs.campos, False, False)
+    f = lambda n: _C.state_field(n, P, W, H, R, True, True, geom, binning, img)
+    pl, rg, m2, co = f("point_list").long(), f("ranges").view(-1, 2).long(), f("means2D").view(-1, 2), f("conic_opacity").view(-1, 4)
+    gx = (W + 15) // 16
+    tile_of = torch.repeat_interleave(torch.arange(rg.shape[0], device=dev), rg[:, 1] - rg[:, 0])
+    px = torch.arange(16, device=dev, dtype=torch.float32)
+    alive_pairs = 0
+    for s0 in range(0, R, 1 << 18):
+        ids, t = pl[s0:s0 + (1 << 18)], tile_of[s0:s0 + (1 << 18)]
+        dx = m2[ids, 0, None, None] - (((t % gx) * 16).float()[:, None, None] + px[None, None, :])
+        dy = m2[ids, 1, None, None] - (((t // gx) * 16).float()[:, None, None] + px[None, :, None])
+        q = co[ids]
+        power = -0.5 * (q[:, 0, None, None] * dx * dx + q[:, 2, None, None] * dy * dy) - q[:, 1, None, None] * dx * dy
+        alive_pairs += int(((power <= 0) & (torch.clamp(q[:, 3, None, None] * torch.exp(power), max=0.99) >= 1.0 / 255.0)).sum())
+    res["alive_pairs"] = {"per_frame_view0": alive_pairs, "G_pairs_per_s_at_headline_rate": round(alive_pairs / (headline_ms * 1e-3) / 1e9, 2),
+                          "what": "(pixel, tile-list entry) pairs with alpha >= 1/255 (forward.cu:340-343) of view 0, termination ignored"}
+    return res
 
 
 def cpu_baseline(cloud, cam, dL_np, a):

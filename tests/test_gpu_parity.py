@@ -31,6 +31,25 @@ def test_golden(name, gpu_device):
     assert np.all(mr[ne][1:, 0] == mr[ne][:-1, 1]) and (not ne.any() or (mr[ne][0, 0] == 0 and mr[ne][-1, 1] == mine["num_rendered"]))
 
 
+@pytest.mark.parametrize("name", util.mid_golden_names())
+def test_mid_size_golden(name, gpu_device):
+    """The HIP path against the mid-size emulated-reference fixtures (20k Gaussians / 256x256; BASELINE config 2 at 800x800): with instance
+    pruning off the integer state is the reference's (num_rendered, tiles_touched, ranges; n_contrib and the per-tile lists up to the
+    near-coincident depths a last-bit difference in view-space z may swap); with the default pruning image and gradients."""
+    from diff_gaussian_rasterization import _C
+    inp, dL, fx = util.load_mid_golden(name)
+    _C.set_instance_pruning(False)
+    try:
+        full = util.hip_run(inp, None)
+    finally:
+        _C.set_instance_pruning(True)
+    rep = util.compare_mid(full, fx, exact_lists=True)
+    mine = util.hip_run(inp, dL)
+    rep.update(util.compare_mid(mine, fx, exact_lists=False))
+    util.record_parity(name, rep)
+    print(name, {k: f"{v:.2e}" for k, v in rep.items()})
+
+
 @pytest.mark.parametrize("P,W,H,deg,mode,cov_mode,scale_mult", [
     (10_000, 256, 256, 0, "sh", "scale_rot", 1.0),       # BASELINE config 1
     (20_000, 320, 200, 3, "sh", "scale_rot", 2.0),

@@ -254,3 +254,81 @@ def compare(mine: dict, ref: dict, golden_out: Optional[dict] = None, nc_frac: f
                 assert e <= tol, f"{k} rel-L2 {e:.3e} > {tol:.1e}"
             assert np.all(a[~vis] == 0), f"{k}: culled Gaussians must have zero gradient"
     return rep
+
+
+# ---- mid-size goldens (tests/golden/m*.npz, oracle/emu_crosscheck/make_mid_goldens.py): recipe + outputs on a seeded subset ----
+def mid_golden_names():
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "m[0-9]*.npz")))
+
+
+def load_mid_golden(name: str):
+    """-> (inp, dL, fixture): the inputs are regenerated from the fixture's recipe by the seeded generators of scenes.py and checked
+    against the stored checksum (a fixture made from other inputs would pin nothing)."""
+    import zlib
+    from youreditableavatar_amd import scenes
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    r = {k[7:]: z[k].item() for k in z.files if k.startswith("recipe_")}
+    cloud = scenes.make_cloud(int(r["P"]), int(r["deg"]), seed=int(r["seed"]), scale_mult=float(r["scale_mult"]))
+    cam = scenes.orbit_camera(int(r["W"]), int(r["H"]), azimuth_deg=float(r["az"]))
+    inp = scene_input(cloud, cam)
+    dL = scenes.upstream_gradient(int(r["W"]), int(r["H"]), seed=int(r["dl_seed"]))
+    c = 0
+    for k in sorted(inp):
+        if isinstance(inp[k], np.ndarray):
+            c = zlib.crc32(np.ascontiguousarray(inp[k]).tobytes(), c)
+    c = zlib.crc32(np.ascontiguousarray(dL).tobytes(), c)
+    assert np.uint32(c) == z["input_crc"], f"{name}: the regenerated inputs are not the ones the fixture was made from"
+    return inp, dL, {k: z[k] for k in z.files}
+
+
+def list_checksums(point_list, ranges) -> np.ndarray:
+    import zlib
+    rg = np.asarray(ranges).reshape(-1, 2)
+    out = np.zeros(len(rg), np.uint32)
+    for t, (a, b) in enumerate(rg):
+        if b > a:
+            out[t] = zlib.crc32(np.ascontiguousarray(point_list[a:b], np.uint32).tobytes())
+    return out
+
+
+def compare_mid(mine: dict, fx: dict, exact_lists: bool, nc_frac: float = 0.999, list_frac: float = 0.99) -> dict:
+    """mine (oracle_run / hip_run output) against a mid-size fixture; exact_lists: the integer state must equal the reference's
+    (the oracle, or the HIP path with instance pruning off), otherwise it must be the pruned subset."""
+    rep = {}
+    idx = fx["subset"]
+    y0, x0, wh, ww = [int(v) for v in fx["window"]]
+    assert np.array_equal(np.asarray(mine["radii"]), fx["out_radii"]), "radii differ"
+    if exact_lists:
+        assert int(mine["num_rendered"]) == int(fx["out_num_rendered"])
+        assert np.array_equal(np.asarray(mine["tiles_touched"]).astype(np.uint32), fx["out_tiles_touched"])
+        assert np.array_equal(np.asarray(mine["ranges"]).reshape(-1, 2).astype(np.uint32), fx["out_ranges"].reshape(-1, 2))
+        rep["n_contrib_equal"] = float((np.asarray(mine["n_contrib"]).astype(np.int64) == fx["out_n_contrib"].astype(np.int64)).mean())
+        assert rep["n_contrib_equal"] >= nc_frac
+        crc = list_checksums(mine["point_list"], mine["ranges"])
+        rep["tile_lists_equal"] = float((crc == fx["out_list_crc"]).mean())
+        assert rep["tile_lists_equal"] >= list_frac
+    else:
+        assert int(mine["num_rendered"]) <= int(fx["out_num_rendered"])
+        assert np.all(np.asarray(mine["tiles_touched"]).astype(np.int64) <= fx["out_tiles_touched"].astype(np.int64))
+    col = np.asarray(mine["color"], np.float64)
+    rep["color_window"] = rel_l2(col[:, y0:y0 + wh, x0:x0 + ww], fx["out_color_window"])
+    assert rep["color_window"] <= REL_TOL
+    assert np.allclose(col.sum(axis=(1, 2)), fx["out_color_sum"], rtol=1e-5) and np.allclose((col * col).sum(axis=(1, 2)), fx["out_color_sumsq"], rtol=1e-5)
+    if "final_T" in mine:
+        assert rel_l2(np.asarray(mine["final_T"])[y0:y0 + wh, x0:x0 + ww], fx["out_final_T_window"]) <= 1e-4
+    vis = fx["out_radii"][idx] > 0
+    for k, tol in (("means2D", 1e-6), ("depths", 1e-6), ("conic_opacity", 1e-4)):
+        if k in mine:
+            assert rel_l2(np.asarray(mine[k])[idx][vis], fx["out_" + k + "_subset"][vis]) <= tol, k
+    for k in GRAD_KEYS + ("dL_dconic",):
+        if k not in mine:
+            continue
+        a, b = np.asarray(mine[k]).reshape(len(fx["out_radii"]), -1)[idx], fx["out_" + k + "_subset"].reshape(len(idx), -1)
+        tol = REL_TOL
+        if k in NOISY:
+            tol = max(tol, 3.0 * rel_l2(fx["out_nofma_" + k + "_subset"].reshape(len(idx), -1), b))
+        e = rel_l2(a, b); rep[k] = e
+        assert e <= tol, f"{k} (subset of {len(idx)} Gaussians) rel-L2 {e:.3e} > {tol:.1e}"
+        n = float(np.linalg.norm(np.asarray(mine[k], np.float64)))
+        assert abs(n - float(fx["out_" + k + "_norm"])) <= 2 * tol * max(float(fx["out_" + k + "_norm"]), 1e-30), f"{k}: full-tensor norm"
+    return rep

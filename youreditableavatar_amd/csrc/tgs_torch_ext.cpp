@@ -7,8 +7,9 @@
 // sits behind the C ABI in libtgs_raster.so, which this module links.  Built by plain g++ against the torch / pybind11
 // headers (youreditableavatar_amd/build.py: no CUDAExtension, no hipify); host code only, there is no kernel in this file.
 #include <torch/extension.h>
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+// torch on ROCm names its HIP devices "cuda": the guard / stream types that accept that device type are the *MasqueradingAsCUDA ones
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 
 #include <stdexcept>
 #include <string>
@@ -66,7 +67,7 @@ py::tuple rasterize_gaussians(const torch::Tensor& background, const torch::Tens
     if (means3D.dim() != 2 || means3D.size(1) != 3) throw std::runtime_error("means3D must have dimensions (num_points, 3)");   // rasterize_points.cu:57-59
     const c10::Device dev = require_gpu(means3D);
     const int P = (int)means3D.size(0), H = image_height, W = image_width, M = sh_coeffs(sh);
-    c10::hip::HIPGuard guard(dev);
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
     const auto f32 = torch::TensorOptions().dtype(torch::kFloat32).device(dev);
     torch::Tensor out_color = torch::empty({3, H, W}, f32);
     torch::Tensor radii = torch::empty({P}, f32.dtype(torch::kInt32));
@@ -75,7 +76,7 @@ py::tuple rasterize_gaussians(const torch::Tensor& background, const torch::Tens
     const Arg bg(background, dev, "background"), means(means3D, dev, "means3D"), col(colors, dev, "colors"), op(opacity, dev, "opacity"),
         sc(scales, dev, "scales"), rot(rotations, dev, "rotations"), cov(cov3D_precomp, dev, "cov3D_precomp"), view(viewmatrix, dev, "viewmatrix"),
         proj(projmatrix, dev, "projmatrix"), shs(sh, dev, "sh"), cam(campos, dev, "campos");
-    void* stream = (void*)c10::hip::getCurrentHIPStream(dev.index()).stream();
+    void* stream = (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream();
     int64_t true_R = 0, r;
     if (r_guess)
         r = tgs_forward_speculative(*r_guess, &true_R, alloc_resize, bufs, stream, P, degree, M, bg.p, W, H, means.p, shs.p, col.p, op.p, sc.p, scale_modifier,
@@ -103,7 +104,7 @@ py::tuple rasterize_gaussians_backward(const torch::Tensor& background, const to
 {
     const c10::Device dev = require_gpu(means3D);
     const int P = (int)means3D.size(0), H = (int)dL_dout_color.size(1), W = (int)dL_dout_color.size(2), M = sh_coeffs(sh);
-    c10::hip::HIPGuard guard(dev);
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
     const auto f32 = torch::TensorOptions().dtype(torch::kFloat32).device(dev);
     torch::Tensor dL_dmeans3D = torch::empty({P, 3}, f32), dL_dmeans2D = torch::empty({P, 3}, f32), dL_dcolors = torch::empty({P, 3}, f32),
                   dL_dconic = torch::empty({P, 2, 2}, f32), dL_dopacity = torch::empty({P, 1}, f32), dL_dcov3D = torch::empty({P, 6}, f32),
@@ -117,7 +118,7 @@ py::tuple rasterize_gaussians_backward(const torch::Tensor& background, const to
             view(viewmatrix, dev, "viewmatrix"), proj(projmatrix, dev, "projmatrix"), shs(sh, dev, "sh"), cam(campos, dev, "campos"),
             dL(dL_dout_color, dev, "dL_dout_color");
         const torch::Tensor radii_c = radii.contiguous();
-        void* stream = (void*)c10::hip::getCurrentHIPStream(dev.index()).stream();
+        void* stream = (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream();
         const int r = tgs_backward(stream, P, degree, M, R, bg.p, W, H, means.p, shs.p, col.p, sc.p, scale_modifier, rot.p, cov.p, view.p, proj.p, cam.p, tan_fovx,
                                    tan_fovy, radii_c.data_ptr<int>(), geomBuffer.data_ptr(), binningBuffer.data_ptr(), imageBuffer.data_ptr(), dL.p,
                                    dL_dmeans2D.data_ptr<float>(), dL_dconic.data_ptr<float>(), dL_dopacity.data_ptr<float>(), dL_dcolors.data_ptr<float>(),
@@ -134,11 +135,11 @@ torch::Tensor mark_visible(const torch::Tensor& means3D, const torch::Tensor& vi
 {
     const c10::Device dev = require_gpu(means3D);
     const int P = (int)means3D.size(0);
-    c10::hip::HIPGuard guard(dev);
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
     torch::Tensor present = torch::zeros({P}, torch::TensorOptions().dtype(torch::kBool).device(dev));
     if (P != 0) {
         const Arg m(means3D, dev, "means3D"), v(viewmatrix, dev, "viewmatrix"), pj(projmatrix, dev, "projmatrix");
-        void* stream = (void*)c10::hip::getCurrentHIPStream(dev.index()).stream();
+        void* stream = (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream();
         const int r = tgs_mark_visible(stream, P, m.p, v.p, pj.p, (uint8_t*)present.data_ptr());
         if (r < 0) raise_last(r);
     }
