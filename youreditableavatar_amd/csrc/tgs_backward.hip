@@ -1018,7 +1018,8 @@ void launch_selftest_reduce36(hipStream_t st, const float* in, float* out)
 void launch_render_bwd(hipStream_t st, const ImgState& s, const BinState& b, int W, int H, uint32_t gx, uint32_t T, const float* bg, const float* dL_dpix,
                        bool deterministic)
 {
-    if (deterministic) hipLaunchKernelGGL(k_render_bwd_det, dim3(T), dim3(256), 0, st, s, b, W, H, gx, bg, dL_dpix);
+    // (-DTGS_FAST_MATH=0 builds always take the fixed-order kernel: it evaluates exp / the divisions in their accurate forms)
+    if (deterministic || !TGS_FAST_MATH) hipLaunchKernelGGL(k_render_bwd_det, dim3(T), dim3(256), 0, st, s, b, W, H, gx, bg, dL_dpix);
     else hipLaunchKernelGGL(k_render_bwd, dim3(T), dim3(BWD_THREADS), 0, st, s, b, W, H, gx, bg, dL_dpix);
 }
 void launch_preprocess_bwd(hipStream_t st, const BwdIn& in, const CamParams& cam, const GeomState& g, const BinState& b)

@@ -852,8 +852,13 @@ __global__ __launch_bounds__(FWD_THREADS, 8) void k_render_fwd(const ImgState s,
         }
         const uint32_t cnt = min((uint32_t)FCH, rg.y - base);
         if (ht < cnt) {
+#if TGS_FAST_MATH
             if (!upper) { stage_conic_a(r4); sA[ht] = r4; sC[ht] = __uint_as_float(r2.x); }
             else { stage_conic_b(r4); sB[ht] = r4; sQ[ht] = r2; }
+#else
+            if (!upper) { sA[ht] = r4; sC[ht] = __uint_as_float(r2.x); }
+            else { sB[ht] = r4; sQ[ht] = r2; }
+#endif
         }
         __syncthreads();
         if (base + FCH + ht < rg.y) fetch(base + FCH + ht);
@@ -871,8 +876,13 @@ __global__ __launch_bounds__(FWD_THREADS, 8) void k_render_fwd(const ImgState s,
                 const float4 bb = sB[j];                       // conic yy pre-scaled, opacity, colour r g
                 const float cc = sC[j];
                 const float dx = a.x - pixfx, dy = a.y - pixfy;
+#if TGS_FAST_MATH
                 const float power2 = (a.z * dx + a.w * dy) * dx + (bb.x * dy) * dy;    // log2(e) * power of forward.cu:336
                 const float alpha = fminf(0.99f, bb.y * __builtin_amdgcn_exp2f(power2));
+#else           // -DTGS_FAST_MATH=0: the reference's expression and libm-grade expf (forward.cu:336-339), for the fuzz comparison of DESIGN.md section 3
+                const float power2 = -0.5f * (a.z * dx * dx + bb.x * dy * dy) - a.w * dx * dy;
+                const float alpha = fminf(0.99f, bb.y * expf(power2));
+#endif
                 // forward.cu:337-343 skips; a finished pixel skips everything (a padding entry has opacity 0)
                 const bool live = !done && !(power2 > 0.0f) && !(alpha < 1.0f / 255.0f);
                 const float pown = live ? 1.f - alpha : 1.0f;   // a skipped entry leaves T alone
