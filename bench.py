@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to smoke-test the N>1 control flow)")
     ap.add_argument("--same-device", action="store_true", help="testing only: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--cpu-frames", type=int, default=3)
+    ap.add_argument("--order", default="random", choices=["random", "morton"], help="index order of the synthetic Gaussians: the generator's random permutation "
+                    "(default, the headline) or a 3-D Morton curve (neighbours in index are neighbours in space, like mesh-bound Gaussians); not the headline")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads (drop-in API per frame, the trainers' protocol at 2048x2048, grown splats, "
                     "alive-pair count) that are reported beside the headline at N = 1")
     ap.add_argument("--grad-chunks", type=int, default=4, help="N > 1: the step's per-Gaussian pass runs in this many Gaussian ranges and each range's all-reduce "
@@ -116,6 +118,8 @@ def main():
     cfg = dict(scenes.CONFIGS[a.config])
     P, W, H, D = cfg["P"], cfg["width"], cfg["height"], cfg["sh_degree"]
     cloud = scenes.config_cloud(a.config)
+    if a.order == "morton":
+        cloud = scenes.morton_order(cloud)
     dL_np = scenes.upstream_gradient(W, H, seed=cfg["seed"] + 1000)
     V = a.views
     cams = [scenes.orbit_camera(W, H, azimuth_deg=k * 360.0 / V) for k in range(V)]

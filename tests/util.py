@@ -249,7 +249,7 @@ def compare(mine: dict, ref: dict, golden_out: Optional[dict] = None, nc_frac: f
             if split and k in NOISY:
                 e2 = rel_l2(a, pg[k]); rep[k + "|own_inputs"] = e2
                 assert e2 <= tol, f"{k} (per-Gaussian half on own inputs) rel-L2 {e2:.3e} > {tol:.1e}"
-                assert e <= tol, f"{k} rel-L2 {e:.3e} (direct comparison, bound {tol:.1e})"
+                assert e <= 3 * tol, f"{k} rel-L2 {e:.3e} (direct comparison, bound {3 * tol:.1e})"
             else:
                 assert e <= tol, f"{k} rel-L2 {e:.3e} > {tol:.1e}"
             assert np.all(a[~vis] == 0), f"{k}: culled Gaussians must have zero gradient"

@@ -44,11 +44,12 @@ __device__ __forceinline__ unsigned long long quadrant_mask(float2 xy, float4 co
 {
     const float o255 = 255.0f * co.w;
     if (o255 < 0.999f) return 0ull;                     // alpha <= o < 1/255 for every pixel (G <= 1)
-    const float tau = (fmaxf(logf(o255), 0.f) + 0.01f) * 1.001f;
+    // (culling only: the hardware's 1-ulp log / sqrt / rcp are far inside the margins, and the IEEE-exact forms cost ~10 VALU each)
+    const float tau = (fmaxf(__logf(o255), 0.f) + 0.01f) * 1.001f;
     const float A = co.x, B = co.y, Cc = co.z;
     if (!(A * Cc - B * B > 0.f && A > 0.f && Cc > 0.f)) return ~0ull;
     // f = 1/2 A dx^2 + (B dy) dx + 1/2 C dy^2 <= tau  <=>  dx in [(-B dy - s) / A, (-B dy + s) / A], s^2 = (B dy)^2 - A (C dy^2 - 2 tau)
-    const float rA = 1.0f / A;
+    const float rA = __builtin_amdgcn_rcpf(A);
     const float ox = xy.x - (float)(tx * TILE), y0 = (float)(ty * TILE) - xy.y;       // mean relative to the tile; first row relative to the mean
     unsigned long long keep = 0ull;
 #pragma unroll
@@ -59,7 +60,7 @@ __device__ __forceinline__ unsigned long long quadrant_mask(float2 xy, float4 co
             const float dy = y0 + (float)(2 * R + h), gB = B * dy;
             const float disc = gB * gB - A * (Cc * dy * dy - 2.f * tau);
             if (disc < 0.f) continue;                   // the row misses the footprint (a NaN falls through and keeps the row)
-            const float sq = sqrtf(disc);
+            const float sq = __builtin_amdgcn_sqrtf(disc);
             const float lo = fmaxf(ox + (-gB - sq) * rA - 0.01f, 0.f), hi = fminf(ox + (-gB + sq) * rA + 0.01f, 15.f);   // pixel columns of the tile
             const int il = (int)ceilf(lo), ih = (int)floorf(hi);
             if (il > ih) continue;
@@ -91,21 +92,56 @@ __device__ __forceinline__ bool tile_reachable(float2 xy, float4 co, uint32_t tx
 {
     const float o255 = 255.0f * co.w;
     if (o255 < 0.999f) return false;
-    const float tau = fmaxf(logf(o255), 0.f) + 0.01f;
+    const float tau = fmaxf(__logf(o255), 0.f) + 0.01f;
     const float A = co.x, B = co.y, Cc = co.z;
     const float det = A * Cc - B * B;
     if (!(det > 0.f && A > 0.f && Cc > 0.f)) return true;              // NaNs and non-convex conics keep everything
-    const float hx = sqrtf(2.f * tau * Cc / det) * 1.001f + 0.01f, hy = sqrtf(2.f * tau * A / det) * 1.001f + 0.01f;
+    const float tdi = 2.f * tau * __builtin_amdgcn_rcpf(det);
+    const float hx = __builtin_amdgcn_sqrtf(tdi * Cc) * 1.001f + 0.01f, hy = __builtin_amdgcn_sqrtf(tdi * A) * 1.001f + 0.01f;
     const float xl = (float)(tx * TILE) - xy.x, xh = xl + (float)(TILE - 1), yl = (float)(ty * TILE) - xy.y, yh = yl + (float)(TILE - 1);
     if (hx < xl || -hx > xh || hy < yl || -hy > yh) return false;       // bounding box of the level set misses the tile
     if (xl <= 0.f && xh >= 0.f && yl <= 0.f && yh >= 0.f) return true;  // the mean is inside
-    const float rC = -B / Cc, rA = -B / A;
+    const float rC = -B * __builtin_amdgcn_rcpf(Cc), rA = -B * __builtin_amdgcn_rcpf(A);
     const float e0 = conic_min_on_edge(xl, yl, yh, A, Cc, B, rC), e1 = conic_min_on_edge(xh, yl, yh, A, Cc, B, rC);
     const float e2 = conic_min_on_edge(yl, xl, xh, Cc, A, B, rA), e3 = conic_min_on_edge(yh, xl, xh, Cc, A, B, rA);
     return !(fminf(fminf(e0, e1), fminf(e2, e3)) > tau * 1.001f);
 }
 
 constexpr uint32_t RANK_DEAD = 0xffffffffu;   // rank slot of a rectangle tile the splat cannot reach with alpha >= 1/255: no instance
+constexpr uint32_t RANK_DEAD_VALUE = RANK_DEAD;
+
+// Ranks of a wave's instances in their tiles (call from CONVERGENT code): lane l wants an instance in tile `t` (TILE_NONE: none).
+// Lanes of the wave that want the SAME tile are combined -- they rank themselves in LDS and one of them takes the whole group's
+// range from the tile's counter with ONE returning atomic.  The counters are updated at the memory side at ~20 G requests/s
+// chip-wide whatever the address pattern (profiles/: TCC_EA0_ATOMIC ~ instances, the kernel's largest cost), so what counts is the
+// number of requests: Gaussians that are neighbours in index AND in space (mesh-bound Gaussians are: TetGS binds them to the
+// faces of a marching-tetrahedra surface) share tiles inside a wave and need a fraction of the atomics; for a randomly
+// ordered cloud nearly every group is a single lane and this costs a few LDS operations per instance.
+constexpr uint32_t TILE_NONE = 0xffffffffu;
+struct WaveRankTab { uint32_t tile[WAVE]; uint32_t cnt[WAVE]; uint32_t base[WAVE]; };
+__device__ __forceinline__ uint32_t wave_tile_rank(uint32_t t, uint32_t* __restrict__ tile_count, WaveRankTab& tab)
+{
+    uint32_t rank = RANK_DEAD_VALUE;
+    bool pending = t != TILE_NONE;
+    while (__builtin_amdgcn_ballot_w64(pending) != 0ull) {                 // wave-uniform
+        const uint32_t slot = (t ^ (t >> 6)) & 63u;
+        if (pending) tab.tile[slot] = t;                                    // one of the lanes that hash here wins the slot
+        wave_sync();
+        const bool mine = pending && tab.tile[slot] == t;
+        uint32_t r = 0;
+        if (mine) r = atomicAdd(&tab.cnt[slot], 1u);                        // ds_add_rtn_u32: my rank inside the group
+        wave_sync();
+        if (mine && r == 0u) {                                              // the group's first lane fetches the range for all of them
+            const uint32_t n = tab.cnt[slot];
+            tab.cnt[slot] = 0u;
+            tab.base[slot] = atomicAdd(&tile_count[(size_t)t * CSTRIDE], n);
+        }
+        wave_sync();
+        if (mine) { rank = tab.base[slot] + r; pending = false; }
+        wave_sync();
+    }
+    return rank;
+}
 
 // One Gaussian of one view: projection, EWA covariance, SH colour, tile rectangle, the 64-B pack line, and the per-tile
 // instance count whose returned values are the instance's ranks.  Shared by the one-view and the all-views kernel.
@@ -115,6 +151,9 @@ __device__ __forceinline__ uint32_t preprocess_fwd_one(const FwdIn& in, int* __r
 {
 #pragma clang fp contract(off)      // projection, covariance, radius and colour un-fused: the oracle's (and the reference's source's) operation order
     uint32_t tiles = 0;
+    uint32_t want[RANK_TILES] = {TILE_NONE, TILE_NONE, TILE_NONE, TILE_NONE};   // tiles of a <= 4-tile rectangle that get an instance
+    bool ranked = false, has_pack = false;
+    float4 pk0 = make_float4(0.f, 0.f, 0.f, 0.f), pk1 = pk0, pk2 = pk0, pk3 = pk0;
     const ViewMat V = load_mat(cam.view), PM = load_mat(cam.proj);      // uniform -> scalar loads, before any store
     const float camx = cam.campos[0], camy = cam.campos[1], camz = cam.campos[2];
     if (idx < in.P) {
@@ -218,31 +257,32 @@ __device__ __forceinline__ uint32_t preprocess_fwd_one(const FwdIn& in, int* __r
                     }
                     g.depth[idx] = view_z;
                     my_radius_i = (int)my_radius;
-                    float4* pk = g.pack + 4 * (size_t)idx;
-                    pk[0] = make_float4(pix, piy, conx, cony);
-                    pk[1] = make_float4(conz, in.opacities[idx], col0, col1);
-                    pk[2] = make_float4(col2, __uint_as_float(minx | (miny << 16)), __uint_as_float(maxx | (maxy << 16)), 0.f);   // .w: slab offset, k_scatter
+                    // the 64-B pack line is stored in one go at the end (with the ranks, which are taken in convergent code)
+                    has_pack = true;
+                    pk0 = make_float4(pix, piy, conx, cony);
+                    pk1 = make_float4(conz, in.opacities[idx], col0, col1);
+                    pk2 = make_float4(col2, __uint_as_float(minx | (miny << 16)), __uint_as_float(maxx | (maxy << 16)), 0.f);   // .w: slab offset, k_scatter
                     // Per-tile instance count (replaces the tile half of the reference's 64-bit sort keys).  A splat on <= 4 tiles
                     // (almost all) takes its rank inside each tile from the same atomic, so k_scatter needs no second atomic pass.
                     if (tiles <= (uint32_t)RANK_TILES) {
                         // The 3-sigma square over-covers: a tile of the rectangle where the splat stays below alpha = 1/255 everywhere
                         // (tile_reachable: the conservative test that masks the 4x4 blocks for the render kernels, applied to the whole
                         // tile, so nothing that could be blended is lost) gets no instance at all -- no count, no key, no sort, no record (about a fifth of them).
-                        uint32_t rk[RANK_TILES] = {RANK_DEAD, RANK_DEAD, RANK_DEAD, RANK_DEAD};
+                        // The live tiles are only LISTED here; their ranks are taken below, in convergent code, wave by wave (wave_tile_rank).
                         const uint32_t rw = maxx - minx, area = tiles;
                         const float opac = in.opacities[idx];
                         uint32_t live = 0;
 #pragma unroll
-                        for (int k = 0; k < RANK_TILES; k++) {     // constant indices: rk stays in registers
+                        for (int k = 0; k < RANK_TILES; k++) {     // constant indices: want stays in registers
                             if ((uint32_t)k < area) {
                                 const uint32_t tx = minx + k % rw, ty = miny + k / rw;
                                 if (!in.prune || tile_reachable(make_float2(pix, piy), make_float4(conx, cony, conz, opac), tx, ty)) {
-                                    rk[k] = atomicAdd(&s.tile_count[(size_t)(ty * cam.gx + tx) * CSTRIDE], 1u);
+                                    want[k] = ty * cam.gx + tx;
                                     live++;
                                 }
                             }
                         }
-                        pk[3] = make_float4(__uint_as_float(rk[0]), __uint_as_float(rk[1]), __uint_as_float(rk[2]), __uint_as_float(rk[3]));
+                        ranked = true;
                         tiles = live;
                     } else if (tiles <= (uint32_t)COOP_TILES) {
                         // 5..64 tiles: the same pruning, the live tiles as a 64-bit mask over the rectangle (row-major) in the rank slots
@@ -255,7 +295,7 @@ __device__ __forceinline__ uint32_t preprocess_fwd_one(const FwdIn& in, int* __r
                                     atomicAdd(&s.tile_count[(size_t)(ty * cam.gx + tx) * CSTRIDE + 1], 1u);
                                     live_mask |= 1ull << k;
                                 }
-                        pk[3] = make_float4(__uint_as_float((uint32_t)live_mask), __uint_as_float((uint32_t)(live_mask >> 32)), 0.f, 0.f);
+                        pk3 = make_float4(__uint_as_float((uint32_t)live_mask), __uint_as_float((uint32_t)(live_mask >> 32)), 0.f, 0.f);
                         tiles = (uint32_t)__builtin_popcountll(live_mask);
                     } else {
                         for (uint32_t ty = miny; ty < maxy; ty++)
@@ -267,6 +307,32 @@ __device__ __forceinline__ uint32_t preprocess_fwd_one(const FwdIn& in, int* __r
         if (radii) radii[idx] = my_radius_i;
         g.tiles_touched[idx] = tiles;
         g.rect[idx] = make_ushort4((unsigned short)minx, (unsigned short)miny, (unsigned short)maxx, (unsigned short)maxy);
+    }
+    // Per-tile instance count of the splats on <= 4 tiles (almost all): the value the counter returns is the instance's rank inside its
+    // tile (stored in the pack line), so k_scatter needs no second atomic pass.  Convergent: every lane of the wave takes part.
+    {
+        __shared__ WaveRankTab rank_tab[PRE_BLOCK / WAVE];
+        WaveRankTab& tab = rank_tab[threadIdx.x >> 6];
+        tab.cnt[threadIdx.x & 63] = 0u;
+        wave_sync();
+        uint32_t rk[RANK_TILES] = {RANK_DEAD, RANK_DEAD, RANK_DEAD, RANK_DEAD};
+        // Combining pays when index neighbours share tiles (measured at config 3, Gaussians along a Morton curve: 171 -> 62 us, plain
+        // atomics of a wave on ONE counter serialise at the memory side) and costs ~6 us of LDS round trips when they do not
+        // (random order: 97 -> 102 us), so the wave looks first: how many lanes want the tile their index neighbour wants?
+        const uint32_t nb = (uint32_t)__shfl_down((int)want[0], 1, 64);
+        const bool combine = __builtin_popcountll(__builtin_amdgcn_ballot_w64(want[0] != TILE_NONE && want[0] == nb)) >= 6;
+        if (combine) {
+#pragma unroll
+            for (int k = 0; k < RANK_TILES; k++) rk[k] = wave_tile_rank(want[k], s.tile_count, tab);
+        } else {
+#pragma unroll
+            for (int k = 0; k < RANK_TILES; k++) if (want[k] != TILE_NONE) rk[k] = atomicAdd(&s.tile_count[(size_t)want[k] * CSTRIDE], 1u);
+        }
+        if (ranked) pk3 = make_float4(__uint_as_float(rk[0]), __uint_as_float(rk[1]), __uint_as_float(rk[2]), __uint_as_float(rk[3]));
+        if (has_pack) {
+            float4* pk = g.pack + 4 * (size_t)idx;
+            pk[0] = pk0; pk[1] = pk1; pk[2] = pk2; pk[3] = pk3;
+        }
     }
     return tiles;
 }

@@ -140,6 +140,22 @@ def concentrate(cloud: Dict[str, np.ndarray], n: int, centre=(0.0, 0.0, 0.0), si
     return out
 
 
+def morton_order(cloud: Dict[str, np.ndarray], bits: int = 10) -> Dict[str, np.ndarray]:
+    """The same cloud with its Gaussians re-numbered along a 3-D Morton curve of their centres: consecutive indices are spatial
+    neighbours, the way mesh-bound Gaussians come (TetGS binds 1 or 3 Gaussians to every face of a marching-tetrahedra surface,
+    tetgs_scene/tetgs_model.py:335-377, and faces come out cell by cell).  make_cloud's own order is a random permutation -- the worst
+    case for everything that profits from neighbours sharing tiles."""
+    m = cloud["means3D"].astype(np.float64)
+    lo, hi = m.min(0), m.max(0)
+    q = np.clip(((m - lo) / np.maximum(hi - lo, 1e-12) * ((1 << bits) - 1)).astype(np.uint64), 0, (1 << bits) - 1)
+    code = np.zeros(len(m), np.uint64)
+    for b in range(bits):
+        for a in range(3):
+            code |= ((q[:, a] >> np.uint64(b)) & np.uint64(1)) << np.uint64(3 * b + a)
+    perm = np.argsort(code, kind="stable")
+    return {k: (np.ascontiguousarray(v[perm]) if isinstance(v, np.ndarray) and v.shape[:1] == (len(m),) else v) for k, v in cloud.items()}
+
+
 def upstream_gradient(width: int, height: int, seed: int = 99) -> np.ndarray:
     """dL/d out_color ~ N(0,1)/(3HW)."""
     rng = np.random.Generator(np.random.PCG64(seed))
