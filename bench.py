@@ -452,6 +452,18 @@ def secondary_workloads(a, cloud, dev, D, W, H, headline_ms):
         del b2, big
         torch.cuda.empty_cache()
     res["grown_splats"] = gs
+    # ---- the same cloud with its Gaussians numbered along a Morton curve (mesh-bound Gaussians come spatially ordered; the generator's order is random)
+    mc = scenes.morton_order(cloud)
+    co = {k: g(mc[k], True) for k in ("means3D", "opacities", "scales", "rotations", "shs")}
+    FlatGradients([co[k] for k in ("means3D", "opacities", "scales", "rotations", "shs")])
+    b3 = SyncFreeBatch(streams=a.streams)
+    S4 = settings_for(W, H, D, 8)
+    ms = timed(lambda i: b3.run_views(S4, co["means3D"], co["opacities"], co["shs"], co["scales"], co["rotations"], None, accumulate=False,
+                                      upstream_view=lambda v, image: dL), 10, 4) / len(S4)
+    res["spatially_ordered_gaussians"] = {"ms_per_frame": round(ms, 4), "what": "the headline path on the same cloud re-numbered along a 3-D Morton curve: index neighbours share tiles, "
+                                          "so a wave's counting atomics combine (k_preprocess_fwd) and the gathers hit neighbouring lines"}
+    del b3, co
+    torch.cuda.empty_cache()
     # ---- alive (pixel, entry) pairs of view 0
     rs = S[0]
     e = torch.Tensor([])

@@ -24,7 +24,12 @@
  * All pointers are device pointers to contiguous fp32 (int32 for radii) unless noted.  The layout
  * inside the three state buffers is private to this library (the reference's is private too:
  * rasterizer_impl.h:29-65); they only have to be handed back to tgs_backward unmodified.
- * The library keeps no state between calls and is re-entrant.
+ * The render entry points keep no state between calls and are re-entrant: everything a backward needs travels in the three
+ * state buffers.  What IS process-wide, and only that: the test / experiment knobs declared further down -- tgs_set_sort_lds_cap,
+ * tgs_set_instance_pruning, tgs_set_forward_group, tgs_set_deterministic (relaxed atomics read once per call; none of them changes a
+ * result beyond summation order, instance pruning changes num_rendered / n_contrib as documented) -- and the optional bench profiler
+ * (tgs_profile_*).  Per calling thread: the message of tgs_last_error(), tgs_set_render_streams, and the pinned 64-byte staging slot +
+ * event of tgs_forward_speculative (one per thread and device).  A caller that never touches the knobs shares nothing between calls.
  */
 #ifndef TGS_RASTER_H
 #define TGS_RASTER_H
@@ -67,8 +72,8 @@ int64_t tgs_forward(tgs_alloc_fn alloc, void* alloc_ctx, void* stream,
  * reads num_rendered back to size the binning buffer (rasterizer_impl.cu:280-281: the GPU idles while the host
  * catches up); here the CALLER bounds it: the binning buffer is requested for r_capacity tile instances before
  * anything runs, nothing is read back and the call returns r_capacity -- pass that as R to tgs_backward[_accumulate]
- * and tgs_state_field.  A frame that needs more instances than r_capacity (or holds a tile list longer than the LDS
- * sort, which needs host-sized launches) is REJECTED on the device: the kernels behind the scan do no work, out_color
+ * and tgs_state_field.  A frame that needs more instances than r_capacity is REJECTED on the device (a tile list longer than the LDS
+ * sort is not a reason: it is sorted in global memory by workgroups of the same launch): the kernels behind the scan do no work, out_color
  * is the background, dL_dmean2D is zero, the other gradient outputs are left untouched (nothing is accumulated), and
  * tgs_frame_status reports TGS_FRAME_REJECTED; render such a frame again with tgs_forward.  The prefiltered check
  * (TGS_ERR_PREFILTERED) also moves to tgs_frame_status (TGS_FRAME_PREFILTERED). */

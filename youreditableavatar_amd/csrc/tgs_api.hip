@@ -334,7 +334,7 @@ static int64_t forward_impl(int preprocessed, int64_t r_capacity, int64_t* specu
         if (meta.R > 0x7fffffffull) return fail(TGS_ERR_TOO_MANY, "%llu tile instances exceed 2^31-1", (unsigned long long)meta.R);
         *speculative_true_R = (int64_t)meta.R;
         if (meta.error & META_ERR_CAPACITY) {
-            // the guess was too small (or a list needs the host-sized overflow sort): every kernel behind the scan returned at
+            // the guess was too small: every kernel behind the scan returned at
             // once; clear the flag and run those stages again with the exact sizes, as tgs_forward does
             HIP_TRY(hipMemsetAsync(&s.meta->error, 0, sizeof(uint32_t), st));
             R = meta.R;

@@ -250,7 +250,7 @@ class SyncFreeBatch:
         self.split = bool(split)
         self._host: Optional[torch.Tensor] = None
         self._side = {}
-        self._cooldown = 0                      # batches to render synchronously after a tile list outgrew the LDS sort
+        self._cooldown = 0                      # batches left to render synchronously (unused since overflow lists are sorted on the device; kept for callers that set it)
         self._pool = None
         self.viewspace_grads: Optional[torch.Tensor] = None
         self.color_grads: Optional[torch.Tensor] = None      # run_views with colors_precomp: dL/d colours per view [V,P,3]
@@ -473,8 +473,6 @@ class SyncFreeBatch:
                 seen, redo = 0, []
                 for v in range(V):
                     R, flags, _longest, n_overflow = _C.decode_meta_full(pool["host"][v])
-                    if n_overflow > 0 and (flags & _C.FRAME_REJECTED):
-                        self._cooldown = 16
                     if flags & _C.FRAME_PREFILTERED:
                         raise RuntimeError("Point is filtered although prefiltered is set. This shouldn't happen!")
                     if flags & _C.FRAME_REJECTED:
@@ -597,10 +595,7 @@ class SyncFreeBatch:
             self._cooldown -= 1
         for i, v in enumerate(views):
             R, flags, _longest, n_overflow = _C.decode_meta_full(host[i])
-            if n_overflow > 0 and cap is not None:
-                # tile lists longer than the LDS sort need host-sized launches: the sync-free forward rejects such frames every
-                # time, so render synchronously for a while before trying again
-                self._cooldown = 16
+            # (a tile list longer than the LDS sort is no reason to reject a frame any more: k_tile_sort's overflow workers sort it on the device)
             if flags & _C.FRAME_PREFILTERED:
                 raise RuntimeError("Point is filtered although prefiltered is set. This shouldn't happen!")
             if flags & _C.FRAME_REJECTED:
