@@ -140,11 +140,18 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// max over the wave, returned in every lane: 6 DPP steps like wave_sum (a __shfl_xor butterfly is 6 ds_bpermute round trips through LDS)
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { uint32_t t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
-    return v;
+#define TGS_DPP_MAX(ctrl, rowmask) { const uint32_t o_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rowmask, 0xf, false); v = o_ > v ? o_ : v; }
+    TGS_DPP_MAX(0xB1, 0xf)     // quad_perm [1,0,3,2]
+    TGS_DPP_MAX(0x4E, 0xf)     // quad_perm [2,3,0,1]
+    TGS_DPP_MAX(0x141, 0xf)    // row_half_mirror
+    TGS_DPP_MAX(0x140, 0xf)    // row_mirror
+    TGS_DPP_MAX(0x142, 0xa)    // row_bcast15 -> rows 1,3
+    TGS_DPP_MAX(0x143, 0xc)    // row_bcast31 -> rows 2,3
+#undef TGS_DPP_MAX
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 // inclusive scan over the wave
 __device__ __forceinline__ uint32_t wave_iscan_u32(uint32_t v, int lane)
@@ -270,6 +277,38 @@ __device__ __forceinline__ uint32_t build_chunk_quadrant_lists(unsigned short (*
         if (on) ql[q][__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (unsigned short)slot;
         if (cq + lane < (uint32_t)QL_ROW) ql[q][cq + lane] = (unsigned short)null_slot;      // short lists idle on the null record
         nmax = max(nmax, cq);
+    }
+    return nmax;
+}
+
+// The forward's variant: chunks of 128 block-list entries (two ballots per quadrant).  Longer chunks even out the four rows of a wave --
+// tools/culling_potential.py at config 3: 325 k wave passes with 64-entry chunks, 304 k with 128 -- and halve the number of list builds;
+// the forward has the LDS for the longer rows (the backward, at 2 x 75.6 KB per CU, does not).
+constexpr int QCH_F = 128;
+constexpr int QL_ROW_F = QCH_F + 8;
+__device__ __forceinline__ uint32_t build_chunk_quadrant_lists_128(unsigned short (*ql)[QL_ROW_F], const unsigned short* list, uint32_t c0, uint32_t n, int lane,
+                                                                  int null_slot)
+{
+    uint32_t cq[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const uint32_t i = c0 + 64u * h + lane;
+        const uint32_t ent = i < n ? list[i] : 0u;
+        const uint32_t nib = ent >> 10, slot = ent & 1023u;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const bool on = (nib >> q) & 1u;
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(on);
+            if (on) ql[q][cq[q] + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (unsigned short)slot;
+            cq[q] += (uint32_t)__builtin_popcountll(bal);
+        }
+    }
+    uint32_t nmax = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {                          // short lists idle on the null record up to the longest list of the chunk
+        if (cq[q] + lane < (uint32_t)QL_ROW_F) ql[q][cq[q] + lane] = (unsigned short)null_slot;
+        if (cq[q] + 64u + lane < (uint32_t)QL_ROW_F) ql[q][cq[q] + 64u + lane] = (unsigned short)null_slot;
+        nmax = max(nmax, cq[q]);
     }
     return nmax;
 }

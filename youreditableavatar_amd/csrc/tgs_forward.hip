@@ -861,7 +861,7 @@ __global__ __launch_bounds__(FWD_THREADS, 8) void k_render_fwd(const ImgState s,
     __shared__ float sC[FCH + 1];
     __shared__ uint2 sQ[FCH];                              // quadrant masks of the staged entries
     __shared__ __attribute__((aligned(16))) unsigned short lists[16][FCH + 8];   // one list per block (= per wave): slot | quadrant nibble << 10
-    __shared__ __attribute__((aligned(16))) unsigned short qlists[16][4][QL_ROW]; // per wave: the current chunk's four quadrant lists
+    __shared__ __attribute__((aligned(16))) unsigned short qlists[16][4][QL_ROW_F]; // per wave: the current chunk's four quadrant lists
     __shared__ uint32_t wave_alive[2][16];                 // double-buffered "this wave still has live pixels"
     __shared__ uint32_t wave_qmax[16];
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
@@ -933,8 +933,8 @@ __global__ __launch_bounds__(FWD_THREADS, 8) void k_render_fwd(const ImgState s,
             const uint32_t n = wave_live ? build_own_list_q<FCH>(lists[wv], sQ, cnt, wv, lane) : 0u;
             const unsigned short* myq = &qlists[wv][qd][e];
 #pragma unroll 1
-            for (uint32_t c0 = 0; c0 < n && wave_live; c0 += QCH) {
-            const uint32_t nq = build_chunk_quadrant_lists(qlists[wv], lists[wv], c0, n, lane, FNULL);
+            for (uint32_t c0 = 0; c0 < n && wave_live; c0 += QCH_F) {
+            const uint32_t nq = build_chunk_quadrant_lists_128(qlists[wv], lists[wv], c0, n, lane, FNULL);
 #pragma unroll 1
             for (uint32_t k = 0; k < nq; k += 4) {              // 4 entries of its own quadrant list per row and pass
                 const uint32_t j = myq[k];
