@@ -62,7 +62,10 @@ json.dump(sq, open(f"{P}/{name}_sq_counters.json", "w"), indent=1)
 
 for src, dst in (("bench_default.json", "bench_default.json"), ("bench_under_rocprof.json", "bench_under_rocprof.json"),
                  ("bench_under_rocprof_one_stream.json", "bench_under_rocprof_one_stream.json"), ("rp4/rp_kernel_stats.csv", "kernel_stats.csv"),
-                 ("rp1/rp_kernel_stats.csv", "kernel_stats_one_stream.csv"), ("valu_issue_rate.txt", "valu_issue_rate.txt")):
+                 ("rp1/rp_kernel_stats.csv", "kernel_stats_one_stream.csv"), ("valu_issue_rate.txt", "valu_issue_rate.txt"),
+                 ("rp_cfg2/rp_kernel_stats.csv", "kernel_stats_cfg2.csv"), ("rp_cfg5/rp_kernel_stats.csv", "kernel_stats_cfg5.csv"),
+                 ("rp_trainer/rp_kernel_stats.csv", "kernel_stats_trainer_protocol.csv"), ("bench_cfg2.json", "bench_cfg2.json"), ("bench_cfg5.json", "bench_cfg5.json"),
+                 ("trainer_protocol.json", "trainer_protocol_under_rocprof.json")):
     if os.path.exists(O + src):
         shutil.copy(O + src, f"{P}/{name}_{dst}")
 for k, v in out["kernels"].items():

@@ -4,7 +4,7 @@ set -x
 # Counter passes never share a run with trace domains other than --kernel-trace (MI355X_MICROARCH.md, rocprofv3 PMC slots: 8 SQ counters or
 # FETCH_SIZE (3 TCC slots) or WRITE_SIZE (2) per pass).
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/${1:-r02_a}
+O=$R/gpurun_out/${1:-r02_b}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
@@ -17,3 +17,9 @@ rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_
 (cd $R/tools/microbench && ./valu_issue_rate) > $O/valu_issue_rate.txt 2>&1
 ls -R $O | head -60
 tail -c 600 $O/bench_default.json
+# other configurations and the trainers' protocol (rocprof summaries only)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/rp_cfg2 -o rp -- python3 $R/bench.py --config 2 --steps 6 --warmup 2 --no-cpu --no-secondary > $O/bench_cfg2_under_rocprof.json 2> $O/rp_cfg2.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/rp_cfg5 -o rp -- python3 $R/bench.py --config 5 --views-per-gpu 4 --steps 4 --warmup 2 --no-cpu --no-secondary > $O/bench_cfg5_under_rocprof.json 2> $O/rp_cfg5.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/rp_trainer -o rp -- python3 $R/tools/trainer_protocol.py > $O/trainer_protocol.json 2> $O/rp_trainer.err
+python3 $R/bench.py --config 2 --no-cpu --no-secondary > $O/bench_cfg2.json 2>/dev/null
+python3 $R/bench.py --config 5 --views-per-gpu 4 --no-cpu --no-secondary > $O/bench_cfg5.json 2>/dev/null
