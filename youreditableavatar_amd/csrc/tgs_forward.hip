@@ -661,32 +661,26 @@ __device__ __forceinline__ void sort_tile_lds(unsigned long long* lk, uint32_t t
     }
 }
 
-// ---- overflow path: lists longer than the LDS sort (sort_cap keys), sorted in global memory by OVF_WORKERS workgroups of the SAME launch ----
+// ---- overflow path: lists longer than the LDS sort (sort_cap keys), sorted in global memory by workgroups of the SAME launch ----
 // The reference sorts any R globally (rasterizer_impl.cu:303-308).  Here the rare list that does not fit LDS runs the same all-ascending
-// bitonic network in global memory, LDS for the strides below `cap`: the last OVF_WORKERS workgroups of k_tile_sort's grid walk the
-// network step by step with a grid barrier between steps (a counter in the frame's Meta, zeroed with it).  They read n_overflow on the device
-// and return at once when there is nothing to do, so the sync-free forward needs neither host-sized launches nor a rejection, and a frame
-// with ordinary lists pays nothing.  Visibility between workgroups (other CUs, other XCDs' L2): release fence -> counter -> acquire fence
-// by one lane, workgroup barriers around it (MI355X_MICROARCH.md, correctness boundaries).
-constexpr uint32_t OVF_WORKERS = 128;
+// bitonic network in global memory, LDS for the strides below `cap`: the last OVF_WORKERS workgroups of k_tile_sort's grid take the
+// overflow tiles (worker w: tiles w, w + OVF_WORKERS, ...), ONE workgroup per tile walking the whole network with workgroup barriers.
+// They read n_overflow on the device and return at once when there is nothing to do, so the sync-free forward needs neither host-sized
+// launches nor a rejection, and a frame with ordinary lists pays nothing.  Deliberately no barrier BETWEEN workgroups: a first version
+// spread one list over 128 workgroups with a spinning grid barrier, and with four streams in flight the 4 x 128 spinning workgroups filled
+// every CU while their peers waited for a slot -- config 5 took 37 ms per k_render_bwd instead of 0.9.  A workgroup that depends on no other
+// cannot be starved; the price is the time of one long list on one workgroup (~0.1 ms per 10 k entries), which the render kernels spend on
+// such a tile many times over.
+constexpr uint32_t OVF_WORKERS = 32;
 constexpr uint32_t OVF_THREADS = 1024;
 
-__device__ __forceinline__ void ovf_grid_barrier(uint32_t* ctr, uint32_t& phase, uint32_t nwg)
+// all global stores of the workgroup are visible to all of its waves (L1 of the CU invalidated) before anybody goes on
+__device__ __forceinline__ void ovf_wg_sync()
 {
-    __syncthreads();                                        // every wave's stores are issued ...
-    if (threadIdx.x == 0) {
-        __threadfence();                                    // ... and made visible device-wide (release)
-        atomicAdd(ctr, 1u);
-        const uint32_t target = (phase + 1u) * nwg;
-        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(8);
-        __threadfence();                                    // acquire: later loads see the other workgroups' stores
-    }
-    phase++;
+    __threadfence();
     __syncthreads();
 }
 
-// k_only == 0: full network for k = 2..cap on the aligned block `blk` of cap keys of overflow tile `ot`;
-// k_only  > 0: only the disperse steps j = cap/2..1 of merge size k_only.
 __device__ __forceinline__ void ovf_local(const ImgState& s, const BinState& b, unsigned long long* lk, uint32_t ot, uint32_t blk, uint32_t k_only, uint32_t cap)
 {
     const uint32_t tile = s.ovf_tiles[ot];
@@ -734,24 +728,24 @@ __device__ __forceinline__ void ovf_global(const ImgState& s, const BinState& b,
 
 __device__ __forceinline__ void ovf_worker(const ImgState& s, const BinState& b, unsigned long long* lk, uint32_t w, uint32_t nw, uint32_t cap)
 {
-    const uint32_t n_ovf = s.meta->n_overflow;              // written by k_scan, the same for every worker
-    if (n_ovf == 0) return;
-    const uint32_t npad = next_pow2(s.meta->max_count);     // >= 2 cap: the longest list is longer than cap
-    uint32_t* ctr = &s.meta->pad[0];
-    uint32_t phase = 0;
-    const uint32_t bpt = npad / cap;                        // aligned blocks of cap keys per (padded) list
-    const uint32_t cpt = max(1u, (npad >> 1) / OVF_THREADS); // chunks of OVF_THREADS comparators per list
-    for (uint32_t it = w; it < n_ovf * bpt; it += nw) ovf_local(s, b, lk, it / bpt, it % bpt, 0u, cap);
-    ovf_grid_barrier(ctr, phase, nw);
-    for (uint32_t k = cap * 2; k <= npad; k <<= 1) {
-        for (uint32_t it = w; it < n_ovf * cpt; it += nw) ovf_global(s, b, it / cpt, (it % cpt) * OVF_THREADS, k, 0u, 1);
-        ovf_grid_barrier(ctr, phase, nw);
-        for (uint32_t j = k >> 2; j >= cap; j >>= 1) {
-            for (uint32_t it = w; it < n_ovf * cpt; it += nw) ovf_global(s, b, it / cpt, (it % cpt) * OVF_THREADS, k, j, 0);
-            ovf_grid_barrier(ctr, phase, nw);
+    const uint32_t n_ovf = s.meta->n_overflow;              // written by k_scan
+    for (uint32_t ot = w; ot < n_ovf; ot += nw) {           // one workgroup per overflow tile: no dependency on any other workgroup
+        const uint2 rg = s.ranges[s.ovf_tiles[ot]];
+        const uint32_t npad = next_pow2(rg.y - rg.x);       // >= 2 cap: the list is longer than cap
+        const uint32_t bpt = npad / cap;                    // aligned blocks of cap keys
+        const uint32_t half = npad >> 1;                    // comparators per step
+        for (uint32_t blk = 0; blk < bpt; blk++) ovf_local(s, b, lk, ot, blk, 0u, cap);
+        for (uint32_t k = cap * 2; k <= npad; k <<= 1) {
+            ovf_wg_sync();
+            for (uint32_t c0 = 0; c0 < half; c0 += OVF_THREADS) ovf_global(s, b, ot, c0, k, 0u, 1);
+            for (uint32_t j = k >> 2; j >= cap; j >>= 1) {
+                ovf_wg_sync();
+                for (uint32_t c0 = 0; c0 < half; c0 += OVF_THREADS) ovf_global(s, b, ot, c0, k, j, 0);
+            }
+            ovf_wg_sync();
+            for (uint32_t blk = 0; blk < bpt; blk++) ovf_local(s, b, lk, ot, blk, k, cap);
         }
-        for (uint32_t it = w; it < n_ovf * bpt; it += nw) ovf_local(s, b, lk, it / bpt, it % bpt, k, cap);
-        ovf_grid_barrier(ctr, phase, nw);
+        ovf_wg_sync();
     }
 }
 
