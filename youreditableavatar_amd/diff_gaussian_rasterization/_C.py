@@ -393,7 +393,7 @@ def set_render_streams(stream_handles) -> None:
 
 def backward_render_views(stream_handles, P, views, n_views) -> None:
     arr = (C.c_void_p * len(stream_handles))(*stream_handles)
-    r = _lib.tgs_backward_render_views(arr, len(stream_handles), int(P), int(n_views), C.cast(views, C.c_void_p))
+    r = _lib.tgs_backward_render_views(arr, len(stream_handles), int(P), int(n_views), views if isinstance(views, C.c_void_p) else C.cast(views, C.c_void_p))
     if r < 0:
         raise _err(int(r))
 
@@ -402,7 +402,8 @@ def backward_batch_raw(stream, P, D, M, views, n_views, means3D, shs, scales, sc
                        dL_drot, accumulate, first: int = 0, count: Optional[int] = None) -> None:
     """tgs_backward_batch[_range] on prepared device pointers (scales/rotations path; ``shs`` None: per-view colours, their gradients go to
     the views' dL_dcolor).  ``first`` / ``count``: only Gaussians [first, first + count) (multiples of 256, or ending at P)."""
-    r = _lib.tgs_backward_batch_range(stream, int(P), int(D), int(M), int(n_views), C.cast(views, C.c_void_p), means3D, shs, scales, float(scale_modifier),
+    r = _lib.tgs_backward_batch_range(stream, int(P), int(D), int(M), int(n_views), views if isinstance(views, C.c_void_p) else C.cast(views, C.c_void_p), means3D, shs,
+                                      scales, float(scale_modifier),
                                       rotations, None, dL_dopacity, dL_dmean3D, None, dL_dsh if shs else None, dL_dscale, dL_drot, 1 if accumulate else 0,
                                       int(first), int(P - first if count is None else count))
     if r < 0:

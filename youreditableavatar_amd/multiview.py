@@ -14,6 +14,8 @@ from __future__ import annotations
 
 from typing import Callable, Iterable, List, Optional, Sequence
 
+import ctypes as C
+
 import torch
 import torch.distributed as dist
 
@@ -248,6 +250,8 @@ class SyncFreeBatch:
         # run_views(upstream_view=...): half of the streams bin (per-Gaussian forward .. finalize), the other half composite
         # (k_render_fwd, the loss, k_render_bwd): kernels bound by the L2 atomics / by latency next to kernels bound by VALU issue
         self.split = bool(split)
+        self.split_pass = False                 # experiment (measured slower): per-Gaussian pass of the first round of views beside the remaining per-pixel backwards
+        self._pass_stream = {}
         self._host: Optional[torch.Tensor] = None
         self._side = {}
         self._cooldown = 0                      # batches left to render synchronously (unused since overflow lists are sorted on the device; kept for callers that set it)
@@ -464,8 +468,31 @@ class SyncFreeBatch:
                 for v, g in dLs:
                     arr[v].dL_dpix = g.data_ptr()
                 self._keep = dLs                                 # (alive until the next batch)
-            _C.backward_render_views([st.cuda_stream for st in ren_lanes] if upstream_view is not None else handles, P, arr, V)
-            join()
+            bw_handles = [st.cuda_stream for st in ren_lanes] if upstream_view is not None else handles
+            first = len(bw_handles)                         # views of the lanes' first round
+            early = self.split_pass and V > first and not precomp
+            if early:
+                # The per-Gaussian pass of the views whose per-pixel backward finishes first runs on a stream of its own BESIDE the per-pixel
+                # backwards of the remaining views (it is bound by HBM latency, they by vector issue and LDS); the pass at the end of the step,
+                # alone on the GPU, then covers the remaining views only.
+                _C.backward_render_views(bw_handles, P, arr, first)
+                ps = self._pass_stream.setdefault(dev, torch.cuda.Stream(device=dev))
+                for st in (ren_lanes if upstream_view is not None else lanes):
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    ps.wait_event(ev)
+                _C.backward_batch_raw(ps.cuda_stream, P, D, M, arr, first, means3D.data_ptr(), shs.data_ptr(), scales.data_ptr(), rs0.scale_modifier,
+                                      rotations.data_ptr(), opacities.grad.data_ptr(), means3D.grad.data_ptr(), shs.grad.data_ptr(), scales.grad.data_ptr(),
+                                      rotations.grad.data_ptr(), accumulate)
+                ev_a = torch.cuda.Event()
+                ev_a.record(ps)
+                rest = C.cast(C.addressof(arr) + first * C.sizeof(_C._ViewT), C.c_void_p)
+                _C.backward_render_views(bw_handles, P, rest, V - first)
+                join()
+                main.wait_event(ev_a)
+            else:
+                _C.backward_render_views(bw_handles, P, arr, V)
+                join()
             def verdict():
                 """waits for the Meta records (the one host wait of the batch: they left right behind the forwards) -> (views to render again, largest count)"""
                 for ev in ready:
@@ -485,12 +512,13 @@ class SyncFreeBatch:
             known = verdict() if on_chunk is not None else None
             eager = known is not None and not known[0]
             # the one per-Gaussian pass of the step, range by range: a range's gradients are final behind its launch
-            for first, count in ranges:
-                _C.backward_batch_raw(main.cuda_stream, P, D, M, arr, V, means3D.data_ptr(), None if precomp else shs.data_ptr(), scales.data_ptr(),
+            last_arr, last_n, last_acc = (rest, V - first, True) if early else (arr, V, accumulate)
+            for g0, gcount in ranges:
+                _C.backward_batch_raw(main.cuda_stream, P, D, M, last_arr, last_n, means3D.data_ptr(), None if precomp else shs.data_ptr(), scales.data_ptr(),
                                       rs0.scale_modifier, rotations.data_ptr(), opacities.grad.data_ptr(), means3D.grad.data_ptr(),
-                                      None if precomp else shs.grad.data_ptr(), scales.grad.data_ptr(), rotations.grad.data_ptr(), accumulate, first, count)
+                                      None if precomp else shs.grad.data_ptr(), scales.grad.data_ptr(), rotations.grad.data_ptr(), last_acc, g0, gcount)
                 if eager:
-                    on_chunk(first, count)
+                    on_chunk(g0, gcount)
         self.viewspace_grads = pool["g2d"]
         self.color_grads = gcol
         if self._cooldown > 0:
