@@ -37,9 +37,33 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+class _BuildLock:
+    """Serialises builds between processes (the ranks of one launch import the package at the same moment): flock on a file next to the
+    outputs; whoever gets it second finds everything fresh."""
+
+    def __enter__(self):
+        import fcntl
+        os.makedirs(LIBDIR, exist_ok=True)
+        self.f = open(os.path.join(LIBDIR, ".build.lock"), "w")
+        fcntl.flock(self.f, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *exc):
+        import fcntl
+        fcntl.flock(self.f, fcntl.LOCK_UN)
+        self.f.close()
+
+
 def build_native(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return LIB
+    with _BuildLock():
+        if not force and not _stale():
+            return LIB
+        return _build_native_locked(verbose)
+
+
+def _build_native_locked(verbose: bool) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     cc = hipcc()
     objs = []
@@ -58,10 +82,12 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=6) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    cmd = [cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]
+    tmp = LIB + f".tmp{os.getpid()}"
+    cmd = [cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", tmp, *objs]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    os.replace(tmp, LIB)                                    # atomic: a process that is loading the old file keeps its mapping
     return LIB
 
 
@@ -82,8 +108,16 @@ def build_torch_ext(force: bool = False, verbose: bool = False) -> str:
     lib = build_native(force=force, verbose=verbose)
     out = ext_path()
     deps = [EXT_SRC, os.path.join(HERE, "..", "include", "tgs_raster.h")]
-    if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+    fresh = lambda: os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps)
+    if not force and fresh():
         return out
+    with _BuildLock():
+        if not force and fresh():
+            return out
+        return _build_torch_ext_locked(lib, out, verbose)
+
+
+def _build_torch_ext_locked(lib: str, out: str, verbose: bool) -> str:
     import sysconfig
     import torch
     from torch.utils import cpp_extension as ce
@@ -98,13 +132,14 @@ def build_torch_ext(force: bool = False, verbose: bool = False) -> str:
     tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
     cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
            f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", f"-DTORCH_EXTENSION_NAME={EXT_NAME}", "-DTORCH_API_INCLUDE_EXTENSION_H",
-           "-Wno-deprecated-declarations", *inc, EXT_SRC, "-o", out, f"-L{LIBDIR}", f"-l:{os.path.basename(lib)}", f"-L{tlib}", "-ltorch_python", "-ltorch",
+           "-Wno-deprecated-declarations", *inc, EXT_SRC, "-o", out + f".tmp{os.getpid()}", f"-L{LIBDIR}", f"-l:{os.path.basename(lib)}", f"-L{tlib}", "-ltorch_python", "-ltorch",
            "-ltorch_cpu", "-ltorch_hip", "-lc10", "-lc10_hip", "-Wl,-rpath,$ORIGIN/../lib", f"-Wl,-rpath,{tlib}"]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"building {EXT_NAME} failed:\n{r.stdout}\n{r.stderr}")
+    os.replace(out + f".tmp{os.getpid()}", out)
     return out
 
 
