@@ -267,6 +267,11 @@ int tgs_backward_batch_range(void* stream, int P, int D, int M, int n_views, con
 size_t tgs_l1_ssim_workspace_bytes(int planes, int height, int width);
 int tgs_l1_ssim(void* stream, int planes, int height, int width, const float* img, const float* gt, float dssim_factor,
                 float* out3, float* dL_dimg, void* workspace, size_t workspace_bytes);
+/* The gradient pass on its own, for an autograd backward: the SAME img / gt / dssim_factor / workspace a tgs_l1_ssim call (with dL_dimg NULL
+ * or not) has filled, kept unmodified since; dL_dimg = upstream[0] * d loss / d img with `upstream` a DEVICE scalar (the gradient arriving
+ * at the loss; NULL = 1) -- the chain rule is folded into the pass instead of a separate image-sized multiply. */
+int tgs_l1_ssim_backward(void* stream, int planes, int height, int width, const float* img, const float* gt, float dssim_factor,
+                         const float* upstream, float* dL_dimg, const void* workspace, size_t workspace_bytes);
 
 /* Test knob (process-wide): longest tile list that is depth-sorted inside LDS; longer lists take the
  * multi-workgroup global-memory path.  Power of two in [2, 8192]; default 8192. */

@@ -8,8 +8,8 @@ O=$R/gpurun_out/${1:-r02_c}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/rp4 -o rp -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu > $O/bench_under_rocprof.json 2> $O/rp4.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/rp1 -o rp -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu --streams 1 > $O/bench_under_rocprof_one_stream.json 2> $O/rp1.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/rp4 -o rp -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu --no-secondary > $O/bench_under_rocprof.json 2> $O/rp4.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/rp1 -o rp -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu --no-secondary --streams 1 > $O/bench_under_rocprof_one_stream.json 2> $O/rp1.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o pmc -- python3 $R/tools/pmc_workload.py 4 > $O/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o pmc -- python3 $R/tools/pmc_workload.py 4 > $O/pmc_write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES --output-format csv -d $O/pmc_sq -o pmc -- python3 $R/tools/pmc_workload.py 4 > $O/pmc_sq.log 2>&1

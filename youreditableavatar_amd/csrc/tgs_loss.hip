@@ -202,10 +202,11 @@ __global__ __launch_bounds__(1024) void k_loss_reduce(int n, const float2* __res
 
 __global__ __launch_bounds__(256) void k_ssim_grad(int H, int W, const float* __restrict__ img, const float* __restrict__ gt, LossWin win,
                                                   const float* __restrict__ dM1, const float* __restrict__ dX2, const float* __restrict__ dXY,
-                                                  float gs, float gl, float* __restrict__ grad)
+                                                  float gs, float gl, const float* __restrict__ upstream, float* __restrict__ grad)
 {
     __shared__ float t[3][LTH][LTW + 1];
     __shared__ float h[3][LTH][LW + 1];
+    if (upstream) { const float u = upstream[0]; gs *= u; gl *= u; }      // d(outer)/d(loss), a device scalar: the chain rule costs no pass of its own
     const int x0 = blockIdx.x * LW;
     const size_t plane = (size_t)blockIdx.z * H * W;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -288,8 +289,29 @@ int tgs_l1_ssim(void* stream, int planes, int height, int width, const float* im
     hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(1024), 0, st, nblk, partial, 1.0 / (double)n, dssim_factor, out3);
     if (dL_dimg) {
         const float gs = (float)(-(double)dssim_factor / (double)n), gl = (float)((1.0 - (double)dssim_factor) / (double)n);
-        hipLaunchKernelGGL(k_ssim_grad, grid, dim3(256), 0, st, height, width, img, gt, win, dM1, dX2, dXY, gs, gl, dL_dimg);
+        hipLaunchKernelGGL(k_ssim_grad, grid, dim3(256), 0, st, height, width, img, gt, win, dM1, dX2, dXY, gs, gl, (const float*)nullptr, dL_dimg);
     }
     return hip_status("tgs_l1_ssim");
+}
+
+int tgs_l1_ssim_backward(void* stream, int planes, int height, int width, const float* img, const float* gt, float dssim_factor,
+                         const float* upstream, float* dL_dimg, const void* workspace, size_t workspace_bytes)
+{
+    using namespace tgs;
+    hipStream_t st = (hipStream_t)stream;
+    if (planes <= 0 || height <= 0 || width <= 0 || !img || !gt || !dL_dimg || !workspace)
+        return set_error(TGS_ERR_INVALID, "tgs_l1_ssim_backward: positive sizes and non-NULL img / gt / dL_dimg / workspace required");
+    if (workspace_bytes < tgs_l1_ssim_workspace_bytes(planes, height, width))
+        return set_error(TGS_ERR_INVALID, "tgs_l1_ssim_backward: workspace smaller than tgs_l1_ssim_workspace_bytes()");
+    const size_t n = (size_t)planes * height * width;
+    const dim3 grid((width + LW - 1) / LW, (height + LH * LTY - 1) / (LH * LTY), planes);
+    if (grid.y > 65535u || grid.z > 65535u) return set_error(TGS_ERR_INVALID, "tgs_l1_ssim_backward: image too large");
+    const float* dM1 = (const float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    const float* dX2 = dM1 + n;
+    const float* dXY = dX2 + n;
+    const LossWin win = make_window();
+    const float gs = (float)(-(double)dssim_factor / (double)n), gl = (float)((1.0 - (double)dssim_factor) / (double)n);
+    hipLaunchKernelGGL(k_ssim_grad, grid, dim3(256), 0, st, height, width, img, gt, win, dM1, dX2, dXY, gs, gl, upstream, dL_dimg);
+    return hip_status("tgs_l1_ssim_backward");
 }
 }

@@ -50,17 +50,45 @@ def l1_ssim_value_and_grad(img: torch.Tensor, gt: torch.Tensor, dssim_factor: fl
     return out3, grad
 
 
+_lib.tgs_l1_ssim_backward.restype = C.c_int
+_lib.tgs_l1_ssim_backward.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+
+
 class _L1SSIM(torch.autograd.Function):
+    """Forward: the statistics pass + the reduction (value only); the gradient pass runs in backward with the incoming gradient as a device
+    scalar folded in (tgs_l1_ssim_backward) -- no image-sized ``grad * g`` pass, and no gradient image is computed for a loss that is never
+    back-propagated."""
+
     @staticmethod
     def forward(ctx, img, gt, dssim_factor, which):
-        out3, grad = l1_ssim_value_and_grad(img, gt, dssim_factor, need_grad=img.requires_grad)
-        ctx.save_for_backward(grad)
+        planes, H, W = _check(img, gt)
+        dev = img.device
+        a, b = img.detach().contiguous(), gt.detach().contiguous()
+        with torch.cuda.device(dev):
+            nbytes = int(_lib.tgs_l1_ssim_workspace_bytes(planes, H, W))
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            out3 = torch.empty(3, dtype=torch.float32, device=dev)
+            r = _lib.tgs_l1_ssim(torch.cuda.current_stream(dev).cuda_stream, planes, H, W, a.data_ptr(), b.data_ptr(), float(dssim_factor),
+                                 out3.data_ptr(), None, ws.data_ptr(), nbytes)
+        if r < 0:
+            raise _rast_c._err(r)
+        ctx.save_for_backward(a, b, ws)
+        ctx.dims, ctx.f, ctx.shape = (planes, H, W), float(dssim_factor), img.shape
         return out3[which]
 
     @staticmethod
     def backward(ctx, g):
-        (grad,) = ctx.saved_tensors
-        return (grad * g if grad is not None else None), None, None, None
+        a, b, ws = ctx.saved_tensors
+        planes, H, W = ctx.dims
+        dev = a.device
+        g = g.detach().to(device=dev, dtype=torch.float32).contiguous()
+        grad = torch.empty_like(a)
+        with torch.cuda.device(dev):
+            r = _lib.tgs_l1_ssim_backward(torch.cuda.current_stream(dev).cuda_stream, planes, H, W, a.data_ptr(), b.data_ptr(), ctx.f, g.data_ptr(),
+                                          grad.data_ptr(), ws.data_ptr(), ws.numel())
+        if r < 0:
+            raise _rast_c._err(r)
+        return grad.view(ctx.shape), None, None, None
 
 
 def l1_ssim_loss(network_output: torch.Tensor, gt: torch.Tensor, dssim_factor: float = 0.2) -> torch.Tensor:
