@@ -343,9 +343,13 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
 #ifdef TGS_EXP_NOATOM
                 asm volatile("" :: "v"(s0), "v"(s1), "v"(v[8]));
 #else
-                atomicAdd(&acc[pq][j], (double)s0);
-                atomicAdd(&acc[4 + pq][j], (double)s1);
-                if (pq == 0) atomicAdd(&acc[8][j], (double)v[8]);
+                // rows whose list is shorter than the longest of the chunk idle on the null record: their sums are zero, and without this
+                // test all of them would add into the ONE spare column -- same-address LDS atomics serialise
+                if (j != (uint32_t)BNULL) {
+                    atomicAdd(&acc[pq][j], (double)s0);
+                    atomicAdd(&acc[4 + pq][j], (double)s1);
+                    if (pq == 0) atomicAdd(&acc[8][j], (double)v[8]);
+                }
 #endif
             }
             }
