@@ -38,7 +38,7 @@ sq = {"note": "rocprofv3 --kernel-trace --pmc <8 SQ counters> (two passes: pmc_s
               "SQ_WAIT_* / SQ_ACTIVE_INST_* / SQ_BUSY_CYCLES count quad-cycles (4 shader cycles) summed over waves (MI355X_MICROARCH.md, cycle constants). "
               "us_in_pass = average dispatch duration inside the counter pass (profiled passes run at a lower clock). valu_rate_G_per_s = SQ_INSTS_VALU / duration.",
       "kernels": {}}
-for d in ("pmc_sq", "pmc_sq2"):
+for d in ("pmc_sq", "pmc_sq2", "pmc_sq3"):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     dur = collections.defaultdict(dict)
     for r in rows(d):
@@ -51,11 +51,17 @@ for d in ("pmc_sq", "pmc_sq2"):
         e = sq["kernels"].setdefault(k, {})
         for c, v in cs.items():
             e[c] = round(sum(v) / len(v), 1)
+        if not dur[k]:
+            continue
         e["us_in_pass_" + d] = round(sum(dur[k].values()) / len(dur[k]), 2)
         e["launches_" + d] = len(dur[k])
 for k, e in sq["kernels"].items():
     if "SQ_INSTS_VALU" in e and e.get("us_in_pass_pmc_sq"):
         e["valu_rate_G_per_s"] = round(e["SQ_INSTS_VALU"] / e["us_in_pass_pmc_sq"] / 1e3, 1)
+    if e.get("SQ_LDS_IDX_ACTIVE"):
+        e["lds_bank_conflict_frac_of_lds_active"] = round(e.get("SQ_LDS_BANK_CONFLICT", 0.0) / e["SQ_LDS_IDX_ACTIVE"], 3)
+    if e.get("SQ_THREAD_CYCLES_VALU") and e.get("SQ_ACTIVE_INST_VALU"):
+        e["valu_lanes_active_frac"] = round(e["SQ_THREAD_CYCLES_VALU"] / (64.0 * e["SQ_ACTIVE_INST_VALU"]), 3)
     if e.get("SQ_WAVE_CYCLES"):
         e["wait_any_frac_of_wave_cycles"] = round(e.get("SQ_WAIT_ANY", 0.0) / e["SQ_WAVE_CYCLES"], 3)
 json.dump(sq, open(f"{P}/{name}_sq_counters.json", "w"), indent=1)

@@ -14,6 +14,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o pmc -- python3 $R/tools/pmc_workload.py 4 > $O/pmc_write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES --output-format csv -d $O/pmc_sq -o pmc -- python3 $R/tools/pmc_workload.py 4 > $O/pmc_sq.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM TCC_EA0_ATOMIC_sum --output-format csv -d $O/pmc_sq2 -o pmc -- python3 $R/tools/pmc_workload.py 4 > $O/pmc_sq2.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL SQ_LDS_ATOMIC_RETURN SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT --output-format csv -d $O/pmc_sq3 -o pmc -- python3 $R/tools/pmc_workload.py 4 > $O/pmc_sq3.log 2>&1
 (cd $R/tools/microbench && ./valu_issue_rate) > $O/valu_issue_rate.txt 2>&1
 ls -R $O | head -60
 tail -c 600 $O/bench_default.json
