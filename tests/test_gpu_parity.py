@@ -73,6 +73,27 @@ def test_vs_oracle_seeded(P, W, H, deg, mode, cov_mode, scale_mult, gpu_device):
     print({k: f"{v:.2e}" for k, v in rep.items()})
 
 
+def test_spatially_ordered_cloud_vs_oracle(gpu_device):
+    """Gaussians numbered along a Morton curve (index neighbours are spatial neighbours, the way mesh-bound Gaussians come): the waves of
+    k_preprocess_fwd then take the COMBINED counting path -- lanes that want the same tile rank themselves in LDS and share one atomic
+    (wave_tile_rank) -- which a randomly ordered cloud almost never does.  Lists, image and gradients against the oracle."""
+    from youreditableavatar_amd import scenes
+    cloud = scenes.morton_order(scenes.make_cloud(60_000, 2, seed=314, scale_mult=1.5))
+    cam = scenes.orbit_camera(640, 400, azimuth_deg=65.0)
+    inp = util.scene_input(cloud, cam)
+    dL = scenes.upstream_gradient(640, 400, seed=15)
+    ref = util.oracle_run(inp, dL)
+    mine = util.hip_run(inp, dL)
+    rep = util.compare(mine, ref)
+    assert rep["lists_equal"] > 0.999
+    util.record_parity("morton_ordered_60k", rep)
+    # how often index neighbours share their first tile here (the combined path needs >= 6 such lanes in a wave)
+    m2 = ref["means2D"]; vis = ref["radii"] > 0
+    t = (np.floor(m2[:, 0] / 16).astype(np.int64) + 40 * np.floor(m2[:, 1] / 16).astype(np.int64))
+    same = (t[1:] == t[:-1]) & vis[1:] & vis[:-1]
+    assert same.mean() > 0.3
+
+
 def test_backward_is_bitwise_reproducible(gpu_device):
     """Deterministic mode: no float atomics anywhere, two runs give identical bits (the reference's do not)."""
     from youreditableavatar_amd import scenes
