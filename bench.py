@@ -424,6 +424,8 @@ def secondary_workloads(a, cloud, dev, D, W, H, headline_ms):
     dL = g(scenes.upstream_gradient(W, H, seed=4321))
 
     def dropin(i):
+        for t in leaves.values():
+            t.grad = None                                   # optimizer.zero_grad(set_to_none=True), as the reference's trainers do every step (refine.py:323)
         m2 = torch.zeros(P, 3, device=dev, requires_grad=True)
         img, _radii = GaussianRasterizer(S[i % len(S)])(means3D=leaves["means3D"], means2D=m2, opacities=leaves["opacities"], shs=leaves["shs"],
                                                         scales=leaves["scales"], rotations=leaves["rotations"])
