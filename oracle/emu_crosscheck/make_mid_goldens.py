@@ -34,6 +34,8 @@ WINDOW = 256
 RECIPES = {
     "m01_mid_20k_256": dict(P=20_000, W=256, H=256, deg=3, seed=31, scale_mult=2.0, az=35.0, dl_seed=1031),
     "m02_cfg2_800": dict(P=100_000, W=800, H=800, deg=3, seed=scenes.CONFIGS[2]["seed"], scale_mult=1.0, az=0.0, dl_seed=scenes.CONFIGS[2]["seed"] + 1000),
+    # BASELINE config 3 = the headline workload at full size (500 000 Gaussians, 1920x1080, SH 3), view 0
+    "m03_cfg3_1080p": dict(P=500_000, W=1920, H=1080, deg=3, seed=scenes.CONFIGS[3]["seed"], scale_mult=1.0, az=0.0, dl_seed=scenes.CONFIGS[3]["seed"] + 1000),
 }
 
 
@@ -66,7 +68,10 @@ def subset_indices(P, seed):
 
 def main():
     Lf, Ln = mg.load("fma"), mg.load("nofma")
+    only = sys.argv[1:]
     for name, r in RECIPES.items():
+        if only and name not in only:
+            continue
         inp, dL = build_input(r)
         H, W, P = r["H"], r["W"], r["P"]
         t0 = time.time()

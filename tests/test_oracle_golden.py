@@ -28,14 +28,18 @@ def test_oracle_matches_golden(name):
 
 @pytest.mark.parametrize("name", util.mid_golden_names())
 def test_oracle_matches_mid_size_golden(name):
-    """20 000 Gaussians at 256x256 and BASELINE config 2 at full size (100 000 Gaussians, 800x800, SH 3): the oracle against the reference's
+    """20 000 Gaussians at 256x256, BASELINE config 2 (100 000 Gaussians, 800x800, SH 3) and config 3 -- the headline workload: 500 000
+    Gaussians, 1920x1080, SH 3 -- at full size: the oracle against the reference's
     kernel text under the emulation -- integer state (radii, num_rendered, tiles_touched, ranges, n_contrib) bit-exact, every tile's list
     equal except where two depths differ in the last bit between the FMA-contracted emulation build and the oracle (1 tile of 2500 at
     config 2: two entries whose view-space z is equal in one build and one ulp apart in the other), image and gradients (on the fixture's
     subset of Gaussians) within the parity bar."""
     inp, dL, fx = util.load_mid_golden(name)
     mine = util.oracle_run(inp, dL)
-    rep = util.compare_mid(mine, fx, exact_lists=True, nc_frac=1.0, list_frac=0.999)
+    # config 3 at full size: 31 of 8160 tile lists hold such a pair and 5 of 2 073 600 pixels end on one of them -- exactly the difference
+    # between the emulation's own two builds (FMA contraction on / off: n_contrib equal on 0.999998 of the pixels)
+    rep = util.compare_mid(mine, fx, exact_lists=True, nc_frac=0.99999, list_frac=0.995)
+    assert name == "m03_cfg3_1080p" or (rep["n_contrib_equal"] == 1.0 and rep["tile_lists_equal"] >= 0.999)
     print(name, {k: f"{v:.2e}" for k, v in rep.items()})
 
 
