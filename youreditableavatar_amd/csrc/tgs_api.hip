@@ -11,7 +11,7 @@ namespace tgs {
 void launch_preprocess_fwd(hipStream_t, const FwdIn&, const CamParams&, const GeomState&, const ImgState&);
 void launch_preprocess_fwd_batch(hipStream_t, const FwdIn&, const FwdViews&);
 void launch_scan(hipStream_t, const GeomState&, const ImgState&, uint32_t nblocks, uint32_t T, uint32_t sort_cap, unsigned long long r_capacity,
-                 int allow_overflow);
+                 int allow_overflow, Meta* host_meta);
 void launch_scatter(hipStream_t, int P, const GeomState&, const ImgState&, const BinState&, uint32_t gx);
 void launch_tile_sort(hipStream_t, const GeomState&, const ImgState&, const BinState&, uint32_t gx, uint32_t T, uint64_t r_bound, const Meta* m,
                       uint32_t sort_cap);
@@ -279,16 +279,19 @@ static int64_t forward_impl(int preprocessed, int64_t r_capacity, int64_t* specu
         launch_preprocess_fwd(st, in, cam, g, s);
         STAGE_CHECK("preprocess", TGS_STAGE_PREPROCESS_FWD);
     }
-    STAGE_BEGIN(TGS_STAGE_SCAN);
-    launch_scan(st, g, s, (uint32_t)n_blocks((size_t)P), (uint32_t)T, sort_cap, async ? (unsigned long long)r_capacity : ~0ull, async ? 0 : 1);
-    STAGE_CHECK("scan", TGS_STAGE_SCAN);
     SpecSlot* spec = nullptr;
     if (async && speculative_true_R) {
-        // speculative synchronous forward: Meta travels to the host NOW, the remaining stages are enqueued against the guessed
-        // capacity without waiting, and only then the host waits for this copy -- the GPU never idles behind the read-back
         spec = spec_slot();
         if (!spec) return fail(TGS_ERR_HIP, "pinned staging for the speculative forward could not be allocated");
-        HIP_TRY(hipMemcpyAsync(spec->meta, s.meta, sizeof(Meta), hipMemcpyDeviceToHost, st));
+    }
+    STAGE_BEGIN(TGS_STAGE_SCAN);
+    launch_scan(st, g, s, (uint32_t)n_blocks((size_t)P), (uint32_t)T, sort_cap, async ? (unsigned long long)r_capacity : ~0ull, async ? 0 : 1,
+                spec ? spec->meta : nullptr);
+    STAGE_CHECK("scan", TGS_STAGE_SCAN);
+    if (spec) {
+        // speculative synchronous forward: k_scan itself has written Meta into the pinned host slot; the event marks its end, the remaining
+        // stages are enqueued against the guessed capacity without waiting, and only then the host waits for the event -- the GPU never
+        // idles behind the read-back, and no copy sits in the stream
         HIP_TRY(hipEventRecord(spec->ready, st));
     }
     if (!async) {

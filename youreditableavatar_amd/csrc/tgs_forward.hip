@@ -408,7 +408,10 @@ __device__ __forceinline__ unsigned long long block_exscan_u64(unsigned long lon
     return base + inc - v;
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const ImgState s, uint32_t nblocks, uint32_t T, uint32_t sort_cap, unsigned long long r_capacity, int allow_overflow)
+// host_meta (may be NULL): a copy of Meta in pinned, device-visible HOST memory, written by the two workgroups themselves -- the speculative
+// forward's read-back without a copy engine or blit kernel in the stream (a D2H blit between k_scan and k_scatter cost 4 us + a 6-us gap)
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const ImgState s, uint32_t nblocks, uint32_t T, uint32_t sort_cap, unsigned long long r_capacity, int allow_overflow,
+                                                       Meta* host_meta)
 {
     __shared__ unsigned long long lds[SCAN_THREADS / WAVE];
     __shared__ uint32_t lds_max[SCAN_THREADS / WAVE];
@@ -429,7 +432,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const 
         }
         if (threadIdx.x == 0) {
             s.meta->R = carry;
-            if (carry > r_capacity) atomicOr(&s.meta->error, META_ERR_CAPACITY);     // tgs_forward_async: the frame does not fit
+            uint32_t err = s.meta->error;                   // (bit 0: a prefiltered Gaussian was culled, set by k_preprocess_fwd)
+            if (carry > r_capacity) { atomicOr(&s.meta->error, META_ERR_CAPACITY); err |= META_ERR_CAPACITY; }   // tgs_forward_async: the frame does not fit
+            if (host_meta) { host_meta->R = carry; host_meta->error = err; }
         }
     } else {
         // Tile pass.  One workgroup is latency bound, so every global access is issued 8-deep: the counters of a
@@ -499,6 +504,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const 
             for (int i = 0; i < SCAN_THREADS / WAVE; i++) m = lds_max[i] > m ? lds_max[i] : m;
             s.meta->max_count = m;
             s.meta->n_overflow = ovf_n;
+            if (host_meta) {
+                host_meta->max_count = m; host_meta->n_overflow = ovf_n;
+                host_meta->n_nonempty = s.meta->n_nonempty; host_meta->n_heavy = s.meta->n_heavy; host_meta->n_mid = s.meta->n_mid;   // (this thread wrote them above)
+            }
             (void)allow_overflow;                       // lists beyond the LDS sort are handled on the device (k_tile_sort's overflow workers): no rejection
         }
     }
@@ -1042,9 +1051,9 @@ void launch_preprocess_fwd_batch(hipStream_t st, const FwdIn& in, const FwdViews
     else hipLaunchKernelGGL((k_preprocess_fwd_batch<false, false>), grid, blk, 0, st, in, views);
 }
 void launch_scan(hipStream_t st, const GeomState& g, const ImgState& s, uint32_t nblocks, uint32_t T, uint32_t sort_cap, unsigned long long r_capacity,
-                 int allow_overflow)
+                 int allow_overflow, Meta* host_meta)
 {
-    hipLaunchKernelGGL(k_scan, dim3(2), dim3(SCAN_THREADS), 0, st, g, s, nblocks, T, sort_cap, r_capacity, allow_overflow);
+    hipLaunchKernelGGL(k_scan, dim3(2), dim3(SCAN_THREADS), 0, st, g, s, nblocks, T, sort_cap, r_capacity, allow_overflow, host_meta);
 }
 void launch_scatter(hipStream_t st, int P, const GeomState& g, const ImgState& s, const BinState& b, uint32_t gx)
 {
