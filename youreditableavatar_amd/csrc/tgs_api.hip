@@ -12,7 +12,8 @@ void launch_preprocess_fwd(hipStream_t, const FwdIn&, const CamParams&, const Ge
 void launch_preprocess_fwd_batch(hipStream_t, const FwdIn&, const FwdViews&);
 void launch_scan(hipStream_t, const GeomState&, const ImgState&, uint32_t nblocks, uint32_t T, uint32_t sort_cap, unsigned long long r_capacity,
                  int allow_overflow, Meta* host_meta);
-void launch_scatter(hipStream_t, int P, const GeomState&, const ImgState&, const BinState&, uint32_t gx);
+void launch_bin_count(hipStream_t, int P, const GeomState&, const ImgState&, uint32_t gx, uint32_t T);
+void launch_scatter(hipStream_t, int P, const GeomState&, const ImgState&, const BinState&, uint32_t gx, uint32_t T);
 void launch_tile_sort(hipStream_t, const GeomState&, const ImgState&, const BinState&, uint32_t gx, uint32_t T, uint64_t r_bound, const Meta* m,
                       uint32_t sort_cap);
 void launch_render_fwd(hipStream_t, const ImgState&, const BinState&, int W, int H, uint32_t gx, uint32_t T, const Meta* m, const float* bg,
@@ -262,9 +263,9 @@ static int64_t forward_impl(int preprocessed, int64_t r_capacity, int64_t* specu
     geom_carve(g, geom_ptr, (size_t)P, has_sh, has_sr);
     img_carve(s, img_ptr, N, T);
 
-    // meta + ranges + tile_count are contiguous at the head of the image buffer: one memset
-    // (preprocessed: tgs_forward_views has cleared them and run the per-Gaussian stage for all views at once)
-    if (!preprocessed) HIP_TRY(hipMemsetAsync(img_ptr, 0, (size_t)((char*)s.cursor - img_ptr), st));
+    // Meta sits at the head of the image buffer; everything else is written before it is read
+    // (preprocessed: tgs_forward_views has cleared it and run the per-Gaussian stage for all views at once)
+    if (!preprocessed) HIP_TRY(hipMemsetAsync(img_ptr, 0, (size_t)((char*)s.ranges - img_ptr), st));
 
     FwdIn in;
     in.P = P; in.D = D; in.M = M; in.means3D = means3D; in.shs = shs; in.colors_precomp = colors_precomp; in.opacities = opacities;
@@ -285,6 +286,7 @@ static int64_t forward_impl(int preprocessed, int64_t r_capacity, int64_t* specu
         if (!spec) return fail(TGS_ERR_HIP, "pinned staging for the speculative forward could not be allocated");
     }
     STAGE_BEGIN(TGS_STAGE_SCAN);
+    launch_bin_count(st, P, g, s, cam.gx, (uint32_t)T);
     launch_scan(st, g, s, (uint32_t)n_blocks((size_t)P), (uint32_t)T, sort_cap, async ? (unsigned long long)r_capacity : ~0ull, async ? 0 : 1,
                 spec ? spec->meta : nullptr);
     STAGE_CHECK("scan", TGS_STAGE_SCAN);
@@ -312,7 +314,7 @@ static int64_t forward_impl(int preprocessed, int64_t r_capacity, int64_t* specu
 
     if (R > 0) {
         STAGE_BEGIN(TGS_STAGE_SCATTER);
-        launch_scatter(st, P, g, s, b, cam.gx);
+        launch_scatter(st, P, g, s, b, cam.gx, (uint32_t)T);
         STAGE_CHECK("scatter", TGS_STAGE_SCATTER);
         STAGE_BEGIN(TGS_STAGE_TILE_SORT);
         launch_tile_sort(st, g, s, b, cam.gx, (uint32_t)T, R, known, sort_cap);
@@ -346,7 +348,7 @@ static int64_t forward_impl(int preprocessed, int64_t r_capacity, int64_t* specu
             if (!exact_ptr) return fail(TGS_ERR_ALLOC, "binning buffer allocation failed");
             bin_carve(b, exact_ptr, (size_t)R);
             if (R > 0) {
-                launch_scatter(st, P, g, s, b, cam.gx);
+                launch_scatter(st, P, g, s, b, cam.gx, (uint32_t)T);
                 launch_tile_sort(st, g, s, b, cam.gx, (uint32_t)T, R, &meta, sort_cap);
             }
             launch_render_fwd(st, s, b, width, height, cam.gx, (uint32_t)T, &meta, background, out_color);
@@ -550,7 +552,7 @@ int tgs_forward_views(void* const* streams, int n_streams, int64_t r_capacity, i
                 geom_carve(o.g, (char*)v.geom_buffer, (size_t)P, has_sh, has_sr);
                 img_carve(o.s, (char*)v.img_buffer, N, T);
                 o.radii = v.radii_out;
-                HIP_TRY(hipMemsetAsync((void*)v.img_buffer, 0, (size_t)((char*)o.s.cursor - (char*)v.img_buffer), st0));
+                HIP_TRY(hipMemsetAsync((void*)v.img_buffer, 0, (size_t)((char*)o.s.ranges - (char*)v.img_buffer), st0));
             }
             {
                 hipStream_t st = st0;

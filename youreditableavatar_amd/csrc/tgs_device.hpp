@@ -11,14 +11,14 @@ constexpr int TILE_PIX = TILE * TILE;
 constexpr int WAVE = 64;
 constexpr int PRE_BLOCK = 256;      // Gaussians per workgroup in the per-Gaussian kernels
 constexpr uint32_t SORT_LDS_CAP = 8192;   // longest tile list sorted inside LDS (64 KiB of u64 keys)
-constexpr int COOP_TILES = 64;
-constexpr int RANK_TILES = 4;        // splats touching at most this many tiles get their in-tile ranks while they are counted
+constexpr int COOP_TILES = 64;       // rectangles up to this size carry a 64-bit mask of their live tiles; their (splat, tile) pairs are spread over a wave
+constexpr int RANK_TILES = 4;        // rectangles up to this size (almost all) are binned by the splat's own lane
 constexpr int SLAB_ROW = 3;          // float4 per gradient-slab row: 9 sums padded to 48 B so rows move as three 16-B accesses
-#ifndef TGS_CSTRIDE
-#define TGS_CSTRIDE 16
-#endif
-static_assert(TGS_CSTRIDE >= 4, "the per-tile counter line holds 3 words");
-constexpr int CSTRIDE = TGS_CSTRIDE;  // u32 stride of the per-tile counters (16 = one counter per 64-B line)      // a Gaussian touching more tiles than this is emitted by the whole workgroup
+// Binning (k_bin_count / k_bin_colscan / k_scatter): the Gaussians are cut into BIN_WGS_MAX (or fewer) contiguous chunks, one fat
+// workgroup each, which count and later emit their instances through a per-tile table in LDS -- no global atomics.
+constexpr int BIN_WGS_MAX = 128;          // rows of the per-view table (bin_table: BIN_WGS_MAX x T words)
+constexpr int BIN_THREADS = 1024;
+constexpr uint32_t BIN_LDS_TILES = 24576; // tiles per pass of the LDS table (96 KB); larger tile grids are walked in bands
 
 // ---------------------------------------------------------------------------------------------
 // state buffers (opaque to callers; the reference's equivalents: rasterizer_impl.h:29-65)
@@ -41,9 +41,10 @@ struct GeomState {
     // .conic_opacity, .rgb of the reference, plus the tile rectangle and the slab offset):
     //   pack[4g+0] = (x, y, conic.x, conic.y)   pack[4g+1] = (conic.z, opacity, r, g)
     //   pack[4g+2] = (b, bits(minx | miny<<16), bits(maxx | maxy<<16), bits(offset))
-    //   pack[4g+3] = in-tile ranks of its (<= RANK_TILES) instances, row-major over the rectangle; for a rectangle of 5..COOP_TILES
-    //                tiles the 64-bit mask of its live tiles instead (.x low word, .y high word)
+    //   pack[4g+3] = for a rectangle of <= COOP_TILES tiles the 64-bit mask of its LIVE tiles, row-major (.x low word, .y high word):
+    //                a tile of the rectangle the splat cannot reach with alpha >= 1/255 gets no instance
     float4* pack;
+    uint2* live;              // the same mask once more, compact (the binning kernels read 20 B per Gaussian instead of its pack line)
     float* depth;             // view-space z                       (geomState.depths)
     float* cov3D;             // 6 floats, scale/rot path only      (geomState.cov3D)
     uint8_t* clamped;         // 3 clamp bits per Gaussian          (geomState.clamped)
@@ -55,9 +56,9 @@ struct GeomState {
 struct ImgState {
     Meta* meta;
     uint2* ranges;            // per tile [start, end)              (imgState.ranges)
-    uint32_t* tile_count;     // per tile, one 64-B line (CSTRIDE words): [0] instances of splats touching <= RANK_TILES tiles
-                              // (their ranks are taken in k_preprocess_fwd), [1] instances of larger splats, [2] k_scatter's cursor for those: an absolute list position, primed by k_scan
-    uint32_t* cursor;         // (unused, kept for layout stability)
+    uint32_t* tile_count;     // per tile: number of instances (k_bin_colscan)
+    uint32_t* bin_table;      // [BIN_WGS_MAX][T]: instances of binning chunk w in tile t (k_bin_count), then their first position
+                              // inside the tile's list (exclusive scan over w, k_bin_colscan)
     uint32_t* ovf_tiles;      // list of overflow tiles
     uint32_t* tile_order;     // tiles by descending list length: render kernels start the long lists first
     uint4* tile_desc;         // the same order with the range inlined: (tile, start, end, 0) -- one load instead of a dependent pair
@@ -89,7 +90,7 @@ __host__ __device__ inline size_t geom_carve(GeomState& g, char* base, size_t P,
 {
     char* p = base;
     (void)has_sh;
-    carve(p, g.pack, 4 * P); carve(p, g.depth, P); carve(p, g.cov3D, has_scale_rot ? 6 * P : 0);
+    carve(p, g.pack, 4 * P); carve(p, g.live, P); carve(p, g.depth, P); carve(p, g.cov3D, has_scale_rot ? 6 * P : 0);
     carve(p, g.clamped, P); carve(p, g.rect, P); carve(p, g.tiles_touched, P); carve(p, g.offsets, P);
     carve(p, g.block_sums, n_blocks(P) + 1);
     return (size_t)(p - base) + 256;
@@ -97,7 +98,7 @@ __host__ __device__ inline size_t geom_carve(GeomState& g, char* base, size_t P,
 __host__ __device__ inline size_t img_carve(ImgState& s, char* base, size_t N, size_t T)
 {
     char* p = base;
-    carve(p, s.meta, 1); carve(p, s.ranges, T); carve(p, s.tile_count, T * CSTRIDE); carve(p, s.cursor, 1);
+    carve(p, s.meta, 1); carve(p, s.ranges, T); carve(p, s.tile_count, T); carve(p, s.bin_table, (size_t)BIN_WGS_MAX * T);
     carve(p, s.ovf_tiles, T); carve(p, s.tile_order, T); carve(p, s.tile_desc, T); carve(p, s.tile_qmax, T);
     carve(p, s.final_T, N); carve(p, s.n_contrib, N);
     carve(p, s.stamps, 4 * T);

@@ -1,12 +1,15 @@
 // tgs_forward.hip -- forward pass kernels for gfx950 (wave64).
 //
 // Pipeline (what it replaces in cuda_rasterizer/rasterizer_impl.cu:198-336):
-//   k_preprocess_fwd   per-Gaussian EWA projection, SH colour, tile rectangle        (forward.cu:155-256)
-//                      + per-tile instance COUNT by integer atomics and per-block sums of tiles_touched
+//   k_preprocess_fwd   per-Gaussian EWA projection, SH colour, tile rectangle + the mask of its live tiles, per-block sums of
+//                      tiles_touched                                                    (forward.cu:155-256)
+//   k_bin_count        per-tile instance COUNT: the Gaussians in BIN_WGS contiguous chunks, one fat workgroup each with a
+//                      per-tile table in LDS -- no global atomics                       (the tile half of duplicateWithKeys' keys)
+//   k_bin_colscan      per tile: exclusive scan of the chunks' counts (-> where chunk w's instances start inside the tile's list)
 //   k_scan             exclusive scans: block sums (-> Gaussian offsets) and tile counts (-> ranges)
 //                                                                   (cub InclusiveSum, identifyTileRanges)
 //   [host reads R, longest list]                                     (the reference's D2H copy, :280-281)
-//   k_scatter          every instance goes straight to its tile's segment              (duplicateWithKeys)
+//   k_scatter          every instance goes straight to its tile's segment: the same chunks, LDS cursors   (duplicateWithKeys)
 //   k_tile_sort*       per-tile sort by (depth, index) inside LDS; lists longer than       (cub SortPairs)
 //                      SORT_LDS_CAP take the k_ovf_* path
 //   k_finalize         gather of the per-instance records in sorted order + the 64-bit quadrant mask of each
@@ -107,53 +110,14 @@ __device__ __forceinline__ bool tile_reachable(float2 xy, float4 co, uint32_t tx
     return !(fminf(fminf(e0, e1), fminf(e2, e3)) > tau * 1.001f);
 }
 
-constexpr uint32_t RANK_DEAD = 0xffffffffu;   // rank slot of a rectangle tile the splat cannot reach with alpha >= 1/255: no instance
-constexpr uint32_t RANK_DEAD_VALUE = RANK_DEAD;
-
-// Ranks of a wave's instances in their tiles (call from CONVERGENT code): lane l wants an instance in tile `t` (TILE_NONE: none).
-// Lanes of the wave that want the SAME tile are combined -- they rank themselves in LDS and one of them takes the whole group's
-// range from the tile's counter with ONE returning atomic.  The counters are updated at the memory side at ~20 G requests/s
-// chip-wide whatever the address pattern (profiles/: TCC_EA0_ATOMIC ~ instances, the kernel's largest cost), so what counts is the
-// number of requests: Gaussians that are neighbours in index AND in space (mesh-bound Gaussians are: TetGS binds them to the
-// faces of a marching-tetrahedra surface) share tiles inside a wave and need a fraction of the atomics; for a randomly
-// ordered cloud nearly every group is a single lane and this costs a few LDS operations per instance.
-constexpr uint32_t TILE_NONE = 0xffffffffu;
-struct WaveRankTab { uint32_t tile[WAVE]; uint32_t cnt[WAVE]; uint32_t base[WAVE]; };
-__device__ __forceinline__ uint32_t wave_tile_rank(uint32_t t, uint32_t* __restrict__ tile_count, WaveRankTab& tab)
-{
-    uint32_t rank = RANK_DEAD_VALUE;
-    bool pending = t != TILE_NONE;
-    while (__builtin_amdgcn_ballot_w64(pending) != 0ull) {                 // wave-uniform
-        const uint32_t slot = (t ^ (t >> 6)) & 63u;
-        if (pending) tab.tile[slot] = t;                                    // one of the lanes that hash here wins the slot
-        wave_sync();
-        const bool mine = pending && tab.tile[slot] == t;
-        uint32_t r = 0;
-        if (mine) r = atomicAdd(&tab.cnt[slot], 1u);                        // ds_add_rtn_u32: my rank inside the group
-        wave_sync();
-        if (mine && r == 0u) {                                              // the group's first lane fetches the range for all of them
-            const uint32_t n = tab.cnt[slot];
-            tab.cnt[slot] = 0u;
-            tab.base[slot] = atomicAdd(&tile_count[(size_t)t * CSTRIDE], n);
-        }
-        wave_sync();
-        if (mine) { rank = tab.base[slot] + r; pending = false; }
-        wave_sync();
-    }
-    return rank;
-}
-
-// One Gaussian of one view: projection, EWA covariance, SH colour, tile rectangle, the 64-B pack line, and the per-tile
-// instance count whose returned values are the instance's ranks.  Shared by the one-view and the all-views kernel.
+// One Gaussian of one view: projection, EWA covariance, SH colour, tile rectangle, the mask of the rectangle's live tiles and
+// the 64-B pack line.  Shared by the one-view and the all-views kernel.
 template <bool HAS_SH, bool HAS_SCALE_ROT>
 __device__ __forceinline__ uint32_t preprocess_fwd_one(const FwdIn& in, int* __restrict__ radii, const CamParams& cam, const GeomState& g, const ImgState& s,
                                                        const float4* sh_lds, bool sh_staged, int idx)
 {
 #pragma clang fp contract(off)      // projection, covariance, radius and colour un-fused: the oracle's (and the reference's source's) operation order
     uint32_t tiles = 0;
-    uint32_t want[RANK_TILES] = {TILE_NONE, TILE_NONE, TILE_NONE, TILE_NONE};   // tiles of a <= 4-tile rectangle that get an instance
-    bool ranked = false, has_pack = false;
-    float4 pk0 = make_float4(0.f, 0.f, 0.f, 0.f), pk1 = pk0, pk2 = pk0, pk3 = pk0;
     const ViewMat V = load_mat(cam.view), PM = load_mat(cam.proj);      // uniform -> scalar loads, before any store
     const float camx = cam.campos[0], camy = cam.campos[1], camz = cam.campos[2];
     if (idx < in.P) {
@@ -257,82 +221,42 @@ __device__ __forceinline__ uint32_t preprocess_fwd_one(const FwdIn& in, int* __r
                     }
                     g.depth[idx] = view_z;
                     my_radius_i = (int)my_radius;
-                    // the 64-B pack line is stored in one go at the end (with the ranks, which are taken in convergent code)
-                    has_pack = true;
-                    pk0 = make_float4(pix, piy, conx, cony);
-                    pk1 = make_float4(conz, in.opacities[idx], col0, col1);
-                    pk2 = make_float4(col2, __uint_as_float(minx | (miny << 16)), __uint_as_float(maxx | (maxy << 16)), 0.f);   // .w: slab offset, k_scatter
-                    // Per-tile instance count (replaces the tile half of the reference's 64-bit sort keys).  A splat on <= 4 tiles
-                    // (almost all) takes its rank inside each tile from the same atomic, so k_scatter needs no second atomic pass.
+                    // The 3-sigma square over-covers: a tile of the rectangle where the splat stays below alpha = 1/255 everywhere
+                    // (tile_reachable: the conservative test that masks the 4x4 blocks for the render kernels, applied to the whole
+                    // tile, so nothing that could be blended is lost) gets no instance at all -- no count, no key, no sort, no record
+                    // (about a fifth of them).  The live tiles of a rectangle of <= COOP_TILES tiles are a 64-bit mask, row-major.
+                    const float opac = in.opacities[idx];
+                    unsigned long long live_mask = 0ull;
                     if (tiles <= (uint32_t)RANK_TILES) {
-                        // The 3-sigma square over-covers: a tile of the rectangle where the splat stays below alpha = 1/255 everywhere
-                        // (tile_reachable: the conservative test that masks the 4x4 blocks for the render kernels, applied to the whole
-                        // tile, so nothing that could be blended is lost) gets no instance at all -- no count, no key, no sort, no record (about a fifth of them).
-                        // The live tiles are only LISTED here; their ranks are taken below, in convergent code, wave by wave (wave_tile_rank).
-                        const uint32_t rw = maxx - minx, area = tiles;
-                        const float opac = in.opacities[idx];
-                        uint32_t live = 0;
+                        uint32_t kx = 0, ky = 0;
 #pragma unroll
-                        for (int k = 0; k < RANK_TILES; k++) {     // constant indices: want stays in registers
-                            if ((uint32_t)k < area) {
-                                const uint32_t tx = minx + k % rw, ty = miny + k / rw;
-                                if (!in.prune || tile_reachable(make_float2(pix, piy), make_float4(conx, cony, conz, opac), tx, ty)) {
-                                    want[k] = ty * cam.gx + tx;
-                                    live++;
-                                }
+                        for (int k = 0; k < RANK_TILES; k++) {
+                            if ((uint32_t)k < tiles) {
+                                if (!in.prune || tile_reachable(make_float2(pix, piy), make_float4(conx, cony, conz, opac), minx + kx, miny + ky)) live_mask |= 1ull << k;
+                                if (++kx == maxx - minx) { kx = 0; ky++; }
                             }
                         }
-                        ranked = true;
-                        tiles = live;
+                        tiles = (uint32_t)__builtin_popcountll(live_mask);
                     } else if (tiles <= (uint32_t)COOP_TILES) {
-                        // 5..64 tiles: the same pruning, the live tiles as a 64-bit mask over the rectangle (row-major) in the rank slots
-                        const float opac = in.opacities[idx];
-                        unsigned long long live_mask = 0ull;
                         uint32_t k = 0;
                         for (uint32_t ty = miny; ty < maxy; ty++)
                             for (uint32_t tx = minx; tx < maxx; tx++, k++)
-                                if (!in.prune || tile_reachable(make_float2(pix, piy), make_float4(conx, cony, conz, opac), tx, ty)) {
-                                    atomicAdd(&s.tile_count[(size_t)(ty * cam.gx + tx) * CSTRIDE + 1], 1u);
-                                    live_mask |= 1ull << k;
-                                }
-                        pk3 = make_float4(__uint_as_float((uint32_t)live_mask), __uint_as_float((uint32_t)(live_mask >> 32)), 0.f, 0.f);
+                                if (!in.prune || tile_reachable(make_float2(pix, piy), make_float4(conx, cony, conz, opac), tx, ty)) live_mask |= 1ull << k;
                         tiles = (uint32_t)__builtin_popcountll(live_mask);
-                    } else {
-                        for (uint32_t ty = miny; ty < maxy; ty++)
-                            for (uint32_t tx = minx; tx < maxx; tx++) atomicAdd(&s.tile_count[(size_t)(ty * cam.gx + tx) * CSTRIDE + 1], 1u);
                     }
+                    // the 64-B pack line in one go (.w of the third quarter: slab offset, k_scatter)
+                    float4* pk = g.pack + 4 * (size_t)idx;
+                    pk[0] = make_float4(pix, piy, conx, cony);
+                    pk[1] = make_float4(conz, opac, col0, col1);
+                    pk[2] = make_float4(col2, __uint_as_float(minx | (miny << 16)), __uint_as_float(maxx | (maxy << 16)), 0.f);
+                    pk[3] = make_float4(__uint_as_float((uint32_t)live_mask), __uint_as_float((uint32_t)(live_mask >> 32)), 0.f, 0.f);
+                    g.live[idx] = make_uint2((uint32_t)live_mask, (uint32_t)(live_mask >> 32));
                 }
             }
         }
         if (radii) radii[idx] = my_radius_i;
         g.tiles_touched[idx] = tiles;
         g.rect[idx] = make_ushort4((unsigned short)minx, (unsigned short)miny, (unsigned short)maxx, (unsigned short)maxy);
-    }
-    // Per-tile instance count of the splats on <= 4 tiles (almost all): the value the counter returns is the instance's rank inside its
-    // tile (stored in the pack line), so k_scatter needs no second atomic pass.  Convergent: every lane of the wave takes part.
-    {
-        __shared__ WaveRankTab rank_tab[PRE_BLOCK / WAVE];
-        WaveRankTab& tab = rank_tab[threadIdx.x >> 6];
-        tab.cnt[threadIdx.x & 63] = 0u;
-        wave_sync();
-        uint32_t rk[RANK_TILES] = {RANK_DEAD, RANK_DEAD, RANK_DEAD, RANK_DEAD};
-        // Combining pays when index neighbours share tiles (measured at config 3, Gaussians along a Morton curve: 171 -> 62 us, plain
-        // atomics of a wave on ONE counter serialise at the memory side) and costs ~6 us of LDS round trips when they do not
-        // (random order: 97 -> 102 us), so the wave looks first: how many lanes want the tile their index neighbour wants?
-        const uint32_t nb = (uint32_t)__shfl_down((int)want[0], 1, 64);
-        const bool combine = __builtin_popcountll(__builtin_amdgcn_ballot_w64(want[0] != TILE_NONE && want[0] == nb)) >= 6;
-        if (combine) {
-#pragma unroll
-            for (int k = 0; k < RANK_TILES; k++) rk[k] = wave_tile_rank(want[k], s.tile_count, tab);
-        } else {
-#pragma unroll
-            for (int k = 0; k < RANK_TILES; k++) if (want[k] != TILE_NONE) rk[k] = atomicAdd(&s.tile_count[(size_t)want[k] * CSTRIDE], 1u);
-        }
-        if (ranked) pk3 = make_float4(__uint_as_float(rk[0]), __uint_as_float(rk[1]), __uint_as_float(rk[2]), __uint_as_float(rk[3]));
-        if (has_pack) {
-            float4* pk = g.pack + 4 * (size_t)idx;
-            pk[0] = pk0; pk[1] = pk1; pk[2] = pk2; pk[3] = pk3;
-        }
     }
     return tiles;
 }
@@ -442,7 +366,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const 
         // longest-list search and the length histogram then run out of LDS.
         constexpr uint32_t SC = SCAN_THREADS * 8;
         __shared__ uint32_t lc[SC];
-        __shared__ uint32_t lc0[SC];                        // the share of splats on <= RANK_TILES tiles (they hold their ranks already)
         __shared__ uint32_t hist[34];
         if (threadIdx.x == 0) ovf_n = 0;
         if (threadIdx.x < 34) hist[threadIdx.x] = 0;
@@ -451,11 +374,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const 
         uint32_t mx = 0;
         for (uint32_t sc = 0; sc < T; sc += SC) {
             const uint32_t n = min(SC, T - sc);
-            uint32_t v[8], v0[8];
+            uint32_t v[8];
 #pragma unroll
-            for (int k = 0; k < 8; k++) { const uint32_t i = k * SCAN_THREADS + threadIdx.x; if (i < n) { const uint2 c2 = *reinterpret_cast<const uint2*>(&s.tile_count[(size_t)(sc + i) * CSTRIDE]); v[k] = c2.x + c2.y; v0[k] = c2.x; } else { v[k] = 0u; v0[k] = 0u; } }
+            for (int k = 0; k < 8; k++) { const uint32_t i = k * SCAN_THREADS + threadIdx.x; v[k] = i < n ? s.tile_count[sc + i] : 0u; }
 #pragma unroll
-            for (int k = 0; k < 8; k++) { lc[k * SCAN_THREADS + threadIdx.x] = v[k]; lc0[k * SCAN_THREADS + threadIdx.x] = v0[k]; }
+            for (int k = 0; k < 8; k++) lc[k * SCAN_THREADS + threadIdx.x] = v[k];
             __syncthreads();
             unsigned long long sum = 0;
             const uint32_t i0 = threadIdx.x * 8;
@@ -468,8 +391,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const 
                 if (i0 + k < n) {
                     const uint32_t t = sc + i0 + k;
                     s.ranges[t] = make_uint2((uint32_t)ex, (uint32_t)(ex + v[k]));
-                    // cursor of the larger splats (k_scatter): they follow the ranked instances of the small ones
-                    if (v[k] != lc0[i0 + k]) s.tile_count[(size_t)t * CSTRIDE + 2] = (uint32_t)ex + lc0[i0 + k];
                     if (v[k] > sort_cap) s.ovf_tiles[atomicAdd(&ovf_n, 1u)] = t;
                     atomicAdd(&hist[v[k] ? 32 - __builtin_clz(v[k]) : 0], 1u);
                 }
@@ -514,93 +435,169 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const 
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_scatter: instance -> its tile's segment.  Also finishes the Gaussian offsets (exclusive scan).
+// Binning without global atomics.  The per-tile counters of a frame would be ~1 M memory-side atomic requests (one per instance, ~18 G/s
+// chip-wide whatever the address pattern: half of k_preprocess_fwd's time when it took them).  Instead the Gaussians are cut into
+// `nchunks` contiguous chunks, one 1024-thread workgroup each (a multiple of 1024 Gaussians: every thread walks the same number of
+// steps), and a chunk keeps the per-tile table in LDS:
+//   k_bin_count    table[w][t] = instances of chunk w in tile t                                  (ds_add_u32)
+//   k_bin_colscan  per tile: exclusive scan over w in place, total -> tile_count[t]
+//   k_scan         ranges[t] from tile_count                                                     (as before)
+//   k_scatter      chunk w again: cursor[t] = ranges[t].x + table[w][t] in LDS, every instance takes its position with a returning
+//                  ds_add and stores its key there
+// The order of a chunk's instances inside a tile is whatever the LDS atomics make it; k_tile_sort orders by (depth, index) anyway.
+// Tile grids beyond BIN_LDS_TILES are walked in bands of that many tiles (one more pass over the chunk per band).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PRE_BLOCK) void k_scatter(int P, const GeomState g, const ImgState s, const BinState b, uint32_t gx)
-{
-    __shared__ uint32_t wtot[PRE_BLOCK / WAVE];
-    __shared__ uint32_t queue[PRE_BLOCK];
-    __shared__ uint32_t qn;
-    __shared__ uint32_t mid_excl[PRE_BLOCK / WAVE][WAVE];
-    __shared__ unsigned long long mid_keys[PRE_BLOCK / WAVE][WAVE];
-    __shared__ uint2 mid_rects[PRE_BLOCK / WAVE][WAVE];
-    __shared__ unsigned long long mid_lives[PRE_BLOCK / WAVE][WAVE];
-    unsigned long long mid_live = 0;
-    uint32_t mid_area = 0;
-    unsigned long long mid_key = 0;
-    uint2 mid_rect = make_uint2(0u, 1u);
-    const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (frame_rejected(s)) return;
-    if (threadIdx.x == 0) qn = 0;
-    const uint32_t tiles = idx < P ? g.tiles_touched[idx] : 0u;
-    const uint32_t inc = wave_iscan_u32(tiles, lane);
-    if (lane == 63) wtot[wv] = inc;
-    __syncthreads();
-    uint32_t base = g.block_sums[blockIdx.x];
-    for (int i = 0; i < wv; i++) base += wtot[i];
-    if (idx < P) {
-        g.offsets[idx] = base + inc - tiles;
-        if (tiles > 0) reinterpret_cast<uint32_t*>(g.pack + 4 * (size_t)idx + 2)[3] = base + inc - tiles;
-    }
+// rectangles of 5..COOP_TILES tiles: the wave's (splat, tile) pairs are spread over its lanes, 64 pairs per step
+struct MidTab { uint32_t excl[WAVE]; uint2 rect[WAVE]; unsigned long long live[WAVE]; unsigned long long key[WAVE]; };
 
-    if (tiles > 0) {
-        const unsigned long long key = ((unsigned long long)__float_as_uint(g.depth[idx]) << 32) | (uint32_t)idx;
-        const ushort4 r = g.rect[idx];
-        const uint32_t rw = (uint32_t)r.z - r.x, area = rw * ((uint32_t)r.w - r.y);      // tiles <= area: dead tiles of small rectangles have no instance
-        if (area <= (uint32_t)RANK_TILES) {
-            // position = start of the tile's segment + the rank taken in k_preprocess_fwd: no atomic
-            const float4 rk4 = g.pack[4 * (size_t)idx + 3];
-            const uint32_t rk[RANK_TILES] = {__float_as_uint(rk4.x), __float_as_uint(rk4.y), __float_as_uint(rk4.z), __float_as_uint(rk4.w)};
+// Calls f(tile, key) once for every instance of the wave's 64 Gaussians (lane l: `tiles` instances after pruning, rectangle r, live
+// mask, key).  Convergent: every lane of the wave calls this.  <= RANK_TILES tiles (almost all): the lane itself; up to COOP_TILES:
+// pairs spread over the lanes (prefix sum of the areas + a 6-step search in LDS; one lane walking a 64-tile rectangle of its own
+// would hold the wave for 64 steps); larger: the whole wave, one rectangle after the other (the reference's thread-serial double
+// loop, rasterizer_impl.cu:98-109, is its tail-latency problem).
+template <typename F>
+__device__ __forceinline__ void wave_emit_instances(uint32_t tiles, ushort4 r, uint2 live2, unsigned long long key, uint32_t gx, MidTab& tab, int lane, F&& f)
+{
+    const uint32_t rw = (uint32_t)r.z - r.x, area = tiles ? rw * ((uint32_t)r.w - r.y) : 0u;
+    const unsigned long long live = (unsigned long long)live2.x | ((unsigned long long)live2.y << 32);
+    if (area != 0 && area <= (uint32_t)RANK_TILES) {
+        uint32_t kx = 0, t = (uint32_t)r.y * gx + r.x;
 #pragma unroll
-            for (int k = 0; k < RANK_TILES; k++)
-                if ((uint32_t)k < area && rk[k] != RANK_DEAD) b.keys[s.ranges[(r.y + k / rw) * gx + r.x + k % rw].x + rk[k]] = key;
-        } else if (area <= (uint32_t)COOP_TILES) {
-            mid_area = area;                                // emitted below by the whole wave
-            mid_key = key;
-            mid_rect = make_uint2((uint32_t)r.x | ((uint32_t)r.y << 16), rw);
-            const float4 lm = g.pack[4 * (size_t)idx + 3];  // live tiles of the rectangle (k_preprocess_fwd)
-            mid_live = (unsigned long long)__float_as_uint(lm.x) | ((unsigned long long)__float_as_uint(lm.y) << 32);
-        } else {
-            queue[atomicAdd(&qn, 1u)] = (uint32_t)idx;
-        }
-    }
-    // Splats on 5..COOP_TILES tiles: their (splat, tile) pairs are spread over the wave's lanes, 64 pairs per step, so that the
-    // 64 cursor atomics of a step are in flight together.  (One lane walking its own rectangle waits for every returned cursor
-    // before the next store: ~2 us per tile, the whole kernel's duration at larger splats -- 487 us at 4x the scales of config 3.)
-    {
-        const uint32_t incl = wave_iscan_u32(mid_area, lane), total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        if (total > 0) {                                    // wave-uniform
-            mid_excl[wv][lane] = incl - mid_area;
-            mid_keys[wv][lane] = mid_key;
-            mid_rects[wv][lane] = mid_rect;
-            mid_lives[wv][lane] = mid_live;
-            wave_sync();
-            for (uint32_t w = lane; w < total; w += 64) {
-                uint32_t lo = 0, hi = 63;                   // owner: the last lane whose first pair is <= w (lanes without pairs share their successor's start)
-#pragma unroll
-                for (int it = 0; it < 6; it++) { const uint32_t mid = (lo + hi + 1) >> 1; if (mid_excl[wv][mid] <= w) lo = mid; else hi = mid - 1; }
-                const uint2 rc = mid_rects[wv][lo];
-                const uint32_t k = w - mid_excl[wv][lo], rw2 = rc.y;
-                if (!((mid_lives[wv][lo] >> k) & 1ull)) continue;     // a tile of the rectangle the splat cannot reach: no instance
-                const uint32_t ky = k / rw2, tx = (rc.x & 0xffffu) + (k - ky * rw2), ty = (rc.x >> 16) + ky;
-                b.keys[atomicAdd(&s.tile_count[(size_t)(ty * gx + tx) * CSTRIDE + 2], 1u)] = mid_keys[wv][lo];      // (cursor primed by k_scan)
+        for (int k = 0; k < RANK_TILES; k++) {
+            if ((uint32_t)k < area) {
+                if ((live2.x >> k) & 1u) f(t + kx, key);
+                if (++kx == rw) { kx = 0; t += gx; }
             }
         }
     }
-    __syncthreads();
-    // large splats: the whole workgroup emits one Gaussian's rectangle (the reference's thread-serial
-    // double loop, rasterizer_impl.cu:98-109, is its tail-latency problem)
-    const uint32_t nq = qn;
-    for (uint32_t q = 0; q < nq; q++) {
-        const uint32_t id = queue[q];
-        const ushort4 r = g.rect[id];
-        const uint32_t w = (uint32_t)r.z - r.x, n = w * ((uint32_t)r.w - r.y);
-        const unsigned long long key = ((unsigned long long)__float_as_uint(g.depth[id]) << 32) | id;
-        for (uint32_t k = threadIdx.x; k < n; k += PRE_BLOCK) {
-            const uint32_t ty = r.y + k / w, tx = r.x + k % w;
-            b.keys[atomicAdd(&s.tile_count[(size_t)(ty * gx + tx) * CSTRIDE + 2], 1u)] = key;
+    const uint32_t mid_area = (area > (uint32_t)RANK_TILES && area <= (uint32_t)COOP_TILES) ? area : 0u;
+    const uint32_t incl = wave_iscan_u32(mid_area, lane), total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    if (total > 0) {                                        // wave-uniform
+        tab.excl[lane] = incl - mid_area;
+        tab.rect[lane] = make_uint2((uint32_t)r.x | ((uint32_t)r.y << 16), rw);
+        tab.live[lane] = live;
+        tab.key[lane] = key;
+        wave_sync();
+        for (uint32_t w = lane; w < total; w += 64) {
+            uint32_t lo = 0, hi = 63;                       // owner: the last lane whose first pair is <= w (lanes without pairs share their successor's start)
+#pragma unroll
+            for (int it = 0; it < 6; it++) { const uint32_t mid = (lo + hi + 1) >> 1; if (tab.excl[mid] <= w) lo = mid; else hi = mid - 1; }
+            const uint2 rc = tab.rect[lo];
+            const uint32_t k = w - tab.excl[lo], rw2 = rc.y;
+            if (!((tab.live[lo] >> k) & 1ull)) continue;    // a tile of the rectangle the splat cannot reach: no instance
+            const uint32_t ky = k / rw2;
+            f(((rc.x >> 16) + ky) * gx + (rc.x & 0xffffu) + (k - ky * rw2), tab.key[lo]);
         }
+        wave_sync();                                        // the table is reused by the wave's next step
+    }
+    unsigned long long bigs = __builtin_amdgcn_ballot_w64(area > (uint32_t)COOP_TILES);
+    while (bigs) {                                          // wave-uniform
+        const int src = __builtin_ctzll(bigs);
+        bigs &= bigs - 1;
+        const uint32_t x0 = (uint32_t)__builtin_amdgcn_readlane((int)r.x, src), y0 = (uint32_t)__builtin_amdgcn_readlane((int)r.y, src);
+        const uint32_t w2 = (uint32_t)__builtin_amdgcn_readlane((int)rw, src), n = (uint32_t)__builtin_amdgcn_readlane((int)area, src);
+        const unsigned long long kk = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(key >> 32), src) << 32) |
+                                      (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, src);
+        for (uint32_t k = lane; k < n; k += 64) { const uint32_t ky = k / w2; f((y0 + ky) * gx + x0 + (k - ky * w2), kk); }
+    }
+}
+
+__global__ __launch_bounds__(BIN_THREADS) void k_bin_count(int P, uint32_t chunk, const GeomState g, const ImgState s, uint32_t gx, uint32_t T, uint32_t band)
+{
+    extern __shared__ uint32_t bin_lds[];                   // min(T, band) counters
+    __shared__ MidTab tabs[BIN_THREADS / WAVE];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t lo = blockIdx.x * chunk;
+    uint32_t* row = s.bin_table + (size_t)blockIdx.x * T;
+    for (uint32_t band0 = 0; band0 < T; band0 += band) {
+        const uint32_t nb = min(band, T - band0);
+        for (uint32_t i = threadIdx.x; i < nb; i += BIN_THREADS) bin_lds[i] = 0u;
+        __syncthreads();
+#pragma unroll 1
+        for (uint32_t base = lo; base < lo + chunk; base += BIN_THREADS) {
+            const uint32_t idx = base + threadIdx.x;
+            const uint32_t tiles = idx < (uint32_t)P ? g.tiles_touched[idx] : 0u;
+            ushort4 r = make_ushort4(0, 0, 0, 0);
+            uint2 live = make_uint2(0u, 0u);
+            if (tiles) { r = g.rect[idx]; live = g.live[idx]; }
+            wave_emit_instances(tiles, r, live, 0ull, gx, tabs[wv], lane, [&](uint32_t t, unsigned long long) {
+                if (t - band0 < nb) atomicAdd(&bin_lds[t - band0], 1u);
+            });
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < nb; i += BIN_THREADS) row[band0 + i] = bin_lds[i];
+        __syncthreads();
+    }
+}
+
+// per tile: table[w][t] <- sum of table[w'][t], w' < w; tile_count[t] <- the total.  64 tiles per workgroup, wave q takes a quarter of the chunks.
+__global__ __launch_bounds__(256) void k_bin_colscan(const ImgState s, uint32_t T, uint32_t nchunks)
+{
+    __shared__ uint32_t part[4][WAVE];
+    const int q = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const uint32_t t = blockIdx.x * WAVE + l;
+    const uint32_t per = (nchunks + 3) / 4, w0 = min(nchunks, q * per), w1 = min(nchunks, w0 + per);
+    uint32_t* col = s.bin_table + t;
+    uint32_t c[32];                                         // per <= BIN_WGS_MAX / 4
+    uint32_t sum = 0;
+    if (t < T) {
+#pragma unroll
+        for (int k = 0; k < BIN_WGS_MAX / 4; k++) { c[k] = w0 + k < w1 ? col[(size_t)(w0 + k) * T] : 0u; }
+#pragma unroll
+        for (int k = 0; k < BIN_WGS_MAX / 4; k++) sum += c[k];
+    }
+    part[q][l] = sum;
+    __syncthreads();
+    if (t < T) {
+        uint32_t run = 0;
+        for (int i = 0; i < q; i++) run += part[i][l];
+#pragma unroll
+        for (int k = 0; k < BIN_WGS_MAX / 4; k++) { if (w0 + k < w1) col[(size_t)(w0 + k) * T] = run; run += c[k]; }
+        if (q == 3) s.tile_count[t] = run;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_scatter: instance -> its tile's segment.  Also finishes the Gaussian offsets (exclusive scan).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BIN_THREADS) void k_scatter(int P, uint32_t chunk, const GeomState g, const ImgState s, const BinState b, uint32_t gx, uint32_t T, uint32_t band)
+{
+    extern __shared__ uint32_t bin_lds[];                   // min(T, band) cursors: absolute positions in b.keys
+    __shared__ MidTab tabs[BIN_THREADS / WAVE];
+    __shared__ uint32_t wtot[2][BIN_THREADS / WAVE];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (frame_rejected(s)) return;
+    const uint32_t lo = blockIdx.x * chunk;
+    const uint32_t* row = s.bin_table + (size_t)blockIdx.x * T;
+    for (uint32_t band0 = 0; band0 < T; band0 += band) {
+        const uint32_t nb = min(band, T - band0);
+        for (uint32_t i = threadIdx.x; i < nb; i += BIN_THREADS) bin_lds[i] = s.ranges[band0 + i].x + row[band0 + i];
+        __syncthreads();
+        int par = 0;
+#pragma unroll 1
+        for (uint32_t base = lo; base < lo + chunk; base += BIN_THREADS, par ^= 1) {
+            const uint32_t idx = base + threadIdx.x;
+            const uint32_t tiles = idx < (uint32_t)P ? g.tiles_touched[idx] : 0u;
+            if (band0 == 0) {                               // offsets[idx] = block_sums[its PRE_BLOCK] + prefix inside the block
+                const uint32_t inc = wave_iscan_u32(tiles, lane);
+                if (lane == 63) wtot[par][wv] = inc;
+                __syncthreads();
+                if (idx < (uint32_t)P) {
+                    uint32_t off = g.block_sums[idx / PRE_BLOCK] + inc - tiles;
+                    for (int i = wv & ~3; i < wv; i++) off += wtot[par][i];
+                    g.offsets[idx] = off;
+                    if (tiles > 0) reinterpret_cast<uint32_t*>(g.pack + 4 * (size_t)idx + 2)[3] = off;
+                }
+            }
+            ushort4 r = make_ushort4(0, 0, 0, 0);
+            uint2 live = make_uint2(0u, 0u);
+            unsigned long long key = 0ull;
+            if (tiles) { r = g.rect[idx]; live = g.live[idx]; key = ((unsigned long long)__float_as_uint(g.depth[idx]) << 32) | idx; }
+            wave_emit_instances(tiles, r, live, key, gx, tabs[wv], lane, [&](uint32_t t, unsigned long long k) {
+                if (t - band0 < nb) b.keys[atomicAdd(&bin_lds[t - band0], 1u)] = k;
+            });
+        }
+        __syncthreads();
     }
 }
 
@@ -625,14 +622,7 @@ __device__ __forceinline__ void finalize_entry(unsigned long long key, uint32_t 
     // row of this instance in the gradient slab: the Gaussian's rows are its LIVE tiles in rectangle order
     const uint32_t rw = maxx - minx, k = (ty - miny) * rw + (tx - minx);
     uint32_t ord = k;
-    const uint32_t area = rw * (maxy - miny);
-    if (area <= (uint32_t)RANK_TILES) {
-        const float4 p3 = pk[3];
-        const uint32_t rk[RANK_TILES] = {__float_as_uint(p3.x), __float_as_uint(p3.y), __float_as_uint(p3.z), __float_as_uint(p3.w)};
-        ord = 0;
-#pragma unroll
-        for (int j = 0; j < RANK_TILES; j++) if ((uint32_t)j < k && rk[j] != RANK_DEAD) ord++;
-    } else if (area <= (uint32_t)COOP_TILES) {
+    if (rw * (maxy - miny) <= (uint32_t)COOP_TILES) {
         const float4 p3 = pk[3];                            // 64-bit mask of the rectangle's live tiles
         const unsigned long long live = (unsigned long long)__float_as_uint(p3.x) | ((unsigned long long)__float_as_uint(p3.y) << 32);
         ord = (uint32_t)__builtin_popcountll(live & ((1ull << k) - 1ull));
@@ -1055,9 +1045,36 @@ void launch_scan(hipStream_t st, const GeomState& g, const ImgState& s, uint32_t
 {
     hipLaunchKernelGGL(k_scan, dim3(2), dim3(SCAN_THREADS), 0, st, g, s, nblocks, T, sort_cap, r_capacity, allow_overflow, host_meta);
 }
-void launch_scatter(hipStream_t st, int P, const GeomState& g, const ImgState& s, const BinState& b, uint32_t gx)
+// Binning chunks: `nchunks` workgroups of BIN_THREADS threads, `chunk` Gaussians each (a multiple of BIN_THREADS)
+static int g_bin_wgs = 0;
+void bin_shape(int P, uint32_t T, uint32_t& nchunks, uint32_t& chunk, uint32_t& band, size_t& lds)
 {
-    hipLaunchKernelGGL(k_scatter, dim3((unsigned)n_blocks(P)), dim3(PRE_BLOCK), 0, st, P, g, s, b, gx);
+    if (g_bin_wgs == 0) {                                   // TGS_BIN_WGS: tuning knob, read once
+        const char* e = getenv("TGS_BIN_WGS");
+        int v = e ? atoi(e) : 64;
+        g_bin_wgs = v < 1 ? 1 : (v > BIN_WGS_MAX ? BIN_WGS_MAX : v);
+    }
+    const uint32_t per = ((uint32_t)P + (uint32_t)g_bin_wgs - 1) / (uint32_t)g_bin_wgs;
+    chunk = (per + BIN_THREADS - 1) / BIN_THREADS * BIN_THREADS;
+    if (chunk == 0) chunk = BIN_THREADS;
+    nchunks = ((uint32_t)P + chunk - 1) / chunk;
+    band = T < BIN_LDS_TILES ? T : BIN_LDS_TILES;
+    lds = (size_t)band * sizeof(uint32_t);
+}
+void launch_bin_count(hipStream_t st, int P, const GeomState& g, const ImgState& s, uint32_t gx, uint32_t T)
+{
+    uint32_t nchunks, chunk, band; size_t lds;
+    bin_shape(P, T, nchunks, chunk, band, lds);
+    if (lds > 32 * 1024) (void)hipFuncSetAttribute((const void*)k_bin_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_bin_count, dim3(nchunks), dim3(BIN_THREADS), lds, st, P, chunk, g, s, gx, T, band);
+    hipLaunchKernelGGL(k_bin_colscan, dim3((T + WAVE - 1) / WAVE), dim3(256), 0, st, s, T, nchunks);
+}
+void launch_scatter(hipStream_t st, int P, const GeomState& g, const ImgState& s, const BinState& b, uint32_t gx, uint32_t T)
+{
+    uint32_t nchunks, chunk, band; size_t lds;
+    bin_shape(P, T, nchunks, chunk, band, lds);
+    if (lds > 32 * 1024) (void)hipFuncSetAttribute((const void*)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_scatter, dim3(nchunks), dim3(BIN_THREADS), lds, st, P, chunk, g, s, b, gx, T, band);
 }
 static uint32_t host_next_pow2(uint32_t n) { uint32_t p = 1; while (p < n) p <<= 1; return p; }
 // Exact sizes (after the forward's read-back of Meta) or, with m == nullptr, upper bounds for the sync-free forward:
