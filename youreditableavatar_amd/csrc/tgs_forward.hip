@@ -513,13 +513,17 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(int P, uint32_t chunk
         const uint32_t nb = min(band, T - band0);
         for (uint32_t i = threadIdx.x; i < nb; i += BIN_THREADS) bin_lds[i] = 0u;
         __syncthreads();
+        // (the three loads of a step do not wait for each other -- rect and live of a culled Gaussian are simply not used -- and the next
+        // step's are in flight while this one counts: a chunk is a handful of steps, each a full memory round trip otherwise)
+        uint32_t n_tiles = 0; ushort4 n_r = make_ushort4(0, 0, 0, 0); uint2 n_live = make_uint2(0u, 0u);
+        auto fetch = [&](uint32_t idx) {
+            if (idx < (uint32_t)P) { n_tiles = g.tiles_touched[idx]; n_r = g.rect[idx]; n_live = g.live[idx]; } else n_tiles = 0u;
+        };
+        fetch(lo + threadIdx.x);
 #pragma unroll 1
         for (uint32_t base = lo; base < lo + chunk; base += BIN_THREADS) {
-            const uint32_t idx = base + threadIdx.x;
-            const uint32_t tiles = idx < (uint32_t)P ? g.tiles_touched[idx] : 0u;
-            ushort4 r = make_ushort4(0, 0, 0, 0);
-            uint2 live = make_uint2(0u, 0u);
-            if (tiles) { r = g.rect[idx]; live = g.live[idx]; }
+            const uint32_t tiles = n_tiles; const ushort4 r = n_r; const uint2 live = n_live;
+            if (base + BIN_THREADS < lo + chunk) fetch(base + BIN_THREADS + threadIdx.x);
             wave_emit_instances(tiles, r, live, 0ull, gx, tabs[wv], lane, [&](uint32_t t, unsigned long long) {
                 if (t - band0 < nb) atomicAdd(&bin_lds[t - band0], 1u);
             });
@@ -574,25 +578,29 @@ __global__ __launch_bounds__(BIN_THREADS) void k_scatter(int P, uint32_t chunk, 
         for (uint32_t i = threadIdx.x; i < nb; i += BIN_THREADS) bin_lds[i] = s.ranges[band0 + i].x + row[band0 + i];
         __syncthreads();
         int par = 0;
+        uint32_t n_tiles = 0, n_depth = 0, n_bsum = 0; ushort4 n_r = make_ushort4(0, 0, 0, 0); uint2 n_live = make_uint2(0u, 0u);
+        auto fetch = [&](uint32_t idx) {                    // (as in k_bin_count: independent loads, one step ahead)
+            if (idx < (uint32_t)P) { n_tiles = g.tiles_touched[idx]; n_r = g.rect[idx]; n_live = g.live[idx]; n_depth = __float_as_uint(g.depth[idx]); n_bsum = g.block_sums[idx / PRE_BLOCK]; }
+            else n_tiles = 0u;
+        };
+        fetch(lo + threadIdx.x);
 #pragma unroll 1
         for (uint32_t base = lo; base < lo + chunk; base += BIN_THREADS, par ^= 1) {
             const uint32_t idx = base + threadIdx.x;
-            const uint32_t tiles = idx < (uint32_t)P ? g.tiles_touched[idx] : 0u;
+            const uint32_t tiles = n_tiles, bsum = n_bsum; const ushort4 r = n_r; const uint2 live = n_live;
+            const unsigned long long key = ((unsigned long long)n_depth << 32) | idx;
+            if (base + BIN_THREADS < lo + chunk) fetch(base + BIN_THREADS + threadIdx.x);
             if (band0 == 0) {                               // offsets[idx] = block_sums[its PRE_BLOCK] + prefix inside the block
                 const uint32_t inc = wave_iscan_u32(tiles, lane);
                 if (lane == 63) wtot[par][wv] = inc;
                 __syncthreads();
                 if (idx < (uint32_t)P) {
-                    uint32_t off = g.block_sums[idx / PRE_BLOCK] + inc - tiles;
+                    uint32_t off = bsum + inc - tiles;
                     for (int i = wv & ~3; i < wv; i++) off += wtot[par][i];
                     g.offsets[idx] = off;
                     if (tiles > 0) reinterpret_cast<uint32_t*>(g.pack + 4 * (size_t)idx + 2)[3] = off;
                 }
             }
-            ushort4 r = make_ushort4(0, 0, 0, 0);
-            uint2 live = make_uint2(0u, 0u);
-            unsigned long long key = 0ull;
-            if (tiles) { r = g.rect[idx]; live = g.live[idx]; key = ((unsigned long long)__float_as_uint(g.depth[idx]) << 32) | idx; }
             wave_emit_instances(tiles, r, live, key, gx, tabs[wv], lane, [&](uint32_t t, unsigned long long k) {
                 if (t - band0 < nb) b.keys[atomicAdd(&bin_lds[t - band0], 1u)] = k;
             });
@@ -1051,7 +1059,7 @@ void bin_shape(int P, uint32_t T, uint32_t& nchunks, uint32_t& chunk, uint32_t& 
 {
     if (g_bin_wgs == 0) {                                   // TGS_BIN_WGS: tuning knob, read once
         const char* e = getenv("TGS_BIN_WGS");
-        int v = e ? atoi(e) : 64;
+        int v = e ? atoi(e) : BIN_WGS_MAX;
         g_bin_wgs = v < 1 ? 1 : (v > BIN_WGS_MAX ? BIN_WGS_MAX : v);
     }
     const uint32_t per = ((uint32_t)P + (uint32_t)g_bin_wgs - 1) / (uint32_t)g_bin_wgs;
