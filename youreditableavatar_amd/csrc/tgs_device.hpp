@@ -69,6 +69,7 @@ struct ImgState {
 };
 struct BinState {
     unsigned long long* keys; // (depth bits << 32 | gaussian idx), per tile segment, sorted after k_tile_sort
+    uint32_t* tile_of;        // tile of list position p (written by k_tile_sort with the sorted keys: k_finalize is one thread per position)
     float4* recA;             // sorted per-instance records: xy.x, xy.y, conic.x, conic.y
     float4* recB;             //                              conic.z, opacity, r, g
     float2* recC;             //                              b, bits(gaussian idx)
@@ -107,7 +108,7 @@ __host__ __device__ inline size_t img_carve(ImgState& s, char* base, size_t N, s
 __host__ __device__ inline size_t bin_carve(BinState& b, char* base, size_t R)
 {
     char* p = base;
-    carve(p, b.keys, R); carve(p, b.recA, R); carve(p, b.recB, R); carve(p, b.recC, R); carve(p, b.slot, R); carve(p, b.qmask, R); carve(p, b.slab, (size_t)SLAB_ROW * R);
+    carve(p, b.keys, R); carve(p, b.tile_of, R); carve(p, b.recA, R); carve(p, b.recB, R); carve(p, b.recC, R); carve(p, b.slot, R); carve(p, b.qmask, R); carve(p, b.slab, (size_t)SLAB_ROW * R);
     return (size_t)(p - base) + 256;
 }
 
@@ -522,9 +523,9 @@ __device__ __forceinline__ void wave_reduce36(const float (&v)[36], float (&r)[9
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void pair_flip(uint32_t t, uint32_t k, uint32_t& i, uint32_t& l)
 {
-    const uint32_t h = k >> 1, blk = t / h, off = t % h;
-    i = blk * k + off;
-    l = blk * k + (k - 1 - off);
+    const uint32_t h = k >> 1;                              // (k is a power of two: no division)
+    i = ((t & ~(h - 1)) << 1) | (t & (h - 1));              // block * k + offset, offset < k / 2
+    l = i ^ (k - 1);                                        // block * k + (k - 1 - offset)
 }
 __device__ __forceinline__ void pair_disperse(uint32_t t, uint32_t j, uint32_t& i, uint32_t& l)
 {
@@ -545,38 +546,106 @@ __device__ __forceinline__ void cmp_swap(KeyPtr keys, uint32_t i, uint32_t l, ui
     }
 }
 
-// Steps of the network that stay inside one aligned chunk of SORT_CHUNK = 128 keys are run by ONE wave (64 pairs per
-// step, one per lane) without workgroup barriers: LDS instructions of a wave execute in order, so the next step's
-// reads see this step's writes.
+// Steps of the network that stay inside one aligned chunk of SORT_CHUNK = 128 keys are run by ONE wave in registers
+// (regs_sort128 / regs_disperse_from64 below), without LDS traffic or workgroup barriers.
 constexpr uint32_t SORT_CHUNK = 128;
 __device__ __forceinline__ void wave_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
-template <typename KeyPtr>
-__device__ __forceinline__ void wave_chunk_disperse(KeyPtr lk, uint32_t base, uint32_t n, uint32_t lane, uint32_t j0)
+// ---- the same network on one chunk of 128 keys held in REGISTERS: element e of the chunk is k[e & 1] of lane e >> 1 ----
+// A step of the network pairs element e with e ^ m (m = k - 1 for flip(k), m = j for disperse(j)); the element whose bit (k/2
+// resp. j) is clear keeps the smaller key.  disperse(1) and flip(2) pair a lane's own two registers; every other partner sits in
+// another lane: lane ^ 1, 2, 3, 7, 8, 15 are one DPP move per 32-bit half (quad_perm, row_half_mirror, row_ror:8, row_mirror),
+// lane ^ 4 two (half mirror + quad reverse), lane ^ 16, 31, 32, 63 a ds_bpermute (LDS crossbar, no memory).  28 steps sort 128 keys
+// without an LDS access, ~5 VALU per key and step; as LDS read-compare-write round trips the chunk-local steps kept the LDS pipe of
+// a CU busy for the whole kernel.  Call from convergent code with all 64 lanes active.  The keys are unique (the index is their low
+// word), so one comparison decides a pair for both sides; between two +inf paddings either answer is right.
+template <int CTRL> __device__ __forceinline__ unsigned long long key_dpp(unsigned long long k)
 {
-#pragma unroll 1
-    for (uint32_t j = j0; j > 0; j >>= 1) { uint32_t i, l; pair_disperse(lane, j, i, l); cmp_swap(lk, base + i, base + l, n); wave_sync(); }
+    // (bound_ctrl: every lane has a source in these permutations, and with it the compiler need not preset the destination)
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)k, CTRL, 0xf, 0xf, true);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(k >> 32), CTRL, 0xf, 0xf, true);
+    return ((unsigned long long)hi << 32) | lo;
 }
-// full network k = 2..kmax (kmax <= SORT_CHUNK) on keys [base, base + kmax)
-template <typename KeyPtr>
-__device__ __forceinline__ void wave_chunk_sort(KeyPtr lk, uint32_t base, uint32_t n, uint32_t lane, uint32_t kmax)
+__device__ __forceinline__ unsigned long long key_bperm(unsigned long long k, uint32_t src_lane)
 {
-#pragma unroll 1
-    for (uint32_t k = 2; k <= kmax; k <<= 1) {
-        if (lane < (kmax >> 1)) { uint32_t i, l; pair_flip(lane, k, i, l); cmp_swap(lk, base + i, base + l, n); }
-        wave_sync();
-#pragma unroll 1
-        for (uint32_t j = k >> 2; j > 0; j >>= 1) {
-            if (lane < (kmax >> 1)) { uint32_t i, l; pair_disperse(lane, j, i, l); cmp_swap(lk, base + i, base + l, n); }
-            wave_sync();
-        }
-    }
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)(uint32_t)k);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)(uint32_t)(k >> 32));
+    return ((unsigned long long)hi << 32) | lo;
 }
-
-
+// the key of lane ^ M
+template <uint32_t M> __device__ __forceinline__ unsigned long long key_xor(unsigned long long k, uint32_t lane)
+{
+    if constexpr (M == 1) return key_dpp<0xB1>(k);          // quad_perm [1,0,3,2]
+    else if constexpr (M == 2) return key_dpp<0x4E>(k);     // quad_perm [2,3,0,1]
+    else if constexpr (M == 3) return key_dpp<0x1B>(k);     // quad_perm [3,2,1,0]
+    else if constexpr (M == 7) return key_dpp<0x141>(k);    // row_half_mirror
+    else if constexpr (M == 15) return key_dpp<0x140>(k);   // row_mirror
+    else if constexpr (M == 8) return key_dpp<0x128>(k);    // row_ror:8
+    else if constexpr (M == 4) return key_dpp<0x1B>(key_dpp<0x141>(k));   // (lane ^ 7) ^ 3
+    else return key_bperm(k, lane ^ M);
+}
+// disperse(1) / flip(2): element 2l against 2l + 1
+__device__ __forceinline__ void regs_pair(unsigned long long& k0, unsigned long long& k1)
+{
+    const unsigned long long a = k0, c = k1;
+    const bool sw = a > c;
+    k0 = sw ? c : a; k1 = sw ? a : c;
+}
+// disperse(J), J = 2 .. 64: the same register of lane ^ (J / 2)
+template <uint32_t J> __device__ __forceinline__ void regs_disperse_step(unsigned long long& k0, unsigned long long& k1, uint32_t lane)
+{
+    const bool lower = (lane & (J >> 1)) == 0u;
+    const unsigned long long o0 = key_xor<(J >> 1)>(k0, lane), o1 = key_xor<(J >> 1)>(k1, lane);
+    k0 = ((o0 < k0) == lower) ? o0 : k0;
+    k1 = ((o1 < k1) == lower) ? o1 : k1;
+}
+// flip(K), K = 4 .. 128: the OTHER register of lane ^ (K / 2 - 1)
+template <uint32_t K> __device__ __forceinline__ void regs_flip_step(unsigned long long& k0, unsigned long long& k1, uint32_t lane)
+{
+    const bool lower = (lane & (K >> 2)) == 0u;
+    const unsigned long long o0 = key_xor<(K >> 1) - 1>(k1, lane), o1 = key_xor<(K >> 1) - 1>(k0, lane);
+    k0 = ((o0 < k0) == lower) ? o0 : k0;
+    k1 = ((o1 < k1) == lower) ? o1 : k1;
+}
+// disperse steps j = 64 .. 1: the tail of a merge whose wider steps ran outside the chunk
+__device__ __forceinline__ void regs_disperse_from64(unsigned long long& k0, unsigned long long& k1, uint32_t lane)
+{
+    regs_disperse_step<64>(k0, k1, lane); regs_disperse_step<32>(k0, k1, lane); regs_disperse_step<16>(k0, k1, lane);
+    regs_disperse_step<8>(k0, k1, lane); regs_disperse_step<4>(k0, k1, lane); regs_disperse_step<2>(k0, k1, lane);
+    regs_pair(k0, k1);
+}
+// the whole network on 128 keys (pad with ~0ull behind the real ones)
+__device__ __forceinline__ void regs_sort128(unsigned long long& k0, unsigned long long& k1, uint32_t lane)
+{
+    regs_pair(k0, k1);
+    regs_flip_step<4>(k0, k1, lane); regs_pair(k0, k1);
+    regs_flip_step<8>(k0, k1, lane); regs_disperse_step<2>(k0, k1, lane); regs_pair(k0, k1);
+    regs_flip_step<16>(k0, k1, lane); regs_disperse_step<4>(k0, k1, lane); regs_disperse_step<2>(k0, k1, lane); regs_pair(k0, k1);
+    regs_flip_step<32>(k0, k1, lane); regs_disperse_step<8>(k0, k1, lane); regs_disperse_step<4>(k0, k1, lane); regs_disperse_step<2>(k0, k1, lane);
+    regs_pair(k0, k1);
+    regs_flip_step<64>(k0, k1, lane); regs_disperse_step<16>(k0, k1, lane); regs_disperse_step<8>(k0, k1, lane); regs_disperse_step<4>(k0, k1, lane);
+    regs_disperse_step<2>(k0, k1, lane); regs_pair(k0, k1);
+    regs_flip_step<128>(k0, k1, lane); regs_disperse_step<32>(k0, k1, lane); regs_disperse_step<16>(k0, k1, lane); regs_disperse_step<8>(k0, k1, lane);
+    regs_disperse_step<4>(k0, k1, lane); regs_disperse_step<2>(k0, k1, lane); regs_pair(k0, k1);
+}
+// chunk [base, base + 128) of a list of n keys (LDS or global memory) <-> registers (virtual +inf behind n)
+template <typename KeyPtr>
+__device__ __forceinline__ void regs_load_chunk(KeyPtr lk, uint32_t base, uint32_t n, uint32_t lane, unsigned long long& k0, unsigned long long& k1)
+{
+    const uint32_t e = base + 2 * lane;
+    k0 = e < n ? lk[e] : ~0ull;
+    k1 = e + 1 < n ? lk[e + 1] : ~0ull;
+}
+template <typename KeyPtr>
+__device__ __forceinline__ void regs_store_chunk(KeyPtr lk, uint32_t base, uint32_t n, uint32_t lane, unsigned long long k0, unsigned long long k1)
+{
+    const uint32_t e = base + 2 * lane;
+    if (e < n) lk[e] = k0;
+    if (e + 1 < n) lk[e + 1] = k1;
+}
 
 // SH basis constants (cuda_rasterizer/auxiliary.h:22-39)
 __device__ constexpr float SH_C0 = 0.28209479177387814f;

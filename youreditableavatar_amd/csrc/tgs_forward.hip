@@ -654,7 +654,13 @@ __device__ __forceinline__ void sort_tile_lds(unsigned long long* lk, uint32_t t
     const uint32_t half = npad_loop >> 1;
     const uint32_t lane = tid & 63, wv = tid >> 6;
     constexpr uint32_t W = NT / 64;
-    for (uint32_t c = wv * SORT_CHUNK; c < n; c += W * SORT_CHUNK) wave_chunk_sort(lk, c, n, lane, min(SORT_CHUNK, npad_loop));
+    // every aligned chunk of 128 keys is sorted, and later re-merged, in the registers of one wave (regs_sort128, tgs_device.hpp)
+    for (uint32_t c = wv * SORT_CHUNK; c < n; c += W * SORT_CHUNK) {
+        unsigned long long k0, k1;
+        regs_load_chunk(lk, c, n, lane, k0, k1);
+        regs_sort128(k0, k1, lane);
+        regs_store_chunk(lk, c, n, lane, k0, k1);
+    }
     __syncthreads();
     for (uint32_t k = 2 * SORT_CHUNK; k <= npad_loop; k <<= 1) {
         for (uint32_t p = tid; p < half; p += NT) { uint32_t i, l; pair_flip(p, k, i, l); cmp_swap(lk, i, l, n); }
@@ -663,7 +669,12 @@ __device__ __forceinline__ void sort_tile_lds(unsigned long long* lk, uint32_t t
             for (uint32_t p = tid; p < half; p += NT) { uint32_t i, l; pair_disperse(p, j, i, l); cmp_swap(lk, i, l, n); }
             __syncthreads();
         }
-        for (uint32_t c = wv * SORT_CHUNK; c < n; c += W * SORT_CHUNK) wave_chunk_disperse(lk, c, n, lane, SORT_CHUNK >> 1);
+        for (uint32_t c = wv * SORT_CHUNK; c < n; c += W * SORT_CHUNK) {
+            unsigned long long k0, k1;
+            regs_load_chunk(lk, c, n, lane, k0, k1);
+            regs_disperse_from64(k0, k1, lane);
+            regs_store_chunk(lk, c, n, lane, k0, k1);
+        }
         __syncthreads();
     }
 }
@@ -774,7 +785,8 @@ __global__ __launch_bounds__(1024) void k_tile_sort(const ImgState s, const BinS
         if (t >= n_heavy) return;
         const uint4 td = s.tile_desc[t];
         const uint32_t n = td.z - td.y;
-        if (n < 2 || n > sort_cap) return;                  // (longer lists: k_ovf_*)
+        for (uint32_t i = threadIdx.x; i < n; i += 1024) b.tile_of[td.y + i] = td.x;
+        if (n < 2 || n > sort_cap) return;                  // (longer lists: the overflow workers)
         for (uint32_t i = threadIdx.x; i < n; i += 1024) lk[i] = b.keys[td.y + i];
         __syncthreads();
         sort_tile_lds<1024>(lk, threadIdx.x, n, next_pow2(n));
@@ -783,8 +795,9 @@ __global__ __launch_bounds__(1024) void k_tile_sort(const ImgState s, const BinS
         const uint32_t grp = threadIdx.x >> 8, tid = threadIdx.x & 255u;
         const uint32_t t = n_heavy + (blockIdx.x - heavy_blocks) * 4 + grp;
         if (n_heavy + (blockIdx.x - heavy_blocks) * 4 >= n_mid) return;          // the whole workgroup is behind the class
-        uint32_t n = 0, start = 0;
-        if (t < n_mid) { const uint4 td = s.tile_desc[t]; start = td.y; n = td.z - td.y; }
+        uint32_t n = 0, start = 0, tile = 0;
+        if (t < n_mid) { const uint4 td = s.tile_desc[t]; tile = td.x; start = td.y; n = td.z - td.y; }
+        for (uint32_t i = tid; i < n; i += 256) b.tile_of[start + i] = tile;
         if (n > 1024u || n > sort_cap) n = 0;               // (cannot happen by the class boundary; keeps the LDS segment safe)
         unsigned long long* seg = lk + grp * 1024;
         for (uint32_t i = tid; i < n; i += 256) seg[i] = b.keys[start + i];
@@ -798,27 +811,22 @@ __global__ __launch_bounds__(1024) void k_tile_sort(const ImgState s, const BinS
         if (t >= n_nonempty) return;                        // wave-uniform: no workgroup barrier below
         const uint4 td = s.tile_desc[t];
         const uint32_t n = td.z - td.y;
+        for (uint32_t i = lane; i < n; i += 64) b.tile_of[td.y + i] = td.x;
         if (n < 2 || n > sort_cap || n > SORT_CHUNK) return;    // (n < 128 by the class boundary in k_scan)
-        unsigned long long* seg = lk + wv * SORT_CHUNK;
-        for (uint32_t i = lane; i < n; i += 64) seg[i] = b.keys[td.y + i];
-        wave_sync();
-        wave_chunk_sort(seg, 0u, n, lane, next_pow2(n));
-        for (uint32_t i = lane; i < n; i += 64) b.keys[td.y + i] = seg[i];
+        unsigned long long k0, k1;                          // global memory -> registers -> global memory: no LDS
+        regs_load_chunk(b.keys + td.y, 0u, n, lane, k0, k1);
+        regs_sort128(k0, k1, lane);
+        regs_store_chunk(b.keys + td.y, 0u, n, lane, k0, k1);
     }
 }
 
-// One thread per sorted instance, evenly over all R of them: finds its tile by binary search in the (monotone)
-// range starts, gathers the Gaussian's 64-B line and writes the 40-B record, the block mask and the slab row.
+// One thread per sorted instance, evenly over all R of them: its tile comes with the sorted keys (tile_of; a binary search in the
+// range starts was 13 dependent loads), it gathers the Gaussian's 64-B line and writes the 40-B record, the block mask and the slab row.
 __global__ __launch_bounds__(256) void k_finalize(const GeomState g, const ImgState s, const BinState b, uint32_t gx, uint32_t T)
 {
     const uint32_t p = blockIdx.x * 256 + threadIdx.x;
     if (frame_rejected(s) || p >= (uint32_t)s.meta->R) return;
-    uint32_t lo = 0, hi = T - 1;                            // last tile whose start is <= p (empty tiles before it share its start)
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi + 1) >> 1;
-        if (s.ranges[mid].x <= p) lo = mid; else hi = mid - 1;
-    }
-    finalize_entry(b.keys[p], p, lo, gx, g, b);
+    finalize_entry(b.keys[p], p, b.tile_of[p], gx, g, b);
 }
 
 // ---------------------------------------------------------------------------------------------
