@@ -611,14 +611,10 @@ __global__ __launch_bounds__(BIN_THREADS) void k_scatter(int P, uint32_t chunk, 
 
 // (the bitonic network helpers pair_flip / pair_disperse / cmp_swap live in tgs_device.hpp)
 
-// gathers the per-instance record of sorted entry i of a tile (what renderCUDA fetches per entry:
-// forward.cu:315-321,355 and backward.cu:470-480)
-__device__ __forceinline__ void finalize_entry(unsigned long long key, uint32_t pos, uint32_t tile, uint32_t gx, const GeomState& g,
-                                               const BinState& b)
+// the per-instance record of sorted entry `pos` of a tile (what renderCUDA fetches per entry: forward.cu:315-321,355 and
+// backward.cu:470-480) from the Gaussian's 64-B pack line p0..p3
+__device__ __forceinline__ void finalize_entry(float4 p0, float4 p1, float4 p2, float4 p3, uint32_t pos, uint32_t tile, uint32_t gx, const BinState& b)
 {
-    const uint32_t id = (uint32_t)key;
-    const float4* pk = g.pack + 4 * (size_t)id;               // one 64-B line per Gaussian
-    const float4 p0 = pk[0], p1 = pk[1], p2 = pk[2];
     const uint32_t rmin = __float_as_uint(p2.y), rmax = __float_as_uint(p2.z);
     const uint32_t minx = rmin & 0xffffu, miny = rmin >> 16, maxx = rmax & 0xffffu, maxy = rmax >> 16;
     const uint32_t tx = tile % gx, ty = tile / gx;
@@ -630,8 +626,7 @@ __device__ __forceinline__ void finalize_entry(unsigned long long key, uint32_t 
     // row of this instance in the gradient slab: the Gaussian's rows are its LIVE tiles in rectangle order
     const uint32_t rw = maxx - minx, k = (ty - miny) * rw + (tx - minx);
     uint32_t ord = k;
-    if (rw * (maxy - miny) <= (uint32_t)COOP_TILES) {
-        const float4 p3 = pk[3];                            // 64-bit mask of the rectangle's live tiles
+    if (rw * (maxy - miny) <= (uint32_t)COOP_TILES) {       // p3: 64-bit mask of the rectangle's live tiles
         const unsigned long long live = (unsigned long long)__float_as_uint(p3.x) | ((unsigned long long)__float_as_uint(p3.y) << 32);
         ord = (uint32_t)__builtin_popcountll(live & ((1ull << k) - 1ull));
     }
@@ -820,13 +815,38 @@ __global__ __launch_bounds__(1024) void k_tile_sort(const ImgState s, const BinS
     }
 }
 
-// One thread per sorted instance, evenly over all R of them: its tile comes with the sorted keys (tile_of; a binary search in the
-// range starts was 13 dependent loads), it gathers the Gaussian's 64-B line and writes the 40-B record, the block mask and the slab row.
+// FIN_E sorted instances per thread, evenly over all R of them: the tile comes with the sorted keys (tile_of; a binary search in the
+// range starts was 13 dependent loads), the thread gathers the Gaussians' 64-B lines and writes the 40-B records, the quadrant masks
+// and the slab rows.  The loads of the FIN_E instances are issued together, level by level (keys, then lines): with one instance per
+// thread the whole grid fitted the chip ~1.5 times, and every wave of a pass was in the same phase -- loading, then computing, then storing.
+#ifndef TGS_FIN_E
+#define TGS_FIN_E 2
+#endif
+constexpr int FIN_E = TGS_FIN_E;
 __global__ __launch_bounds__(256) void k_finalize(const GeomState g, const ImgState s, const BinState b, uint32_t gx, uint32_t T)
 {
-    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
-    if (frame_rejected(s) || p >= (uint32_t)s.meta->R) return;
-    finalize_entry(b.keys[p], p, b.tile_of[p], gx, g, b);
+    if (frame_rejected(s)) return;
+    const uint32_t R = (uint32_t)s.meta->R;
+    const uint32_t p0 = blockIdx.x * (256 * FIN_E) + threadIdx.x;
+    if (p0 >= R) return;
+    uint32_t id[FIN_E], tile[FIN_E];
+#pragma unroll
+    for (int e = 0; e < FIN_E; e++) {
+        const uint32_t p = p0 + e * 256;
+        id[e] = p < R ? (uint32_t)b.keys[p] : 0u;
+        tile[e] = p < R ? b.tile_of[p] : 0u;
+    }
+    float4 q0[FIN_E], q1[FIN_E], q2[FIN_E], q3[FIN_E];
+#pragma unroll
+    for (int e = 0; e < FIN_E; e++) {
+        const float4* pk = g.pack + 4 * (size_t)id[e];         // one 64-B line per Gaussian
+        q0[e] = pk[0]; q1[e] = pk[1]; q2[e] = pk[2]; q3[e] = pk[3];
+    }
+#pragma unroll
+    for (int e = 0; e < FIN_E; e++) {
+        const uint32_t p = p0 + e * 256;
+        if (p < R) finalize_entry(q0[e], q1[e], q2[e], q3[e], p, tile[e], gx, b);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1123,7 +1143,7 @@ void launch_tile_sort(hipStream_t st, const GeomState& g, const ImgState& s, con
             hipLaunchKernelGGL(k_tile_sort, dim3(heavy + mid_blocks + small_blocks + ovf_blocks), dim3(1024), bytes, st, s, b, sort_cap, heavy, mid_blocks,
                                small_blocks, ovf_blocks);
     }
-    if (r_bound > 0) hipLaunchKernelGGL(k_finalize, dim3((unsigned)((r_bound + 255) / 256)), dim3(256), 0, st, g, s, b, gx, T);
+    if (r_bound > 0) hipLaunchKernelGGL(k_finalize, dim3((unsigned)((r_bound + 256 * FIN_E - 1) / (256 * FIN_E))), dim3(256), 0, st, g, s, b, gx, T);
 }
 void launch_render_fwd(hipStream_t st, const ImgState& s, const BinState& b, int W, int H, uint32_t gx, uint32_t T, const Meta* m,
                        const float* bg, float* out_color)
