@@ -1,6 +1,6 @@
 set -x
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r02_c
+O=$R/gpurun_out/r02_d
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rm -rf $O/rp4 $O/rp1

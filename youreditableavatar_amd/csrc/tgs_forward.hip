@@ -542,7 +542,7 @@ __global__ __launch_bounds__(256) void k_bin_colscan(const ImgState s, uint32_t 
     const uint32_t t = blockIdx.x * WAVE + l;
     const uint32_t per = (nchunks + 3) / 4, w0 = min(nchunks, q * per), w1 = min(nchunks, w0 + per);
     uint32_t* col = s.bin_table + t;
-    uint32_t c[32];                                         // per <= BIN_WGS_MAX / 4
+    uint32_t c[BIN_WGS_MAX / 4];
     uint32_t sum = 0;
     if (t < T) {
 #pragma unroll
