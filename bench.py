@@ -34,7 +34,7 @@ VALU_PEAK_GWIPS = 1228.8
 # render loops' mix (6 fma/mul + 1 DPP + 1 transcendental per 8: DPP operations issue at half rate, v_exp_f32 at a quarter)
 VALU_MEASURED_FMA_GWIPS = 955.5
 VALU_MEASURED_MIX_GWIPS = 628.4
-PROFILE_SET = "r02_c"          # profiles/<set>_{hbm,sq}_counters.json: the PMC passes the roofline object quotes (tools/profile_round.sh)
+PROFILE_SET = "r02_d"          # profiles/<set>_{hbm,sq}_counters.json: the PMC passes the roofline object quotes (tools/profile_round.sh)
 
 
 def parse():
@@ -473,8 +473,8 @@ def secondary_workloads(a, cloud, dev, D, W, H, headline_ms):
     S4 = settings_for(W, H, D, 8)
     ms = timed(lambda i: b3.run_views(S4, co["means3D"], co["opacities"], co["shs"], co["scales"], co["rotations"], None, accumulate=False,
                                       upstream_view=lambda v, image: dL), 10, 4) / len(S4)
-    res["spatially_ordered_gaussians"] = {"ms_per_frame": round(ms, 4), "what": "the headline path on the same cloud re-numbered along a 3-D Morton curve: index neighbours share tiles, "
-                                          "so a wave's counting atomics combine (k_preprocess_fwd) and the gathers hit neighbouring lines"}
+    res["spatially_ordered_gaussians"] = {"ms_per_frame": round(ms, 4), "what": "the headline path on the same cloud re-numbered along a 3-D Morton curve (index neighbours share tiles: the "
+                                          "gathers hit neighbouring lines; the binning has no global atomics, so the order no longer decides its cost)"}
     del b3, co
     torch.cuda.empty_cache()
     # ---- alive (pixel, entry) pairs of view 0
