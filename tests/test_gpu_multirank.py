@@ -28,13 +28,13 @@ def _free_port():
     return p
 
 
-@pytest.mark.timeout(900)
+@pytest.mark.timeout(400)
 def test_bench_starts_two_ranks(gpu_device):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-device", "--config", "2", "--steps", "2",
-                        "--warmup", "2", "--views-per-gpu", "4", "--no-cpu"], capture_output=True, text=True, timeout=800, env=env, cwd=ROOT)
+                        "--warmup", "2", "--views-per-gpu", "4", "--no-cpu"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
@@ -51,7 +51,8 @@ from youreditableavatar_amd.multiview import FlatGradients, SyncFreeBatch, shard
 from diff_gaussian_rasterization import GaussianRasterizationSettings, _C
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 if world > 1:
-    dist.init_process_group("gloo")
+    import datetime
+    dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=180))
 dev = torch.device("cuda:0")
 P, W, H, D, V = 7000, 208, 144, 2, 6
 cloud = scenes.make_cloud(P, D, seed=77, scale_mult=3.0)
@@ -92,22 +93,39 @@ if world > 1:
 """
 
 
-@pytest.mark.timeout(900)
+@pytest.mark.timeout(700)
 def test_two_rank_step_on_the_hip_path_equals_unsharded(gpu_device, tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
     out = str(tmp_path / "res")
 
     def launch(world):
+        # logs go to files (a rank blocked on a full pipe would stall its peer inside a collective), and the ranks are watched together:
+        # if one dies, the other is not left waiting in the rendezvous for gloo's half-hour timeout
+        import time
         port = _free_port()
-        procs = []
+        procs, logs = [], []
         for rank in range(world):
             env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                        TGS_ROOT=ROOT, TGS_OUT=out + f"_w{world}", HSA_ENABLE_IPC_MODE_LEGACY="0")
-            procs.append(subprocess.Popen([sys.executable, str(script)], env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
-        for p in procs:
-            so, se = p.communicate(timeout=600)
-            assert p.returncode == 0, se[-3000:]
+            log = open(str(tmp_path / f"w{world}_r{rank}.log"), "w+")
+            logs.append(log)
+            procs.append(subprocess.Popen([sys.executable, str(script)], env=env, cwd=ROOT, stdout=log, stderr=subprocess.STDOUT, text=True))
+        deadline = time.time() + 300
+        failed = None
+        while any(p.poll() is None for p in procs):
+            bad = [r for r, p in enumerate(procs) if p.poll() not in (None, 0)]
+            if bad or time.time() > deadline:
+                failed = bad[0] if bad else -1
+                for p in procs:
+                    if p.poll() is None:
+                        p.kill()
+                break
+            time.sleep(0.2)
+        tails = []
+        for log in logs:
+            log.seek(0); tails.append(log.read()[-2000:]); log.close()
+        assert failed is None and all(p.wait() == 0 for p in procs), (failed, tails)
         return [np.load(out + f"_w{world}.{r}.npz") for r in range(world)]
 
     one = launch(1)[0]
