@@ -240,8 +240,9 @@ void tgs_set_instance_pruning(int on);
  * n = 0 restores one stream per view. */
 int tgs_set_render_streams(void* const* streams, int n);
 
-/* Knob (process-wide): views per launch of the per-Gaussian forward stage inside tgs_forward_views (1..8, default 1).  Groups
- * read the SH rows once per group; measured, that does not pay when the views overlap on several streams. */
+/* Knob (process-wide): views per launch of the per-Gaussian forward stage inside tgs_forward_views (1..8, default 2).  Groups
+ * read the SH rows once per group; measured with four streams, pairs pay (-2 % per frame) and larger groups do not (the views of a
+ * group start their remaining stages together). */
 void tgs_set_forward_group(int views_per_launch);
 int tgs_backward_render(void* stream, int P, int64_t R, const float* background, int width, int height,
                         const void* binning_buffer, const void* img_buffer, const float* dL_dpix);

@@ -533,7 +533,7 @@ def test_run_views_whole_batch_path(streams, group, gpu_device):
         assert torch.isfinite(flat.flat).all() and flat.flat.abs().max() > 0
     finally:
         _C.set_deterministic(False)
-        _C.set_forward_group(1)
+        _C.set_forward_group(2)                 # the default
 
 
 def test_run_views_with_a_list_beyond_the_lds_sort(gpu_device):

@@ -35,7 +35,7 @@ static thread_local char g_err[512] = "";
 // -1: not set by the API -> environment variable TGS_DETERMINISTIC decides (default 0)
 static std::atomic<int> g_deterministic{-1};
 static std::atomic<uint32_t> g_sort_cap{SORT_LDS_CAP};
-static std::atomic<int> g_fwd_group{1};
+static std::atomic<int> g_fwd_group{2};
 static std::atomic<int> g_prune{1};
 static bool deterministic_mode()
 {
@@ -512,11 +512,14 @@ int tgs_forward_views(void* const* streams, int n_streams, int64_t r_capacity, i
     const bool has_sh = shs != nullptr, has_sr = scales != nullptr && rotations != nullptr;
     // views that can share the per-Gaussian stage: same model, the usual case (P > 0, all pointers there; the rest is
     // validated by forward_impl below)
-    // Views per launch of the shared per-Gaussian stage (tgs_set_forward_group; default 1 = every view runs its own).  More
-    // views per launch read the SH rows fewer times (0.57 ms for 8 views against 8 x 0.106), but the views of a group start
-    // their remaining stages together and the launch itself is bound by the L2 atomic units with the CUs mostly idle;
-    // measured at 4 streams the forward phase is 0.249 / 0.255 / 0.262 / 0.259 ms per frame for groups of 1 / 2 / 4 / 8.
-    const int group = g_fwd_group.load(std::memory_order_relaxed);
+    // Views per launch of the shared per-Gaussian stage (tgs_set_forward_group, TGS_FORWARD_GROUP; default 2).  More views per launch
+    // read the SH rows -- more than half of what the stage reads -- fewer times: 51 us for one view, 78 / 125 / 218 us for 2 / 4 / 8.
+    // But the views of a group start their remaining stages together, and with four streams that costs more than the bytes save
+    // beyond pairs: 0.302 / 0.296 / 0.308 / 0.306 ms per frame for groups of 1 / 2 / 4 / 8 at config 3.  (With the counting atomics
+    // in this stage, until round 2, the launch was bound by them and no grouping paid.)
+    static const int env_group = [] { const char* e = getenv("TGS_FORWARD_GROUP"); return e ? atoi(e) : 0; }();   // tuning knob, read once
+    int group = g_fwd_group.load(std::memory_order_relaxed);
+    if (env_group > 0) group = env_group > BATCH_VIEWS ? BATCH_VIEWS : env_group;
     bool per_view_colors = false;
     for (int k = 0; k < n_views; k++) per_view_colors = per_view_colors || views[k].colors_precomp != nullptr;
     if (per_view_colors && shs) return fail(TGS_ERR_INVALID, "provide exactly one of shs / colors_precomp");
