@@ -74,9 +74,9 @@ def test_vs_oracle_seeded(P, W, H, deg, mode, cov_mode, scale_mult, gpu_device):
 
 
 def test_spatially_ordered_cloud_vs_oracle(gpu_device):
-    """Gaussians numbered along a Morton curve (index neighbours are spatial neighbours, the way mesh-bound Gaussians come): the waves of
-    k_preprocess_fwd then take the COMBINED counting path -- lanes that want the same tile rank themselves in LDS and share one atomic
-    (wave_tile_rank) -- which a randomly ordered cloud almost never does.  Lists, image and gradients against the oracle."""
+    """Gaussians numbered along a Morton curve (index neighbours are spatial neighbours, the way mesh-bound Gaussians come): many lanes
+    of a wave of k_bin_count / k_scatter then add to the SAME counter of the chunk's LDS table in one instruction, which a randomly
+    ordered cloud almost never does.  Lists, image and gradients against the oracle."""
     from youreditableavatar_amd import scenes
     cloud = scenes.morton_order(scenes.make_cloud(60_000, 2, seed=314, scale_mult=1.5))
     cam = scenes.orbit_camera(640, 400, azimuth_deg=65.0)
@@ -92,6 +92,29 @@ def test_spatially_ordered_cloud_vs_oracle(gpu_device):
     t = (np.floor(m2[:, 0] / 16).astype(np.int64) + 40 * np.floor(m2[:, 1] / 16).astype(np.int64))
     same = (t[1:] == t[:-1]) & vis[1:] & vis[:-1]
     assert same.mean() > 0.3
+
+
+def test_tile_grid_beyond_one_lds_table(gpu_device):
+    """26 125 tiles (3344 x 2000): more than the 24 576 counters one pass of the binning chunks' LDS table holds, so k_bin_count and
+    k_scatter walk the tile grid in two bands (and ask for 96 KB of dynamic LDS).  Splats of every emission class -- <= 4 tiles, 5..64
+    (spread over the wave), larger (walked by the wave) -- against the oracle."""
+    from youreditableavatar_amd import scenes
+    W, H = 3344, 2000
+    cloud = scenes.make_cloud(6_000, 1, seed=2611, scale_mult=0.6)
+    cloud["means3D"] = cloud["means3D"].copy(); cloud["means3D"][:, 1] -= 0.5        # towards the bottom of the image: the last band is not empty
+    cloud["scales"] = cloud["scales"].copy(); cloud["scales"][::150] *= 6.0           # some splats on more than 64 tiles
+    cam = scenes.orbit_camera(W, H, azimuth_deg=20.0)
+    inp = util.scene_input(cloud, cam)
+    dL = scenes.upstream_gradient(W, H, seed=26)
+    ref = util.oracle_run(inp, dL)
+    mine = util.hip_run(inp, dL)
+    rep = util.compare(mine, ref)
+    tt = ref["tiles_touched"]
+    assert (tt > 64).sum() > 50 and ((tt > 4) & (tt <= 64)).sum() > 1000 and ((tt > 0) & (tt <= 4)).sum() > 100
+    r = ref["ranges"].reshape(-1, 2)
+    assert len(r) > 24576 and (r[24576:, 1] > r[24576:, 0]).sum() > 500       # the second band holds instances
+    assert rep["lists_equal"] == 1.0
+    print({k: f"{v:.2e}" for k, v in rep.items()})
 
 
 def test_backward_is_bitwise_reproducible(gpu_device):
