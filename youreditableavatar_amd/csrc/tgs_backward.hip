@@ -219,8 +219,8 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
     __shared__ __attribute__((aligned(16))) unsigned short lists[16][BCH + 8];   // one list per block (= per wave): slot | quadrant nibble << 10
     __shared__ __attribute__((aligned(16))) unsigned short qlists[16][4][QL_ROW]; // per wave: the current chunk's four quadrant lists
 
+    const uint4 td = s.tile_desc[blockIdx.x];               // (in flight beside the frame's flags)
     if (frame_rejected(s)) return;
-    const uint4 td = s.tile_desc[blockIdx.x];
     const uint32_t tile = td.x;
     const uint32_t tx = tile % gx, ty = tile / gx;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;

@@ -2,6 +2,7 @@
 // gfx950 (CDNA4) only: wave64, DPP row operations, 160 KiB LDS per CU.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 namespace tgs {
@@ -438,6 +439,14 @@ __device__ __forceinline__ void row_stride4_sum9(float (&v)[9])
 #undef TGS_ROR
 }
 
+// (error, n_nonempty) of the frame's Meta in ONE load -- the render kernels need both before anything else, and as two loads with a
+// branch between them they were two L2 round trips in front of every tile's first record fetch
+__device__ __forceinline__ uint2 frame_flags(const ImgState& s)
+{
+    static_assert(offsetof(Meta, n_nonempty) == offsetof(Meta, error) + 4 && offsetof(Meta, error) % 8 == 0, "Meta layout");
+    const unsigned long long v = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(&s.meta->error));
+    return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+}
 // A frame that tgs_forward_async could not fit into the caller's binning capacity: every kernel behind k_scan returns.
 __device__ __forceinline__ bool frame_rejected(const ImgState& s)
 {

@@ -895,11 +895,12 @@ __global__ __launch_bounds__(FWD_THREADS, 8) void k_render_fwd(const ImgState s,
     __shared__ uint32_t wave_qmax[16];
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     const uint4 td = s.tile_desc[blockIdx.x];
-    if (blockIdx.x >= s.meta->n_nonempty) {                // grid = all tiles (sync-free forward): the empty ones are the tail of tile_order
+    const uint2 ff = frame_flags(s);                       // (error bits, non-empty tiles): one load, in flight beside the descriptor's
+    if (blockIdx.x >= ff.y) {                              // grid = all tiles (sync-free forward): the empty ones are the tail of tile_order
         if (fill_tail && threadIdx.x < 256) fill_tile_background(s, td.x, threadIdx.x, W, H, gx, bg, out_color);
         return;
     }
-    if (frame_rejected(s)) {
+    if (ff.x & META_ERR_CAPACITY) {
         if (threadIdx.x < 256) fill_tile_background(s, td.x, threadIdx.x, W, H, gx, bg, out_color);
         return;
     }
