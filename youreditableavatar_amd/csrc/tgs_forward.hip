@@ -112,9 +112,48 @@ __device__ __forceinline__ bool tile_reachable(float2 xy, float4 co, uint32_t tx
 
 // One Gaussian of one view: projection, EWA covariance, SH colour, tile rectangle, the mask of the rectangle's live tiles and
 // the 64-B pack line.  Shared by the one-view and the all-views kernel.
+// computeColorFromSH (forward.cu:20-71): colour of a Gaussian seen along (dx, dy, dz) = mean - camera position, from its 16 x 3
+// coefficients shv (those of the active degree D are read); clampbits: the channels clamped at 0
+__device__ __forceinline__ void sh_to_color(int D, const float (&shv)[48], float dx, float dy, float dz, float& col0, float& col1, float& col2, uint32_t& clampbits)
+{
+#pragma clang fp contract(off)      // un-fused like the rest of the per-Gaussian forward: the oracle's (and the reference's source's) operation order
+    const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float x = dx / len, y = dy / len, z = dz / len;
+    float res[3];
+    clampbits = 0;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+#define SH(k) shv[3 * (k) + c]
+        float r = SH_C0 * SH(0);
+        if (D > 0) {
+            r = r - SH_C1 * y * SH(1) + SH_C1 * z * SH(2) - SH_C1 * x * SH(3);
+            if (D > 1) {
+                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                r = r + SH_C2_0 * xy * SH(4) + SH_C2_1 * yz * SH(5) + SH_C2_2 * (2.0f * zz - xx - yy) * SH(6) +
+                    SH_C2_3 * xz * SH(7) + SH_C2_4 * (xx - yy) * SH(8);
+                if (D > 2) {
+                    r = r + SH_C3_0 * y * (3.0f * xx - yy) * SH(9) + SH_C3_1 * xy * z * SH(10) +
+                        SH_C3_2 * y * (4.0f * zz - xx - yy) * SH(11) +
+                        SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * SH(12) +
+                        SH_C3_4 * x * (4.0f * zz - xx - yy) * SH(13) + SH_C3_5 * z * (xx - yy) * SH(14) +
+                        SH_C3_6 * x * (xx - 3.0f * yy) * SH(15);
+                }
+            }
+        }
+#undef SH
+        r += 0.5f;
+        if (r < 0.f) clampbits |= 1u << c;
+        res[c] = fmaxf(r, 0.0f);
+    }
+    col0 = res[0]; col1 = res[1]; col2 = res[2];
+}
+
+// a view's colour of one Gaussian, evaluated before the per-view stage (sh_colors_half_staged); valid == false: evaluate in place
+struct PreColor { bool valid; float c0, c1, c2; uint32_t clampbits; };
+
 template <bool HAS_SH, bool HAS_SCALE_ROT>
 __device__ __forceinline__ uint32_t preprocess_fwd_one(const FwdIn& in, int* __restrict__ radii, const CamParams& cam, const GeomState& g, const ImgState& s,
-                                                       const float4* sh_lds, bool sh_staged, int idx)
+                                                       const float4* sh_lds, bool sh_staged, int idx, const PreColor& pre)
 {
 #pragma clang fp contract(off)      // projection, covariance, radius and colour un-fused: the oracle's (and the reference's source's) operation order
     uint32_t tiles = 0;
@@ -171,51 +210,26 @@ __device__ __forceinline__ uint32_t preprocess_fwd_one(const FwdIn& in, int* __r
                 if (tiles != 0) {
                     float col0, col1, col2;
                     if (HAS_SH) {
-                        // computeColorFromSH (forward.cu:20-71)
-                        float dx = mx - camx, dy = my - camy, dz = mz - camz;
-                        const float len = sqrtf(dx * dx + dy * dy + dz * dz);
-                        const float x = dx / len, y = dy / len, z = dz / len;
-                        // coefficients of the active degree; M = 16 rows are 192 B and 16-B aligned: read them as float4
-                        float shv[48];
-                        const int ncoef = (in.D + 1) * (in.D + 1);
-                        if (sh_staged) {
-#pragma unroll
-                            for (int q = 0; q < 12; q++) {
-                                if (q * 4 < ncoef * 3) { const float4 t = sh_lds[threadIdx.x * 12 + q]; shv[4 * q] = t.x; shv[4 * q + 1] = t.y; shv[4 * q + 2] = t.z; shv[4 * q + 3] = t.w; }
-                            }
+                        if (pre.valid) {                       // colour of this view evaluated in the staging phase (sh_colors_half_staged)
+                            col0 = pre.c0; col1 = pre.c1; col2 = pre.c2;
+                            g.clamped[idx] = (uint8_t)pre.clampbits;
                         } else {
-                            const float* sh = in.shs + (size_t)idx * in.M * 3;
+                            float shv[48];
+                            const int ncoef = (in.D + 1) * (in.D + 1);
+                            if (sh_staged) {
 #pragma unroll
-                            for (int q = 0; q < 48; q++) if (q < ncoef * 3) shv[q] = sh[q];
-                        }
-                        float res[3];
-                        uint32_t clampbits = 0;
-#pragma unroll
-                        for (int c = 0; c < 3; c++) {
-#define SH(k) shv[3 * (k) + c]
-                            float r = SH_C0 * SH(0);
-                            if (in.D > 0) {
-                                r = r - SH_C1 * y * SH(1) + SH_C1 * z * SH(2) - SH_C1 * x * SH(3);
-                                if (in.D > 1) {
-                                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                                    r = r + SH_C2_0 * xy * SH(4) + SH_C2_1 * yz * SH(5) + SH_C2_2 * (2.0f * zz - xx - yy) * SH(6) +
-                                        SH_C2_3 * xz * SH(7) + SH_C2_4 * (xx - yy) * SH(8);
-                                    if (in.D > 2) {
-                                        r = r + SH_C3_0 * y * (3.0f * xx - yy) * SH(9) + SH_C3_1 * xy * z * SH(10) +
-                                            SH_C3_2 * y * (4.0f * zz - xx - yy) * SH(11) +
-                                            SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * SH(12) +
-                                            SH_C3_4 * x * (4.0f * zz - xx - yy) * SH(13) + SH_C3_5 * z * (xx - yy) * SH(14) +
-                                            SH_C3_6 * x * (xx - 3.0f * yy) * SH(15);
-                                    }
+                                for (int q = 0; q < 12; q++) {
+                                    if (q * 4 < ncoef * 3) { const float4 t = sh_lds[threadIdx.x * 12 + q]; shv[4 * q] = t.x; shv[4 * q + 1] = t.y; shv[4 * q + 2] = t.z; shv[4 * q + 3] = t.w; }
                                 }
+                            } else {
+                                const float* sh = in.shs + (size_t)idx * in.M * 3;
+#pragma unroll
+                                for (int q = 0; q < 48; q++) if (q < ncoef * 3) shv[q] = sh[q];
                             }
-#undef SH
-                            r += 0.5f;
-                            if (r < 0.f) clampbits |= 1u << c;
-                            res[c] = fmaxf(r, 0.0f);
+                            uint32_t clampbits;
+                            sh_to_color(in.D, shv, mx - camx, my - camy, mz - camz, col0, col1, col2, clampbits);
+                            g.clamped[idx] = (uint8_t)clampbits;
                         }
-                        col0 = res[0]; col1 = res[1]; col2 = res[2];
-                        g.clamped[idx] = (uint8_t)clampbits;
                     } else {
                         col0 = in.colors_precomp[3 * (size_t)idx]; col1 = in.colors_precomp[3 * (size_t)idx + 1]; col2 = in.colors_precomp[3 * (size_t)idx + 2];
                     }
@@ -282,20 +296,89 @@ __device__ __forceinline__ void stage_sh_rows(const FwdIn& in, float4* sh_lds)
     __syncthreads();
 }
 
-template <bool HAS_SH, bool HAS_SCALE_ROT>
-__global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd(const FwdIn in, const CamParams cam, const GeomState g,
-                                                              const ImgState s)
+// The colours of the workgroup's 256 Gaussians for NV views, with HALF of their SH rows in LDS at a time (24 KB instead of 48: the
+// kernel's occupancy is bound by LDS -- 3 workgroups per CU with the whole set staged, and its time follows the occupancy: 63 us at 2
+// workgroups per CU, 52 at 3).  Rows of Gaussians [0, 128) of the block go to LDS (coalesced 16-B-per-lane loads; a per-thread walk
+// over its own 192-B row would touch 64 lines per instruction), threads 0..127 evaluate their colour for every view, then the same for
+// [128, 256) -- whose rows were fetched into registers before the first half was evaluated.  A Gaussian behind the near plane of a
+// view gets no colour (it is never read).
+constexpr int SH_HALF = PRE_BLOCK / 2;
+template <int NV>
+__device__ __forceinline__ void sh_colors_half_staged(const FwdIn& in, const FwdView* __restrict__ views, int idx, float4* sh_lds, PreColor (&pre)[NV])
 {
-    const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
-    __shared__ float4 sh_lds[HAS_SH ? PRE_BLOCK * 12 : 1];
-    const bool sh_staged = HAS_SH && in.M == 16;
-    if (sh_staged) stage_sh_rows(in, sh_lds);
-    const uint32_t tiles = preprocess_fwd_one<HAS_SH, HAS_SCALE_ROT>(in, in.radii, cam, g, s, sh_lds, sh_staged, idx);
-    block_sum_tiles(tiles, g.block_sums);
+    const float4* s4 = reinterpret_cast<const float4*>(in.shs);
+    const size_t base4 = (size_t)blockIdx.x * PRE_BLOCK * 12, total4 = (size_t)in.P * 12;
+    constexpr int PER = SH_HALF * 12 / PRE_BLOCK;            // float4 per thread and half (6)
+    float4 r0[PER], r1[PER];
+#pragma unroll
+    for (int q = 0; q < PER; q++) { const size_t i = base4 + q * PRE_BLOCK + threadIdx.x; r0[q] = i < total4 ? nt_load4(&s4[i]) : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+    for (int q = 0; q < PER; q++) sh_lds[q * PRE_BLOCK + threadIdx.x] = r0[q];
+#pragma unroll
+    for (int q = 0; q < PER; q++) { const size_t i = base4 + SH_HALF * 12 + q * PRE_BLOCK + threadIdx.x; r1[q] = i < total4 ? nt_load4(&s4[i]) : make_float4(0.f, 0.f, 0.f, 0.f); }
+    float mx = 0.f, my = 0.f, mz = 0.f;
+    if (idx < in.P) { mx = in.means3D[3 * (size_t)idx]; my = in.means3D[3 * (size_t)idx + 1]; mz = in.means3D[3 * (size_t)idx + 2]; }
+    auto eval = [&]() {
+        float shv[48];
+        const int ncoef = (in.D + 1) * (in.D + 1);
+        const float4* row = sh_lds + (threadIdx.x & (SH_HALF - 1)) * 12;
+#pragma unroll
+        for (int q = 0; q < 12; q++) {
+            if (q * 4 < ncoef * 3) { const float4 t = row[q]; shv[4 * q] = t.x; shv[4 * q + 1] = t.y; shv[4 * q + 2] = t.z; shv[4 * q + 3] = t.w; }
+        }
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            const CamParams& cam = views[v].cam;
+            const float view_z = cam.view[2] * mx + cam.view[6] * my + cam.view[10] * mz + cam.view[14];
+            pre[v].valid = true;
+            if (!(view_z <= 0.2f)) sh_to_color(in.D, shv, mx - cam.campos[0], my - cam.campos[1], mz - cam.campos[2], pre[v].c0, pre[v].c1, pre[v].c2, pre[v].clampbits);
+        }
+    };
+#pragma unroll
+    for (int v = 0; v < NV; v++) { pre[v].valid = true; pre[v].c0 = pre[v].c1 = pre[v].c2 = 0.f; pre[v].clampbits = 0u; }
+    __syncthreads();
+    if (threadIdx.x < SH_HALF && idx < in.P) eval();
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PER; q++) sh_lds[q * PRE_BLOCK + threadIdx.x] = r1[q];
+    __syncthreads();
+    if (threadIdx.x >= SH_HALF && idx < in.P) eval();
 }
 
-// All views of a batch in one launch (tgs_forward_views): the 192-B SH row -- 80 % of what the kernel reads -- is
-// staged once and every view then projects, colours and counts from it.
+template <bool HAS_SH, bool HAS_SCALE_ROT>
+__global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd(const FwdIn in, const FwdView vw)
+{
+    const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
+    __shared__ float4 sh_lds[HAS_SH ? SH_HALF * 12 : 1];
+    PreColor pre[1];
+    pre[0].valid = false;
+    if (HAS_SH && in.M == 16) sh_colors_half_staged<1>(in, &vw, idx, sh_lds, pre);
+    const uint32_t tiles = preprocess_fwd_one<HAS_SH, HAS_SCALE_ROT>(in, vw.radii, vw.cam, vw.g, vw.s, sh_lds, false, idx, pre[0]);
+    block_sum_tiles(tiles, vw.g.block_sums);
+}
+
+// Two views of a batch in one launch (tgs_forward_views, the default group): the 192-B SH row -- more than half of what the stage
+// reads -- is fetched once for both.
+template <bool HAS_SH, bool HAS_SCALE_ROT>
+__global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd_pair(const FwdIn in, const FwdView v0, const FwdView v1)
+{
+    const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
+    __shared__ float4 sh_lds[HAS_SH ? SH_HALF * 12 : 1];
+    const FwdView vws[2] = {v0, v1};
+    PreColor pre[2];
+    pre[0].valid = pre[1].valid = false;
+    if (HAS_SH && in.M == 16) sh_colors_half_staged<2>(in, vws, idx, sh_lds, pre);
+#pragma unroll
+    for (int v = 0; v < 2; v++) {
+        const FwdView& vw = v == 0 ? v0 : v1;
+        const uint32_t tiles = preprocess_fwd_one<HAS_SH, HAS_SCALE_ROT>(in, vw.radii, vw.cam, vw.g, vw.s, sh_lds, false, idx, pre[v]);
+        block_sum_tiles(tiles, vw.g.block_sums);
+        __syncthreads();                                   // wsum is reused by the next view
+    }
+}
+
+// More than two views of a batch in one launch (tgs_set_forward_group > 2): the whole set of rows staged once, every view then projects,
+// colours and counts from it.
 template <bool HAS_SH, bool HAS_SCALE_ROT>
 __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd_batch(const FwdIn in, const FwdViews views)
 {
@@ -303,10 +386,12 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd_batch(const FwdIn 
     __shared__ float4 sh_lds[HAS_SH ? PRE_BLOCK * 12 : 1];
     const bool sh_staged = HAS_SH && in.M == 16;
     if (sh_staged) stage_sh_rows(in, sh_lds);
+    PreColor pre;
+    pre.valid = false;
 #pragma unroll 1
     for (int v = 0; v < views.n; v++) {
         const FwdView& vw = views.v[v];
-        const uint32_t tiles = preprocess_fwd_one<HAS_SH, HAS_SCALE_ROT>(in, vw.radii, vw.cam, vw.g, vw.s, sh_lds, sh_staged, idx);
+        const uint32_t tiles = preprocess_fwd_one<HAS_SH, HAS_SCALE_ROT>(in, vw.radii, vw.cam, vw.g, vw.s, sh_lds, sh_staged, idx, pre);
         block_sum_tiles(tiles, vw.g.block_sums);
         __syncthreads();                                   // wsum is reused by the next view
     }
@@ -1063,15 +1148,24 @@ void launch_preprocess_fwd(hipStream_t st, const FwdIn& in, const CamParams& cam
 {
     const dim3 grid((unsigned)n_blocks(in.P)), blk(PRE_BLOCK);
     const bool sh = in.colors_precomp == nullptr, sr = in.cov3D_precomp == nullptr;
-    if (sh && sr) hipLaunchKernelGGL((k_preprocess_fwd<true, true>), grid, blk, 0, st, in, cam, g, s);
-    else if (sh) hipLaunchKernelGGL((k_preprocess_fwd<true, false>), grid, blk, 0, st, in, cam, g, s);
-    else if (sr) hipLaunchKernelGGL((k_preprocess_fwd<false, true>), grid, blk, 0, st, in, cam, g, s);
-    else hipLaunchKernelGGL((k_preprocess_fwd<false, false>), grid, blk, 0, st, in, cam, g, s);
+    FwdView vw;
+    vw.cam = cam; vw.g = g; vw.s = s; vw.radii = in.radii;
+    if (sh && sr) hipLaunchKernelGGL((k_preprocess_fwd<true, true>), grid, blk, 0, st, in, vw);
+    else if (sh) hipLaunchKernelGGL((k_preprocess_fwd<true, false>), grid, blk, 0, st, in, vw);
+    else if (sr) hipLaunchKernelGGL((k_preprocess_fwd<false, true>), grid, blk, 0, st, in, vw);
+    else hipLaunchKernelGGL((k_preprocess_fwd<false, false>), grid, blk, 0, st, in, vw);
 }
 void launch_preprocess_fwd_batch(hipStream_t st, const FwdIn& in, const FwdViews& views)
 {
     const dim3 grid((unsigned)n_blocks(in.P)), blk(PRE_BLOCK);
     const bool sh = in.colors_precomp == nullptr, sr = in.cov3D_precomp == nullptr;
+    if (views.n == 2) {
+        if (sh && sr) hipLaunchKernelGGL((k_preprocess_fwd_pair<true, true>), grid, blk, 0, st, in, views.v[0], views.v[1]);
+        else if (sh) hipLaunchKernelGGL((k_preprocess_fwd_pair<true, false>), grid, blk, 0, st, in, views.v[0], views.v[1]);
+        else if (sr) hipLaunchKernelGGL((k_preprocess_fwd_pair<false, true>), grid, blk, 0, st, in, views.v[0], views.v[1]);
+        else hipLaunchKernelGGL((k_preprocess_fwd_pair<false, false>), grid, blk, 0, st, in, views.v[0], views.v[1]);
+        return;
+    }
     if (sh && sr) hipLaunchKernelGGL((k_preprocess_fwd_batch<true, true>), grid, blk, 0, st, in, views);
     else if (sh) hipLaunchKernelGGL((k_preprocess_fwd_batch<true, false>), grid, blk, 0, st, in, views);
     else if (sr) hipLaunchKernelGGL((k_preprocess_fwd_batch<false, true>), grid, blk, 0, st, in, views);
