@@ -389,10 +389,11 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
 // tail of the whole kernel on scenes with oversized splats -- is summed by the whole wave: lane l takes rows l, l + 64, ...
 // and the nine totals are formed with wave_sum.  Fixed order either way.  Call from convergent code.
 constexpr uint32_t SLAB_COOP = 128;
-__device__ __forceinline__ void slab_sum(bool live, int idx, const GeomState& g, const BinState& b, float (&a)[NACC])
+// (tiles, off): the Gaussian's tiles_touched and offsets of this view, fetched by the caller
+__device__ __forceinline__ void slab_sum(bool live, uint32_t tiles_in, uint32_t off_in, const BinState& b, float (&a)[NACC])
 {
     const int lane = threadIdx.x & 63;
-    const uint32_t tiles = live ? g.tiles_touched[idx] : 0u, off = live ? g.offsets[idx] : 0u;
+    const uint32_t tiles = live ? tiles_in : 0u, off = live ? off_in : 0u;
 #pragma unroll
     for (int c = 0; c < NACC; c++) a[c] = 0.f;
     unsigned long long big = __builtin_amdgcn_ballot_w64(tiles >= SLAB_COOP);
@@ -429,12 +430,12 @@ struct GaussTerms {
 template <bool HAS_SH, bool HAS_SCALE_ROT, typename ShRow>
 __device__ __forceinline__ void pergauss_terms(int idx, bool live, int D, const ShRow& sh, const BwdIn& in, const float* __restrict__ cov3D_precomp,
                                                const CamParams& cam, const ViewMat& V, const ViewMat& PM, float camx, float camy, float camz,
-                                               const GeomState& g, const BinState& b, GaussTerms& t)
+                                               const GeomState& g, const BinState& b, uint32_t tiles_in, uint32_t off_in, GaussTerms& t)
 {
     float (&a)[NACC] = t.a;
     float (&dmean)[3] = t.dmean; float (&dcov)[6] = t.dcov; float (&dscale)[3] = t.dscale; float (&drot)[4] = t.drot;
     float (&coef)[16] = t.coef; float (&dRGB)[3] = t.dRGB;
-    slab_sum(live, idx, g, b, a);                          // convergent: the wave helps its splats that touch many tiles
+    slab_sum(live, tiles_in, off_in, b, a);                // convergent: the wave helps its splats that touch many tiles
 #pragma unroll
     for (int k = 0; k < 3; k++) { dmean[k] = 0.f; dscale[k] = 0.f; dRGB[k] = 0.f; }
 #pragma unroll
@@ -705,7 +706,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
     const bool live = in_range && in.radii[idx] > 0;        // backward.cu:156,367
     float mx = 0.f, my = 0.f, mz = 0.f;
     float dRGB[3] = {0.f, 0.f, 0.f};
-    slab_sum(live, idx, g, b, a);                           // sum of this Gaussian's tile partials (wave-cooperative for big splats)
+    slab_sum(live, live ? g.tiles_touched[idx] : 0u, live ? g.offsets[idx] : 0u, b, a);   // sum of this Gaussian's tile partials (wave-cooperative for big splats)
     if (live) {
         mx = in.means3D[i3]; my = in.means3D[i3 + 1]; mz = in.means3D[i3 + 2];
 
@@ -947,6 +948,20 @@ __global__ __launch_bounds__(PRE_BLOCK, 2) void k_preprocess_bwd_batch(const Bwd
     if (sh_staged) load_sh_rows_staged(in, sh_lds, blk);
     const bool in_range = idx < in.P;
     const float* sh_row = sh_staged ? reinterpret_cast<const float*>(&sh_lds[threadIdx.x * 12]) : (HAS_SH ? in.shs + (size_t)(in_range ? idx : 0) * in.M * 3 : nullptr);
+    // radii / tiles_touched / offsets of this Gaussian in every view, fetched together up front (one memory round trip instead of two per
+    // view in front of the view's slab rows: at 2 waves per SIMD the pass is bound by the latency of such chains) and parked in LDS --
+    // each thread reads back only what it wrote, so no barrier
+    __shared__ uint32_t pv_lds[BATCH_VIEWS][3][PRE_BLOCK];
+    {
+        uint32_t pr[BATCH_VIEWS], pt[BATCH_VIEWS], po[BATCH_VIEWS];
+#pragma unroll
+        for (int v = 0; v < BATCH_VIEWS; v++) {
+            pr[v] = pt[v] = po[v] = 0u;
+            if (v < views.n && in_range) { pr[v] = (uint32_t)views.v[v].radii[idx]; pt[v] = views.v[v].g.tiles_touched[idx]; po[v] = views.v[v].g.offsets[idx]; }
+        }
+#pragma unroll
+        for (int v = 0; v < BATCH_VIEWS; v++) { pv_lds[v][0][threadIdx.x] = pr[v]; pv_lds[v][1][threadIdx.x] = pt[v]; pv_lds[v][2][threadIdx.x] = po[v]; }
+    }
     float o48[48];                                         // dL_dsh row accumulated over the views (dead code without SH)
 #pragma unroll
     for (int i = 0; i < 48; i++) o48[i] = 0.f;
@@ -955,12 +970,12 @@ __global__ __launch_bounds__(PRE_BLOCK, 2) void k_preprocess_bwd_batch(const Bwd
     for (int v = 0; v < views.n; v++) {
         const BatchView& vw = views.v[v];
         const bool rejected = (vw.meta->error & META_ERR_CAPACITY) != 0u;       // tgs_forward_async could not fit this frame: it contributes nothing
-        const bool live = in_range && !rejected && vw.radii[idx] > 0;
+        const bool live = in_range && !rejected && (int)pv_lds[v][0][threadIdx.x] > 0;
         GaussTerms t;
         if (__builtin_amdgcn_ballot_w64(live) != 0) {
             const ViewMat V = load_mat(vw.cam.view), PM = load_mat(vw.cam.proj);
             pergauss_terms<HAS_SH, HAS_SCALE_ROT>(idx, live, in.D, [&](int i) { return sh_row[i]; }, in, in.cov3D_precomp, vw.cam, V, PM, vw.cam.campos[0], vw.cam.campos[1],
-                                                  vw.cam.campos[2], vw.g, vw.b, t);
+                                                  vw.cam.campos[2], vw.g, vw.b, pv_lds[v][1][threadIdx.x], pv_lds[v][2][threadIdx.x], t);
         } else {
             t.a[0] = t.a[1] = t.a[2] = t.a[3] = t.a[4] = 0.f;
         }
