@@ -28,7 +28,8 @@
  * state buffers.  What IS process-wide, and only that: the test / experiment knobs declared further down -- tgs_set_sort_lds_cap,
  * tgs_set_instance_pruning, tgs_set_forward_group, tgs_set_deterministic (relaxed atomics read once per call; none of them changes a
  * result beyond summation order, instance pruning changes num_rendered / n_contrib as documented) -- and the optional bench profiler
- * (tgs_profile_*).  Per calling thread: the message of tgs_last_error(), tgs_set_render_streams, and the pinned 64-byte staging slot +
+ * (tgs_profile_*) -- plus two tuning variables of the environment, read once: TGS_BIN_WGS (binning chunks per view, default 128) and
+ * TGS_FORWARD_GROUP (overrides tgs_set_forward_group).  Per calling thread: the message of tgs_last_error(), tgs_set_render_streams, and the pinned 64-byte staging slot +
  * event of tgs_forward_speculative (one per thread and device).  A caller that never touches the knobs shares nothing between calls.
  */
 #ifndef TGS_RASTER_H
