@@ -1177,15 +1177,14 @@ void launch_scan(hipStream_t st, const GeomState& g, const ImgState& s, uint32_t
     hipLaunchKernelGGL(k_scan, dim3(2), dim3(SCAN_THREADS), 0, st, g, s, nblocks, T, sort_cap, r_capacity, allow_overflow, host_meta);
 }
 // Binning chunks: `nchunks` workgroups of BIN_THREADS threads, `chunk` Gaussians each (a multiple of BIN_THREADS)
-static int g_bin_wgs = 0;
 void bin_shape(int P, uint32_t T, uint32_t& nchunks, uint32_t& chunk, uint32_t& band, size_t& lds)
 {
-    if (g_bin_wgs == 0) {                                   // TGS_BIN_WGS: tuning knob, read once
+    static const int bin_wgs = [] {                         // TGS_BIN_WGS: tuning knob, read once (thread-safe initialisation)
         const char* e = getenv("TGS_BIN_WGS");
-        int v = e ? atoi(e) : BIN_WGS_MAX;
-        g_bin_wgs = v < 1 ? 1 : (v > BIN_WGS_MAX ? BIN_WGS_MAX : v);
-    }
-    const uint32_t per = ((uint32_t)P + (uint32_t)g_bin_wgs - 1) / (uint32_t)g_bin_wgs;
+        const int v = e ? atoi(e) : BIN_WGS_MAX;
+        return v < 1 ? 1 : (v > BIN_WGS_MAX ? BIN_WGS_MAX : v);
+    }();
+    const uint32_t per = ((uint32_t)P + (uint32_t)bin_wgs - 1) / (uint32_t)bin_wgs;
     chunk = (per + BIN_THREADS - 1) / BIN_THREADS * BIN_THREADS;
     if (chunk == 0) chunk = BIN_THREADS;
     nchunks = ((uint32_t)P + chunk - 1) / chunk;
