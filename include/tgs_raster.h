@@ -219,6 +219,9 @@ typedef struct {
     const float* dL_dpix;      /* [3,H,W] */
     size_t geom_bytes, binning_bytes, img_bytes;   /* capacities of the three caller-allocated state buffers */
     const float* colors_precomp;  /* [P,3] colours of THIS view (tgs_forward_views; overrides the shared argument) or NULL */
+    int64_t tile_bound;        /* *_views entry points: upper bound on the tiles that hold instances, or 0 (none): the sync-free grids are then
+                                  sized for that many tiles instead of all of them (surplus workgroups of thousands of empty tiles cost ~4 % of a
+                                  frame each way at config 3); a frame with MORE non-empty tiles is rejected like one that exceeds r_capacity */
 } tgs_view_t;
 /* Whole-batch entry points: one call enqueues the forward (or the per-pixel backward) of every view, view k on
  * streams[k % n_streams], with state buffers the CALLER allocated up front (tgs_state_sizes) -- no allocation callback, no
@@ -240,6 +243,12 @@ void tgs_set_instance_pruning(int on);
  * view's own stream -- so that binning (L2 atomics, latency) and compositing (VALU) of different views run on streams of their own.
  * n = 0 restores one stream per view. */
 int tgs_set_render_streams(void* const* streams, int n);
+/* Per calling thread: the same bound for the single-view sync-free entry points (tgs_forward_async, tgs_forward_speculative -- which
+ * repeats the stages behind the scan with exact sizes when the guess was too small -- and tgs_backward / tgs_backward_render /
+ * tgs_backward_accumulate of a frame KNOWN to have at most that many non-empty tiles).  0 (default): none.  It stays set until changed. */
+void tgs_set_tile_bound(int64_t n_tiles_with_instances);
+/* Non-empty tiles of the last frame this thread rendered with tgs_forward or tgs_forward_speculative (their Meta read-back); -1 if none. */
+int64_t tgs_last_nonempty_tiles(void);
 
 /* Knob (process-wide): views per launch of the per-Gaussian forward stage inside tgs_forward_views (1..8, default 2).  Groups
  * read the SH rows once per group; measured with four streams, pairs pay (-2 % per frame) and larger groups do not (the views of a

@@ -523,6 +523,17 @@ def test_run_views_whole_batch_path(streams, group, gpu_device):
         assert all(same(imgs[v], want_img[v]) for v in range(5))
         assert all(same(batch.viewspace_grads[v], want_2d[v]) for v in range(5))
         assert util.rel_l2(flat.flat.cpu().numpy(), want.cpu().numpy()) <= 2e-5
+        # a bound on the tiles with instances that every view exceeds (the sync-free grids are sized by it): rejected by k_scan, rendered again
+        assert batch.tile_bound is not None and 8 < batch.tile_bound <= 77 and batch.tile_capacity() >= batch.tile_bound
+        rejected_before, learned = batch.rejected, batch.tile_bound
+        batch.tile_capacity = lambda: 8
+        flat.zero_()
+        imgs = run()
+        del batch.tile_capacity
+        assert batch.rejected == rejected_before + 5 and batch.tile_bound == learned
+        assert all(same(imgs[v], want_img[v]) for v in range(5))
+        assert all(same(batch.viewspace_grads[v], want_2d[v]) for v in range(5))
+        assert util.rel_l2(flat.flat.cpu().numpy(), want.cpu().numpy()) <= 2e-5
         # accumulate=False stores: whatever the buffers held is gone
         flat.flat.fill_(5.0)
         batch.run_views(settings, L["means3D"], L["opacities"], L["shs"], L["scales"], L["rotations"], upstream, accumulate=False)

@@ -11,15 +11,15 @@ namespace tgs {
 void launch_preprocess_fwd(hipStream_t, const FwdIn&, const CamParams&, const GeomState&, const ImgState&);
 void launch_preprocess_fwd_batch(hipStream_t, const FwdIn&, const FwdViews&);
 void launch_scan(hipStream_t, const GeomState&, const ImgState&, uint32_t nblocks, uint32_t T, uint32_t sort_cap, unsigned long long r_capacity,
-                 int allow_overflow, Meta* host_meta);
+                 uint32_t tile_bound, Meta* host_meta);
 void launch_bin_count(hipStream_t, int P, const GeomState&, const ImgState&, uint32_t gx, uint32_t T);
 void launch_scatter(hipStream_t, int P, const GeomState&, const ImgState&, const BinState&, uint32_t gx, uint32_t T);
 void launch_tile_sort(hipStream_t, const GeomState&, const ImgState&, const BinState&, uint32_t gx, uint32_t T, uint64_t r_bound, const Meta* m,
-                      uint32_t sort_cap);
+                      uint32_t sort_cap, uint32_t tile_bound);
 void launch_render_fwd(hipStream_t, const ImgState&, const BinState&, int W, int H, uint32_t gx, uint32_t T, const Meta* m, const float* bg,
-                       float* out_color);
+                       float* out_color, uint32_t tile_bound);
 void launch_mark_visible(hipStream_t, int P, const float* means3D, const float* view, uint8_t* present);
-void launch_render_bwd(hipStream_t, const ImgState&, const BinState&, int W, int H, uint32_t gx, uint32_t T, const float* bg, const float* dL_dpix,
+void launch_render_bwd(hipStream_t, const ImgState&, const BinState&, int W, int H, uint32_t gx, uint32_t tiles, const float* bg, const float* dL_dpix,
                        bool deterministic);
 void launch_preprocess_bwd(hipStream_t, const BwdIn&, const CamParams&, const GeomState&, const BinState&);
 void launch_preprocess_bwd_batch(hipStream_t, const BwdIn&, const BatchViews&);
@@ -216,6 +216,10 @@ static SpecSlot* spec_slot()
 // tgs_set_render_streams: k_render_fwd of view k goes to render stream k mod n (behind an event on the view's own stream)
 static thread_local std::vector<hipStream_t> t_render_streams;
 static thread_local hipStream_t t_render_stream = nullptr;
+// tgs_set_tile_bound / tgs_view_t::tile_bound: upper bound on the tiles with instances for the sync-free grids (0: none)
+static thread_local int64_t t_tile_bound = 0;
+static thread_local int64_t t_last_nonempty = -1;
+static uint32_t bounded_tiles(size_t T) { return (t_tile_bound > 0 && (uint64_t)t_tile_bound < (uint64_t)T) ? (uint32_t)t_tile_bound : (uint32_t)T; }
 
 static int64_t forward_impl(int preprocessed, int64_t r_capacity, int64_t* speculative_true_R, tgs_alloc_fn alloc, void* alloc_ctx, void* stream, int P, int D, int M, const float* background, int width,
                     int height, const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
@@ -285,9 +289,11 @@ static int64_t forward_impl(int preprocessed, int64_t r_capacity, int64_t* specu
         spec = spec_slot();
         if (!spec) return fail(TGS_ERR_HIP, "pinned staging for the speculative forward could not be allocated");
     }
+    // sync-free grids cover `tb` tiles (the caller's bound on the tiles with instances, or all of them); k_scan rejects a frame with more
+    const uint32_t tb = async ? bounded_tiles(T) : (uint32_t)T;
     STAGE_BEGIN(TGS_STAGE_SCAN);
     launch_bin_count(st, P, g, s, cam.gx, (uint32_t)T);
-    launch_scan(st, g, s, (uint32_t)n_blocks((size_t)P), (uint32_t)T, sort_cap, async ? (unsigned long long)r_capacity : ~0ull, async ? 0 : 1,
+    launch_scan(st, g, s, (uint32_t)n_blocks((size_t)P), (uint32_t)T, sort_cap, async ? (unsigned long long)r_capacity : ~0ull, tb,
                 spec ? spec->meta : nullptr);
     STAGE_CHECK("scan", TGS_STAGE_SCAN);
     if (spec) {
@@ -303,6 +309,7 @@ static int64_t forward_impl(int preprocessed, int64_t r_capacity, int64_t* specu
         if (meta.error & 1u) return fail(TGS_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
         R = meta.R;
         if (R > 0x7fffffffull) return fail(TGS_ERR_TOO_MANY, "%llu tile instances exceed 2^31-1", (unsigned long long)R);
+        t_last_nonempty = (int64_t)meta.n_nonempty;
     } else {
         R = (uint64_t)r_capacity;
     }
@@ -317,7 +324,7 @@ static int64_t forward_impl(int preprocessed, int64_t r_capacity, int64_t* specu
         launch_scatter(st, P, g, s, b, cam.gx, (uint32_t)T);
         STAGE_CHECK("scatter", TGS_STAGE_SCATTER);
         STAGE_BEGIN(TGS_STAGE_TILE_SORT);
-        launch_tile_sort(st, g, s, b, cam.gx, (uint32_t)T, R, known, sort_cap);
+        launch_tile_sort(st, g, s, b, cam.gx, (uint32_t)T, R, known, sort_cap, tb);
         STAGE_CHECK("tile_sort", TGS_STAGE_TILE_SORT);
     }
     hipStream_t rst = st;
@@ -330,7 +337,7 @@ static int64_t forward_impl(int preprocessed, int64_t r_capacity, int64_t* specu
         rst = t_render_stream;
     }
     STAGE_BEGIN(TGS_STAGE_RENDER_FWD);
-    launch_render_fwd(rst, s, b, width, height, cam.gx, (uint32_t)T, known, background, out_color);
+    launch_render_fwd(rst, s, b, width, height, cam.gx, (uint32_t)T, known, background, out_color, tb);
     STAGE_CHECK("render", TGS_STAGE_RENDER_FWD);
     if (spec) {
         HIP_TRY(hipEventSynchronize(spec->ready));
@@ -338,7 +345,8 @@ static int64_t forward_impl(int preprocessed, int64_t r_capacity, int64_t* specu
         if (meta.error & 1u) return fail(TGS_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
         if (meta.R > 0x7fffffffull) return fail(TGS_ERR_TOO_MANY, "%llu tile instances exceed 2^31-1", (unsigned long long)meta.R);
         *speculative_true_R = (int64_t)meta.R;
-        if (meta.error & META_ERR_CAPACITY) {
+        t_last_nonempty = (int64_t)meta.n_nonempty;
+        if ((meta.error & META_ERR_CAPACITY) || meta.pad[0] != 0u) {     // (pad[0]: more tiles with instances than the caller's bound, k_scan)
             // the guess was too small: every kernel behind the scan returned at
             // once; clear the flag and run those stages again with the exact sizes, as tgs_forward does
             HIP_TRY(hipMemsetAsync(&s.meta->error, 0, sizeof(uint32_t), st));
@@ -349,9 +357,9 @@ static int64_t forward_impl(int preprocessed, int64_t r_capacity, int64_t* specu
             bin_carve(b, exact_ptr, (size_t)R);
             if (R > 0) {
                 launch_scatter(st, P, g, s, b, cam.gx, (uint32_t)T);
-                launch_tile_sort(st, g, s, b, cam.gx, (uint32_t)T, R, &meta, sort_cap);
+                launch_tile_sort(st, g, s, b, cam.gx, (uint32_t)T, R, &meta, sort_cap, (uint32_t)T);
             }
-            launch_render_fwd(st, s, b, width, height, cam.gx, (uint32_t)T, &meta, background, out_color);
+            launch_render_fwd(st, s, b, width, height, cam.gx, (uint32_t)T, &meta, background, out_color, (uint32_t)T);
             HIP_TRY(hipGetLastError());
         }
     }
@@ -442,7 +450,7 @@ static int backward_impl(int accumulate, void* stream, int P, int D, int M, int6
 
     if (R > 0) {
         STAGE_BEGIN(TGS_STAGE_RENDER_BWD);
-        launch_render_bwd(st, s, b, width, height, cam.gx, (uint32_t)T, background, dL_dpix, deterministic_mode());
+        launch_render_bwd(st, s, b, width, height, cam.gx, bounded_tiles(T), background, dL_dpix, deterministic_mode());
         STAGE_CHECK("render_bwd", TGS_STAGE_RENDER_BWD);
     }
     STAGE_BEGIN(TGS_STAGE_PREPROCESS_BWD);
@@ -493,6 +501,9 @@ static void* alloc_preset(void* ctx, int which, size_t bytes)
     if (which == TGS_BUF_IMAGE) return bytes <= v->img_bytes ? const_cast<void*>(v->img_buffer) : nullptr;
     return nullptr;
 }
+
+void tgs_set_tile_bound(int64_t n) { t_tile_bound = n > 0 ? n : 0; }
+int64_t tgs_last_nonempty_tiles(void) { return t_last_nonempty; }
 
 int tgs_set_render_streams(void* const* streams, int n)
 {
@@ -574,6 +585,8 @@ int tgs_forward_views(void* const* streams, int n_streams, int64_t r_capacity, i
             if (pre_done && st != st0) HIP_TRY(hipStreamWaitEvent(st, pre_done, 0));
             t_render_stream = t_render_streams.empty() ? nullptr : t_render_streams[(size_t)(v0 + k) % t_render_streams.size()];
             struct Reset { ~Reset() { t_render_stream = nullptr; } } reset_render_stream;
+            struct BoundReset { int64_t old; ~BoundReset() { t_tile_bound = old; } } bound_reset{t_tile_bound};
+            t_tile_bound = v.tile_bound > 0 ? v.tile_bound : 0;
             const int64_t r = forward_impl(batched ? 1 : 0, r_capacity, nullptr, alloc_preset, &v, st, P, D, M, v.background, v.width, v.height, means3D, shs,
                                            v.colors_precomp ? v.colors_precomp : colors_precomp,
                                            opacities, scales, scale_modifier, rotations, cov3D_precomp, v.viewmatrix, v.projmatrix, v.campos, v.tan_fovx, v.tan_fovy,
@@ -592,7 +605,10 @@ int tgs_backward_render_views(void* const* streams, int n_streams, int P, int n_
     if (!streams || n_streams <= 0 || n_views < 0 || !views) return fail(TGS_ERR_INVALID, "bad arguments");
     for (int k = 0; k < n_views; k++) {
         const tgs_view_t& v = views[k];
+        const int64_t old_bound = t_tile_bound;
+        t_tile_bound = v.tile_bound > 0 ? v.tile_bound : 0;
         const int r = tgs_backward_render(streams[k % n_streams], P, v.R, v.background, v.width, v.height, v.binning_buffer, v.img_buffer, v.dL_dpix);
+        t_tile_bound = old_bound;
         if (r < 0) return r;
     }
     return TGS_OK;
@@ -613,7 +629,7 @@ int tgs_backward_render(void* stream, int P, int64_t R, const float* background,
     bin_carve(b, (char*)binning_buffer, (size_t)R);
     if (R > 0) {
         STAGE_BEGIN(TGS_STAGE_RENDER_BWD);
-        launch_render_bwd(st, s, b, width, height, gx, gx * gy, background, dL_dpix, deterministic_mode());
+        launch_render_bwd(st, s, b, width, height, gx, bounded_tiles((size_t)gx * gy), background, dL_dpix, deterministic_mode());
         STAGE_CHECK("render_bwd", TGS_STAGE_RENDER_BWD);
     }
     return TGS_OK;

@@ -1034,12 +1034,13 @@ void launch_selftest_reduce36(hipStream_t st, const float* in, float* out)
     hipLaunchKernelGGL(k_selftest_reduce36, dim3(1), dim3(64), 0, st, in, out);
 }
 
-void launch_render_bwd(hipStream_t st, const ImgState& s, const BinState& b, int W, int H, uint32_t gx, uint32_t T, const float* bg, const float* dL_dpix,
+// `tiles`: leading entries of tile_order to visit -- all of them, or the caller's bound on the tiles with instances (the rest is empty)
+void launch_render_bwd(hipStream_t st, const ImgState& s, const BinState& b, int W, int H, uint32_t gx, uint32_t tiles, const float* bg, const float* dL_dpix,
                        bool deterministic)
 {
     // (-DTGS_FAST_MATH=0 builds always take the fixed-order kernel: it evaluates exp / the divisions in their accurate forms)
-    if (deterministic || !TGS_FAST_MATH) hipLaunchKernelGGL(k_render_bwd_det, dim3(T), dim3(256), 0, st, s, b, W, H, gx, bg, dL_dpix);
-    else hipLaunchKernelGGL(k_render_bwd, dim3(T), dim3(BWD_THREADS), 0, st, s, b, W, H, gx, bg, dL_dpix);
+    if (deterministic || !TGS_FAST_MATH) hipLaunchKernelGGL(k_render_bwd_det, dim3(tiles), dim3(256), 0, st, s, b, W, H, gx, bg, dL_dpix);
+    else hipLaunchKernelGGL(k_render_bwd, dim3(tiles), dim3(BWD_THREADS), 0, st, s, b, W, H, gx, bg, dL_dpix);
 }
 void launch_preprocess_bwd(hipStream_t st, const BwdIn& in, const CamParams& cam, const GeomState& g, const BinState& b)
 {

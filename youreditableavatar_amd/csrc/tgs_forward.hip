@@ -419,7 +419,9 @@ __device__ __forceinline__ unsigned long long block_exscan_u64(unsigned long lon
 
 // host_meta (may be NULL): a copy of Meta in pinned, device-visible HOST memory, written by the two workgroups themselves -- the speculative
 // forward's read-back without a copy engine or blit kernel in the stream (a D2H blit between k_scan and k_scatter cost 4 us + a 6-us gap)
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const ImgState s, uint32_t nblocks, uint32_t T, uint32_t sort_cap, unsigned long long r_capacity, int allow_overflow,
+// tile_bound: the sync-free grids behind the scan cover that many entries of tile_order; a frame with more non-empty tiles is rejected
+// like one that exceeds r_capacity (T: no bound)
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const ImgState s, uint32_t nblocks, uint32_t T, uint32_t sort_cap, unsigned long long r_capacity, uint32_t tile_bound,
                                                        Meta* host_meta)
 {
     __shared__ unsigned long long lds[SCAN_THREADS / WAVE];
@@ -485,7 +487,21 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const 
             __syncthreads();
         }
         // tiles by descending list length (power-of-two buckets; order inside a bucket does not matter)
-        if (threadIdx.x == 0) { uint32_t acc = 0; for (int b2 = 33; b2-- > 0;) { const uint32_t h = hist[b2]; hist[b2] = acc; if (b2 == 1) s.meta->n_nonempty = acc + h; if (b2 == 11) s.meta->n_heavy = acc + h; if (b2 == 8) s.meta->n_mid = acc + h; acc += h; } }
+        if (threadIdx.x == 0) {
+            uint32_t acc = 0;
+            for (int b2 = 33; b2-- > 0;) {
+                const uint32_t h = hist[b2]; hist[b2] = acc;
+                if (b2 == 1) {
+                    s.meta->n_nonempty = acc + h;
+                    const bool too_many = acc + h > tile_bound;     // more tiles with instances than the grids behind the scan cover
+                    if (too_many) atomicOr(&s.meta->error, META_ERR_CAPACITY);
+                    if (host_meta) host_meta->pad[0] = too_many ? 1u : 0u;   // (a word of its own: workgroup 0 writes host_meta->error)
+                }
+                if (b2 == 11) s.meta->n_heavy = acc + h;
+                if (b2 == 8) s.meta->n_mid = acc + h;
+                acc += h;
+            }
+        }
         __syncthreads();
         for (uint32_t sc = 0; sc < T; sc += SC) {
             const uint32_t n = min(SC, T - sc);
@@ -514,7 +530,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const 
                 host_meta->max_count = m; host_meta->n_overflow = ovf_n;
                 host_meta->n_nonempty = s.meta->n_nonempty; host_meta->n_heavy = s.meta->n_heavy; host_meta->n_mid = s.meta->n_mid;   // (this thread wrote them above)
             }
-            (void)allow_overflow;                       // lists beyond the LDS sort are handled on the device (k_tile_sort's overflow workers): no rejection
         }
     }
 }
@@ -968,7 +983,7 @@ __device__ __forceinline__ void fill_tile_background(const ImgState& s, uint32_t
 }
 
 __global__ __launch_bounds__(FWD_THREADS, 8) void k_render_fwd(const ImgState s, const BinState b, int W, int H, uint32_t gx,
-                                                            const float* __restrict__ bg, float* __restrict__ out_color, int fill_tail)
+                                                            const float* __restrict__ bg, float* __restrict__ out_color, int fill_tail, uint32_t n_tiles)
 {
     __shared__ float4 sA[FCH + 1];
     __shared__ float4 sB[FCH + 1];
@@ -981,12 +996,16 @@ __global__ __launch_bounds__(FWD_THREADS, 8) void k_render_fwd(const ImgState s,
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     const uint4 td = s.tile_desc[blockIdx.x];
     const uint2 ff = frame_flags(s);                       // (error bits, non-empty tiles): one load, in flight beside the descriptor's
-    if (blockIdx.x >= ff.y) {                              // grid = all tiles (sync-free forward): the empty ones are the tail of tile_order
-        if (fill_tail && threadIdx.x < 256) fill_tile_background(s, td.x, threadIdx.x, W, H, gx, bg, out_color);
-        return;
-    }
-    if (ff.x & META_ERR_CAPACITY) {
-        if (threadIdx.x < 256) fill_tile_background(s, td.x, threadIdx.x, W, H, gx, bg, out_color);
+    const uint32_t n_ne = (ff.x & META_ERR_CAPACITY) ? 0u : ff.y;      // a frame tgs_forward_async rejected renders the background everywhere
+    if (blockIdx.x >= n_ne) {
+        // Sync-free forward: the workgroups behind the non-empty tiles (the grid covers the caller's bound on those, plus one workgroup per
+        // 16 tiles beyond it) share the EMPTY tiles -- the tail of tile_order -- four at a time.  (One workgroup per empty tile was 5400
+        // surplus workgroups at config 3: ~4 % of a frame.)
+        if (fill_tail) {
+            const uint32_t nfill = gridDim.x - n_ne, j = blockIdx.x - n_ne;
+            for (uint32_t i = n_ne + 4u * j + (threadIdx.x >> 8); i < n_tiles; i += 4u * nfill)
+                fill_tile_background(s, s.tile_desc[i].x, threadIdx.x & 255u, W, H, gx, bg, out_color);
+        }
         return;
     }
     const uint32_t tile = td.x;
@@ -1121,10 +1140,10 @@ __global__ __launch_bounds__(FWD_THREADS, 8) void k_render_fwd(const ImgState s,
 }
 
 // tiles without any instance: background only (they sit at the end of tile_order)
-__global__ __launch_bounds__(256) void k_fill_empty(const ImgState s, int W, int H, uint32_t gx, uint32_t T, const float* __restrict__ bg,
+__global__ __launch_bounds__(256) void k_fill_empty(const ImgState s, int W, int H, uint32_t gx, uint32_t T, uint32_t first, const float* __restrict__ bg,
                                                     float* __restrict__ out_color)
 {
-    const uint32_t t = s.meta->n_nonempty + blockIdx.x;     // empty tiles are the tail of tile_order
+    const uint32_t t = first + blockIdx.x;                  // empty tiles are the tail of tile_order
     if (t >= T) return;
     fill_tile_background(s, s.tile_desc[t].x, threadIdx.x, W, H, gx, bg, out_color);
 }
@@ -1172,9 +1191,9 @@ void launch_preprocess_fwd_batch(hipStream_t st, const FwdIn& in, const FwdViews
     else hipLaunchKernelGGL((k_preprocess_fwd_batch<false, false>), grid, blk, 0, st, in, views);
 }
 void launch_scan(hipStream_t st, const GeomState& g, const ImgState& s, uint32_t nblocks, uint32_t T, uint32_t sort_cap, unsigned long long r_capacity,
-                 int allow_overflow, Meta* host_meta)
+                 uint32_t tile_bound, Meta* host_meta)
 {
-    hipLaunchKernelGGL(k_scan, dim3(2), dim3(SCAN_THREADS), 0, st, g, s, nblocks, T, sort_cap, r_capacity, allow_overflow, host_meta);
+    hipLaunchKernelGGL(k_scan, dim3(2), dim3(SCAN_THREADS), 0, st, g, s, nblocks, T, sort_cap, r_capacity, tile_bound, host_meta);
 }
 // Binning chunks: `nchunks` workgroups of BIN_THREADS threads, `chunk` Gaussians each (a multiple of BIN_THREADS)
 void bin_shape(int P, uint32_t T, uint32_t& nchunks, uint32_t& chunk, uint32_t& band, size_t& lds)
@@ -1209,9 +1228,11 @@ void launch_scatter(hipStream_t st, int P, const GeomState& g, const ImgState& s
 static uint32_t host_next_pow2(uint32_t n) { uint32_t p = 1; while (p < n) p <<= 1; return p; }
 // Exact sizes (after the forward's read-back of Meta) or, with m == nullptr, upper bounds for the sync-free forward:
 // workgroups beyond the device-side counts return at once.
+// tile_bound (m == nullptr): the caller's bound on the tiles with instances (k_scan rejects a frame with more), or T
 void launch_tile_sort(hipStream_t st, const GeomState& g, const ImgState& s, const BinState& b, uint32_t gx, uint32_t T, uint64_t r_bound,
-                      const Meta* m, uint32_t sort_cap)
+                      const Meta* m, uint32_t sort_cap, uint32_t tile_bound)
 {
+    if (!m && tile_bound < T) T = tile_bound;               // (T only bounds the class sizes below)
     const uint32_t max_count = m ? m->max_count : sort_cap;
     const uint32_t cap = max_count < sort_cap ? max_count : sort_cap;
     const size_t lds = (size_t)(cap ? cap : 1) * 8;
@@ -1240,15 +1261,18 @@ void launch_tile_sort(hipStream_t st, const GeomState& g, const ImgState& s, con
     if (r_bound > 0) hipLaunchKernelGGL(k_finalize, dim3((unsigned)((r_bound + 256 * FIN_E - 1) / (256 * FIN_E))), dim3(256), 0, st, g, s, b, gx, T);
 }
 void launch_render_fwd(hipStream_t st, const ImgState& s, const BinState& b, int W, int H, uint32_t gx, uint32_t T, const Meta* m,
-                       const float* bg, float* out_color)
+                       const float* bg, float* out_color, uint32_t tile_bound)
 {
-    if (!m) {   // sync-free: one launch over all tiles; workgroups behind the non-empty ones write the background of the empty tiles
-        hipLaunchKernelGGL(k_render_fwd, dim3(T), dim3(FWD_THREADS), 0, st, s, b, W, H, gx, bg, out_color, 1);
+    if (!m) {   // sync-free: tile_bound workgroups (k_scan has rejected the frame if more tiles hold instances) + one per 16 tiles beyond the
+                // bound; those behind the non-empty tiles write the background of all empty ones
+        const uint32_t tb = tile_bound < T ? tile_bound : T;
+        const uint32_t grid = tb + (T - tb + 15u) / 16u;    // (tb == T: one workgroup per tile)
+        hipLaunchKernelGGL(k_render_fwd, dim3(grid), dim3(FWD_THREADS), 0, st, s, b, W, H, gx, bg, out_color, 1, T);
         return;
     }
     const uint32_t nonempty = m->n_nonempty, empty = T - m->n_nonempty;
-    if (nonempty > 0) hipLaunchKernelGGL(k_render_fwd, dim3(nonempty), dim3(FWD_THREADS), 0, st, s, b, W, H, gx, bg, out_color, 0);
-    if (empty > 0) hipLaunchKernelGGL(k_fill_empty, dim3(empty), dim3(256), 0, st, s, W, H, gx, T, bg, out_color);
+    if (nonempty > 0) hipLaunchKernelGGL(k_render_fwd, dim3(nonempty), dim3(FWD_THREADS), 0, st, s, b, W, H, gx, bg, out_color, 0, T);
+    if (empty > 0) hipLaunchKernelGGL(k_fill_empty, dim3(empty), dim3(256), 0, st, s, W, H, gx, T, nonempty, bg, out_color);
 }
 void launch_mark_visible(hipStream_t st, int P, const float* means3D, const float* view, uint8_t* present)
 {

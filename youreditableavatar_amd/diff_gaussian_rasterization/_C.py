@@ -258,6 +258,12 @@ def decode_meta_full(meta_bytes: torch.Tensor) -> Tuple[int, int, int, int]:
     return int(R), int(flags), int(max_count), int(n_overflow)
 
 
+def decode_meta_tiles(meta_bytes: torch.Tensor) -> int:
+    """64 Meta bytes on the host -> number of tiles that hold instances."""
+    import struct
+    return int(struct.unpack_from("<I", bytes(meta_bytes.cpu().numpy().tobytes()), 20)[0])
+
+
 def decode_meta(meta_bytes: torch.Tensor) -> Tuple[int, int]:
     """64 Meta bytes on the host -> (num_rendered, flags)."""
     R, flags, _m, _o = decode_meta_full(meta_bytes)
@@ -363,7 +369,8 @@ class _ViewT(C.Structure):
                 ("geom_buffer", C.c_void_p), ("binning_buffer", C.c_void_p), ("img_buffer", C.c_void_p), ("R", C.c_int64),
                 ("dL_dmean2D", C.c_void_p), ("dL_dcolor", C.c_void_p),
                 ("background", C.c_void_p), ("out_color", C.c_void_p), ("radii_out", C.c_void_p), ("dL_dpix", C.c_void_p),
-                ("geom_bytes", C.c_size_t), ("binning_bytes", C.c_size_t), ("img_bytes", C.c_size_t), ("colors_precomp", C.c_void_p)]
+                ("geom_bytes", C.c_size_t), ("binning_bytes", C.c_size_t), ("img_bytes", C.c_size_t), ("colors_precomp", C.c_void_p),
+                ("tile_bound", C.c_int64)]
 
 
 ViewArray = lambda n: (_ViewT * n)()

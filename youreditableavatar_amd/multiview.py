@@ -15,6 +15,7 @@ from __future__ import annotations
 from typing import Callable, Iterable, List, Optional, Sequence
 
 import ctypes as C
+import os
 
 import torch
 import torch.distributed as dist
@@ -244,6 +245,7 @@ class SyncFreeBatch:
     def __init__(self, headroom: float = 1.25, granule: int = 1 << 16, streams: int = 4, deferred: bool = True, split: bool = False):
         self.headroom, self.granule = float(headroom), int(granule)
         self.bound: Optional[int] = None        # largest num_rendered seen (decays slowly)
+        self.tile_bound: Optional[int] = None   # largest number of tiles with instances seen (decays slowly): sizes the sync-free grids
         self.rejected = 0                       # frames re-rendered so far
         self.streams = max(1, int(streams))     # 2: consecutive views alternate between two HIP streams (see run)
         self.deferred = bool(deferred)          # one per-Gaussian backward pass for the whole batch (DeferredBackward)
@@ -258,6 +260,12 @@ class SyncFreeBatch:
         self._pool = None
         self.viewspace_grads: Optional[torch.Tensor] = None
         self.color_grads: Optional[torch.Tensor] = None      # run_views with colors_precomp: dL/d colours per view [V,P,3]
+
+    def tile_capacity(self) -> int:
+        """bound on the tiles with instances handed to the sync-free forward (0: none yet); a frame with more is rejected and rendered again"""
+        if self.tile_bound is None or os.environ.get("TGS_TILE_BOUND", "1") == "0":      # (TGS_TILE_BOUND=0: grids over all tiles, for A/B runs)
+            return 0
+        return (int(self.tile_bound * 1.1) + 64) // 64 * 64
 
     def capacity(self) -> Optional[int]:
         if self.bound is None or self._cooldown > 0:
@@ -320,6 +328,7 @@ class SyncFreeBatch:
                 raise RuntimeError(f"run_views: {name} must be a contiguous float32 leaf parameter on the GPU with an allocated .grad (see FlatGradients)")
         M = 0 if precomp else int(shs.size(1))
         cap = self.capacity()
+        tcap = self.tile_capacity()
         dev = means3D.device
         n_chunks = max(1, min(int(grad_chunks), (P + 255) // 256))
         per = ((P + n_chunks - 1) // n_chunks + 255) // 256 * 256
@@ -401,6 +410,7 @@ class SyncFreeBatch:
             a.out_color, a.dL_dmean2D, a.dL_dpix = pool["images"][v].data_ptr(), pool["g2d"][v].data_ptr(), None
             a.dL_dcolor = gcol[v].data_ptr() if precomp else None
             a.colors_precomp = colors_precomp[v].data_ptr() if precomp else None
+            a.tile_bound = tcap
         main = torch.cuda.current_stream(dev)
         side = self._side.setdefault(dev, [])
         n_lanes = max(1, min(self.streams, V))
@@ -497,7 +507,7 @@ class SyncFreeBatch:
                 """waits for the Meta records (the one host wait of the batch: they left right behind the forwards) -> (views to render again, largest count)"""
                 for ev in ready:
                     ev.synchronize()
-                seen, redo = 0, []
+                seen, redo, tiles = 0, [], 0
                 for v in range(V):
                     R, flags, _longest, n_overflow = _C.decode_meta_full(pool["host"][v])
                     if flags & _C.FRAME_PREFILTERED:
@@ -505,6 +515,8 @@ class SyncFreeBatch:
                     if flags & _C.FRAME_REJECTED:
                         redo.append(v)
                     seen = max(seen, R)
+                    tiles = max(tiles, _C.decode_meta_tiles(pool["host"][v]))
+                self.tile_bound = tiles if self.tile_bound is None else max(tiles, int(self.tile_bound * 0.95))
                 return redo, seen
 
             # With on_chunk the verdict is read BEFORE the per-Gaussian pass is enqueued (the GPU still has the per-pixel backwards in its
