@@ -354,6 +354,7 @@ def main():
                        "streams": batch.streams if batch is not None else 1,
                        "per_gaussian_backward": "one pass per step (tgs_backward_batch)" if (batch is not None and batch.deferred) else "one pass per view",
                        "frames_rerendered": batch.rejected if batch is not None else 0,
+                       "sync_free_grid_tiles": (batch.tile_capacity() if batch is not None else 0) or None,   # bound on the tiles with instances the sync-free grids are sized for (learned from the previous steps; None: all tiles)
                        "parallelism": f"view-sharded dp{N}: {N} rank(s) x 1 GPU, torch.distributed world size {dist.get_world_size() if dist is not None else 1} "
                                       f"(backend {a.backend if N > 1 else 'none'}), {n_devices} GPU(s) visible per node"
                                       + ((f", gradient all-reduce in {chunks} Gaussian ranges overlapped with the per-Gaussian pass" if (chunks > 1 and batch is not None and not a.per_view_calls)

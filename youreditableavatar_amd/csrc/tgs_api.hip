@@ -228,6 +228,7 @@ static int64_t forward_impl(int preprocessed, int64_t r_capacity, int64_t* specu
                     int prefiltered, float* out_color, int* radii, int debug)
 {
     const bool async = r_capacity >= 0;
+    t_last_nonempty = -1;                                   // (known again once this call has read the frame's Meta)
     if (r_capacity > 0x7fffffffll) return fail(TGS_ERR_INVALID, "r_capacity exceeds 2^31-1");
     hipStream_t st = (hipStream_t)stream;
     g_err[0] = 0;

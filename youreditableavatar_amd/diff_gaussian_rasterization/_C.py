@@ -72,6 +72,10 @@ def _load() -> C.CDLL:
     lib.tgs_set_instance_pruning.argtypes = [it]
     lib.tgs_set_forward_group.restype = None
     lib.tgs_set_forward_group.argtypes = [it]
+    lib.tgs_set_tile_bound.restype = None
+    lib.tgs_set_tile_bound.argtypes = [C.c_int64]
+    lib.tgs_last_nonempty_tiles.restype = C.c_int64
+    lib.tgs_last_nonempty_tiles.argtypes = []
     lib.tgs_set_deterministic.restype = None
     lib.tgs_set_deterministic.argtypes = [it]
     lib.tgs_selftest_reduce36.restype = it
@@ -122,6 +126,17 @@ def set_instance_pruning(on: bool) -> None:
 def set_forward_group(views_per_launch: int) -> None:
     """Views per launch of the per-Gaussian forward stage inside forward_views (1..8; default 1)."""
     _lib.tgs_set_forward_group(int(views_per_launch))
+
+
+def set_tile_bound(n_tiles: int) -> None:
+    """tgs_set_tile_bound (this thread): bound on the tiles with instances for the sync-free / speculative forward and for the backward of
+    a frame known to stay below it; 0: none.  Stays set until changed."""
+    _lib.tgs_set_tile_bound(int(n_tiles))
+
+
+def last_nonempty_tiles() -> int:
+    """Tiles with instances of the last frame this thread rendered with the synchronous or the speculative forward (-1: unknown)."""
+    return int(_lib.tgs_last_nonempty_tiles())
 
 
 def set_deterministic(on: bool) -> None:

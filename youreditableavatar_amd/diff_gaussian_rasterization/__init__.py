@@ -77,11 +77,19 @@ class _Speculation:
             return None
         return (int(st[0] * self.HEADROOM) + self.GRANULE - 1) // self.GRANULE * self.GRANULE
 
-    def update(self, key, true_count, guess):
-        st = self.state.setdefault(key, [0, 0, 0])            # [bound, consecutive misses, calls left without speculation]
+    def tile_guess(self, key):
+        """bound on the tiles with instances for the grids of the speculative forward (0: none yet): the same kind of decaying maximum"""
+        st = self.state.get(key)
+        return (int(st[3] * self.HEADROOM) + 64) // 64 * 64 if st is not None and st[3] > 0 else 0
+
+    def update(self, key, true_count, guess, tiles=-1, tile_guess=0):
+        st = self.state.setdefault(key, [0, 0, 0, 0])         # [bound, consecutive misses, calls left without speculation, bound on the tiles]
         st[0] = max(int(true_count), int(st[0] * self.DECAY))
+        if tiles >= 0:
+            st[3] = max(int(tiles), int(st[3] * self.DECAY))
         if guess is not None:
-            st[1] = st[1] + 1 if true_count > guess else 0
+            missed = true_count > guess or (tile_guess > 0 and tiles > tile_guess)
+            st[1] = st[1] + 1 if missed else 0
             if st[1] >= self.MAX_MISSES:
                 st[1], st[2] = 0, self.COOLDOWN
 
@@ -102,16 +110,25 @@ class _RasterizeGaussians(torch.autograd.Function):
         # needs more repeats them with the exact sizes).  num_rendered below is what the binning buffer is carved for.
         key = (int(means3D.shape[0]), int(rs.image_height), int(rs.image_width), means3D.device)
         guess = _speculation.guess(key) if _SPECULATE else None
+        tile_guess = 0
         if guess is not None:
-            num_rendered, color, radii, geom, binning, img, true_R = _call_native(
-                lambda *a: _C.rasterize_gaussians(*a, r_guess=guess), args, rs.debug, "snapshot_fw.dump", "forward")
+            # the grids of the stages enqueued ahead of the read-back cover a guessed number of tiles with instances, not all tiles
+            tile_guess = _speculation.tile_guess(key)
+            _C.set_tile_bound(tile_guess)
+            try:
+                num_rendered, color, radii, geom, binning, img, true_R = _call_native(
+                    lambda *a: _C.rasterize_gaussians(*a, r_guess=guess), args, rs.debug, "snapshot_fw.dump", "forward")
+            finally:
+                _C.set_tile_bound(0)
         else:
             num_rendered, color, radii, geom, binning, img = _call_native(_C.rasterize_gaussians, args, rs.debug, "snapshot_fw.dump", "forward")
             true_R = num_rendered
+        tiles = _C.last_nonempty_tiles()                    # of THIS frame (the forward has read its Meta); -1: unknown
         if _SPECULATE:
-            _speculation.update(key, true_R, guess)
+            _speculation.update(key, true_R, guess, tiles, tile_guess)
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
+        ctx.nonempty_tiles = tiles
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img)
         ctx.mark_non_differentiable(radii)
         return color, radii
@@ -124,8 +141,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
                 rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, sh, rs.sh_degree, rs.campos, geom, ctx.num_rendered,
                 binning, img, rs.debug)
-        (g_means2D, g_colors, g_opac, g_means3D, g_cov3D, g_sh, g_scales, g_rots) = _call_native(
-            _C.rasterize_gaussians_backward, args, rs.debug, "snapshot_bw.dump", "backward")
+        # the per-pixel backward visits the tiles with instances only: their number is known exactly from the forward's read-back
+        _C.set_tile_bound(ctx.nonempty_tiles if ctx.nonempty_tiles > 0 else 0)
+        try:
+            (g_means2D, g_colors, g_opac, g_means3D, g_cov3D, g_sh, g_scales, g_rots) = _call_native(
+                _C.rasterize_gaussians_backward, args, rs.debug, "snapshot_bw.dump", "backward")
+        finally:
+            _C.set_tile_bound(0)
         # forward-argument order (__init__.py:143-153); all eight are always returned
         return g_means3D, g_means2D, g_sh, g_colors, g_opac, g_scales, g_rots, g_cov3D, None
 
