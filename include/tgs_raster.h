@@ -222,6 +222,8 @@ typedef struct {
     int64_t tile_bound;        /* *_views entry points: upper bound on the tiles that hold instances, or 0 (none): the sync-free grids are then
                                   sized for that many tiles instead of all of them (surplus workgroups of thousands of empty tiles cost ~4 % of a
                                   frame each way at config 3); a frame with MORE non-empty tiles is rejected like one that exceeds r_capacity */
+    int64_t heavy_bound, mid_bound;   /* the same for the two upper classes of the tile sort: tiles with >= 1024 / >= 128 instances (the second
+                                  includes the first); 0: none.  Only read when tile_bound is set. */
 } tgs_view_t;
 /* Whole-batch entry points: one call enqueues the forward (or the per-pixel backward) of every view, view k on
  * streams[k % n_streams], with state buffers the CALLER allocated up front (tgs_state_sizes) -- no allocation callback, no

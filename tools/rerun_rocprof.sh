@@ -1,6 +1,6 @@
 set -x
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r02_e
+O=$R/gpurun_out/r02_f
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rm -rf $O/rp4 $O/rp1

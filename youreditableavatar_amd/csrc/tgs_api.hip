@@ -11,11 +11,11 @@ namespace tgs {
 void launch_preprocess_fwd(hipStream_t, const FwdIn&, const CamParams&, const GeomState&, const ImgState&);
 void launch_preprocess_fwd_batch(hipStream_t, const FwdIn&, const FwdViews&);
 void launch_scan(hipStream_t, const GeomState&, const ImgState&, uint32_t nblocks, uint32_t T, uint32_t sort_cap, unsigned long long r_capacity,
-                 uint32_t tile_bound, Meta* host_meta);
+                 uint32_t tile_bound, uint32_t heavy_bound, uint32_t mid_bound, Meta* host_meta);
 void launch_bin_count(hipStream_t, int P, const GeomState&, const ImgState&, uint32_t gx, uint32_t T);
 void launch_scatter(hipStream_t, int P, const GeomState&, const ImgState&, const BinState&, uint32_t gx, uint32_t T);
 void launch_tile_sort(hipStream_t, const GeomState&, const ImgState&, const BinState&, uint32_t gx, uint32_t T, uint64_t r_bound, const Meta* m,
-                      uint32_t sort_cap, uint32_t tile_bound);
+                      uint32_t sort_cap, uint32_t tile_bound, uint32_t heavy_bound, uint32_t mid_bound);
 void launch_render_fwd(hipStream_t, const ImgState&, const BinState&, int W, int H, uint32_t gx, uint32_t T, const Meta* m, const float* bg,
                        float* out_color, uint32_t tile_bound);
 void launch_mark_visible(hipStream_t, int P, const float* means3D, const float* view, uint8_t* present);
@@ -219,6 +219,7 @@ static thread_local hipStream_t t_render_stream = nullptr;
 // tgs_set_tile_bound / tgs_view_t::tile_bound: upper bound on the tiles with instances for the sync-free grids (0: none)
 static thread_local int64_t t_tile_bound = 0;
 static thread_local int64_t t_last_nonempty = -1;
+static thread_local int64_t t_class_bound[2] = {0, 0};      // tgs_view_t::heavy_bound / mid_bound (tile sort classes), with t_tile_bound
 static uint32_t bounded_tiles(size_t T) { return (t_tile_bound > 0 && (uint64_t)t_tile_bound < (uint64_t)T) ? (uint32_t)t_tile_bound : (uint32_t)T; }
 
 static int64_t forward_impl(int preprocessed, int64_t r_capacity, int64_t* speculative_true_R, tgs_alloc_fn alloc, void* alloc_ctx, void* stream, int P, int D, int M, const float* background, int width,
@@ -292,9 +293,12 @@ static int64_t forward_impl(int preprocessed, int64_t r_capacity, int64_t* specu
     }
     // sync-free grids cover `tb` tiles (the caller's bound on the tiles with instances, or all of them); k_scan rejects a frame with more
     const uint32_t tb = async ? bounded_tiles(T) : (uint32_t)T;
+    const bool classes = async && tb < T;                   // class bounds come with a tile bound only
+    const uint32_t hb = (classes && t_class_bound[0] > 0 && (uint64_t)t_class_bound[0] < tb) ? (uint32_t)t_class_bound[0] : tb;
+    const uint32_t mb = (classes && t_class_bound[1] > 0 && (uint64_t)t_class_bound[1] < tb) ? (uint32_t)t_class_bound[1] : tb;
     STAGE_BEGIN(TGS_STAGE_SCAN);
     launch_bin_count(st, P, g, s, cam.gx, (uint32_t)T);
-    launch_scan(st, g, s, (uint32_t)n_blocks((size_t)P), (uint32_t)T, sort_cap, async ? (unsigned long long)r_capacity : ~0ull, tb,
+    launch_scan(st, g, s, (uint32_t)n_blocks((size_t)P), (uint32_t)T, sort_cap, async ? (unsigned long long)r_capacity : ~0ull, tb, hb, mb,
                 spec ? spec->meta : nullptr);
     STAGE_CHECK("scan", TGS_STAGE_SCAN);
     if (spec) {
@@ -325,7 +329,7 @@ static int64_t forward_impl(int preprocessed, int64_t r_capacity, int64_t* specu
         launch_scatter(st, P, g, s, b, cam.gx, (uint32_t)T);
         STAGE_CHECK("scatter", TGS_STAGE_SCATTER);
         STAGE_BEGIN(TGS_STAGE_TILE_SORT);
-        launch_tile_sort(st, g, s, b, cam.gx, (uint32_t)T, R, known, sort_cap, tb);
+        launch_tile_sort(st, g, s, b, cam.gx, (uint32_t)T, R, known, sort_cap, tb, hb, mb);
         STAGE_CHECK("tile_sort", TGS_STAGE_TILE_SORT);
     }
     hipStream_t rst = st;
@@ -358,7 +362,7 @@ static int64_t forward_impl(int preprocessed, int64_t r_capacity, int64_t* specu
             bin_carve(b, exact_ptr, (size_t)R);
             if (R > 0) {
                 launch_scatter(st, P, g, s, b, cam.gx, (uint32_t)T);
-                launch_tile_sort(st, g, s, b, cam.gx, (uint32_t)T, R, &meta, sort_cap, (uint32_t)T);
+                launch_tile_sort(st, g, s, b, cam.gx, (uint32_t)T, R, &meta, sort_cap, (uint32_t)T, (uint32_t)T, (uint32_t)T);
             }
             launch_render_fwd(st, s, b, width, height, cam.gx, (uint32_t)T, &meta, background, out_color, (uint32_t)T);
             HIP_TRY(hipGetLastError());
@@ -586,8 +590,9 @@ int tgs_forward_views(void* const* streams, int n_streams, int64_t r_capacity, i
             if (pre_done && st != st0) HIP_TRY(hipStreamWaitEvent(st, pre_done, 0));
             t_render_stream = t_render_streams.empty() ? nullptr : t_render_streams[(size_t)(v0 + k) % t_render_streams.size()];
             struct Reset { ~Reset() { t_render_stream = nullptr; } } reset_render_stream;
-            struct BoundReset { int64_t old; ~BoundReset() { t_tile_bound = old; } } bound_reset{t_tile_bound};
+            struct BoundReset { int64_t old; ~BoundReset() { t_tile_bound = old; t_class_bound[0] = t_class_bound[1] = 0; } } bound_reset{t_tile_bound};
             t_tile_bound = v.tile_bound > 0 ? v.tile_bound : 0;
+            t_class_bound[0] = v.heavy_bound > 0 ? v.heavy_bound : 0; t_class_bound[1] = v.mid_bound > 0 ? v.mid_bound : 0;
             const int64_t r = forward_impl(batched ? 1 : 0, r_capacity, nullptr, alloc_preset, &v, st, P, D, M, v.background, v.width, v.height, means3D, shs,
                                            v.colors_precomp ? v.colors_precomp : colors_precomp,
                                            opacities, scales, scale_modifier, rotations, cov3D_precomp, v.viewmatrix, v.projmatrix, v.campos, v.tan_fovx, v.tan_fovy,

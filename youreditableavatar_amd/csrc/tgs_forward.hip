@@ -422,7 +422,7 @@ __device__ __forceinline__ unsigned long long block_exscan_u64(unsigned long lon
 // tile_bound: the sync-free grids behind the scan cover that many entries of tile_order; a frame with more non-empty tiles is rejected
 // like one that exceeds r_capacity (T: no bound)
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const ImgState s, uint32_t nblocks, uint32_t T, uint32_t sort_cap, unsigned long long r_capacity, uint32_t tile_bound,
-                                                       Meta* host_meta)
+                                                       uint32_t heavy_bound, uint32_t mid_bound, Meta* host_meta)
 {
     __shared__ unsigned long long lds[SCAN_THREADS / WAVE];
     __shared__ uint32_t lds_max[SCAN_THREADS / WAVE];
@@ -489,18 +489,16 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const 
         // tiles by descending list length (power-of-two buckets; order inside a bucket does not matter)
         if (threadIdx.x == 0) {
             uint32_t acc = 0;
+            bool too_many = false;                          // more tiles (of a class) than the grids behind the scan cover
             for (int b2 = 33; b2-- > 0;) {
                 const uint32_t h = hist[b2]; hist[b2] = acc;
-                if (b2 == 1) {
-                    s.meta->n_nonempty = acc + h;
-                    const bool too_many = acc + h > tile_bound;     // more tiles with instances than the grids behind the scan cover
-                    if (too_many) atomicOr(&s.meta->error, META_ERR_CAPACITY);
-                    if (host_meta) host_meta->pad[0] = too_many ? 1u : 0u;   // (a word of its own: workgroup 0 writes host_meta->error)
-                }
-                if (b2 == 11) s.meta->n_heavy = acc + h;
-                if (b2 == 8) s.meta->n_mid = acc + h;
+                if (b2 == 1) { s.meta->n_nonempty = acc + h; too_many = too_many || acc + h > tile_bound; }
+                if (b2 == 11) { s.meta->n_heavy = acc + h; too_many = too_many || acc + h > heavy_bound; }
+                if (b2 == 8) { s.meta->n_mid = acc + h; too_many = too_many || acc + h > mid_bound; }
                 acc += h;
             }
+            if (too_many) atomicOr(&s.meta->error, META_ERR_CAPACITY);
+            if (host_meta) host_meta->pad[0] = too_many ? 1u : 0u;   // (a word of its own: workgroup 0 writes host_meta->error)
         }
         __syncthreads();
         for (uint32_t sc = 0; sc < T; sc += SC) {
@@ -1191,9 +1189,9 @@ void launch_preprocess_fwd_batch(hipStream_t st, const FwdIn& in, const FwdViews
     else hipLaunchKernelGGL((k_preprocess_fwd_batch<false, false>), grid, blk, 0, st, in, views);
 }
 void launch_scan(hipStream_t st, const GeomState& g, const ImgState& s, uint32_t nblocks, uint32_t T, uint32_t sort_cap, unsigned long long r_capacity,
-                 uint32_t tile_bound, Meta* host_meta)
+                 uint32_t tile_bound, uint32_t heavy_bound, uint32_t mid_bound, Meta* host_meta)
 {
-    hipLaunchKernelGGL(k_scan, dim3(2), dim3(SCAN_THREADS), 0, st, g, s, nblocks, T, sort_cap, r_capacity, tile_bound, host_meta);
+    hipLaunchKernelGGL(k_scan, dim3(2), dim3(SCAN_THREADS), 0, st, g, s, nblocks, T, sort_cap, r_capacity, tile_bound, heavy_bound, mid_bound, host_meta);
 }
 // Binning chunks: `nchunks` workgroups of BIN_THREADS threads, `chunk` Gaussians each (a multiple of BIN_THREADS)
 void bin_shape(int P, uint32_t T, uint32_t& nchunks, uint32_t& chunk, uint32_t& band, size_t& lds)
@@ -1230,7 +1228,7 @@ static uint32_t host_next_pow2(uint32_t n) { uint32_t p = 1; while (p < n) p <<=
 // workgroups beyond the device-side counts return at once.
 // tile_bound (m == nullptr): the caller's bound on the tiles with instances (k_scan rejects a frame with more), or T
 void launch_tile_sort(hipStream_t st, const GeomState& g, const ImgState& s, const BinState& b, uint32_t gx, uint32_t T, uint64_t r_bound,
-                      const Meta* m, uint32_t sort_cap, uint32_t tile_bound)
+                      const Meta* m, uint32_t sort_cap, uint32_t tile_bound, uint32_t heavy_bound, uint32_t mid_bound)
 {
     if (!m && tile_bound < T) T = tile_bound;               // (T only bounds the class sizes below)
     const uint32_t max_count = m ? m->max_count : sort_cap;
@@ -1239,6 +1237,8 @@ void launch_tile_sort(hipStream_t st, const GeomState& g, const ImgState& s, con
     const uint32_t nonempty = m ? m->n_nonempty : (uint32_t)(r_bound < T ? r_bound : T);
     uint32_t heavy = m ? m->n_heavy : (uint32_t)(r_bound / 1024 < T ? r_bound / 1024 : T);
     uint32_t mid = m ? m->n_mid : (uint32_t)(r_bound / 128 < T ? r_bound / 128 : T);     // tiles with >= 128 instances, heavy ones included
+    if (!m && heavy > heavy_bound) heavy = heavy_bound;      // (k_scan has rejected a frame with more)
+    if (!m && mid > mid_bound) mid = mid_bound;
     if (heavy > nonempty) heavy = nonempty;
     if (mid < heavy) mid = heavy;
     if (mid > nonempty) mid = nonempty;

@@ -273,10 +273,11 @@ def decode_meta_full(meta_bytes: torch.Tensor) -> Tuple[int, int, int, int]:
     return int(R), int(flags), int(max_count), int(n_overflow)
 
 
-def decode_meta_tiles(meta_bytes: torch.Tensor) -> int:
-    """64 Meta bytes on the host -> number of tiles that hold instances."""
+def decode_meta_tiles(meta_bytes: torch.Tensor) -> Tuple[int, int, int]:
+    """64 Meta bytes on the host -> tiles that hold instances, tiles with >= 1024 of them, tiles with >= 128."""
     import struct
-    return int(struct.unpack_from("<I", bytes(meta_bytes.cpu().numpy().tobytes()), 20)[0])
+    n, heavy, mid = struct.unpack_from("<III", bytes(meta_bytes.cpu().numpy().tobytes()), 20)
+    return int(n), int(heavy), int(mid)
 
 
 def decode_meta(meta_bytes: torch.Tensor) -> Tuple[int, int]:
@@ -385,7 +386,7 @@ class _ViewT(C.Structure):
                 ("dL_dmean2D", C.c_void_p), ("dL_dcolor", C.c_void_p),
                 ("background", C.c_void_p), ("out_color", C.c_void_p), ("radii_out", C.c_void_p), ("dL_dpix", C.c_void_p),
                 ("geom_bytes", C.c_size_t), ("binning_bytes", C.c_size_t), ("img_bytes", C.c_size_t), ("colors_precomp", C.c_void_p),
-                ("tile_bound", C.c_int64)]
+                ("tile_bound", C.c_int64), ("heavy_bound", C.c_int64), ("mid_bound", C.c_int64)]
 
 
 ViewArray = lambda n: (_ViewT * n)()

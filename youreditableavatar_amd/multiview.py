@@ -246,6 +246,7 @@ class SyncFreeBatch:
         self.headroom, self.granule = float(headroom), int(granule)
         self.bound: Optional[int] = None        # largest num_rendered seen (decays slowly)
         self.tile_bound: Optional[int] = None   # largest number of tiles with instances seen (decays slowly): sizes the sync-free grids
+        self.class_bound = [0, 0]               # the same for the tiles with >= 1024 / >= 128 instances (classes of the tile sort)
         self.rejected = 0                       # frames re-rendered so far
         self.streams = max(1, int(streams))     # 2: consecutive views alternate between two HIP streams (see run)
         self.deferred = bool(deferred)          # one per-Gaussian backward pass for the whole batch (DeferredBackward)
@@ -411,6 +412,8 @@ class SyncFreeBatch:
             a.dL_dcolor = gcol[v].data_ptr() if precomp else None
             a.colors_precomp = colors_precomp[v].data_ptr() if precomp else None
             a.tile_bound = tcap
+            # (generous: the class counts move more from view to view than the number of tiles with instances does, and a miss costs a frame)
+            a.heavy_bound, a.mid_bound = ((int(self.class_bound[0] * 1.5) + 64) // 32 * 32, (int(self.class_bound[1] * 1.3) + 128) // 64 * 64) if tcap else (0, 0)
         main = torch.cuda.current_stream(dev)
         side = self._side.setdefault(dev, [])
         n_lanes = max(1, min(self.streams, V))
@@ -507,7 +510,7 @@ class SyncFreeBatch:
                 """waits for the Meta records (the one host wait of the batch: they left right behind the forwards) -> (views to render again, largest count)"""
                 for ev in ready:
                     ev.synchronize()
-                seen, redo, tiles = 0, [], 0
+                seen, redo, tiles, heavy_seen, mid_seen = 0, [], 0, 0, 0
                 for v in range(V):
                     R, flags, _longest, n_overflow = _C.decode_meta_full(pool["host"][v])
                     if flags & _C.FRAME_PREFILTERED:
@@ -515,8 +518,10 @@ class SyncFreeBatch:
                     if flags & _C.FRAME_REJECTED:
                         redo.append(v)
                     seen = max(seen, R)
-                    tiles = max(tiles, _C.decode_meta_tiles(pool["host"][v]))
+                    n_t, n_heavy, n_mid = _C.decode_meta_tiles(pool["host"][v])
+                    tiles, heavy_seen, mid_seen = max(tiles, n_t), max(heavy_seen, n_heavy), max(mid_seen, n_mid)
                 self.tile_bound = tiles if self.tile_bound is None else max(tiles, int(self.tile_bound * 0.95))
+                self.class_bound = [max(heavy_seen, int(self.class_bound[0] * 0.95)), max(mid_seen, int(self.class_bound[1] * 0.95))]
                 return redo, seen
 
             # With on_chunk the verdict is read BEFORE the per-Gaussian pass is enqueued (the GPU still has the per-pixel backwards in its
