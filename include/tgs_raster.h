@@ -224,6 +224,10 @@ typedef struct {
                                   frame each way at config 3); a frame with MORE non-empty tiles is rejected like one that exceeds r_capacity */
     int64_t heavy_bound, mid_bound;   /* the same for the two upper classes of the tile sort: tiles with >= 1024 / >= 128 instances (the second
                                   includes the first); 0: none.  Only read when tile_bound is set. */
+    void* host_meta;           /* tgs_forward_views: 64 bytes of pinned, device-visible host memory or NULL.  The scan kernel writes the frame's
+                                  Meta record there itself (num_rendered at byte 0, longest list at 8, lists beyond the LDS sort at 12, flags at
+                                  16, tiles with instances / with >= 1024 / with >= 128 at 20 / 24 / 28, 1 at byte 32 if a tile bound was
+                                  exceeded: the frame is rejected): the caller's verdict needs no device-to-host copy in the stream */
 } tgs_view_t;
 /* Whole-batch entry points: one call enqueues the forward (or the per-pixel backward) of every view, view k on
  * streams[k % n_streams], with state buffers the CALLER allocated up front (tgs_state_sizes) -- no allocation callback, no

@@ -220,6 +220,7 @@ static thread_local hipStream_t t_render_stream = nullptr;
 static thread_local int64_t t_tile_bound = 0;
 static thread_local int64_t t_last_nonempty = -1;
 static thread_local int64_t t_class_bound[2] = {0, 0};      // tgs_view_t::heavy_bound / mid_bound (tile sort classes), with t_tile_bound
+static thread_local Meta* t_host_meta = nullptr;            // tgs_view_t::host_meta of the view being enqueued
 static uint32_t bounded_tiles(size_t T) { return (t_tile_bound > 0 && (uint64_t)t_tile_bound < (uint64_t)T) ? (uint32_t)t_tile_bound : (uint32_t)T; }
 
 static int64_t forward_impl(int preprocessed, int64_t r_capacity, int64_t* speculative_true_R, tgs_alloc_fn alloc, void* alloc_ctx, void* stream, int P, int D, int M, const float* background, int width,
@@ -238,6 +239,7 @@ static int64_t forward_impl(int preprocessed, int64_t r_capacity, int64_t* specu
     if (P == 0) {   // rasterize_points.cu:81: nothing runs, the image keeps its zero fill (empty inputs have no pointers to check)
         if (!out_color) return fail(TGS_ERR_INVALID, "NULL required pointer");
         HIP_TRY(hipMemsetAsync(out_color, 0, 3 * (size_t)width * height * sizeof(float), st));
+        if (t_host_meta) memset(t_host_meta, 0, sizeof(Meta));   // (pinned host memory: no kernel of this frame writes it)
         if (async) {   // the caller still gets a (zeroed) Meta to query
             ImgState s0;
             const size_t bytes = img_carve(s0, nullptr, (size_t)width * height, (size_t)((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE));
@@ -299,7 +301,7 @@ static int64_t forward_impl(int preprocessed, int64_t r_capacity, int64_t* specu
     STAGE_BEGIN(TGS_STAGE_SCAN);
     launch_bin_count(st, P, g, s, cam.gx, (uint32_t)T);
     launch_scan(st, g, s, (uint32_t)n_blocks((size_t)P), (uint32_t)T, sort_cap, async ? (unsigned long long)r_capacity : ~0ull, tb, hb, mb,
-                spec ? spec->meta : nullptr);
+                spec ? spec->meta : t_host_meta);
     STAGE_CHECK("scan", TGS_STAGE_SCAN);
     if (spec) {
         // speculative synchronous forward: k_scan itself has written Meta into the pinned host slot; the event marks its end, the remaining
@@ -590,7 +592,8 @@ int tgs_forward_views(void* const* streams, int n_streams, int64_t r_capacity, i
             if (pre_done && st != st0) HIP_TRY(hipStreamWaitEvent(st, pre_done, 0));
             t_render_stream = t_render_streams.empty() ? nullptr : t_render_streams[(size_t)(v0 + k) % t_render_streams.size()];
             struct Reset { ~Reset() { t_render_stream = nullptr; } } reset_render_stream;
-            struct BoundReset { int64_t old; ~BoundReset() { t_tile_bound = old; t_class_bound[0] = t_class_bound[1] = 0; } } bound_reset{t_tile_bound};
+            struct BoundReset { int64_t old; ~BoundReset() { t_tile_bound = old; t_class_bound[0] = t_class_bound[1] = 0; t_host_meta = nullptr; } } bound_reset{t_tile_bound};
+            t_host_meta = (Meta*)v.host_meta;
             t_tile_bound = v.tile_bound > 0 ? v.tile_bound : 0;
             t_class_bound[0] = v.heavy_bound > 0 ? v.heavy_bound : 0; t_class_bound[1] = v.mid_bound > 0 ? v.mid_bound : 0;
             const int64_t r = forward_impl(batched ? 1 : 0, r_capacity, nullptr, alloc_preset, &v, st, P, D, M, v.background, v.width, v.height, means3D, shs,

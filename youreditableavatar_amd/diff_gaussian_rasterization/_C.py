@@ -266,10 +266,13 @@ def frame_meta(image_buffer: torch.Tensor) -> torch.Tensor:
 
 
 def decode_meta_full(meta_bytes: torch.Tensor) -> Tuple[int, int, int, int]:
-    """64 Meta bytes on the host -> (num_rendered, flags, longest tile list, tiles beyond the LDS sort)."""
+    """64 Meta bytes on the host -> (num_rendered, flags, longest tile list, tiles beyond the LDS sort).  In a record the scan kernel wrote
+    to pinned memory itself (tgs_view_t.host_meta) the word at byte 32 says that a tile bound was exceeded: folded into FRAME_REJECTED."""
     import struct
     raw = bytes(meta_bytes.cpu().numpy().tobytes())
     R, max_count, n_overflow, flags = struct.unpack_from("<QIII", raw, 0)
+    if struct.unpack_from("<I", raw, 32)[0]:
+        flags |= FRAME_REJECTED
     return int(R), int(flags), int(max_count), int(n_overflow)
 
 
@@ -386,7 +389,7 @@ class _ViewT(C.Structure):
                 ("dL_dmean2D", C.c_void_p), ("dL_dcolor", C.c_void_p),
                 ("background", C.c_void_p), ("out_color", C.c_void_p), ("radii_out", C.c_void_p), ("dL_dpix", C.c_void_p),
                 ("geom_bytes", C.c_size_t), ("binning_bytes", C.c_size_t), ("img_bytes", C.c_size_t), ("colors_precomp", C.c_void_p),
-                ("tile_bound", C.c_int64), ("heavy_bound", C.c_int64), ("mid_bound", C.c_int64)]
+                ("tile_bound", C.c_int64), ("heavy_bound", C.c_int64), ("mid_bound", C.c_int64), ("host_meta", C.c_void_p)]
 
 
 ViewArray = lambda n: (_ViewT * n)()

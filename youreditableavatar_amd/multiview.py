@@ -411,6 +411,7 @@ class SyncFreeBatch:
             a.out_color, a.dL_dmean2D, a.dL_dpix = pool["images"][v].data_ptr(), pool["g2d"][v].data_ptr(), None
             a.dL_dcolor = gcol[v].data_ptr() if precomp else None
             a.colors_precomp = colors_precomp[v].data_ptr() if precomp else None
+            a.host_meta = pool["host"][v].data_ptr()        # k_scan writes the frame's Meta record here itself: no device-to-host copy in the stream
             a.tile_bound = tcap
             # (generous: the class counts move more from view to view than the number of tiles with instances does, and a miss costs a frame)
             a.heavy_bound, a.mid_bound = ((int(self.class_bound[0] * 1.5) + 64) // 32 * 32, (int(self.class_bound[1] * 1.3) + 128) // 64 * 64) if tcap else (0, 0)
@@ -452,8 +453,7 @@ class SyncFreeBatch:
             images = pool["images"]
             if upstream_view is None:
                 join()
-                pool["host"].copy_(pool["img"][:, :_C.META_BYTES], non_blocking=True)      # the verdict travels while the GPU works on
-                ready = [torch.cuda.Event()]
+                ready = [torch.cuda.Event()]                # (the verdicts are in pinned memory once the scans have run: tgs_view_t.host_meta)
                 ready[0].record(main)
                 dL = check(upstream_batch(images))
                 for v in range(V):
@@ -464,9 +464,7 @@ class SyncFreeBatch:
                 ready, dLs = [], []
                 for l, st in enumerate(bin_lanes):
                     with torch.cuda.stream(st):
-                        for v in range(l, V, len(bin_lanes)):
-                            pool["host"][v].copy_(pool["img"][v, :_C.META_BYTES], non_blocking=True)
-                        ev = torch.cuda.Event()
+                        ev = torch.cuda.Event()             # behind the lane's forwards: their scans have written the verdicts to pinned memory
                         ev.record(st)
                         ready.append(ev)
                 for l, st in enumerate(ren_lanes):
