@@ -749,6 +749,27 @@ def test_speculative_forward_is_the_complete_frame(gpu_device):
             got = bw(carve, radii2, geom2, binning2, img2)
             for a, b in zip(got, want):
                 assert torch.equal(a, b), guess
+        # The grids of the stages enqueued ahead of the read-back can be sized by a guessed bound on the tiles with instances
+        # (tgs_set_tile_bound): a fitting bound and one that is far too small (retry with exact sizes) give the same frame, and the
+        # backward may visit the frame's exact number of non-empty tiles only.
+        tiles = _C.last_nonempty_tiles()
+        assert 8 < tiles <= 77
+        for bound in (tiles + 3, tiles, 4):
+            _C.set_tile_bound(bound)
+            try:
+                carve, color2, radii2, geom2, binning2, img2, true_R = _C.rasterize_gaussians(*args, r_guess=R + 1000)
+            finally:
+                _C.set_tile_bound(0)
+            assert true_R == R and _C.last_nonempty_tiles() == tiles, bound
+            assert torch.equal(color2, color) and torch.equal(radii2, radii), bound
+            assert _C.frame_status(img2) == (R, 0)
+            _C.set_tile_bound(tiles)
+            try:
+                got = bw(carve, radii2, geom2, binning2, img2)
+            finally:
+                _C.set_tile_bound(0)
+            for a, b in zip(got, want):
+                assert torch.equal(a, b), bound
     finally:
         _C.set_deterministic(False)
 
