@@ -421,6 +421,65 @@ __device__ __forceinline__ void slab_sum(bool live, uint32_t tiles_in, uint32_t 
     }
 }
 
+// computeColorFromSH backward (backward.cu:20-139) of one Gaussian in one view: from the summed colour gradient rgb[0..2] and the clamp
+// bits, dRGB (the gradient that reaches the SH row), coef[k] (dL_dsh[k][c] = coef[k] * dRGB[c]) and the view-direction path's share of
+// dL_dmean3D, ADDED to dmean.  sh(i): coefficient i of the Gaussian's [16][3] row.
+template <typename ShRow>
+__device__ __forceinline__ void sh_backward_terms(int D, const ShRow& sh, uint32_t cl, float rgb0, float rgb1, float rgb2, float mx, float my, float mz,
+                                          float camx, float camy, float camz, float (&coef)[16], float (&dRGB)[3], float (&dmean)[3])
+{
+    dRGB[0] = rgb0 * ((cl & 1u) ? 0.f : 1.f);
+    dRGB[1] = rgb1 * ((cl & 2u) ? 0.f : 1.f);
+    dRGB[2] = rgb2 * ((cl & 4u) ? 0.f : 1.f);
+    const float ox = mx - camx, oy = my - camy, oz = mz - camz;
+    const float len = sqrtf(ox * ox + oy * oy + oz * oz);
+    const float x = ox / len, y = oy / len, z = oz / len;
+    float gxv[3] = {0.f, 0.f, 0.f}, gyv[3] = {0.f, 0.f, 0.f}, gzv[3] = {0.f, 0.f, 0.f};
+#define SH(k) sh(3 * (k) + c)
+    coef[0] = SH_C0;
+    if (D > 0) {
+        coef[1] = -SH_C1 * y; coef[2] = SH_C1 * z; coef[3] = -SH_C1 * x;
+#pragma unroll
+        for (int c = 0; c < 3; c++) { gxv[c] = -SH_C1 * SH(3); gyv[c] = -SH_C1 * SH(1); gzv[c] = SH_C1 * SH(2); }
+        if (D > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            coef[4] = SH_C2_0 * xy; coef[5] = SH_C2_1 * yz; coef[6] = SH_C2_2 * (2.f * zz - xx - yy); coef[7] = SH_C2_3 * xz; coef[8] = SH_C2_4 * (xx - yy);
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                gxv[c] += SH_C2_0 * y * SH(4) + SH_C2_2 * 2.f * -x * SH(6) + SH_C2_3 * z * SH(7) + SH_C2_4 * 2.f * x * SH(8);
+                gyv[c] += SH_C2_0 * x * SH(4) + SH_C2_1 * z * SH(5) + SH_C2_2 * 2.f * -y * SH(6) + SH_C2_4 * 2.f * -y * SH(8);
+                gzv[c] += SH_C2_1 * y * SH(5) + SH_C2_2 * 2.f * 2.f * z * SH(6) + SH_C2_3 * x * SH(7);
+            }
+            if (D > 2) {
+                coef[9] = SH_C3_0 * y * (3.f * xx - yy); coef[10] = SH_C3_1 * xy * z; coef[11] = SH_C3_2 * y * (4.f * zz - xx - yy);
+                coef[12] = SH_C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy); coef[13] = SH_C3_4 * x * (4.f * zz - xx - yy);
+                coef[14] = SH_C3_5 * z * (xx - yy); coef[15] = SH_C3_6 * x * (xx - 3.f * yy);
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    gxv[c] += (SH_C3_0 * SH(9) * 3.f * 2.f * xy + SH_C3_1 * SH(10) * yz + SH_C3_2 * SH(11) * -2.f * xy +
+                               SH_C3_3 * SH(12) * -3.f * 2.f * xz + SH_C3_4 * SH(13) * (-3.f * xx + 4.f * zz - yy) +
+                               SH_C3_5 * SH(14) * 2.f * xz + SH_C3_6 * SH(15) * 3.f * (xx - yy));
+                    gyv[c] += (SH_C3_0 * SH(9) * 3.f * (xx - yy) + SH_C3_1 * SH(10) * xz + SH_C3_2 * SH(11) * (-3.f * yy + 4.f * zz - xx) +
+                               SH_C3_3 * SH(12) * -3.f * 2.f * yz + SH_C3_4 * SH(13) * -2.f * xy + SH_C3_5 * SH(14) * -2.f * yz +
+                               SH_C3_6 * SH(15) * -3.f * 2.f * xy);
+                    gzv[c] += (SH_C3_1 * SH(10) * xy + SH_C3_2 * SH(11) * 4.f * 2.f * yz + SH_C3_3 * SH(12) * 3.f * (2.f * zz - xx - yy) +
+                               SH_C3_4 * SH(13) * 4.f * 2.f * xz + SH_C3_5 * SH(14) * (xx - yy));
+                }
+            }
+        }
+    }
+#undef SH
+    const float ddx = gxv[0] * dRGB[0] + gxv[1] * dRGB[1] + gxv[2] * dRGB[2];
+    const float ddy = gyv[0] * dRGB[0] + gyv[1] * dRGB[1] + gyv[2] * dRGB[2];
+    const float ddz = gzv[0] * dRGB[0] + gzv[1] * dRGB[1] + gzv[2] * dRGB[2];
+    // dnormvdv (auxiliary.h:107-117)
+    const float sum2 = ox * ox + oy * oy + oz * oz;
+    const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+    dmean[0] += ((+sum2 - ox * ox) * ddx - oy * ox * ddy - oz * ox * ddz) * invsum32;
+    dmean[1] += (-ox * oy * ddx + (sum2 - oy * oy) * ddy - oz * oy * ddz) * invsum32;
+    dmean[2] += (-ox * oz * ddx - oy * oz * ddy + (sum2 - oz * oz) * ddz) * invsum32;
+}
+
 struct GaussTerms {
     float a[NACC];                 // sums of the tile partials: colour rgb, mean2D xy, conic xx xy yy, opacity
     float dmean[3], dcov[6], dscale[3], drot[4];
@@ -543,57 +602,7 @@ __device__ __forceinline__ void pergauss_terms(int idx, bool live, int D, const 
     }
     if (HAS_SH) {
             asm volatile("" ::: "memory");            // keep the 48 SH reads below from being hoisted over the covariance math (VGPR pressure)
-            const uint32_t cl = g.clamped[idx];
-            dRGB[0] = a[0] * ((cl & 1u) ? 0.f : 1.f);
-            dRGB[1] = a[1] * ((cl & 2u) ? 0.f : 1.f);
-            dRGB[2] = a[2] * ((cl & 4u) ? 0.f : 1.f);
-            const float ox = mx - camx, oy = my - camy, oz = mz - camz;
-            const float len = sqrtf(ox * ox + oy * oy + oz * oz);
-            const float x = ox / len, y = oy / len, z = oz / len;
-            float gxv[3] = {0.f, 0.f, 0.f}, gyv[3] = {0.f, 0.f, 0.f}, gzv[3] = {0.f, 0.f, 0.f};
-#define SH(k) sh(3 * (k) + c)
-            coef[0] = SH_C0;
-            if (D > 0) {
-                coef[1] = -SH_C1 * y; coef[2] = SH_C1 * z; coef[3] = -SH_C1 * x;
-#pragma unroll
-                for (int c = 0; c < 3; c++) { gxv[c] = -SH_C1 * SH(3); gyv[c] = -SH_C1 * SH(1); gzv[c] = SH_C1 * SH(2); }
-                if (D > 1) {
-                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                    coef[4] = SH_C2_0 * xy; coef[5] = SH_C2_1 * yz; coef[6] = SH_C2_2 * (2.f * zz - xx - yy); coef[7] = SH_C2_3 * xz; coef[8] = SH_C2_4 * (xx - yy);
-#pragma unroll
-                    for (int c = 0; c < 3; c++) {
-                        gxv[c] += SH_C2_0 * y * SH(4) + SH_C2_2 * 2.f * -x * SH(6) + SH_C2_3 * z * SH(7) + SH_C2_4 * 2.f * x * SH(8);
-                        gyv[c] += SH_C2_0 * x * SH(4) + SH_C2_1 * z * SH(5) + SH_C2_2 * 2.f * -y * SH(6) + SH_C2_4 * 2.f * -y * SH(8);
-                        gzv[c] += SH_C2_1 * y * SH(5) + SH_C2_2 * 2.f * 2.f * z * SH(6) + SH_C2_3 * x * SH(7);
-                    }
-                    if (D > 2) {
-                        coef[9] = SH_C3_0 * y * (3.f * xx - yy); coef[10] = SH_C3_1 * xy * z; coef[11] = SH_C3_2 * y * (4.f * zz - xx - yy);
-                        coef[12] = SH_C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy); coef[13] = SH_C3_4 * x * (4.f * zz - xx - yy);
-                        coef[14] = SH_C3_5 * z * (xx - yy); coef[15] = SH_C3_6 * x * (xx - 3.f * yy);
-#pragma unroll
-                        for (int c = 0; c < 3; c++) {
-                            gxv[c] += (SH_C3_0 * SH(9) * 3.f * 2.f * xy + SH_C3_1 * SH(10) * yz + SH_C3_2 * SH(11) * -2.f * xy +
-                                       SH_C3_3 * SH(12) * -3.f * 2.f * xz + SH_C3_4 * SH(13) * (-3.f * xx + 4.f * zz - yy) +
-                                       SH_C3_5 * SH(14) * 2.f * xz + SH_C3_6 * SH(15) * 3.f * (xx - yy));
-                            gyv[c] += (SH_C3_0 * SH(9) * 3.f * (xx - yy) + SH_C3_1 * SH(10) * xz + SH_C3_2 * SH(11) * (-3.f * yy + 4.f * zz - xx) +
-                                       SH_C3_3 * SH(12) * -3.f * 2.f * yz + SH_C3_4 * SH(13) * -2.f * xy + SH_C3_5 * SH(14) * -2.f * yz +
-                                       SH_C3_6 * SH(15) * -3.f * 2.f * xy);
-                            gzv[c] += (SH_C3_1 * SH(10) * xy + SH_C3_2 * SH(11) * 4.f * 2.f * yz + SH_C3_3 * SH(12) * 3.f * (2.f * zz - xx - yy) +
-                                       SH_C3_4 * SH(13) * 4.f * 2.f * xz + SH_C3_5 * SH(14) * (xx - yy));
-                        }
-                    }
-                }
-            }
-#undef SH
-            const float ddx = gxv[0] * dRGB[0] + gxv[1] * dRGB[1] + gxv[2] * dRGB[2];
-            const float ddy = gyv[0] * dRGB[0] + gyv[1] * dRGB[1] + gyv[2] * dRGB[2];
-            const float ddz = gzv[0] * dRGB[0] + gzv[1] * dRGB[1] + gzv[2] * dRGB[2];
-            // dnormvdv (auxiliary.h:107-117)
-            const float sum2 = ox * ox + oy * oy + oz * oz;
-            const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
-            dmean[0] += ((+sum2 - ox * ox) * ddx - oy * ox * ddy - oz * ox * ddz) * invsum32;
-            dmean[1] += (-ox * oy * ddx + (sum2 - oy * oy) * ddy - oz * oy * ddz) * invsum32;
-            dmean[2] += (-ox * oz * ddx - oy * oz * ddy + (sum2 - oz * oz) * ddz) * invsum32;
+            sh_backward_terms(D, sh, g.clamped[idx], a[0], a[1], a[2], mx, my, mz, camx, camy, camz, coef, dRGB, dmean);
     }
 }
 
@@ -1017,6 +1026,152 @@ __global__ __launch_bounds__(PRE_BLOCK, 2) void k_preprocess_bwd_batch(const Bwd
     store_param_grads(shared, idx, dopacity, nocolor, dmean, dcov, dscale, drot);
 }
 
+// The same pass with TWO threads per Gaussian (SH path, M == 16): a workgroup takes 128 Gaussians, its waves 0-1 do the geometry half
+// of every view (slab sums, cov2D / projection / cov3D backward: the 17 accumulators of pergauss_terms without its SH block), waves 2-3 the
+// colour half (the colour sums of the slab rows, sh_backward_terms, the 48 dL_dsh accumulators).  The one-thread kernel needs 256 VGPRs --
+// 2 waves per SIMD -- and is bound by the latency of its own dependent arithmetic and loads at that occupancy (278 us per 8 views, alone
+// on the GPU at the end of the step); split, the kernel needs 168 and three waves per SIMD are resident, each with half the work: 239 us
+// (forced into 128 VGPRs for four waves it spills 144 B and takes 307).  The halves meet once, at the end: the colour half's share of
+// dL_dmean3D goes through LDS to the geometry half, which stores the parameter gradients.
+// a[0..2] of slab_sum only: the colour sums of the Gaussian's slab rows (their first 16 bytes)
+__device__ __forceinline__ void slab_sum_rgb(bool live, uint32_t tiles_in, uint32_t off_in, const BinState& b, float (&rgb)[3])
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t tiles = live ? tiles_in : 0u, off = live ? off_in : 0u;
+    rgb[0] = rgb[1] = rgb[2] = 0.f;
+    unsigned long long big = __builtin_amdgcn_ballot_w64(tiles >= SLAB_COOP);
+    while (big) {
+        const int src = __builtin_ctzll(big);
+        big &= big - 1;
+        const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)tiles, src), o = (uint32_t)__builtin_amdgcn_readlane((int)off, src);
+        float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+        for (uint32_t k = lane; k < n; k += 64) { const float4 r0 = b.slab[(size_t)(o + k) * SLAB_ROW]; p0 += r0.x; p1 += r0.y; p2 += r0.z; }
+        const float t0 = wave_sum(p0), t1 = wave_sum(p1), t2 = wave_sum(p2);
+        if (lane == src) { rgb[0] = t0; rgb[1] = t1; rgb[2] = t2; }
+    }
+    if (tiles < SLAB_COOP) {
+        const float4* row = b.slab + (size_t)off * SLAB_ROW;
+        for (uint32_t k = 0; k < tiles; k++, row += SLAB_ROW) { const float4 r0 = row[0]; rgb[0] += r0.x; rgb[1] += r0.y; rgb[2] += r0.z; }
+    }
+}
+
+constexpr int SPLIT_G = PRE_BLOCK / 2;                      // Gaussians per workgroup of the split pass
+#ifndef TGS_SPLIT_WAVES
+#define TGS_SPLIT_WAVES 3
+#endif
+template <bool HAS_SCALE_ROT>
+__global__ __launch_bounds__(PRE_BLOCK, TGS_SPLIT_WAVES) void k_preprocess_bwd_batch_split(const BwdIn in, const BatchViews views)
+{
+    __shared__ float4 sh_lds[SPLIT_G * 12];                 // the SH rows of the 128 Gaussians in, their dL_dsh rows out
+    __shared__ uint32_t pv_lds[BATCH_VIEWS][3][SPLIT_G];    // radii / tiles_touched / offsets of every Gaussian in every view (as in the one-thread kernel), shared by its two threads
+    __shared__ float dm_lds[3][SPLIT_G];                    // the colour half's share of dL_dmean3D
+    const bool colour = threadIdx.x >= SPLIT_G;             // wave-uniform
+    const int gl = threadIdx.x & (SPLIT_G - 1);             // Gaussian of the workgroup
+    const size_t gbase = ((size_t)in.block0 * 2 + blockIdx.x) * SPLIT_G;
+    const int idx = (int)(gbase + gl);
+    const bool in_range = idx < in.P;
+    {   // SH rows: 128 x 12 float4, 6 coalesced 16-B loads per thread
+        const float4* s4 = reinterpret_cast<const float4*>(in.shs);
+        const size_t base4 = gbase * 12, total4 = (size_t)in.P * 12;
+#pragma unroll
+        for (int q = 0; q < 6; q++) { const size_t i = base4 + q * PRE_BLOCK + threadIdx.x; if (i < total4) sh_lds[q * PRE_BLOCK + threadIdx.x] = s4[i]; }
+    }
+    if (!colour) {
+        uint32_t pr[BATCH_VIEWS], pt[BATCH_VIEWS], po[BATCH_VIEWS];
+#pragma unroll
+        for (int v = 0; v < BATCH_VIEWS; v++) {
+            pr[v] = pt[v] = po[v] = 0u;
+            if (v < views.n && in_range) { pr[v] = (uint32_t)views.v[v].radii[idx]; pt[v] = views.v[v].g.tiles_touched[idx]; po[v] = views.v[v].g.offsets[idx]; }
+        }
+#pragma unroll
+        for (int v = 0; v < BATCH_VIEWS; v++) { pv_lds[v][0][gl] = pr[v]; pv_lds[v][1][gl] = pt[v]; pv_lds[v][2][gl] = po[v]; }
+    }
+    __syncthreads();
+    if (colour) {
+        const float* sh_row = reinterpret_cast<const float*>(&sh_lds[gl * 12]);
+        float mx = 0.f, my = 0.f, mz = 0.f;
+        if (in_range) { mx = in.means3D[3 * (size_t)idx]; my = in.means3D[3 * (size_t)idx + 1]; mz = in.means3D[3 * (size_t)idx + 2]; }
+        float o48[48];
+#pragma unroll
+        for (int i = 0; i < 48; i++) o48[i] = 0.f;
+        float dmean[3] = {0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int v = 0; v < views.n; v++) {
+            const BatchView& vw = views.v[v];
+            const bool rejected = (vw.meta->error & META_ERR_CAPACITY) != 0u;
+            const bool live = in_range && !rejected && (int)pv_lds[v][0][gl] > 0;
+            if (__builtin_amdgcn_ballot_w64(live) == 0) continue;
+            float rgb[3];
+            slab_sum_rgb(live, pv_lds[v][1][gl], pv_lds[v][2][gl], vw.b, rgb);
+            if (live) {
+                float coef[16], dRGB[3];
+#pragma unroll
+                for (int k = 0; k < 16; k++) coef[k] = 0.f;
+                sh_backward_terms(in.D, [&](int i) { return sh_row[i]; }, vw.g.clamped[idx], rgb[0], rgb[1], rgb[2], mx, my, mz, vw.cam.campos[0], vw.cam.campos[1],
+                                  vw.cam.campos[2], coef, dRGB, dmean);
+#pragma unroll
+                for (int i = 0; i < 48; i++) o48[i] += coef[i / 3] * dRGB[i % 3];
+            }
+        }
+        dm_lds[0][gl] = dmean[0]; dm_lds[1][gl] = dmean[1]; dm_lds[2][gl] = dmean[2];
+        __syncthreads();                                   // (A) the geometry half has the colour half's dL_dmean3D; every SH row has been consumed
+#pragma unroll
+        for (int q = 0; q < 12; q++) sh_lds[gl * 12 + q] = make_float4(o48[4 * q], o48[4 * q + 1], o48[4 * q + 2], o48[4 * q + 3]);
+        __syncthreads();                                   // (B) the dL_dsh rows are staged
+    } else {
+        float dopacity = 0.f, dmean[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dscale[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int v = 0; v < views.n; v++) {
+            const BatchView& vw = views.v[v];
+            const bool rejected = (vw.meta->error & META_ERR_CAPACITY) != 0u;
+            const bool live = in_range && !rejected && (int)pv_lds[v][0][gl] > 0;
+            GaussTerms t;
+            if (__builtin_amdgcn_ballot_w64(live) != 0) {
+                const ViewMat V = load_mat(vw.cam.view), PM = load_mat(vw.cam.proj);
+                pergauss_terms<false, HAS_SCALE_ROT>(idx, live, in.D, [&](int) { return 0.f; }, in, in.cov3D_precomp, vw.cam, V, PM, vw.cam.campos[0], vw.cam.campos[1],
+                                                     vw.cam.campos[2], vw.g, vw.b, pv_lds[v][1][gl], pv_lds[v][2][gl], t);
+            } else {
+                t.a[3] = t.a[4] = 0.f;
+            }
+            if (in_range) {
+                const size_t i3 = 3 * (size_t)idx;
+                vw.dL_dmean2D[i3] = live ? t.a[3] : 0.f; vw.dL_dmean2D[i3 + 1] = live ? t.a[4] : 0.f; vw.dL_dmean2D[i3 + 2] = 0.f;
+            }
+            if (live) {
+                dopacity += t.a[8];
+#pragma unroll
+                for (int k = 0; k < 3; k++) { dmean[k] += t.dmean[k]; dscale[k] += t.dscale[k]; }
+#pragma unroll
+                for (int k = 0; k < 6; k++) dcov[k] += t.dcov[k];
+#pragma unroll
+                for (int k = 0; k < 4; k++) drot[k] += t.drot[k];
+            }
+        }
+        __syncthreads();                                   // (A)
+        if (in_range) {
+            dmean[0] += dm_lds[0][gl]; dmean[1] += dm_lds[1][gl]; dmean[2] += dm_lds[2][gl];
+            const float nocolor[3] = {0.f, 0.f, 0.f};
+            BwdIn shared = in;
+            shared.dL_dcolor = nullptr;
+            store_param_grads(shared, idx, dopacity, nocolor, dmean, dcov, dscale, drot);
+        }
+        __syncthreads();                                   // (B)
+    }
+    {   // dL_dsh rows out: 6 coalesced 16-B stores per thread
+        float4* d4 = reinterpret_cast<float4*>(in.dL_dsh);
+        const size_t base4 = gbase * 12, total4 = (size_t)in.P * 12;
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            const size_t i = base4 + q * PRE_BLOCK + threadIdx.x;
+            if (i < total4) {
+                float4 o = sh_lds[q * PRE_BLOCK + threadIdx.x];
+                if (in.accumulate) { const float4 p = d4[i]; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+                d4[i] = o;
+            }
+        }
+    }
+}
+
 // hardware self-test of wave_reduce36: in[64][36] -> out[4][9] (row e, component k)
 __global__ void k_selftest_reduce36(const float* in, float* out)
 {
@@ -1056,6 +1211,13 @@ void launch_preprocess_bwd_batch(hipStream_t st, const BwdIn& in, const BatchVie
 {
     const dim3 grid((unsigned)(in.nblocks > 0 ? in.nblocks : n_blocks(in.P))), blk(PRE_BLOCK);
     const bool sh = in.shs != nullptr, sr = in.scales != nullptr;
+    static const bool split = [] { const char* e = getenv("TGS_SPLIT_PASS"); return !e || atoi(e) != 0; }();    // (TGS_SPLIT_PASS=0: the one-thread kernel, for A/B runs)
+    if (sh && in.M == 16 && split) {                        // two threads per Gaussian: 128 Gaussians per workgroup
+        const dim3 grid2(2 * grid.x);
+        if (sr) hipLaunchKernelGGL((k_preprocess_bwd_batch_split<true>), grid2, blk, 0, st, in, views);
+        else hipLaunchKernelGGL((k_preprocess_bwd_batch_split<false>), grid2, blk, 0, st, in, views);
+        return;
+    }
     if (sh && sr) hipLaunchKernelGGL((k_preprocess_bwd_batch<true, true>), grid, blk, 0, st, in, views);
     else if (sh) hipLaunchKernelGGL((k_preprocess_bwd_batch<true, false>), grid, blk, 0, st, in, views);
     else if (sr) hipLaunchKernelGGL((k_preprocess_bwd_batch<false, true>), grid, blk, 0, st, in, views);
