@@ -111,7 +111,7 @@ def test_two_rank_step_on_the_hip_path_equals_unsharded(gpu_device, tmp_path):
             log = open(str(tmp_path / f"w{world}_r{rank}.log"), "w+")
             logs.append(log)
             procs.append(subprocess.Popen([sys.executable, str(script)], env=env, cwd=ROOT, stdout=log, stderr=subprocess.STDOUT, text=True))
-        deadline = time.time() + 300
+        deadline = time.time() + 120
         failed = None
         while any(p.poll() is None for p in procs):
             bad = [r for r, p in enumerate(procs) if p.poll() not in (None, 0)]
