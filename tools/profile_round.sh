@@ -4,7 +4,7 @@ set -x
 # Counter passes never share a run with trace domains other than --kernel-trace (MI355X_MICROARCH.md, rocprofv3 PMC slots: 8 SQ counters or
 # FETCH_SIZE (3 TCC slots) or WRITE_SIZE (2) per pass).
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/${1:-r02_f}
+O=$R/gpurun_out/${1:-r02_g}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench_default.json 2> $O/bench_default.err

@@ -1,6 +1,6 @@
 set -x
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r02_f
+O=$R/gpurun_out/r02_g
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rm -rf $O/rp4 $O/rp1
