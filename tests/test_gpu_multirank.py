@@ -128,7 +128,7 @@ def test_two_rank_step_on_the_hip_path_equals_unsharded(gpu_device, tmp_path):
     script.write_text(_WORKER)
     out = str(tmp_path / "res")
 
-    def launch(world):
+    def launch(world, retried=False):
         # logs go to files (a rank blocked on a full pipe would stall its peer inside a collective), and the ranks are watched together:
         # if one dies, the other is not left waiting in the rendezvous for gloo's half-hour timeout
         import time
@@ -154,6 +154,11 @@ def test_two_rank_step_on_the_hip_path_equals_unsharded(gpu_device, tmp_path):
         tails = []
         for log in logs:
             log.seek(0); tails.append(log.read()[-2000:]); log.close()
+        if failed == -1 and not retried:                    # a stall, not a crash: one retry (see test_bench_starts_two_ranks)
+            print("ranks stalled; logs of the first attempt:\n" + "\n---\n".join(tails), file=sys.stderr)
+            for p in procs:
+                p.wait()
+            return launch(world, retried=True)
         assert failed is None and all(p.wait() == 0 for p in procs), (failed, tails)
         return [np.load(out + f"_w{world}.{r}.npz") for r in range(world)]
 
