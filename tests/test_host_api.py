@@ -152,6 +152,32 @@ def test_sync_free_batch_capacity_policy():
     assert b.capacity() == 1 << 16
 
 
+def test_tile_bound_policy(monkeypatch):
+    """Host logic of the bounds on the tiles with instances that size the sync-free grids: none until a step has reported counts, 10 %
+    headroom rounded up to 64 tiles, TGS_TILE_BOUND=0 switches them off; the drop-in API's speculation keeps a decaying maximum of the
+    tile counts beside the instance counts and counts an exceeded tile guess as a miss."""
+    from youreditableavatar_amd.multiview import SyncFreeBatch
+    b = SyncFreeBatch()
+    assert b.tile_bound is None and b.tile_capacity() == 0 and b.class_bound == [0, 0]
+    b.tile_bound = 2721
+    assert b.tile_capacity() == 3008 and b.tile_capacity() % 64 == 0 and b.tile_capacity() >= 2721 * 1.1
+    monkeypatch.setenv("TGS_TILE_BOUND", "0")
+    assert b.tile_capacity() == 0
+    monkeypatch.delenv("TGS_TILE_BOUND")
+    from youreditableavatar_amd.diff_gaussian_rasterization import _Speculation
+    sp = _Speculation()
+    key = (500_000, 1080, 1920, "cuda:0")
+    assert sp.guess(key) is None and sp.tile_guess(key) == 0
+    sp.update(key, 750_000, None, tiles=2700, tile_guess=0)
+    g, tg = sp.guess(key), sp.tile_guess(key)
+    assert g >= 750_000 * 1.15 and tg % 64 == 0 and 2700 * 1.15 <= tg <= 2700 * 1.15 + 64
+    sp.update(key, 700_000, g, tiles=2500, tile_guess=tg)            # inside both guesses: no miss, the maxima decay slowly
+    assert sp.state[key][1] == 0 and sp.state[key][0] >= 700_000 and sp.state[key][3] >= 2500
+    for _ in range(sp.MAX_MISSES):                                   # the instance guess holds, the tile guess does not: misses all the same
+        sp.update(key, 700_000, sp.guess(key) or 10 ** 9, tiles=10 * tg, tile_guess=tg)
+    assert sp.guess(key) is None                                      # cooling down
+
+
 def test_deferred_backward_rejects_mixed_batches():
     import torch
     from youreditableavatar_amd.multiview import DeferredBackward
