@@ -24,13 +24,16 @@
  * All pointers are device pointers to contiguous fp32 (int32 for radii) unless noted.  The layout
  * inside the three state buffers is private to this library (the reference's is private too:
  * rasterizer_impl.h:29-65); they only have to be handed back to tgs_backward unmodified.
- * The render entry points keep no state between calls and are re-entrant: everything a backward needs travels in the three
- * state buffers.  What IS process-wide, and only that: the test / experiment knobs declared further down -- tgs_set_sort_lds_cap,
- * tgs_set_instance_pruning, tgs_set_forward_group, tgs_set_deterministic (relaxed atomics read once per call; none of them changes a
- * result beyond summation order, instance pruning changes num_rendered / n_contrib as documented) -- and the optional bench profiler
- * (tgs_profile_*) -- plus two tuning variables of the environment, read once: TGS_BIN_WGS (binning chunks per view, default 128) and
- * TGS_FORWARD_GROUP (overrides tgs_set_forward_group).  Per calling thread: the message of tgs_last_error(), tgs_set_render_streams, and the pinned 64-byte staging slot +
- * event of tgs_forward_speculative (one per thread and device).  A caller that never touches the knobs shares nothing between calls.
+ * The render entry points keep no state between calls and are re-entrant (Rasterizer's statics are stateless too, rasterizer.h:20-85):
+ * everything a backward needs travels in the three state buffers, and everything that tunes a call travels in an explicit
+ * tgs_options_t (the *_opt entry points below; NULL = defaults) -- instance pruning, the deterministic backward, the LDS sort budget,
+ * the forward group and the bounds on the tiles with instances.  Two threads that render through one library with different options
+ * do not see each other's (tests/test_gpu_api.py::test_two_threads_with_different_options).
+ * The setters tgs_set_sort_lds_cap / tgs_set_instance_pruning / tgs_set_forward_group / tgs_set_deterministic / tgs_set_tile_bound
+ * are TEST-ONLY shims: process-wide (tile bound: per thread) defaults that a call WITHOUT options falls back to.  Also process-wide:
+ * the optional bench profiler (tgs_profile_*) and two tuning variables of the environment, read once: TGS_BIN_WGS (binning chunks per
+ * view, default 128) and TGS_FORWARD_GROUP.  Per calling thread: the message of tgs_last_error(), tgs_set_render_streams (experiment),
+ * and the pinned 64-byte staging slot + event of the speculative forward (one per thread and device).
  */
 #ifndef TGS_RASTER_H
 #define TGS_RASTER_H
@@ -42,7 +45,7 @@
 extern "C" {
 #endif
 
-#define TGS_ABI_VERSION 1
+#define TGS_ABI_VERSION 2      /* 2: tgs_view_t carries the tile bounds + host_meta, tgs_options_t / *_opt entry points, dc/rest SH colours */
 
 enum { TGS_BUF_GEOM = 0, TGS_BUF_BINNING = 1, TGS_BUF_IMAGE = 2 };
 
@@ -104,11 +107,49 @@ int64_t tgs_forward_speculative(int64_t r_guess, int64_t* num_rendered, tgs_allo
                                 float tan_fovx, float tan_fovy, int prefiltered,
                                 float* out_color, int* radii, int debug);
 
-enum { TGS_FRAME_PREFILTERED = 1, TGS_FRAME_REJECTED = 2 };
+enum { TGS_FRAME_PREFILTERED = 1, TGS_FRAME_REJECTED = 2, TGS_FRAME_TILE_BOUND = 4 /* a backward ran with a tile bound below the frame's non-empty tiles: gradients incomplete */ };
 /* Synchronises `stream` and returns the frame's true num_rendered and its TGS_FRAME_* flags.  The same 64 bytes sit at
  * the start of the image buffer (u64 num_rendered, u32 longest list, u32 overflow tiles, u32 flags, ...), so a batch
  * can also gather them on the device and read them back once. */
 int tgs_frame_status(void* stream, const void* img_buffer, int64_t* num_rendered, int* flags);
+
+/* ---- explicit per-call options (re-entrancy; ABI 2) ----
+ * Every field's zero / -1 value means "the library default" (or, for the first four, whatever the test-only setter of the same name
+ * last stored), so `tgs_options_t o = {sizeof o};` followed by the fields a caller cares about is the whole protocol. */
+typedef struct {
+    uint32_t struct_size;      /* sizeof(tgs_options_t) of the caller's build: fields beyond it read as defaults */
+    int32_t instance_pruning;  /* 1: no instance in rectangle tiles the splat cannot reach with alpha >= 1/255; 0: the reference's lists; -1: default (on) */
+    int32_t deterministic;     /* 1: bitwise-reproducible per-pixel backward (k_render_bwd_det); 0: default kernel; -1: default (TGS_DETERMINISTIC, else 0) */
+    int32_t forward_group;     /* tgs_forward_views: views per launch of the per-Gaussian stage, 1..8; 0: default (2) */
+    uint32_t sort_lds_cap;     /* longest tile list sorted inside LDS, power of two in [2, 8192]; 0: default (8192) */
+    int64_t tile_bound;        /* sync-free / speculative forward and the per-pixel backward: upper bound on the tiles that hold instances
+                                  (grids are sized by it; a forward with more is rejected / repeated; a backward with more sets
+                                  TGS_FRAME_TILE_BOUND in the frame's flags and returns TGS_ERR_INVALID from tgs_frame_status); 0: none */
+    int64_t heavy_bound, mid_bound;   /* the same for the tile sort's classes (>= 1024 / >= 128 instances); only read with tile_bound */
+    int32_t render_split;      /* experiment: 1 = heavy tiles are composited by several workgroups (k_render_*_split); 0 / -1: default */
+    int32_t reserved;
+} tgs_options_t;
+/* What a forward learned about its frame (filled when non-NULL; the synchronous and the speculative forward read the frame's Meta,
+ * the sync-free one cannot: num_rendered / nonempty_tiles are -1 there). */
+typedef struct {
+    int64_t num_rendered;      /* true instance count of the frame */
+    int64_t nonempty_tiles;    /* tiles that hold instances: the exact bound for this frame's backward */
+    int32_t flags;             /* TGS_FRAME_* */
+    int32_t reserved;
+} tgs_frame_info_t;
+enum { TGS_FWD_SYNC = 0, TGS_FWD_ASYNC = 1, TGS_FWD_SPECULATIVE = 2 };
+/* tgs_forward (mode TGS_FWD_SYNC; r ignored), tgs_forward_async (TGS_FWD_ASYNC; r = r_capacity) or tgs_forward_speculative
+ * (TGS_FWD_SPECULATIVE; r = r_guess) with explicit options.  Returns what the binning buffer is carved for (pass it as R to the backward). */
+int64_t tgs_forward_opt(const tgs_options_t* opt, int mode, int64_t r, tgs_frame_info_t* info,
+                        tgs_alloc_fn alloc, void* alloc_ctx, void* stream,
+                        int P, int D, int M,
+                        const float* background, int width, int height,
+                        const float* means3D, const float* shs, const float* colors_precomp,
+                        const float* opacities, const float* scales, float scale_modifier,
+                        const float* rotations, const float* cov3D_precomp,
+                        const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                        float tan_fovx, float tan_fovy, int prefiltered,
+                        float* out_color, int* radii, int debug);
 
 /* Gradient outputs need NOT be zero-initialised (the reference requires torch::zeros,
  * rasterize_points.cu:151-159); every element is written.  dL_dconic[P,4] is scratch.
@@ -140,6 +181,19 @@ int tgs_backward_accumulate(void* stream, int P, int D, int M, int64_t R,
                             float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
                             float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
                             int debug);
+
+/* tgs_backward (accumulate = 0) / tgs_backward_accumulate (1) with explicit options (deterministic, tile_bound). */
+int tgs_backward_opt(const tgs_options_t* opt, int accumulate, void* stream, int P, int D, int M, int64_t R,
+                     const float* background, int width, int height,
+                     const float* means3D, const float* shs, const float* colors_precomp,
+                     const float* scales, float scale_modifier, const float* rotations,
+                     const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                     const float* campos, float tan_fovx, float tan_fovy, const int* radii,
+                     const void* geom_buffer, const void* binning_buffer, const void* img_buffer,
+                     const float* dL_dpix,
+                     float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+                     float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                     int debug);
 
 /* present[P]: 1 byte per Gaussian, 1 iff view-space z > 0.2 (auxiliary.h:154). */
 int tgs_mark_visible(void* stream, int P, const float* means3D, const float* viewmatrix,
@@ -240,7 +294,21 @@ int tgs_forward_views(void* const* streams, int n_streams, int64_t r_capacity, i
                       const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
                       int prefiltered, int n_views, tgs_view_t* views);
 int tgs_backward_render_views(void* const* streams, int n_streams, int P, int n_views, const tgs_view_t* views);
-/* Knob (process-wide, default on): a splat gets no tile instance in a tile of its 3-sigma rectangle where it stays below
+/* The same with explicit options (instance pruning, forward group, sort budget, render_split / deterministic); the tile bounds of a
+ * view travel in its tgs_view_t. */
+int tgs_forward_views_opt(const tgs_options_t* opt, void* const* streams, int n_streams, int64_t r_capacity, int P, int D, int M,
+                          const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+                          const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                          int prefiltered, int n_views, tgs_view_t* views);
+int tgs_backward_render_views_opt(const tgs_options_t* opt, void* const* streams, int n_streams, int P, int n_views, const tgs_view_t* views);
+int tgs_backward_render_opt(const tgs_options_t* opt, void* stream, int P, int64_t R, const float* background, int width, int height,
+                            const void* binning_buffer, const void* img_buffer, const float* dL_dpix);
+/* sizeof(tgs_view_t) / sizeof(tgs_options_t) of THIS build: a binding checks them against its own declaration before it walks an array */
+size_t tgs_sizeof_view(void);
+size_t tgs_sizeof_options(void);
+
+/* ---- test-only shims: defaults for calls WITHOUT options (see the top of this file) ---- */
+/* Test-only shim (process-wide, default on): a splat gets no tile instance in a tile of its 3-sigma rectangle where it stays below
  * alpha = 1/255 on every pixel (the reference creates the instance, rasterizer_impl.cu:98-109, and skips it pixel by pixel,
  * forward.cu:340-343).  Images and gradients do not change; num_rendered and the internal n_contrib (a list position) do.
  * Off = the reference's instance lists, e.g. to count fragments the way the reference's state defines them. */
@@ -249,14 +317,14 @@ void tgs_set_instance_pruning(int on);
  * view's own stream -- so that binning (L2 atomics, latency) and compositing (VALU) of different views run on streams of their own.
  * n = 0 restores one stream per view. */
 int tgs_set_render_streams(void* const* streams, int n);
-/* Per calling thread: the same bound for the single-view sync-free entry points (tgs_forward_async, tgs_forward_speculative -- which
+/* Test-only shim, per calling thread: the same bound for the single-view sync-free entry points (tgs_forward_async, tgs_forward_speculative -- which
  * repeats the stages behind the scan with exact sizes when the guess was too small -- and tgs_backward / tgs_backward_render /
  * tgs_backward_accumulate of a frame KNOWN to have at most that many non-empty tiles).  0 (default): none.  It stays set until changed. */
 void tgs_set_tile_bound(int64_t n_tiles_with_instances);
 /* Non-empty tiles of the last frame this thread rendered with tgs_forward or tgs_forward_speculative (their Meta read-back); -1 if none. */
 int64_t tgs_last_nonempty_tiles(void);
 
-/* Knob (process-wide): views per launch of the per-Gaussian forward stage inside tgs_forward_views (1..8, default 2).  Groups
+/* Test-only shim (process-wide): views per launch of the per-Gaussian forward stage inside tgs_forward_views (1..8, default 2).  Groups
  * read the SH rows once per group; measured with four streams, pairs pay (-2 % per frame) and larger groups do not (the views of a
  * group start their remaining stages together). */
 void tgs_set_forward_group(int views_per_launch);
@@ -290,11 +358,11 @@ int tgs_l1_ssim(void* stream, int planes, int height, int width, const float* im
 int tgs_l1_ssim_backward(void* stream, int planes, int height, int width, const float* img, const float* gt, float dssim_factor,
                          const float* upstream, float* dL_dimg, const void* workspace, size_t workspace_bytes);
 
-/* Test knob (process-wide): longest tile list that is depth-sorted inside LDS; longer lists take the
+/* Test-only shim (process-wide): longest tile list that is depth-sorted inside LDS; longer lists take the
  * multi-workgroup global-memory path.  Power of two in [2, 8192]; default 8192. */
 int tgs_set_sort_lds_cap(unsigned cap);
 
-/* Process-wide switch for the backward render kernel: 1 = fixed summation order inside a tile (gradients
+/* Test-only shim, process-wide switch for the backward render kernel: 1 = fixed summation order inside a tile (gradients
  * bitwise reproducible run to run, about 2.5x slower in that kernel), 0 = LDS float atomics inside a tile
  * (default), -1 = follow the environment variable TGS_DETERMINISTIC.  Neither mode uses global atomics. */
 void tgs_set_deterministic(int on);

@@ -1,0 +1,59 @@
+"""Random small scenes against the CPU oracle (the body of tests/tools/fuzz_vs_oracle.py as a function, so that the GPU suite can assert
+and record its miss rate).  A *miss* is a scene on which util.compare raises at the stated fp32 tolerance with the direct comparison of
+the cancellation-prone tensors held to 1 x their tolerance."""
+from __future__ import annotations
+
+import numpy as np
+
+from tests import util
+
+
+def random_scene(rng, it: int):
+    from youreditableavatar_amd import scenes
+    P = int(rng.integers(50, 6000)); W = int(rng.integers(17, 300)); H = int(rng.integers(17, 220)); D = int(rng.integers(0, 4))
+    sm = float(rng.choice([0.3, 1.0, 3.0, 8.0])); ff = float(rng.uniform(0, 1)); tf = float(rng.choice([0.0, 0.05]))
+    cloud = scenes.make_cloud(P, D, seed=int(rng.integers(1 << 30)), scale_mult=sm, flat_fraction=ff, tiny_fraction=tf, n_oversized=int(rng.choice([0, 0, 3])))
+    cam = scenes.orbit_camera(W, H, azimuth_deg=float(rng.uniform(0, 360)), elevation_deg=float(rng.uniform(-30, 30)))
+    return (P, W, H, D, sm), util.scene_input(cloud, cam), scenes.upstream_gradient(W, H, seed=it)
+
+
+def diagnose(mine: dict, ref: dict, P: int) -> str:
+    """where does the difference sit?  (one Gaussian / one pixel = a threshold flip or an ill-conditioned splat, not a defect)"""
+    try:
+        dT = np.abs(np.asarray(mine["final_T"], np.float64) - np.asarray(ref["final_T"], np.float64).reshape(np.asarray(mine["final_T"]).shape))
+        conc = {}
+        for k in ("dL_dmeans2D", "dL_dconic", "dL_dscales", "dL_drotations"):
+            if k in mine and k in ref:
+                a = np.asarray(mine[k], np.float64).reshape(P, -1); b = np.asarray(ref[k], np.float64).reshape(P, -1)[:, :a.shape[1]]
+                d = ((a - b) ** 2).sum(1)
+                conc[k] = float(d.max() / max(d.sum(), 1e-300))
+        return f"pixels with |dT| > 1e-3: {int((dT > 1e-3).sum())}, share of the squared error in ONE Gaussian: " + ", ".join(f"{k} {v:.2f}" for k, v in conc.items())
+    except Exception as ex:      # noqa: BLE001
+        return f"(no diagnosis: {ex})"
+
+
+def run(seed: int, n_scenes: int, direct_factor: float = 1.0, log=print) -> dict:
+    """-> {scenes, misses, miss_rate, worst_rel_l2, worst (text), largest_ok: per-tensor maximum over the scenes that passed}"""
+    import re
+    rng = np.random.default_rng(seed)
+    misses, worst, worst_txt, largest = 0, 0.0, "", {}
+    for it in range(n_scenes):
+        desc, inp, dL = random_scene(rng, it)
+        ref = util.oracle_run(inp, dL)
+        mine = util.hip_run(inp, dL)
+        try:
+            rep = util.compare(mine, ref, direct_factor=direct_factor)
+            for k, v in rep.items():
+                if k.startswith("dL_") or k == "color":
+                    largest[k] = max(largest.get(k, 0.0), float(v))
+            log(it, *desc, f"R={mine['num_rendered']}/{ref['num_rendered']}", "ok")
+        except AssertionError as e:
+            misses += 1
+            m = re.search(r"rel-L2 ([0-9.e+-]+)", str(e))
+            val = float(m.group(1)) if m else float("nan")
+            txt = f"{it} {desc} {str(e)[:110]} | {diagnose(mine, ref, desc[0])}"
+            if not (val <= worst):
+                worst, worst_txt = val, txt
+            log("MISS", txt)
+    return dict(scenes=n_scenes, misses=misses, miss_rate=misses / max(n_scenes, 1), worst_rel_l2=worst, worst=worst_txt, seed=seed,
+                direct_factor=direct_factor, largest_ok={k: float(f"{v:.3g}") for k, v in largest.items()})

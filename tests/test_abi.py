@@ -39,7 +39,22 @@ def test_library_exports_every_declared_symbol():
     for f in declared_functions():
         assert hasattr(lib, f), f"libtgs_raster.so does not export {f}"
     lib.tgs_abi_version.restype = ctypes.c_int
-    assert lib.tgs_abi_version() == 1
+    header_version = int(re.search(r"#define TGS_ABI_VERSION (\d+)", open(HEADER).read()).group(1))
+    assert lib.tgs_abi_version() == header_version == 2
+
+
+def test_bindings_check_abi_version_and_struct_sizes():
+    """A stale libtgs_raster.so must not be walked with a newer tgs_view_t: the ctypes binding and the compiled module
+    both compare the ABI version and sizeof(tgs_view_t) / sizeof(tgs_options_t) with the library's at import."""
+    import ctypes as C
+    from diff_gaussian_rasterization import _C
+    assert _C.ABI_VERSION == 2 and _C._ext.abi_version() == 2 and _C._ext.compiled_abi_version() == 2
+    assert _C._lib.tgs_sizeof_view() == C.sizeof(_C._ViewT) == _C._ext.sizeof_view()
+    assert _C._lib.tgs_sizeof_options() == C.sizeof(_C._OptionsT)
+    o = _C.options(tile_bound=640, pruning=False, deterministic=True, sort_lds_cap=512)
+    assert (o.struct_size, o.tile_bound, o.instance_pruning, o.deterministic, o.sort_lds_cap, o.render_split) == (C.sizeof(_C._OptionsT), 640, 0, 1, 512, -1)
+    src = open(os.path.join(ROOT, "youreditableavatar_amd", "diff_gaussian_rasterization", "_C.py")).read()
+    assert "could not be rebuilt" in src and "older than its sources" in src        # a failed rebuild of a stale library raises, it is not swallowed
 
 
 def test_library_is_independent_of_torch_and_oracle():
@@ -100,6 +115,22 @@ def test_argument_validation_needs_no_gpu():
     lib.tgs_forward_views.restype = it
     lib.tgs_forward_views.argtypes = [vp, it, i64, it, it, it, vp, vp, vp, vp, vp, fl, vp, vp, it, it, vp]
     assert lib.tgs_forward_views(None, 0, 100, 10, 3, 16, None, None, None, None, None, 1.0, None, None, 0, 2, None) == INVALID
+    # the explicit-options entry points validate the same way (NULL options = defaults)
+    lib.tgs_forward_opt.restype = i64
+    lib.tgs_forward_opt.argtypes = [vp, it, i64, vp] + lib.tgs_forward.argtypes
+    fwd_args = (None, None, None, 10, 0, 0, None, 64, 64, None, None, None, None, None, 1.0, None, None, None, None, None, 1.0, 1.0, 0, None, None, 0)
+    assert lib.tgs_forward_opt(None, 0, 0, None, *fwd_args) == INVALID and "alloc" in msg()
+    assert lib.tgs_forward_opt(None, 7, 0, None, *fwd_args) == INVALID and "mode" in msg()
+    assert lib.tgs_forward_opt(None, 1, -3, None, *fwd_args) == INVALID
+    lib.tgs_backward_render_opt.restype = it
+    lib.tgs_backward_render_opt.argtypes = [vp] + lib.tgs_backward_render.argtypes
+    assert lib.tgs_backward_render_opt(None, None, 10, 5, None, 64, 64, None, None, None) == INVALID and "NULL" in msg()
+    lib.tgs_forward_views_opt.restype = it
+    lib.tgs_forward_views_opt.argtypes = [vp] + lib.tgs_forward_views.argtypes
+    assert lib.tgs_forward_views_opt(None, None, 0, 100, 10, 3, 16, None, None, None, None, None, 1.0, None, None, 0, 2, None) == INVALID
+    lib.tgs_sizeof_view.restype = sz
+    lib.tgs_sizeof_options.restype = sz
+    assert lib.tgs_sizeof_view() == 192 and lib.tgs_sizeof_options() == 56
     lib.tgs_dist2.restype = it
     lib.tgs_dist2.argtypes = [vp, it, vp, vp, vp, sz]
     assert lib.tgs_dist2(None, -1, None, None, None, 0) == INVALID and "tgs_dist2" in msg()

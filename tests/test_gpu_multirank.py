@@ -79,10 +79,14 @@ from youreditableavatar_amd import scenes
 from youreditableavatar_amd.multiview import FlatGradients, SyncFreeBatch, shard_views
 from diff_gaussian_rasterization import GaussianRasterizationSettings, _C
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-if world > 1:
-    import datetime
-    dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=180))
+backend = os.environ.get("TGS_BACKEND", "gloo")
+alone = os.environ.get("TGS_EVEN_ALONE") == "1"          # world size 1 THROUGH the process group: the RCCL path on a one-GPU box
 dev = torch.device("cuda:0")
+if world > 1 or alone:
+    import datetime
+    torch.cuda.set_device(0)
+    kw = dict(device_id=dev) if backend == "nccl" else {}
+    dist.init_process_group(backend, timeout=datetime.timedelta(seconds=180), **kw)
 P, W, H, D, V = 7000, 208, 144, 2, 6
 cloud = scenes.make_cloud(P, D, seed=77, scale_mult=3.0)
 t = lambda a, rg=False: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev).requires_grad_(rg)
@@ -97,10 +101,10 @@ dLs = [t(scenes.upstream_gradient(W, H, seed=300 + v)) for v in range(V)]
 mine = list(shard_views(V, rank, world))
 _C.set_deterministic(True)
 batch = SyncFreeBatch(granule=256, streams=2)
-pending, calls = [], []
+pending, calls, n_handles = [], [], []
 def on_chunk(first, count):
     calls.append((first, count))
-    pending.extend(flat.all_reduce_rows(first, count))
+    pending.extend(flat.all_reduce_rows(first, count, even_alone=alone))
 res = {}
 for step in range(4):
     if step == 3 and rank == world - 1:
@@ -108,6 +112,7 @@ for step in range(4):
     calls.clear()
     batch.run_views([settings[v] for v in mine], L["means3D"], L["opacities"], L["shs"], L["scales"], L["rotations"], None, accumulate=False,
                     upstream_view=lambda i, img: dLs[mine[i]], grad_chunks=3, on_chunk=on_chunk)
+    n_handles.append(len(pending))
     for w in pending:
         w.wait()
     pending.clear()
@@ -115,55 +120,57 @@ for step in range(4):
     res[f"flat{step}"] = flat.flat.cpu().numpy().copy()
     res[f"calls{step}"] = np.asarray(calls)
 res["rejected"] = np.asarray(batch.rejected)
+res["handles"] = np.asarray(n_handles)
 np.savez(os.environ["TGS_OUT"] + f".{rank}.npz", **res)
-if world > 1:
+if world > 1 or alone:
     dist.barrier()
     dist.destroy_process_group()
 """
 
 
-@pytest.mark.timeout(700)
-def test_two_rank_step_on_the_hip_path_equals_unsharded(gpu_device, tmp_path):
+def _launch_workers(tmp_path, world, tag, extra_env=None):
+    """Starts `world` worker processes (all on cuda:0) and returns what each saved.  Logs go to files (a rank blocked on a full pipe would
+    stall its peer inside a collective), and the ranks are watched together: if one dies, the other is not left waiting in the rendezvous
+    for the backend's timeout.  A stall is a FAILURE (faulthandler stacks of every rank in the message), not something to retry."""
+    import signal
+    import time
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
-    out = str(tmp_path / "res")
-
-    def launch(world, retried=False):
-        # logs go to files (a rank blocked on a full pipe would stall its peer inside a collective), and the ranks are watched together:
-        # if one dies, the other is not left waiting in the rendezvous for gloo's half-hour timeout
-        import time
-        port = _free_port()
-        procs, logs = [], []
-        for rank in range(world):
-            env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                       TGS_ROOT=ROOT, TGS_OUT=out + f"_w{world}", HSA_ENABLE_IPC_MODE_LEGACY="0")
-            log = open(str(tmp_path / f"w{world}_r{rank}.log"), "w+")
-            logs.append(log)
-            procs.append(subprocess.Popen([sys.executable, str(script)], env=env, cwd=ROOT, stdout=log, stderr=subprocess.STDOUT, text=True))
-        deadline = time.time() + 120
-        failed = None
-        while any(p.poll() is None for p in procs):
-            bad = [r for r, p in enumerate(procs) if p.poll() not in (None, 0)]
-            if bad or time.time() > deadline:
-                failed = bad[0] if bad else -1
-                for p in procs:
-                    if p.poll() is None:
-                        p.kill()
-                break
-            time.sleep(0.2)
-        tails = []
-        for log in logs:
-            log.seek(0); tails.append(log.read()[-2000:]); log.close()
-        if failed == -1 and not retried:                    # a stall, not a crash: one retry (see test_bench_starts_two_ranks)
-            print("ranks stalled; logs of the first attempt:\n" + "\n---\n".join(tails), file=sys.stderr)
+    out = str(tmp_path / f"res_{tag}")
+    port = _free_port()
+    procs, logs = [], []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   TGS_ROOT=ROOT, TGS_OUT=out, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONFAULTHANDLER="1", **(extra_env or {}))
+        log = open(str(tmp_path / f"{tag}_r{rank}.log"), "w+")
+        logs.append(log)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, cwd=ROOT, stdout=log, stderr=subprocess.STDOUT, text=True))
+    deadline = time.time() + 150
+    failed = None
+    while any(p.poll() is None for p in procs):
+        bad = [r for r, p in enumerate(procs) if p.poll() not in (None, 0)]
+        if bad or time.time() > deadline:
+            failed = bad[0] if bad else -1
             for p in procs:
-                p.wait()
-            return launch(world, retried=True)
-        assert failed is None and all(p.wait() == 0 for p in procs), (failed, tails)
-        return [np.load(out + f"_w{world}.{r}.npz") for r in range(world)]
+                if p.poll() is None:
+                    p.send_signal(signal.SIGABRT)            # faulthandler: every thread's Python stack into the log
+            time.sleep(3)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.2)
+    tails = []
+    for log in logs:
+        log.seek(0); tails.append(log.read()[-3000:]); log.close()
+    assert failed is None and all(p.wait() == 0 for p in procs), ("stalled" if failed == -1 else f"rank {failed} failed", tails)
+    return [np.load(out + f".{r}.npz") for r in range(world)]
 
-    one = launch(1)[0]
-    two = launch(2)
+
+@pytest.mark.timeout(700)
+def test_two_rank_step_on_the_hip_path_equals_unsharded(gpu_device, tmp_path):
+    one = _launch_workers(tmp_path, 1, "w1")[0]
+    two = _launch_workers(tmp_path, 2, "w2")
     for step in range(4):
         want = one[f"flat{step}"]
         assert np.abs(want).max() > 0
@@ -176,3 +183,20 @@ def test_two_rank_step_on_the_hip_path_equals_unsharded(gpu_device, tmp_path):
         # the same ranges in the same order on both ranks (collectives pair up), also when one of them had to render views again
         assert np.array_equal(two[0][f"calls{step}"], two[1][f"calls{step}"]) and len(two[0][f"calls{step}"]) == 3
     assert int(two[1]["rejected"]) >= 1 and int(two[0]["rejected"]) == 0
+
+
+@pytest.mark.timeout(500)
+def test_range_wise_reduce_through_rccl_at_world_size_one(gpu_device, tmp_path):
+    """The production backend on the one GPU this pool has: backend "nccl" (= RCCL) at world size 1, with the early return of
+    FlatGradients.all_reduce_rows bypassed -- RCCL initialisation with HSA_ENABLE_IPC_MODE_LEGACY=0, the coalesced all-reduce of five
+    device slices per Gaussian range (one group launch), its ordering against the per-Gaussian pass on the step's stream and the waits at
+    the end of the step all run for real.  A sum over one rank is the identity: the gradients must equal the run without a process group
+    bit for bit, in all four steps (the last one re-renders views)."""
+    plain = _launch_workers(tmp_path, 1, "plain")[0]
+    rccl = _launch_workers(tmp_path, 1, "rccl", dict(TGS_BACKEND="nccl", TGS_EVEN_ALONE="1"))[0]
+    assert list(plain["handles"]) == [0, 0, 0, 0]
+    assert list(rccl["handles"]) == [3, 3, 3, 3]            # one coalesced collective per Gaussian range (not one per parameter slice)
+    for step in range(4):
+        assert np.array_equal(plain[f"flat{step}"], rccl[f"flat{step}"]), step
+        assert np.array_equal(plain[f"calls{step}"], rccl[f"calls{step}"]) and len(rccl[f"calls{step}"]) == 3
+    assert int(rccl["rejected"]) >= 1

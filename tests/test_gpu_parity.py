@@ -314,3 +314,46 @@ def test_random_small_scenes_vs_oracle(seed, gpu_device):
     dL = scenes.upstream_gradient(W, H, seed=seed)
     rep = util.compare(util.hip_run(inp, dL), util.oracle_run(inp, dL))
     print(seed, P, W, H, D, sm, {k: f"{v:.1e}" for k, v in rep.items() if k in ("color", "lists_equal", "instances_dropped", "n_contrib_equal")})
+
+
+@pytest.mark.parametrize("mode,seed", [("sh", 91), ("precomp", 92)])
+def test_hip_vs_independent_fp64_autograd(mode, seed, gpu_device):
+    """The HIP path against oracle/torch_splat.py -- a forward written from the textbook formulas (Sigma = R S^2 R^T, EWA projection,
+    front-to-back compositing) and differentiated by autograd in float64, i.e. code that shares NOTHING with the reference-derived C
+    oracle or the emulated-reference fixtures -- at 6000 Gaussians / 256 x 256, both colour modes.  The bar is the plain 1e-4 on every
+    tensor, no relaxation: exact arithmetic is the yardstick here, and the fp32 paths sit 1e-6 .. 2e-5 from it on this scene."""
+    from oracle import torch_splat
+    from youreditableavatar_amd import scenes
+    cloud = scenes.make_cloud(6000, 3, seed=seed, scale_mult=3.0)
+    cam = scenes.orbit_camera(256, 256, azimuth_deg=33.0)
+    dL = scenes.upstream_gradient(256, 256, seed=5)
+    ref = torch_splat.run_scene(cloud, cam, dL, mode=mode)
+    inp = util.scene_input(cloud, cam, mode)
+    full = util.hip_run(inp, None, pruning=False)           # the reference's instance lists: n_contrib is comparable as a list position
+    assert int(full["num_rendered"]) == int(ref["num_rendered"]) > 40_000
+    assert np.array_equal(full["radii"], ref["radii"])
+    assert (full["n_contrib"].astype(np.int64) == ref["n_contrib"]).mean() >= 0.999
+    assert util.rel_l2(full["final_T"], ref["final_T"]) <= 1e-5
+    mine = util.hip_run(inp, dL)
+    rep = {"color": util.rel_l2(mine["color"], ref["color"])}
+    assert np.array_equal(mine["radii"], ref["radii"])
+    pairs = [("dL_dmeans3D", "grad_means3D"), ("dL_dopacity", "grad_opacities"), ("dL_dscales", "grad_scales"), ("dL_drotations", "grad_rotations")]
+    pairs += [("dL_dsh", "grad_shs")] if mode == "sh" else [("dL_dcolors", "grad_colors_precomp")]
+    for a, b in pairs:
+        rep[a] = util.rel_l2(mine[a], ref[b])
+    rep["dL_dmeans2D"] = util.rel_l2(mine["dL_dmeans2D"][:, :2], ref["grad_means2D"][:, :2])
+    util.record_parity(f"fp64_autograd_{mode}_6000_256", rep)
+    print(mode, {k: f"{v:.2e}" for k, v in rep.items()})
+    for k, v in rep.items():
+        assert v <= util.REL_TOL, (k, v)
+
+
+def test_fuzz_miss_rate_vs_oracle(gpu_device):
+    """The fuzz as a tracked, asserted number (round 2 kept it in a text file): 128 random scenes against the CPU oracle with the direct
+    comparison of the cancellation-prone tensors held to 1 x their tolerance.  A miss is one near-threshold fragment or one needle-shaped
+    splat over the fp32 bar; the accurate-math build misses as often.  At most 3 % of the scenes."""
+    from tests import fuzz
+    res = fuzz.run(seed=2026, n_scenes=128, direct_factor=1.0, log=lambda *a: None)
+    util.record_parity("fuzz_128_scenes_direct_1x", res)
+    print({k: v for k, v in res.items() if k != "largest_ok"})
+    assert res["miss_rate"] <= 0.03, res

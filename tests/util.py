@@ -83,8 +83,10 @@ def scene_input(cloud: dict, cam, mode: str = "sh", cov_mode: str = "scale_rot")
     return inp
 
 
-def hip_run(inp: dict, dL: Optional[np.ndarray] = None, device="cuda:0", debug=False, introspect=True) -> Dict[str, np.ndarray]:
-    """The HIP path through the reference's ``_C`` surface (ctypes over the C ABI of include/tgs_raster.h)."""
+def hip_run(inp: dict, dL: Optional[np.ndarray] = None, device="cuda:0", debug=False, introspect=True, pruning: Optional[bool] = None,
+            deterministic: Optional[bool] = None) -> Dict[str, np.ndarray]:
+    """The HIP path through the reference's ``_C`` surface (the compiled module over the C ABI of include/tgs_raster.h).  ``pruning`` /
+    ``deterministic``: explicit per-call options (tgs_options_t); None = the library defaults."""
     import torch
     from diff_gaussian_rasterization import _C
     dev = torch.device(device)
@@ -94,7 +96,7 @@ def hip_run(inp: dict, dL: Optional[np.ndarray] = None, device="cuda:0", debug=F
     H, W, D = int(inp["image_height"]), int(inp["image_width"]), int(inp["sh_degree"])
     sm, tfx, tfy = float(inp.get("scale_modifier", 1.0)), float(inp["tanfovx"]), float(inp["tanfovy"])
     R, color, radii, geom, binning, img = _C.rasterize_gaussians(bg, means3D, colors, opac, scales, rots, sm, cov, view, proj,
-                                                                 tfx, tfy, H, W, sh, D, campos, False, debug)
+                                                                 tfx, tfy, H, W, sh, D, campos, False, debug, pruning=pruning)
     P = means3D.shape[0]
     out = dict(color=color.cpu().numpy(), radii=radii.cpu().numpy(), num_rendered=R)
     has_sh, has_sr = inp.get("shs") is not None, inp.get("scales") is not None
@@ -114,7 +116,7 @@ def hip_run(inp: dict, dL: Optional[np.ndarray] = None, device="cuda:0", debug=F
     if dL is not None:
         g = _C.rasterize_gaussians_backward(bg, means3D, radii, colors, scales, rots, sm, cov, view, proj, tfx, tfy,
                                             torch.from_numpy(np.ascontiguousarray(dL, np.float32)).to(dev), sh, D, campos, geom, R, binning, img, debug,
-                                            _with_conic=True)
+                                            _with_conic=True, deterministic=deterministic)
         names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations", "dL_dconic")
         out.update({n: v.cpu().numpy() for n, v in zip(names, g)})
     torch.cuda.synchronize()
@@ -209,7 +211,11 @@ def record_parity(name: str, rep: dict, extra: Optional[dict] = None) -> None:
         pass
 
 
-def compare(mine: dict, ref: dict, golden_out: Optional[dict] = None, nc_frac: float = 0.999, check_lists: bool = True):
+DIRECT_FACTOR = 1.5     # direct comparison of the cancellation-prone tensors against the oracle: this multiple of their tolerance (round 2: 3)
+
+
+def compare(mine: dict, ref: dict, golden_out: Optional[dict] = None, nc_frac: float = 0.999, check_lists: bool = True,
+            direct_factor: float = DIRECT_FACTOR):
     """Asserts the SURVEY.md section 8d parity bar; returns {tensor: rel_l2} for reporting."""
     H, W = ref["n_contrib"].shape
     rep = {}
@@ -249,7 +255,7 @@ def compare(mine: dict, ref: dict, golden_out: Optional[dict] = None, nc_frac: f
             if split and k in NOISY:
                 e2 = rel_l2(a, pg[k]); rep[k + "|own_inputs"] = e2
                 assert e2 <= tol, f"{k} (per-Gaussian half on own inputs) rel-L2 {e2:.3e} > {tol:.1e}"
-                assert e <= 3 * tol, f"{k} rel-L2 {e:.3e} (direct comparison, bound {3 * tol:.1e})"
+                assert e <= direct_factor * tol, f"{k} rel-L2 {e:.3e} (direct comparison, bound {direct_factor * tol:.1e})"
             else:
                 assert e <= tol, f"{k} rel-L2 {e:.3e} > {tol:.1e}"
             assert np.all(a[~vis] == 0), f"{k}: culled Gaussians must have zero gradient"

@@ -37,12 +37,51 @@ static std::atomic<int> g_deterministic{-1};
 static std::atomic<uint32_t> g_sort_cap{SORT_LDS_CAP};
 static std::atomic<int> g_fwd_group{2};
 static std::atomic<int> g_prune{1};
+#ifndef TGS_RENDER_SPLIT_DEFAULT
+#define TGS_RENDER_SPLIT_DEFAULT 0
+#endif
 static bool deterministic_mode()
 {
     const int v = g_deterministic.load(std::memory_order_relaxed);
     if (v >= 0) return v != 0;
     const char* e = getenv("TGS_DETERMINISTIC");
     return e && e[0] && e[0] != '0';
+}
+
+// Everything that tunes one call (include/tgs_raster.h: tgs_options_t), resolved ONCE at the entry point and passed down by value: the
+// kernels and launchers never read a global.  Fields a caller leaves at their default fall back to the test-only setters' values.
+struct Opts {
+    int prune;
+    bool deterministic;
+    int fwd_group;
+    uint32_t sort_cap;
+    int64_t tile_bound, heavy_bound, mid_bound;
+    int render_split;
+};
+static thread_local int64_t t_tile_bound = 0;               // tgs_set_tile_bound (test-only shim): default tile bound of this thread's calls without options
+static Opts resolve_options(const tgs_options_t* o)
+{
+    Opts r;
+    r.prune = g_prune.load(std::memory_order_relaxed);
+    r.deterministic = deterministic_mode();
+    r.fwd_group = g_fwd_group.load(std::memory_order_relaxed);
+    r.sort_cap = g_sort_cap.load(std::memory_order_relaxed);
+    r.tile_bound = t_tile_bound; r.heavy_bound = 0; r.mid_bound = 0;
+    static const int env_split = [] { const char* e = getenv("TGS_RENDER_SPLIT"); return e ? atoi(e) : -1; }();     // tuning knob, read once
+    r.render_split = env_split >= 0 ? env_split : TGS_RENDER_SPLIT_DEFAULT;
+    if (!o) return r;
+    const size_t n = o->struct_size;
+#define TGS_HAS(f) (n >= offsetof(tgs_options_t, f) + sizeof(o->f))
+    if (TGS_HAS(instance_pruning) && o->instance_pruning >= 0) r.prune = o->instance_pruning ? 1 : 0;
+    if (TGS_HAS(deterministic) && o->deterministic >= 0) r.deterministic = o->deterministic != 0;
+    if (TGS_HAS(forward_group) && o->forward_group > 0) r.fwd_group = o->forward_group > BATCH_VIEWS ? BATCH_VIEWS : o->forward_group;
+    if (TGS_HAS(sort_lds_cap) && o->sort_lds_cap >= 2 && o->sort_lds_cap <= SORT_LDS_CAP && !(o->sort_lds_cap & (o->sort_lds_cap - 1))) r.sort_cap = o->sort_lds_cap;
+    if (TGS_HAS(tile_bound)) r.tile_bound = o->tile_bound > 0 ? o->tile_bound : 0;      // (explicit options: 0 really means none)
+    if (TGS_HAS(heavy_bound) && o->heavy_bound > 0) r.heavy_bound = o->heavy_bound;
+    if (TGS_HAS(mid_bound) && o->mid_bound > 0) r.mid_bound = o->mid_bound;
+    if (TGS_HAS(render_split) && o->render_split >= 0) r.render_split = o->render_split;
+#undef TGS_HAS
+    return r;
 }
 
 // ---- optional per-stage timing (bench only): hipEvents recorded on the caller's stream, no sync ----
@@ -215,15 +254,10 @@ static SpecSlot* spec_slot()
 // the binning buffer is sized for r_capacity instances before anything runs and nothing is read back.
 // tgs_set_render_streams: k_render_fwd of view k goes to render stream k mod n (behind an event on the view's own stream)
 static thread_local std::vector<hipStream_t> t_render_streams;
-static thread_local hipStream_t t_render_stream = nullptr;
-// tgs_set_tile_bound / tgs_view_t::tile_bound: upper bound on the tiles with instances for the sync-free grids (0: none)
-static thread_local int64_t t_tile_bound = 0;
-static thread_local int64_t t_last_nonempty = -1;
-static thread_local int64_t t_class_bound[2] = {0, 0};      // tgs_view_t::heavy_bound / mid_bound (tile sort classes), with t_tile_bound
-static thread_local Meta* t_host_meta = nullptr;            // tgs_view_t::host_meta of the view being enqueued
-static uint32_t bounded_tiles(size_t T) { return (t_tile_bound > 0 && (uint64_t)t_tile_bound < (uint64_t)T) ? (uint32_t)t_tile_bound : (uint32_t)T; }
+static thread_local int64_t t_last_nonempty = -1;           // tgs_last_nonempty_tiles (legacy read-out; tgs_frame_info_t carries it explicitly)
+static uint32_t bounded_tiles(const Opts& o, size_t T) { return (o.tile_bound > 0 && (uint64_t)o.tile_bound < (uint64_t)T) ? (uint32_t)o.tile_bound : (uint32_t)T; }
 
-static int64_t forward_impl(int preprocessed, int64_t r_capacity, int64_t* speculative_true_R, tgs_alloc_fn alloc, void* alloc_ctx, void* stream, int P, int D, int M, const float* background, int width,
+static int64_t forward_impl(const Opts& opt, Meta* host_meta, hipStream_t render_stream, tgs_frame_info_t* info, int preprocessed, int64_t r_capacity, int64_t* speculative_true_R, tgs_alloc_fn alloc, void* alloc_ctx, void* stream, int P, int D, int M, const float* background, int width,
                     int height, const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
                     const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
                     const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
@@ -231,6 +265,7 @@ static int64_t forward_impl(int preprocessed, int64_t r_capacity, int64_t* specu
 {
     const bool async = r_capacity >= 0;
     t_last_nonempty = -1;                                   // (known again once this call has read the frame's Meta)
+    if (info) { info->num_rendered = -1; info->nonempty_tiles = -1; info->flags = 0; info->reserved = 0; }
     if (r_capacity > 0x7fffffffll) return fail(TGS_ERR_INVALID, "r_capacity exceeds 2^31-1");
     hipStream_t st = (hipStream_t)stream;
     g_err[0] = 0;
@@ -239,7 +274,8 @@ static int64_t forward_impl(int preprocessed, int64_t r_capacity, int64_t* specu
     if (P == 0) {   // rasterize_points.cu:81: nothing runs, the image keeps its zero fill (empty inputs have no pointers to check)
         if (!out_color) return fail(TGS_ERR_INVALID, "NULL required pointer");
         HIP_TRY(hipMemsetAsync(out_color, 0, 3 * (size_t)width * height * sizeof(float), st));
-        if (t_host_meta) memset(t_host_meta, 0, sizeof(Meta));   // (pinned host memory: no kernel of this frame writes it)
+        if (host_meta) memset(host_meta, 0, sizeof(Meta));   // (pinned host memory: no kernel of this frame writes it)
+        if (info && !(async && !speculative_true_R)) { info->num_rendered = 0; info->nonempty_tiles = 0; }
         if (async) {   // the caller still gets a (zeroed) Meta to query
             ImgState s0;
             const size_t bytes = img_carve(s0, nullptr, (size_t)width * height, (size_t)((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE));
@@ -261,7 +297,7 @@ static int64_t forward_impl(int preprocessed, int64_t r_capacity, int64_t* specu
     const size_t N = (size_t)width * height, T = (size_t)cam.gx * cam.gy;
     const bool has_sh = shs != nullptr;
 
-    const uint32_t sort_cap = g_sort_cap.load(std::memory_order_relaxed);
+    const uint32_t sort_cap = opt.sort_cap;
     GeomState g; ImgState s; BinState b;
     const size_t geom_bytes = geom_carve(g, nullptr, (size_t)P, has_sh, has_sr);
     const size_t img_bytes = img_carve(s, nullptr, N, T);
@@ -278,7 +314,7 @@ static int64_t forward_impl(int preprocessed, int64_t r_capacity, int64_t* specu
     FwdIn in;
     in.P = P; in.D = D; in.M = M; in.means3D = means3D; in.shs = shs; in.colors_precomp = colors_precomp; in.opacities = opacities;
     in.scales = scales; in.rotations = rotations; in.cov3D_precomp = cov3D_precomp; in.background = background;
-    in.prefiltered = prefiltered; in.out_color = out_color; in.radii = radii; in.prune = g_prune.load(std::memory_order_relaxed);
+    in.prefiltered = prefiltered; in.out_color = out_color; in.radii = radii; in.prune = opt.prune;
 
     uint64_t R = 0;
     Meta meta;
@@ -294,14 +330,14 @@ static int64_t forward_impl(int preprocessed, int64_t r_capacity, int64_t* specu
         if (!spec) return fail(TGS_ERR_HIP, "pinned staging for the speculative forward could not be allocated");
     }
     // sync-free grids cover `tb` tiles (the caller's bound on the tiles with instances, or all of them); k_scan rejects a frame with more
-    const uint32_t tb = async ? bounded_tiles(T) : (uint32_t)T;
+    const uint32_t tb = async ? bounded_tiles(opt, T) : (uint32_t)T;
     const bool classes = async && tb < T;                   // class bounds come with a tile bound only
-    const uint32_t hb = (classes && t_class_bound[0] > 0 && (uint64_t)t_class_bound[0] < tb) ? (uint32_t)t_class_bound[0] : tb;
-    const uint32_t mb = (classes && t_class_bound[1] > 0 && (uint64_t)t_class_bound[1] < tb) ? (uint32_t)t_class_bound[1] : tb;
+    const uint32_t hb = (classes && opt.heavy_bound > 0 && (uint64_t)opt.heavy_bound < tb) ? (uint32_t)opt.heavy_bound : tb;
+    const uint32_t mb = (classes && opt.mid_bound > 0 && (uint64_t)opt.mid_bound < tb) ? (uint32_t)opt.mid_bound : tb;
     STAGE_BEGIN(TGS_STAGE_SCAN);
     launch_bin_count(st, P, g, s, cam.gx, (uint32_t)T);
     launch_scan(st, g, s, (uint32_t)n_blocks((size_t)P), (uint32_t)T, sort_cap, async ? (unsigned long long)r_capacity : ~0ull, tb, hb, mb,
-                spec ? spec->meta : t_host_meta);
+                spec ? spec->meta : host_meta);
     STAGE_CHECK("scan", TGS_STAGE_SCAN);
     if (spec) {
         // speculative synchronous forward: k_scan itself has written Meta into the pinned host slot; the event marks its end, the remaining
@@ -317,6 +353,7 @@ static int64_t forward_impl(int preprocessed, int64_t r_capacity, int64_t* specu
         R = meta.R;
         if (R > 0x7fffffffull) return fail(TGS_ERR_TOO_MANY, "%llu tile instances exceed 2^31-1", (unsigned long long)R);
         t_last_nonempty = (int64_t)meta.n_nonempty;
+        if (info) { info->num_rendered = (int64_t)meta.R; info->nonempty_tiles = (int64_t)meta.n_nonempty; info->flags = (int32_t)meta.error; }
     } else {
         R = (uint64_t)r_capacity;
     }
@@ -335,13 +372,13 @@ static int64_t forward_impl(int preprocessed, int64_t r_capacity, int64_t* specu
         STAGE_CHECK("tile_sort", TGS_STAGE_TILE_SORT);
     }
     hipStream_t rst = st;
-    if (t_render_stream && t_render_stream != st && !spec) {     // binning and compositing on different streams (tgs_set_render_streams)
+    if (render_stream && render_stream != st && !spec) {     // binning and compositing on different streams (tgs_set_render_streams)
         hipEvent_t binned;
         HIP_TRY(hipEventCreateWithFlags(&binned, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(binned, st));
-        HIP_TRY(hipStreamWaitEvent(t_render_stream, binned, 0));
+        HIP_TRY(hipStreamWaitEvent(render_stream, binned, 0));
         (void)hipEventDestroy(binned);
-        rst = t_render_stream;
+        rst = render_stream;
     }
     STAGE_BEGIN(TGS_STAGE_RENDER_FWD);
     launch_render_fwd(rst, s, b, width, height, cam.gx, (uint32_t)T, known, background, out_color, tb);
@@ -353,6 +390,7 @@ static int64_t forward_impl(int preprocessed, int64_t r_capacity, int64_t* specu
         if (meta.R > 0x7fffffffull) return fail(TGS_ERR_TOO_MANY, "%llu tile instances exceed 2^31-1", (unsigned long long)meta.R);
         *speculative_true_R = (int64_t)meta.R;
         t_last_nonempty = (int64_t)meta.n_nonempty;
+        if (info) { info->num_rendered = (int64_t)meta.R; info->nonempty_tiles = (int64_t)meta.n_nonempty; info->flags = (int32_t)(meta.error & ~META_ERR_CAPACITY); }
         if ((meta.error & META_ERR_CAPACITY) || meta.pad[0] != 0u) {     // (pad[0]: more tiles with instances than the caller's bound, k_scan)
             // the guess was too small: every kernel behind the scan returned at
             // once; clear the flag and run those stages again with the exact sizes, as tgs_forward does
@@ -379,8 +417,24 @@ int64_t tgs_forward(tgs_alloc_fn alloc, void* alloc_ctx, void* stream, int P, in
                     const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
                     int prefiltered, float* out_color, int* radii, int debug)
 {
-    return forward_impl(0, -1, nullptr, alloc, alloc_ctx, stream, P, D, M, background, width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
-                        rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, radii, debug);
+    return tgs_forward_opt(nullptr, TGS_FWD_SYNC, 0, nullptr, alloc, alloc_ctx, stream, P, D, M, background, width, height, means3D, shs, colors_precomp, opacities,
+                           scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, radii, debug);
+}
+
+int64_t tgs_forward_opt(const tgs_options_t* o, int mode, int64_t r, tgs_frame_info_t* info, tgs_alloc_fn alloc, void* alloc_ctx, void* stream, int P, int D, int M,
+                        const float* background, int width, int height, const float* means3D, const float* shs, const float* colors_precomp,
+                        const float* opacities, const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                        const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
+                        float* out_color, int* radii, int debug)
+{
+    const Opts opt = resolve_options(o);
+    int64_t true_R = 0;
+    if (mode == TGS_FWD_SYNC) r = -1;
+    else if (mode != TGS_FWD_ASYNC && mode != TGS_FWD_SPECULATIVE) return fail(TGS_ERR_INVALID, "tgs_forward_opt: unknown mode %d", mode);
+    else if (r < 0) return fail(TGS_ERR_INVALID, "r_capacity / r_guess must be >= 0");
+    return forward_impl(opt, nullptr, nullptr, info, 0, r, mode == TGS_FWD_SPECULATIVE ? &true_R : nullptr, alloc, alloc_ctx, stream, P, D, M, background, width, height,
+                        means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy,
+                        prefiltered, out_color, radii, debug);
 }
 
 int64_t tgs_forward_async(int64_t r_capacity, tgs_alloc_fn alloc, void* alloc_ctx, void* stream, int P, int D, int M, const float* background,
@@ -390,8 +444,8 @@ int64_t tgs_forward_async(int64_t r_capacity, tgs_alloc_fn alloc, void* alloc_ct
                           int prefiltered, float* out_color, int* radii, int debug)
 {
     if (r_capacity < 0) return fail(TGS_ERR_INVALID, "r_capacity must be >= 0");
-    return forward_impl(0, r_capacity, nullptr, alloc, alloc_ctx, stream, P, D, M, background, width, height, means3D, shs, colors_precomp, opacities, scales,
-                        scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, radii, debug);
+    return tgs_forward_opt(nullptr, TGS_FWD_ASYNC, r_capacity, nullptr, alloc, alloc_ctx, stream, P, D, M, background, width, height, means3D, shs, colors_precomp, opacities,
+                           scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, radii, debug);
 }
 
 int64_t tgs_forward_speculative(int64_t r_guess, int64_t* num_rendered, tgs_alloc_fn alloc, void* alloc_ctx, void* stream, int P, int D, int M,
@@ -402,9 +456,12 @@ int64_t tgs_forward_speculative(int64_t r_guess, int64_t* num_rendered, tgs_allo
 {
     if (r_guess < 0 || !num_rendered) return fail(TGS_ERR_INVALID, "r_guess must be >= 0 and num_rendered non-NULL");
     *num_rendered = 0;
-    return forward_impl(0, r_guess, num_rendered, alloc, alloc_ctx, stream, P, D, M, background, width, height, means3D, shs, colors_precomp, opacities,
-                        scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, radii,
-                        debug);
+    tgs_frame_info_t info;
+    const int64_t r = tgs_forward_opt(nullptr, TGS_FWD_SPECULATIVE, r_guess, &info, alloc, alloc_ctx, stream, P, D, M, background, width, height, means3D, shs, colors_precomp,
+                                      opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color,
+                                      radii, debug);
+    if (r >= 0 && info.num_rendered >= 0) *num_rendered = info.num_rendered;
+    return r;
 }
 
 int tgs_frame_status(void* stream, const void* img_buffer, int64_t* num_rendered, int* flags)
@@ -418,10 +475,12 @@ int tgs_frame_status(void* stream, const void* img_buffer, int64_t* num_rendered
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     *num_rendered = (int64_t)meta.R;
     *flags = (int)meta.error;
+    if (meta.error & META_ERR_TILE_BOUND)
+        return fail(TGS_ERR_INVALID, "a backward of this frame ran with a tile bound below its %u tiles with instances: gradients are incomplete", meta.n_nonempty);
     return TGS_OK;
 }
 
-static int backward_impl(int accumulate, void* stream, int P, int D, int M, int64_t R, const float* background, int width, int height, const float* means3D,
+static int backward_impl(const Opts& opt, int accumulate, void* stream, int P, int D, int M, int64_t R, const float* background, int width, int height, const float* means3D,
                  const float* shs, const float* colors_precomp, const float* scales, float scale_modifier, const float* rotations,
                  const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx,
                  float tan_fovy, const int* radii, const void* geom_buffer, const void* binning_buffer, const void* img_buffer,
@@ -457,7 +516,7 @@ static int backward_impl(int accumulate, void* stream, int P, int D, int M, int6
 
     if (R > 0) {
         STAGE_BEGIN(TGS_STAGE_RENDER_BWD);
-        launch_render_bwd(st, s, b, width, height, cam.gx, bounded_tiles(T), background, dL_dpix, deterministic_mode());
+        launch_render_bwd(st, s, b, width, height, cam.gx, bounded_tiles(opt, T), background, dL_dpix, opt.deterministic);
         STAGE_CHECK("render_bwd", TGS_STAGE_RENDER_BWD);
     }
     STAGE_BEGIN(TGS_STAGE_PREPROCESS_BWD);
@@ -473,8 +532,20 @@ int tgs_backward(void* stream, int P, int D, int M, int64_t R, const float* back
                  const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
                  float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug)
 {
-    return backward_impl(0, stream, P, D, M, R, background, width, height, means3D, shs, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp,
+    return backward_impl(resolve_options(nullptr), 0, stream, P, D, M, R, background, width, height, means3D, shs, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp,
                          viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer, img_buffer, dL_dpix, dL_dmean2D,
+                         dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug);
+}
+
+int tgs_backward_opt(const tgs_options_t* o, int accumulate, void* stream, int P, int D, int M, int64_t R, const float* background, int width, int height,
+                     const float* means3D, const float* shs, const float* colors_precomp, const float* scales, float scale_modifier, const float* rotations,
+                     const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy,
+                     const int* radii, const void* geom_buffer, const void* binning_buffer, const void* img_buffer, const float* dL_dpix, float* dL_dmean2D,
+                     float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                     int debug)
+{
+    return backward_impl(resolve_options(o), accumulate ? 1 : 0, stream, P, D, M, R, background, width, height, means3D, shs, colors_precomp, scales, scale_modifier, rotations,
+                         cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer, img_buffer, dL_dpix, dL_dmean2D,
                          dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug);
 }
 
@@ -485,7 +556,7 @@ int tgs_backward_accumulate(void* stream, int P, int D, int M, int64_t R, const 
                             const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
                             float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug)
 {
-    return backward_impl(1, stream, P, D, M, R, background, width, height, means3D, shs, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp,
+    return backward_impl(resolve_options(nullptr), 1, stream, P, D, M, R, background, width, height, means3D, shs, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp,
                          viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer, img_buffer, dL_dpix, dL_dmean2D,
                          dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug);
 }
@@ -519,10 +590,22 @@ int tgs_set_render_streams(void* const* streams, int n)
     return TGS_OK;
 }
 
+size_t tgs_sizeof_view(void) { return sizeof(tgs_view_t); }
+size_t tgs_sizeof_options(void) { return sizeof(tgs_options_t); }
+
 int tgs_forward_views(void* const* streams, int n_streams, int64_t r_capacity, int P, int D, int M, const float* means3D, const float* shs,
                       const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier, const float* rotations,
                       const float* cov3D_precomp, int prefiltered, int n_views, tgs_view_t* views)
 {
+    return tgs_forward_views_opt(nullptr, streams, n_streams, r_capacity, P, D, M, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp,
+                                 prefiltered, n_views, views);
+}
+
+int tgs_forward_views_opt(const tgs_options_t* o, void* const* streams, int n_streams, int64_t r_capacity, int P, int D, int M, const float* means3D, const float* shs,
+                          const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                          const float* cov3D_precomp, int prefiltered, int n_views, tgs_view_t* views)
+{
+    const Opts opt0 = resolve_options(o);
     g_err[0] = 0;
     if (n_views == 0) return TGS_OK;
     if (!streams || n_streams <= 0 || n_views < 0 || !views || r_capacity < 0) return fail(TGS_ERR_INVALID, "bad arguments");
@@ -536,7 +619,7 @@ int tgs_forward_views(void* const* streams, int n_streams, int64_t r_capacity, i
     // beyond pairs: 0.302 / 0.296 / 0.308 / 0.306 ms per frame for groups of 1 / 2 / 4 / 8 at config 3.  (With the counting atomics
     // in this stage, until round 2, the launch was bound by them and no grouping paid.)
     static const int env_group = [] { const char* e = getenv("TGS_FORWARD_GROUP"); return e ? atoi(e) : 0; }();   // tuning knob, read once
-    int group = g_fwd_group.load(std::memory_order_relaxed);
+    int group = opt0.fwd_group;
     if (env_group > 0) group = env_group > BATCH_VIEWS ? BATCH_VIEWS : env_group;
     bool per_view_colors = false;
     for (int k = 0; k < n_views; k++) per_view_colors = per_view_colors || views[k].colors_precomp != nullptr;
@@ -558,7 +641,7 @@ int tgs_forward_views(void* const* streams, int n_streams, int64_t r_capacity, i
             memset(&in, 0, sizeof(in));
             in.P = P; in.D = D; in.M = M; in.means3D = means3D; in.shs = shs; in.colors_precomp = colors_precomp; in.opacities = opacities;
             in.scales = scales; in.rotations = rotations; in.cov3D_precomp = cov3D_precomp; in.prefiltered = prefiltered;
-            in.prune = g_prune.load(std::memory_order_relaxed);
+            in.prune = opt0.prune;
             FwdViews fv;
             memset(&fv, 0, sizeof(fv));
             fv.n = nv;
@@ -590,13 +673,11 @@ int tgs_forward_views(void* const* streams, int n_streams, int64_t r_capacity, i
             tgs_view_t& v = views[v0 + k];
             hipStream_t st = (hipStream_t)streams[(v0 + k) % n_streams];
             if (pre_done && st != st0) HIP_TRY(hipStreamWaitEvent(st, pre_done, 0));
-            t_render_stream = t_render_streams.empty() ? nullptr : t_render_streams[(size_t)(v0 + k) % t_render_streams.size()];
-            struct Reset { ~Reset() { t_render_stream = nullptr; } } reset_render_stream;
-            struct BoundReset { int64_t old; ~BoundReset() { t_tile_bound = old; t_class_bound[0] = t_class_bound[1] = 0; t_host_meta = nullptr; } } bound_reset{t_tile_bound};
-            t_host_meta = (Meta*)v.host_meta;
-            t_tile_bound = v.tile_bound > 0 ? v.tile_bound : 0;
-            t_class_bound[0] = v.heavy_bound > 0 ? v.heavy_bound : 0; t_class_bound[1] = v.mid_bound > 0 ? v.mid_bound : 0;
-            const int64_t r = forward_impl(batched ? 1 : 0, r_capacity, nullptr, alloc_preset, &v, st, P, D, M, v.background, v.width, v.height, means3D, shs,
+            hipStream_t render_stream = t_render_streams.empty() ? nullptr : t_render_streams[(size_t)(v0 + k) % t_render_streams.size()];
+            Opts opt = opt0;                                // the bounds of a view travel in its tgs_view_t
+            opt.tile_bound = v.tile_bound > 0 ? v.tile_bound : 0;
+            opt.heavy_bound = v.heavy_bound > 0 ? v.heavy_bound : 0; opt.mid_bound = v.mid_bound > 0 ? v.mid_bound : 0;
+            const int64_t r = forward_impl(opt, (Meta*)v.host_meta, render_stream, nullptr, batched ? 1 : 0, r_capacity, nullptr, alloc_preset, &v, st, P, D, M, v.background, v.width, v.height, means3D, shs,
                                            v.colors_precomp ? v.colors_precomp : colors_precomp,
                                            opacities, scales, scale_modifier, rotations, cov3D_precomp, v.viewmatrix, v.projmatrix, v.campos, v.tan_fovx, v.tan_fovy,
                                            prefiltered, v.out_color, v.radii_out, 0);
@@ -608,16 +689,24 @@ int tgs_forward_views(void* const* streams, int n_streams, int64_t r_capacity, i
     return TGS_OK;
 }
 
+static int backward_render_impl(const Opts& opt, void* stream, int P, int64_t R, const float* background, int width, int height, const void* binning_buffer,
+                                const void* img_buffer, const float* dL_dpix);
+
 int tgs_backward_render_views(void* const* streams, int n_streams, int P, int n_views, const tgs_view_t* views)
+{
+    return tgs_backward_render_views_opt(nullptr, streams, n_streams, P, n_views, views);
+}
+
+int tgs_backward_render_views_opt(const tgs_options_t* o, void* const* streams, int n_streams, int P, int n_views, const tgs_view_t* views)
 {
     if (n_views == 0) return TGS_OK;
     if (!streams || n_streams <= 0 || n_views < 0 || !views) return fail(TGS_ERR_INVALID, "bad arguments");
+    const Opts opt0 = resolve_options(o);
     for (int k = 0; k < n_views; k++) {
         const tgs_view_t& v = views[k];
-        const int64_t old_bound = t_tile_bound;
-        t_tile_bound = v.tile_bound > 0 ? v.tile_bound : 0;
-        const int r = tgs_backward_render(streams[k % n_streams], P, v.R, v.background, v.width, v.height, v.binning_buffer, v.img_buffer, v.dL_dpix);
-        t_tile_bound = old_bound;
+        Opts opt = opt0;
+        opt.tile_bound = v.tile_bound > 0 ? v.tile_bound : 0;
+        const int r = backward_render_impl(opt, streams[k % n_streams], P, v.R, v.background, v.width, v.height, v.binning_buffer, v.img_buffer, v.dL_dpix);
         if (r < 0) return r;
     }
     return TGS_OK;
@@ -625,6 +714,18 @@ int tgs_backward_render_views(void* const* streams, int n_streams, int P, int n_
 
 int tgs_backward_render(void* stream, int P, int64_t R, const float* background, int width, int height, const void* binning_buffer,
                         const void* img_buffer, const float* dL_dpix)
+{
+    return backward_render_impl(resolve_options(nullptr), stream, P, R, background, width, height, binning_buffer, img_buffer, dL_dpix);
+}
+
+int tgs_backward_render_opt(const tgs_options_t* o, void* stream, int P, int64_t R, const float* background, int width, int height, const void* binning_buffer,
+                            const void* img_buffer, const float* dL_dpix)
+{
+    return backward_render_impl(resolve_options(o), stream, P, R, background, width, height, binning_buffer, img_buffer, dL_dpix);
+}
+
+static int backward_render_impl(const Opts& opt, void* stream, int P, int64_t R, const float* background, int width, int height, const void* binning_buffer,
+                                const void* img_buffer, const float* dL_dpix)
 {
     hipStream_t st = (hipStream_t)stream;
     g_err[0] = 0;
@@ -638,7 +739,7 @@ int tgs_backward_render(void* stream, int P, int64_t R, const float* background,
     bin_carve(b, (char*)binning_buffer, (size_t)R);
     if (R > 0) {
         STAGE_BEGIN(TGS_STAGE_RENDER_BWD);
-        launch_render_bwd(st, s, b, width, height, gx, bounded_tiles((size_t)gx * gy), background, dL_dpix, deterministic_mode());
+        launch_render_bwd(st, s, b, width, height, gx, bounded_tiles(opt, (size_t)gx * gy), background, dL_dpix, opt.deterministic);
         STAGE_CHECK("render_bwd", TGS_STAGE_RENDER_BWD);
     }
     return TGS_OK;

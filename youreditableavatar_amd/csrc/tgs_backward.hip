@@ -17,6 +17,14 @@ namespace tgs {
 
 constexpr int NACC = 9;        // colour rgb, mean2D xy, conic xx/xy/yy, opacity
 
+// The per-pixel backward visits the first gridDim.x tiles of tile_order -- all tiles, or the caller's bound on the tiles with instances
+// (tgs_options_t::tile_bound).  A bound below the frame's real count would silently drop the remaining tiles' gradients: the first
+// workgroup raises META_ERR_TILE_BOUND instead (tgs_frame_status then fails; TGS_FRAME_TILE_BOUND).
+__device__ __forceinline__ void check_tile_bound(const ImgState& s)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0 && s.meta->n_nonempty > gridDim.x) atomicOr(&s.meta->error, META_ERR_TILE_BOUND);
+}
+
 __global__ __launch_bounds__(256) void k_render_bwd_det(const ImgState s, const BinState b, int W, int H, uint32_t gx,
                                                     const float* __restrict__ bg, const float* __restrict__ dL_dpix)
 {
@@ -30,6 +38,7 @@ __global__ __launch_bounds__(256) void k_render_bwd_det(const ImgState s, const 
     __shared__ uint32_t wmax[4];
 
     if (frame_rejected(s)) return;
+    check_tile_bound(s);
     const uint4 td = s.tile_desc[blockIdx.x];
     const uint32_t tile = td.x;
     const uint32_t tx = tile % gx, ty = tile / gx;
@@ -221,6 +230,7 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
 
     const uint4 td = s.tile_desc[blockIdx.x];               // (in flight beside the frame's flags)
     if (frame_rejected(s)) return;
+    check_tile_bound(s);
     const uint32_t tile = td.x;
     const uint32_t tx = tile % gx, ty = tile / gx;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;

@@ -28,7 +28,7 @@ struct Meta {                 // lives at the start of the image buffer
     unsigned long long R;     // number of tile instances ("num_rendered")
     uint32_t max_count;       // longest tile list
     uint32_t n_overflow;      // tiles whose list is longer than SORT_LDS_CAP
-    uint32_t error;           // bit0: prefiltered Gaussian culled; bit1 (META_ERR_CAPACITY): frame rejected by tgs_forward_async
+    uint32_t error;           // bit0: prefiltered Gaussian culled; bit1 (META_ERR_CAPACITY): frame rejected by tgs_forward_async; bit2: META_ERR_TILE_BOUND
     uint32_t n_nonempty;      // tiles with at least one instance (they come first in tile_order)
     uint32_t n_heavy;         // tiles with >= 1024 instances (first in tile_order): sorted by 1024-thread workgroups
     uint32_t n_mid;           // tiles with >= 128 instances (heavy ones included); the rest are sorted one wave per tile
@@ -36,6 +36,7 @@ struct Meta {                 // lives at the start of the image buffer
 };
 
 constexpr uint32_t META_ERR_CAPACITY = 2u;
+constexpr uint32_t META_ERR_TILE_BOUND = 4u;   // a per-pixel backward was launched over fewer tiles than hold instances (caller's tile bound too small): TGS_FRAME_TILE_BOUND
 
 struct GeomState {
     // One 64-byte line per Gaussian with everything the per-tile gather needs (geomState.means2D,

@@ -21,19 +21,25 @@ from .. import build as _build
 _LIB_PATH = os.environ.get("TGS_LIBRARY") or _build.LIB       # TGS_LIBRARY: another build of the same ABI (A/B measurements on one box)
 
 
+ABI_VERSION = 2                # TGS_ABI_VERSION of include/tgs_raster.h this binding is written against
+
+
 def _load() -> C.CDLL:
     if "TGS_LIBRARY" not in os.environ:
         try:
             _build.build_native()       # no-op when the library is newer than csrc/*.hip and tgs_raster.h: never run stale kernels
-        except Exception as e:  # loud: no silent fallback
-            if not os.path.exists(_LIB_PATH):
-                raise ImportError(f"libtgs_raster.so is missing and could not be built ({e}); run "
-                                  f"`python -c 'import __graft_entry__ as g; g.build()'` on a ROCm machine") from e
+        except Exception as e:  # loud: no silent fallback -- neither to a CPU path nor to a library older than its sources
+            what = "is older than its sources" if os.path.exists(_LIB_PATH) else "is missing"
+            raise ImportError(f"libtgs_raster.so {what} and could not be rebuilt ({e}); run "
+                              f"`python -c 'import __graft_entry__ as g; g.build()'` on a ROCm machine") from e
     lib = C.CDLL(_LIB_PATH, mode=C.RTLD_GLOBAL)        # the compiled _Cext resolves its tgs_* symbols against this very library
     vp, fl, it = C.c_void_p, C.c_float, C.c_int
     lib.tgs_abi_version.restype = it
-    if lib.tgs_abi_version() != 1:
-        raise ImportError("libtgs_raster.so ABI version mismatch")
+    if lib.tgs_abi_version() != ABI_VERSION:
+        raise ImportError(f"libtgs_raster.so has ABI version {lib.tgs_abi_version()}, this binding needs {ABI_VERSION}: rebuild it "
+                          "(`python -m youreditableavatar_amd.build --force`)")
+    lib.tgs_sizeof_view.restype = C.c_size_t
+    lib.tgs_sizeof_options.restype = C.c_size_t
     lib.tgs_last_error.restype = C.c_char_p
     lib.tgs_forward.restype = C.c_int64
     lib.tgs_forward.argtypes = [vp, vp, vp, it, it, it, vp, it, it, vp, vp, vp, vp, vp, fl, vp, vp, vp, vp, vp, fl, fl, it, vp, vp, it]
@@ -50,12 +56,22 @@ def _load() -> C.CDLL:
     lib.tgs_backward_accumulate.argtypes = lib.tgs_backward.argtypes
     lib.tgs_state_sizes.restype = None
     lib.tgs_state_sizes.argtypes = [it, it, it, it, it, C.c_int64, C.POINTER(C.c_size_t)]
+    lib.tgs_forward_opt.restype = C.c_int64
+    lib.tgs_forward_opt.argtypes = [vp, it, C.c_int64, vp] + lib.tgs_forward.argtypes
+    lib.tgs_backward_opt.restype = it
+    lib.tgs_backward_opt.argtypes = [vp, it] + lib.tgs_backward.argtypes
     lib.tgs_forward_views.restype = it
     lib.tgs_set_render_streams.restype = it
     lib.tgs_set_render_streams.argtypes = [vp, it]
     lib.tgs_forward_views.argtypes = [vp, it, C.c_int64, it, it, it, vp, vp, vp, vp, vp, fl, vp, vp, it, it, vp]
+    lib.tgs_forward_views_opt.restype = it
+    lib.tgs_forward_views_opt.argtypes = [vp] + lib.tgs_forward_views.argtypes
     lib.tgs_backward_render_views.restype = it
     lib.tgs_backward_render_views.argtypes = [vp, it, it, it, vp]
+    lib.tgs_backward_render_views_opt.restype = it
+    lib.tgs_backward_render_views_opt.argtypes = [vp] + lib.tgs_backward_render_views.argtypes
+    lib.tgs_backward_render_opt.restype = it
+    lib.tgs_backward_render_opt.argtypes = [vp, vp, it, C.c_int64, vp, it, it, vp, vp, vp]
     lib.tgs_backward_render.restype = it
     lib.tgs_backward_render.argtypes = [vp, it, C.c_int64, vp, it, it, vp, vp, vp]
     lib.tgs_backward_batch.restype = it
@@ -98,12 +114,12 @@ def _load_ext():
     try:
         _build.build_torch_ext()
     except Exception as e:
-        if not os.path.exists(_build.ext_path()):
-            raise ImportError(f"the compiled _C extension ({_build.EXT_NAME}) is missing and could not be built ({e}); run "
-                              f"`python -c 'import __graft_entry__ as g; g.build()'`") from e
+        what = "is older than its sources" if os.path.exists(_build.ext_path()) else "is missing"
+        raise ImportError(f"the compiled _C extension ({_build.EXT_NAME}) {what} and could not be rebuilt ({e}); run "
+                          f"`python -c 'import __graft_entry__ as g; g.build()'`") from e
     ext = importlib.import_module(__package__ + "." + _build.EXT_NAME)
-    if ext.abi_version() != 1:
-        raise ImportError("compiled _C extension: ABI version mismatch")
+    if ext.abi_version() != ABI_VERSION or ext.compiled_abi_version() != ABI_VERSION:
+        raise ImportError(f"compiled _C extension: ABI version {ext.compiled_abi_version()} (library {ext.abi_version()}), this binding needs {ABI_VERSION}")
     return ext
 
 
@@ -173,6 +189,31 @@ def profile_end():
 _ALLOC_T = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, C.c_size_t)
 
 
+class _OptionsT(C.Structure):
+    """tgs_options_t (include/tgs_raster.h): everything that tunes one call, passed explicitly -- nothing process-wide is touched"""
+    _fields_ = [("struct_size", C.c_uint32), ("instance_pruning", C.c_int32), ("deterministic", C.c_int32), ("forward_group", C.c_int32),
+                ("sort_lds_cap", C.c_uint32), ("tile_bound", C.c_int64), ("heavy_bound", C.c_int64), ("mid_bound", C.c_int64),
+                ("render_split", C.c_int32), ("reserved", C.c_int32)]
+
+
+class _FrameInfoT(C.Structure):
+    """tgs_frame_info_t"""
+    _fields_ = [("num_rendered", C.c_int64), ("nonempty_tiles", C.c_int64), ("flags", C.c_int32), ("reserved", C.c_int32)]
+
+
+def options(tile_bound: int = 0, pruning: Optional[bool] = None, deterministic: Optional[bool] = None, forward_group: int = 0, sort_lds_cap: int = 0,
+            render_split: Optional[bool] = None) -> _OptionsT:
+    """A filled tgs_options_t (None / 0: the library default of that field)."""
+    o = _OptionsT()
+    o.struct_size = C.sizeof(_OptionsT)
+    o.instance_pruning = -1 if pruning is None else int(bool(pruning))
+    o.deterministic = -1 if deterministic is None else int(bool(deterministic))
+    o.forward_group, o.sort_lds_cap = int(forward_group), int(sort_lds_cap)
+    o.tile_bound = max(0, int(tile_bound))
+    o.render_split = -1 if render_split is None else int(bool(render_split))
+    return o
+
+
 def loaded_library() -> str:
     """Path of the native library this process is using (for diagnostics)."""
     return _LIB_PATH
@@ -206,7 +247,8 @@ def _require_gpu(means3D: torch.Tensor) -> torch.device:
 
 def _rasterize_gaussians_ctypes(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                                 viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                                prefiltered, debug, r_capacity: Optional[int] = None, r_guess: Optional[int] = None
+                                prefiltered, debug, r_capacity: Optional[int] = None, r_guess: Optional[int] = None, tile_bound: int = 0,
+                                pruning: Optional[bool] = None, sort_lds_cap: int = 0, info: bool = False
                                 ) -> Tuple[int, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     """RasterizeGaussiansCUDA (rasterize_points.cu:35-115) over ctypes -- kept for A/B measurements of the host cost
     (``TGS_CTYPES_GLUE=1``); the module-level ``rasterize_gaussians`` is the compiled one (csrc/tgs_torch_ext.cpp).
@@ -217,7 +259,8 @@ def _rasterize_gaussians_ctypes(background, means3D, colors, opacity, scales, ro
 
     ``r_guess`` (extension, tgs_forward_speculative): the complete frame like the plain call, but the stages behind the scan are
     enqueued against the guessed instance count while the read-back is in flight (they run again if the guess was too small).
-    Returns a 7-tuple then: the value to pass as ``R`` to the backward / ``state_field`` first, the true num_rendered last."""
+    Returns an 8-tuple then (also with ``info=True``): the value to pass as ``R`` to the backward / ``state_field`` first, the true
+    num_rendered and the number of tiles with instances last.  ``tile_bound`` / ``pruning`` / ``sort_lds_cap``: tgs_options_t fields."""
     if means3D.dim() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     dev = _require_gpu(means3D)
@@ -243,15 +286,13 @@ def _rasterize_gaussians_ctypes(background, means3D, colors, opacity, scales, ro
                 _p(t["sh"]), _p(t["colors"]), _p(t["opac"]), _p(t["scales"]), float(scale_modifier), _p(t["rots"]),
                 _p(t["cov"]), _p(t["view"]), _p(t["proj"]), _p(t["campos"]), float(tan_fovx), float(tan_fovy),
                 int(bool(prefiltered)), out_color.data_ptr(), _p(radii) if P else None, int(bool(debug)))
-        true_R = C.c_int64(0)
-        if r_guess is not None:
-            r = _lib.tgs_forward_speculative(int(r_guess), C.byref(true_R), *args)
-        else:
-            r = _lib.tgs_forward(*args) if r_capacity is None else _lib.tgs_forward_async(int(r_capacity), *args)
+        opt, fi = options(tile_bound=tile_bound, pruning=pruning, sort_lds_cap=sort_lds_cap), _FrameInfoT()
+        mode, rr = (2, int(r_guess)) if r_guess is not None else ((1, int(r_capacity)) if r_capacity is not None else (0, 0))
+        r = _lib.tgs_forward_opt(C.byref(opt), mode, rr, C.byref(fi), *args)
         if r < 0:
             raise _err(int(r))
-    if r_guess is not None:
-        return int(r), out_color, radii, bufs[0], bufs[1], bufs[2], int(true_R.value)
+    if r_guess is not None or info:
+        return int(r), out_color, radii, bufs[0], bufs[1], bufs[2], int(fi.num_rendered), int(fi.nonempty_tiles)
     return int(r), out_color, radii, bufs[0], bufs[1], bufs[2]
 
 
@@ -302,7 +343,8 @@ def frame_status(image_buffer: torch.Tensor) -> Tuple[int, int]:
 
 def _rasterize_gaussians_backward_ctypes(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                          viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos,
-                                         geomBuffer, R, binningBuffer, imageBuffer, debug, _with_conic=False):
+                                         geomBuffer, R, binningBuffer, imageBuffer, debug, _with_conic=False, tile_bound: int = 0,
+                                         deterministic: Optional[bool] = None):
     """RasterizeGaussiansBackwardCUDA (rasterize_points.cu:117-196) over ctypes (see _rasterize_gaussians_ctypes); return order of :195.
     ``_with_conic`` (tests only) appends the scratch tensor dL_dconic[P,2,2]."""
     dev = _require_gpu(means3D)
@@ -324,7 +366,8 @@ def _rasterize_gaussians_backward_ctypes(background, means3D, radii, colors, sca
                 dL_dscales.zero_(); dL_drotations.zero_()
             radii_c = radii.contiguous()
             stream = torch.cuda.current_stream(dev).cuda_stream
-            r = _lib.tgs_backward(stream, P, int(degree), M, int(R), _p(t["bg"]), W, H, _p(t["means"]), _p(t["sh"]), _p(t["colors"]),
+            opt = options(tile_bound=tile_bound, deterministic=deterministic)
+            r = _lib.tgs_backward_opt(C.byref(opt), 0, stream, P, int(degree), M, int(R), _p(t["bg"]), W, H, _p(t["means"]), _p(t["sh"]), _p(t["colors"]),
                                   _p(t["scales"]), float(scale_modifier), _p(t["rots"]), _p(t["cov"]), _p(t["view"]), _p(t["proj"]),
                                   _p(t["campos"]), float(tan_fovx), float(tan_fovy), radii_c.data_ptr(), geomBuffer.data_ptr(),
                                   binningBuffer.data_ptr(), imageBuffer.data_ptr(), _p(t["dL"]), dL_dmeans2D.data_ptr(),
@@ -340,7 +383,8 @@ def _rasterize_gaussians_backward_ctypes(background, means3D, radii, colors, sca
 
 def rasterize_gaussians_backward_accumulate(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                             viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos,
-                                            geomBuffer, R, binningBuffer, imageBuffer, debug, into):
+                                            geomBuffer, R, binningBuffer, imageBuffer, debug, into, tile_bound: int = 0,
+                                            deterministic: Optional[bool] = None):
     """Multi-view extension (tgs_backward_accumulate): parameter gradients are ADDED into the fp32 tensors of ``into``
     (keys: means3D, opacities, and sh|colors_precomp, scales+rotations|cov3D_precomp; contiguous, on the device).
     Returns dL_dmeans2D[P,3], the only per-view gradient."""
@@ -368,8 +412,9 @@ def rasterize_gaussians_backward_accumulate(background, means3D, radii, colors, 
             return g.data_ptr()
 
         has_sh, has_sr = t["sh"] is not None, t["scales"] is not None
-        r = _lib.tgs_backward_accumulate(
-            torch.cuda.current_stream(dev).cuda_stream, P, int(degree), M, int(R), _p(t["bg"]), W, H, _p(t["means"]), _p(t["sh"]), _p(t["colors"]),
+        opt = options(tile_bound=tile_bound, deterministic=deterministic)
+        r = _lib.tgs_backward_opt(
+            C.byref(opt), 1, torch.cuda.current_stream(dev).cuda_stream, P, int(degree), M, int(R), _p(t["bg"]), W, H, _p(t["means"]), _p(t["sh"]), _p(t["colors"]),
             _p(t["scales"]), float(scale_modifier), _p(t["rots"]), _p(t["cov"]), _p(t["view"]), _p(t["proj"]), _p(t["campos"]),
             float(tan_fovx), float(tan_fovy), radii.contiguous().data_ptr(), geomBuffer.data_ptr(), binningBuffer.data_ptr(),
             imageBuffer.data_ptr(), _p(t["dL"]), dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dst("opacities", (P, 1)),
@@ -392,6 +437,9 @@ class _ViewT(C.Structure):
                 ("tile_bound", C.c_int64), ("heavy_bound", C.c_int64), ("mid_bound", C.c_int64), ("host_meta", C.c_void_p)]
 
 
+if _lib.tgs_sizeof_view() != C.sizeof(_ViewT) or _ext.sizeof_view() != C.sizeof(_ViewT) or _lib.tgs_sizeof_options() != C.sizeof(_OptionsT):
+    raise ImportError(f"tgs_view_t / tgs_options_t: the library says {_lib.tgs_sizeof_view()} / {_lib.tgs_sizeof_options()} bytes, this binding declares "
+                      f"{C.sizeof(_ViewT)} / {C.sizeof(_OptionsT)} -- a stale library or binding")
 ViewArray = lambda n: (_ViewT * n)()
 
 
@@ -402,11 +450,12 @@ def state_sizes(P: int, width: int, height: int, has_sh: bool, has_scale_rot: bo
     return int(out[0]), int(out[1]), int(out[2])
 
 
-def forward_views(stream_handles, r_capacity, P, D, M, means3D, shs, opacities, scales, scale_modifier, rotations, views, n_views, prefiltered=False) -> None:
-    """tgs_forward_views on prepared device pointers (ints) and a filled ``ViewArray``."""
+def forward_views(stream_handles, r_capacity, P, D, M, means3D, shs, opacities, scales, scale_modifier, rotations, views, n_views, prefiltered=False,
+                  opt: Optional[_OptionsT] = None) -> None:
+    """tgs_forward_views_opt on prepared device pointers (ints) and a filled ``ViewArray``; ``opt``: ``options(...)`` or None (defaults)."""
     arr = (C.c_void_p * len(stream_handles))(*stream_handles)
-    r = _lib.tgs_forward_views(arr, len(stream_handles), int(r_capacity), int(P), int(D), int(M), means3D, shs, None, opacities, scales,
-                               float(scale_modifier), rotations, None, int(bool(prefiltered)), int(n_views), C.cast(views, C.c_void_p))
+    r = _lib.tgs_forward_views_opt(C.byref(opt) if opt is not None else None, arr, len(stream_handles), int(r_capacity), int(P), int(D), int(M), means3D, shs, None,
+                                   opacities, scales, float(scale_modifier), rotations, None, int(bool(prefiltered)), int(n_views), C.cast(views, C.c_void_p))
     if r < 0:
         raise _err(int(r))
 
@@ -417,9 +466,10 @@ def set_render_streams(stream_handles) -> None:
     _lib.tgs_set_render_streams(arr, len(stream_handles))
 
 
-def backward_render_views(stream_handles, P, views, n_views) -> None:
+def backward_render_views(stream_handles, P, views, n_views, opt: Optional[_OptionsT] = None) -> None:
     arr = (C.c_void_p * len(stream_handles))(*stream_handles)
-    r = _lib.tgs_backward_render_views(arr, len(stream_handles), int(P), int(n_views), views if isinstance(views, C.c_void_p) else C.cast(views, C.c_void_p))
+    r = _lib.tgs_backward_render_views_opt(C.byref(opt) if opt is not None else None, arr, len(stream_handles), int(P), int(n_views),
+                                           views if isinstance(views, C.c_void_p) else C.cast(views, C.c_void_p))
     if r < 0:
         raise _err(int(r))
 
@@ -436,15 +486,17 @@ def backward_batch_raw(stream, P, D, M, views, n_views, means3D, shs, scales, sc
         raise _err(int(r))
 
 
-def rasterize_gaussians_backward_render(background, dL_dout_color, R, binningBuffer, imageBuffer, P) -> None:
+def rasterize_gaussians_backward_render(background, dL_dout_color, R, binningBuffer, imageBuffer, P, tile_bound: int = 0,
+                                        deterministic: Optional[bool] = None) -> None:
     """tgs_backward_render: the per-pixel half of one view's backward; the tile partials stay in ``binningBuffer`` for
     ``rasterize_gaussians_backward_batch``."""
     dev = _require_gpu(dL_dout_color)
     H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
     with torch.cuda.device(dev):
         bg, dL = _dev_f32(background, dev, "background"), _dev_f32(dL_dout_color, dev, "dL_dout_color")
-        r = _lib.tgs_backward_render(torch.cuda.current_stream(dev).cuda_stream, int(P), int(R), _p(bg), W, H, binningBuffer.data_ptr(),
-                                     imageBuffer.data_ptr(), _p(dL))
+        opt = options(tile_bound=tile_bound, deterministic=deterministic)
+        r = _lib.tgs_backward_render_opt(C.byref(opt), torch.cuda.current_stream(dev).cuda_stream, int(P), int(R), _p(bg), W, H, binningBuffer.data_ptr(),
+                                         imageBuffer.data_ptr(), _p(dL))
     if r < 0:
         raise _err(int(r))
 

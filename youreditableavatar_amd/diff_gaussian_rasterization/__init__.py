@@ -111,19 +111,16 @@ class _RasterizeGaussians(torch.autograd.Function):
         key = (int(means3D.shape[0]), int(rs.image_height), int(rs.image_width), means3D.device)
         guess = _speculation.guess(key) if _SPECULATE else None
         tile_guess = 0
+        # (the extension keywords travel to the library as an explicit tgs_options_t: no process- or thread-wide knob is touched)
         if guess is not None:
             # the grids of the stages enqueued ahead of the read-back cover a guessed number of tiles with instances, not all tiles
             tile_guess = _speculation.tile_guess(key)
-            _C.set_tile_bound(tile_guess)
-            try:
-                num_rendered, color, radii, geom, binning, img, true_R = _call_native(
-                    lambda *a: _C.rasterize_gaussians(*a, r_guess=guess), args, rs.debug, "snapshot_fw.dump", "forward")
-            finally:
-                _C.set_tile_bound(0)
+            num_rendered, color, radii, geom, binning, img, true_R, tiles = _call_native(
+                lambda *a: _C.rasterize_gaussians(*a, r_guess=guess, tile_bound=tile_guess), args, rs.debug, "snapshot_fw.dump", "forward")
         else:
-            num_rendered, color, radii, geom, binning, img = _call_native(_C.rasterize_gaussians, args, rs.debug, "snapshot_fw.dump", "forward")
-            true_R = num_rendered
-        tiles = _C.last_nonempty_tiles()                    # of THIS frame (the forward has read its Meta); -1: unknown
+            num_rendered, color, radii, geom, binning, img, true_R, tiles = _call_native(
+                lambda *a: _C.rasterize_gaussians(*a, info=True), args, rs.debug, "snapshot_fw.dump", "forward")
+        # tiles: tiles with instances of THIS frame (the forward has read its Meta); -1: unknown
         if _SPECULATE:
             _speculation.update(key, true_R, guess, tiles, tile_guess)
         ctx.raster_settings = rs
@@ -142,12 +139,9 @@ class _RasterizeGaussians(torch.autograd.Function):
                 rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, sh, rs.sh_degree, rs.campos, geom, ctx.num_rendered,
                 binning, img, rs.debug)
         # the per-pixel backward visits the tiles with instances only: their number is known exactly from the forward's read-back
-        _C.set_tile_bound(ctx.nonempty_tiles if ctx.nonempty_tiles > 0 else 0)
-        try:
-            (g_means2D, g_colors, g_opac, g_means3D, g_cov3D, g_sh, g_scales, g_rots) = _call_native(
-                _C.rasterize_gaussians_backward, args, rs.debug, "snapshot_bw.dump", "backward")
-        finally:
-            _C.set_tile_bound(0)
+        bound = ctx.nonempty_tiles if ctx.nonempty_tiles > 0 else 0
+        (g_means2D, g_colors, g_opac, g_means3D, g_cov3D, g_sh, g_scales, g_rots) = _call_native(
+            lambda *a: _C.rasterize_gaussians_backward(*a, tile_bound=bound), args, rs.debug, "snapshot_bw.dump", "backward")
         # forward-argument order (__init__.py:143-153); all eight are always returned
         return g_means3D, g_means2D, g_sh, g_colors, g_opac, g_scales, g_rots, g_cov3D, None
 

@@ -71,21 +71,43 @@ class FlatGradients:
             off += p.numel()
         return out
 
-    def all_reduce_rows(self, first: int, count: int, group=None):
+    def all_reduce_rows(self, first: int, count: int, group=None, even_alone: bool = False):
         """Asynchronous sum over ranks of the gradients of Gaussians [first, first + count) -- one coalesced collective over the
         parameters' slices (a single RCCL group launch), enqueued behind whatever the current stream holds, so it runs beside the kernels
         that follow (the per-Gaussian pass over the next range, ``SyncFreeBatch.run_views(grad_chunks=..., on_chunk=...)``).  Returns the
-        handles to ``wait()`` on before the gradients are used (empty without a process group)."""
-        if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        handles to ``wait()`` on before the gradients are used (empty without a process group).
+
+        Coalesced or one collective per slice is decided ONCE per backend, before anything is issued and identically on every rank
+        (``_coalesced_all_reduce_supported``): no exception handling around collectives that may already be in flight -- a fallback taken
+        by one rank only, or after a partial issue, would double-sum or unpair them.  ``even_alone``: issue the collectives at world size 1
+        too (tests: the RCCL path on a one-GPU box)."""
+        if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not even_alone):
             return []
         pieces = [t for t in self.row_slices(first, count) if t.numel()]
-        try:
+        if not pieces:
+            return []
+        if _coalesced_all_reduce_supported(group):
             with dist._coalescing_manager(group=group, async_ops=True) as cm:
                 for t in pieces:
                     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
             return [cm]
-        except (AttributeError, RuntimeError, ValueError):      # a backend without coalescing: one collective per slice
-            return [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True) for t in pieces]
+        return [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True) for t in pieces]
+
+
+_COALESCE_DECISION = {}
+
+
+def _coalesced_all_reduce_supported(group=None) -> bool:
+    """One group launch for several tensors (``allreduce_coalesced`` behind torch's coalescing context) exists for device tensors on the
+    ``nccl`` (= RCCL) backend; gloo rejects device tensors there.  A pure function of the backend's name and of the torch build, so every
+    rank decides the same; cached per backend.  ``TGS_COALESCE_ALLREDUCE=0`` forces one collective per slice (same on all ranks: the
+    launcher passes the environment on)."""
+    backend = str(dist.get_backend(group)).lower()
+    hit = _COALESCE_DECISION.get(backend)
+    if hit is None:
+        hit = backend == "nccl" and hasattr(dist, "_coalescing_manager") and os.environ.get("TGS_COALESCE_ALLREDUCE", "1") != "0"
+        _COALESCE_DECISION[backend] = hit
+    return hit
 
 
 def render_batch_sharded(render_view: Callable[[int], torch.Tensor], upstream: Callable[[int, torch.Tensor], torch.Tensor],
@@ -178,7 +200,7 @@ class _RasterizeAccumulate(torch.autograd.Function):
             r_capacity=r_capacity, r_guess=guess)
         num_rendered, color, radii, geom, binning, img = out[:6]
         if dgr._SPECULATE and r_capacity is None:
-            dgr._speculation.update(key, out[6] if guess is not None else num_rendered, guess)
+            dgr._speculation.update(key, out[6] if guess is not None else num_rendered, guess)     # (out[6]: the true count, out[7]: tiles with instances)
         ctx.rs, ctx.num_rendered = rs, num_rendered         # sync-free: the binning capacity (what the buffers are carved for)
         ctx.collector = _collector if (r_capacity is not None and colors_precomp.numel() == 0) else None
         ctx.means2D = means2D
