@@ -34,7 +34,8 @@ VALU_PEAK_GWIPS = 1228.8
 # render loops' mix (6 fma/mul + 1 DPP + 1 transcendental per 8: DPP operations issue at half rate, v_exp_f32 at a quarter)
 VALU_MEASURED_FMA_GWIPS = 955.5
 VALU_MEASURED_MIX_GWIPS = 628.4
-PROFILE_SET = "r02_g"          # profiles/<set>_{hbm,sq}_counters.json: the PMC passes the roofline object quotes (tools/profile_round.sh)
+PROFILE_SET = "r02_g"          # profiles/<set>_{hbm,sq}_counters.json: the PMC passes the roofline object quotes (tools/profile_round.sh); only
+                               # used while their csrc_sha16 equals the hash of the sources this run executes (build.source_hash)
 
 
 def parse():
@@ -303,18 +304,25 @@ def main():
         if dom:
             # Dominant kernel = most time per step.  Its duration is measured LIVE with HIP events on the launch stream, in the one-stream pass
             # above where the kernel has the GPU to itself (in the timed region up to `streams` launches share the GPU and stretch each other:
-            # avg_launch_ms_in_timed_region).  What it is priced against depends on what bounds it: the render kernels are bound by vector
-            # instruction issue (SQ counters), so achieved = wave-instructions per launch / duration against the chip's
-            # VALU issue peak; the HBM figures stay beside it.  Instruction counts and HBM traffic per launch are PMC measurements of the same
-            # workload committed under profiles/ (collected offline: counter passes cannot run inside a timed benchmark).
+            # avg_launch_ms_streams_sharing_the_gpu).  The roofline object is priced against HBM (the path's bounding roofline):
+            # achieved = algorithmic bytes of the launch / that duration.  For the render kernels, which sit far below it because they are bound
+            # by vector-instruction issue and LDS, the object carries `valu_issue` as the explanation: wave-instructions
+            # per launch (a PMC count of the same workload committed under profiles/) / duration against the chip's issue peak.  Counter figures
+            # are quoted only when the committed set was collected on the SAME kernel sources (csrc_sha16): otherwise traffic is null.
             prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-            traffic, valu_insts = None, None
+            traffic, valu_insts, counters_note = None, None, None
             if a.config in (3, 4) and a.mode == "sh":
                 try:
+                    from youreditableavatar_amd.build import source_hash
                     pmc = json.load(open(os.path.join(prof_dir, PROFILE_SET + "_hbm_counters.json")))
-                    traffic = next(v["hbm_bytes_est"] for k, v in pmc["kernels"].items() if k.startswith("tgs::k_" + dom))
                     sq = json.load(open(os.path.join(prof_dir, PROFILE_SET + "_sq_counters.json")))
-                    valu_insts = next(v["SQ_INSTS_VALU"] for k, v in sq["kernels"].items() if k.startswith("tgs::k_" + dom))
+                    if pmc.get("csrc_sha16") == source_hash() == sq.get("csrc_sha16"):
+                        traffic = next(v["hbm_bytes_est"] for k, v in pmc["kernels"].items() if k.startswith("tgs::k_" + dom))
+                        valu_insts = next(v["SQ_INSTS_VALU"] for k, v in sq["kernels"].items() if k.startswith("tgs::k_" + dom))
+                        counters_note = PROFILE_SET + "_{hbm,sq}_counters.json (same kernel sources: csrc_sha16 " + pmc["csrc_sha16"] + ")"
+                    else:
+                        counters_note = (f"profiles/{PROFILE_SET}_*_counters.json were collected on other kernel sources (csrc_sha16 {pmc.get('csrc_sha16')} vs "
+                                         f"{source_hash()}): not quoted")
                 except (OSError, StopIteration, KeyError, ValueError):
                     pass
             Rb = sum(Rb_view[v] for s in range(a.steps) for v in views_of(s)) / frames_rank     # instances the timed path really bins
@@ -322,22 +330,19 @@ def main():
             alg_b["render_fwd"] = 48 * Rb + 20 * Npix
             alg_b["render_bwd"] = (48 + 4 + 48) * Rb + 20 * Npix          # records + quadrant mask + slot in, one 48-B slab row out; pixels in
             t_alone = kern[dom]
-            hbm = {"algorithmic_bytes_per_launch": int(alg_b.get(dom, alg[dom])), "achieved_GBps": round(alg_b.get(dom, alg[dom]) / (t_alone * 1e-3) / 1e9, 2),
-                   "frac_of_8TBps": round(alg_b.get(dom, alg[dom]) / (t_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "instances": int(Rb)}
+            ab = alg_b.get(dom, alg[dom])
+            roof = {"kernel": "k_" + dom, "bound": "hbm", "achieved": round(ab / (t_alone * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ab / (t_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": int(ab), "instances": int(Rb),
+                    "avg_launch_ms": round(t_alone, 4), "duration": "kernel alone on the GPU (one-stream pass of this run, HIP events on the launch stream)",
+                    "avg_launch_ms_streams_sharing_the_gpu": round(dom_timed, 4) if dom_timed else None, "concurrent_streams": batch.streams if batch is not None else 1,
+                    "counters": counters_note}
             if dom in ("render_fwd", "render_bwd") and valu_insts:
                 ach = valu_insts / (t_alone * 1e-3) / 1e9
-                roof = {"kernel": "k_" + dom, "bound": "valu", "achieved": round(ach, 1), "peak": VALU_PEAK_GWIPS, "unit": "G wave-instr/s",
-                        "frac": round(ach / VALU_PEAK_GWIPS, 4), "traffic": traffic,
-                        "avg_launch_ms": round(t_alone, 4), "duration": "kernel alone on the GPU (one-stream pass of this run, HIP events on the launch stream)",
-                        "avg_launch_ms_streams_sharing_the_gpu": round(dom_timed, 4) if dom_timed else None, "concurrent_streams": batch.streams if batch is not None else 1,
-                        "valu_instructions_per_launch": int(valu_insts), "counters": PROFILE_SET + "_sq_counters.json",
-                        "peak_measured_v_fma_f32": VALU_MEASURED_FMA_GWIPS, "peak_measured_render_mix": VALU_MEASURED_MIX_GWIPS,
-                        "frac_of_measured_render_mix": round(ach / VALU_MEASURED_MIX_GWIPS, 4), "hbm": hbm}
-            else:
-                roof = {"kernel": "k_" + dom, "bound": "hbm", "achieved": hbm["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm["frac_of_8TBps"],
-                        "traffic": traffic, "avg_launch_ms": round(t_alone, 4), "duration": "kernel alone on the GPU (one-stream pass of this run, HIP events on the launch stream)",
-                        "avg_launch_ms_streams_sharing_the_gpu": round(dom_timed, 4) if dom_timed else None, "algorithmic_bytes_per_launch": hbm["algorithmic_bytes_per_launch"],
-                        "concurrent_streams": batch.streams if batch is not None else 1}
+                roof["valu_issue"] = {"what": "the bound that applies to this kernel: vector-instruction issue (+ the LDS accumulator), DESIGN.md section 6",
+                                      "achieved": round(ach, 1), "peak": VALU_PEAK_GWIPS, "unit": "G wave-instr/s", "frac": round(ach / VALU_PEAK_GWIPS, 4),
+                                      "valu_instructions_per_launch": int(valu_insts), "peak_measured_v_fma_f32": VALU_MEASURED_FMA_GWIPS,
+                                      "peak_measured_render_mix": VALU_MEASURED_MIX_GWIPS, "frac_of_measured_render_mix": round(ach / VALU_MEASURED_MIX_GWIPS, 4)}
         k_P = (430 + 3 * Cin) if a.mode == "sh" else 412
         B_alg = k_P * P + 124 * Rm + 40 * Npix
         out = {
@@ -363,6 +368,8 @@ def main():
             "kernels_ms": {k: round(v, 4) for k, v in kern.items()},      # each kernel alone on the GPU (one-stream pass before the timed region)
             "frame_algorithmic_bytes": int(B_alg),
             "frame_hbm_frac": round(B_alg / (ms_per_step / VPG * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+            "hbm_frac_of_8TBps": {"frame": round(B_alg / (ms_per_step / VPG * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "dominant_kernel": roof["frac"] if roof else None,
+                                  "what": "algorithmic bytes (SURVEY.md 8d) / time / 8 TB/s: the whole frame in the timed region, and the dominant kernel alone on the GPU"},
             "other_rates": {"Minstances/s": round(R_tot / elapsed / 1e6, 2), "Mpixels/s": round(Npix * frames_rank * N / elapsed / 1e6, 2),
                             "MGaussians/s": round(P * frames_rank * N / elapsed / 1e6, 2), "frames/s": round(frames_rank * N / elapsed, 1)},
         }
@@ -394,7 +401,7 @@ def secondary_workloads(a, cloud, dev, D, W, H, headline_ms):
     from youreditableavatar_amd import scenes
     from youreditableavatar_amd.loss import l1_ssim_loss
     from youreditableavatar_amd.multiview import FlatGradients, SyncFreeBatch
-    from youreditableavatar_amd.sh_color import points_rgb
+    from youreditableavatar_amd.sh_color import points_rgb_dc_rest
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _C
     P = cloud["means3D"].shape[0]
     g = lambda x, rg=False: torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev).requires_grad_(rg)
@@ -437,21 +444,27 @@ def secondary_workloads(a, cloud, dev, D, W, H, headline_ms):
     TW = TH = 2048
     gt = torch.rand(3, TH, TW, device=dev)
     tp = {}
+    # the model's own colour parameters (tetgs_model.py:234-239): _sh_coordinates_dc [P,1,3] and, for models with more than one level,
+    # _sh_coordinates_rest [P,15,3]; the inpainting-stage models have one level and no rest tensor
+    sh_dc = g(cloud["shs"][:, :1], True)
+    sh_rest = g(cloud["shs"][:, 1:], True)
     for deg in (0, 3):
         S2 = settings_for(TW, TH, deg, 16)
+        colour_params = [sh_dc] + ([sh_rest] if deg > 0 else [])
 
-        def train_step(i, S2=S2, deg=deg):
+        def train_step(i, S2=S2, deg=deg, colour_params=colour_params):
             rs = S2[i % len(S2)]
-            for t in leaves.values():
+            for t in list(leaves.values()) + colour_params:
                 t.grad = None
-            colors = points_rgb(leaves["shs"], deg + 1, positions=leaves["means3D"], camera_centers=rs.campos)
+            colors = points_rgb_dc_rest(sh_dc, sh_rest if deg > 0 else None, deg + 1, positions=leaves["means3D"], camera_centers=rs.campos)
             m2 = torch.zeros(P, 3, device=dev, requires_grad=True)
             img, _radii = GaussianRasterizer(rs)(means3D=leaves["means3D"], means2D=m2, opacities=leaves["opacities"], colors_precomp=colors,
                                                  scales=leaves["scales"], rotations=leaves["rotations"])
             l1_ssim_loss(img, gt, 0.2).backward()
         tp[f"sh{deg}"] = round(timed(train_step, 30, 10), 4)
-    res["trainer_protocol"] = {"ms_per_step": tp, "what": f"{P} Gaussians, 2048x2048, one view per step: sh_color.points_rgb -> GaussianRasterizer(colors_precomp) -> "
-                               "l1_ssim_loss -> backward, all through autograd (SH degree 0: the inpainting stage, 16 800 of the reference's ~22 800 rasterizer iterations; 3: refinement)"}
+    res["trainer_protocol"] = {"ms_per_step": tp, "what": f"{P} Gaussians, 2048x2048, one view per step: sh_color.points_rgb_dc_rest (the model's dc / rest parameters, no "
+                               "torch.cat) -> GaussianRasterizer(colors_precomp) -> l1_ssim_loss -> backward, all through autograd (SH degree 0: the inpainting stage, "
+                               "a one-level model, 16 800 of the reference's ~22 800 rasterizer iterations; 3: refinement)"}
     del gt
     # ---- grown splats through the headline path
     gs = {}
@@ -504,7 +517,8 @@ def secondary_workloads(a, cloud, dev, D, W, H, headline_ms):
 
 def cpu_baseline(cloud, cam, dL_np, a):
     """The CPU oracle (C restatement of the reference, OpenMP over tiles) timed on this box's host
-    cores on the SAME workload frame (view 0): a reported baseline, not the target."""
+    cores on the SAME workload frame (view 0): a reported baseline, not the target.  Beside it, BASELINE.json's named baseline: the
+    PyTorch-autograd point-splat (oracle/torch_splat.py, float32) on BASELINE config 1 (10k Gaussians, 256 x 256, SH degree 0)."""
     from oracle import oracle
     mode = a.mode
     t_all = []
@@ -516,9 +530,44 @@ def cpu_baseline(cloud, cam, dL_np, a):
         F = int(st.field("n_contrib").astype(np.int64).sum())
         del st
     t = float(np.median(t_all))
-    return {"value": round(F / t / 1e6, 2), "unit": "Mfrag/s", "cores": oracle.threads(), "kind": "port",
-            "sample": f"{a.cpu_frames} full fwd+bwd frames of view 0 of the same workload (median {t:.2f} s/frame, F={F})",
-            "host_cpus": os.cpu_count()}
+    out = {"value": round(F / t / 1e6, 2), "unit": "Mfrag/s", "cores": oracle.threads(), "kind": "port",
+           "sample": f"{a.cpu_frames} full fwd+bwd frames of view 0 of the same workload (median {t:.2f} s/frame, F={F})",
+           "host_cpus": os.cpu_count()}
+    try:
+        out["torch_point_splat_cfg1"] = torch_point_splat_cfg1()
+    except Exception as ex:          # noqa: BLE001 -- a baseline leg must not take the bench line down
+        out["torch_point_splat_cfg1"] = {"error": repr(ex)[:200]}
+    return out
+
+
+def torch_point_splat_cfg1(frames: int = 6):
+    """north_star's CPU baseline as named: "the reference's CPU fallback (PyTorch autograd point-splat) timed on the host cores" on BASELINE
+    config 1 -- 10 000 random Gaussians, 256 x 256, SH degree 0, white background, one orbit camera, upstream N(0,1)/(3HW) (BASELINE.md
+    section 3).  oracle/torch_splat.py in float32 with torch.set_num_threads(all cores): forward + autograd backward, median of `frames`
+    after one warm-up.  F = sum of n_contrib of that frame."""
+    import torch as th
+    from oracle import torch_splat
+    from youreditableavatar_amd import scenes
+    cfg = scenes.CONFIGS[1]
+    cloud = scenes.config_cloud(1)
+    cam = scenes.orbit_camera(cfg["width"], cfg["height"])
+    dL1 = scenes.upstream_gradient(cfg["width"], cfg["height"], seed=cfg["seed"] + 1000)
+    old = th.get_num_threads()
+    th.set_num_threads(os.cpu_count() or 1)
+    try:
+        ts, F = [], 0
+        for i in range(frames + 1):
+            t0 = time.perf_counter()
+            r = torch_splat.run_scene(cloud, cam, dL1, mode="sh", dtype=th.float32)
+            if i > 0:
+                ts.append(time.perf_counter() - t0)
+            F = int(r["n_contrib"].sum())
+        t = float(np.median(ts))
+        return {"value": round(F / t / 1e6, 3), "unit": "Mfrag/s", "cores": th.get_num_threads(), "kind": "port (PyTorch autograd point-splat, float32)",
+                "sample": f"{frames} fwd+bwd frames of BASELINE config 1 (10k Gaussians, 256x256, SH0), median {t * 1e3:.0f} ms/frame, F={F}",
+                "ms_per_frame": round(t * 1e3, 1)}
+    finally:
+        th.set_num_threads(old)
 
 
 if __name__ == "__main__":

@@ -125,17 +125,20 @@ typedef struct {
     int64_t tile_bound;        /* sync-free / speculative forward and the per-pixel backward: upper bound on the tiles that hold instances
                                   (grids are sized by it; a forward with more is rejected / repeated; a backward with more sets
                                   TGS_FRAME_TILE_BOUND in the frame's flags and returns TGS_ERR_INVALID from tgs_frame_status); 0: none */
-    int64_t heavy_bound, mid_bound;   /* the same for the tile sort's classes (>= 1024 / >= 128 instances); only read with tile_bound */
-    int32_t render_split;      /* experiment: 1 = heavy tiles are composited by several workgroups (k_render_*_split); 0 / -1: default */
+    int64_t heavy_bound, mid_bound;   /* the same for the tiles with >= 1024 / >= 128 instances (classes of the tile sort; the second also sizes the
+                                  1024-thread render kernels' grids when light_tiles is on); only read with tile_bound */
+    int32_t light_tiles;       /* 1: tiles with fewer than 128 instances are composited several per workgroup (four forward, three backward) by the
+                                  last workgroups of the render kernels' grids, the others one per workgroup; 0: one workgroup per tile; -1: default
+                                  (1 in the *_views entry points, 0 in the single-view ones; TGS_LIGHT_TILES overrides both) */
     int32_t reserved;
 } tgs_options_t;
 /* What a forward learned about its frame (filled when non-NULL; the synchronous and the speculative forward read the frame's Meta,
  * the sync-free one cannot: num_rendered / nonempty_tiles are -1 there). */
 typedef struct {
     int64_t num_rendered;      /* true instance count of the frame */
-    int64_t nonempty_tiles;    /* tiles that hold instances: the exact bound for this frame's backward */
+    int64_t nonempty_tiles;    /* tiles that hold instances: the exact tile_bound for this frame's backward */
     int32_t flags;             /* TGS_FRAME_* */
-    int32_t reserved;
+    int32_t mid_tiles;         /* tiles with >= 128 instances: the exact mid_bound for this frame's backward (-1: unknown) */
 } tgs_frame_info_t;
 enum { TGS_FWD_SYNC = 0, TGS_FWD_ASYNC = 1, TGS_FWD_SPECULATIVE = 2 };
 /* tgs_forward (mode TGS_FWD_SYNC; r ignored), tgs_forward_async (TGS_FWD_ASYNC; r = r_capacity) or tgs_forward_speculative
@@ -236,6 +239,17 @@ int tgs_sh_rgb_forward(void* stream, int P, int M, int levels, const float* sh, 
 int tgs_sh_rgb_backward(void* stream, int P, int M, int levels, const float* sh, const float* positions,
                         const float* camera_center, const float* directions, const float* dL_dcolors,
                         float* dL_dsh, float* dL_dpositions, float* dL_ddirections);
+
+/* The same colours from the TWO parameter tensors the reference's models keep -- _sh_coordinates_dc [P,1,3] and _sh_coordinates_rest
+ * [P,M_rest,3] (tetgs_model.py:234-239) -- without the concatenation that the `sh_coordinates` property performs in front of every get_points_rgb call
+ * (:268-272) and the split of its gradient.  Only the levels^2 - 1 active rest rows are read; at levels == 1 (the inpainting stage)
+ * sh_rest / dL_dsh_rest are not touched and may be NULL (the gradient of the rest rows is exactly zero there).  For levels > 1 the backward
+ * writes every element of dL_dsh_dc[P,3] and dL_dsh_rest[P,M_rest,3] (zeros above the active levels). */
+int tgs_sh_rgb_dcrest_forward(void* stream, int P, int M_rest, int levels, const float* sh_dc, const float* sh_rest, const float* positions,
+                              const float* camera_center, const float* directions, float* colors);
+int tgs_sh_rgb_dcrest_backward(void* stream, int P, int M_rest, int levels, const float* sh_dc, const float* sh_rest, const float* positions,
+                               const float* camera_center, const float* directions, const float* dL_dcolors, float* dL_dsh_dc, float* dL_dsh_rest,
+                               float* dL_dpositions, float* dL_ddirections);
 
 /* ---- "next" row 4: simple-knn ----
  * distCUDA2 (Edit_core/thirdparties/simple-knn/spatial.cu:15-26 -> SimpleKNN::knn, simple_knn.cu:185-221):

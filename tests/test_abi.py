@@ -52,7 +52,7 @@ def test_bindings_check_abi_version_and_struct_sizes():
     assert _C._lib.tgs_sizeof_view() == C.sizeof(_C._ViewT) == _C._ext.sizeof_view()
     assert _C._lib.tgs_sizeof_options() == C.sizeof(_C._OptionsT)
     o = _C.options(tile_bound=640, pruning=False, deterministic=True, sort_lds_cap=512)
-    assert (o.struct_size, o.tile_bound, o.instance_pruning, o.deterministic, o.sort_lds_cap, o.render_split) == (C.sizeof(_C._OptionsT), 640, 0, 1, 512, -1)
+    assert (o.struct_size, o.tile_bound, o.instance_pruning, o.deterministic, o.sort_lds_cap, o.light_tiles) == (C.sizeof(_C._OptionsT), 640, 0, 1, 512, -1)
     src = open(os.path.join(ROOT, "youreditableavatar_amd", "diff_gaussian_rasterization", "_C.py")).read()
     assert "could not be rebuilt" in src and "older than its sources" in src        # a failed rebuild of a stale library raises, it is not swallowed
 

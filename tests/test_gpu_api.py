@@ -402,6 +402,59 @@ def test_fused_sh_color_matches_reference(levels, M, gpu_device):
         assert util.rel_l2(dirs.grad.cpu().numpy(), dirs_c.grad.numpy()) <= 1e-5
 
 
+@pytest.mark.parametrize("levels,M", [(1, 1), (1, 16), (2, 4), (2, 16), (3, 9), (3, 16), (4, 16)])
+def test_fused_sh_color_from_dc_and_rest(levels, M, gpu_device):
+    """sh_color.points_rgb_dc_rest (tgs_sh_rgb_dcrest_*): colours straight from the model's two parameters (_sh_coordinates_dc [P,1,3],
+    _sh_coordinates_rest [P,M-1,3]; tetgs_model.py:234-239) -- the same numbers and gradients as the reference's get_points_rgb on their
+    torch.cat (recorded in ref_utils_fixture.npz), with the gradients arriving on the two parameters; at one level the rest parameter is
+    not touched (None gradient where the reference hands out zeros).  M - 1 == levels^2 - 1 takes the block-staged path, M = 16 with
+    fewer levels the row-wise one."""
+    import os
+    from oracle import sh_color_ref
+    from youreditableavatar_amd import sh_color
+    fx = np.load(os.path.join(util.GOLDEN_DIR, "ref_utils_fixture.npz"))
+    sh_np = fx["rgb_sh"][:, :M].copy()
+    t = lambda a, g=True: torch.tensor(np.ascontiguousarray(a), device=gpu_device, requires_grad=g)
+    dc, pos = t(sh_np[:, :1]), t(fx["rgb_pos"])
+    rest = t(sh_np[:, 1:]) if M > 1 else None
+    col = sh_color.points_rgb_dc_rest(dc, rest, levels, positions=pos, camera_centers=t(fx["rgb_cam"], False))
+    col.backward(t(fx["rgb_gcol"], False))
+    want_dsh = fx[f"rgb_dsh_l{levels}"][:, :M]
+    assert util.rel_l2(col.detach().cpu().numpy(), fx[f"rgb_colors_l{levels}"]) <= 1e-6
+    assert util.rel_l2(dc.grad.cpu().numpy(), want_dsh[:, :1]) <= 1e-6
+    if levels == 1:
+        assert rest is None or rest.grad is None                 # exactly zero in the reference: not materialised here
+        assert np.all(want_dsh[:, 1:] == 0)
+        assert torch.all(pos.grad == 0)
+    else:
+        assert util.rel_l2(rest.grad.cpu().numpy(), want_dsh[:, 1:]) <= 1e-6
+        assert np.all(rest.grad.cpu().numpy()[:, levels * levels - 1:] == 0)
+        assert util.rel_l2(pos.grad.cpu().numpy(), fx[f"rgb_dpos_l{levels}"]) <= 1e-5
+    # direction mode, and the same result as the [P,M,3] entry point bit for bit
+    d_np = fx["sh_dirs"][:, :].repeat(4, 0)[:sh_np.shape[0]]
+    dc2, dirs = t(sh_np[:, :1]), t(d_np)
+    rest2 = t(sh_np[:, 1:]) if M > 1 else None
+    cd = sh_color.points_rgb_dc_rest(dc2, rest2, levels, directions=dirs)
+    cd.backward(t(fx["rgb_gcol"], False))
+    shd, dirs_b = t(sh_np), t(d_np)
+    cb = sh_color.points_rgb(shd, levels, directions=dirs_b)
+    cb.backward(t(fx["rgb_gcol"], False))
+    assert torch.equal(cd, cb) and torch.equal(dc2.grad, shd.grad[:, :1])
+    if levels > 1:
+        assert torch.equal(rest2.grad, shd.grad[:, 1:])
+        assert util.rel_l2(dirs.grad.cpu().numpy(), dirs_b.grad.cpu().numpy()) <= 1e-6      # (two kernels: the compiler contracts the polynomials differently)
+    # a point count that is not a multiple of the block or of four floats (direct path of the last block)
+    n = 1001
+    dc3 = t(sh_np[:n, :1]); rest3 = t(sh_np[:n, 1:]) if M > 1 else None
+    c3 = sh_color.points_rgb_dc_rest(dc3, rest3, levels, directions=t(d_np[:n], False))
+    assert torch.equal(c3, cb[:n])
+    with pytest.raises(ValueError):
+        sh_color.points_rgb_dc_rest(dc, rest, levels)
+    if levels > 1:
+        with pytest.raises(ValueError):
+            sh_color.points_rgb_dc_rest(dc, None, levels, directions=dirs)
+
+
 def test_fused_sh_color_feeds_the_rasterizer(gpu_device):
     """The training-step composition: fused SH->RGB -> colors_precomp rasterizer -> gradients reach the SH tensor."""
     from diff_gaussian_rasterization import GaussianRasterizer
@@ -773,7 +826,7 @@ def test_speculative_forward_is_the_complete_frame(gpu_device):
     want = bw(R, radii, geom, binning, img)
     tiles = -1
     for guess in (R + 7000, R, max(R // 10, 1), 0):
-        carve, color2, radii2, geom2, binning2, img2, true_R, tiles = _C.rasterize_gaussians(*args, r_guess=guess)
+        carve, color2, radii2, geom2, binning2, img2, true_R, (tiles, mid_tiles) = _C.rasterize_gaussians(*args, r_guess=guess)
         assert true_R == R and carve == (guess if guess >= R else R), guess
         assert torch.equal(color2, color) and torch.equal(radii2, radii), guess
         assert _C.frame_status(img2) == (R, 0)
@@ -782,19 +835,27 @@ def test_speculative_forward_is_the_complete_frame(gpu_device):
             assert torch.equal(a, b), guess
     # the synchronous forward reports the same frame facts on request
     out = _C.rasterize_gaussians(*args, info=True)
-    assert len(out) == 8 and out[6] == R and out[7] == tiles
+    assert len(out) == 8 and out[6] == R and out[7] == (tiles, mid_tiles) and 0 <= mid_tiles <= tiles
     # The grids of the stages enqueued ahead of the read-back can be sized by a guessed bound on the tiles with instances
     # (tgs_options_t::tile_bound): a fitting bound and one that is far too small (retry with exact sizes) give the same frame, and the
     # backward may visit the frame's exact number of non-empty tiles only.
     assert 8 < tiles <= 77
     for bound in (tiles + 3, tiles, 4):
-        carve, color2, radii2, geom2, binning2, img2, true_R, tiles2 = _C.rasterize_gaussians(*args, r_guess=R + 1000, tile_bound=bound)
-        assert true_R == R and tiles2 == tiles, bound
+        carve, color2, radii2, geom2, binning2, img2, true_R, (tiles2, mid2) = _C.rasterize_gaussians(*args, r_guess=R + 1000, tile_bound=bound)
+        assert true_R == R and tiles2 == tiles and mid2 == mid_tiles, bound
         assert torch.equal(color2, color) and torch.equal(radii2, radii), bound
         assert _C.frame_status(img2) == (R, 0)
         got = bw(carve, radii2, geom2, binning2, img2, tile_bound=tiles)
         for a, b in zip(got, want):
             assert torch.equal(a, b), bound
+        # the default (LDS-atomic) kernels with exact bounds for both tile classes, and with the light-tile kernels switched off: same gradients
+        # up to the in-tile summation order
+        for kw in (dict(tile_bound=tiles, mid_bound=max(mid_tiles, 1)), dict(tile_bound=tiles, light_tiles=False), dict()):
+            got = _C.rasterize_gaussians_backward(args[0], args[1], radii2, e, args[4], args[5], 1.0, e, args[8], args[9], cam.tanfovx, cam.tanfovy, dL, args[14], 3,
+                                                  args[16], geom2, carve, binning2, img2, False, **kw)
+            for a, b in zip(got, want):
+                assert util.rel_l2(a.cpu().numpy(), b.cpu().numpy()) <= 1e-5, (bound, kw)
+        assert _C.frame_status(img2) == (R, 0)
     # a backward with a bound BELOW the frame's tiles with instances would drop gradients silently: the frame's flags say so instead
     bw(carve, radii2, geom2, binning2, img2, tile_bound=tiles - 3)
     with pytest.raises(RuntimeError, match="tile bound"):
@@ -824,7 +885,7 @@ def test_two_threads_with_different_options(gpu_device):
     def run(job, stream=None):
         args, cam, dL = job["scene"]
         with torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.current_stream()):
-            R, color, radii, geom, binning, img, true_R, tiles = _C.rasterize_gaussians(*args, info=True, **job["fw"])
+            R, color, radii, geom, binning, img, true_R, _tiles = _C.rasterize_gaussians(*args, info=True, **job["fw"])
             g = _C.rasterize_gaussians_backward(args[0], args[1], radii, e, args[4], args[5], 1.0, e, args[8], args[9], cam.tanfovx, cam.tanfovy, dL, args[14], 2,
                                                 args[16], geom, R, binning, img, False, **job["bw"])
             n_contrib = _C.state_field("n_contrib", args[1].shape[0], args[13], args[12], R, True, True, geom, binning, img)

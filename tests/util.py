@@ -84,7 +84,7 @@ def scene_input(cloud: dict, cam, mode: str = "sh", cov_mode: str = "scale_rot")
 
 
 def hip_run(inp: dict, dL: Optional[np.ndarray] = None, device="cuda:0", debug=False, introspect=True, pruning: Optional[bool] = None,
-            deterministic: Optional[bool] = None) -> Dict[str, np.ndarray]:
+            deterministic: Optional[bool] = None, light_tiles: Optional[bool] = None) -> Dict[str, np.ndarray]:
     """The HIP path through the reference's ``_C`` surface (the compiled module over the C ABI of include/tgs_raster.h).  ``pruning`` /
     ``deterministic``: explicit per-call options (tgs_options_t); None = the library defaults."""
     import torch
@@ -96,7 +96,7 @@ def hip_run(inp: dict, dL: Optional[np.ndarray] = None, device="cuda:0", debug=F
     H, W, D = int(inp["image_height"]), int(inp["image_width"]), int(inp["sh_degree"])
     sm, tfx, tfy = float(inp.get("scale_modifier", 1.0)), float(inp["tanfovx"]), float(inp["tanfovy"])
     R, color, radii, geom, binning, img = _C.rasterize_gaussians(bg, means3D, colors, opac, scales, rots, sm, cov, view, proj,
-                                                                 tfx, tfy, H, W, sh, D, campos, False, debug, pruning=pruning)
+                                                                 tfx, tfy, H, W, sh, D, campos, False, debug, pruning=pruning, light_tiles=light_tiles)
     P = means3D.shape[0]
     out = dict(color=color.cpu().numpy(), radii=radii.cpu().numpy(), num_rendered=R)
     has_sh, has_sr = inp.get("shs") is not None, inp.get("scales") is not None
@@ -116,7 +116,7 @@ def hip_run(inp: dict, dL: Optional[np.ndarray] = None, device="cuda:0", debug=F
     if dL is not None:
         g = _C.rasterize_gaussians_backward(bg, means3D, radii, colors, scales, rots, sm, cov, view, proj, tfx, tfy,
                                             torch.from_numpy(np.ascontiguousarray(dL, np.float32)).to(dev), sh, D, campos, geom, R, binning, img, debug,
-                                            _with_conic=True, deterministic=deterministic)
+                                            _with_conic=True, deterministic=deterministic, light_tiles=light_tiles)
         names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations", "dL_dconic")
         out.update({n: v.cpu().numpy() for n, v in zip(names, g)})
     torch.cuda.synchronize()

@@ -22,14 +22,43 @@ def load(d, counter):
     return {k: sum(v) / len(v) for k, v in agg.items()}
 
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from youreditableavatar_amd.build import source_hash
+SRC = source_hash()           # bench.py quotes these counters only while the kernel sources still hash to this
+
+# Per-kernel FETCH_SIZE calibration (round 3; round 2 doubled every kernel's FETCH): the dominant READ pattern of each kernel, and the factor
+# tools/microbench/fetch_calibration.hip measured for that pattern on this chip (profiles/<name>_fetch_calibration.json when the round has
+# one, else the guide's 2.0 for 16-B-per-lane streams and 1.0 for everything else -- stated per kernel in the output).
+READ_PATTERN = {
+    "k_preprocess_fwd": "k_stream16", "k_preprocess_fwd_pair": "k_stream16", "k_preprocess_fwd_batch": "k_stream16",   # SH rows, 16 B per lane
+    "k_preprocess_bwd": "k_gather48", "k_preprocess_bwd_batch": "k_gather48", "k_preprocess_bwd_batch_split": "k_gather48",   # slab rows + SH rows
+    "k_render_fwd": "k_stream16", "k_render_bwd": "k_stream16", "k_render_bwd_det": "k_stream16",                    # records, 16 B per lane
+    "k_finalize": "k_gather64", "k_tile_sort": "k_stream8", "k_scatter": "k_stream4", "k_bin_count": "k_stream4", "k_bin_colscan": "k_stream4",
+    "k_scan": "k_stream4", "k_fill_empty": "k_stream4", "k_ssim_stats": "k_stream4", "k_ssim_grad": "k_stream4", "k_sh_rgb": "k_stream16",
+}
+cal_path = f"{P}/{name}_fetch_calibration.json"
+cal = json.load(open(cal_path))["patterns"] if os.path.exists(cal_path) else None
+DEFAULT_FACTOR = {"k_stream16": 2.0}
+
+
+def fetch_factor(kernel):
+    base = kernel.split("::")[-1].split("<")[0]
+    pat = READ_PATTERN.get(base, "k_stream4")
+    if cal and pat in cal and "fetch_factor" in cal[pat]:
+        return pat, float(cal[pat]["fetch_factor"]), os.path.basename(cal_path)
+    return pat, DEFAULT_FACTOR.get(pat, 1.0), "MI355X_MICROARCH.md (2.0 for 16-B-per-lane streams, uncalibrated 1.0 otherwise)"
+
+
 f, w = load("pmc_fetch", "FETCH_SIZE"), load("pmc_write", "WRITE_SIZE")
 out = {"note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over tools/pmc_workload.py (4 frames forward+backward, cfg3: 500k Gaussians, "
-               "1080p, SH3, fused accumulation through the one-view kernels, one stream; " + what + "); KB per launch as reported. FETCH_SIZE under-reports 16-B-per-lane "
-               "streaming reads by 2x on gfx950 (MI355X_MICROARCH.md, HBM section): hbm_bytes_est = 2*FETCH + WRITE.", "kernels": {}}
+               "1080p, SH3, fused accumulation through the one-view kernels, one stream; " + what + "); KB per launch as reported.  hbm_bytes_est = fetch_factor * FETCH + WRITE "
+               "with the factor of the kernel's dominant read pattern (read_pattern, calibration source stated per kernel).", "csrc_sha16": SRC, "kernels": {}}
 for k in sorted(set(f) | set(w)):
     if "tgs" in k:
+        pat, fac, src = fetch_factor(k)
         out["kernels"][k] = {"FETCH_SIZE_KB_per_launch": round(f.get(k, 0.0), 1), "WRITE_SIZE_KB_per_launch": round(w.get(k, 0.0), 1),
-                             "hbm_bytes_est": int((2 * f.get(k, 0.0) + w.get(k, 0.0)) * 1024)}
+                             "read_pattern": pat, "fetch_factor": fac, "calibration": src,
+                             "hbm_bytes_est": int((fac * f.get(k, 0.0) + w.get(k, 0.0)) * 1024)}
 json.dump(out, open(f"{P}/{name}_hbm_counters.json", "w"), indent=1)
 
 # SQ passes: per kernel, per launch averages + the launch duration seen in the same pass (dispatch timestamps of the counter CSV)
@@ -37,7 +66,7 @@ sq = {"note": "rocprofv3 --kernel-trace --pmc <8 SQ counters> (two passes: pmc_s
               "one-view kernels, one stream: every kernel alone on the GPU; " + what + "). Per launch averages. SQ_INSTS_* count wave-instructions; SQ_WAVE_CYCLES / "
               "SQ_WAIT_* / SQ_ACTIVE_INST_* / SQ_BUSY_CYCLES count quad-cycles (4 shader cycles) summed over waves (MI355X_MICROARCH.md, cycle constants). "
               "us_in_pass = average dispatch duration inside the counter pass (profiled passes run at a lower clock). valu_rate_G_per_s = SQ_INSTS_VALU / duration.",
-      "kernels": {}}
+      "csrc_sha16": SRC, "kernels": {}}
 for d in ("pmc_sq", "pmc_sq2", "pmc_sq3"):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     dur = collections.defaultdict(dict)

@@ -37,6 +37,18 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+def source_hash() -> str:
+    """sha256 (first 16 hex digits) over the kernel / ABI sources: profiles/*_counters.json carry it, and bench.py only quotes counter figures
+    (instructions, HBM traffic per launch) whose hash equals the sources it is running."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".cpp"))) 
+    for f in files:
+        h.update(f.encode()); h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(open(os.path.join(HERE, "..", "include", "tgs_raster.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
 class _BuildLock:
     """Serialises builds between processes (the ranks of one launch import the package at the same moment): flock on a file next to the
     outputs; whoever gets it second finds everything fresh."""

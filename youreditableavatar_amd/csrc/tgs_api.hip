@@ -17,10 +17,10 @@ void launch_scatter(hipStream_t, int P, const GeomState&, const ImgState&, const
 void launch_tile_sort(hipStream_t, const GeomState&, const ImgState&, const BinState&, uint32_t gx, uint32_t T, uint64_t r_bound, const Meta* m,
                       uint32_t sort_cap, uint32_t tile_bound, uint32_t heavy_bound, uint32_t mid_bound);
 void launch_render_fwd(hipStream_t, const ImgState&, const BinState&, int W, int H, uint32_t gx, uint32_t T, const Meta* m, const float* bg,
-                       float* out_color, uint32_t tile_bound);
+                       float* out_color, uint32_t tile_bound, uint32_t mid_bound, int light);
 void launch_mark_visible(hipStream_t, int P, const float* means3D, const float* view, uint8_t* present);
 void launch_render_bwd(hipStream_t, const ImgState&, const BinState&, int W, int H, uint32_t gx, uint32_t tiles, const float* bg, const float* dL_dpix,
-                       bool deterministic);
+                       bool deterministic, uint32_t mid_tiles, int light, uint32_t T);
 void launch_preprocess_bwd(hipStream_t, const BwdIn&, const CamParams&, const GeomState&, const BinState&);
 void launch_preprocess_bwd_batch(hipStream_t, const BwdIn&, const BatchViews&);
 void launch_selftest_reduce36(hipStream_t, const float* in, float* out);
@@ -37,8 +37,8 @@ static std::atomic<int> g_deterministic{-1};
 static std::atomic<uint32_t> g_sort_cap{SORT_LDS_CAP};
 static std::atomic<int> g_fwd_group{2};
 static std::atomic<int> g_prune{1};
-#ifndef TGS_RENDER_SPLIT_DEFAULT
-#define TGS_RENDER_SPLIT_DEFAULT 0
+#ifndef TGS_LIGHT_TILES_DEFAULT
+#define TGS_LIGHT_TILES_DEFAULT 1
 #endif
 static bool deterministic_mode()
 {
@@ -56,10 +56,12 @@ struct Opts {
     int fwd_group;
     uint32_t sort_cap;
     int64_t tile_bound, heavy_bound, mid_bound;
-    int render_split;
+    int light;
 };
 static thread_local int64_t t_tile_bound = 0;               // tgs_set_tile_bound (test-only shim): default tile bound of this thread's calls without options
-static Opts resolve_options(const tgs_options_t* o)
+// batch: the *_views entry points (several views in flight on several streams), where the light groups pay: +4 % on the 8-view step of
+// config 3 (2.16 -> 2.07 ms), while a view that has the GPU to itself loses 1-2 % (its kernels end with the light groups' ~10-us tail)
+static Opts resolve_options(const tgs_options_t* o, bool batch = false)
 {
     Opts r;
     r.prune = g_prune.load(std::memory_order_relaxed);
@@ -67,8 +69,8 @@ static Opts resolve_options(const tgs_options_t* o)
     r.fwd_group = g_fwd_group.load(std::memory_order_relaxed);
     r.sort_cap = g_sort_cap.load(std::memory_order_relaxed);
     r.tile_bound = t_tile_bound; r.heavy_bound = 0; r.mid_bound = 0;
-    static const int env_split = [] { const char* e = getenv("TGS_RENDER_SPLIT"); return e ? atoi(e) : -1; }();     // tuning knob, read once
-    r.render_split = env_split >= 0 ? env_split : TGS_RENDER_SPLIT_DEFAULT;
+    static const int env_light = [] { const char* e = getenv("TGS_LIGHT_TILES"); return e ? atoi(e) : -1; }();     // A/B knob, read once
+    r.light = env_light >= 0 ? (env_light ? 1 : 0) : (batch ? TGS_LIGHT_TILES_DEFAULT : 0);
     if (!o) return r;
     const size_t n = o->struct_size;
 #define TGS_HAS(f) (n >= offsetof(tgs_options_t, f) + sizeof(o->f))
@@ -79,7 +81,7 @@ static Opts resolve_options(const tgs_options_t* o)
     if (TGS_HAS(tile_bound)) r.tile_bound = o->tile_bound > 0 ? o->tile_bound : 0;      // (explicit options: 0 really means none)
     if (TGS_HAS(heavy_bound) && o->heavy_bound > 0) r.heavy_bound = o->heavy_bound;
     if (TGS_HAS(mid_bound) && o->mid_bound > 0) r.mid_bound = o->mid_bound;
-    if (TGS_HAS(render_split) && o->render_split >= 0) r.render_split = o->render_split;
+    if (TGS_HAS(light_tiles) && o->light_tiles >= 0) r.light = o->light_tiles ? 1 : 0;
 #undef TGS_HAS
     return r;
 }
@@ -256,6 +258,12 @@ static SpecSlot* spec_slot()
 static thread_local std::vector<hipStream_t> t_render_streams;
 static thread_local int64_t t_last_nonempty = -1;           // tgs_last_nonempty_tiles (legacy read-out; tgs_frame_info_t carries it explicitly)
 static uint32_t bounded_tiles(const Opts& o, size_t T) { return (o.tile_bound > 0 && (uint64_t)o.tile_bound < (uint64_t)T) ? (uint32_t)o.tile_bound : (uint32_t)T; }
+// bound on the tiles with >= LIGHT_MAX instances (the 1024-thread render kernel's grid): the caller's mid_bound, else the tile bound
+static uint32_t bounded_mid(const Opts& o, size_t T)
+{
+    const uint32_t tb = bounded_tiles(o, T);
+    return (o.tile_bound > 0 && o.mid_bound > 0 && (uint64_t)o.mid_bound < tb) ? (uint32_t)o.mid_bound : tb;
+}
 
 static int64_t forward_impl(const Opts& opt, Meta* host_meta, hipStream_t render_stream, tgs_frame_info_t* info, int preprocessed, int64_t r_capacity, int64_t* speculative_true_R, tgs_alloc_fn alloc, void* alloc_ctx, void* stream, int P, int D, int M, const float* background, int width,
                     int height, const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
@@ -265,7 +273,7 @@ static int64_t forward_impl(const Opts& opt, Meta* host_meta, hipStream_t render
 {
     const bool async = r_capacity >= 0;
     t_last_nonempty = -1;                                   // (known again once this call has read the frame's Meta)
-    if (info) { info->num_rendered = -1; info->nonempty_tiles = -1; info->flags = 0; info->reserved = 0; }
+    if (info) { info->num_rendered = -1; info->nonempty_tiles = -1; info->flags = 0; info->mid_tiles = -1; }
     if (r_capacity > 0x7fffffffll) return fail(TGS_ERR_INVALID, "r_capacity exceeds 2^31-1");
     hipStream_t st = (hipStream_t)stream;
     g_err[0] = 0;
@@ -275,7 +283,7 @@ static int64_t forward_impl(const Opts& opt, Meta* host_meta, hipStream_t render
         if (!out_color) return fail(TGS_ERR_INVALID, "NULL required pointer");
         HIP_TRY(hipMemsetAsync(out_color, 0, 3 * (size_t)width * height * sizeof(float), st));
         if (host_meta) memset(host_meta, 0, sizeof(Meta));   // (pinned host memory: no kernel of this frame writes it)
-        if (info && !(async && !speculative_true_R)) { info->num_rendered = 0; info->nonempty_tiles = 0; }
+        if (info && !(async && !speculative_true_R)) { info->num_rendered = 0; info->nonempty_tiles = 0; info->mid_tiles = 0; }
         if (async) {   // the caller still gets a (zeroed) Meta to query
             ImgState s0;
             const size_t bytes = img_carve(s0, nullptr, (size_t)width * height, (size_t)((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE));
@@ -353,7 +361,7 @@ static int64_t forward_impl(const Opts& opt, Meta* host_meta, hipStream_t render
         R = meta.R;
         if (R > 0x7fffffffull) return fail(TGS_ERR_TOO_MANY, "%llu tile instances exceed 2^31-1", (unsigned long long)R);
         t_last_nonempty = (int64_t)meta.n_nonempty;
-        if (info) { info->num_rendered = (int64_t)meta.R; info->nonempty_tiles = (int64_t)meta.n_nonempty; info->flags = (int32_t)meta.error; }
+        if (info) { info->num_rendered = (int64_t)meta.R; info->nonempty_tiles = (int64_t)meta.n_nonempty; info->flags = (int32_t)meta.error; info->mid_tiles = (int32_t)meta.n_mid; }
     } else {
         R = (uint64_t)r_capacity;
     }
@@ -381,7 +389,7 @@ static int64_t forward_impl(const Opts& opt, Meta* host_meta, hipStream_t render
         rst = render_stream;
     }
     STAGE_BEGIN(TGS_STAGE_RENDER_FWD);
-    launch_render_fwd(rst, s, b, width, height, cam.gx, (uint32_t)T, known, background, out_color, tb);
+    launch_render_fwd(rst, s, b, width, height, cam.gx, (uint32_t)T, known, background, out_color, tb, mb, opt.light);
     STAGE_CHECK("render", TGS_STAGE_RENDER_FWD);
     if (spec) {
         HIP_TRY(hipEventSynchronize(spec->ready));
@@ -390,7 +398,7 @@ static int64_t forward_impl(const Opts& opt, Meta* host_meta, hipStream_t render
         if (meta.R > 0x7fffffffull) return fail(TGS_ERR_TOO_MANY, "%llu tile instances exceed 2^31-1", (unsigned long long)meta.R);
         *speculative_true_R = (int64_t)meta.R;
         t_last_nonempty = (int64_t)meta.n_nonempty;
-        if (info) { info->num_rendered = (int64_t)meta.R; info->nonempty_tiles = (int64_t)meta.n_nonempty; info->flags = (int32_t)(meta.error & ~META_ERR_CAPACITY); }
+        if (info) { info->num_rendered = (int64_t)meta.R; info->nonempty_tiles = (int64_t)meta.n_nonempty; info->flags = (int32_t)(meta.error & ~META_ERR_CAPACITY); info->mid_tiles = (int32_t)meta.n_mid; }
         if ((meta.error & META_ERR_CAPACITY) || meta.pad[0] != 0u) {     // (pad[0]: more tiles with instances than the caller's bound, k_scan)
             // the guess was too small: every kernel behind the scan returned at
             // once; clear the flag and run those stages again with the exact sizes, as tgs_forward does
@@ -404,7 +412,7 @@ static int64_t forward_impl(const Opts& opt, Meta* host_meta, hipStream_t render
                 launch_scatter(st, P, g, s, b, cam.gx, (uint32_t)T);
                 launch_tile_sort(st, g, s, b, cam.gx, (uint32_t)T, R, &meta, sort_cap, (uint32_t)T, (uint32_t)T, (uint32_t)T);
             }
-            launch_render_fwd(st, s, b, width, height, cam.gx, (uint32_t)T, &meta, background, out_color, (uint32_t)T);
+            launch_render_fwd(st, s, b, width, height, cam.gx, (uint32_t)T, &meta, background, out_color, (uint32_t)T, (uint32_t)T, opt.light);
             HIP_TRY(hipGetLastError());
         }
     }
@@ -516,7 +524,7 @@ static int backward_impl(const Opts& opt, int accumulate, void* stream, int P, i
 
     if (R > 0) {
         STAGE_BEGIN(TGS_STAGE_RENDER_BWD);
-        launch_render_bwd(st, s, b, width, height, cam.gx, bounded_tiles(opt, T), background, dL_dpix, opt.deterministic);
+        launch_render_bwd(st, s, b, width, height, cam.gx, bounded_tiles(opt, T), background, dL_dpix, opt.deterministic, bounded_mid(opt, T), opt.light, (uint32_t)T);
         STAGE_CHECK("render_bwd", TGS_STAGE_RENDER_BWD);
     }
     STAGE_BEGIN(TGS_STAGE_PREPROCESS_BWD);
@@ -605,7 +613,7 @@ int tgs_forward_views_opt(const tgs_options_t* o, void* const* streams, int n_st
                           const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier, const float* rotations,
                           const float* cov3D_precomp, int prefiltered, int n_views, tgs_view_t* views)
 {
-    const Opts opt0 = resolve_options(o);
+    const Opts opt0 = resolve_options(o, true);
     g_err[0] = 0;
     if (n_views == 0) return TGS_OK;
     if (!streams || n_streams <= 0 || n_views < 0 || !views || r_capacity < 0) return fail(TGS_ERR_INVALID, "bad arguments");
@@ -701,11 +709,12 @@ int tgs_backward_render_views_opt(const tgs_options_t* o, void* const* streams, 
 {
     if (n_views == 0) return TGS_OK;
     if (!streams || n_streams <= 0 || n_views < 0 || !views) return fail(TGS_ERR_INVALID, "bad arguments");
-    const Opts opt0 = resolve_options(o);
+    const Opts opt0 = resolve_options(o, true);
     for (int k = 0; k < n_views; k++) {
         const tgs_view_t& v = views[k];
         Opts opt = opt0;
         opt.tile_bound = v.tile_bound > 0 ? v.tile_bound : 0;
+        opt.mid_bound = v.mid_bound > 0 ? v.mid_bound : 0;
         const int r = backward_render_impl(opt, streams[k % n_streams], P, v.R, v.background, v.width, v.height, v.binning_buffer, v.img_buffer, v.dL_dpix);
         if (r < 0) return r;
     }
@@ -739,7 +748,7 @@ static int backward_render_impl(const Opts& opt, void* stream, int P, int64_t R,
     bin_carve(b, (char*)binning_buffer, (size_t)R);
     if (R > 0) {
         STAGE_BEGIN(TGS_STAGE_RENDER_BWD);
-        launch_render_bwd(st, s, b, width, height, gx, bounded_tiles(opt, (size_t)gx * gy), background, dL_dpix, opt.deterministic);
+        launch_render_bwd(st, s, b, width, height, gx, bounded_tiles(opt, (size_t)gx * gy), background, dL_dpix, opt.deterministic, bounded_mid(opt, (size_t)gx * gy), opt.light, gx * gy);
         STAGE_CHECK("render_bwd", TGS_STAGE_RENDER_BWD);
     }
     return TGS_OK;

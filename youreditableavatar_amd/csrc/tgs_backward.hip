@@ -215,8 +215,146 @@ constexpr int BWD_THREADS = 1024;
 constexpr int BCH = TGS_BCH;               // list entries per round
 constexpr int BNULL = BCH;
 
+// ---------------------------------------------------------------------------------------------
+// Light groups of k_render_bwd: THREE light tiles (fewer than LIGHT_MAX instances, one round) per workgroup -- the staging arrays hold
+// BCH = 384 = 3 x 128 entries --, tile q on waves 4q .. 4q+3 (waves 12..15 only meet the barriers), wave w of a tile walking its blocks
+// 4w .. 4w+3 one after the other (fwd_light_group is the forward's counterpart: why, there).  Same arithmetic per (pixel, entry) pair, same f64
+// LDS accumulator and flush as the heavy path; the pixel inputs of a wave's four blocks are fetched up front.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bwd_light_group(const ImgState& s, const BinState& b, int W, int H, uint32_t gx, const float* __restrict__ bg,
+                                                const float* __restrict__ dL_dpix, uint4 td, bool active, float4* sA, float4* sB, float* sC, uint32_t* sSlot,
+                                                double (*acc)[BCH + 1], uint2* sQ, unsigned short (*lists)[BCH + 8], unsigned short (*qlists)[4][QL_ROW])
+{
+    const int sub = threadIdx.x >> 8, lt = threadIdx.x & 255;
+    const int wv = threadIdx.x >> 6, w4 = wv & 3, lane = threadIdx.x & 63;
+    const int qd = lane >> 4, pq = (lane >> 2) & 3, e = lane & 3;
+    const uint32_t base = (uint32_t)LIGHT_MAX * (sub < BWD_LIGHT_PER_WG ? sub : 0);
+    const uint32_t tile = td.x, n = active ? td.z - td.y : 0u;
+    const uint32_t tx = tile % gx, ty = tile / gx;
+    stamp_if(s, tile, 2, active && lt == 0);
+    const size_t N = (size_t)W * H;
+    const uint32_t qmax = active ? min(s.tile_qmax[tile], n) : 0u;     // deepest position any pixel of the tile blended (fwd_light_group)
+    // pixel inputs of this wave's four blocks (5 loads each, all in flight together)
+    float Tf[4], d0[4], d1[4], d2[4];
+    uint32_t lc[4];
+#pragma unroll
+    for (int bi = 0; bi < 4; bi++) {
+        const int blk = 4 * w4 + bi;
+        const int px = tx * TILE + (blk & 3) * 4 + (qd & 1) * 2 + (pq & 1);
+        const int py = ty * TILE + (blk >> 2) * 4 + (qd >> 1) * 2 + (pq >> 1);
+        const bool inside = active && px < W && py < H;
+        const size_t pix_id = (size_t)W * py + px;
+        Tf[bi] = inside ? s.final_T[pix_id] : 0.f;
+        lc[bi] = inside ? s.n_contrib[pix_id] : 0u;
+        d0[bi] = inside ? dL_dpix[pix_id] : 0.f; d1[bi] = inside ? dL_dpix[N + pix_id] : 0.f; d2[bi] = inside ? dL_dpix[2 * N + pix_id] : 0.f;
+    }
+    // rows of the never-visited tail are zero
+    for (uint32_t q = qmax + lt; q < n; q += 256) {
+        float4* row = b.slab + (size_t)b.slot[td.y + q] * SLAB_ROW;
+        row[0] = make_float4(0.f, 0.f, 0.f, 0.f); row[1] = make_float4(0.f, 0.f, 0.f, 0.f); row[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    {   // stage back to front: slot t = list position qmax-1-t.  Thread t < 128 of the quarter: recA + quadrant mask, thread 128 + t: recB + recC + slot
+        const uint32_t ht = lt & (LIGHT_MAX - 1);
+        const bool upper = lt >= LIGHT_MAX;
+        if (ht < qmax) {
+            const uint32_t pos = td.y + qmax - 1 - ht;
+            if (!upper) { float4 r4 = b.recA[pos]; const uint2 q = b.qmask[pos]; stage_conic_a(r4); sA[base + ht] = r4; sQ[base + ht] = q; }
+            else { float4 r4 = b.recB[pos]; const float c = b.recC[pos].x; const uint32_t sl = b.slot[pos]; stage_conic_b(r4); sB[base + ht] = r4; sC[base + ht] = c; sSlot[base + ht] = sl; }
+        }
+        for (uint32_t i = threadIdx.x; i < NACC * (BCH + 1); i += BWD_THREADS) (&acc[0][0])[i] = 0.0;
+    }
+    __syncthreads();                                        // (the null record was written in front of the kernel's first barrier)
+    float vone = 1.0f, vzero = 0.0f;
+    asm volatile("" : "+v"(vone), "+v"(vzero));
+    const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);   // backward.cu:460-461
+    const float bgr = bg[0], bgg = bg[1], bgb = bg[2];
+    const unsigned short* myq = &qlists[wv][qd][e];
+    const uint32_t null_local = (uint32_t)BNULL - base;
+    if (qmax > 0) {
+#pragma unroll
+    for (int bi = 0; bi < 4; bi++) {
+        const int blk = 4 * w4 + bi;
+        const int px = tx * TILE + (blk & 3) * 4 + (qd & 1) * 2 + (pq & 1);
+        const int py = ty * TILE + (blk >> 2) * 4 + (qd >> 1) * 2 + (pq >> 1);
+        const float pixfx = (float)px, pixfy = (float)py;
+        const float T_final = Tf[bi], dpx0 = d0[bi], dpx1 = d1[bi], dpx2 = d2[bi];
+        const uint32_t last_contributor = lc[bi];
+        float T = T_final;
+        float bg_dot_dpixel = 0.f;                          // backward.cu:533-535
+        bg_dot_dpixel += bgr * dpx0; bg_dot_dpixel += bgg * dpx1; bg_dot_dpixel += bgb * dpx2;
+        const float tfinal_bg = T_final * bg_dot_dpixel;
+        float arA = 0.f;
+        uint32_t qlast[4];
+        {
+            uint32_t m = last_contributor;
+            m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x124, 0xf, 0xf, false));     // row_ror:4
+            m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x128, 0xf, 0xf, false));     // row_ror:8
+#pragma unroll
+            for (int q = 0; q < 4; q++) qlast[q] = (uint32_t)__builtin_amdgcn_readlane((int)m, 16 * q);
+        }
+        if ((qlast[0] | qlast[1] | qlast[2] | qlast[3]) == 0u) continue;     // nothing was blended into this block
+        const uint32_t nl = build_own_list_q<LIGHT_MAX>(lists[wv], sQ + base, qmax, blk, lane);
+#pragma unroll 1
+        for (uint32_t c0 = 0; c0 < nl; c0 += QCH) {
+            const uint32_t nq = build_chunk_quadrant_lists<TGS_BWD_BOUNDED>(qlists[wv], lists[wv], c0, nl, lane, (int)null_local, qmax - 1, qlast);
+#pragma unroll 1
+            for (uint32_t k = 0; k < nq; k += 4) {          // the pass of the heavy path (backward.cu:507-555 per pair: see there)
+                const uint32_t jl = myq[k], j = jl + base;
+                const float4 a = sA[j];
+                const float4 bb = sB[j];
+                const float c0_ = bb.z, c1_ = bb.w, c2_ = sC[j];
+                const float dx = a.x - pixfx, dy = a.y - pixfy;
+                const float power2 = (a.z * dx + a.w * dy) * dx + (bb.x * dy) * dy;
+                const float G = __builtin_amdgcn_exp2f(power2);
+                const float alpha = fminf(0.99f, bb.y * G);
+                const bool valid = (qmax - 1 - jl < last_contributor) && !(power2 > 0.0f) && !(alpha < 1.0f / 255.0f);
+                if (__builtin_amdgcn_ballot_w64(valid) == 0) continue;
+                const float aeff = valid ? alpha : 0.f;
+                const float Geff = valid ? G : 0.f;
+                float Town, inv_om, Aown;
+                float sdot = c0_ * dpx0;
+                sdot += c1_ * dpx1; sdot += c2_ * dpx2;
+                bwd_chain4s(aeff, sdot, T, arA, Town, inv_om, Aown, vone, vzero);
+                const float dchannel_dcolor = aeff * Town;
+                float dL_dalpha = sdot - Aown;
+                dL_dalpha = dL_dalpha * Town - tfinal_bg * inv_om;
+                const float w = Geff * dL_dalpha;
+                const float wdx = w * dx, wdy = w * dy;
+                float v[NACC];
+                v[0] = dchannel_dcolor * dpx0; v[1] = dchannel_dcolor * dpx1; v[2] = dchannel_dcolor * dpx2;
+                v[3] = wdx; v[4] = wdy;
+                v[5] = wdx * dx; v[6] = wdx * dy; v[7] = wdy * dy;
+                v[8] = w;
+                row_stride4_sum9(v);
+                const float s0 = pq == 0 ? v[0] : pq == 1 ? v[1] : pq == 2 ? v[2] : v[3];
+                const float s1 = pq == 0 ? v[4] : pq == 1 ? v[5] : pq == 2 ? v[6] : v[7];
+                if (j != (uint32_t)BNULL) {
+                    atomicAdd(&acc[pq][j], (double)s0);
+                    atomicAdd(&acc[4 + pq][j], (double)s1);
+                    if (pq == 0) atomicAdd(&acc[8][j], (double)v[8]);
+                }
+            }
+        }
+    }
+    }
+    __syncthreads();
+    if (lt < qmax) {                                        // flush: one 48-B row per instance (flush of the heavy path; op and conic yy from the staged record)
+        const uint32_t j = base + lt;
+        const float4 a = sA[j], bb = sB[j];
+        const float cxx = a.z * UNSCALE_CONIC, cxy = a.w * UNSCALE_CONIC_XY, cyy = bb.x * UNSCALE_CONIC, op = bb.y;
+        const float Sx = (float)acc[3][j], Sy = (float)acc[4][j];
+        float4* row = b.slab + (size_t)sSlot[j] * SLAB_ROW;
+        row[0] = make_float4((float)acc[0][j], (float)acc[1][j], (float)acc[2][j], op * (-Sx * cxx - Sy * cxy) * ddelx_dx);
+        row[1] = make_float4(op * (-Sy * cyy - Sx * cxy) * ddely_dy, -0.5f * op * (float)acc[5][j], -0.5f * op * (float)acc[6][j], -0.5f * op * (float)acc[7][j]);
+        row[2] = make_float4((float)acc[8][j], 0.f, 0.f, 0.f);
+    }
+    stamp_if(s, tile, 3, active && lt == 0);
+}
+
+// light != 0: tiles with fewer than LIGHT_MAX instances are composited three per workgroup by the LAST workgroups of the grid (bwd_light_group);
+// this kernel's one-tile workgroups end at Meta::n_mid
 __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s, const BinState b, int W, int H, uint32_t gx,
-                                                            const float* __restrict__ bg, const float* __restrict__ dL_dpix)
+                                                            const float* __restrict__ bg, const float* __restrict__ dL_dpix, int light, uint32_t n_tiles)
 {
     __shared__ float4 sA[BCH + 1];
     __shared__ float4 sB[BCH + 1];
@@ -229,8 +367,22 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
     __shared__ __attribute__((aligned(16))) unsigned short qlists[16][4][QL_ROW]; // per wave: the current chunk's four quadrant lists
 
     const uint4 td = s.tile_desc[blockIdx.x];               // (in flight beside the frame's flags)
-    if (frame_rejected(s)) return;
-    check_tile_bound(s);
+    // candidate light tile of this thread's quarter: light group g is workgroup gridDim.x - 1 - g and takes light tiles 3 g .. 3 g + 2
+    const uint32_t lgroup = gridDim.x - 1u - blockIdx.x, lsub = threadIdx.x >> 8, li = (uint32_t)BWD_LIGHT_PER_WG * lgroup + lsub;
+    const uint4 tdl = (light && lsub < (uint32_t)BWD_LIGHT_PER_WG && li < n_tiles) ? s.light_desc[li] : make_uint4(0u, 0u, 0u, 0u);
+    const uint4 ff = frame_counts(s);
+    if (ff.x & META_ERR_CAPACITY) return;
+    if (light) {
+        const uint32_t n_ne = min(ff.w, ff.y), n_light = ff.y - n_ne, n_lgroups = (n_light + BWD_LIGHT_PER_WG - 1) / BWD_LIGHT_PER_WG;
+        // (check_tile_bound: the grid must hold the one-tile workgroups and the light groups side by side)
+        if (blockIdx.x == 0 && threadIdx.x == 0 && n_ne + n_lgroups > gridDim.x) atomicOr(&s.meta->error, META_ERR_TILE_BOUND);
+        if (blockIdx.x >= n_ne) {
+            if (lgroup >= n_lgroups) return;                // (uniform over the workgroup)
+            if (threadIdx.x == 0) { sA[BNULL] = make_float4(0.f, 0.f, 0.f, 0.f); sB[BNULL] = make_float4(0.f, 0.f, 0.f, 0.f); sC[BNULL] = 0.f; }
+            bwd_light_group(s, b, W, H, gx, bg, dL_dpix, tdl, lsub < (uint32_t)BWD_LIGHT_PER_WG && li < n_light, sA, sB, sC, sSlot[0], acc, sQ, lists, qlists);
+            return;
+        }
+    } else check_tile_bound(s);
     const uint32_t tile = td.x;
     const uint32_t tx = tile % gx, ty = tile / gx;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -388,6 +540,7 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
     }
     stamp(s, tile, 3);
 }
+
 
 // ---------------------------------------------------------------------------------------------
 // Per-Gaussian half of the backward for ONE view (computeCov2DCUDA backward.cu:144-274, preprocessCUDA :346-396,
@@ -1200,12 +1353,19 @@ void launch_selftest_reduce36(hipStream_t st, const float* in, float* out)
 }
 
 // `tiles`: leading entries of tile_order to visit -- all of them, or the caller's bound on the tiles with instances (the rest is empty)
+// tiles: leading entries of tile_order that can hold instances (all, or the caller's bound); mid_tiles (light != 0): how many of them can hold
+// >= LIGHT_MAX instances -- the caller's bound, or `tiles`.  T: tiles of the image.
 void launch_render_bwd(hipStream_t st, const ImgState& s, const BinState& b, int W, int H, uint32_t gx, uint32_t tiles, const float* bg, const float* dL_dpix,
-                       bool deterministic)
+                       bool deterministic, uint32_t mid_tiles, int light, uint32_t T)
 {
     // (-DTGS_FAST_MATH=0 builds always take the fixed-order kernel: it evaluates exp / the divisions in their accurate forms)
-    if (deterministic || !TGS_FAST_MATH) hipLaunchKernelGGL(k_render_bwd_det, dim3(tiles), dim3(256), 0, st, s, b, W, H, gx, bg, dL_dpix);
-    else hipLaunchKernelGGL(k_render_bwd, dim3(tiles), dim3(BWD_THREADS), 0, st, s, b, W, H, gx, bg, dL_dpix);
+    if (deterministic || !TGS_FAST_MATH) { hipLaunchKernelGGL(k_render_bwd_det, dim3(tiles), dim3(256), 0, st, s, b, W, H, gx, bg, dL_dpix); return; }
+    if (!light) { hipLaunchKernelGGL(k_render_bwd, dim3(tiles), dim3(BWD_THREADS), 0, st, s, b, W, H, gx, bg, dL_dpix, 0, T); return; }
+    const uint32_t heavy = mid_tiles < tiles ? mid_tiles : tiles;
+    // one-tile workgroups for the (bound on the) tiles with >= LIGHT_MAX instances + light groups for the rest, three tiles each.  With exact
+    // counts (heavy = n_mid, tiles = n_nonempty) that is n_mid + ceil((n_nonempty - n_mid) / 3); with bounds it is an upper bound of it.
+    const uint32_t grid = heavy + (tiles - heavy + BWD_LIGHT_PER_WG - 1) / BWD_LIGHT_PER_WG;      // (largest when n_mid reaches its bound)
+    hipLaunchKernelGGL(k_render_bwd, dim3(grid > 0 ? grid : 1u), dim3(BWD_THREADS), 0, st, s, b, W, H, gx, bg, dL_dpix, 1, T);
 }
 void launch_preprocess_bwd(hipStream_t st, const BwdIn& in, const CamParams& cam, const GeomState& g, const BinState& b)
 {

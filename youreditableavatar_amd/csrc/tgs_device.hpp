@@ -64,6 +64,8 @@ struct ImgState {
     uint32_t* ovf_tiles;      // list of overflow tiles
     uint32_t* tile_order;     // tiles by descending list length: render kernels start the long lists first
     uint4* tile_desc;         // the same order with the range inlined: (tile, start, end, 0) -- one load instead of a dependent pair
+    uint4* light_desc;        // the descriptors of the LIGHT tiles once more (tile_desc[n_mid + i], i < n_nonempty - n_mid: fewer than LIGHT_MAX instances),
+                              // indexed from 0: the light render kernels fetch descriptor and frame counts side by side instead of one behind the other
     uint32_t* tile_qmax;      // per tile: deepest list position any of its pixels blended (max n_contrib), written by k_render_fwd
     float* final_T;           //                                    (imgState.accum_alpha)
     uint32_t* n_contrib;      //                                    (imgState.n_contrib)
@@ -102,7 +104,7 @@ __host__ __device__ inline size_t img_carve(ImgState& s, char* base, size_t N, s
 {
     char* p = base;
     carve(p, s.meta, 1); carve(p, s.ranges, T); carve(p, s.tile_count, T); carve(p, s.bin_table, (size_t)BIN_WGS_MAX * T);
-    carve(p, s.ovf_tiles, T); carve(p, s.tile_order, T); carve(p, s.tile_desc, T); carve(p, s.tile_qmax, T);
+    carve(p, s.ovf_tiles, T); carve(p, s.tile_order, T); carve(p, s.tile_desc, T); carve(p, s.light_desc, T); carve(p, s.tile_qmax, T);
     carve(p, s.final_T, N); carve(p, s.n_contrib, N);
     carve(p, s.stamps, 4 * T);
     return (size_t)(p - base) + 256;
@@ -448,6 +450,21 @@ __device__ __forceinline__ uint2 frame_flags(const ImgState& s)
     const unsigned long long v = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(&s.meta->error));
     return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
 }
+// (error, n_nonempty, n_heavy, n_mid) in one 16-B load
+__device__ __forceinline__ uint4 frame_counts(const ImgState& s)
+{
+    static_assert(offsetof(Meta, error) % 16 == 0 && offsetof(Meta, n_mid) == offsetof(Meta, error) + 12, "Meta layout");
+    const tgs_v4f t = __builtin_nontemporal_load(reinterpret_cast<const tgs_v4f*>(&s.meta->error));
+    return make_uint4(__float_as_uint(t.x), __float_as_uint(t.y), __float_as_uint(t.z), __float_as_uint(t.w));
+}
+// Light tiles: fewer than LIGHT_MAX instances (Meta::n_mid counts the tiles with at least that many, k_scan's length classes) -- a single
+// staging round, so 4 waves that take the tile's 16 blocks four each need no per-pixel state across rounds, and several such tiles share
+// one 1024-thread workgroup of the render kernels (fwd_light_group: four, bwd_light_group: three -- what the staging arrays hold).
+// Measured (per-tile stamps, config 3): the 1811 tiles below 128 entries hold 16 % of the instances but took 30 % of k_render_fwd's and
+// 24 % of k_render_bwd's workgroup time -- ~3 us of launch / descriptor / record-fetch latency each during which a workgroup of its own
+// holds half of a CU's wave slots.
+constexpr int LIGHT_MAX = 128;
+constexpr int FWD_LIGHT_PER_WG = 4, BWD_LIGHT_PER_WG = 3;
 // A frame that tgs_forward_async could not fit into the caller's binning capacity: every kernel behind k_scan returns.
 __device__ __forceinline__ bool frame_rejected(const ImgState& s)
 {
@@ -461,6 +478,14 @@ __device__ __forceinline__ void stamp(const ImgState& s, uint32_t tile, int whic
 {
 #if TGS_STAMPS
     if (threadIdx.x == 0) s.stamps[4 * (size_t)tile + which] = wall_clock64();
+#endif
+}
+
+// (light groups: the first thread of the tile's quarter stamps)
+__device__ __forceinline__ void stamp_if(const ImgState& s, uint32_t tile, int which, bool who)
+{
+#if TGS_STAMPS
+    if (who) s.stamps[4 * (size_t)tile + which] = wall_clock64();
 #endif
 }
 

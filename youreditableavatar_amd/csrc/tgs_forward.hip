@@ -454,6 +454,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const 
         constexpr uint32_t SC = SCAN_THREADS * 8;
         __shared__ uint32_t lc[SC];
         __shared__ uint32_t hist[34];
+        __shared__ uint32_t cls[2];                         // (n_mid, n_nonempty) for the second pass
         if (threadIdx.x == 0) ovf_n = 0;
         if (threadIdx.x < 34) hist[threadIdx.x] = 0;
         __syncthreads();
@@ -492,9 +493,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const 
             bool too_many = false;                          // more tiles (of a class) than the grids behind the scan cover
             for (int b2 = 33; b2-- > 0;) {
                 const uint32_t h = hist[b2]; hist[b2] = acc;
-                if (b2 == 1) { s.meta->n_nonempty = acc + h; too_many = too_many || acc + h > tile_bound; }
+                if (b2 == 1) { s.meta->n_nonempty = acc + h; cls[1] = acc + h; too_many = too_many || acc + h > tile_bound; }
                 if (b2 == 11) { s.meta->n_heavy = acc + h; too_many = too_many || acc + h > heavy_bound; }
-                if (b2 == 8) { s.meta->n_mid = acc + h; too_many = too_many || acc + h > mid_bound; }
+                if (b2 == 8) { s.meta->n_mid = acc + h; cls[0] = acc + h; too_many = too_many || acc + h > mid_bound; }
                 acc += h;
             }
             if (too_many) atomicOr(&s.meta->error, META_ERR_CAPACITY);
@@ -513,6 +514,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const 
                     const uint32_t c = r[k].y - r[k].x, pos = atomicAdd(&hist[c ? 32 - __builtin_clz(c) : 0], 1u);
                     s.tile_order[pos] = sc + i;
                     s.tile_desc[pos] = make_uint4(sc + i, r[k].x, r[k].y, 0u);
+                    if (pos >= cls[0] && pos < cls[1]) s.light_desc[pos - cls[0]] = make_uint4(sc + i, r[k].x, r[k].y, 0u);
                 }
             }
         }
@@ -980,8 +982,129 @@ __device__ __forceinline__ void fill_tile_background(const ImgState& s, uint32_t
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Light groups of k_render_fwd: FOUR light tiles (fewer than LIGHT_MAX instances: one staging round) per 1024-thread workgroup, one per
+// 256-thread quarter.  Quarter q stages its tile's whole list into slots [128 q, 128 q + 128) of the workgroup's staging arrays; its wave
+// w then takes the tile's blocks 4w .. 4w+3 one after the other with the row / quad structure of the heavy path (a 16-lane row = one
+// 2x2-pixel quadrant x 4 entries of its own list; fwd_chain4) -- with a single round no pixel state outlives a block.  A short tile is
+// mostly latency (descriptor -> records -> staging barrier, ~3 us) during which a workgroup of its own held half of a CU's wave slots:
+// the 1811 tiles below 128 entries of config 3 hold 16 % of the instances and took 30 % of the kernel's workgroup time (per-tile stamps).
+// Light groups are counted from the END of the grid, so a workgroup fetches its candidate descriptors before it knows the frame's counts.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void fwd_light_group(const ImgState& s, const BinState& b, int W, int H, uint32_t gx, const float* __restrict__ bg,
+                                                float* __restrict__ out_color, uint4 td, bool active, float4* sA, float4* sB, float* sC, uint2* sQ,
+                                                unsigned short (*lists)[FCH + 8], unsigned short (*qlists)[4][QL_ROW_F], uint32_t* wave_qmax)
+{
+    const int sub = threadIdx.x >> 8, lt = threadIdx.x & 255;
+    const int wv = threadIdx.x >> 6, w4 = wv & 3, lane = threadIdx.x & 63;
+    const int qd = lane >> 4, pq = (lane >> 2) & 3, e = lane & 3;
+    const uint32_t base = (uint32_t)LIGHT_MAX * sub;
+    const uint32_t tile = td.x, n = active ? td.z - td.y : 0u;      // 1 <= n < LIGHT_MAX
+    const uint32_t tx = tile % gx, ty = tile / gx;
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+    stamp_if(s, tile, 0, active && lt == 0);
+    {   // stage the whole list: thread t < 128 of the quarter carries recA + recC of entry t, thread 128 + t recB + the quadrant mask
+        const uint32_t ht = lt & (LIGHT_MAX - 1);
+        const bool upper = lt >= LIGHT_MAX;
+        if (ht < n) {
+            const uint32_t pos = td.y + ht;
+            if (!upper) {
+                float4 r4 = b.recA[pos]; const float c = b.recC[pos].x;
+#if TGS_FAST_MATH
+                stage_conic_a(r4);
+#endif
+                sA[base + ht] = r4; sC[base + ht] = c;
+            } else {
+                float4 r4 = b.recB[pos]; const uint2 q = b.qmask[pos];
+#if TGS_FAST_MATH
+                stage_conic_b(r4);
+#endif
+                sB[base + ht] = r4; sQ[base + ht] = q;
+            }
+        }
+        if (threadIdx.x == 0) { sA[FNULL] = make_float4(0.f, 0.f, 0.f, 0.f); sB[FNULL] = make_float4(0.f, 0.f, 0.f, 0.f); sC[FNULL] = 0.f; }
+    }
+    __syncthreads();
+    float vone = 1.0f;
+    asm volatile("" : "+v"(vone));
+    uint32_t wq = 0;
+    const unsigned short* myq = &qlists[wv][qd][e];
+    const uint32_t null_local = (uint32_t)FNULL - base;     // the shared null record as an index relative to this quarter's slots
+    if (active) {
+#pragma unroll 1
+    for (int bi = 0; bi < 4; bi++) {
+        const int blk = 4 * w4 + bi;
+        const int px = tx * TILE + (blk & 3) * 4 + (qd & 1) * 2 + (pq & 1);
+        const int py = ty * TILE + (blk >> 2) * 4 + (qd >> 1) * 2 + (pq >> 1);
+        const bool inside = px < W && py < H;
+        const float pixfx = (float)px, pixfy = (float)py;
+        bool done = !inside;
+        float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
+        uint32_t last_contributor = 0;
+        const uint32_t nb = __builtin_amdgcn_ballot_w64(!done) != 0 ? build_own_list_q<LIGHT_MAX>(lists[wv], sQ + base, n, blk, lane) : 0u;
+        if (nb > 0) {
+            const uint32_t nq = build_chunk_quadrant_lists_128(qlists[wv], lists[wv], 0u, nb, lane, (int)null_local);
+#pragma unroll 1
+            for (uint32_t k = 0; k < nq; k += 4) {          // the pass of the heavy path below (forward.cu:325-362 semantics: see there)
+                const uint32_t jl = myq[k], j = jl + base;
+                const float4 a = sA[j];
+                const float4 bb = sB[j];
+                const float cc = sC[j];
+                const float dx = a.x - pixfx, dy = a.y - pixfy;
+#if TGS_FAST_MATH
+                const float power2 = (a.z * dx + a.w * dy) * dx + (bb.x * dy) * dy;
+                const float alpha = fminf(0.99f, bb.y * __builtin_amdgcn_exp2f(power2));
+#else
+                const float power2 = -0.5f * (a.z * dx * dx + bb.x * dy * dy) - a.w * dx * dy;
+                const float alpha = fminf(0.99f, bb.y * expf(power2));
+#endif
+                const bool live = !done && !(power2 > 0.0f) && !(alpha < 1.0f / 255.0f);
+                const float pown = live ? 1.f - alpha : 1.0f;
+                float y, x, x3;
+                fwd_chain4(pown, T, y, x, vone);
+                const bool fail = live && (x < 0.0001f);
+                const bool upd = live && !fail;
+                float cand = fail ? y : -1.0f;
+                quad_max_bcast3(cand, x, x3);
+                const float w = upd ? alpha * y : 0.f;
+                C0 += bb.z * w; C1 += bb.w * w; C2 += cc * w;
+                last_contributor = upd ? 1u + jl : last_contributor;    // (list position of slot jl + 1: the single round starts at the range's first entry)
+                const bool stop = cand >= 0.0f;
+                T = stop ? cand : x3;
+                done = done || stop;
+                if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
+            }
+        }
+        TGS_DPP_ADD(C0, 0xB1, 0xf); TGS_DPP_ADD(C0, 0x4E, 0xf);
+        TGS_DPP_ADD(C1, 0xB1, 0xf); TGS_DPP_ADD(C1, 0x4E, 0xf);
+        TGS_DPP_ADD(C2, 0xB1, 0xf); TGS_DPP_ADD(C2, 0x4E, 0xf);
+        {
+            uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)last_contributor, 0xB1, 0xf, 0xf, false);
+            last_contributor = max(last_contributor, o);
+            o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)last_contributor, 0x4E, 0xf, 0xf, false);
+            last_contributor = max(last_contributor, o);
+        }
+        if (inside && e == 0) {
+            const size_t pix_id = (size_t)W * py + px, N = (size_t)W * H;
+            s.final_T[pix_id] = T;
+            s.n_contrib[pix_id] = last_contributor;
+            out_color[pix_id] = C0 + T * bg0;
+            out_color[N + pix_id] = C1 + T * bg1;
+            out_color[2 * N + pix_id] = C2 + T * bg2;
+        }
+        wq = max(wq, wave_max_u32(inside ? last_contributor : 0u));
+    }
+    }
+    if (lane == 0) wave_qmax[wv] = wq;
+    __syncthreads();
+    if (lt == 0 && active) s.tile_qmax[tile] = max(max(wave_qmax[4 * sub], wave_qmax[4 * sub + 1]), max(wave_qmax[4 * sub + 2], wave_qmax[4 * sub + 3]));
+    stamp_if(s, tile, 1, active && lt == 0);
+}
+
+// light != 0: tiles with fewer than LIGHT_MAX instances (Meta::n_mid counts the others) are composited four per workgroup by the LAST workgroups
+// of the grid (fwd_light_group); this kernel's one-tile workgroups then end at n_mid instead of n_nonempty.
 __global__ __launch_bounds__(FWD_THREADS, 8) void k_render_fwd(const ImgState s, const BinState b, int W, int H, uint32_t gx,
-                                                            const float* __restrict__ bg, float* __restrict__ out_color, int fill_tail, uint32_t n_tiles)
+                                                            const float* __restrict__ bg, float* __restrict__ out_color, int fill_tail, uint32_t n_tiles, int light)
 {
     __shared__ float4 sA[FCH + 1];
     __shared__ float4 sB[FCH + 1];
@@ -993,15 +1116,24 @@ __global__ __launch_bounds__(FWD_THREADS, 8) void k_render_fwd(const ImgState s,
     __shared__ uint32_t wave_qmax[16];
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     const uint4 td = s.tile_desc[blockIdx.x];
-    const uint2 ff = frame_flags(s);                       // (error bits, non-empty tiles): one load, in flight beside the descriptor's
-    const uint32_t n_ne = (ff.x & META_ERR_CAPACITY) ? 0u : ff.y;      // a frame tgs_forward_async rejected renders the background everywhere
+    // candidate light tile of this thread's quarter: light group g is workgroup gridDim.x - 1 - g and takes light tiles 4 g .. 4 g + 3
+    const uint32_t lgroup = gridDim.x - 1u - blockIdx.x, li = 4u * lgroup + (threadIdx.x >> 8);
+    const uint4 tdl = (light && li < n_tiles) ? s.light_desc[li] : make_uint4(0u, 0u, 0u, 0u);
+    const uint4 ff = frame_counts(s);                      // (error bits, non-empty tiles, heavy, mid): one load, in flight beside the descriptors'
+    const uint32_t n_all = (ff.x & META_ERR_CAPACITY) ? 0u : ff.y;     // a frame tgs_forward_async rejected renders the background everywhere
+    const uint32_t n_ne = light ? min(ff.w, n_all) : n_all;           // one-tile workgroups: the first n_ne entries of tile_order
+    const uint32_t n_light = n_all - n_ne, n_lgroups = (n_light + 3u) / 4u;
     if (blockIdx.x >= n_ne) {
-        // Sync-free forward: the workgroups behind the non-empty tiles (the grid covers the caller's bound on those, plus one workgroup per
-        // 16 tiles beyond it) share the EMPTY tiles -- the tail of tile_order -- four at a time.  (One workgroup per empty tile was 5400
-        // surplus workgroups at config 3: ~4 % of a frame.)
+        if (lgroup < n_lgroups) {                           // (uniform over the workgroup)
+            fwd_light_group(s, b, W, H, gx, bg, out_color, tdl, li < n_light, sA, sB, sC, sQ, lists, qlists, wave_qmax);
+            return;
+        }
+        // Sync-free forward: the workgroups between the one-tile ones and the light groups (the grid covers the caller's bounds on both,
+        // plus one workgroup per 16 tiles beyond the tile bound) share the EMPTY tiles -- the tail of tile_order -- four at a time.  (One
+        // workgroup per empty tile was 5400 surplus workgroups at config 3: ~4 % of a frame.)
         if (fill_tail) {
-            const uint32_t nfill = gridDim.x - n_ne, j = blockIdx.x - n_ne;
-            for (uint32_t i = n_ne + 4u * j + (threadIdx.x >> 8); i < n_tiles; i += 4u * nfill)
+            const uint32_t nfill = gridDim.x - n_ne - n_lgroups, j = blockIdx.x - n_ne;
+            for (uint32_t i = n_all + 4u * j + (threadIdx.x >> 8); i < n_tiles; i += 4u * nfill)
                 fill_tile_background(s, s.tile_desc[i].x, threadIdx.x & 255u, W, H, gx, bg, out_color);
         }
         return;
@@ -1137,6 +1269,7 @@ __global__ __launch_bounds__(FWD_THREADS, 8) void k_render_fwd(const ImgState s,
     stamp(s, tile, 1);
 }
 
+
 // tiles without any instance: background only (they sit at the end of tile_order)
 __global__ __launch_bounds__(256) void k_fill_empty(const ImgState s, int W, int H, uint32_t gx, uint32_t T, uint32_t first, const float* __restrict__ bg,
                                                     float* __restrict__ out_color)
@@ -1260,18 +1393,23 @@ void launch_tile_sort(hipStream_t st, const GeomState& g, const ImgState& s, con
     }
     if (r_bound > 0) hipLaunchKernelGGL(k_finalize, dim3((unsigned)((r_bound + 256 * FIN_E - 1) / (256 * FIN_E))), dim3(256), 0, st, g, s, b, gx, T);
 }
+// mid_bound (sync-free, with a tile bound): upper bound on the tiles with >= LIGHT_MAX instances (k_scan rejects a frame with more)
 void launch_render_fwd(hipStream_t st, const ImgState& s, const BinState& b, int W, int H, uint32_t gx, uint32_t T, const Meta* m,
-                       const float* bg, float* out_color, uint32_t tile_bound)
+                       const float* bg, float* out_color, uint32_t tile_bound, uint32_t mid_bound, int light)
 {
-    if (!m) {   // sync-free: tile_bound workgroups (k_scan has rejected the frame if more tiles hold instances) + one per 16 tiles beyond the
-                // bound; those behind the non-empty tiles write the background of all empty ones
+    if (!m) {   // sync-free: workgroups for the bounds on the tiles with instances (k_scan has rejected the frame if more hold any) + one per 16
+                // tiles beyond the bound; those not needed for compositing write the background of all empty tiles
         const uint32_t tb = tile_bound < T ? tile_bound : T;
-        const uint32_t grid = tb + (T - tb + 15u) / 16u;    // (tb == T: one workgroup per tile)
-        hipLaunchKernelGGL(k_render_fwd, dim3(grid), dim3(FWD_THREADS), 0, st, s, b, W, H, gx, bg, out_color, 1, T);
+        const uint32_t hb = light ? (mid_bound < tb ? mid_bound : tb) : tb;     // one-tile workgroups, at most
+        const uint32_t lg = light ? (tb - hb + 3u) / 4u : 0u;                   // light groups beside them, at most (four tiles each; largest when n_mid reaches its bound)
+        const uint32_t grid = hb + lg + (T - tb + 15u) / 16u;
+        hipLaunchKernelGGL(k_render_fwd, dim3(grid), dim3(FWD_THREADS), 0, st, s, b, W, H, gx, bg, out_color, 1, T, light);
         return;
     }
     const uint32_t nonempty = m->n_nonempty, empty = T - m->n_nonempty;
-    if (nonempty > 0) hipLaunchKernelGGL(k_render_fwd, dim3(nonempty), dim3(FWD_THREADS), 0, st, s, b, W, H, gx, bg, out_color, 0, T);
+    const uint32_t heavy = light ? (m->n_mid < nonempty ? m->n_mid : nonempty) : nonempty;
+    const uint32_t grid = heavy + (nonempty - heavy + 3u) / 4u;
+    if (grid > 0) hipLaunchKernelGGL(k_render_fwd, dim3(grid), dim3(FWD_THREADS), 0, st, s, b, W, H, gx, bg, out_color, 0, T, light);
     if (empty > 0) hipLaunchKernelGGL(k_fill_empty, dim3(empty), dim3(256), 0, st, s, W, H, gx, T, nonempty, bg, out_color);
 }
 void launch_mark_visible(hipStream_t st, int P, const float* means3D, const float* view, uint8_t* present)

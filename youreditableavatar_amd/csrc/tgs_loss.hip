@@ -14,6 +14,7 @@
 // Both image passes are bound by HBM: 2 planes read + 3 written, then 5 read + 1 written (4 B each).
 #include "tgs_device.hpp"
 #include <cmath>
+#include <cstdlib>
 
 namespace tgs {
 
@@ -244,6 +245,200 @@ __global__ __launch_bounds__(256) void k_ssim_grad(int H, int W, const float* __
     }
 }
 
+// =====================================================================================================================================
+// Round 3: the same two passes as STREAMING kernels without LDS and without barriers.  A wave owns a vertical strip of the plane -- lane =
+// column, 64 input columns = 54 output columns + the window's 5-column halo on either side -- and walks down SS_SEG output rows:
+//   per input row: one coalesced 4-B load per lane and map; the horizontal 11-tap window from the neighbouring lanes by ten full-wave DPP
+//   shifts (wave_shr:1) per input map; the vertical window as 11 running sums per lane and map (a row adds w[k] * H to the 11 output rows
+//   it belongs to; the row loop is unrolled by 11 so that the slot of a running sum is a compile-time register);
+//   the output row 5 rows behind is finished: SSIM map and its derivatives (stats pass) / the gradient (gradient pass), one store per map.
+// No tile staging, no shared memory, no workgroup barrier: the tiled kernels above spent their time waiting on exactly those (3 workgroups
+// per CU at 42 KB of LDS each, three barriers per tile; 1.9 / 2.7 TB/s of their algorithmic bytes at 3 x 2048 x 2048).  Cost of the scheme:
+// 64 / 54 of the input loads (neighbouring strips overlap by 10 columns, L2 hits) and 10 warm-up rows per segment.
+// The tiled kernels remain for A/B runs (TGS_LOSS_TILED=1).
+// =====================================================================================================================================
+constexpr int SS_OUT = WAVE - 2 * LR;       // 54 output columns per wave
+#ifndef TGS_SS_SEG
+#define TGS_SS_SEG 64
+#endif
+constexpr int SS_SEG = TGS_SS_SEG;          // output rows per wave
+
+__device__ __forceinline__ float wave_shr1(float v)     // lane i <- lane i - 1 (lane 0 keeps an unspecified value: never used)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+
+struct StripGeom { int col_in, col_out, y0, y1; bool in_x, out_ok, own_col; size_t plane; };
+__device__ __forceinline__ bool strip_geom(StripGeom& g, int H, int W, int nstrips)
+{
+    const int lane = threadIdx.x & 63, strip = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (strip >= nstrips) return false;
+    g.col_in = strip * SS_OUT - LR + lane;
+    g.col_out = g.col_in - LR;
+    g.in_x = g.col_in >= 0 && g.col_in < W;
+    g.out_ok = lane >= 2 * LR && g.col_out < W;
+    g.own_col = lane >= LR && lane < LR + SS_OUT && g.in_x;        // the columns whose |x - y| this wave adds up
+    g.y0 = blockIdx.y * SS_SEG;
+    g.y1 = min(g.y0 + SS_SEG, H);
+    g.plane = (size_t)blockIdx.z * H * W;
+    return true;
+}
+
+// one input row of the stats pass in phase P (= row counter mod 11): horizontal window of the five maps, scatter into the running sums,
+// finish output row r - 5
+template <int P>
+__device__ __forceinline__ void stats_row(float x, float y, int r, const StripGeom& g, const LossWin& win, float (&V)[5][NTAP], int W,
+                                          float* __restrict__ dM1, float* __restrict__ dX2, float* __restrict__ dXY, float& s_map)
+{
+    float hx = 0.f, hy = 0.f, hxx = 0.f, hyy = 0.f, hxy = 0.f;
+    float xs = x, ys = y;
+#pragma unroll
+    for (int j = 0; j < NTAP; j++) {                        // lane L holds column c; after j shifts xs = x(c - j): the window of output column c - 5
+        const float w = win.w[j];
+        const float wx = w * xs, wy = w * ys;
+        hx += wx; hy += wy; hxx += wx * xs; hyy += wy * ys; hxy += wx * ys;
+        if (j + 1 < NTAP) { xs = wave_shr1(xs); ys = wave_shr1(ys); }
+    }
+#pragma unroll
+    for (int k = 0; k < NTAP; k++) {                        // this row is tap k of output row r + 5 - k, whose running sums sit in slot (P + 10 - k) % 11
+        const float w = win.w[k];
+        constexpr int dummy = 0; (void)dummy;
+        const int sl = (P + NTAP - 1 - k) % NTAP;
+        V[0][sl] += w * hx; V[1][sl] += w * hy; V[2][sl] += w * hxx; V[3][sl] += w * hyy; V[4][sl] += w * hxy;
+    }
+    const int ro = r - LR;
+    if (ro >= g.y0 && ro < g.y1) {                          // (uniform over the wave)
+        const float m1 = V[0][P], m2 = V[1][P], X2 = V[2][P], Y2 = V[3][P], XY = V[4][P];
+        // loss_utils.py:49-58
+        const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+        const float m11 = m1 * m1, m22 = m2 * m2, m12 = m1 * m2;
+        const float s1 = X2 - m11, s2 = Y2 - m22, s12 = XY - m12;
+        const float N1 = 2.f * m12 + C1, N2 = 2.f * s12 + C2, D1 = m11 + m22 + C1, D2 = s1 + s2 + C2;
+        const float iD1 = 1.f / D1, iD2 = 1.f / D2, q = iD1 * iD2;
+        const float map = N1 * N2 * q;
+        if (g.out_ok) {
+            const size_t at = g.plane + (size_t)ro * W + g.col_out;
+            dM1[at] = 2.f * q * (m2 * (N2 - N1) - m1 * map * (D2 - D1));
+            dX2[at] = -map * iD2;
+            dXY[at] = 2.f * N1 * q;
+            s_map += map;
+        }
+    }
+    V[0][P] = 0.f; V[1][P] = 0.f; V[2][P] = 0.f; V[3][P] = 0.f; V[4][P] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void k_ssim_stats_stream(int H, int W, int nstrips, const float* __restrict__ img, const float* __restrict__ gt, LossWin win,
+                                                          float* __restrict__ dM1, float* __restrict__ dX2, float* __restrict__ dXY, float2* __restrict__ partial)
+{
+    StripGeom g;
+    const size_t pidx = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * (gridDim.x * 4) + blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (!strip_geom(g, H, W, nstrips)) { if ((threadIdx.x & 63) == 0) partial[pidx] = make_float2(0.f, 0.f); return; }
+    float V[5][NTAP];
+#pragma unroll
+    for (int m = 0; m < 5; m++)
+#pragma unroll
+        for (int k = 0; k < NTAP; k++) V[m][k] = 0.f;
+    float s_map = 0.f, s_l1 = 0.f;
+    const float* px = img + g.plane + g.col_in;
+    const float* py = gt + g.plane + g.col_in;
+    auto ld = [&](const float* p, int r) { return (g.in_x && r >= 0 && r < H) ? p[(size_t)r * W] : 0.f; };
+    const int r_first = g.y0 - LR, r_last = g.y1 + LR - 1;  // input rows this segment needs (zero padding outside the image)
+    float xa = ld(px, r_first), ya = ld(py, r_first), xb = ld(px, r_first + 1), yb = ld(py, r_first + 1), xc = ld(px, r_first + 2), yc = ld(py, r_first + 2);
+    int r = r_first;
+#define TGS_STATS_STEP(P)                                                                                                   \
+    if (r <= r_last) {                                                                                                      \
+        const float x = xa, y = ya;                                                                                         \
+        xa = xb; ya = yb; xb = xc; yb = yc; xc = ld(px, r + 3); yc = ld(py, r + 3);     /* three rows in flight */          \
+        if (g.own_col && r >= g.y0 && r < g.y1) s_l1 += fabsf(x - y);                                                       \
+        stats_row<P>(x, y, r, g, win, V, W, dM1, dX2, dXY, s_map);                                                          \
+        r++;                                                                                                                \
+    }
+    while (r <= r_last) {
+        TGS_STATS_STEP(0) TGS_STATS_STEP(1) TGS_STATS_STEP(2) TGS_STATS_STEP(3) TGS_STATS_STEP(4) TGS_STATS_STEP(5)
+        TGS_STATS_STEP(6) TGS_STATS_STEP(7) TGS_STATS_STEP(8) TGS_STATS_STEP(9) TGS_STATS_STEP(10)
+    }
+#undef TGS_STATS_STEP
+    s_map = wave_sum(s_map); s_l1 = wave_sum(s_l1);
+    if ((threadIdx.x & 63) == 0) partial[pidx] = make_float2(s_map, s_l1);
+}
+
+template <int P>
+__device__ __forceinline__ void grad_row(float a, float b, float c, float xo, float yo, int r, const StripGeom& g, const LossWin& win, float (&V)[3][NTAP], int W,
+                                         float gs, float gl, float* __restrict__ grad)
+{
+    float h0 = 0.f, h1 = 0.f, h2 = 0.f;
+    float as = a, bs = b, cs = c;
+#pragma unroll
+    for (int j = 0; j < NTAP; j++) {
+        const float w = win.w[j];
+        h0 += w * as; h1 += w * bs; h2 += w * cs;
+        if (j + 1 < NTAP) { as = wave_shr1(as); bs = wave_shr1(bs); cs = wave_shr1(cs); }
+    }
+#pragma unroll
+    for (int k = 0; k < NTAP; k++) {
+        const float w = win.w[k];
+        const int sl = (P + NTAP - 1 - k) % NTAP;
+        V[0][sl] += w * h0; V[1][sl] += w * h1; V[2][sl] += w * h2;
+    }
+    const int ro = r - LR;
+    if (ro >= g.y0 && ro < g.y1 && g.out_ok) {
+        const float d = xo - yo;
+        const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);             // torch's abs backward: 0 at 0
+        grad[g.plane + (size_t)ro * W + g.col_out] = gl * sgn + gs * (V[0][P] + 2.f * xo * V[1][P] + yo * V[2][P]);
+    }
+    V[0][P] = 0.f; V[1][P] = 0.f; V[2][P] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void k_ssim_grad_stream(int H, int W, int nstrips, const float* __restrict__ img, const float* __restrict__ gt, LossWin win,
+                                                         const float* __restrict__ dM1, const float* __restrict__ dX2, const float* __restrict__ dXY,
+                                                         float gs, float gl, const float* __restrict__ upstream, float* __restrict__ grad)
+{
+    StripGeom g;
+    if (!strip_geom(g, H, W, nstrips)) return;
+    if (upstream) { const float u = upstream[0]; gs *= u; gl *= u; }      // d(outer)/d(loss), a device scalar: the chain rule costs no pass of its own
+    float V[3][NTAP];
+#pragma unroll
+    for (int m = 0; m < 3; m++)
+#pragma unroll
+        for (int k = 0; k < NTAP; k++) V[m][k] = 0.f;
+    const float* p0 = dM1 + g.plane + g.col_in;
+    const float* p1 = dX2 + g.plane + g.col_in;
+    const float* p2 = dXY + g.plane + g.col_in;
+    const bool oc = g.col_out >= 0 && g.col_out < W;
+    const float* qx = img + g.plane + (oc ? g.col_out : 0);
+    const float* qy = gt + g.plane + (oc ? g.col_out : 0);
+    auto ld = [&](const float* p, int r) { return (g.in_x && r >= 0 && r < H) ? p[(size_t)r * W] : 0.f; };
+    auto ldo = [&](const float* p, int r) { return (oc && r >= 0 && r < H) ? p[(size_t)r * W] : 0.f; };       // the image at the OUTPUT pixel of row r - 5
+    const int r_first = g.y0 - LR, r_last = g.y1 + LR - 1;
+    float a0 = ld(p0, r_first), b0 = ld(p1, r_first), c0 = ld(p2, r_first), x0 = ldo(qx, r_first - LR), y0v = ldo(qy, r_first - LR);
+    float a1 = ld(p0, r_first + 1), b1 = ld(p1, r_first + 1), c1 = ld(p2, r_first + 1), x1 = ldo(qx, r_first + 1 - LR), y1v = ldo(qy, r_first + 1 - LR);
+    int r = r_first;
+#define TGS_GRAD_STEP(P)                                                                                                    \
+    if (r <= r_last) {                                                                                                      \
+        const float a = a0, b = b0, c = c0, xo = x0, yo = y0v;                                                              \
+        a0 = a1; b0 = b1; c0 = c1; x0 = x1; y0v = y1v;                                                                      \
+        a1 = ld(p0, r + 2); b1 = ld(p1, r + 2); c1 = ld(p2, r + 2); x1 = ldo(qx, r + 2 - LR); y1v = ldo(qy, r + 2 - LR);    \
+        grad_row<P>(a, b, c, xo, yo, r, g, win, V, W, gs, gl, grad);                                                         \
+        r++;                                                                                                                \
+    }
+    while (r <= r_last) {
+        TGS_GRAD_STEP(0) TGS_GRAD_STEP(1) TGS_GRAD_STEP(2) TGS_GRAD_STEP(3) TGS_GRAD_STEP(4) TGS_GRAD_STEP(5)
+        TGS_GRAD_STEP(6) TGS_GRAD_STEP(7) TGS_GRAD_STEP(8) TGS_GRAD_STEP(9) TGS_GRAD_STEP(10)
+    }
+#undef TGS_GRAD_STEP
+}
+
+static bool loss_tiled()
+{
+    static const bool v = [] { const char* e = getenv("TGS_LOSS_TILED"); return e && atoi(e) != 0; }();      // A/B knob, read once
+    return v;
+}
+static dim3 stream_grid(int planes, int height, int width, int& nstrips)
+{
+    nstrips = (width + SS_OUT - 1) / SS_OUT;
+    return dim3((unsigned)((nstrips + 3) / 4), (unsigned)((height + SS_SEG - 1) / SS_SEG), (unsigned)planes);
+}
+
 static LossWin make_window()
 {
     // loss_utils.py:23-25: exp in double, stored fp32, normalised in fp32
@@ -264,7 +459,9 @@ size_t tgs_l1_ssim_workspace_bytes(int planes, int height, int width)
     if (planes <= 0 || height <= 0 || width <= 0) return 0;
     const size_t n = (size_t)planes * height * width;
     const size_t blocks = (size_t)planes * ((height + tgs::LH * tgs::LTY - 1) / (tgs::LH * tgs::LTY)) * ((width + tgs::LW - 1) / tgs::LW);
-    return 3 * n * sizeof(float) + blocks * sizeof(float2) + 1024;
+    const size_t strips = (size_t)((width + tgs::SS_OUT - 1) / tgs::SS_OUT + 3) / 4 * 4;                       // streaming kernels: one partial per wave
+    const size_t waves = (size_t)planes * ((height + tgs::SS_SEG - 1) / tgs::SS_SEG) * strips;
+    return 3 * n * sizeof(float) + (blocks > waves ? blocks : waves) * sizeof(float2) + 1024;
 }
 
 int tgs_l1_ssim(void* stream, int planes, int height, int width, const float* img, const float* gt, float dssim_factor, float* out3,
@@ -284,12 +481,18 @@ int tgs_l1_ssim(void* stream, int planes, int height, int width, const float* im
     float* dXY = dX2 + n;
     float2* partial = (float2*)(dXY + n);
     const LossWin win = make_window();
-    const int nblk = (int)(grid.x * grid.y * grid.z);
-    hipLaunchKernelGGL(k_ssim_stats, grid, dim3(256), 0, st, height, width, img, gt, win, dM1, dX2, dXY, partial);
+    int nstrips = 0;
+    const dim3 sgrid = stream_grid(planes, height, width, nstrips);
+    if (sgrid.y > 65535u) return set_error(TGS_ERR_INVALID, "tgs_l1_ssim: image too large");
+    const bool tiled = loss_tiled();
+    const int nblk = tiled ? (int)(grid.x * grid.y * grid.z) : (int)(sgrid.x * 4 * sgrid.y * sgrid.z);
+    if (tiled) hipLaunchKernelGGL(k_ssim_stats, grid, dim3(256), 0, st, height, width, img, gt, win, dM1, dX2, dXY, partial);
+    else hipLaunchKernelGGL(k_ssim_stats_stream, sgrid, dim3(256), 0, st, height, width, nstrips, img, gt, win, dM1, dX2, dXY, partial);
     hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(1024), 0, st, nblk, partial, 1.0 / (double)n, dssim_factor, out3);
     if (dL_dimg) {
         const float gs = (float)(-(double)dssim_factor / (double)n), gl = (float)((1.0 - (double)dssim_factor) / (double)n);
-        hipLaunchKernelGGL(k_ssim_grad, grid, dim3(256), 0, st, height, width, img, gt, win, dM1, dX2, dXY, gs, gl, (const float*)nullptr, dL_dimg);
+        if (tiled) hipLaunchKernelGGL(k_ssim_grad, grid, dim3(256), 0, st, height, width, img, gt, win, dM1, dX2, dXY, gs, gl, (const float*)nullptr, dL_dimg);
+        else hipLaunchKernelGGL(k_ssim_grad_stream, sgrid, dim3(256), 0, st, height, width, nstrips, img, gt, win, dM1, dX2, dXY, gs, gl, (const float*)nullptr, dL_dimg);
     }
     return hip_status("tgs_l1_ssim");
 }
@@ -311,7 +514,10 @@ int tgs_l1_ssim_backward(void* stream, int planes, int height, int width, const 
     const float* dXY = dX2 + n;
     const LossWin win = make_window();
     const float gs = (float)(-(double)dssim_factor / (double)n), gl = (float)((1.0 - (double)dssim_factor) / (double)n);
-    hipLaunchKernelGGL(k_ssim_grad, grid, dim3(256), 0, st, height, width, img, gt, win, dM1, dX2, dXY, gs, gl, upstream, dL_dimg);
+    int nstrips = 0;
+    const dim3 sgrid = stream_grid(planes, height, width, nstrips);
+    if (loss_tiled()) hipLaunchKernelGGL(k_ssim_grad, grid, dim3(256), 0, st, height, width, img, gt, win, dM1, dX2, dXY, gs, gl, upstream, dL_dimg);
+    else hipLaunchKernelGGL(k_ssim_grad_stream, sgrid, dim3(256), 0, st, height, width, nstrips, img, gt, win, dM1, dX2, dXY, gs, gl, upstream, dL_dimg);
     return hip_status("tgs_l1_ssim_backward");
 }
 }

@@ -60,7 +60,8 @@ c10::Device require_gpu(const torch::Tensor& means3D)
 int sh_coeffs(const torch::Tensor& sh) { return (sh.dim() > 1 && sh.size(0) != 0) ? (int)sh.size(1) : 0; }   // rasterize_points.cu:83-87
 
 // keyword-only extensions -> tgs_options_t (None / 0 = library defaults)
-tgs_options_t make_options(int64_t tile_bound, c10::optional<bool> pruning, c10::optional<bool> deterministic, int64_t sort_lds_cap)
+tgs_options_t make_options(int64_t tile_bound, c10::optional<bool> pruning, c10::optional<bool> deterministic, int64_t sort_lds_cap, int64_t mid_bound,
+                           c10::optional<bool> light_tiles)
 {
     tgs_options_t o;
     memset(&o, 0, sizeof(o));
@@ -69,20 +70,21 @@ tgs_options_t make_options(int64_t tile_bound, c10::optional<bool> pruning, c10:
     o.deterministic = deterministic ? (*deterministic ? 1 : 0) : -1;
     o.sort_lds_cap = sort_lds_cap > 0 ? (uint32_t)sort_lds_cap : 0u;
     o.tile_bound = tile_bound > 0 ? tile_bound : 0;
-    o.render_split = -1;
+    o.mid_bound = mid_bound > 0 ? mid_bound : 0;
+    o.light_tiles = light_tiles ? (*light_tiles ? 1 : 0) : -1;
     return o;
 }
 
 // RasterizeGaussiansCUDA (rasterize_points.cu:35-115).  r_capacity / r_guess: the sync-free / speculative forwards of
 // include/tgs_raster.h (extensions; None = the reference's protocol).  With r_guess or info=True the tuple has two more elements: the true
-// num_rendered and the number of tiles with instances (-1 where the call did not read the frame's Meta).  tile_bound / pruning /
+// num_rendered and the pair (tiles with instances, tiles with >= 128 instances) (-1 where the call did not read the frame's Meta).  tile_bound / pruning /
 // sort_lds_cap travel as an explicit tgs_options_t: nothing process-wide is touched, so threads with different options do not interfere.
 py::tuple rasterize_gaussians(const torch::Tensor& background, const torch::Tensor& means3D, const torch::Tensor& colors, const torch::Tensor& opacity,
                               const torch::Tensor& scales, const torch::Tensor& rotations, float scale_modifier, const torch::Tensor& cov3D_precomp,
                               const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix, float tan_fovx, float tan_fovy, int image_height,
                               int image_width, const torch::Tensor& sh, int degree, const torch::Tensor& campos, bool prefiltered, bool debug,
                               c10::optional<int64_t> r_capacity, c10::optional<int64_t> r_guess, int64_t tile_bound, c10::optional<bool> pruning,
-                              int64_t sort_lds_cap, bool info)
+                              int64_t sort_lds_cap, bool info, int64_t mid_bound, c10::optional<bool> light_tiles)
 {
     if (means3D.dim() != 2 || means3D.size(1) != 3) throw std::runtime_error("means3D must have dimensions (num_points, 3)");   // rasterize_points.cu:57-59
     const c10::Device dev = require_gpu(means3D);
@@ -97,7 +99,7 @@ py::tuple rasterize_gaussians(const torch::Tensor& background, const torch::Tens
         sc(scales, dev, "scales"), rot(rotations, dev, "rotations"), cov(cov3D_precomp, dev, "cov3D_precomp"), view(viewmatrix, dev, "viewmatrix"),
         proj(projmatrix, dev, "projmatrix"), shs(sh, dev, "sh"), cam(campos, dev, "campos");
     void* stream = (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream();
-    const tgs_options_t opt = make_options(tile_bound, pruning, c10::nullopt, sort_lds_cap);
+    const tgs_options_t opt = make_options(tile_bound, pruning, c10::nullopt, sort_lds_cap, mid_bound, light_tiles);
     tgs_frame_info_t fi;
     const int mode = r_guess ? TGS_FWD_SPECULATIVE : (r_capacity ? TGS_FWD_ASYNC : TGS_FWD_SYNC);
     int64_t r;
@@ -108,7 +110,7 @@ py::tuple rasterize_gaussians(const torch::Tensor& background, const torch::Tens
                             P ? radii.data_ptr<int>() : nullptr, debug);
     }
     if (r < 0) raise_last(r);
-    if (r_guess || info) return py::make_tuple(r, out_color, radii, bufs[0], bufs[1], bufs[2], fi.num_rendered, fi.nonempty_tiles);
+    if (r_guess || info) return py::make_tuple(r, out_color, radii, bufs[0], bufs[1], bufs[2], fi.num_rendered, py::make_tuple(fi.nonempty_tiles, (int64_t)fi.mid_tiles));
     return py::make_tuple(r, out_color, radii, bufs[0], bufs[1], bufs[2]);
 }
 
@@ -119,7 +121,7 @@ py::tuple rasterize_gaussians_backward(const torch::Tensor& background, const to
                                        const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix, float tan_fovx, float tan_fovy,
                                        const torch::Tensor& dL_dout_color, const torch::Tensor& sh, int degree, const torch::Tensor& campos,
                                        const torch::Tensor& geomBuffer, int64_t R, const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer, bool debug,
-                                       bool with_conic, int64_t tile_bound, c10::optional<bool> deterministic)
+                                       bool with_conic, int64_t tile_bound, c10::optional<bool> deterministic, int64_t mid_bound, c10::optional<bool> light_tiles)
 {
     const c10::Device dev = require_gpu(means3D);
     const int P = (int)means3D.size(0), H = (int)dL_dout_color.size(1), W = (int)dL_dout_color.size(2), M = sh_coeffs(sh);
@@ -138,7 +140,7 @@ py::tuple rasterize_gaussians_backward(const torch::Tensor& background, const to
             dL(dL_dout_color, dev, "dL_dout_color");
         const torch::Tensor radii_c = radii.contiguous();
         void* stream = (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream();
-        const tgs_options_t opt = make_options(tile_bound, c10::nullopt, deterministic, 0);
+        const tgs_options_t opt = make_options(tile_bound, c10::nullopt, deterministic, 0, mid_bound, light_tiles);
         int r;
         {
             py::gil_scoped_release nogil;
@@ -179,12 +181,12 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
           py::arg("rotations"), py::arg("scale_modifier"), py::arg("cov3D_precomp"), py::arg("viewmatrix"), py::arg("projmatrix"), py::arg("tan_fovx"),
           py::arg("tan_fovy"), py::arg("image_height"), py::arg("image_width"), py::arg("sh"), py::arg("degree"), py::arg("campos"), py::arg("prefiltered"),
           py::arg("debug"), py::arg("r_capacity") = py::none(), py::arg("r_guess") = py::none(), py::arg("tile_bound") = 0, py::arg("pruning") = py::none(),
-          py::arg("sort_lds_cap") = 0, py::arg("info") = false);
+          py::arg("sort_lds_cap") = 0, py::arg("info") = false, py::arg("mid_bound") = 0, py::arg("light_tiles") = py::none());
     m.def("rasterize_gaussians_backward", &rasterize_gaussians_backward, py::arg("background"), py::arg("means3D"), py::arg("radii"), py::arg("colors"),
           py::arg("scales"), py::arg("rotations"), py::arg("scale_modifier"), py::arg("cov3D_precomp"), py::arg("viewmatrix"), py::arg("projmatrix"),
           py::arg("tan_fovx"), py::arg("tan_fovy"), py::arg("dL_dout_color"), py::arg("sh"), py::arg("degree"), py::arg("campos"), py::arg("geomBuffer"),
           py::arg("R"), py::arg("binningBuffer"), py::arg("imageBuffer"), py::arg("debug"), py::arg("_with_conic") = false, py::arg("tile_bound") = 0,
-          py::arg("deterministic") = py::none());
+          py::arg("deterministic") = py::none(), py::arg("mid_bound") = 0, py::arg("light_tiles") = py::none());
     m.def("mark_visible", &mark_visible);
     m.def("abi_version", []() { return tgs_abi_version(); });
     m.def("compiled_abi_version", []() { return TGS_ABI_VERSION; });      // the header THIS module was compiled against

@@ -193,24 +193,24 @@ class _OptionsT(C.Structure):
     """tgs_options_t (include/tgs_raster.h): everything that tunes one call, passed explicitly -- nothing process-wide is touched"""
     _fields_ = [("struct_size", C.c_uint32), ("instance_pruning", C.c_int32), ("deterministic", C.c_int32), ("forward_group", C.c_int32),
                 ("sort_lds_cap", C.c_uint32), ("tile_bound", C.c_int64), ("heavy_bound", C.c_int64), ("mid_bound", C.c_int64),
-                ("render_split", C.c_int32), ("reserved", C.c_int32)]
+                ("light_tiles", C.c_int32), ("reserved", C.c_int32)]
 
 
 class _FrameInfoT(C.Structure):
     """tgs_frame_info_t"""
-    _fields_ = [("num_rendered", C.c_int64), ("nonempty_tiles", C.c_int64), ("flags", C.c_int32), ("reserved", C.c_int32)]
+    _fields_ = [("num_rendered", C.c_int64), ("nonempty_tiles", C.c_int64), ("flags", C.c_int32), ("mid_tiles", C.c_int32)]
 
 
 def options(tile_bound: int = 0, pruning: Optional[bool] = None, deterministic: Optional[bool] = None, forward_group: int = 0, sort_lds_cap: int = 0,
-            render_split: Optional[bool] = None) -> _OptionsT:
+            light_tiles: Optional[bool] = None, mid_bound: int = 0, heavy_bound: int = 0) -> _OptionsT:
     """A filled tgs_options_t (None / 0: the library default of that field)."""
     o = _OptionsT()
     o.struct_size = C.sizeof(_OptionsT)
     o.instance_pruning = -1 if pruning is None else int(bool(pruning))
     o.deterministic = -1 if deterministic is None else int(bool(deterministic))
     o.forward_group, o.sort_lds_cap = int(forward_group), int(sort_lds_cap)
-    o.tile_bound = max(0, int(tile_bound))
-    o.render_split = -1 if render_split is None else int(bool(render_split))
+    o.tile_bound, o.mid_bound, o.heavy_bound = max(0, int(tile_bound)), max(0, int(mid_bound)), max(0, int(heavy_bound))
+    o.light_tiles = -1 if light_tiles is None else int(bool(light_tiles))
     return o
 
 
@@ -248,7 +248,8 @@ def _require_gpu(means3D: torch.Tensor) -> torch.device:
 def _rasterize_gaussians_ctypes(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                                 viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
                                 prefiltered, debug, r_capacity: Optional[int] = None, r_guess: Optional[int] = None, tile_bound: int = 0,
-                                pruning: Optional[bool] = None, sort_lds_cap: int = 0, info: bool = False
+                                pruning: Optional[bool] = None, sort_lds_cap: int = 0, info: bool = False, mid_bound: int = 0,
+                                light_tiles: Optional[bool] = None
                                 ) -> Tuple[int, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     """RasterizeGaussiansCUDA (rasterize_points.cu:35-115) over ctypes -- kept for A/B measurements of the host cost
     (``TGS_CTYPES_GLUE=1``); the module-level ``rasterize_gaussians`` is the compiled one (csrc/tgs_torch_ext.cpp).
@@ -260,7 +261,8 @@ def _rasterize_gaussians_ctypes(background, means3D, colors, opacity, scales, ro
     ``r_guess`` (extension, tgs_forward_speculative): the complete frame like the plain call, but the stages behind the scan are
     enqueued against the guessed instance count while the read-back is in flight (they run again if the guess was too small).
     Returns an 8-tuple then (also with ``info=True``): the value to pass as ``R`` to the backward / ``state_field`` first, the true
-    num_rendered and the number of tiles with instances last.  ``tile_bound`` / ``pruning`` / ``sort_lds_cap``: tgs_options_t fields."""
+    num_rendered and the pair (tiles with instances, tiles with >= 128 instances) last -- the exact ``tile_bound`` / ``mid_bound`` of the
+    frame's backward.  ``tile_bound`` / ``pruning`` / ``sort_lds_cap``: tgs_options_t fields."""
     if means3D.dim() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     dev = _require_gpu(means3D)
@@ -286,13 +288,13 @@ def _rasterize_gaussians_ctypes(background, means3D, colors, opacity, scales, ro
                 _p(t["sh"]), _p(t["colors"]), _p(t["opac"]), _p(t["scales"]), float(scale_modifier), _p(t["rots"]),
                 _p(t["cov"]), _p(t["view"]), _p(t["proj"]), _p(t["campos"]), float(tan_fovx), float(tan_fovy),
                 int(bool(prefiltered)), out_color.data_ptr(), _p(radii) if P else None, int(bool(debug)))
-        opt, fi = options(tile_bound=tile_bound, pruning=pruning, sort_lds_cap=sort_lds_cap), _FrameInfoT()
+        opt, fi = options(tile_bound=tile_bound, pruning=pruning, sort_lds_cap=sort_lds_cap, mid_bound=mid_bound, light_tiles=light_tiles), _FrameInfoT()
         mode, rr = (2, int(r_guess)) if r_guess is not None else ((1, int(r_capacity)) if r_capacity is not None else (0, 0))
         r = _lib.tgs_forward_opt(C.byref(opt), mode, rr, C.byref(fi), *args)
         if r < 0:
             raise _err(int(r))
     if r_guess is not None or info:
-        return int(r), out_color, radii, bufs[0], bufs[1], bufs[2], int(fi.num_rendered), int(fi.nonempty_tiles)
+        return int(r), out_color, radii, bufs[0], bufs[1], bufs[2], int(fi.num_rendered), (int(fi.nonempty_tiles), int(fi.mid_tiles))
     return int(r), out_color, radii, bufs[0], bufs[1], bufs[2]
 
 
@@ -344,7 +346,7 @@ def frame_status(image_buffer: torch.Tensor) -> Tuple[int, int]:
 def _rasterize_gaussians_backward_ctypes(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                          viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos,
                                          geomBuffer, R, binningBuffer, imageBuffer, debug, _with_conic=False, tile_bound: int = 0,
-                                         deterministic: Optional[bool] = None):
+                                         deterministic: Optional[bool] = None, mid_bound: int = 0, light_tiles: Optional[bool] = None):
     """RasterizeGaussiansBackwardCUDA (rasterize_points.cu:117-196) over ctypes (see _rasterize_gaussians_ctypes); return order of :195.
     ``_with_conic`` (tests only) appends the scratch tensor dL_dconic[P,2,2]."""
     dev = _require_gpu(means3D)
@@ -366,7 +368,7 @@ def _rasterize_gaussians_backward_ctypes(background, means3D, radii, colors, sca
                 dL_dscales.zero_(); dL_drotations.zero_()
             radii_c = radii.contiguous()
             stream = torch.cuda.current_stream(dev).cuda_stream
-            opt = options(tile_bound=tile_bound, deterministic=deterministic)
+            opt = options(tile_bound=tile_bound, deterministic=deterministic, mid_bound=mid_bound, light_tiles=light_tiles)
             r = _lib.tgs_backward_opt(C.byref(opt), 0, stream, P, int(degree), M, int(R), _p(t["bg"]), W, H, _p(t["means"]), _p(t["sh"]), _p(t["colors"]),
                                   _p(t["scales"]), float(scale_modifier), _p(t["rots"]), _p(t["cov"]), _p(t["view"]), _p(t["proj"]),
                                   _p(t["campos"]), float(tan_fovx), float(tan_fovy), radii_c.data_ptr(), geomBuffer.data_ptr(),
@@ -384,7 +386,7 @@ def _rasterize_gaussians_backward_ctypes(background, means3D, radii, colors, sca
 def rasterize_gaussians_backward_accumulate(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                             viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos,
                                             geomBuffer, R, binningBuffer, imageBuffer, debug, into, tile_bound: int = 0,
-                                            deterministic: Optional[bool] = None):
+                                            deterministic: Optional[bool] = None, mid_bound: int = 0):
     """Multi-view extension (tgs_backward_accumulate): parameter gradients are ADDED into the fp32 tensors of ``into``
     (keys: means3D, opacities, and sh|colors_precomp, scales+rotations|cov3D_precomp; contiguous, on the device).
     Returns dL_dmeans2D[P,3], the only per-view gradient."""
@@ -412,7 +414,7 @@ def rasterize_gaussians_backward_accumulate(background, means3D, radii, colors, 
             return g.data_ptr()
 
         has_sh, has_sr = t["sh"] is not None, t["scales"] is not None
-        opt = options(tile_bound=tile_bound, deterministic=deterministic)
+        opt = options(tile_bound=tile_bound, deterministic=deterministic, mid_bound=mid_bound)
         r = _lib.tgs_backward_opt(
             C.byref(opt), 1, torch.cuda.current_stream(dev).cuda_stream, P, int(degree), M, int(R), _p(t["bg"]), W, H, _p(t["means"]), _p(t["sh"]), _p(t["colors"]),
             _p(t["scales"]), float(scale_modifier), _p(t["rots"]), _p(t["cov"]), _p(t["view"]), _p(t["proj"]), _p(t["campos"]),

@@ -115,17 +115,17 @@ class _RasterizeGaussians(torch.autograd.Function):
         if guess is not None:
             # the grids of the stages enqueued ahead of the read-back cover a guessed number of tiles with instances, not all tiles
             tile_guess = _speculation.tile_guess(key)
-            num_rendered, color, radii, geom, binning, img, true_R, tiles = _call_native(
+            num_rendered, color, radii, geom, binning, img, true_R, (tiles, mid_tiles) = _call_native(
                 lambda *a: _C.rasterize_gaussians(*a, r_guess=guess, tile_bound=tile_guess), args, rs.debug, "snapshot_fw.dump", "forward")
         else:
-            num_rendered, color, radii, geom, binning, img, true_R, tiles = _call_native(
+            num_rendered, color, radii, geom, binning, img, true_R, (tiles, mid_tiles) = _call_native(
                 lambda *a: _C.rasterize_gaussians(*a, info=True), args, rs.debug, "snapshot_fw.dump", "forward")
-        # tiles: tiles with instances of THIS frame (the forward has read its Meta); -1: unknown
+        # tiles / mid_tiles: tiles with instances / with >= 128 instances of THIS frame (the forward has read its Meta); -1: unknown
         if _SPECULATE:
             _speculation.update(key, true_R, guess, tiles, tile_guess)
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
-        ctx.nonempty_tiles = tiles
+        ctx.nonempty_tiles, ctx.mid_tiles = tiles, mid_tiles
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img)
         ctx.mark_non_differentiable(radii)
         return color, radii
@@ -139,9 +139,11 @@ class _RasterizeGaussians(torch.autograd.Function):
                 rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, sh, rs.sh_degree, rs.campos, geom, ctx.num_rendered,
                 binning, img, rs.debug)
         # the per-pixel backward visits the tiles with instances only: their number is known exactly from the forward's read-back
+        # (and the 1024-thread kernel only the ones with >= 128 instances; the rest take the 256-thread one)
         bound = ctx.nonempty_tiles if ctx.nonempty_tiles > 0 else 0
+        mid = max(ctx.mid_tiles, 1) if (bound > 0 and ctx.mid_tiles >= 0) else 0
         (g_means2D, g_colors, g_opac, g_means3D, g_cov3D, g_sh, g_scales, g_rots) = _call_native(
-            lambda *a: _C.rasterize_gaussians_backward(*a, tile_bound=bound), args, rs.debug, "snapshot_bw.dump", "backward")
+            lambda *a: _C.rasterize_gaussians_backward(*a, tile_bound=bound, mid_bound=mid), args, rs.debug, "snapshot_bw.dump", "backward")
         # forward-argument order (__init__.py:143-153); all eight are always returned
         return g_means3D, g_means2D, g_sh, g_colors, g_opac, g_scales, g_rots, g_cov3D, None
 

@@ -24,6 +24,10 @@ _lib.tgs_sh_rgb_forward.restype = C.c_int
 _lib.tgs_sh_rgb_forward.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5
 _lib.tgs_sh_rgb_backward.restype = C.c_int
 _lib.tgs_sh_rgb_backward.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 8
+_lib.tgs_sh_rgb_dcrest_forward.restype = C.c_int
+_lib.tgs_sh_rgb_dcrest_forward.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6
+_lib.tgs_sh_rgb_dcrest_backward.restype = C.c_int
+_lib.tgs_sh_rgb_dcrest_backward.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 10
 
 
 def _check(t: torch.Tensor, name: str, dev) -> torch.Tensor:
@@ -73,6 +77,81 @@ class _SHColor(torch.autograd.Function):
         if r < 0:
             raise _rast_c._err(r)
         return d_sh, d_pos, None, d_dir, None
+
+
+class _SHColorDcRest(torch.autograd.Function):
+    """colours from the two parameter tensors the reference keeps (tetgs_model.py:234-239), no ``torch.cat`` (tgs_sh_rgb_dcrest_*)"""
+
+    @staticmethod
+    def forward(ctx, sh_dc, sh_rest, positions, camera_center, directions, sh_levels):
+        dev = sh_dc.device
+        dc = _check(sh_dc, "sh_coordinates_dc", dev)
+        if dc.dim() != 3 or dc.shape[1] != 1 or dc.shape[2] != 3:
+            raise RuntimeError("sh_coordinates_dc must have dimensions (num_points, 1, 3)")
+        P = int(dc.shape[0])
+        levels = int(sh_levels)
+        rest = _check(sh_rest, "sh_coordinates_rest", dev) if (sh_rest is not None and sh_rest.numel()) else None
+        Mr = int(rest.shape[1]) if rest is not None else 0
+        if rest is not None and (rest.dim() != 3 or rest.shape[0] != P or rest.shape[2] != 3):
+            raise RuntimeError("sh_coordinates_rest must have dimensions (num_points, M - 1, 3)")
+        pos = _check(positions, "positions", dev) if positions is not None else None
+        cam = _check(camera_center.reshape(-1), "camera_centers", dev) if camera_center is not None else None
+        dirs = _check(directions, "directions", dev) if directions is not None else None
+        colors = torch.empty((P, 3), dtype=torch.float32, device=dev)
+        p = lambda t: None if t is None else t.data_ptr()
+        with torch.cuda.device(dev):
+            r = _lib.tgs_sh_rgb_dcrest_forward(torch.cuda.current_stream(dev).cuda_stream, P, Mr, levels, p(dc), p(rest), p(pos), p(cam), p(dirs), colors.data_ptr())
+        if r < 0:
+            raise _rast_c._err(r)
+        e = torch.Tensor([])
+        ctx.save_for_backward(dc, rest if rest is not None else e, pos if pos is not None else e, cam if cam is not None else e, dirs if dirs is not None else e)
+        ctx.levels = levels
+        return colors
+
+    @staticmethod
+    def backward(ctx, grad_colors):
+        dc, rest, pos, cam, dirs = ctx.saved_tensors
+        dev = dc.device
+        P = int(dc.shape[0])
+        rest = rest if rest.numel() else None
+        pos = pos if pos.numel() else None
+        cam = cam if cam.numel() else None
+        dirs = dirs if dirs.numel() else None
+        Mr = int(rest.shape[1]) if rest is not None else 0
+        g = _check(grad_colors, "grad_colors", dev)
+        d_dc = torch.empty_like(dc)
+        # levels == 1: the rest rows get exactly zero gradient -- returned as None (no 180 B of zeros per Gaussian written, read by the optimiser ...)
+        d_rest = torch.empty_like(rest) if (rest is not None and ctx.levels > 1) else None
+        d_pos = torch.empty_like(pos) if pos is not None else None
+        d_dir = torch.empty_like(dirs) if dirs is not None else None
+        p = lambda t: None if t is None else t.data_ptr()
+        with torch.cuda.device(dev):
+            r = _lib.tgs_sh_rgb_dcrest_backward(torch.cuda.current_stream(dev).cuda_stream, P, Mr, ctx.levels, p(dc), p(rest), p(pos), p(cam), p(dirs), g.data_ptr(),
+                                                d_dc.data_ptr(), p(d_rest), p(d_pos), p(d_dir))
+        if r < 0:
+            raise _rast_c._err(r)
+        return d_dc, d_rest, d_pos, None, d_dir, None
+
+
+def points_rgb_dc_rest(sh_coordinates_dc: torch.Tensor, sh_coordinates_rest: Optional[torch.Tensor], sh_levels: int,
+                       positions: Optional[torch.Tensor] = None, camera_centers: Optional[torch.Tensor] = None,
+                       directions: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``points_rgb`` on the model's own two parameters: ``_sh_coordinates_dc`` [P,1,3] and ``_sh_coordinates_rest`` [P,M-1,3] (or None for
+    a one-level model) instead of ``self.sh_coordinates`` -- which is ``torch.cat([dc, rest], dim=1)`` on every access
+    (tetgs_model.py:268-272): a 192-B read + 192-B write per Gaussian in front of every render and the split of its gradient behind it.
+    Gradients arrive on the two parameters directly; with ``sh_levels == 1`` the rest parameter gets none (``.grad`` stays ``None`` -- the
+    reference hands it a tensor of zeros there)."""
+    if sh_levels > 1 and (sh_coordinates_rest is None or sh_coordinates_rest.shape[1] < sh_levels ** 2 - 1):
+        raise ValueError("sh_coordinates_rest must hold at least sh_levels**2 - 1 coefficient rows")
+    if camera_centers is not None:
+        if positions is None:
+            raise ValueError("positions are required with camera_centers")
+        if camera_centers.numel() != 3:
+            raise ValueError("one camera centre ([3] or [1,3]) is supported")
+        return _SHColorDcRest.apply(sh_coordinates_dc, sh_coordinates_rest, positions, camera_centers, None, sh_levels)
+    if directions is not None:
+        return _SHColorDcRest.apply(sh_coordinates_dc, sh_coordinates_rest, None, None, directions, sh_levels)
+    raise ValueError("Either camera_centers or directions must be provided.")
 
 
 def points_rgb(sh_coordinates: torch.Tensor, sh_levels: int, positions: Optional[torch.Tensor] = None,
