@@ -402,6 +402,7 @@ def secondary_workloads(a, cloud, dev, D, W, H, headline_ms):
     from youreditableavatar_amd.loss import l1_ssim_loss
     from youreditableavatar_amd.multiview import FlatGradients, SyncFreeBatch
     from youreditableavatar_amd.sh_color import points_rgb_dc_rest
+    from youreditableavatar_amd.bindings import gaussian_bind
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _C
     P = cloud["means3D"].shape[0]
     g = lambda x, rg=False: torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev).requires_grad_(rg)
@@ -448,22 +449,26 @@ def secondary_workloads(a, cloud, dev, D, W, H, headline_ms):
     # _sh_coordinates_rest [P,15,3]; the inpainting-stage models have one level and no rest tensor
     sh_dc = g(cloud["shs"][:, :1], True)
     sh_rest = g(cloud["shs"][:, 1:], True)
+    # ... and its raw geometry parameters (tetgs_model.py:196-229): densities before the sigmoid, log-scales, unnormalised quaternions
+    op_np = np.clip(cloud["opacities"], 1e-4, 1 - 1e-4)
+    raw = {"all_densities": g(np.log(op_np / (1 - op_np)), True), "_scales": g(np.log(cloud["scales"]), True), "_quaternions": g(cloud["rotations"], True)}
     for deg in (0, 3):
         S2 = settings_for(TW, TH, deg, 16)
         colour_params = [sh_dc] + ([sh_rest] if deg > 0 else [])
 
         def train_step(i, S2=S2, deg=deg, colour_params=colour_params):
             rs = S2[i % len(S2)]
-            for t in list(leaves.values()) + colour_params:
+            for t in [leaves["means3D"]] + list(raw.values()) + colour_params:
                 t.grad = None
             colors = points_rgb_dc_rest(sh_dc, sh_rest if deg > 0 else None, deg + 1, positions=leaves["means3D"], camera_centers=rs.campos)
+            opacities, scales_a, rotations_a, _ = gaussian_bind(raw["all_densities"], raw["_scales"], raw["_quaternions"])   # strengths / scaling / quaternions
             m2 = torch.zeros(P, 3, device=dev, requires_grad=True)
-            img, _radii = GaussianRasterizer(rs)(means3D=leaves["means3D"], means2D=m2, opacities=leaves["opacities"], colors_precomp=colors,
-                                                 scales=leaves["scales"], rotations=leaves["rotations"])
+            img, _radii = GaussianRasterizer(rs)(means3D=leaves["means3D"], means2D=m2, opacities=opacities, colors_precomp=colors,
+                                                 scales=scales_a, rotations=rotations_a)
             l1_ssim_loss(img, gt, 0.2).backward()
         tp[f"sh{deg}"] = round(timed(train_step, 30, 10), 4)
-    res["trainer_protocol"] = {"ms_per_step": tp, "what": f"{P} Gaussians, 2048x2048, one view per step: sh_color.points_rgb_dc_rest (the model's dc / rest parameters, no "
-                               "torch.cat) -> GaussianRasterizer(colors_precomp) -> l1_ssim_loss -> backward, all through autograd (SH degree 0: the inpainting stage, "
+    res["trainer_protocol"] = {"ms_per_step": tp, "what": f"{P} Gaussians, 2048x2048, one view per step from the model's RAW parameters: bindings.gaussian_bind (sigmoid / exp / normalize, "
+                               "one kernel) + sh_color.points_rgb_dc_rest (dc / rest parameters, no torch.cat) -> GaussianRasterizer(colors_precomp) -> l1_ssim_loss -> backward, all through autograd (SH degree 0: the inpainting stage, "
                                "a one-level model, 16 800 of the reference's ~22 800 rasterizer iterations; 3: refinement)"}
     del gt
     # ---- grown splats through the headline path

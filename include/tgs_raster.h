@@ -251,6 +251,20 @@ int tgs_sh_rgb_dcrest_backward(void* stream, int P, int M_rest, int levels, cons
                                const float* camera_center, const float* directions, const float* dL_dcolors, float* dL_dsh_dc, float* dL_dsh_rest,
                                float* dL_dpositions, float* dL_ddirections);
 
+/* ---- the binding side (BASELINE.json: "tetgs_scene Gaussian model bindings") ----
+ * What the model classes do in front of every rasterizer call, each as a framework kernel of its own plus its backward
+ * (Edit_core/tetgs_scene/tetgs_model.py): strengths :261-265 opacity = sigmoid(all_densities); scaling :279-281 scales = exp(_scales);
+ * quaternions :283-286 quats = x / max(|x|, 1e-12); points :252-258 points = ori_points + normals * _points (one learnable offset per
+ * mesh-bound Gaussian).  One kernel forward, one backward.  Every group is optional: pass NULL for its inputs AND outputs.
+ * raw_density[P,1] raw_scales[P,3] raw_quats[P,4] ori_points[P,3] normals[P,3] deltas[P,1] -> opacity[P,1] scales[P,3] quats[P,4] points[P,3].
+ * The backward takes the forward's OUTPUTS opacity / scales (sigmoid' and exp' from their values), the inputs raw_quats / normals, the
+ * incoming gradients g_*, and writes the requested d_* (a NULL d_* is skipped). */
+int tgs_bind_forward(void* stream, int P, const float* raw_density, const float* raw_scales, const float* raw_quats, const float* ori_points,
+                     const float* normals, const float* deltas, float* opacity, float* scales, float* quats, float* points);
+int tgs_bind_backward(void* stream, int P, const float* raw_quats, const float* normals, const float* opacity, const float* scales,
+                      const float* g_opacity, const float* g_scales, const float* g_quats, const float* g_points,
+                      float* d_density, float* d_scales, float* d_quats, float* d_deltas);
+
 /* ---- "next" row 4: simple-knn ----
  * distCUDA2 (Edit_core/thirdparties/simple-knn/spatial.cu:15-26 -> SimpleKNN::knn, simple_knn.cu:185-221):
  * mean_dist2[i] = mean of the 3 smallest squared distances from points[i] to the other points (FLT_MAX terms, i.e.

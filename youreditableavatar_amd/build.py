@@ -15,9 +15,16 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, os.environ.get("TGS_LIB_NAME", "libtgs_raster.so"))       # TGS_LIB_NAME: build a variant next to the default one
-SOURCES = ["tgs_forward.hip", "tgs_backward.hip", "tgs_api.hip", "tgs_shcolor.hip", "tgs_knn.hip", "tgs_loss.hip"]
+SOURCES = ["tgs_forward.hip", "tgs_backward.hip", "tgs_api.hip", "tgs_shcolor.hip", "tgs_knn.hip", "tgs_loss.hip", "tgs_bind.hip"]
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+# -fno-slp-vectorize: the SLP vectoriser pairs scalar f32 operations into v_pk_fma_f32 / v_pk_mul_f32, which on gfx950 issue no faster than
+# the two scalar instructions (MI355X_MICROARCH.md: packed f32 VALU is an anti-lever) while the pairing costs registers and moves:
+# k_preprocess_bwd_batch_split 166 -> 127 VGPRs (3 -> 4 waves per SIMD), k_preprocess_bwd<false,true> 108 -> 72, the streaming SSIM kernels
+# 138 -> 86 / 91 -> 68.  Measured on the MI355X (round 3, A/B by library): every kernel of the frame 3-7 % faster, the 8-view step
+# 2.04 -> 1.97 ms, the drop-in frame 0.386 -> 0.376 ms.
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
+# Per-source flags (none at the moment; the hook stays for A/B builds of one file)
+EXTRA_FLAGS = {}
 # experiment knobs, e.g. TGS_DEFINES="-DTGS_FAST_MATH=0" python -m youreditableavatar_amd.build --force
 FLAGS += os.environ.get("TGS_DEFINES", "").split()
 
@@ -82,7 +89,7 @@ def _build_native_locked(verbose: bool) -> str:
 
     def compile_one(src):
         obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
-        cmd = [cc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [cc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -92,7 +99,7 @@ def _build_native_locked(verbose: bool) -> str:
             print(r.stderr, file=sys.stderr)
         return obj
 
-    with ThreadPoolExecutor(max_workers=6) as ex:
+    with ThreadPoolExecutor(max_workers=7) as ex:
         objs = list(ex.map(compile_one, SOURCES))
     tmp = LIB + f".tmp{os.getpid()}"
     cmd = [cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", tmp, *objs]

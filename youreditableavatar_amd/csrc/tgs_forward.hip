@@ -664,6 +664,15 @@ __global__ __launch_bounds__(256) void k_bin_colscan(const ImgState s, uint32_t 
 // ---------------------------------------------------------------------------------------------
 // k_scatter: instance -> its tile's segment.  Also finishes the Gaussian offsets (exclusive scan).
 // ---------------------------------------------------------------------------------------------
+#ifndef TGS_SCATTER_XCD_MAJOR
+#define TGS_SCATTER_XCD_MAJOR 1
+#endif
+// bijection workgroup b -> chunk (n of each): the workgroups with b % 8 == x take chunks [start_x, start_x + count_x) in the order of b / 8
+__device__ __forceinline__ uint32_t xcd_major(uint32_t b, uint32_t n)
+{
+    const uint32_t x = b & 7u, q = n >> 3, r = n & 7u;
+    return x * q + min(x, r) + (b >> 3);
+}
 __global__ __launch_bounds__(BIN_THREADS) void k_scatter(int P, uint32_t chunk, const GeomState g, const ImgState s, const BinState b, uint32_t gx, uint32_t T, uint32_t band)
 {
     extern __shared__ uint32_t bin_lds[];                   // min(T, band) cursors: absolute positions in b.keys
@@ -671,8 +680,14 @@ __global__ __launch_bounds__(BIN_THREADS) void k_scatter(int P, uint32_t chunk, 
     __shared__ uint32_t wtot[2][BIN_THREADS / WAVE];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (frame_rejected(s)) return;
-    const uint32_t lo = blockIdx.x * chunk;
-    const uint32_t* row = s.bin_table + (size_t)blockIdx.x * T;
+    // Which chunk this workgroup scatters.  Inside a tile's segment the instances lie in chunk order (k_bin_colscan), ~2 keys = 18 B per chunk
+    // and tile at config 3: every store is a partial line, and the L2 of an XCD can only merge the partial lines its OWN workgroups write.
+    // Workgroups b, b + 8, b + 16 ... share an XCD (observed round-robin placement; used for speed only, any mapping is correct), so XCD x
+    // takes a CONSECUTIVE range of chunks: its 16 runs in a tile's segment are adjacent (~290 B) and leave the L2 as whole lines
+    // (WRITE_SIZE of this kernel 38 MB -> see DESIGN.md for 6 MB of keys with chunk = workgroup index).
+    const uint32_t w = TGS_SCATTER_XCD_MAJOR ? xcd_major(blockIdx.x, gridDim.x) : blockIdx.x;
+    const uint32_t lo = w * chunk;
+    const uint32_t* row = s.bin_table + (size_t)w * T;
     for (uint32_t band0 = 0; band0 < T; band0 += band) {
         const uint32_t nb = min(band, T - band0);
         for (uint32_t i = threadIdx.x; i < nb; i += BIN_THREADS) bin_lds[i] = s.ranges[band0 + i].x + row[band0 + i];

@@ -263,9 +263,10 @@ constexpr int SS_OUT = WAVE - 2 * LR;       // 54 output columns per wave
 #endif
 constexpr int SS_SEG = TGS_SS_SEG;          // output rows per wave
 
-__device__ __forceinline__ float wave_shr1(float v)     // lane i <- lane i - 1 (lane 0 keeps an unspecified value: never used)
+__device__ __forceinline__ float wave_shr1(float v)     // lane i <- lane i - 1 (lane 0 gets 0: never used)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+    // (bound_ctrl: the lane without a source reads 0, so the compiler need not preset the destination -- one instruction, not two)
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
 }
 
 struct StripGeom { int col_in, col_out, y0, y1; bool in_x, out_ok, own_col; size_t plane; };
@@ -299,10 +300,14 @@ __device__ __forceinline__ void stats_row(float x, float y, int r, const StripGe
         hx += wx; hy += wy; hxx += wx * xs; hyy += wy * ys; hxy += wx * ys;
         if (j + 1 < NTAP) { xs = wave_shr1(xs); ys = wave_shr1(ys); }
     }
+    {   // tap 0 opens the running sums of output row r + 5 (slot (P + 10) % 11, finished and read 11 rows ago): an assignment, no zeroing pass
+        const float w = win.w[0];
+        const int sl = (P + NTAP - 1) % NTAP;
+        V[0][sl] = w * hx; V[1][sl] = w * hy; V[2][sl] = w * hxx; V[3][sl] = w * hyy; V[4][sl] = w * hxy;
+    }
 #pragma unroll
-    for (int k = 0; k < NTAP; k++) {                        // this row is tap k of output row r + 5 - k, whose running sums sit in slot (P + 10 - k) % 11
+    for (int k = 1; k < NTAP; k++) {                        // this row is tap k of output row r + 5 - k, whose running sums sit in slot (P + 10 - k) % 11
         const float w = win.w[k];
-        constexpr int dummy = 0; (void)dummy;
         const int sl = (P + NTAP - 1 - k) % NTAP;
         V[0][sl] += w * hx; V[1][sl] += w * hy; V[2][sl] += w * hxx; V[3][sl] += w * hyy; V[4][sl] += w * hxy;
     }
@@ -314,7 +319,7 @@ __device__ __forceinline__ void stats_row(float x, float y, int r, const StripGe
         const float m11 = m1 * m1, m22 = m2 * m2, m12 = m1 * m2;
         const float s1 = X2 - m11, s2 = Y2 - m22, s12 = XY - m12;
         const float N1 = 2.f * m12 + C1, N2 = 2.f * s12 + C2, D1 = m11 + m22 + C1, D2 = s1 + s2 + C2;
-        const float iD1 = 1.f / D1, iD2 = 1.f / D2, q = iD1 * iD2;
+        const float iD1 = __builtin_amdgcn_rcpf(D1), iD2 = __builtin_amdgcn_rcpf(D2), q = iD1 * iD2;     // v_rcp_f32 (1 ulp); D1, D2 >= C1, C2 > 0
         const float map = N1 * N2 * q;
         if (g.out_ok) {
             const size_t at = g.plane + (size_t)ro * W + g.col_out;
@@ -324,7 +329,6 @@ __device__ __forceinline__ void stats_row(float x, float y, int r, const StripGe
             s_map += map;
         }
     }
-    V[0][P] = 0.f; V[1][P] = 0.f; V[2][P] = 0.f; V[3][P] = 0.f; V[4][P] = 0.f;
 }
 
 __global__ __launch_bounds__(256) void k_ssim_stats_stream(int H, int W, int nstrips, const float* __restrict__ img, const float* __restrict__ gt, LossWin win,
@@ -374,8 +378,13 @@ __device__ __forceinline__ void grad_row(float a, float b, float c, float xo, fl
         h0 += w * as; h1 += w * bs; h2 += w * cs;
         if (j + 1 < NTAP) { as = wave_shr1(as); bs = wave_shr1(bs); cs = wave_shr1(cs); }
     }
+    {
+        const float w = win.w[0];
+        const int sl = (P + NTAP - 1) % NTAP;
+        V[0][sl] = w * h0; V[1][sl] = w * h1; V[2][sl] = w * h2;
+    }
 #pragma unroll
-    for (int k = 0; k < NTAP; k++) {
+    for (int k = 1; k < NTAP; k++) {
         const float w = win.w[k];
         const int sl = (P + NTAP - 1 - k) % NTAP;
         V[0][sl] += w * h0; V[1][sl] += w * h1; V[2][sl] += w * h2;
@@ -386,7 +395,6 @@ __device__ __forceinline__ void grad_row(float a, float b, float c, float xo, fl
         const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);             // torch's abs backward: 0 at 0
         grad[g.plane + (size_t)ro * W + g.col_out] = gl * sgn + gs * (V[0][P] + 2.f * xo * V[1][P] + yo * V[2][P]);
     }
-    V[0][P] = 0.f; V[1][P] = 0.f; V[2][P] = 0.f;
 }
 
 __global__ __launch_bounds__(256) void k_ssim_grad_stream(int H, int W, int nstrips, const float* __restrict__ img, const float* __restrict__ gt, LossWin win,
