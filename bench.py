@@ -515,6 +515,16 @@ def secondary_workloads(a, cloud, dev, D, W, H, headline_ms):
         q = co[ids]
         power = -0.5 * (q[:, 0, None, None] * dx * dx + q[:, 2, None, None] * dy * dy) - q[:, 1, None, None] * dx * dy
         alive_pairs += int(((power <= 0) & (torch.clamp(q[:, 3, None, None] * torch.exp(power), max=0.99) >= 1.0 / 255.0)).sum())
+    # ---- the N > 1 step's collective path through the REAL backend (RCCL) at world size 1: tools/rccl_world1.py as a CHILD process with a time
+    # limit, started after this process has released its big allocations -- a problem in the collective library must not take the line down
+    try:
+        import subprocess
+        torch.cuda.empty_cache()
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_world1.py"), str(a.config)], capture_output=True, text=True, timeout=240)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        res["rccl_world1"] = json.loads(line[-1]) if (r.returncode == 0 and line) else {"error": f"rc {r.returncode}: " + (r.stderr or "")[-300:]}
+    except Exception as ex:          # noqa: BLE001 (TimeoutExpired included)
+        res["rccl_world1"] = {"error": repr(ex)[:300]}
     res["alive_pairs"] = {"per_frame_view0": alive_pairs, "G_pairs_per_s_at_headline_rate": round(alive_pairs / (headline_ms * 1e-3) / 1e9, 2),
                           "what": "(pixel, tile-list entry) pairs with alpha >= 1/255 (forward.cu:340-343) of view 0, termination ignored"}
     return res

@@ -1,0 +1,69 @@
+"""The reference's checkpoint format (tetgs_model.py:635-640, :678-736) -> rasterizer inputs (youreditableavatar_amd/checkpoints.py)."""
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+
+
+def _state(P=300, levels=3, bound=True, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g)
+    sd = {"all_densities": r(P, 1), "_scales": torch.log(r(P, 3).abs() * 0.02 + 1e-8), "_quaternions": r(P, 4),
+          "_sh_coordinates_dc": r(P, 1, 3), "_surface_mesh_faces": torch.zeros(10, 3, dtype=torch.long), "face_to_global_tet_idx": torch.arange(10)}
+    if levels > 1:
+        sd["_sh_coordinates_rest"] = r(P, levels * levels - 1, 3) * 0.1
+    if bound:
+        n = r(P, 3)
+        sd.update(ori_points=r(P, 3) * 0.3, normals=n / n.norm(dim=1, keepdim=True), _points=r(P, 1) * 0.01)
+    else:
+        sd["_points"] = r(P, 3) * 0.3
+    return sd
+
+
+def test_checkpoint_round_trip_and_formats(tmp_path):
+    from youreditableavatar_amd import checkpoints
+    sd = _state()
+    path = str(tmp_path / "tetgs.pt")
+    torch.save({"state_dict": sd, "epoch": 3}, path)                 # save_model's layout
+    st = checkpoints.load(path)
+    assert st.n_points == 300 and st.sh_levels == 3 and st.points is None
+    assert torch.equal(st.offsets, sd["_points"]) and torch.equal(st.sh_rest, sd["_sh_coordinates_rest"]) and st.sh_dc.shape == (300, 1, 3)
+    free = checkpoints.from_state_dict(_state(levels=1, bound=False))
+    assert free.sh_levels == 1 and free.sh_rest is None and free.points.shape == (300, 3) and free.offsets is None
+    keep = {"keep_xyz": sd["ori_points"], "keep_opacities": sd["all_densities"], "keep_scales": sd["_scales"], "keep_rots": sd["_quaternions"],
+            "keep_sh_coordinates_dc": sd["_sh_coordinates_dc"], "keep_sh_coordinates_rest": sd["_sh_coordinates_rest"], "sh_level": 3}
+    k = checkpoints.from_state_dict(keep)                            # the editing stages' hand-off dict (tetgs_model.py:716-735)
+    assert torch.equal(k.points, sd["ori_points"]) and k.sh_levels == 3
+    with pytest.raises(KeyError):
+        checkpoints.from_state_dict({"_scales": sd["_scales"]})
+    bad = dict(sd); del bad["normals"]
+    with pytest.raises(ValueError):
+        checkpoints.from_state_dict(bad)
+
+
+@pytest.mark.gpu
+def test_checkpoint_renders_like_the_model_properties(gpu_device, tmp_path):
+    """A saved state -> GaussianState.rasterizer_inputs (fused bind + dc/rest colours) -> GaussianRasterizer equals the same render from the
+    torch restatement of the model's properties (oracle/bind_ref.py, oracle/sh_color_ref.py)."""
+    from diff_gaussian_rasterization import GaussianRasterizer, GaussianRasterizationSettings
+    from oracle import bind_ref, sh_color_ref
+    from youreditableavatar_amd import checkpoints, scenes
+    sd = _state(P=4000, levels=3, seed=5)
+    sd["_scales"] = torch.log(torch.rand(4000, 3) * 0.03 + 0.002)
+    path = str(tmp_path / "m.pt")
+    torch.save({"state_dict": sd}, path)
+    st = checkpoints.load(path).to(gpu_device)
+    cam = scenes.orbit_camera(160, 128, azimuth_deg=20.0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(gpu_device)
+    rs = GaussianRasterizationSettings(image_height=128, image_width=160, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=t(cam.bg), scale_modifier=1.0,
+                                       viewmatrix=t(cam.viewmatrix), projmatrix=t(cam.projmatrix), sh_degree=2, campos=t(cam.campos), prefiltered=False, debug=False)
+    inp = st.rasterizer_inputs(rs.campos)
+    img, radii = GaussianRasterizer(rs)(means2D=torch.zeros(4000, 3, device=gpu_device), **inp)
+    d = {k: v.double() for k, v in sd.items() if v.is_floating_point()}
+    op, sc, qu, pts = bind_ref.bind(d["all_densities"], d["_scales"], d["_quaternions"], d["ori_points"], d["normals"], d["_points"])
+    col = sh_color_ref.points_rgb(torch.cat([d["_sh_coordinates_dc"], d["_sh_coordinates_rest"]], 1), 3, positions=pts, camera_centers=torch.tensor(cam.campos, dtype=torch.float64))
+    f = lambda x: x.float().to(gpu_device)
+    img2, radii2 = GaussianRasterizer(rs)(means3D=f(pts), means2D=torch.zeros(4000, 3, device=gpu_device), opacities=f(op), colors_precomp=f(col), scales=f(sc), rotations=f(qu))
+    assert (radii > 0).sum() > 1000 and torch.equal(radii, radii2)
+    assert util.rel_l2(img.cpu().numpy(), img2.cpu().numpy()) <= 1e-5

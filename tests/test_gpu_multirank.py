@@ -36,35 +36,29 @@ def test_bench_starts_two_ranks(gpu_device, tmp_path):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     # Its own session: if the ranks hang, the whole group gets SIGABRT (faulthandler prints every Python stack into the log) and the
-    # assertion below shows where they stood.  Two processes sharing ONE GPU over gloo is this test's stand-in for two GPUs, and on this
-    # pool that pair has been seen to stall once in a dozen full-suite runs (never alone, never twice in a row; the production path -- one
-    # rank per GPU over RCCL -- has no second process on the device): one retry, with the first attempt's stacks kept for the log.
-    def attempt(tag):
-        out_f, err_f = open(str(tmp_path / f"bench{tag}.out"), "w+"), open(str(tmp_path / f"bench{tag}.err"), "w+")
-        p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-device", "--config", "2", "--steps", "2",
-                              "--warmup", "2", "--views-per-gpu", "4", "--no-cpu"], stdout=out_f, stderr=err_f, text=True, env=env, cwd=ROOT, start_new_session=True)
-        t0 = time.time()
-        while p.poll() is None and time.time() - t0 < 120:
-            time.sleep(0.2)
-        hung = p.poll() is None
-        if hung:
-            os.killpg(p.pid, signal.SIGABRT)
-            time.sleep(3)
-            try:
-                os.killpg(p.pid, signal.SIGKILL)
-            except ProcessLookupError:
-                pass
-            p.wait()
-        out_f.seek(0); err_f.seek(0)
-        res = (hung, p.returncode, out_f.read(), err_f.read())
-        out_f.close(); err_f.close()
-        return res
-
-    hung, rc, stdout, stderr = attempt(0)
+    # assertion below shows where they stood.  A stall is a FAILURE, not something to retry: round 2 saw this pair stall about once in a
+    # dozen full-suite runs and papered over it with a retry; round 3 ran the same two rehearsals 90 times in a row on the MI355X box, half
+    # of them beside a third process holding a GPU context like the pytest parent does (tools/mr_loop.py, profiles/r03_multirank_loop.txt):
+    # no stall, no failure -- the cause was not reproduced, so if it ever shows again the stacks must surface.
+    out_f, err_f = open(str(tmp_path / "bench.out"), "w+"), open(str(tmp_path / "bench.err"), "w+")
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-device", "--config", "2", "--steps", "2",
+                          "--warmup", "2", "--views-per-gpu", "4", "--no-cpu"], stdout=out_f, stderr=err_f, text=True, env=env, cwd=ROOT, start_new_session=True)
+    t0 = time.time()
+    while p.poll() is None and time.time() - t0 < 150:
+        time.sleep(0.2)
+    hung = p.poll() is None
     if hung:
-        print("first attempt stalled; stacks of its processes:\n" + stderr[-6000:], file=sys.stderr)
-        hung, rc, stdout, stderr = attempt(1)
-    assert not hung and rc == 0, (hung, rc, stderr[-6000:])
+        os.killpg(p.pid, signal.SIGABRT)
+        time.sleep(3)
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        p.wait()
+    out_f.seek(0); err_f.seek(0)
+    rc, stdout, stderr = p.returncode, out_f.read(), err_f.read()
+    out_f.close(); err_f.close()
+    assert not hung and rc == 0, ("stalled" if hung else f"rc {rc}", stderr[-6000:])
     line = [l for l in stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["config"]["frames_per_step"] == 8

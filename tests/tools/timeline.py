@@ -27,7 +27,7 @@ for name, a, b in (('fwd', 0, 1), ('bwd', 2, 3)):
     base = t0.min(); t0 = (t0 - base) / 100.0; t1 = (t1 - base) / 100.0   # us
     dur = t1 - t0
     nn = n[sel]
-    print(f'{name}: kernel span {t1.max():.1f} us; last start {t0.max():.1f} us; sum of WG durations {dur.sum():.0f} us -> /2048 slots = {dur.sum()/2048:.1f} us')
+    print(f'{name}: kernel span {t1.max():.1f} us; last start {t0.max():.1f} us; sum of WG durations {dur.sum():.0f} us -> /512 workgroup slots (2 per CU) = {dur.sum()/512:.1f} us')
     order = np.argsort(-dur)[:6]
     print('  longest WGs: ', [(int(nn[i]), round(float(dur[i]),1), round(float(t0[i]),1)) for i in order], '(list len, dur us, start us)')
     # concurrency profile

@@ -100,7 +100,9 @@ for src, dst in (("bench_default.json", "bench_default.json"), ("bench_under_roc
                  ("rp1/rp_kernel_stats.csv", "kernel_stats_one_stream.csv"), ("valu_issue_rate.txt", "valu_issue_rate.txt"),
                  ("rp_cfg2/rp_kernel_stats.csv", "kernel_stats_cfg2.csv"), ("rp_cfg5/rp_kernel_stats.csv", "kernel_stats_cfg5.csv"),
                  ("rp_trainer/rp_kernel_stats.csv", "kernel_stats_trainer_protocol.csv"), ("bench_cfg2.json", "bench_cfg2.json"), ("bench_cfg5.json", "bench_cfg5.json"),
-                 ("trainer_protocol.json", "trainer_protocol_under_rocprof.json")):
+                 ("trainer_protocol.json", "trainer_protocol_under_rocprof.json"), ("rp_trainer3/rp_kernel_stats.csv", "kernel_stats_trainer_protocol_sh3.csv"),
+                 ("trainer_protocol_sh3.json", "trainer_protocol_sh3_under_rocprof.json"), ("rp_dropin/rp_kernel_stats.csv", "kernel_stats_dropin.csv"),
+                 ("dropin_under_rocprof.json", "dropin_under_rocprof.json")):
     if os.path.exists(O + src):
         shutil.copy(O + src, f"{P}/{name}_{dst}")
 for k, v in out["kernels"].items():

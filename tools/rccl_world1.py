@@ -1,0 +1,67 @@
+"""The N > 1 step's collective path through the REAL backend at world size 1 (the pool has one GPU per box): backend "nccl" = RCCL, the
+gradients of the 8-view step of config 3 all-reduced in 4 Gaussian ranges behind the per-Gaussian pass (SyncFreeBatch.run_views(grad_chunks,
+on_chunk) + FlatGradients.all_reduce_rows(even_alone=True)).  A sum over one rank moves no data between GPUs: this times RCCL's launches and
+the stream choreography, not xGMI.  Stand-alone (bench.py runs it as a child process with a time limit and copies the JSON line into
+secondary.rccl_world1, so that a problem in the collective library cannot take the bench line down).   python tools/rccl_world1.py [config]"""
+import json, os, socket, sys, time
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np, torch, torch.distributed as dist
+from youreditableavatar_amd import scenes
+from youreditableavatar_amd.multiview import FlatGradients, SyncFreeBatch
+from diff_gaussian_rasterization import GaussianRasterizationSettings
+
+cfg_i = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+with socket.socket() as sk:
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+cfg = scenes.CONFIGS[cfg_i]; P, W, H, D = cfg["P"], cfg["width"], cfg["height"], cfg["sh_degree"]
+cloud = scenes.config_cloud(cfg_i)
+g = lambda x, rg=False: torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev).requires_grad_(rg)
+L = {k: g(cloud[k], True) for k in ("means3D", "opacities", "scales", "rotations", "shs")}
+flat = FlatGradients([L[k] for k in ("means3D", "opacities", "scales", "rotations", "shs")])
+S = []
+for k in range(8):
+    c = scenes.orbit_camera(W, H, azimuth_deg=(k * 137.5) % 360.0)
+    S.append(GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=c.tanfovx, tanfovy=c.tanfovy, bg=g(c.bg), scale_modifier=1.0, viewmatrix=g(c.viewmatrix),
+                                           projmatrix=g(c.projmatrix), sh_degree=D, campos=g(c.campos), prefiltered=False, debug=False))
+dL = g(scenes.upstream_gradient(W, H, seed=4321))
+batch = SyncFreeBatch(streams=4)
+pend = []
+
+
+def step(reduce):
+    batch.run_views(S, L["means3D"], L["opacities"], L["shs"], L["scales"], L["rotations"], None, accumulate=False, upstream_view=lambda v, image: dL, grad_chunks=4,
+                    on_chunk=(lambda first, count: pend.extend(flat.all_reduce_rows(first, count, even_alone=True))) if reduce else (lambda f, c: None))
+    n = len(pend)
+    for w in pend:
+        w.wait()
+    pend.clear()
+    return n
+
+
+def timed(reduce, n, warm):
+    for _ in range(warm):
+        step(reduce)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        handles = step(reduce)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3, handles
+
+
+ms_r, handles = timed(True, 10, 4)
+ms_n, _ = timed(False, 10, 2)
+ref = flat.flat.clone()
+step(True)
+torch.cuda.synchronize()
+same = bool(torch.equal(ref, flat.flat))
+print(json.dumps({"ms_per_step_with_reduce": round(ms_r, 4), "ms_per_step_without": round(ms_n, 4), "backend": str(dist.get_backend()), "collective_handles_per_step": handles,
+                  "gradients_unchanged_by_the_one_rank_sum": same, "frames_rerendered": batch.rejected,
+                  "what": f"8-view step of config {cfg_i} with its gradients all-reduced in 4 Gaussian ranges through RCCL at world size 1 (one coalesced collective per range, "
+                          "overlapped with the per-Gaussian pass): the N > 1 control flow on the production backend; no data crosses xGMI"}), flush=True)
+dist.destroy_process_group()

@@ -421,6 +421,9 @@ __device__ __forceinline__ unsigned long long block_exscan_u64(unsigned long lon
 // forward's read-back without a copy engine or blit kernel in the stream (a D2H blit between k_scan and k_scatter cost 4 us + a 6-us gap)
 // tile_bound: the sync-free grids behind the scan cover that many entries of tile_order; a frame with more non-empty tiles is rejected
 // like one that exceeds r_capacity (T: no bound)
+// TI: tile counters per thread and super-chunk of the tile pass (8: 8192 tiles per iteration, 16: 16 384 -- a 2048 x 2048 image in ONE
+// iteration instead of two: the iterations are serial round trips of a single workgroup, 30 -> see DESIGN.md us at that size)
+template <int TI>
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const ImgState s, uint32_t nblocks, uint32_t T, uint32_t sort_cap, unsigned long long r_capacity, uint32_t tile_bound,
                                                        uint32_t heavy_bound, uint32_t mid_bound, Meta* host_meta)
 {
@@ -451,7 +454,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const 
         // Tile pass.  One workgroup is latency bound, so every global access is issued 8-deep: the counters of a
         // super-chunk of 8192 tiles are pulled into LDS with 8 independent loads per thread, and the scan, the
         // longest-list search and the length histogram then run out of LDS.
-        constexpr uint32_t SC = SCAN_THREADS * 8;
+        constexpr uint32_t SC = SCAN_THREADS * TI;
         __shared__ uint32_t lc[SC];
         __shared__ uint32_t hist[34];
         __shared__ uint32_t cls[2];                         // (n_mid, n_nonempty) for the second pass
@@ -462,20 +465,20 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const 
         uint32_t mx = 0;
         for (uint32_t sc = 0; sc < T; sc += SC) {
             const uint32_t n = min(SC, T - sc);
-            uint32_t v[8];
+            uint32_t v[TI];
 #pragma unroll
-            for (int k = 0; k < 8; k++) { const uint32_t i = k * SCAN_THREADS + threadIdx.x; v[k] = i < n ? s.tile_count[sc + i] : 0u; }
+            for (int k = 0; k < TI; k++) { const uint32_t i = k * SCAN_THREADS + threadIdx.x; v[k] = i < n ? s.tile_count[sc + i] : 0u; }
 #pragma unroll
-            for (int k = 0; k < 8; k++) lc[k * SCAN_THREADS + threadIdx.x] = v[k];
+            for (int k = 0; k < TI; k++) lc[k * SCAN_THREADS + threadIdx.x] = v[k];
             __syncthreads();
             unsigned long long sum = 0;
-            const uint32_t i0 = threadIdx.x * 8;
+            const uint32_t i0 = threadIdx.x * TI;
 #pragma unroll
-            for (int k = 0; k < 8; k++) { v[k] = lc[i0 + k]; sum += v[k]; mx = v[k] > mx ? v[k] : mx; }
+            for (int k = 0; k < TI; k++) { v[k] = lc[i0 + k]; sum += v[k]; mx = v[k] > mx ? v[k] : mx; }
             unsigned long long tot;
             unsigned long long ex = block_exscan_u64(sum, lds, tot) + carry;
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
+            for (int k = 0; k < TI; k++) {
                 if (i0 + k < n) {
                     const uint32_t t = sc + i0 + k;
                     s.ranges[t] = make_uint2((uint32_t)ex, (uint32_t)(ex + v[k]));
@@ -504,11 +507,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const 
         __syncthreads();
         for (uint32_t sc = 0; sc < T; sc += SC) {
             const uint32_t n = min(SC, T - sc);
-            uint2 r[8];
+            uint2 r[TI];
 #pragma unroll
-            for (int k = 0; k < 8; k++) { const uint32_t i = k * SCAN_THREADS + threadIdx.x; r[k] = i < n ? s.ranges[sc + i] : make_uint2(0u, 0u); }
+            for (int k = 0; k < TI; k++) { const uint32_t i = k * SCAN_THREADS + threadIdx.x; r[k] = i < n ? s.ranges[sc + i] : make_uint2(0u, 0u); }
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
+            for (int k = 0; k < TI; k++) {
                 const uint32_t i = k * SCAN_THREADS + threadIdx.x;
                 if (i < n) {
                     const uint32_t c = r[k].y - r[k].x, pos = atomicAdd(&hist[c ? 32 - __builtin_clz(c) : 0], 1u);
@@ -1339,7 +1342,8 @@ void launch_preprocess_fwd_batch(hipStream_t st, const FwdIn& in, const FwdViews
 void launch_scan(hipStream_t st, const GeomState& g, const ImgState& s, uint32_t nblocks, uint32_t T, uint32_t sort_cap, unsigned long long r_capacity,
                  uint32_t tile_bound, uint32_t heavy_bound, uint32_t mid_bound, Meta* host_meta)
 {
-    hipLaunchKernelGGL(k_scan, dim3(2), dim3(SCAN_THREADS), 0, st, g, s, nblocks, T, sort_cap, r_capacity, tile_bound, heavy_bound, mid_bound, host_meta);
+    if (T > SCAN_THREADS * 8) hipLaunchKernelGGL(k_scan<16>, dim3(2), dim3(SCAN_THREADS), 0, st, g, s, nblocks, T, sort_cap, r_capacity, tile_bound, heavy_bound, mid_bound, host_meta);
+    else hipLaunchKernelGGL(k_scan<8>, dim3(2), dim3(SCAN_THREADS), 0, st, g, s, nblocks, T, sort_cap, r_capacity, tile_bound, heavy_bound, mid_bound, host_meta);
 }
 // Binning chunks: `nchunks` workgroups of BIN_THREADS threads, `chunk` Gaussians each (a multiple of BIN_THREADS)
 void bin_shape(int P, uint32_t T, uint32_t& nchunks, uint32_t& chunk, uint32_t& band, size_t& lds)
