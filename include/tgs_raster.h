@@ -129,7 +129,9 @@ typedef struct {
                                   1024-thread render kernels' grids when light_tiles is on); only read with tile_bound */
     int32_t light_tiles;       /* 1: tiles with fewer than 128 instances are composited several per workgroup (four forward, three backward) by the
                                   last workgroups of the render kernels' grids, the others one per workgroup; 0: one workgroup per tile; -1: default
-                                  (1 in the *_views entry points, 0 in the single-view ones; TGS_LIGHT_TILES overrides both) */
+                                  (1 in the *_views entry points, 0 in the single-view ones; TGS_LIGHT_TILES overrides both).  A backward forms
+                                  light groups only for a frame whose FORWARD ran with them (the forward records their descriptors): pass
+                                  the same options to both; light_tiles = 1 on a frame rendered without is reported as TGS_FRAME_TILE_BOUND */
     int32_t reserved;
 } tgs_options_t;
 /* What a forward learned about its frame (filled when non-NULL; the synchronous and the speculative forward read the frame's Meta,

@@ -176,6 +176,13 @@ def test_tile_bound_policy(monkeypatch):
     for _ in range(sp.MAX_MISSES):                                   # the instance guess holds, the tile guess does not: misses all the same
         sp.update(key, 700_000, sp.guess(key) or 10 ** 9, tiles=10 * tg, tile_guess=tg)
     assert sp.guess(key) is None                                      # cooling down
+    # light-tile groups for a frame that has the GPU to itself: only when the last frame had thousands of light tiles (2048 x 2048), not at 1080p
+    sp2 = _Speculation()
+    assert sp2.light_tiles(key) is False
+    sp2.update(key, 750_000, None, tiles=2700, tile_guess=0, mid_tiles=890)
+    assert sp2.light_tiles(key) is False
+    sp2.update(key, 1_500_000, None, tiles=9000, tile_guess=0, mid_tiles=2500)
+    assert sp2.light_tiles(key) is True
 
 
 def test_deferred_backward_rejects_mixed_batches():

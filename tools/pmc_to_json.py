@@ -24,14 +24,16 @@ def load(d, counter):
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from youreditableavatar_amd.build import source_hash
-SRC = source_hash()           # bench.py quotes these counters only while the kernel sources still hash to this
+# bench.py quotes these counters only while the kernel sources still hash to this: the hash recorded ON THE BOX when the passes ran
+# (tools/profile_round.sh: csrc_sha16.txt), or -- for older sets without the file -- of the tree this script runs in
+SRC = open(O + "csrc_sha16.txt").read().strip() if os.path.exists(O + "csrc_sha16.txt") else source_hash()
 
 # Per-kernel FETCH_SIZE calibration (round 3; round 2 doubled every kernel's FETCH): the dominant READ pattern of each kernel, and the factor
 # tools/microbench/fetch_calibration.hip measured for that pattern on this chip (profiles/<name>_fetch_calibration.json when the round has
 # one, else the guide's 2.0 for 16-B-per-lane streams and 1.0 for everything else -- stated per kernel in the output).
 READ_PATTERN = {
     "k_preprocess_fwd": "k_stream16", "k_preprocess_fwd_pair": "k_stream16", "k_preprocess_fwd_batch": "k_stream16",   # SH rows, 16 B per lane
-    "k_preprocess_bwd": "k_gather48", "k_preprocess_bwd_batch": "k_gather48", "k_preprocess_bwd_batch_split": "k_gather48",   # slab rows + SH rows
+    "k_preprocess_bwd": "k_stream16", "k_preprocess_bwd_batch": "k_stream16", "k_preprocess_bwd_batch_split": "k_stream16",   # SH rows (streams, staged through LDS) outweigh the slab rows (gathers): see hbm_bytes_bounds
     "k_render_fwd": "k_stream16", "k_render_bwd": "k_stream16", "k_render_bwd_det": "k_stream16",                    # records, 16 B per lane
     "k_finalize": "k_gather64", "k_tile_sort": "k_stream8", "k_scatter": "k_stream4", "k_bin_count": "k_stream4", "k_bin_colscan": "k_stream4",
     "k_scan": "k_stream4", "k_fill_empty": "k_stream4", "k_ssim_stats": "k_stream4", "k_ssim_grad": "k_stream4", "k_sh_rgb": "k_stream16",
@@ -42,10 +44,14 @@ DEFAULT_FACTOR = {"k_stream16": 2.0}
 
 
 def fetch_factor(kernel):
+    """(pattern, bytes moved per reported byte, source).  The calibration divides KNOWN USEFUL bytes by the counter: 2.0 for coalesced streams of
+    4, 8 and 16 B per lane (the counter tallies 128-B requests at 64 B), 1.01 for random 64-B lines (the counter is exact), 0.63 for three 16-B
+    pieces of random 48-B rows -- there the counter EXCEEDS the useful bytes because whole lines move: a ratio below 1 means the counter
+    already is the traffic, so the traffic factor is max(ratio, 1)."""
     base = kernel.split("::")[-1].split("<")[0]
     pat = READ_PATTERN.get(base, "k_stream4")
     if cal and pat in cal and "fetch_factor" in cal[pat]:
-        return pat, float(cal[pat]["fetch_factor"]), os.path.basename(cal_path)
+        return pat, max(1.0, round(float(cal[pat]["fetch_factor"]), 2)), os.path.basename(cal_path)
     return pat, DEFAULT_FACTOR.get(pat, 1.0), "MI355X_MICROARCH.md (2.0 for 16-B-per-lane streams, uncalibrated 1.0 otherwise)"
 
 
@@ -58,7 +64,9 @@ for k in sorted(set(f) | set(w)):
         pat, fac, src = fetch_factor(k)
         out["kernels"][k] = {"FETCH_SIZE_KB_per_launch": round(f.get(k, 0.0), 1), "WRITE_SIZE_KB_per_launch": round(w.get(k, 0.0), 1),
                              "read_pattern": pat, "fetch_factor": fac, "calibration": src,
-                             "hbm_bytes_est": int((fac * f.get(k, 0.0) + w.get(k, 0.0)) * 1024)}
+                             "hbm_bytes_est": int((fac * f.get(k, 0.0) + w.get(k, 0.0)) * 1024),
+                             # a kernel that mixes streams and gathers lies between the two: every read counted once / every read counted twice
+                             "hbm_bytes_bounds": [int((f.get(k, 0.0) + w.get(k, 0.0)) * 1024), int((2 * f.get(k, 0.0) + w.get(k, 0.0)) * 1024)]}
 json.dump(out, open(f"{P}/{name}_hbm_counters.json", "w"), indent=1)
 
 # SQ passes: per kernel, per launch averages + the launch duration seen in the same pass (dispatch timestamps of the counter CSV)

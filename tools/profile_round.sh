@@ -6,6 +6,7 @@ set -x
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/${1:-r03_a}
 mkdir -p $O
+python3 -c "import sys; sys.path.insert(0, '$R'); from youreditableavatar_amd.build import source_hash; print(source_hash())" > $O/csrc_sha16.txt   # the sources these counters belong to
 cd /tmp && export TMPDIR=/tmp
 timeout 420 python3 $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
 timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d $O/rp4 -o rp -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu --no-secondary > $O/bench_under_rocprof.json 2> $O/rp4.err

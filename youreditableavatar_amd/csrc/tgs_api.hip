@@ -11,7 +11,7 @@ namespace tgs {
 void launch_preprocess_fwd(hipStream_t, const FwdIn&, const CamParams&, const GeomState&, const ImgState&);
 void launch_preprocess_fwd_batch(hipStream_t, const FwdIn&, const FwdViews&);
 void launch_scan(hipStream_t, const GeomState&, const ImgState&, uint32_t nblocks, uint32_t T, uint32_t sort_cap, unsigned long long r_capacity,
-                 uint32_t tile_bound, uint32_t heavy_bound, uint32_t mid_bound, Meta* host_meta);
+                 uint32_t tile_bound, uint32_t heavy_bound, uint32_t mid_bound, Meta* host_meta, int light);
 void launch_bin_count(hipStream_t, int P, const GeomState&, const ImgState&, uint32_t gx, uint32_t T);
 void launch_scatter(hipStream_t, int P, const GeomState&, const ImgState&, const BinState&, uint32_t gx, uint32_t T);
 void launch_tile_sort(hipStream_t, const GeomState&, const ImgState&, const BinState&, uint32_t gx, uint32_t T, uint64_t r_bound, const Meta* m,
@@ -345,7 +345,7 @@ static int64_t forward_impl(const Opts& opt, Meta* host_meta, hipStream_t render
     STAGE_BEGIN(TGS_STAGE_SCAN);
     launch_bin_count(st, P, g, s, cam.gx, (uint32_t)T);
     launch_scan(st, g, s, (uint32_t)n_blocks((size_t)P), (uint32_t)T, sort_cap, async ? (unsigned long long)r_capacity : ~0ull, tb, hb, mb,
-                spec ? spec->meta : host_meta);
+                spec ? spec->meta : host_meta, opt.light);
     STAGE_CHECK("scan", TGS_STAGE_SCAN);
     if (spec) {
         // speculative synchronous forward: k_scan itself has written Meta into the pinned host slot; the event marks its end, the remaining

@@ -368,6 +368,8 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
 
     const uint4 td = s.tile_desc[blockIdx.x];               // (in flight beside the frame's flags)
     // candidate light tile of this thread's quarter: light group g is workgroup gridDim.x - 1 - g and takes light tiles 3 g .. 3 g + 2
+    // (light groups only if the frame's forward wrote light_desc -- Meta::pad[1], k_scan: a caller may back-propagate with other options)
+    if (light && __builtin_nontemporal_load(&s.meta->pad[1]) == 0u) light = 0;
     const uint32_t lgroup = gridDim.x - 1u - blockIdx.x, lsub = threadIdx.x >> 8, li = (uint32_t)BWD_LIGHT_PER_WG * lgroup + lsub;
     const uint4 tdl = (light && lsub < (uint32_t)BWD_LIGHT_PER_WG && li < n_tiles) ? s.light_desc[li] : make_uint4(0u, 0u, 0u, 0u);
     const uint4 ff = frame_counts(s);

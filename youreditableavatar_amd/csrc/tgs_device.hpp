@@ -17,7 +17,10 @@ constexpr int RANK_TILES = 4;        // rectangles up to this size (almost all) 
 constexpr int SLAB_ROW = 3;          // float4 per gradient-slab row: 9 sums padded to 48 B so rows move as three 16-B accesses
 // Binning (k_bin_count / k_bin_colscan / k_scatter): the Gaussians are cut into BIN_WGS_MAX (or fewer) contiguous chunks, one fat
 // workgroup each, which count and later emit their instances through a per-tile table in LDS -- no global atomics.
-constexpr int BIN_WGS_MAX = 128;          // rows of the per-view table (bin_table: BIN_WGS_MAX x T words)
+#ifndef TGS_BIN_WGS_MAX
+#define TGS_BIN_WGS_MAX 128
+#endif
+constexpr int BIN_WGS_MAX = TGS_BIN_WGS_MAX;   // rows of the per-view table (bin_table: BIN_WGS_MAX x T words); TGS_BIN_WGS (environment) selects fewer
 constexpr int BIN_THREADS = 1024;
 constexpr uint32_t BIN_LDS_TILES = 24576; // tiles per pass of the LDS table (96 KB); larger tile grids are walked in bands
 
@@ -32,7 +35,7 @@ struct Meta {                 // lives at the start of the image buffer
     uint32_t n_nonempty;      // tiles with at least one instance (they come first in tile_order)
     uint32_t n_heavy;         // tiles with >= 1024 instances (first in tile_order): sorted by 1024-thread workgroups
     uint32_t n_mid;           // tiles with >= 128 instances (heavy ones included); the rest are sorted one wave per tile
-    uint32_t pad[8];
+    uint32_t pad[8];          // [0]: a tile bound was exceeded (k_scan, mirrored to host_meta); [1]: light_desc holds this frame's light tiles
 };
 
 constexpr uint32_t META_ERR_CAPACITY = 2u;

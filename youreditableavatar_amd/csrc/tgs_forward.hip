@@ -425,7 +425,7 @@ __device__ __forceinline__ unsigned long long block_exscan_u64(unsigned long lon
 // iteration instead of two: the iterations are serial round trips of a single workgroup, 30 -> see DESIGN.md us at that size)
 template <int TI>
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const ImgState s, uint32_t nblocks, uint32_t T, uint32_t sort_cap, unsigned long long r_capacity, uint32_t tile_bound,
-                                                       uint32_t heavy_bound, uint32_t mid_bound, Meta* host_meta)
+                                                       uint32_t heavy_bound, uint32_t mid_bound, Meta* host_meta, int light)
 {
     __shared__ unsigned long long lds[SCAN_THREADS / WAVE];
     __shared__ uint32_t lds_max[SCAN_THREADS / WAVE];
@@ -501,6 +501,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const 
                 if (b2 == 8) { s.meta->n_mid = acc + h; cls[0] = acc + h; too_many = too_many || acc + h > mid_bound; }
                 acc += h;
             }
+            s.meta->pad[1] = light ? 1u : 0u;               // light_desc is valid for this frame (the backward may be called with other options)
             if (too_many) atomicOr(&s.meta->error, META_ERR_CAPACITY);
             if (host_meta) host_meta->pad[0] = too_many ? 1u : 0u;   // (a word of its own: workgroup 0 writes host_meta->error)
         }
@@ -517,7 +518,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const 
                     const uint32_t c = r[k].y - r[k].x, pos = atomicAdd(&hist[c ? 32 - __builtin_clz(c) : 0], 1u);
                     s.tile_order[pos] = sc + i;
                     s.tile_desc[pos] = make_uint4(sc + i, r[k].x, r[k].y, 0u);
-                    if (pos >= cls[0] && pos < cls[1]) s.light_desc[pos - cls[0]] = make_uint4(sc + i, r[k].x, r[k].y, 0u);
+                    if (light && pos >= cls[0] && pos < cls[1]) s.light_desc[pos - cls[0]] = make_uint4(sc + i, r[k].x, r[k].y, 0u);   // (only when the render kernels will form light groups)
                 }
             }
         }
@@ -1288,15 +1289,6 @@ __global__ __launch_bounds__(FWD_THREADS, 8) void k_render_fwd(const ImgState s,
 }
 
 
-// tiles without any instance: background only (they sit at the end of tile_order)
-__global__ __launch_bounds__(256) void k_fill_empty(const ImgState s, int W, int H, uint32_t gx, uint32_t T, uint32_t first, const float* __restrict__ bg,
-                                                    float* __restrict__ out_color)
-{
-    const uint32_t t = first + blockIdx.x;                  // empty tiles are the tail of tile_order
-    if (t >= T) return;
-    fill_tile_background(s, s.tile_desc[t].x, threadIdx.x, W, H, gx, bg, out_color);
-}
-
 // ---------------------------------------------------------------------------------------------
 // k_mark_visible (rasterizer_impl.cu:54-66)
 // ---------------------------------------------------------------------------------------------
@@ -1340,10 +1332,10 @@ void launch_preprocess_fwd_batch(hipStream_t st, const FwdIn& in, const FwdViews
     else hipLaunchKernelGGL((k_preprocess_fwd_batch<false, false>), grid, blk, 0, st, in, views);
 }
 void launch_scan(hipStream_t st, const GeomState& g, const ImgState& s, uint32_t nblocks, uint32_t T, uint32_t sort_cap, unsigned long long r_capacity,
-                 uint32_t tile_bound, uint32_t heavy_bound, uint32_t mid_bound, Meta* host_meta)
+                 uint32_t tile_bound, uint32_t heavy_bound, uint32_t mid_bound, Meta* host_meta, int light)
 {
-    if (T > SCAN_THREADS * 8) hipLaunchKernelGGL(k_scan<16>, dim3(2), dim3(SCAN_THREADS), 0, st, g, s, nblocks, T, sort_cap, r_capacity, tile_bound, heavy_bound, mid_bound, host_meta);
-    else hipLaunchKernelGGL(k_scan<8>, dim3(2), dim3(SCAN_THREADS), 0, st, g, s, nblocks, T, sort_cap, r_capacity, tile_bound, heavy_bound, mid_bound, host_meta);
+    if (T > SCAN_THREADS * 8) hipLaunchKernelGGL(k_scan<16>, dim3(2), dim3(SCAN_THREADS), 0, st, g, s, nblocks, T, sort_cap, r_capacity, tile_bound, heavy_bound, mid_bound, host_meta, light);
+    else hipLaunchKernelGGL(k_scan<8>, dim3(2), dim3(SCAN_THREADS), 0, st, g, s, nblocks, T, sort_cap, r_capacity, tile_bound, heavy_bound, mid_bound, host_meta, light);
 }
 // Binning chunks: `nchunks` workgroups of BIN_THREADS threads, `chunk` Gaussians each (a multiple of BIN_THREADS)
 void bin_shape(int P, uint32_t T, uint32_t& nchunks, uint32_t& chunk, uint32_t& band, size_t& lds)
@@ -1425,11 +1417,13 @@ void launch_render_fwd(hipStream_t st, const ImgState& s, const BinState& b, int
         hipLaunchKernelGGL(k_render_fwd, dim3(grid), dim3(FWD_THREADS), 0, st, s, b, W, H, gx, bg, out_color, 1, T, light);
         return;
     }
+    // exact counts (the host has read Meta): one-tile workgroups, light groups, and -- between them in the grid -- one workgroup per 16 empty
+    // tiles for the background (a kernel of its own behind this one, k_fill_empty, was 6.6 us + a launch boundary of a frame that has the
+    // GPU to itself; as workgroups of this launch the fill runs beside the long lists)
     const uint32_t nonempty = m->n_nonempty, empty = T - m->n_nonempty;
     const uint32_t heavy = light ? (m->n_mid < nonempty ? m->n_mid : nonempty) : nonempty;
-    const uint32_t grid = heavy + (nonempty - heavy + 3u) / 4u;
-    if (grid > 0) hipLaunchKernelGGL(k_render_fwd, dim3(grid), dim3(FWD_THREADS), 0, st, s, b, W, H, gx, bg, out_color, 0, T, light);
-    if (empty > 0) hipLaunchKernelGGL(k_fill_empty, dim3(empty), dim3(256), 0, st, s, W, H, gx, T, nonempty, bg, out_color);
+    const uint32_t grid = heavy + (nonempty - heavy + 3u) / 4u + (empty + 15u) / 16u;
+    if (grid > 0) hipLaunchKernelGGL(k_render_fwd, dim3(grid), dim3(FWD_THREADS), 0, st, s, b, W, H, gx, bg, out_color, 1, T, light);
 }
 void launch_mark_visible(hipStream_t st, int P, const float* means3D, const float* view, uint8_t* present)
 {

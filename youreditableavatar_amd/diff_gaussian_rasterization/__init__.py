@@ -82,11 +82,23 @@ class _Speculation:
         st = self.state.get(key)
         return (int(st[3] * self.HEADROOM) + 64) // 64 * 64 if st is not None and st[3] > 0 else 0
 
-    def update(self, key, true_count, guess, tiles=-1, tile_guess=0):
-        st = self.state.setdefault(key, [0, 0, 0, 0])         # [bound, consecutive misses, calls left without speculation, bound on the tiles]
+    LIGHT_TILES_MIN = 4096      # light tiles (fewer than 128 instances) of the last frame from which the light groups pay for a frame that has the GPU to itself
+
+    def light_tiles(self, key):
+        """Whether the render kernels should composite light tiles several per workgroup (tgs_options_t::light_tiles) for the next frame of
+        this key: yes when the last frame had many of them.  Measured on the MI355X, one view per step: at 1920x1080 (1800 light tiles) the
+        groups cost 1.4 % (0.381 -> 0.387 ms per frame: the kernels end with the groups' ~10-us tail), at 2048x2048 they gain 1-5 % of the
+        trainers' step (0.823 -> 0.778 ms at SH degree 3)."""
+        st = self.state.get(key)
+        return bool(st is not None and len(st) > 4 and st[4] >= self.LIGHT_TILES_MIN)
+
+    def update(self, key, true_count, guess, tiles=-1, tile_guess=0, mid_tiles=-1):
+        st = self.state.setdefault(key, [0, 0, 0, 0, 0])      # [bound, consecutive misses, calls left without speculation, bound on the tiles, light tiles of the last frame]
         st[0] = max(int(true_count), int(st[0] * self.DECAY))
         if tiles >= 0:
             st[3] = max(int(tiles), int(st[3] * self.DECAY))
+            if mid_tiles >= 0:
+                st[4] = max(0, int(tiles) - int(mid_tiles))
         if guess is not None:
             missed = true_count > guess or (tile_guess > 0 and tiles > tile_guess)
             st[1] = st[1] + 1 if missed else 0
@@ -110,22 +122,23 @@ class _RasterizeGaussians(torch.autograd.Function):
         # needs more repeats them with the exact sizes).  num_rendered below is what the binning buffer is carved for.
         key = (int(means3D.shape[0]), int(rs.image_height), int(rs.image_width), means3D.device)
         guess = _speculation.guess(key) if _SPECULATE else None
+        light = _speculation.light_tiles(key) if os.environ.get("TGS_LIGHT_TILES") is None else None      # (None: the library's default / the A-B variable)
         tile_guess = 0
         # (the extension keywords travel to the library as an explicit tgs_options_t: no process- or thread-wide knob is touched)
         if guess is not None:
             # the grids of the stages enqueued ahead of the read-back cover a guessed number of tiles with instances, not all tiles
             tile_guess = _speculation.tile_guess(key)
             num_rendered, color, radii, geom, binning, img, true_R, (tiles, mid_tiles) = _call_native(
-                lambda *a: _C.rasterize_gaussians(*a, r_guess=guess, tile_bound=tile_guess), args, rs.debug, "snapshot_fw.dump", "forward")
+                lambda *a: _C.rasterize_gaussians(*a, r_guess=guess, tile_bound=tile_guess, light_tiles=light), args, rs.debug, "snapshot_fw.dump", "forward")
         else:
             num_rendered, color, radii, geom, binning, img, true_R, (tiles, mid_tiles) = _call_native(
-                lambda *a: _C.rasterize_gaussians(*a, info=True), args, rs.debug, "snapshot_fw.dump", "forward")
+                lambda *a: _C.rasterize_gaussians(*a, info=True, light_tiles=light), args, rs.debug, "snapshot_fw.dump", "forward")
         # tiles / mid_tiles: tiles with instances / with >= 128 instances of THIS frame (the forward has read its Meta); -1: unknown
         if _SPECULATE:
-            _speculation.update(key, true_R, guess, tiles, tile_guess)
+            _speculation.update(key, true_R, guess, tiles, tile_guess, mid_tiles)
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
-        ctx.nonempty_tiles, ctx.mid_tiles = tiles, mid_tiles
+        ctx.nonempty_tiles, ctx.mid_tiles, ctx.light = tiles, mid_tiles, light
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img)
         ctx.mark_non_differentiable(radii)
         return color, radii
@@ -143,7 +156,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         bound = ctx.nonempty_tiles if ctx.nonempty_tiles > 0 else 0
         mid = max(ctx.mid_tiles, 1) if (bound > 0 and ctx.mid_tiles >= 0) else 0
         (g_means2D, g_colors, g_opac, g_means3D, g_cov3D, g_sh, g_scales, g_rots) = _call_native(
-            lambda *a: _C.rasterize_gaussians_backward(*a, tile_bound=bound, mid_bound=mid), args, rs.debug, "snapshot_bw.dump", "backward")
+            lambda *a: _C.rasterize_gaussians_backward(*a, tile_bound=bound, mid_bound=mid, light_tiles=ctx.light), args, rs.debug, "snapshot_bw.dump", "backward")
         # forward-argument order (__init__.py:143-153); all eight are always returned
         return g_means3D, g_means2D, g_sh, g_colors, g_opac, g_scales, g_rots, g_cov3D, None
 
