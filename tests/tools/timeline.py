@@ -18,9 +18,25 @@ for it in range(3):
     g = _C.rasterize_gaussians_backward(bg, means3D, radii, colors, scales, rots, 1.0, cov, view, proj, inp['tanfovx'], inp['tanfovy'], dLt, sh, D, campos, geom, R, binning, img, False)
 torch.cuda.synchronize()
 P = means3D.shape[0]
-st = _C.state_field('stamps', P, W, H, R, True, True, geom, binning, img).cpu().numpy().reshape(-1, 4)
+st = _C.state_field('stamps', P, W, H, R, True, True, geom, binning, img).cpu().numpy().reshape(-1, 8)
 rg = _C.state_field('ranges', P, W, H, R, True, True, geom, binning, img).cpu().numpy().reshape(-1, 2)
 n = rg[:,1]-rg[:,0]
+if len(sys.argv) > 1 and sys.argv[1] == 'phases':          # -DTGS_STAMPS=2 build: phases of the one-tile forward workgroups (us, medians per class)
+    sel = n > 0
+    t = st[sel].astype(np.int64); nn = n[sel]
+    ok = t[:, 2] > 0
+    for lo, hi in ((1, 128), (128, 512), (512, 1024), (1024, 1 << 30)):
+        m = ok & (nn >= lo) & (nn < hi)
+        if m.any():
+            x = t[m]
+            print(f'n in [{lo},{hi}): tiles {int(m.sum())}: entry -> descriptor + counts {np.median(x[:,0]-x[:,2])/100:.2f}, -> first round staged {np.median(x[:,3]-x[:,0])/100:.2f}, '
+                  f'-> rounds done {np.median(x[:,6]-x[:,3])/100:.2f}, -> end {np.median(x[:,1]-x[:,6])/100:.2f}; whole {np.median(x[:,1]-x[:,2])/100:.2f}')
+    # turnaround of a workgroup slot: sort the workgroups by entry time; with 512 slots the k-th entry (k >= 512) follows an end
+    ent = np.sort(t[ok, 2]); end = np.sort(t[ok, 1])
+    k = np.arange(512, len(ent))
+    if len(k):
+        print('slot turnaround (entry of workgroup k+512 - k-th end, us): median', np.median(ent[k] - end[k - 512]) / 100)
+    sys.exit(0)
 for name, a, b in (('fwd', 0, 1), ('bwd', 2, 3)):
     sel = n > 0
     t0, t1 = st[sel, a].astype(np.int64), st[sel, b].astype(np.int64)
@@ -35,6 +51,13 @@ for name, a, b in (('fwd', 0, 1), ('bwd', 2, 3)):
         tt = t1.max() * q
         print(f'  t={tt:.0f}us running WGs: {int(((t0 <= tt) & (t1 > tt)).sum())}', end=';')
     print()
+    # utilisation of the 16 wave slots inside a workgroup: sum of the waves' busy time (between a round's staging barrier and their next
+    # barrier) against 16 x the workgroup's span; and against 16 x the slowest wave
+    bs, bm = st[sel, 4 + 2 * (a // 2)].astype(np.float64) / 100.0, st[sel, 5 + 2 * (a // 2)].astype(np.float64) / 100.0
+    for lo, hi in ((128, 512), (512, 1 << 30)):
+        m = (nn >= lo) & (nn < hi) & (bm > 0)
+        if m.any():
+            print(f'  n in [{lo},{hi}): wave busy / (16 x WG span) = {bs[m].sum() / (16 * dur[m].sum()):.3f}; wave busy / (16 x slowest wave) = {bs[m].sum() / (16 * bm[m].sum()):.3f}; slowest wave / WG span = {bm[m].sum() / dur[m].sum():.3f}')
     nz = nn > 0
     print('  us per list entry for non-empty WGs: median', np.median(dur[nz]/nn[nz]), ' heavy(>1000):', np.median(dur[nn>1000]/nn[nn>1000]) if (nn>1000).any() else None)
     # duration vs list length: fixed cost per tile

@@ -164,4 +164,5 @@ def _build_torch_ext_locked(lib: str, out: str, verbose: bool) -> str:
 
 if __name__ == "__main__":
     print(build_native(force="--force" in sys.argv, verbose=True))
-    print(build_torch_ext(force="--force" in sys.argv, verbose=True))
+    if "TGS_LIB_NAME" not in os.environ:                 # (a variant library is loaded through TGS_LIBRARY; the glue stays linked to the default one)
+        print(build_torch_ext(force="--force" in sys.argv, verbose=True))

@@ -843,7 +843,7 @@ int64_t tgs_state_field(void* stream, const char* field, int P, int width, int h
     else if (!strcmp(field, "rgb")) { src = (const char*)g.pack + 24; count = 3 * (size_t)P; esz = 12; stride = 64; rows = (size_t)P; }
     else if (!strcmp(field, "tiles_touched")) { src = g.tiles_touched; count = (size_t)P; }
     else if (!strcmp(field, "tile_order")) { src = s.tile_order; count = T; }
-    else if (!strcmp(field, "stamps")) { src = s.stamps; count = 4 * T; esz = 8; }
+    else if (!strcmp(field, "stamps")) { src = s.stamps; count = 8 * T; esz = 8; }
     else if (!strcmp(field, "block_masks")) { src = (const char*)b.recC + 4; count = (size_t)R; esz = 4; stride = 8; rows = (size_t)R; }   // 16-bit culling mask per sorted instance
     else if (!strcmp(field, "quad_masks")) { src = b.qmask; count = (size_t)R; esz = 8; }                               // 64-bit quadrant mask per sorted instance
     else if (!strcmp(field, "point_list")) { src = b.keys; count = (size_t)R; esz = 4; stride = 8; rows = (size_t)R; }   // low 32 bits of each sorted key

@@ -2,6 +2,7 @@
 // gfx950 (CDNA4) only: wave64, DPP row operations, 160 KiB LDS per CU.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -72,7 +73,7 @@ struct ImgState {
     uint32_t* tile_qmax;      // per tile: deepest list position any of its pixels blended (max n_contrib), written by k_render_fwd
     float* final_T;           //                                    (imgState.accum_alpha)
     uint32_t* n_contrib;      //                                    (imgState.n_contrib)
-    unsigned long long* stamps; // diagnostic builds (-DTGS_STAMPS=1): per tile {fwd start, fwd end, bwd start, bwd end}, 100 MHz ticks
+    unsigned long long* stamps; // diagnostic builds (-DTGS_STAMPS=1): per tile {fwd start, fwd end, bwd start, bwd end, fwd sum / max of the waves' busy time, bwd sum / max}, 100 MHz ticks
 };
 struct BinState {
     unsigned long long* keys; // (depth bits << 32 | gaussian idx), per tile segment, sorted after k_tile_sort
@@ -109,7 +110,7 @@ __host__ __device__ inline size_t img_carve(ImgState& s, char* base, size_t N, s
     carve(p, s.meta, 1); carve(p, s.ranges, T); carve(p, s.tile_count, T); carve(p, s.bin_table, (size_t)BIN_WGS_MAX * T);
     carve(p, s.ovf_tiles, T); carve(p, s.tile_order, T); carve(p, s.tile_desc, T); carve(p, s.light_desc, T); carve(p, s.tile_qmax, T);
     carve(p, s.final_T, N); carve(p, s.n_contrib, N);
-    carve(p, s.stamps, 4 * T);
+    carve(p, s.stamps, 8 * T);
     return (size_t)(p - base) + 256;
 }
 __host__ __device__ inline size_t bin_carve(BinState& b, char* base, size_t R)
@@ -474,13 +475,53 @@ __device__ __forceinline__ bool frame_rejected(const ImgState& s)
     return (__builtin_nontemporal_load(&s.meta->error) & META_ERR_CAPACITY) != 0u;
 }
 
+// Workgroup slots of the persistent render kernels: two 1024-thread workgroups per CU (16 of a CU's 32 wave slots each at <= 64 VGPRs; the
+// LDS of k_render_fwd / k_render_bwd fits twice).  TGS_RENDER_SLOTS overrides (measurements).
+inline uint32_t render_slots()
+{
+    static const uint32_t n = [] {
+        if (const char* e = getenv("TGS_RENDER_SLOTS")) { const long v = atol(e); if (v > 0) return (uint32_t)v; }
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        return 2u * (uint32_t)cus;
+    }();
+    return n;
+}
+
 #ifndef TGS_STAMPS
 #define TGS_STAMPS 0
 #endif
 __device__ __forceinline__ void stamp(const ImgState& s, uint32_t tile, int which)
 {
 #if TGS_STAMPS
-    if (threadIdx.x == 0) s.stamps[4 * (size_t)tile + which] = wall_clock64();
+    if (TGS_STAMPS == 2 && which >= 2) return;             // (TGS_STAMPS=2: the backward's slots carry the forward's phases: phase_stamp)
+    if (threadIdx.x == 0) {
+        s.stamps[8 * (size_t)tile + which] = wall_clock64();
+        if (!(which & 1)) { s.stamps[8 * (size_t)tile + 4 + which] = 0ull; s.stamps[8 * (size_t)tile + 5 + which] = 0ull; }
+    }
+#endif
+}
+// diagnostic builds: time a wave spent between a round's staging barrier and its next barrier (which = 0 forward, 1 backward)
+__device__ __forceinline__ unsigned long long busy_clock()
+{
+#if TGS_STAMPS
+    return wall_clock64();
+#else
+    return 0ull;
+#endif
+}
+// -DTGS_STAMPS=2: phases of a one-tile forward workgroup in the backward's slots -- [2] kernel entry, [3] first round staged, [6] last round done
+__device__ __forceinline__ void phase_stamp(const ImgState& s, uint32_t tile, int slot, unsigned long long t)
+{
+#if TGS_STAMPS == 2
+    if (threadIdx.x == 0) s.stamps[8 * (size_t)tile + slot] = t;
+#endif
+}
+__device__ __forceinline__ void busy_report(const ImgState& s, uint32_t tile, int which, unsigned long long dt)
+{
+#if TGS_STAMPS
+    if (TGS_STAMPS == 2 && which == 1) return;
+    if ((threadIdx.x & 63u) == 0u) { atomicAdd(&s.stamps[8 * (size_t)tile + 4 + 2 * which], dt); atomicMax(&s.stamps[8 * (size_t)tile + 5 + 2 * which], dt); }
 #endif
 }
 
@@ -488,7 +529,8 @@ __device__ __forceinline__ void stamp(const ImgState& s, uint32_t tile, int whic
 __device__ __forceinline__ void stamp_if(const ImgState& s, uint32_t tile, int which, bool who)
 {
 #if TGS_STAMPS
-    if (who) s.stamps[4 * (size_t)tile + which] = wall_clock64();
+    if (TGS_STAMPS == 2 && which >= 2) return;
+    if (who) s.stamps[8 * (size_t)tile + which] = wall_clock64();
 #endif
 }
 
@@ -517,6 +559,7 @@ __device__ __forceinline__ void set_wave_priority(uint32_t n)
     if (n > 1024u) __builtin_amdgcn_s_setprio(3);
     else if (n > 512u) __builtin_amdgcn_s_setprio(2);
     else if (n > 256u) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);                    // (a persistent workgroup comes here once per item: the priority follows the item)
 }
 
 // Sums 36 per-lane values (4 list entries x 9 gradient components, v[e*9+k]) over the 64 lanes of a wave.

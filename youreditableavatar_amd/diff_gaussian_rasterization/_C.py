@@ -579,7 +579,7 @@ def state_field(name: str, P: int, width: int, height: int, R: int, has_sh: bool
     dev = geomBuffer.device
     T = ((width + 15) // 16) * ((height + 15) // 16)
     count = {"n_contrib": width * height, "final_T": width * height, "ranges": 2 * T, "point_list": R, "block_masks": R, "quad_masks": R, "means2D": 2 * P,
-             "depths": P, "conic_opacity": 4 * P, "rgb": 3 * P, "tiles_touched": P, "tile_order": T, "stamps": 4 * T}[name]
+             "depths": P, "conic_opacity": 4 * P, "rgb": 3 * P, "tiles_touched": P, "tile_order": T, "stamps": 8 * T}[name]
     out = torch.empty((count,), dtype=_FIELD_DTYPES[name], device=dev)
     with torch.cuda.device(dev):
         r = _lib.tgs_state_field(torch.cuda.current_stream(dev).cuda_stream, name.encode(), P, width, height, int(R),
