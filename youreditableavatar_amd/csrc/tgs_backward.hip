@@ -351,18 +351,10 @@ __device__ __forceinline__ void bwd_light_group(const ImgState& s, const BinStat
     stamp_if(s, tile, 3, active && lt == 0);
 }
 
-// PERSISTENT workgroups like k_render_fwd's (why and how: there): at most two workgroups per CU take work items until none is left -- the
-// one-tile items first (the first n_ne entries of tile_order), then the light groups (light != 0 and the frame's forward formed them:
-// three tiles with fewer than LIGHT_MAX instances each, bwd_light_group).  The first two items of a workgroup are static, the others come
-// from the ticket counter Meta::pad[3] (drawn two items ahead; the last workgroup to leave resets it, so a frame may be back-propagated
-// again).  A tile's deepest blended position comes with its descriptor (tile_desc[].w, written by k_render_fwd), the records of the next
-// tile's first round are fetched when the current tile's last round has been staged, and the next tile's pixel inputs are loaded into
-// the dying pixel state behind the last round's compute: the chain descriptor -> tile_qmax -> records / pixels that opened every
-// workgroup of the one-tile-per-workgroup kernel is off the critical path.
-// bound_items: the grid the caller's tile bounds would have given the one-workgroup-per-item kernel; a frame with more items raises
-// META_ERR_TILE_BOUND as before (nothing is dropped any more, but the contract of tgs_options_t::tile_bound stays).
+// light != 0: tiles with fewer than LIGHT_MAX instances are composited three per workgroup by the LAST workgroups of the grid (bwd_light_group);
+// this kernel's one-tile workgroups end at Meta::n_mid
 __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s, const BinState b, int W, int H, uint32_t gx,
-                                                            const float* __restrict__ bg, const float* __restrict__ dL_dpix, int light, uint32_t n_tiles, uint32_t bound_items)
+                                                            const float* __restrict__ bg, const float* __restrict__ dL_dpix, int light, uint32_t n_tiles)
 {
     __shared__ float4 sA[BCH + 1];
     __shared__ float4 sB[BCH + 1];
@@ -373,263 +365,186 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
     __shared__ uint2 sQ[BCH];                              // quadrant masks of the staged entries
     __shared__ __attribute__((aligned(16))) unsigned short lists[16][BCH + 8];   // one list per block (= per wave): slot | quadrant nibble << 10
     __shared__ __attribute__((aligned(16))) unsigned short qlists[16][4][QL_ROW]; // per wave: the current chunk's four quadrant lists
-    __shared__ uint32_t next_item[2];
-    __shared__ uint4 next_desc[2];                         // descriptor of the next item (valid when that is a one-tile item)
 
-    // (item, nitem and td are kept wave-uniform by hand -- readfirstlane -- so that what is derived from them stays in SGPRs.  The ticket in
-    // flight and the next descriptor on its way to next_desc[] live in the prefetch registers of thread SCHED: the threads beyond 2 BCH stage
-    // nothing, so their r4 / r2 are free -- the kernel has no VGPR to spare, and spills around the rounds wait for the prefetch in flight.)
-    constexpr uint32_t SCHED = 2 * BCH;
-    auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
-    uint32_t item = blockIdx.x, nitem = 2u * gridDim.x - 1u - blockIdx.x;
-    uint4 td = s.tile_desc[min(item, n_tiles - 1u)];        // (in flight beside the frame's flags)
-    if (threadIdx.x == SCHED) next_desc[0] = s.tile_desc[min(nitem, n_tiles - 1u)];      // (in front of the first barrier below)
+    const uint4 td = s.tile_desc[blockIdx.x];               // (in flight beside the frame's flags)
+    // candidate light tile of this thread's quarter: light group g is workgroup gridDim.x - 1 - g and takes light tiles 3 g .. 3 g + 2
     // (light groups only if the frame's forward wrote light_desc -- Meta::pad[1], k_scan: a caller may back-propagate with other options)
     if (light && __builtin_nontemporal_load(&s.meta->pad[1]) == 0u) light = 0;
+    const uint32_t lgroup = gridDim.x - 1u - blockIdx.x, lsub = threadIdx.x >> 8, li = (uint32_t)BWD_LIGHT_PER_WG * lgroup + lsub;
+    const uint4 tdl = (light && lsub < (uint32_t)BWD_LIGHT_PER_WG && li < n_tiles) ? s.light_desc[li] : make_uint4(0u, 0u, 0u, 0u);
     const uint4 ff = frame_counts(s);
     if (ff.x & META_ERR_CAPACITY) return;
-    const uint32_t n_ne = light ? min(ff.w, ff.y) : ff.y, n_light = ff.y - n_ne, n_lgroups = (n_light + BWD_LIGHT_PER_WG - 1) / BWD_LIGHT_PER_WG;
-    const uint32_t n_items = n_ne + n_lgroups;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && n_items > bound_items) atomicOr(&s.meta->error, META_ERR_TILE_BOUND);
-    const size_t N = (size_t)W * H;
-    const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);   // backward.cu:460-461
+    if (light) {
+        const uint32_t n_ne = min(ff.w, ff.y), n_light = ff.y - n_ne, n_lgroups = (n_light + BWD_LIGHT_PER_WG - 1) / BWD_LIGHT_PER_WG;
+        // (check_tile_bound: the grid must hold the one-tile workgroups and the light groups side by side)
+        if (blockIdx.x == 0 && threadIdx.x == 0 && n_ne + n_lgroups > gridDim.x) atomicOr(&s.meta->error, META_ERR_TILE_BOUND);
+        if (blockIdx.x >= n_ne) {
+            if (lgroup >= n_lgroups) return;                // (uniform over the workgroup)
+            if (threadIdx.x == 0) { sA[BNULL] = make_float4(0.f, 0.f, 0.f, 0.f); sB[BNULL] = make_float4(0.f, 0.f, 0.f, 0.f); sC[BNULL] = 0.f; }
+            bwd_light_group(s, b, W, H, gx, bg, dL_dpix, tdl, lsub < (uint32_t)BWD_LIGHT_PER_WG && li < n_light, sA, sB, sC, sSlot[0], acc, sQ, lists, qlists);
+            return;
+        }
+    } else check_tile_bound(s);
+    const uint32_t tile = td.x;
+    const uint32_t tx = tile % gx, ty = tile / gx;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int qd = lane >> 4, pq = (lane >> 2) & 3, e = lane & 3;   // DPP row = 2x2 quadrant of the block, pixel of the quadrant, entry slot
+    const int px = tx * TILE + (wv & 3) * 4 + (qd & 1) * 2 + (pq & 1);
+    const int py = ty * TILE + (wv >> 2) * 4 + (qd >> 1) * 2 + (pq >> 1);
+    const bool inside = px < W && py < H;
+    const float pixfx = (float)px, pixfy = (float)py;
+    const uint2 rg = make_uint2(td.y, td.z);
+    const uint32_t n = rg.y - rg.x;
+    if (n == 0) return;
+    set_wave_priority(n);
+    stamp(s, tile, 2);
+    const size_t pix_id = (size_t)W * py + px, N = (size_t)W * H;
     if (threadIdx.x == 0) { sA[BNULL] = make_float4(0.f, 0.f, 0.f, 0.f); sB[BNULL] = make_float4(0.f, 0.f, 0.f, 0.f); sC[BNULL] = 0.f; }
-    for (uint32_t i = threadIdx.x; i < NACC * (BCH + 1); i += BWD_THREADS) (&acc[0][0])[i] = 0.0;     // (every flush leaves its columns zero again)
+
+    const float T_final = inside ? s.final_T[pix_id] : 0.f;
+    float T = T_final;
+    const uint32_t last_contributor = inside ? s.n_contrib[pix_id] : 0u;
+    float dpx0 = 0.f, dpx1 = 0.f, dpx2 = 0.f;
+    if (inside) { dpx0 = dL_dpix[pix_id]; dpx1 = dL_dpix[N + pix_id]; dpx2 = dL_dpix[2 * N + pix_id]; }
+    float bg_dot_dpixel = 0.f;                              // backward.cu:533-535
+    bg_dot_dpixel += bg[0] * dpx0; bg_dot_dpixel += bg[1] * dpx1; bg_dot_dpixel += bg[2] * dpx2;
+    const float tfinal_bg = T_final * bg_dot_dpixel;
+    float arA = 0.f;                                        // dL_dpixel . accum_rec with (last_alpha, last_color) already applied (bwd_chain4s)
+    float vone = 1.0f, vzero = 0.0f;                        // identity elements, pinned to VGPRs for the DPP selects
+    asm volatile("" : "+v"(vone), "+v"(vzero));
+    const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);   // backward.cu:460-461
+
+    const uint32_t qmax = min(td.w, n);                     // deepest position any pixel of the tile blended (k_render_fwd wrote it into the descriptor: no dependent load)
+    uint32_t qlast[4];                                      // the same per quadrant of this wave's block (wave-uniform)
+    {
+        uint32_t m = last_contributor;                      // max over the row's 4 pixels (lanes 4 apart), then one lane per row
+        m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x124, 0xf, 0xf, false));     // row_ror:4
+        m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x128, 0xf, 0xf, false));     // row_ror:8
+#pragma unroll
+        for (int q = 0; q < 4; q++) qlast[q] = (uint32_t)__builtin_amdgcn_readlane((int)m, 16 * q);
+    }
+    __syncthreads();                                        // the null record is in LDS
+
+    // rows of the never-visited tail are zero
+    for (uint32_t q = qmax + threadIdx.x; q < n; q += BWD_THREADS) {
+        float4* row = b.slab + (size_t)b.slot[rg.x + q] * SLAB_ROW;
+        row[0] = make_float4(0.f, 0.f, 0.f, 0.f); row[1] = make_float4(0.f, 0.f, 0.f, 0.f); row[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 
     // Register-staged prefetch of the next round, split over the two halves of the workgroup so that it costs 6 VGPRs, not 11
     // (64 VGPRs keep two workgroups per CU): thread t < BCH carries recA + the quadrant mask of entry t, thread BCH + t recB + recC + slot.
-    // One 16-B and two 4-B loads from per-thread addresses, no branch (k_render_fwd: why).  t: the thread's index (the item loop hides it
-    // from the optimiser, see there).
+    const bool upper = threadIdx.x >= BCH;
+    const uint32_t ht = threadIdx.x < 2 * BCH ? (upper ? threadIdx.x - BCH : threadIdx.x) : 0xffffffffu;   // (threads beyond 2 BCH stage nothing)
     float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
     uint2 r2 = make_uint2(0u, 0u);
-    auto fetch_as = [&](uint32_t t, uint32_t pos) {
-        const bool lower = t < (uint32_t)BCH;
-        const float4* p4 = lower ? b.recA : b.recB;
-        const uint32_t* pa = lower ? reinterpret_cast<const uint32_t*>(b.qmask + pos) : reinterpret_cast<const uint32_t*>(b.recC + pos);
-        const uint32_t* pb = lower ? reinterpret_cast<const uint32_t*>(b.qmask + pos) + 1 : b.slot + pos;
-        r4 = p4[pos]; r2.x = *pa; r2.y = *pb;
+    auto fetch = [&](uint32_t pos) {
+        if (!upper) { r4 = b.recA[pos]; r2 = b.qmask[pos]; }
+        else { r4 = b.recB[pos]; r2 = make_uint2(__float_as_uint(b.recC[pos].x), b.slot[pos]); }
     };
-    // the pixel of thread t in tile tl: its inputs (backward.cu:420-440)
-    float T_final = 0.f, dpx0 = 0.f, dpx1 = 0.f, dpx2 = 0.f;
-    uint32_t last_contributor = 0u;
-    auto load_pixel_as = [&](uint32_t t, uint32_t tl) {
-        const int wv_ = t >> 6, qd_ = (t >> 4) & 3, pq_ = (t >> 2) & 3;
-        const int px = (tl % gx) * TILE + (wv_ & 3) * 4 + (qd_ & 1) * 2 + (pq_ & 1);
-        const int py = (tl / gx) * TILE + (wv_ >> 2) * 4 + (qd_ >> 1) * 2 + (pq_ >> 1);
-        const bool inside = px < W && py < H;
-        const size_t pix_id = (size_t)W * py + px;
-        T_final = inside ? s.final_T[pix_id] : 0.f;
-        last_contributor = inside ? s.n_contrib[pix_id] : 0u;
-        dpx0 = inside ? dL_dpix[pix_id] : 0.f; dpx1 = inside ? dL_dpix[N + pix_id] : 0.f; dpx2 = inside ? dL_dpix[2 * N + pix_id] : 0.f;
+    auto stage = [&](int buf) {
+        uint32_t h = ht;
+        asm volatile("" : "+v"(h));                        // keeps the five LDS addresses from being hoisted into (spilled) VGPRs
+        if (!upper) { stage_conic_a(r4); sA[h] = r4; sQ[h] = r2; }
+        else { sFl[buf][h] = make_float2(r4.x, r4.y); stage_conic_b(r4); sB[h] = r4; sC[h] = __uint_as_float(r2.x); sSlot[buf][h] = r2.y; }
     };
-    bool have_first = false;                                // the prefetch registers hold the first round of tile td; the pixel state its pixels
-    if (item < n_ne) {
-        const uint32_t q0 = min(td.w, td.z - td.y), t0 = threadIdx.x;
-        const uint32_t h0 = t0 < 2 * BCH ? (t0 >= BCH ? t0 - BCH : t0) : 0xffffffffu;
-        if (h0 < q0) fetch_as(t0, td.y + q0 - 1 - h0);
-        load_pixel_as(t0, td.x);
-        have_first = true;
-    }
-    __syncthreads();                                        // the null record and the zeroed accumulator are in LDS
+    if (ht < qmax) fetch(rg.x + qmax - 1 - ht);
 
-    int rnd = 0, par = 0;
-    while (item < n_ne) {                                   // ---- one-tile items ----
-        // everything derived from the thread's index is derived again per item (k_render_fwd: why)
-        uint32_t tid = threadIdx.x;
-        asm volatile("" : "+v"(tid));
-        const int wv = tid >> 6, lane = tid & 63;
-        const int qd = lane >> 4, pq = (lane >> 2) & 3, e = lane & 3;   // DPP row = 2x2 quadrant of the block, pixel of the quadrant, entry slot
-        float vone = 1.0f, vzero = 0.0f;                    // identity elements, pinned to VGPRs for the DPP selects
-        asm volatile("" : "+v"(vone), "+v"(vzero));
-        const bool upper = tid >= (uint32_t)BCH;
-        const uint32_t ht = tid < 2 * BCH ? (upper ? tid - BCH : tid) : 0xffffffffu;   // (threads beyond 2 BCH stage nothing)
-        auto fetch = [&](uint32_t pos) { fetch_as(tid, pos); };
-        auto load_pixel = [&](uint32_t tl) { load_pixel_as(tid, tl); };
-        auto stage = [&](int buf) {
-            uint32_t h = ht;
-            asm volatile("" : "+v"(h));                    // keeps the five LDS addresses from being hoisted into (spilled) VGPRs
-            if (!upper) { stage_conic_a(r4); sA[h] = r4; sQ[h] = r2; }
-            else { sFl[buf][h] = make_float2(r4.x, r4.y); stage_conic_b(r4); sB[h] = r4; sC[h] = __uint_as_float(r2.x); sSlot[buf][h] = r2.y; }
-        };
-        // thread SCHED: the item after next, in flight in r2.x until this item's last barrier (atomicAdd of a uniform value is rewritten into
-        // add + readfirstlane: a wait for the round trip right here)
-        if (tid == SCHED) r2.x = atomicInc(&s.meta->pad[3], 0xffffffffu);
-        const uint32_t tile = td.x;
-        const uint32_t tx = tile % gx, ty = tile / gx;
-        const int px = tx * TILE + (wv & 3) * 4 + (qd & 1) * 2 + (pq & 1);
-        const int py = ty * TILE + (wv >> 2) * 4 + (qd >> 1) * 2 + (pq >> 1);
-        const float pixfx = (float)px, pixfy = (float)py;
-        const uint2 rg = make_uint2(td.y, td.z);
-        const uint32_t n = rg.y - rg.x;
-        const uint32_t qmax = min(td.w, n);                 // deepest position any pixel of the tile blended (k_render_fwd)
-        set_wave_priority(n);
-        stamp(s, tile, 2);
-        if (!have_first) { if (ht < qmax) fetch(rg.x + qmax - 1 - ht); load_pixel(tile); }
-        have_first = false;
-        float T = T_final;
-        float bg_dot_dpixel = 0.f;                          // backward.cu:533-535
-        bg_dot_dpixel += bg[0] * dpx0; bg_dot_dpixel += bg[1] * dpx1; bg_dot_dpixel += bg[2] * dpx2;
-        const float tfinal_bg = T_final * bg_dot_dpixel;
-        float arA = 0.f;                                    // dL_dpixel . accum_rec with (last_alpha, last_color) already applied (bwd_chain4s)
-        uint32_t qlast[4];                                  // the deepest last contributor per quadrant of this wave's block (wave-uniform)
+    // Two barriers per round: [compute r] | flush r + zero its accumulator column + stage r+1 | [compute r+1] ...
+    for (uint32_t i = threadIdx.x; i < NACC * (BCH + 1); i += BWD_THREADS) (&acc[0][0])[i] = 0.0;
+    {
+        const uint32_t cnt0 = min((uint32_t)BCH, qmax);
+        if (ht < cnt0) stage(0);
+        if (qmax > BCH && ht < qmax - BCH) fetch(rg.x + qmax - BCH - 1 - ht);
+    }
+    __syncthreads();
+    int rnd = 0;
+    unsigned long long busy = 0ull;                        // (diagnostic builds only: tests/tools/timeline.py)
+    for (uint32_t qhi = qmax; qhi > 0; qhi = qhi > BCH ? qhi - BCH : 0, rnd ^= 1) {
+        const uint32_t cnt = min((uint32_t)BCH, qhi);
+        const unsigned long long tb0 = busy_clock();
         {
-            uint32_t m = last_contributor;                  // max over the row's 4 pixels (lanes 4 apart), then one lane per row
-            m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x124, 0xf, 0xf, false));     // row_ror:4
-            m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x128, 0xf, 0xf, false));     // row_ror:8
-#pragma unroll
-            for (int q = 0; q < 4; q++) qlast[q] = (uint32_t)__builtin_amdgcn_readlane((int)m, 16 * q);
-        }
-        // rows of the never-visited tail are zero
-        for (uint32_t q = qmax + threadIdx.x; q < n; q += BWD_THREADS) {
-            float4* row = b.slab + (size_t)b.slot[rg.x + q] * SLAB_ROW;
-            row[0] = make_float4(0.f, 0.f, 0.f, 0.f); row[1] = make_float4(0.f, 0.f, 0.f, 0.f); row[2] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        // Two barriers per round: [compute r] | flush r + zero its accumulator column + stage r+1 | [compute r+1] ...; the first round of a
-        // tile is staged behind the previous tile's last flush like any other round (the flush reads the other sFl / sSlot buffer)
-        {
-            if (tid == SCHED && item != blockIdx.x) next_desc[par] = make_uint4(__float_as_uint(r4.x), __float_as_uint(r4.y), __float_as_uint(r4.z), __float_as_uint(r4.w));
-            const uint32_t cnt0 = min((uint32_t)BCH, qmax);
-            if (ht < cnt0) stage(rnd);
-            if (qmax > BCH) { if (ht < qmax - BCH) fetch(rg.x + qmax - BCH - 1 - ht); }
-        }
-        __syncthreads();
-        if (qmax <= BCH && nitem < n_ne) {                      // a tile of one round: the next tile's first round already (next_desc[par]: published in front of the barrier)
-            const uint4 nd = next_desc[par];
-            const uint32_t nq = min(nd.w, nd.z - nd.y);
-            if (ht < nq) fetch(nd.y + nq - 1 - ht);
-            have_first = true;
-        }
-        bool next_pixels = false;
-        unsigned long long busy = 0ull;                        // (diagnostic builds only)
-        for (uint32_t qhi = qmax; qhi > 0; qhi = qhi > BCH ? qhi - BCH : 0, rnd ^= 1) {
-            const uint32_t cnt = min((uint32_t)BCH, qhi);
-            const unsigned long long tb0 = busy_clock();
-            {
-                const uint32_t nl = build_own_list_q<BCH>(lists[wv], sQ, cnt, wv, lane);
-                const unsigned short* myq = &qlists[wv][qd][e];
+            const uint32_t nl = build_own_list_q<BCH>(lists[wv], sQ, cnt, wv, lane);
+            const unsigned short* myq = &qlists[wv][qd][e];
 #pragma unroll 1
-                for (uint32_t c0 = 0; c0 < nl; c0 += QCH) {
-                const uint32_t nq = build_chunk_quadrant_lists<TGS_BWD_BOUNDED>(qlists[wv], lists[wv], c0, nl, lane, BNULL, qhi - 1, qlast);
+            for (uint32_t c0 = 0; c0 < nl; c0 += QCH) {
+            const uint32_t nq = build_chunk_quadrant_lists<TGS_BWD_BOUNDED>(qlists[wv], lists[wv], c0, nl, lane, BNULL, qhi - 1, qlast);
 #pragma unroll 1
-                for (uint32_t k = 0; k < nq; k += 4) {          // 4 entries of its own quadrant list per row and pass
-                    const uint32_t j = myq[k];
-                    const float4 a = sA[j];                     // mean2D, conic xx / xy pre-scaled for exp2 (stage_conic)
-                    const float4 bb = sB[j];                    // conic yy pre-scaled, opacity, colour r g
-                    const float c0 = bb.z, c1 = bb.w, c2 = sC[j];
-                    const float dx = a.x - pixfx, dy = a.y - pixfy;
-                    const float power2 = (a.z * dx + a.w * dy) * dx + (bb.x * dy) * dy;   // log2(e) * power of forward.cu:336
-                    const float G = __builtin_amdgcn_exp2f(power2);
-                    const float alpha = fminf(0.99f, bb.y * G);
-                    // list position of slot j is qhi-1-j; "contributor >= last_contributor" skip of backward.cu:487.  A padding
-                    // entry (j == BNULL) has opacity 0 and fails the alpha test.
-                    const bool valid = (qhi - 1 - j < last_contributor) && !(power2 > 0.0f) && !(alpha < 1.0f / 255.0f);
-                    if (__builtin_amdgcn_ballot_w64(valid) == 0) continue;
-                    const float aeff = valid ? alpha : 0.f;     // a skipped entry is walked as alpha = 0, G = 0
-                    const float Geff = valid ? G : 0.f;
-                    // the quad walks the pixel's state through the group's 4 entries (bwd_chain4s, tgs_device.hpp)
-                    float Town, inv_om, Aown;
-                    float sdot = c0 * dpx0;
-                    sdot += c1 * dpx1; sdot += c2 * dpx2;               // dL_dpixel . colour of this entry
-                    bwd_chain4s(aeff, sdot, T, arA, Town, inv_om, Aown, vone, vzero);
-                    // this lane's (pixel, entry) terms, backward.cu:507-555 (all zero for a skipped entry).  Everything that is
-                    // constant per entry -- opacity, the conic, -0.5, the ndc scale -- is applied once per entry at the flush
-                    // (flush_row), so a lane only forms the moments of w = G * dL_dalpha over dx, dy.
-                    const float dchannel_dcolor = aeff * Town;
-                    float dL_dalpha = sdot - Aown;                     // sum_ch (c_ch - accum_rec_ch) * dL_dpixel_ch
-                    dL_dalpha = dL_dalpha * Town - tfinal_bg * inv_om;      // ... + (-T_final / (1 - alpha)) * bg_dot_dpixel
-                    const float w = Geff * dL_dalpha;
-                    const float wdx = w * dx, wdy = w * dy;
-                    float v[NACC];
-                    v[0] = dchannel_dcolor * dpx0; v[1] = dchannel_dcolor * dpx1; v[2] = dchannel_dcolor * dpx2;
-                    v[3] = wdx; v[4] = wdy;
-                    v[5] = wdx * dx; v[6] = wdx * dy; v[7] = wdy * dy;
-                    v[8] = w;
-                    row_stride4_sum9(v);                        // the quadrant's 4 pixels: the 4 lanes of the row that share an entry slot
-                    // every row adds for its own entries: lane (pixel i, slot e) takes components i, 4 + i (and 8 if i == 0) of entry j
-                    const float s0 = pq == 0 ? v[0] : pq == 1 ? v[1] : pq == 2 ? v[2] : v[3];
-                    const float s1 = pq == 0 ? v[4] : pq == 1 ? v[5] : pq == 2 ? v[6] : v[7];
+            for (uint32_t k = 0; k < nq; k += 4) {          // 4 entries of its own quadrant list per row and pass
+                const uint32_t j = myq[k];
+                const float4 a = sA[j];                     // mean2D, conic xx / xy pre-scaled for exp2 (stage_conic)
+                const float4 bb = sB[j];                    // conic yy pre-scaled, opacity, colour r g
+                const float c0 = bb.z, c1 = bb.w, c2 = sC[j];
+                const float dx = a.x - pixfx, dy = a.y - pixfy;
+                const float power2 = (a.z * dx + a.w * dy) * dx + (bb.x * dy) * dy;   // log2(e) * power of forward.cu:336
+                const float G = __builtin_amdgcn_exp2f(power2);
+                const float alpha = fminf(0.99f, bb.y * G);
+                // list position of slot j is qhi-1-j; "contributor >= last_contributor" skip of backward.cu:487.  A padding
+                // entry (j == BNULL) has opacity 0 and fails the alpha test.
+                const bool valid = (qhi - 1 - j < last_contributor) && !(power2 > 0.0f) && !(alpha < 1.0f / 255.0f);
+                if (__builtin_amdgcn_ballot_w64(valid) == 0) continue;
+                const float aeff = valid ? alpha : 0.f;     // a skipped entry is walked as alpha = 0, G = 0
+                const float Geff = valid ? G : 0.f;
+                // the quad walks the pixel's state through the group's 4 entries (bwd_chain4s, tgs_device.hpp)
+                float Town, inv_om, Aown;
+                float sdot = c0 * dpx0;
+                sdot += c1 * dpx1; sdot += c2 * dpx2;               // dL_dpixel . colour of this entry
+                bwd_chain4s(aeff, sdot, T, arA, Town, inv_om, Aown, vone, vzero);
+                // this lane's (pixel, entry) terms, backward.cu:507-555 (all zero for a skipped entry).  Everything that is
+                // constant per entry -- opacity, the conic, -0.5, the ndc scale -- is applied once per entry at the flush
+                // (flush_row), so a lane only forms the moments of w = G * dL_dalpha over dx, dy.
+                const float dchannel_dcolor = aeff * Town;
+                float dL_dalpha = sdot - Aown;                     // sum_ch (c_ch - accum_rec_ch) * dL_dpixel_ch
+                dL_dalpha = dL_dalpha * Town - tfinal_bg * inv_om;      // ... + (-T_final / (1 - alpha)) * bg_dot_dpixel
+                const float w = Geff * dL_dalpha;
+                const float wdx = w * dx, wdy = w * dy;
+                float v[NACC];
+                v[0] = dchannel_dcolor * dpx0; v[1] = dchannel_dcolor * dpx1; v[2] = dchannel_dcolor * dpx2;
+                v[3] = wdx; v[4] = wdy;
+                v[5] = wdx * dx; v[6] = wdx * dy; v[7] = wdy * dy;
+                v[8] = w;
+                row_stride4_sum9(v);                        // the quadrant's 4 pixels: the 4 lanes of the row that share an entry slot
+                // every row adds for its own entries: lane (pixel i, slot e) takes components i, 4 + i (and 8 if i == 0) of entry j
+                const float s0 = pq == 0 ? v[0] : pq == 1 ? v[1] : pq == 2 ? v[2] : v[3];
+                const float s1 = pq == 0 ? v[4] : pq == 1 ? v[5] : pq == 2 ? v[6] : v[7];
 #ifdef TGS_EXP_NOATOM
-                    asm volatile("" :: "v"(s0), "v"(s1), "v"(v[8]));
+                asm volatile("" :: "v"(s0), "v"(s1), "v"(v[8]));
 #else
-                    // rows whose list is shorter than the longest of the chunk idle on the null record: their sums are zero, and without this
-                    // test all of them would add into the ONE spare column -- same-address LDS atomics serialise
-                    if (j != (uint32_t)BNULL) {
-                        atomicAdd(&acc[pq][j], (double)s0);
-                        atomicAdd(&acc[4 + pq][j], (double)s1);
-                        if (pq == 0) atomicAdd(&acc[8][j], (double)v[8]);
-                    }
+                // rows whose list is shorter than the longest of the chunk idle on the null record: their sums are zero, and without this
+                // test all of them would add into the ONE spare column -- same-address LDS atomics serialise
+                if (j != (uint32_t)BNULL) {
+                    atomicAdd(&acc[pq][j], (double)s0);
+                    atomicAdd(&acc[4 + pq][j], (double)s1);
+                    if (pq == 0) atomicAdd(&acc[8][j], (double)v[8]);
+                }
 #endif
-                }
-                }
             }
-            busy += busy_clock() - tb0;
-            if (qhi <= BCH && nitem < n_ne) { load_pixel(next_desc[par].x); next_pixels = true; }    // the tile's last round is composited: the pixel state takes the next tile's pixels
-            __syncthreads();                                    // every wave is done with the records and the accumulator of this round
-            if (threadIdx.x < cnt) {                            // flush: one 48-B row per instance, then clear the column for the next round
-                const uint32_t j = threadIdx.x;
-                // moments -> gradients (backward.cu:537-555): dL_dG = opacity * dL_dalpha, dG/ddel = -G (conic . d), conic terms * -0.5
-                // (sA[j] is restaged by this same thread below; sB[j] by thread BCH + j, possibly already: hence sFl)
-                const float4 a = sA[j]; const float2 fl = sFl[rnd][j];
-                const float cxx = a.z * UNSCALE_CONIC, cxy = a.w * UNSCALE_CONIC_XY, cyy = fl.x, op = fl.y;
-                const float Sx = (float)acc[3][j], Sy = (float)acc[4][j];
-                float4* row = b.slab + (size_t)sSlot[rnd][j] * SLAB_ROW;
-                row[0] = make_float4((float)acc[0][j], (float)acc[1][j], (float)acc[2][j], op * (-Sx * cxx - Sy * cxy) * ddelx_dx);
-                row[1] = make_float4(op * (-Sy * cyy - Sx * cxy) * ddely_dy, -0.5f * op * (float)acc[5][j], -0.5f * op * (float)acc[6][j], -0.5f * op * (float)acc[7][j]);
-                row[2] = make_float4((float)acc[8][j], 0.f, 0.f, 0.f);
+            }
+        }
+        busy += busy_clock() - tb0;
+        __syncthreads();                                    // every wave is done with the records and the accumulator of this round
+        if (threadIdx.x < cnt) {                            // flush: one 48-B row per instance, then clear the column for the next round
+            const uint32_t j = threadIdx.x;
+            // moments -> gradients (backward.cu:537-555): dL_dG = opacity * dL_dalpha, dG/ddel = -G (conic . d), conic terms * -0.5
+            // (sA[j] is restaged by this same thread below; sB[j] by thread BCH + j, possibly already: hence sFl)
+            const float4 a = sA[j]; const float2 fl = sFl[rnd][j];
+            const float cxx = a.z * UNSCALE_CONIC, cxy = a.w * UNSCALE_CONIC_XY, cyy = fl.x, op = fl.y;
+            const float Sx = (float)acc[3][j], Sy = (float)acc[4][j];
+            float4* row = b.slab + (size_t)sSlot[rnd][j] * SLAB_ROW;
+            row[0] = make_float4((float)acc[0][j], (float)acc[1][j], (float)acc[2][j], op * (-Sx * cxx - Sy * cxy) * ddelx_dx);
+            row[1] = make_float4(op * (-Sy * cyy - Sx * cxy) * ddely_dy, -0.5f * op * (float)acc[5][j], -0.5f * op * (float)acc[6][j], -0.5f * op * (float)acc[7][j]);
+            row[2] = make_float4((float)acc[8][j], 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int k = 0; k < NACC; k++) acc[k][j] = 0.0;
-            }
-            if (qhi > BCH) {                                    // stage the next round (its records were prefetched into registers)
-                const uint32_t qn = qhi - BCH, cntn = min((uint32_t)BCH, qn);
-                if (ht < cntn) stage(rnd ^ 1);
-                if (qn > BCH) { if (ht < qn - BCH) fetch(rg.x + qn - BCH - 1 - ht); }
-                else if (nitem < n_ne) {                            // that was the last round: the next tile's first
-                    const uint4 nd = next_desc[par];
-                    const uint32_t nq = min(nd.w, nd.z - nd.y);
-                    if (ht < nq) fetch(nd.y + nq - 1 - ht);
-                    have_first = true;
-                }
-                __syncthreads();
-            }
+            for (int k = 0; k < NACC; k++) acc[k][j] = 0.0;
         }
-        busy_report(s, tile, 1, busy);
-        stamp(s, tile, 3);
-        if (have_first && !next_pixels) load_pixel(next_desc[par].x);      // (a tile nothing was blended into runs no round)
-        {
-            const uint4 nd = next_desc[par];
-            td = make_uint4(uni(nd.x), uni(nd.y), uni(nd.z), uni(nd.w));
+        if (qhi > BCH) {                                    // stage the next round (its records were prefetched into registers)
+            const uint32_t qn = qhi - BCH, cntn = min((uint32_t)BCH, qn);
+            if (ht < cntn) stage(rnd ^ 1);
+            if (qn > BCH && ht < qn - BCH) fetch(rg.x + qn - BCH - 1 - ht);
+            __syncthreads();
         }
-        // thread SCHED: the ticket has arrived; the descriptor of that item goes to the other next_desc slot (nobody reads that one before the
-        // barrier below: its readers of the previous item are past that item's last barrier)
-        if (tid == SCHED) {
-            const uint32_t t2 = r2.x + 2u * gridDim.x;
-            next_item[par] = t2;
-            const uint4 d = s.tile_desc[min(t2, n_tiles - 1u)];     // (in flight in r4 until the next item's first barrier)
-            r4 = make_float4(__uint_as_float(d.x), __uint_as_float(d.y), __uint_as_float(d.z), __uint_as_float(d.w));
-        }
-        __syncthreads();
-        item = nitem; nitem = uni(next_item[par]); par ^= 1;
     }
-    // ---- light groups ----
-    const uint32_t lsub = threadIdx.x >> 8;
-    auto light_td = [&](uint32_t it) {                      // this quarter's light tile of item it (zero: none)
-        const uint32_t li = (uint32_t)BWD_LIGHT_PER_WG * (it - n_ne) + lsub;
-        return (it >= n_ne && it < n_items && lsub < (uint32_t)BWD_LIGHT_PER_WG && li < n_light) ? s.light_desc[li] : make_uint4(0u, 0u, 0u, 0u);
-    };
-    uint4 tdl = light_td(item), ntdl = light_td(nitem);
-    while (item < n_items) {
-        uint32_t ticket = 0u;
-        if (threadIdx.x == 0) ticket = atomicInc(&s.meta->pad[3], 0xffffffffu);      // (atomicAdd of a uniform value is rewritten into add + readfirstlane: a wait for the round trip right here)
-        __syncthreads();                                    // (the previous item is done with the LDS)
-        bwd_light_group(s, b, W, H, gx, bg, dL_dpix, tdl, lsub < (uint32_t)BWD_LIGHT_PER_WG && (uint32_t)BWD_LIGHT_PER_WG * (item - n_ne) + lsub < n_light,
-                        sA, sB, sC, sSlot[0], acc, sQ, lists, qlists);
-        if (threadIdx.x == 0) next_item[par] = ticket + 2u * gridDim.x;
-        __syncthreads();
-        item = nitem; nitem = uni(next_item[par]); par ^= 1;
-        tdl = ntdl; ntdl = light_td(nitem);
-    }
-    // the last workgroup to leave resets the ticket counter: the frame can be back-propagated again (k_scan zeroes both for a new frame)
-    if (threadIdx.x == 0 && atomicAdd(&s.meta->pad[4], 1u) == gridDim.x - 1u) { s.meta->pad[3] = 0u; s.meta->pad[4] = 0u; }
+    busy_report(s, tile, 1, busy);
+    stamp(s, tile, 3);
 }
 
 
@@ -1451,13 +1366,12 @@ void launch_render_bwd(hipStream_t st, const ImgState& s, const BinState& b, int
 {
     // (-DTGS_FAST_MATH=0 builds always take the fixed-order kernel: it evaluates exp / the divisions in their accurate forms)
     if (deterministic || !TGS_FAST_MATH) { hipLaunchKernelGGL(k_render_bwd_det, dim3(tiles), dim3(256), 0, st, s, b, W, H, gx, bg, dL_dpix); return; }
-    // items: one-tile items for the (bound on the) tiles with >= LIGHT_MAX instances + light groups for the rest, three tiles each -- with exact
-    // counts (heavy = n_mid, tiles = n_nonempty) that is n_mid + ceil((n_nonempty - n_mid) / 3), with bounds an upper bound of it; without
-    // light groups every tile with instances is an item.  Persistent workgroups: no more than fit the chip at once.
-    const uint32_t heavy = light ? (mid_tiles < tiles ? mid_tiles : tiles) : tiles;
-    const uint32_t items = heavy + (tiles - heavy + BWD_LIGHT_PER_WG - 1) / BWD_LIGHT_PER_WG;
-    const uint32_t grid = items < render_slots() ? (items > 0 ? items : 1u) : render_slots();
-    hipLaunchKernelGGL(k_render_bwd, dim3(grid), dim3(BWD_THREADS), 0, st, s, b, W, H, gx, bg, dL_dpix, light, T, items);
+    if (!light) { hipLaunchKernelGGL(k_render_bwd, dim3(tiles), dim3(BWD_THREADS), 0, st, s, b, W, H, gx, bg, dL_dpix, 0, T); return; }
+    const uint32_t heavy = mid_tiles < tiles ? mid_tiles : tiles;
+    // one-tile workgroups for the (bound on the) tiles with >= LIGHT_MAX instances + light groups for the rest, three tiles each.  With exact
+    // counts (heavy = n_mid, tiles = n_nonempty) that is n_mid + ceil((n_nonempty - n_mid) / 3); with bounds it is an upper bound of it.
+    const uint32_t grid = heavy + (tiles - heavy + BWD_LIGHT_PER_WG - 1) / BWD_LIGHT_PER_WG;      // (largest when n_mid reaches its bound)
+    hipLaunchKernelGGL(k_render_bwd, dim3(grid > 0 ? grid : 1u), dim3(BWD_THREADS), 0, st, s, b, W, H, gx, bg, dL_dpix, 1, T);
 }
 void launch_preprocess_bwd(hipStream_t st, const BwdIn& in, const CamParams& cam, const GeomState& g, const BinState& b)
 {

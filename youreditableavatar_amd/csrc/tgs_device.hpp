@@ -67,10 +67,9 @@ struct ImgState {
                               // inside the tile's list (exclusive scan over w, k_bin_colscan)
     uint32_t* ovf_tiles;      // list of overflow tiles
     uint32_t* tile_order;     // tiles by descending list length: render kernels start the long lists first
-    uint4* tile_desc;         // the same order with the range inlined: (tile, start, end, 0) -- one load instead of a dependent pair
+    uint4* tile_desc;         // the same order with the range inlined: (tile, start, end, w); w = the deepest list position any pixel of the tile blended (max n_contrib), written by k_render_fwd -- one load instead of a dependent chain
     uint4* light_desc;        // the descriptors of the LIGHT tiles once more (tile_desc[n_mid + i], i < n_nonempty - n_mid: fewer than LIGHT_MAX instances),
                               // indexed from 0: the light render kernels fetch descriptor and frame counts side by side instead of one behind the other
-    uint32_t* tile_qmax;      // per tile: deepest list position any of its pixels blended (max n_contrib), written by k_render_fwd
     float* final_T;           //                                    (imgState.accum_alpha)
     uint32_t* n_contrib;      //                                    (imgState.n_contrib)
     unsigned long long* stamps; // diagnostic builds (-DTGS_STAMPS=1): per tile {fwd start, fwd end, bwd start, bwd end, fwd sum / max of the waves' busy time, bwd sum / max}, 100 MHz ticks
@@ -108,7 +107,7 @@ __host__ __device__ inline size_t img_carve(ImgState& s, char* base, size_t N, s
 {
     char* p = base;
     carve(p, s.meta, 1); carve(p, s.ranges, T); carve(p, s.tile_count, T); carve(p, s.bin_table, (size_t)BIN_WGS_MAX * T);
-    carve(p, s.ovf_tiles, T); carve(p, s.tile_order, T); carve(p, s.tile_desc, T); carve(p, s.light_desc, T); carve(p, s.tile_qmax, T);
+    carve(p, s.ovf_tiles, T); carve(p, s.tile_order, T); carve(p, s.tile_desc, T); carve(p, s.light_desc, T);
     carve(p, s.final_T, N); carve(p, s.n_contrib, N);
     carve(p, s.stamps, 8 * T);
     return (size_t)(p - base) + 256;
@@ -475,19 +474,6 @@ __device__ __forceinline__ bool frame_rejected(const ImgState& s)
     return (__builtin_nontemporal_load(&s.meta->error) & META_ERR_CAPACITY) != 0u;
 }
 
-// Workgroup slots of the persistent render kernels: two 1024-thread workgroups per CU (16 of a CU's 32 wave slots each at <= 64 VGPRs; the
-// LDS of k_render_fwd / k_render_bwd fits twice).  TGS_RENDER_SLOTS overrides (measurements).
-inline uint32_t render_slots()
-{
-    static const uint32_t n = [] {
-        if (const char* e = getenv("TGS_RENDER_SLOTS")) { const long v = atol(e); if (v > 0) return (uint32_t)v; }
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        return 2u * (uint32_t)cus;
-    }();
-    return n;
-}
-
 #ifndef TGS_STAMPS
 #define TGS_STAMPS 0
 #endif
@@ -559,7 +545,6 @@ __device__ __forceinline__ void set_wave_priority(uint32_t n)
     if (n > 1024u) __builtin_amdgcn_s_setprio(3);
     else if (n > 512u) __builtin_amdgcn_s_setprio(2);
     else if (n > 256u) __builtin_amdgcn_s_setprio(1);
-    else __builtin_amdgcn_s_setprio(0);                    // (a persistent workgroup comes here once per item: the priority follows the item)
 }
 
 // Sums 36 per-lane values (4 list entries x 9 gradient components, v[e*9+k]) over the 64 lanes of a wave.

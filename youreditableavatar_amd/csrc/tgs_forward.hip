@@ -502,7 +502,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const 
                 acc += h;
             }
             s.meta->pad[1] = light ? 1u : 0u;               // light_desc is valid for this frame (the backward may be called with other options)
-            s.meta->pad[2] = 0u; s.meta->pad[3] = 0u; s.meta->pad[4] = 0u;   // ticket counters of the persistent render kernels
             if (too_many) atomicOr(&s.meta->error, META_ERR_CAPACITY);
             if (host_meta) host_meta->pad[0] = too_many ? 1u : 0u;   // (a word of its own: workgroup 0 writes host_meta->error)
         }
@@ -993,7 +992,6 @@ __device__ __forceinline__ void fill_tile_background(const ImgState& s, uint32_t
                                                      const float* __restrict__ bg, float* __restrict__ out_color)
 {
     const int px = (tile % gx) * TILE + (t & 15), py = (tile / gx) * TILE + (t >> 4);
-    if (t == 0) s.tile_qmax[tile] = 0;
     if (px < W && py < H) {
         const size_t pix_id = (size_t)W * py + px, N = (size_t)W * H;
         s.final_T[pix_id] = 1.0f;
@@ -1119,26 +1117,14 @@ __device__ __forceinline__ void fwd_light_group(const ImgState& s, const BinStat
     __syncthreads();
     if (lt == 0 && active) {
         const uint32_t q = max(max(wave_qmax[4 * sub], wave_qmax[4 * sub + 1]), max(wave_qmax[4 * sub + 2], wave_qmax[4 * sub + 3]));
-        s.tile_qmax[tile] = q;
-        reinterpret_cast<uint32_t*>(&s.tile_desc[desc_pos])[3] = q;              // (the backward's descriptor load brings it along: both copies of the descriptor)
-        reinterpret_cast<uint32_t*>(&s.light_desc[light_pos])[3] = q;
+        reinterpret_cast<uint32_t*>(&s.light_desc[light_pos])[3] = q;            // deepest blended position of the tile: k_render_bwd's descriptor load brings it along (both copies of the descriptor)
+        reinterpret_cast<uint32_t*>(&s.tile_desc[desc_pos])[3] = q;
     }
     stamp_if(s, tile, 1, active && lt == 0);
 }
 
-// PERSISTENT workgroups: the grid is at most two workgroups per CU (what fits: 56 KB of LDS, 16 of the CU's 32 wave slots), and every
-// workgroup takes work ITEMS until none is left -- its first one by blockIdx, the others from the frame's ticket counter (Meta::pad[2],
-// zeroed by k_scan).  Items in ticket order: the one-tile items (the first n_ne entries of tile_order: longest lists first), then the light
-// groups (light != 0: four tiles with fewer than LIGHT_MAX instances each, fwd_light_group; Meta::n_mid counts the others), then the
-// chunks of 16 empty tiles that only get the background.
-// Why (phase stamps per workgroup, config 3, profiles/r03_fwd_workgroup_phases.txt): with one workgroup per tile a tile of 512..1023
-// instances spent 0.96 us between its first instruction and its descriptor, 2.06 us more until its first round was staged, 13 us
-// compositing, and its slot then stood empty for 1.0 us until the next workgroup's first instruction: a fifth of every slot's time in
-// latencies, 16 wave slots held all the while.  Here a workgroup always knows its NEXT item: the second one is static (2 G - 1 - blockIdx:
-// the workgroup with the longest first list gets the shortest of the second batch), the ticket for item k + 2 is drawn by thread 0 when
-// item k starts and published at item k's last barrier (a ticket published as soon as it was drawn cost the atomic's round trip in
-// front of every item: 64 -> 79 us), its descriptor is fetched when item k + 1 starts, and the records of the next tile's first round are
-// fetched into the prefetch registers as soon as the current tile's last round has been staged -- a tile starts with its data on chip.
+// light != 0: tiles with fewer than LIGHT_MAX instances (Meta::n_mid counts the others) are composited four per workgroup by the LAST workgroups
+// of the grid (fwd_light_group); this kernel's one-tile workgroups then end at n_mid instead of n_nonempty.
 __global__ __launch_bounds__(FWD_THREADS, 8) void k_render_fwd(const ImgState s, const BinState b, int W, int H, uint32_t gx,
                                                             const float* __restrict__ bg, float* __restrict__ out_color, int fill_tail, uint32_t n_tiles, int light)
 {
@@ -1150,211 +1136,168 @@ __global__ __launch_bounds__(FWD_THREADS, 8) void k_render_fwd(const ImgState s,
     __shared__ __attribute__((aligned(16))) unsigned short qlists[16][4][QL_ROW_F]; // per wave: the current chunk's four quadrant lists
     __shared__ uint32_t wave_alive[2][16];                 // double-buffered "this wave still has live pixels"
     __shared__ uint32_t wave_qmax[16];
-    __shared__ uint32_t next_item[2];                      // the ticket drawn while the current item runs
-    const unsigned long long t_entry = busy_clock();
+    const unsigned long long t_entry = busy_clock();       // (diagnostic builds only: tests/tools/timeline.py)
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-    // (item, nitem and td are kept wave-uniform by hand -- readfirstlane -- so that everything derived from them stays in SGPRs as it did when the
-    // item was blockIdx.x; ntd, loaded a whole item ahead, waits in VGPRs)
-    auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
-    uint32_t item = blockIdx.x, nitem = 2u * gridDim.x - 1u - blockIdx.x;
-    uint4 td = s.tile_desc[min(item, n_tiles - 1u)];       // (in flight beside the frame's counts)
-    uint4 ntd = s.tile_desc[min(nitem, n_tiles - 1u)];     // descriptor of the next item (used when that is a one-tile item)
-    const uint4 ff = frame_counts(s);                      // (error bits, non-empty tiles, heavy, mid)
+    const uint4 td = s.tile_desc[blockIdx.x];
+    // candidate light tile of this thread's quarter: light group g is workgroup gridDim.x - 1 - g and takes light tiles 4 g .. 4 g + 3
+    const uint32_t lgroup = gridDim.x - 1u - blockIdx.x, li = 4u * lgroup + (threadIdx.x >> 8);
+    const uint4 tdl = (light && li < n_tiles) ? s.light_desc[li] : make_uint4(0u, 0u, 0u, 0u);
+    const uint4 ff = frame_counts(s);                      // (error bits, non-empty tiles, heavy, mid): one load, in flight beside the descriptors'
     const uint32_t n_all = (ff.x & META_ERR_CAPACITY) ? 0u : ff.y;     // a frame tgs_forward_async rejected renders the background everywhere
-    const uint32_t n_ne = light ? min(ff.w, n_all) : n_all;           // one-tile items: the first n_ne entries of tile_order
+    const uint32_t n_ne = light ? min(ff.w, n_all) : n_all;           // one-tile workgroups: the first n_ne entries of tile_order
     const uint32_t n_light = n_all - n_ne, n_lgroups = (n_light + 3u) / 4u;
-    const uint32_t n_fill = fill_tail ? (n_tiles - n_all + 15u) / 16u : 0u;
-    const uint32_t n_items = n_ne + n_lgroups + n_fill;
+    if (blockIdx.x >= n_ne) {
+        if (lgroup < n_lgroups) {                           // (uniform over the workgroup)
+            fwd_light_group(s, b, W, H, gx, bg, out_color, tdl, li < n_light, sA, sB, sC, sQ, lists, qlists, wave_qmax, li, n_ne + li);
+            return;
+        }
+        // Sync-free forward: the workgroups between the one-tile ones and the light groups (the grid covers the caller's bounds on both,
+        // plus one workgroup per 16 tiles beyond the tile bound) share the EMPTY tiles -- the tail of tile_order -- four at a time.  (One
+        // workgroup per empty tile was 5400 surplus workgroups at config 3: ~4 % of a frame.)
+        if (fill_tail) {
+            const uint32_t nfill = gridDim.x - n_ne - n_lgroups, j = blockIdx.x - n_ne;
+            for (uint32_t i = n_all + 4u * j + (threadIdx.x >> 8); i < n_tiles; i += 4u * nfill)
+                fill_tile_background(s, s.tile_desc[i].x, threadIdx.x & 255u, W, H, gx, bg, out_color);
+        }
+        return;
+    }
+    const uint32_t tile = td.x;
+    const uint32_t tx = tile % gx, ty = tile / gx;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int qd = lane >> 4, pq = (lane >> 2) & 3, e = lane & 3;   // DPP row = 2x2 quadrant of the block, pixel of the quadrant, entry slot of the group
+    const int px = tx * TILE + (wv & 3) * 4 + (qd & 1) * 2 + (pq & 1);
+    const int py = ty * TILE + (wv >> 2) * 4 + (qd >> 1) * 2 + (pq >> 1);
+    const bool inside = px < W && py < H;
+    const float pixfx = (float)px, pixfy = (float)py;
+    const uint2 rg = make_uint2(td.y, td.z);
+    set_wave_priority(rg.y - rg.x);
+    stamp(s, tile, 0);
+    bool done = !inside;                                   // per pixel; identical in the 4 lanes of a quad
+    float vone = 1.0f;                                     // pinned to a VGPR for the DPP selects
+    asm volatile("" : "+v"(vone));
+    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;          // C: this lane's share (entries of slot e)
+    uint32_t last_contributor = 0;
     if (threadIdx.x == 0) { sA[FNULL] = make_float4(0.f, 0.f, 0.f, 0.f); sB[FNULL] = make_float4(0.f, 0.f, 0.f, 0.f); sC[FNULL] = 0.f; }
 
     // Register-staged prefetch of the next round (global loads stay in flight under the compute), split over the two halves
     // of the workgroup to stay inside 64 VGPRs: thread t < FCH carries recA + recC of entry t, thread FCH + t recB + the quadrant mask.
+    const uint32_t ht = threadIdx.x & (FCH - 1);
+    const bool upper = threadIdx.x >= FCH;
     float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
     uint2 r2 = make_uint2(0u, 0u);
-    // (one 16-B and one 8-B load from per-thread base pointers, no branch: with `if (lower) ... else ...` the two sides' results met in copies
-    // right behind the loads -- a wait for the prefetch before the compute it was meant to run under)
-    auto fetch_as = [&](uint32_t t, uint32_t pos) {        // (t: the thread's index; the item loop hides it from the optimiser, see there)
-        const bool lower = t < (uint32_t)FCH;
-        const float4* p4 = lower ? b.recA : b.recB;
-        const uint2* p2 = lower ? reinterpret_cast<const uint2*>(b.recC) : b.qmask;     // (lower half: .x = colour b; .y, the Gaussian's index, is not used)
-        r4 = p4[pos]; r2 = p2[pos];
+    auto fetch = [&](uint32_t pos) {
+        if (!upper) { r4 = b.recA[pos]; r2.x = __float_as_uint(b.recC[pos].x); }
+        else { r4 = b.recB[pos]; r2 = b.qmask[pos]; }
     };
-    bool have_first = false;                               // the prefetch registers hold the first round of tile td (workgroup-uniform)
-    if (item < n_ne) { const uint32_t h0 = threadIdx.x & (FCH - 1); if (td.y + h0 < td.z) fetch_as(threadIdx.x, td.y + h0); have_first = true; }
+    if (rg.x + ht < rg.y) fetch(rg.x + ht);
 
-    int round = 0, par = 0;
-    while (item < n_ne) {                                   // ---- one-tile items ----
-        // Everything derived from the thread's index is derived again per item: as loop invariants of the item loop the addresses and
-        // lane constants stayed in VGPRs across the render loops (78 VGPRs where the one-tile-per-workgroup kernel needed 52; past 64 a
-        // workgroup of 16 waves no longer fits twice per CU, and spills around the rounds wait for the prefetch in flight).
-        uint32_t tid = threadIdx.x;
-        asm volatile("" : "+v"(tid));
-        const int wv = tid >> 6, lane = tid & 63;
-        const int qd = lane >> 4, pq = (lane >> 2) & 3, e = lane & 3;   // DPP row = 2x2 quadrant of the block, pixel of the quadrant, entry slot of the group
-        float vone = 1.0f;                                  // pinned to a VGPR for the DPP selects
-        asm volatile("" : "+v"(vone));
-        const uint32_t ht = tid & (FCH - 1);
-        const bool upper = tid >= (uint32_t)FCH;
-        auto fetch = [&](uint32_t pos) { fetch_as(tid, pos); };
-        uint32_t ticket = 0u;                               // (thread 0) the item after next: in flight until this item's last barrier
-        if (threadIdx.x == 0) ticket = atomicInc(&s.meta->pad[2], 0xffffffffu);      // (atomicAdd of a uniform value is rewritten into add + readfirstlane: a wait for the round trip right here)
-        const uint32_t tile = td.x;
-        const uint32_t tx = tile % gx, ty = tile / gx;
-        const int px = tx * TILE + (wv & 3) * 4 + (qd & 1) * 2 + (pq & 1);
-        const int py = ty * TILE + (wv >> 2) * 4 + (qd >> 1) * 2 + (pq >> 1);
-        const bool inside = px < W && py < H;
-        const float pixfx = (float)px, pixfy = (float)py;
-        const uint2 rg = make_uint2(td.y, td.z);
-        set_wave_priority(rg.y - rg.x);
-        stamp(s, tile, 0);
-        if (!have_first && rg.x + ht < rg.y) fetch(rg.x + ht);
-        have_first = false;
-        bool done = !inside;                                   // per pixel; identical in the 4 lanes of a quad
-        float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;          // C: this lane's share (entries of slot e)
-        uint32_t last_contributor = 0;
-
-        bool wave_live = __builtin_amdgcn_ballot_w64(!done) != 0;
-        unsigned long long busy = 0ull;                        // (diagnostic builds only)
-        for (uint32_t base = rg.x; base < rg.y; base += FCH, round++) {
-            // two barriers per round: (A) everybody has finished reading the previous round's LDS and has posted
-            // its liveness; (B) the new round is staged.  The block stops when no wave has a live pixel (forward.cu:307-310).
-            if (lane == 0) wave_alive[round & 1][wv] = wave_live ? 1u : 0u;
-            __syncthreads();
-            {
-                const uint4* wa = reinterpret_cast<const uint4*>(wave_alive[round & 1]);
-                const uint4 f0 = wa[0], f1 = wa[1], f2 = wa[2], f3 = wa[3];
-                if (((f0.x | f0.y | f0.z | f0.w) | (f1.x | f1.y | f1.z | f1.w) | (f2.x | f2.y | f2.z | f2.w) | (f3.x | f3.y | f3.z | f3.w)) == 0u) break;
-            }
-            const uint32_t cnt = min((uint32_t)FCH, rg.y - base);
-            if (ht < cnt) {
-#if TGS_FAST_MATH
-                if (!upper) { stage_conic_a(r4); sA[ht] = r4; sC[ht] = __uint_as_float(r2.x); }
-                else { stage_conic_b(r4); sB[ht] = r4; sQ[ht] = r2; }
-#else
-                if (!upper) { sA[ht] = r4; sC[ht] = __uint_as_float(r2.x); }
-                else { sB[ht] = r4; sQ[ht] = r2; }
-#endif
-            }
-            __syncthreads();
-            if (base + FCH < rg.y) { if (base + FCH + ht < rg.y) fetch(base + FCH + ht); }
-            else if (nitem < n_ne) {                            // the list's last round is staged: the next tile's first
-                uint32_t ny = ntd.y, nz = ntd.z;
-                asm volatile("" : "+v"(ny), "+v"(nz));          // (addresses formed ahead of this point were spilled, and the reload's wait covered the loads in flight)
-                if (ny + ht < nz) fetch(ny + ht);
-                have_first = true;
-            }
-            const uint32_t cbase = base - rg.x + 1;
-            const unsigned long long tb0 = busy_clock();
-            if (base == rg.x) { phase_stamp(s, tile, 2, t_entry); phase_stamp(s, tile, 3, tb0); }
-            {
-                const uint32_t n = wave_live ? build_own_list_q<FCH>(lists[wv], sQ, cnt, wv, lane) : 0u;
-                const unsigned short* myq = &qlists[wv][qd][e];
-#pragma unroll 1
-                for (uint32_t c0 = 0; c0 < n && wave_live; c0 += QCH_F) {
-                const uint32_t nq = build_chunk_quadrant_lists_128(qlists[wv], lists[wv], c0, n, lane, FNULL);
-#pragma unroll 1
-                for (uint32_t k = 0; k < nq; k += 4) {              // 4 entries of its own quadrant list per row and pass
-                    const uint32_t j = myq[k];
-                    const float4 a = sA[j];                        // mean2D, conic xx / xy pre-scaled for exp2 (stage_conic)
-                    const float4 bb = sB[j];                       // conic yy pre-scaled, opacity, colour r g
-                    const float cc = sC[j];
-                    const float dx = a.x - pixfx, dy = a.y - pixfy;
-#if TGS_FAST_MATH
-                    const float power2 = (a.z * dx + a.w * dy) * dx + (bb.x * dy) * dy;    // log2(e) * power of forward.cu:336
-                    const float alpha = fminf(0.99f, bb.y * __builtin_amdgcn_exp2f(power2));
-#else               // -DTGS_FAST_MATH=0: the reference's expression and libm-grade expf (forward.cu:336-339), for the fuzz comparison of DESIGN.md section 3
-                    const float power2 = -0.5f * (a.z * dx * dx + bb.x * dy * dy) - a.w * dx * dy;
-                    const float alpha = fminf(0.99f, bb.y * expf(power2));
-#endif
-                    // forward.cu:337-343 skips; a finished pixel skips everything (a padding entry has opacity 0)
-                    const bool live = !done && !(power2 > 0.0f) && !(alpha < 1.0f / 255.0f);
-                    const float pown = live ? 1.f - alpha : 1.0f;   // a skipped entry leaves T alone
-                    // The pixel's transmittance over the group's 4 entries, in list order.  The products never grow, so once an
-                    // entry fails `test_T < 0.0001` (forward.cu:345-350) every later live entry fails too: a lane only needs
-                    // its own test, and T stops at the value in front of the first failing entry = the largest such value.
-                    float y, x, x3;
-                    fwd_chain4(pown, T, y, x, vone);
-                    const bool fail = live && (x < 0.0001f);
-                    const bool upd = live && !fail;
-                    float cand = fail ? y : -1.0f;
-                    quad_max_bcast3(cand, x, x3);
-                    const float w = upd ? alpha * y : 0.f;
-                    C0 += bb.z * w; C1 += bb.w * w; C2 += cc * w;
-                    last_contributor = upd ? cbase + j : last_contributor;
-                    const bool stop = cand >= 0.0f;                 // some entry of the group ended the pixel
-                    T = stop ? cand : x3;
-                    done = done || stop;
-                    if (__builtin_amdgcn_ballot_w64(!done) == 0) { wave_live = false; break; }
-                }
-                }
-            }
-            busy += busy_clock() - tb0;
-        }
-        busy_report(s, tile, 0, busy);
-        phase_stamp(s, tile, 6, busy_clock());
-        // the 4 lanes of a quad hold the pixel's colour in shares and the candidates for its last contributor
-        TGS_DPP_ADD(C0, 0xB1, 0xf); TGS_DPP_ADD(C0, 0x4E, 0xf);
-        TGS_DPP_ADD(C1, 0xB1, 0xf); TGS_DPP_ADD(C1, 0x4E, 0xf);
-        TGS_DPP_ADD(C2, 0xB1, 0xf); TGS_DPP_ADD(C2, 0x4E, 0xf);
-        {
-            uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)last_contributor, 0xB1, 0xf, 0xf, false);
-            last_contributor = max(last_contributor, o);
-            o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)last_contributor, 0x4E, 0xf, 0xf, false);
-            last_contributor = max(last_contributor, o);
-        }
-        if (inside && e == 0) {
-            const size_t pix_id = (size_t)W * py + px, N = (size_t)W * H;
-            s.final_T[pix_id] = T;
-            s.n_contrib[pix_id] = last_contributor;
-            out_color[pix_id] = C0 + T * bg0;
-            out_color[N + pix_id] = C1 + T * bg1;
-            out_color[2 * N + pix_id] = C2 + T * bg2;
-        }
-        // deepest blended list position of the tile: the backward starts there without a reduction of its own
-        {
-            const uint32_t m = wave_max_u32(inside ? last_contributor : 0u);
-            if (lane == 0) wave_qmax[wv] = m;
-            if (threadIdx.x == 0) next_item[par] = ticket + 2u * gridDim.x;
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                uint32_t q = 0;
-#pragma unroll
-                for (int i = 0; i < 16; i++) q = max(q, wave_qmax[i]);
-                s.tile_qmax[tile] = q;
-                reinterpret_cast<uint32_t*>(&s.tile_desc[item])[3] = q;     // (the backward's descriptor load brings it along)
-            }
-        }
-        stamp(s, tile, 1);
-        td = make_uint4(uni(ntd.x), uni(ntd.y), uni(ntd.z), 0u); item = nitem; nitem = uni(next_item[par]); par ^= 1;
-        ntd = s.tile_desc[min(nitem, n_tiles - 1u)];
-    }
-    // ---- light groups, then the chunks of empty tiles ----
-    const uint32_t sub = threadIdx.x >> 8;
-    auto light_td = [&](uint32_t it) {                     // this quarter's light tile of item it (zero: none)
-        const uint32_t li = 4u * (it - n_ne) + sub;
-        return (it >= n_ne && it < n_ne + n_lgroups && li < n_light) ? s.light_desc[li] : make_uint4(0u, 0u, 0u, 0u);
-    };
-    uint4 tdl = light_td(item), ntdl = light_td(nitem);
-    while (item < n_items) {
-        uint32_t ticket = 0u;
-        if (threadIdx.x == 0) ticket = atomicInc(&s.meta->pad[2], 0xffffffffu);      // (atomicAdd of a uniform value is rewritten into add + readfirstlane: a wait for the round trip right here)
-        __syncthreads();                                    // (the previous item is done with the LDS)
-        if (item < n_ne + n_lgroups) {
-            fwd_light_group(s, b, W, H, gx, bg, out_color, tdl, 4u * (item - n_ne) + sub < n_light, sA, sB, sC, sQ, lists, qlists, wave_qmax, 4u * (item - n_ne) + sub, n_ne + 4u * (item - n_ne) + sub);
-        } else {
-            // the EMPTY tiles -- the tail of tile_order -- sixteen per item, four at a time
-            const uint32_t j = item - n_ne - n_lgroups;
-            for (uint32_t k = 0; k < 4u; k++) {
-                const uint32_t i = n_all + 16u * j + 4u * k + sub;
-                if (i < n_tiles) fill_tile_background(s, s.tile_desc[i].x, threadIdx.x & 255u, W, H, gx, bg, out_color);
-            }
-        }
-        if (threadIdx.x == 0) next_item[par] = ticket + 2u * gridDim.x;
+    bool wave_live = __builtin_amdgcn_ballot_w64(!done) != 0;
+    int round = 0;
+    unsigned long long busy = 0ull;                        // (diagnostic builds only)
+    for (uint32_t base = rg.x; base < rg.y; base += FCH, round++) {
+        // two barriers per round: (A) everybody has finished reading the previous round's LDS and has posted
+        // its liveness; (B) the new round is staged.  The block stops when no wave has a live pixel (forward.cu:307-310).
+        if (lane == 0) wave_alive[round & 1][wv] = wave_live ? 1u : 0u;
         __syncthreads();
-        item = nitem; nitem = uni(next_item[par]); par ^= 1;
-        tdl = ntdl; ntdl = light_td(nitem);
+        {
+            const uint4* wa = reinterpret_cast<const uint4*>(wave_alive[round & 1]);
+            const uint4 f0 = wa[0], f1 = wa[1], f2 = wa[2], f3 = wa[3];
+            if (((f0.x | f0.y | f0.z | f0.w) | (f1.x | f1.y | f1.z | f1.w) | (f2.x | f2.y | f2.z | f2.w) | (f3.x | f3.y | f3.z | f3.w)) == 0u) break;
+        }
+        const uint32_t cnt = min((uint32_t)FCH, rg.y - base);
+        if (ht < cnt) {
+#if TGS_FAST_MATH
+            if (!upper) { stage_conic_a(r4); sA[ht] = r4; sC[ht] = __uint_as_float(r2.x); }
+            else { stage_conic_b(r4); sB[ht] = r4; sQ[ht] = r2; }
+#else
+            if (!upper) { sA[ht] = r4; sC[ht] = __uint_as_float(r2.x); }
+            else { sB[ht] = r4; sQ[ht] = r2; }
+#endif
+        }
+        __syncthreads();
+        if (base + FCH + ht < rg.y) fetch(base + FCH + ht);
+        const uint32_t cbase = base - rg.x + 1;
+        const unsigned long long tb0 = busy_clock();
+        if (round == 0) { phase_stamp(s, tile, 2, t_entry); phase_stamp(s, tile, 3, tb0); }
+        {
+            const uint32_t n = wave_live ? build_own_list_q<FCH>(lists[wv], sQ, cnt, wv, lane) : 0u;
+            const unsigned short* myq = &qlists[wv][qd][e];
+#pragma unroll 1
+            for (uint32_t c0 = 0; c0 < n && wave_live; c0 += QCH_F) {
+            const uint32_t nq = build_chunk_quadrant_lists_128(qlists[wv], lists[wv], c0, n, lane, FNULL);
+#pragma unroll 1
+            for (uint32_t k = 0; k < nq; k += 4) {              // 4 entries of its own quadrant list per row and pass
+                const uint32_t j = myq[k];
+                const float4 a = sA[j];                        // mean2D, conic xx / xy pre-scaled for exp2 (stage_conic)
+                const float4 bb = sB[j];                       // conic yy pre-scaled, opacity, colour r g
+                const float cc = sC[j];
+                const float dx = a.x - pixfx, dy = a.y - pixfy;
+#if TGS_FAST_MATH
+                const float power2 = (a.z * dx + a.w * dy) * dx + (bb.x * dy) * dy;    // log2(e) * power of forward.cu:336
+                const float alpha = fminf(0.99f, bb.y * __builtin_amdgcn_exp2f(power2));
+#else           // -DTGS_FAST_MATH=0: the reference's expression and libm-grade expf (forward.cu:336-339), for the fuzz comparison of DESIGN.md section 3
+                const float power2 = -0.5f * (a.z * dx * dx + bb.x * dy * dy) - a.w * dx * dy;
+                const float alpha = fminf(0.99f, bb.y * expf(power2));
+#endif
+                // forward.cu:337-343 skips; a finished pixel skips everything (a padding entry has opacity 0)
+                const bool live = !done && !(power2 > 0.0f) && !(alpha < 1.0f / 255.0f);
+                const float pown = live ? 1.f - alpha : 1.0f;   // a skipped entry leaves T alone
+                // The pixel's transmittance over the group's 4 entries, in list order.  The products never grow, so once an
+                // entry fails `test_T < 0.0001` (forward.cu:345-350) every later live entry fails too: a lane only needs
+                // its own test, and T stops at the value in front of the first failing entry = the largest such value.
+                float y, x, x3;
+                fwd_chain4(pown, T, y, x, vone);
+                const bool fail = live && (x < 0.0001f);
+                const bool upd = live && !fail;
+                float cand = fail ? y : -1.0f;
+                quad_max_bcast3(cand, x, x3);
+                const float w = upd ? alpha * y : 0.f;
+                C0 += bb.z * w; C1 += bb.w * w; C2 += cc * w;
+                last_contributor = upd ? cbase + j : last_contributor;
+                const bool stop = cand >= 0.0f;                 // some entry of the group ended the pixel
+                T = stop ? cand : x3;
+                done = done || stop;
+                if (__builtin_amdgcn_ballot_w64(!done) == 0) { wave_live = false; break; }
+            }
+            }
+        }
+        busy += busy_clock() - tb0;
     }
+    busy_report(s, tile, 0, busy);
+    phase_stamp(s, tile, 6, busy_clock());
+    // the 4 lanes of a quad hold the pixel's colour in shares and the candidates for its last contributor
+    TGS_DPP_ADD(C0, 0xB1, 0xf); TGS_DPP_ADD(C0, 0x4E, 0xf);
+    TGS_DPP_ADD(C1, 0xB1, 0xf); TGS_DPP_ADD(C1, 0x4E, 0xf);
+    TGS_DPP_ADD(C2, 0xB1, 0xf); TGS_DPP_ADD(C2, 0x4E, 0xf);
+    {
+        uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)last_contributor, 0xB1, 0xf, 0xf, false);
+        last_contributor = max(last_contributor, o);
+        o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)last_contributor, 0x4E, 0xf, 0xf, false);
+        last_contributor = max(last_contributor, o);
+    }
+    if (inside && e == 0) {
+        const size_t pix_id = (size_t)W * py + px, N = (size_t)W * H;
+        s.final_T[pix_id] = T;
+        s.n_contrib[pix_id] = last_contributor;
+        out_color[pix_id] = C0 + T * bg0;
+        out_color[N + pix_id] = C1 + T * bg1;
+        out_color[2 * N + pix_id] = C2 + T * bg2;
+    }
+    // deepest blended list position of the tile: the backward starts there without a reduction of its own
+    {
+        const uint32_t m = wave_max_u32(inside ? last_contributor : 0u);
+        if (lane == 0) wave_qmax[wv] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t q = 0;
+#pragma unroll
+            for (int i = 0; i < 16; i++) q = max(q, wave_qmax[i]);
+            reinterpret_cast<uint32_t*>(&s.tile_desc[blockIdx.x])[3] = q;      // (k_render_bwd's descriptor load brings it along)
+        }
+    }
+    stamp(s, tile, 1);
 }
+
 
 // ---------------------------------------------------------------------------------------------
 // k_mark_visible (rasterizer_impl.cu:54-66)
@@ -1475,19 +1418,21 @@ void launch_tile_sort(hipStream_t st, const GeomState& g, const ImgState& s, con
 void launch_render_fwd(hipStream_t st, const ImgState& s, const BinState& b, int W, int H, uint32_t gx, uint32_t T, const Meta* m,
                        const float* bg, float* out_color, uint32_t tile_bound, uint32_t mid_bound, int light)
 {
-    // persistent workgroups (k_render_fwd): as many as there are items -- one-tile items, light groups of four, chunks of 16 empty tiles; by
-    // the caller's bounds when the host has not read the frame's counts -- but no more than fit the chip at once (two per CU)
-    uint32_t items;
-    if (!m) {
+    if (!m) {   // sync-free: workgroups for the bounds on the tiles with instances (k_scan has rejected the frame if more hold any) + one per 16
+                // tiles beyond the bound; those not needed for compositing write the background of all empty tiles
         const uint32_t tb = tile_bound < T ? tile_bound : T;
-        const uint32_t hb = light ? (mid_bound < tb ? mid_bound : tb) : tb;
-        items = hb + (light ? (tb - hb + 3u) / 4u : 0u) + (T + 15u) / 16u;
-    } else {
-        const uint32_t nonempty = m->n_nonempty, empty = T - m->n_nonempty;
-        const uint32_t heavy = light ? (m->n_mid < nonempty ? m->n_mid : nonempty) : nonempty;
-        items = heavy + (nonempty - heavy + 3u) / 4u + (empty + 15u) / 16u;
+        const uint32_t hb = light ? (mid_bound < tb ? mid_bound : tb) : tb;     // one-tile workgroups, at most
+        const uint32_t lg = light ? (tb - hb + 3u) / 4u : 0u;                   // light groups beside them, at most (four tiles each; largest when n_mid reaches its bound)
+        const uint32_t grid = hb + lg + (T - tb + 15u) / 16u;
+        hipLaunchKernelGGL(k_render_fwd, dim3(grid), dim3(FWD_THREADS), 0, st, s, b, W, H, gx, bg, out_color, 1, T, light);
+        return;
     }
-    const uint32_t grid = items < render_slots() ? items : render_slots();
+    // exact counts (the host has read Meta): one-tile workgroups, light groups, and -- between them in the grid -- one workgroup per 16 empty
+    // tiles for the background (a kernel of its own behind this one, k_fill_empty, was 6.6 us + a launch boundary of a frame that has the
+    // GPU to itself; as workgroups of this launch the fill runs beside the long lists)
+    const uint32_t nonempty = m->n_nonempty, empty = T - m->n_nonempty;
+    const uint32_t heavy = light ? (m->n_mid < nonempty ? m->n_mid : nonempty) : nonempty;
+    const uint32_t grid = heavy + (nonempty - heavy + 3u) / 4u + (empty + 15u) / 16u;
     if (grid > 0) hipLaunchKernelGGL(k_render_fwd, dim3(grid), dim3(FWD_THREADS), 0, st, s, b, W, H, gx, bg, out_color, 1, T, light);
 }
 void launch_mark_visible(hipStream_t st, int P, const float* means3D, const float* view, uint8_t* present)
