@@ -84,9 +84,12 @@ def scene_input(cloud: dict, cam, mode: str = "sh", cov_mode: str = "scale_rot")
 
 
 def hip_run(inp: dict, dL: Optional[np.ndarray] = None, device="cuda:0", debug=False, introspect=True, pruning: Optional[bool] = None,
-            deterministic: Optional[bool] = None, light_tiles: Optional[bool] = None) -> Dict[str, np.ndarray]:
+            deterministic: Optional[bool] = None, light_tiles: Optional[bool] = None, light_tiles_bwd: Optional[bool] = None,
+            backward_twice: bool = False) -> Dict[str, np.ndarray]:
     """The HIP path through the reference's ``_C`` surface (the compiled module over the C ABI of include/tgs_raster.h).  ``pruning`` /
-    ``deterministic``: explicit per-call options (tgs_options_t); None = the library defaults."""
+    ``deterministic`` / ``light_tiles``: explicit per-call options (tgs_options_t); None = the library defaults.  ``light_tiles_bwd``: another
+    light-group option for the backward than the forward had; ``backward_twice``: back-propagate the same frame a second time (its result is
+    returned)."""
     import torch
     from diff_gaussian_rasterization import _C
     dev = torch.device(device)
@@ -114,9 +117,10 @@ def hip_run(inp: dict, dL: Optional[np.ndarray] = None, device="cuda:0", debug=F
         if has_sh:
             out["rgb"] = f("rgb").reshape(-1, 3)
     if dL is not None:
-        g = _C.rasterize_gaussians_backward(bg, means3D, radii, colors, scales, rots, sm, cov, view, proj, tfx, tfy,
-                                            torch.from_numpy(np.ascontiguousarray(dL, np.float32)).to(dev), sh, D, campos, geom, R, binning, img, debug,
-                                            _with_conic=True, deterministic=deterministic, light_tiles=light_tiles)
+        for _ in range(2 if backward_twice else 1):
+            g = _C.rasterize_gaussians_backward(bg, means3D, radii, colors, scales, rots, sm, cov, view, proj, tfx, tfy,
+                                                torch.from_numpy(np.ascontiguousarray(dL, np.float32)).to(dev), sh, D, campos, geom, R, binning, img, debug,
+                                                _with_conic=True, deterministic=deterministic, light_tiles=light_tiles if light_tiles_bwd is None else light_tiles_bwd)
         names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations", "dL_dconic")
         out.update({n: v.cpu().numpy() for n, v in zip(names, g)})
     torch.cuda.synchronize()
