@@ -1,4 +1,5 @@
-"""Diagnostic (needs a -DTGS_STAMPS=1 build): per-tile start/end stamps of the render kernels."""
+"""Diagnostic (needs a -DTGS_STAMPS=1 build): per-tile start/end stamps of the render kernels (forward: first quarter's start to the last
+quarter's end), and the busy time of the backward's waves inside their workgroup."""
 import sys, os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 import numpy as np, torch
@@ -21,22 +22,6 @@ P = means3D.shape[0]
 st = _C.state_field('stamps', P, W, H, R, True, True, geom, binning, img).cpu().numpy().reshape(-1, 8)
 rg = _C.state_field('ranges', P, W, H, R, True, True, geom, binning, img).cpu().numpy().reshape(-1, 2)
 n = rg[:,1]-rg[:,0]
-if len(sys.argv) > 1 and sys.argv[1] == 'phases':          # -DTGS_STAMPS=2 build: phases of the one-tile forward workgroups (us, medians per class)
-    sel = n > 0
-    t = st[sel].astype(np.int64); nn = n[sel]
-    ok = t[:, 2] > 0
-    for lo, hi in ((1, 128), (128, 512), (512, 1024), (1024, 1 << 30)):
-        m = ok & (nn >= lo) & (nn < hi)
-        if m.any():
-            x = t[m]
-            print(f'n in [{lo},{hi}): tiles {int(m.sum())}: entry -> descriptor + counts {np.median(x[:,0]-x[:,2])/100:.2f}, -> first round staged {np.median(x[:,3]-x[:,0])/100:.2f}, '
-                  f'-> rounds done {np.median(x[:,6]-x[:,3])/100:.2f}, -> end {np.median(x[:,1]-x[:,6])/100:.2f}; whole {np.median(x[:,1]-x[:,2])/100:.2f}')
-    # turnaround of a workgroup slot: sort the workgroups by entry time; with 512 slots the k-th entry (k >= 512) follows an end
-    ent = np.sort(t[ok, 2]); end = np.sort(t[ok, 1])
-    k = np.arange(512, len(ent))
-    if len(k):
-        print('slot turnaround (entry of workgroup k+512 - k-th end, us): median', np.median(ent[k] - end[k - 512]) / 100)
-    sys.exit(0)
 for name, a, b in (('fwd', 0, 1), ('bwd', 2, 3)):
     sel = n > 0
     t0, t1 = st[sel, a].astype(np.int64), st[sel, b].astype(np.int64)

@@ -218,7 +218,7 @@ constexpr int BNULL = BCH;
 // ---------------------------------------------------------------------------------------------
 // Light groups of k_render_bwd: THREE light tiles (fewer than LIGHT_MAX instances, one round) per workgroup -- the staging arrays hold
 // BCH = 384 = 3 x 128 entries --, tile q on waves 4q .. 4q+3 (waves 12..15 only meet the barriers), wave w of a tile walking its blocks
-// 4w .. 4w+3 one after the other (fwd_light_group is the forward's counterpart: why, there).  Same arithmetic per (pixel, entry) pair, same f64
+// 4w .. 4w+3 one after the other (the forward gives a light tile a 256-thread workgroup of its own: k_render_fwd; why light tiles are set apart: tgs_device.hpp, LIGHT_MAX).  Same arithmetic per (pixel, entry) pair, same f64
 // LDS accumulator and flush as the heavy path; the pixel inputs of a wave's four blocks are fetched up front.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void bwd_light_group(const ImgState& s, const BinState& b, int W, int H, uint32_t gx, const float* __restrict__ bg,
@@ -233,7 +233,7 @@ __device__ __forceinline__ void bwd_light_group(const ImgState& s, const BinStat
     const uint32_t tx = tile % gx, ty = tile / gx;
     stamp_if(s, tile, 2, active && lt == 0);
     const size_t N = (size_t)W * H;
-    const uint32_t qmax = active ? min(td.w, n) : 0u;                  // deepest position any pixel of the tile blended (fwd_light_group wrote it into the descriptor)
+    const uint32_t qmax = active ? min(td.w, n) : 0u;                  // deepest position any pixel of the tile blended (k_render_fwd wrote it into the descriptor)
     // pixel inputs of this wave's four blocks (5 loads each, all in flight together)
     float Tf[4], d0[4], d1[4], d2[4];
     uint32_t lc[4];

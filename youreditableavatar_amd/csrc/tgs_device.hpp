@@ -461,13 +461,14 @@ __device__ __forceinline__ uint4 frame_counts(const ImgState& s)
     return make_uint4(__float_as_uint(t.x), __float_as_uint(t.y), __float_as_uint(t.z), __float_as_uint(t.w));
 }
 // Light tiles: fewer than LIGHT_MAX instances (Meta::n_mid counts the tiles with at least that many, k_scan's length classes) -- a single
-// staging round, so 4 waves that take the tile's 16 blocks four each need no per-pixel state across rounds, and several such tiles share
-// one 1024-thread workgroup of the render kernels (fwd_light_group: four, bwd_light_group: three -- what the staging arrays hold).
-// Measured (per-tile stamps, config 3): the 1811 tiles below 128 entries hold 16 % of the instances but took 30 % of k_render_fwd's and
-// 24 % of k_render_bwd's workgroup time -- ~3 us of launch / descriptor / record-fetch latency each during which a workgroup of its own
-// holds half of a CU's wave slots.
+// staging round, so 4 waves that take the tile's 16 blocks four each need no per-pixel state across rounds: the forward gives such a
+// tile ONE 256-thread workgroup (a longer list gets four, one per quarter), and the backward puts three of them into one 1024-thread
+// workgroup (bwd_light_group -- what its staging arrays hold).
+// Measured (per-tile stamps of the one-workgroup-per-tile kernels, config 3): the 1811 tiles below 128 entries hold 16 % of the instances
+// but took 30 % of k_render_fwd's and 24 % of k_render_bwd's workgroup time -- ~3 us of launch / descriptor / record-fetch latency each
+// during which a 16-wave workgroup of its own holds half of a CU's wave slots.
 constexpr int LIGHT_MAX = 128;
-constexpr int FWD_LIGHT_PER_WG = 4, BWD_LIGHT_PER_WG = 3;
+constexpr int BWD_LIGHT_PER_WG = 3;
 // A frame that tgs_forward_async could not fit into the caller's binning capacity: every kernel behind k_scan returns.
 __device__ __forceinline__ bool frame_rejected(const ImgState& s)
 {
@@ -480,7 +481,6 @@ __device__ __forceinline__ bool frame_rejected(const ImgState& s)
 __device__ __forceinline__ void stamp(const ImgState& s, uint32_t tile, int which)
 {
 #if TGS_STAMPS
-    if (TGS_STAMPS == 2 && which >= 2) return;             // (TGS_STAMPS=2: the backward's slots carry the forward's phases: phase_stamp)
     if (threadIdx.x == 0) {
         s.stamps[8 * (size_t)tile + which] = wall_clock64();
         if (!(which & 1)) { s.stamps[8 * (size_t)tile + 4 + which] = 0ull; s.stamps[8 * (size_t)tile + 5 + which] = 0ull; }
@@ -496,26 +496,24 @@ __device__ __forceinline__ unsigned long long busy_clock()
     return 0ull;
 #endif
 }
-// -DTGS_STAMPS=2: phases of a one-tile forward workgroup in the backward's slots -- [2] kernel entry, [3] first round staged, [6] last round done
-__device__ __forceinline__ void phase_stamp(const ImgState& s, uint32_t tile, int slot, unsigned long long t)
-{
-#if TGS_STAMPS == 2
-    if (threadIdx.x == 0) s.stamps[8 * (size_t)tile + slot] = t;
-#endif
-}
 __device__ __forceinline__ void busy_report(const ImgState& s, uint32_t tile, int which, unsigned long long dt)
 {
 #if TGS_STAMPS
-    if (TGS_STAMPS == 2 && which == 1) return;
     if ((threadIdx.x & 63u) == 0u) { atomicAdd(&s.stamps[8 * (size_t)tile + 4 + 2 * which], dt); atomicMax(&s.stamps[8 * (size_t)tile + 5 + 2 * which], dt); }
 #endif
 }
 
+// (several workgroups per tile: the latest end)
+__device__ __forceinline__ void stamp_max(const ImgState& s, uint32_t tile, int which)
+{
+#if TGS_STAMPS
+    if (threadIdx.x == 0) atomicMax(&s.stamps[8 * (size_t)tile + which], wall_clock64());
+#endif
+}
 // (light groups: the first thread of the tile's quarter stamps)
 __device__ __forceinline__ void stamp_if(const ImgState& s, uint32_t tile, int which, bool who)
 {
 #if TGS_STAMPS
-    if (TGS_STAMPS == 2 && which >= 2) return;
     if (who) s.stamps[8 * (size_t)tile + which] = wall_clock64();
 #endif
 }

@@ -14,7 +14,7 @@
 //                      SORT_LDS_CAP take the k_ovf_* path
 //   k_finalize         gather of the per-instance records in sorted order + the 64-bit quadrant mask of each
 //                      instance (which 2x2-pixel quadrants of its tile the splat reaches)   (forward.cu:315-321)
-//   k_render_fwd       front-to-back compositing, one 16x16 tile per workgroup           (forward.cu:261-374)
+//   k_render_fwd       front-to-back compositing, four 256-thread workgroups per 16x16 tile    (forward.cu:261-374)
 //
 // The reference sorts 64-bit (tile|depth) keys globally with a 6-pass radix sort (12 B x R per pass);
 // here the tile is known when an instance is emitted, so only the depth order inside one tile's list
@@ -968,24 +968,6 @@ __global__ __launch_bounds__(256) void k_finalize(const GeomState g, const ImgSt
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// k_render_fwd: one 16x16 tile per 1024-thread workgroup = 16 waves, one wave per 4x4-pixel block.
-// Inside a wave every 16-lane DPP row is one 2x2-pixel quadrant of the block: 4 pixels x 4 CONSECUTIVE
-// entries of the quadrant's OWN list (the entries whose 64-bit quadrant mask names it; tgs_device.hpp
-// "quadrant culling").  Every lane evaluates one (pixel, entry) pair -- conic power, exp, alpha -- and
-// the four lanes of a quad then walk the transmittance chain of their pixel together (DPP quad
-// broadcasts of 1-alpha), so one pass of the loop retires four entries of each quadrant's list with the
-// sequential semantics of forward.cu:325-362 intact (T is multiplied in list order; the first entry that
-// would push T below 1e-4 stops the pixel and is not blended).  The quad chains never leave the quad, so
-// the four rows may walk four different lists in one instruction stream.
-// Why: both render kernels are bound by VALU issue, and only the lanes inside the splat's alpha >= 1/255
-// footprint do useful work -- 33 % of them when a wave's 16 pixels all took the block's entries, 64 %
-// quadrant by quadrant (tools/culling_potential.py).  A tile is spread over 16 waves and long lists are
-// visited first (tile_order) because a kernel ends when its longest list does.
-constexpr int FWD_THREADS = 1024;
-constexpr int FCH = 512;                   // list entries staged per round
-constexpr int FNULL = FCH;                 // LDS slot of the null record
-
 // A tile nothing is blended into: C = 0, T = 1 -> background (forward.cu:366-373 with an empty range).  Also what a frame
 // rejected by tgs_forward_async renders, so its image is defined.
 __device__ __forceinline__ void fill_tile_background(const ImgState& s, uint32_t tile, uint32_t t, int W, int H, uint32_t gx,
@@ -1001,271 +983,89 @@ __device__ __forceinline__ void fill_tile_background(const ImgState& s, uint32_t
 }
 
 // ---------------------------------------------------------------------------------------------
-// Light groups of k_render_fwd: FOUR light tiles (fewer than LIGHT_MAX instances: one staging round) per 1024-thread workgroup, one per
-// 256-thread quarter.  Quarter q stages its tile's whole list into slots [128 q, 128 q + 128) of the workgroup's staging arrays; its wave
-// w then takes the tile's blocks 4w .. 4w+3 one after the other with the row / quad structure of the heavy path (a 16-lane row = one
-// 2x2-pixel quadrant x 4 entries of its own list; fwd_chain4) -- with a single round no pixel state outlives a block.  A short tile is
-// mostly latency (descriptor -> records -> staging barrier, ~3 us) during which a workgroup of its own held half of a CU's wave slots:
-// the 1811 tiles below 128 entries of config 3 hold 16 % of the instances and took 30 % of the kernel's workgroup time (per-tile stamps).
-// Light groups are counted from the END of the grid, so a workgroup fetches its candidate descriptors before it knows the frame's counts.
+// k_render_fwd: front-to-back compositing (renderCUDA, forward.cu:261-374) in 256-thread workgroups = 4 waves, one wave per 4x4-pixel block.
+// Inside a wave every 16-lane DPP row is one 2x2-pixel quadrant of the block: 4 pixels x 4 CONSECUTIVE entries of the quadrant's OWN list
+// (the entries whose 64-bit quadrant mask names it; tgs_device.hpp "quadrant culling").  Every lane evaluates one (pixel, entry) pair --
+// conic power, exp, alpha -- and the four lanes of a quad then walk the transmittance chain of their pixel together (DPP quad broadcasts
+// of 1-alpha, fwd_chain4), so one pass of the loop retires four entries of each quadrant's list with the sequential semantics of
+// forward.cu:325-362 intact (T is multiplied in list order; the first entry that would push T below 1e-4 stops the pixel and is not
+// blended).  The quad chains never leave the quad, so the four rows may walk four different lists in one instruction stream.
+// Why: the kernel is bound by VALU issue, and only the lanes inside the splat's alpha >= 1/255 footprint do useful work -- 33 % of them
+// when a wave's 16 pixels all took the block's entries, 64 % quadrant by quadrant (tools/culling_potential.py).
+//
+// Workgroups (round 3; rounds 1-2 and most of round 3 ran one 1024-thread workgroup of 16 waves per tile): a tile with >= LIGHT_MAX
+// instances is composited by FOUR workgroups, one per 8x8-pixel quarter (its 4 blocks, one wave per block: the per-list chain stays as
+// short as with 16 waves); a light tile (light != 0) by ONE, its wave w walking four blocks one after the other -- a light tile has a
+// single staging round, so no pixel state outlives a block, and a short tile is mostly descriptor -> records -> staging latency that 16
+// waves should not sit through.  Eight workgroups fit a CU.
+// Why (per-wave busy stamps): in a 16-wave workgroup the waves were busy half of the workgroup's span -- the block
+// with the most contributors sets the span, and nothing else can use the slots of the waves that wait for it.  Pixels of different
+// quarters never interact, so a quarter leaves as soon as ITS four blocks are done, and eight workgroups per CU overlap each other's
+// latencies instead of two.  Price: every quarter stages the whole list (4 x the L2 -> LDS traffic of the records; the quarters of a tile
+// get the same blockIdx modulo 8 -- the same XCD's L2 -- and consecutive slots there).  Measured against the 16-wave kernel with its
+// light groups (A/B by library on one box): kernel alone 63.4 -> 59.0 us, the 8-view step 2.01 -> 1.93 ms (the finer workgroups also
+// leave the other streams' kernels more room); 512 entries per round instead of 256: no gain alone, 2.00 ms per step (5 workgroups per CU).
+// Long lists go first (tile_order): the kernel ends when its longest list does.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void fwd_light_group(const ImgState& s, const BinState& b, int W, int H, uint32_t gx, const float* __restrict__ bg,
-                                                float* __restrict__ out_color, uint4 td, bool active, float4* sA, float4* sB, float* sC, uint2* sQ,
-                                                unsigned short (*lists)[FCH + 8], unsigned short (*qlists)[4][QL_ROW_F], uint32_t* wave_qmax, uint32_t light_pos, uint32_t desc_pos)
+constexpr int FQ_THREADS = 256;
+#ifndef TGS_FQ_CH
+#define TGS_FQ_CH 256
+#endif
+constexpr int FQ_CH = TGS_FQ_CH;           // list entries staged per round: FQ_CH / 256 whole entries per thread
+constexpr int FQ_EPT = FQ_CH / FQ_THREADS;
+static_assert(FQ_CH % FQ_THREADS == 0 && FQ_CH >= LIGHT_MAX && FQ_CH <= 768, "whole entries per thread; a light tile is one round; slots are 10-bit in the block lists");
+constexpr int FQ_NULL = FQ_CH;
+
+// one block, one staged round: this wave's pass over the entries of the round that reach its block (forward.cu:325-362
+// semantics: the kernel's header).  Returns true when the block's last live pixel ended.
+__device__ __forceinline__ bool fwd_q_block_round(const float4* sA, const float4* sB, const float* sC, const uint2* sQ, unsigned short* list,
+                                                  unsigned short (*ql)[QL_ROW_F], uint32_t cnt, int blk, int lane, uint32_t cbase, float pixfx, float pixfy,
+                                                  float vone, bool& done, float& T, float& C0, float& C1, float& C2, uint32_t& last_contributor)
 {
-    const int sub = threadIdx.x >> 8, lt = threadIdx.x & 255;
-    const int wv = threadIdx.x >> 6, w4 = wv & 3, lane = threadIdx.x & 63;
-    const int qd = lane >> 4, pq = (lane >> 2) & 3, e = lane & 3;
-    const uint32_t base = (uint32_t)LIGHT_MAX * sub;
-    const uint32_t tile = td.x, n = active ? td.z - td.y : 0u;      // 1 <= n < LIGHT_MAX
-    const uint32_t tx = tile % gx, ty = tile / gx;
-    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-    stamp_if(s, tile, 0, active && lt == 0);
-    {   // stage the whole list: thread t < 128 of the quarter carries recA + recC of entry t, thread 128 + t recB + the quadrant mask
-        const uint32_t ht = lt & (LIGHT_MAX - 1);
-        const bool upper = lt >= LIGHT_MAX;
-        if (ht < n) {
-            const uint32_t pos = td.y + ht;
-            if (!upper) {
-                float4 r4 = b.recA[pos]; const float c = b.recC[pos].x;
-#if TGS_FAST_MATH
-                stage_conic_a(r4);
-#endif
-                sA[base + ht] = r4; sC[base + ht] = c;
-            } else {
-                float4 r4 = b.recB[pos]; const uint2 q = b.qmask[pos];
-#if TGS_FAST_MATH
-                stage_conic_b(r4);
-#endif
-                sB[base + ht] = r4; sQ[base + ht] = q;
-            }
-        }
-        if (threadIdx.x == 0) { sA[FNULL] = make_float4(0.f, 0.f, 0.f, 0.f); sB[FNULL] = make_float4(0.f, 0.f, 0.f, 0.f); sC[FNULL] = 0.f; }
-    }
-    __syncthreads();
-    float vone = 1.0f;
-    asm volatile("" : "+v"(vone));
-    uint32_t wq = 0;
-    const unsigned short* myq = &qlists[wv][qd][e];
-    const uint32_t null_local = (uint32_t)FNULL - base;     // the shared null record as an index relative to this quarter's slots
-    if (active) {
+    const int qd = lane >> 4, e = lane & 3;
+    const uint32_t n = build_own_list_q<FQ_CH>(list, sQ, cnt, blk, lane);
+    const unsigned short* myq = &ql[qd][e];
 #pragma unroll 1
-    for (int bi = 0; bi < 4; bi++) {
-        const int blk = 4 * w4 + bi;
-        const int px = tx * TILE + (blk & 3) * 4 + (qd & 1) * 2 + (pq & 1);
-        const int py = ty * TILE + (blk >> 2) * 4 + (qd >> 1) * 2 + (pq >> 1);
-        const bool inside = px < W && py < H;
-        const float pixfx = (float)px, pixfy = (float)py;
-        bool done = !inside;
-        float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
-        uint32_t last_contributor = 0;
-        const uint32_t nb = __builtin_amdgcn_ballot_w64(!done) != 0 ? build_own_list_q<LIGHT_MAX>(lists[wv], sQ + base, n, blk, lane) : 0u;
-        if (nb > 0) {
-            const uint32_t nq = build_chunk_quadrant_lists_128(qlists[wv], lists[wv], 0u, nb, lane, (int)null_local);
+    for (uint32_t c0 = 0; c0 < n; c0 += QCH_F) {
+        const uint32_t nq = build_chunk_quadrant_lists_128(ql, list, c0, n, lane, FQ_NULL);
 #pragma unroll 1
-            for (uint32_t k = 0; k < nq; k += 4) {          // the pass of the heavy path below (forward.cu:325-362 semantics: see there)
-                const uint32_t jl = myq[k], j = jl + base;
-                const float4 a = sA[j];
-                const float4 bb = sB[j];
-                const float cc = sC[j];
-                const float dx = a.x - pixfx, dy = a.y - pixfy;
+        for (uint32_t k = 0; k < nq; k += 4) {
+            const uint32_t j = myq[k];
+            const float4 a = sA[j];
+            const float4 bb = sB[j];
+            const float cc = sC[j];
+            const float dx = a.x - pixfx, dy = a.y - pixfy;
 #if TGS_FAST_MATH
-                const float power2 = (a.z * dx + a.w * dy) * dx + (bb.x * dy) * dy;
-                const float alpha = fminf(0.99f, bb.y * __builtin_amdgcn_exp2f(power2));
+            const float power2 = (a.z * dx + a.w * dy) * dx + (bb.x * dy) * dy;
+            const float alpha = fminf(0.99f, bb.y * __builtin_amdgcn_exp2f(power2));
 #else
-                const float power2 = -0.5f * (a.z * dx * dx + bb.x * dy * dy) - a.w * dx * dy;
-                const float alpha = fminf(0.99f, bb.y * expf(power2));
+            const float power2 = -0.5f * (a.z * dx * dx + bb.x * dy * dy) - a.w * dx * dy;
+            const float alpha = fminf(0.99f, bb.y * expf(power2));
 #endif
-                const bool live = !done && !(power2 > 0.0f) && !(alpha < 1.0f / 255.0f);
-                const float pown = live ? 1.f - alpha : 1.0f;
-                float y, x, x3;
-                fwd_chain4(pown, T, y, x, vone);
-                const bool fail = live && (x < 0.0001f);
-                const bool upd = live && !fail;
-                float cand = fail ? y : -1.0f;
-                quad_max_bcast3(cand, x, x3);
-                const float w = upd ? alpha * y : 0.f;
-                C0 += bb.z * w; C1 += bb.w * w; C2 += cc * w;
-                last_contributor = upd ? 1u + jl : last_contributor;    // (list position of slot jl + 1: the single round starts at the range's first entry)
-                const bool stop = cand >= 0.0f;
-                T = stop ? cand : x3;
-                done = done || stop;
-                if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
-            }
+            const bool live = !done && !(power2 > 0.0f) && !(alpha < 1.0f / 255.0f);
+            const float pown = live ? 1.f - alpha : 1.0f;
+            float y, x, x3;
+            fwd_chain4(pown, T, y, x, vone);
+            const bool fail = live && (x < 0.0001f);
+            const bool upd = live && !fail;
+            float cand = fail ? y : -1.0f;
+            quad_max_bcast3(cand, x, x3);
+            const float w = upd ? alpha * y : 0.f;
+            C0 += bb.z * w; C1 += bb.w * w; C2 += cc * w;
+            last_contributor = upd ? cbase + j : last_contributor;
+            const bool stop = cand >= 0.0f;
+            T = stop ? cand : x3;
+            done = done || stop;
+            if (__builtin_amdgcn_ballot_w64(!done) == 0) return true;
         }
-        TGS_DPP_ADD(C0, 0xB1, 0xf); TGS_DPP_ADD(C0, 0x4E, 0xf);
-        TGS_DPP_ADD(C1, 0xB1, 0xf); TGS_DPP_ADD(C1, 0x4E, 0xf);
-        TGS_DPP_ADD(C2, 0xB1, 0xf); TGS_DPP_ADD(C2, 0x4E, 0xf);
-        {
-            uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)last_contributor, 0xB1, 0xf, 0xf, false);
-            last_contributor = max(last_contributor, o);
-            o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)last_contributor, 0x4E, 0xf, 0xf, false);
-            last_contributor = max(last_contributor, o);
-        }
-        if (inside && e == 0) {
-            const size_t pix_id = (size_t)W * py + px, N = (size_t)W * H;
-            s.final_T[pix_id] = T;
-            s.n_contrib[pix_id] = last_contributor;
-            out_color[pix_id] = C0 + T * bg0;
-            out_color[N + pix_id] = C1 + T * bg1;
-            out_color[2 * N + pix_id] = C2 + T * bg2;
-        }
-        wq = max(wq, wave_max_u32(inside ? last_contributor : 0u));
     }
-    }
-    if (lane == 0) wave_qmax[wv] = wq;
-    __syncthreads();
-    if (lt == 0 && active) {
-        const uint32_t q = max(max(wave_qmax[4 * sub], wave_qmax[4 * sub + 1]), max(wave_qmax[4 * sub + 2], wave_qmax[4 * sub + 3]));
-        reinterpret_cast<uint32_t*>(&s.light_desc[light_pos])[3] = q;            // deepest blended position of the tile: k_render_bwd's descriptor load brings it along (both copies of the descriptor)
-        reinterpret_cast<uint32_t*>(&s.tile_desc[desc_pos])[3] = q;
-    }
-    stamp_if(s, tile, 1, active && lt == 0);
+    return false;
 }
 
-// light != 0: tiles with fewer than LIGHT_MAX instances (Meta::n_mid counts the others) are composited four per workgroup by the LAST workgroups
-// of the grid (fwd_light_group); this kernel's one-tile workgroups then end at n_mid instead of n_nonempty.
-__global__ __launch_bounds__(FWD_THREADS, 8) void k_render_fwd(const ImgState s, const BinState b, int W, int H, uint32_t gx,
-                                                            const float* __restrict__ bg, float* __restrict__ out_color, int fill_tail, uint32_t n_tiles, int light)
+// the block's pixels are complete: quad shares -> pixel values, stores; returns the deepest blended position of the block
+__device__ __forceinline__ uint32_t fwd_q_block_store(const ImgState& s, float* __restrict__ out_color, int W, int H, int px, int py, bool inside, int lane,
+                                                      float bg0, float bg1, float bg2, float T, float C0, float C1, float C2, uint32_t last_contributor)
 {
-    __shared__ float4 sA[FCH + 1];
-    __shared__ float4 sB[FCH + 1];
-    __shared__ float sC[FCH + 1];
-    __shared__ uint2 sQ[FCH];                              // quadrant masks of the staged entries
-    __shared__ __attribute__((aligned(16))) unsigned short lists[16][FCH + 8];   // one list per block (= per wave): slot | quadrant nibble << 10
-    __shared__ __attribute__((aligned(16))) unsigned short qlists[16][4][QL_ROW_F]; // per wave: the current chunk's four quadrant lists
-    __shared__ uint32_t wave_alive[2][16];                 // double-buffered "this wave still has live pixels"
-    __shared__ uint32_t wave_qmax[16];
-    const unsigned long long t_entry = busy_clock();       // (diagnostic builds only: tests/tools/timeline.py)
-    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-    const uint4 td = s.tile_desc[blockIdx.x];
-    // candidate light tile of this thread's quarter: light group g is workgroup gridDim.x - 1 - g and takes light tiles 4 g .. 4 g + 3
-    const uint32_t lgroup = gridDim.x - 1u - blockIdx.x, li = 4u * lgroup + (threadIdx.x >> 8);
-    const uint4 tdl = (light && li < n_tiles) ? s.light_desc[li] : make_uint4(0u, 0u, 0u, 0u);
-    const uint4 ff = frame_counts(s);                      // (error bits, non-empty tiles, heavy, mid): one load, in flight beside the descriptors'
-    const uint32_t n_all = (ff.x & META_ERR_CAPACITY) ? 0u : ff.y;     // a frame tgs_forward_async rejected renders the background everywhere
-    const uint32_t n_ne = light ? min(ff.w, n_all) : n_all;           // one-tile workgroups: the first n_ne entries of tile_order
-    const uint32_t n_light = n_all - n_ne, n_lgroups = (n_light + 3u) / 4u;
-    if (blockIdx.x >= n_ne) {
-        if (lgroup < n_lgroups) {                           // (uniform over the workgroup)
-            fwd_light_group(s, b, W, H, gx, bg, out_color, tdl, li < n_light, sA, sB, sC, sQ, lists, qlists, wave_qmax, li, n_ne + li);
-            return;
-        }
-        // Sync-free forward: the workgroups between the one-tile ones and the light groups (the grid covers the caller's bounds on both,
-        // plus one workgroup per 16 tiles beyond the tile bound) share the EMPTY tiles -- the tail of tile_order -- four at a time.  (One
-        // workgroup per empty tile was 5400 surplus workgroups at config 3: ~4 % of a frame.)
-        if (fill_tail) {
-            const uint32_t nfill = gridDim.x - n_ne - n_lgroups, j = blockIdx.x - n_ne;
-            for (uint32_t i = n_all + 4u * j + (threadIdx.x >> 8); i < n_tiles; i += 4u * nfill)
-                fill_tile_background(s, s.tile_desc[i].x, threadIdx.x & 255u, W, H, gx, bg, out_color);
-        }
-        return;
-    }
-    const uint32_t tile = td.x;
-    const uint32_t tx = tile % gx, ty = tile / gx;
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int qd = lane >> 4, pq = (lane >> 2) & 3, e = lane & 3;   // DPP row = 2x2 quadrant of the block, pixel of the quadrant, entry slot of the group
-    const int px = tx * TILE + (wv & 3) * 4 + (qd & 1) * 2 + (pq & 1);
-    const int py = ty * TILE + (wv >> 2) * 4 + (qd >> 1) * 2 + (pq >> 1);
-    const bool inside = px < W && py < H;
-    const float pixfx = (float)px, pixfy = (float)py;
-    const uint2 rg = make_uint2(td.y, td.z);
-    set_wave_priority(rg.y - rg.x);
-    stamp(s, tile, 0);
-    bool done = !inside;                                   // per pixel; identical in the 4 lanes of a quad
-    float vone = 1.0f;                                     // pinned to a VGPR for the DPP selects
-    asm volatile("" : "+v"(vone));
-    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;          // C: this lane's share (entries of slot e)
-    uint32_t last_contributor = 0;
-    if (threadIdx.x == 0) { sA[FNULL] = make_float4(0.f, 0.f, 0.f, 0.f); sB[FNULL] = make_float4(0.f, 0.f, 0.f, 0.f); sC[FNULL] = 0.f; }
-
-    // Register-staged prefetch of the next round (global loads stay in flight under the compute), split over the two halves
-    // of the workgroup to stay inside 64 VGPRs: thread t < FCH carries recA + recC of entry t, thread FCH + t recB + the quadrant mask.
-    const uint32_t ht = threadIdx.x & (FCH - 1);
-    const bool upper = threadIdx.x >= FCH;
-    float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    uint2 r2 = make_uint2(0u, 0u);
-    auto fetch = [&](uint32_t pos) {
-        if (!upper) { r4 = b.recA[pos]; r2.x = __float_as_uint(b.recC[pos].x); }
-        else { r4 = b.recB[pos]; r2 = b.qmask[pos]; }
-    };
-    if (rg.x + ht < rg.y) fetch(rg.x + ht);
-
-    bool wave_live = __builtin_amdgcn_ballot_w64(!done) != 0;
-    int round = 0;
-    unsigned long long busy = 0ull;                        // (diagnostic builds only)
-    for (uint32_t base = rg.x; base < rg.y; base += FCH, round++) {
-        // two barriers per round: (A) everybody has finished reading the previous round's LDS and has posted
-        // its liveness; (B) the new round is staged.  The block stops when no wave has a live pixel (forward.cu:307-310).
-        if (lane == 0) wave_alive[round & 1][wv] = wave_live ? 1u : 0u;
-        __syncthreads();
-        {
-            const uint4* wa = reinterpret_cast<const uint4*>(wave_alive[round & 1]);
-            const uint4 f0 = wa[0], f1 = wa[1], f2 = wa[2], f3 = wa[3];
-            if (((f0.x | f0.y | f0.z | f0.w) | (f1.x | f1.y | f1.z | f1.w) | (f2.x | f2.y | f2.z | f2.w) | (f3.x | f3.y | f3.z | f3.w)) == 0u) break;
-        }
-        const uint32_t cnt = min((uint32_t)FCH, rg.y - base);
-        if (ht < cnt) {
-#if TGS_FAST_MATH
-            if (!upper) { stage_conic_a(r4); sA[ht] = r4; sC[ht] = __uint_as_float(r2.x); }
-            else { stage_conic_b(r4); sB[ht] = r4; sQ[ht] = r2; }
-#else
-            if (!upper) { sA[ht] = r4; sC[ht] = __uint_as_float(r2.x); }
-            else { sB[ht] = r4; sQ[ht] = r2; }
-#endif
-        }
-        __syncthreads();
-        if (base + FCH + ht < rg.y) fetch(base + FCH + ht);
-        const uint32_t cbase = base - rg.x + 1;
-        const unsigned long long tb0 = busy_clock();
-        if (round == 0) { phase_stamp(s, tile, 2, t_entry); phase_stamp(s, tile, 3, tb0); }
-        {
-            const uint32_t n = wave_live ? build_own_list_q<FCH>(lists[wv], sQ, cnt, wv, lane) : 0u;
-            const unsigned short* myq = &qlists[wv][qd][e];
-#pragma unroll 1
-            for (uint32_t c0 = 0; c0 < n && wave_live; c0 += QCH_F) {
-            const uint32_t nq = build_chunk_quadrant_lists_128(qlists[wv], lists[wv], c0, n, lane, FNULL);
-#pragma unroll 1
-            for (uint32_t k = 0; k < nq; k += 4) {              // 4 entries of its own quadrant list per row and pass
-                const uint32_t j = myq[k];
-                const float4 a = sA[j];                        // mean2D, conic xx / xy pre-scaled for exp2 (stage_conic)
-                const float4 bb = sB[j];                       // conic yy pre-scaled, opacity, colour r g
-                const float cc = sC[j];
-                const float dx = a.x - pixfx, dy = a.y - pixfy;
-#if TGS_FAST_MATH
-                const float power2 = (a.z * dx + a.w * dy) * dx + (bb.x * dy) * dy;    // log2(e) * power of forward.cu:336
-                const float alpha = fminf(0.99f, bb.y * __builtin_amdgcn_exp2f(power2));
-#else           // -DTGS_FAST_MATH=0: the reference's expression and libm-grade expf (forward.cu:336-339), for the fuzz comparison of DESIGN.md section 3
-                const float power2 = -0.5f * (a.z * dx * dx + bb.x * dy * dy) - a.w * dx * dy;
-                const float alpha = fminf(0.99f, bb.y * expf(power2));
-#endif
-                // forward.cu:337-343 skips; a finished pixel skips everything (a padding entry has opacity 0)
-                const bool live = !done && !(power2 > 0.0f) && !(alpha < 1.0f / 255.0f);
-                const float pown = live ? 1.f - alpha : 1.0f;   // a skipped entry leaves T alone
-                // The pixel's transmittance over the group's 4 entries, in list order.  The products never grow, so once an
-                // entry fails `test_T < 0.0001` (forward.cu:345-350) every later live entry fails too: a lane only needs
-                // its own test, and T stops at the value in front of the first failing entry = the largest such value.
-                float y, x, x3;
-                fwd_chain4(pown, T, y, x, vone);
-                const bool fail = live && (x < 0.0001f);
-                const bool upd = live && !fail;
-                float cand = fail ? y : -1.0f;
-                quad_max_bcast3(cand, x, x3);
-                const float w = upd ? alpha * y : 0.f;
-                C0 += bb.z * w; C1 += bb.w * w; C2 += cc * w;
-                last_contributor = upd ? cbase + j : last_contributor;
-                const bool stop = cand >= 0.0f;                 // some entry of the group ended the pixel
-                T = stop ? cand : x3;
-                done = done || stop;
-                if (__builtin_amdgcn_ballot_w64(!done) == 0) { wave_live = false; break; }
-            }
-            }
-        }
-        busy += busy_clock() - tb0;
-    }
-    busy_report(s, tile, 0, busy);
-    phase_stamp(s, tile, 6, busy_clock());
-    // the 4 lanes of a quad hold the pixel's colour in shares and the candidates for its last contributor
     TGS_DPP_ADD(C0, 0xB1, 0xf); TGS_DPP_ADD(C0, 0x4E, 0xf);
     TGS_DPP_ADD(C1, 0xB1, 0xf); TGS_DPP_ADD(C1, 0x4E, 0xf);
     TGS_DPP_ADD(C2, 0xB1, 0xf); TGS_DPP_ADD(C2, 0x4E, 0xf);
@@ -1275,7 +1075,7 @@ __global__ __launch_bounds__(FWD_THREADS, 8) void k_render_fwd(const ImgState s,
         o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)last_contributor, 0x4E, 0xf, 0xf, false);
         last_contributor = max(last_contributor, o);
     }
-    if (inside && e == 0) {
+    if (inside && (lane & 3) == 0) {
         const size_t pix_id = (size_t)W * py + px, N = (size_t)W * H;
         s.final_T[pix_id] = T;
         s.n_contrib[pix_id] = last_contributor;
@@ -1283,21 +1083,141 @@ __global__ __launch_bounds__(FWD_THREADS, 8) void k_render_fwd(const ImgState s,
         out_color[N + pix_id] = C1 + T * bg1;
         out_color[2 * N + pix_id] = C2 + T * bg2;
     }
-    // deepest blended list position of the tile: the backward starts there without a reduction of its own
-    {
-        const uint32_t m = wave_max_u32(inside ? last_contributor : 0u);
-        if (lane == 0) wave_qmax[wv] = m;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t q = 0;
-#pragma unroll
-            for (int i = 0; i < 16; i++) q = max(q, wave_qmax[i]);
-            reinterpret_cast<uint32_t*>(&s.tile_desc[blockIdx.x])[3] = q;      // (k_render_bwd's descriptor load brings it along)
-        }
-    }
-    stamp(s, tile, 1);
+    return wave_max_u32(inside ? last_contributor : 0u);
 }
 
+__global__ __launch_bounds__(FQ_THREADS, 8) void k_render_fwd(const ImgState s, const BinState b, int W, int H, uint32_t gx,
+                                                              const float* __restrict__ bg, float* __restrict__ out_color, uint32_t n_tiles, int light)
+{
+    __shared__ float4 sA[FQ_CH + 1];
+    __shared__ float4 sB[FQ_CH + 1];
+    __shared__ float sC[FQ_CH + 1];
+    __shared__ uint2 sQ[FQ_CH];
+    __shared__ __attribute__((aligned(16))) unsigned short lists[4][FQ_CH + 8];
+    __shared__ __attribute__((aligned(16))) unsigned short qlists[4][4][QL_ROW_F];
+    __shared__ uint32_t wave_alive[2][4];
+    __shared__ uint32_t wave_qmax[4];
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+    // heavy role: blockIdx = 8 * (4 * (t / 8) + quarter) + t % 8 for the tile of rank t: a tile's quarters share an XCD, the 8 longest tiles come first
+    const uint32_t hk = blockIdx.x >> 3, ht8 = (hk >> 2) * 8u + (blockIdx.x & 7u), quarter = hk & 3u;
+    const uint4 tdh = s.tile_desc[min(ht8, n_tiles - 1u)];           // (candidate descriptor, in flight beside the frame's counts)
+    const uint4 ff = frame_counts(s);
+    const uint32_t n_all = (ff.x & META_ERR_CAPACITY) ? 0u : ff.y;     // a frame tgs_forward_async rejected renders the background everywhere
+    const uint32_t n_ne = light ? min(ff.w, n_all) : n_all;           // tiles composited by four workgroups: the first n_ne entries of tile_order
+    const uint32_t n_light = n_all - n_ne;
+    const uint32_t heavy_wgs = 4u * ((n_ne + 7u) & ~7u);
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int qd = lane >> 4, pq = (lane >> 2) & 3;
+    float vone = 1.0f;
+    asm volatile("" : "+v"(vone));
+    if (threadIdx.x == 0) { sA[FQ_NULL] = make_float4(0.f, 0.f, 0.f, 0.f); sB[FQ_NULL] = make_float4(0.f, 0.f, 0.f, 0.f); sC[FQ_NULL] = 0.f; }
+
+    if (blockIdx.x >= heavy_wgs) {
+        const uint32_t li = blockIdx.x - heavy_wgs;
+        if (li >= n_light) {
+            // the workgroups behind the tiles with instances share the EMPTY tiles -- the tail of tile_order
+            const uint32_t nfill = gridDim.x - heavy_wgs - n_light, j = li - n_light;
+            for (uint32_t i = n_all + j; i < n_tiles; i += nfill)
+                fill_tile_background(s, s.tile_desc[i].x, threadIdx.x, W, H, gx, bg, out_color);
+            return;
+        }
+        // ---- a light tile: one staging round, wave w walks four blocks (one of every block row and column) ----
+        const uint4 td = s.light_desc[li];
+        const uint32_t tile = td.x, n = td.z - td.y;        // 1 <= n < LIGHT_MAX <= FQ_CH
+        const uint32_t tx = tile % gx, ty = tile / gx;
+        stamp(s, tile, 0);
+        if (threadIdx.x < n) {
+            const uint32_t pos = td.y + threadIdx.x;
+            float4 va = b.recA[pos], vb = b.recB[pos];
+            const float vc = b.recC[pos].x; const uint2 vq = b.qmask[pos];
+#if TGS_FAST_MATH
+            stage_conic_a(va); stage_conic_b(vb);
+#endif
+            sA[threadIdx.x] = va; sB[threadIdx.x] = vb; sC[threadIdx.x] = vc; sQ[threadIdx.x] = vq;
+        }
+        __syncthreads();
+        uint32_t wq = 0;
+#pragma unroll 1
+        for (int bi = 0; bi < 4; bi++) {
+            const int bx = (wv + bi) & 3, by = bi, blk = 4 * by + bx;
+            const int px = tx * TILE + bx * 4 + (qd & 1) * 2 + (pq & 1);
+            const int py = ty * TILE + by * 4 + (qd >> 1) * 2 + (pq >> 1);
+            const bool inside = px < W && py < H;
+            bool done = !inside;
+            if (__builtin_amdgcn_ballot_w64(!done) == 0) continue;      // a block outside the image
+            float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
+            uint32_t last_contributor = 0;
+            fwd_q_block_round(sA, sB, sC, sQ, lists[wv], qlists[wv], n, blk, lane, 1u, (float)px, (float)py, vone, done, T, C0, C1, C2, last_contributor);
+            wq = max(wq, fwd_q_block_store(s, out_color, W, H, px, py, inside, lane, bg0, bg1, bg2, T, C0, C1, C2, last_contributor));
+        }
+        if (lane == 0) wave_qmax[wv] = wq;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t q = max(max(wave_qmax[0], wave_qmax[1]), max(wave_qmax[2], wave_qmax[3]));
+            reinterpret_cast<uint32_t*>(&s.light_desc[li])[3] = q;             // deepest blended position of the tile: k_render_bwd's descriptor load brings it along (both copies)
+            reinterpret_cast<uint32_t*>(&s.tile_desc[n_ne + li])[3] = q;
+        }
+        stamp(s, tile, 1);
+        return;
+    }
+    // ---- a quarter of a tile with a long list: one wave per block ----
+    if (ht8 >= n_ne) return;
+    const uint32_t tile = tdh.x;
+    const uint32_t tx = tile % gx, ty = tile / gx;
+    const int bx = 2 * (int)(quarter & 1u) + (wv & 1), by = 2 * (int)(quarter >> 1) + (wv >> 1), blk = 4 * by + bx;
+    const int px = tx * TILE + bx * 4 + (qd & 1) * 2 + (pq & 1);
+    const int py = ty * TILE + by * 4 + (qd >> 1) * 2 + (pq >> 1);
+    const bool inside = px < W && py < H;
+    const float pixfx = (float)px, pixfy = (float)py;
+    const uint2 rg = make_uint2(tdh.y, tdh.z);
+    set_wave_priority(rg.y - rg.x);
+    if (quarter == 0) stamp(s, tile, 0);
+    bool done = !inside;
+    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
+    uint32_t last_contributor = 0;
+    // register-staged prefetch of the next round: thread t carries entry t whole
+    float4 ra[FQ_EPT], rb[FQ_EPT]; float rc[FQ_EPT]; uint2 rq[FQ_EPT];
+#pragma unroll
+    for (int i = 0; i < FQ_EPT; i++) { ra[i] = make_float4(0.f, 0.f, 0.f, 0.f); rb[i] = ra[i]; rc[i] = 0.f; rq[i] = make_uint2(0u, 0u); }
+#define TGS_FQ_FETCH(BASE) { _Pragma("unroll") for (int i = 0; i < FQ_EPT; i++) { const uint32_t pos = (BASE) + (uint32_t)(i * FQ_THREADS) + threadIdx.x; \
+        if (pos < rg.y) { ra[i] = b.recA[pos]; rb[i] = b.recB[pos]; rc[i] = b.recC[pos].x; rq[i] = b.qmask[pos]; } } }
+    TGS_FQ_FETCH(rg.x)
+    bool wave_live = __builtin_amdgcn_ballot_w64(!done) != 0;
+    int round = 0;
+    for (uint32_t base = rg.x; base < rg.y; base += FQ_CH, round++) {
+        // two barriers per round: (A) everybody has finished reading the previous round's LDS and has posted its liveness; (B) the new
+        // round is staged.  The quarter stops when none of its waves has a live pixel (forward.cu:307-310).
+        if (lane == 0) wave_alive[round & 1][wv] = wave_live ? 1u : 0u;
+        __syncthreads();
+        {
+            const uint4 f = *reinterpret_cast<const uint4*>(wave_alive[round & 1]);
+            if ((f.x | f.y | f.z | f.w) == 0u) break;
+        }
+        const uint32_t cnt = min((uint32_t)FQ_CH, rg.y - base);
+#pragma unroll
+        for (int i = 0; i < FQ_EPT; i++) {
+            const uint32_t h = (uint32_t)(i * FQ_THREADS) + threadIdx.x;
+            if (h < cnt) {
+                float4 va = ra[i], vb = rb[i];
+#if TGS_FAST_MATH
+                stage_conic_a(va); stage_conic_b(vb);
+#endif
+                sA[h] = va; sB[h] = vb; sC[h] = rc[i]; sQ[h] = rq[i];
+            }
+        }
+        __syncthreads();
+        if (base + FQ_CH < rg.y) TGS_FQ_FETCH(base + FQ_CH)
+        if (wave_live && fwd_q_block_round(sA, sB, sC, sQ, lists[wv], qlists[wv], cnt, blk, lane, base - rg.x + 1, pixfx, pixfy, vone, done, T, C0, C1, C2, last_contributor))
+            wave_live = false;
+    }
+#undef TGS_FQ_FETCH
+    const uint32_t m = fwd_q_block_store(s, out_color, W, H, px, py, inside, lane, bg0, bg1, bg2, T, C0, C1, C2, last_contributor);
+    if (lane == 0) wave_qmax[wv] = m;
+    __syncthreads();
+    // deepest blended position of the tile (its descriptor's .w, zero from k_scan): the maximum over the four quarters
+    if (threadIdx.x == 0) atomicMax(reinterpret_cast<uint32_t*>(&s.tile_desc[ht8]) + 3, max(max(wave_qmax[0], wave_qmax[1]), max(wave_qmax[2], wave_qmax[3])));
+    stamp_max(s, tile, 1);                                  // (diagnostic builds: the last quarter's end; a frame's stamps start at zero only in a fresh buffer)
+}
 
 // ---------------------------------------------------------------------------------------------
 // k_mark_visible (rasterizer_impl.cu:54-66)
@@ -1418,22 +1338,13 @@ void launch_tile_sort(hipStream_t st, const GeomState& g, const ImgState& s, con
 void launch_render_fwd(hipStream_t st, const ImgState& s, const BinState& b, int W, int H, uint32_t gx, uint32_t T, const Meta* m,
                        const float* bg, float* out_color, uint32_t tile_bound, uint32_t mid_bound, int light)
 {
-    if (!m) {   // sync-free: workgroups for the bounds on the tiles with instances (k_scan has rejected the frame if more hold any) + one per 16
-                // tiles beyond the bound; those not needed for compositing write the background of all empty tiles
-        const uint32_t tb = tile_bound < T ? tile_bound : T;
-        const uint32_t hb = light ? (mid_bound < tb ? mid_bound : tb) : tb;     // one-tile workgroups, at most
-        const uint32_t lg = light ? (tb - hb + 3u) / 4u : 0u;                   // light groups beside them, at most (four tiles each; largest when n_mid reaches its bound)
-        const uint32_t grid = hb + lg + (T - tb + 15u) / 16u;
-        hipLaunchKernelGGL(k_render_fwd, dim3(grid), dim3(FWD_THREADS), 0, st, s, b, W, H, gx, bg, out_color, 1, T, light);
-        return;
-    }
-    // exact counts (the host has read Meta): one-tile workgroups, light groups, and -- between them in the grid -- one workgroup per 16 empty
-    // tiles for the background (a kernel of its own behind this one, k_fill_empty, was 6.6 us + a launch boundary of a frame that has the
-    // GPU to itself; as workgroups of this launch the fill runs beside the long lists)
-    const uint32_t nonempty = m->n_nonempty, empty = T - m->n_nonempty;
-    const uint32_t heavy = light ? (m->n_mid < nonempty ? m->n_mid : nonempty) : nonempty;
-    const uint32_t grid = heavy + (nonempty - heavy + 3u) / 4u + (empty + 15u) / 16u;
-    if (grid > 0) hipLaunchKernelGGL(k_render_fwd, dim3(grid), dim3(FWD_THREADS), 0, st, s, b, W, H, gx, bg, out_color, 1, T, light);
+    // four workgroups per tile of the (bound on the) tiles with >= LIGHT_MAX instances -- all tiles with instances when no light tiles are
+    // set apart --, one per light tile, one per 4 tiles beyond for the background.  m: the frame's counts when the host has read them; otherwise
+    // the caller's bounds (k_scan has rejected a frame that exceeds them), surplus workgroups join the background fill or leave at once.
+    const uint32_t tb = m ? m->n_nonempty : (tile_bound < T ? tile_bound : T);
+    const uint32_t hb = light ? (m ? (m->n_mid < tb ? m->n_mid : tb) : (mid_bound < tb ? mid_bound : tb)) : tb;
+    const uint32_t grid = 4u * ((hb + 7u) & ~7u) + (tb - hb) + (T - tb + 3u) / 4u;
+    if (grid > 0) hipLaunchKernelGGL(k_render_fwd, dim3(grid), dim3(FQ_THREADS), 0, st, s, b, W, H, gx, bg, out_color, T, light);
 }
 void launch_mark_visible(hipStream_t st, int P, const float* means3D, const float* view, uint8_t* present)
 {
