@@ -32,15 +32,16 @@ def diagnose(mine: dict, ref: dict, P: int) -> str:
         return f"(no diagnosis: {ex})"
 
 
-def run(seed: int, n_scenes: int, direct_factor: float = 1.0, log=print) -> dict:
-    """-> {scenes, misses, miss_rate, worst_rel_l2, worst (text), largest_ok: per-tensor maximum over the scenes that passed}"""
+def run(seed: int, n_scenes: int, direct_factor: float = 1.0, log=print, light_tiles=None) -> dict:
+    """-> {scenes, misses, miss_rate, worst_rel_l2, worst (text), largest_ok: per-tensor maximum over the scenes that passed}
+    light_tiles: tgs_options_t::light_tiles for forward and backward (None: the entry points' default)"""
     import re
     rng = np.random.default_rng(seed)
     misses, worst, worst_txt, largest = 0, 0.0, "", {}
     for it in range(n_scenes):
         desc, inp, dL = random_scene(rng, it)
         ref = util.oracle_run(inp, dL)
-        mine = util.hip_run(inp, dL)
+        mine = util.hip_run(inp, dL, light_tiles=light_tiles)
         try:
             rep = util.compare(mine, ref, direct_factor=direct_factor)
             for k, v in rep.items():
