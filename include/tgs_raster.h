@@ -126,12 +126,13 @@ typedef struct {
                                   (grids are sized by it; a forward with more is rejected / repeated; a backward with more sets
                                   TGS_FRAME_TILE_BOUND in the frame's flags and returns TGS_ERR_INVALID from tgs_frame_status); 0: none */
     int64_t heavy_bound, mid_bound;   /* the same for the tiles with >= 1024 / >= 128 instances (classes of the tile sort; the second also sizes the
-                                  1024-thread render kernels' grids when light_tiles is on); only read with tile_bound */
-    int32_t light_tiles;       /* 1: tiles with fewer than 128 instances are composited several per workgroup (four forward, three backward) by the
-                                  last workgroups of the render kernels' grids, the others one per workgroup; 0: one workgroup per tile; -1: default
-                                  (1 in the *_views entry points, 0 in the single-view ones; TGS_LIGHT_TILES overrides both).  A backward forms
-                                  light groups only for a frame whose FORWARD ran with them (the forward records their descriptors): pass
-                                  the same options to both; light_tiles = 1 on a frame rendered without is reported as TGS_FRAME_TILE_BOUND */
+                                  render kernels' grids when light_tiles is on); only read with tile_bound */
+    int32_t light_tiles;       /* 1: tiles with fewer than 128 instances are set apart in the render kernels: the forward composites such a tile
+                                  with ONE 256-thread workgroup (a longer list gets four, one per 8x8-pixel quarter), the backward three of them
+                                  per 1024-thread workgroup (the others one per workgroup); 0: every tile with instances is treated alike;
+                                  -1: default (1 in the *_views entry points, 0 in the single-view ones; TGS_LIGHT_TILES overrides both).
+                                  A backward sets light tiles apart only for a frame whose FORWARD did (the forward records their descriptors):
+                                  pass the same options to both; light_tiles = 1 on a frame rendered without is reported as TGS_FRAME_TILE_BOUND */
     int32_t reserved;
 } tgs_options_t;
 /* What a forward learned about its frame (filled when non-NULL; the synchronous and the speculative forward read the frame's Meta,
