@@ -1106,6 +1106,8 @@ __global__ __launch_bounds__(FQ_THREADS, 8) void k_render_fwd(const ImgState s, 
     const uint32_t n_ne = light ? min(ff.w, n_all) : n_all;           // tiles composited by four workgroups: the first n_ne entries of tile_order
     const uint32_t n_light = n_all - n_ne;
     const uint32_t heavy_wgs = 4u * ((n_ne + 7u) & ~7u);
+    // (cannot happen with a grid sized by launch_render_fwd from bounds k_scan has enforced; a tile left out would be a silent hole in the image)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && heavy_wgs + n_light > gridDim.x) atomicOr(&s.meta->error, META_ERR_TILE_BOUND);
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int qd = lane >> 4, pq = (lane >> 2) & 3;
     float vone = 1.0f;
@@ -1343,7 +1345,9 @@ void launch_render_fwd(hipStream_t st, const ImgState& s, const BinState& b, int
     // the caller's bounds (k_scan has rejected a frame that exceeds them), surplus workgroups join the background fill or leave at once.
     const uint32_t tb = m ? m->n_nonempty : (tile_bound < T ? tile_bound : T);
     const uint32_t hb = light ? (m ? (m->n_mid < tb ? m->n_mid : tb) : (mid_bound < tb ? mid_bound : tb)) : tb;
-    const uint32_t grid = 4u * ((hb + 7u) & ~7u) + (tb - hb) + (T - tb + 3u) / 4u;
+    // (+ 7: with n_ne <= hb tiles in the first class the kernel needs 4 * roundup8(n_ne) + (n_all - n_ne) workgroups, and 4 * roundup8(x) - x
+    // is not monotone inside a block of 8 -- n_ne = hb - 7 needs 7 more than n_ne = hb)
+    const uint32_t grid = 4u * ((hb + 7u) & ~7u) + 7u + (tb - hb) + (T - tb + 3u) / 4u;
     if (grid > 0) hipLaunchKernelGGL(k_render_fwd, dim3(grid), dim3(FQ_THREADS), 0, st, s, b, W, H, gx, bg, out_color, T, light);
 }
 void launch_mark_visible(hipStream_t st, int P, const float* means3D, const float* view, uint8_t* present)
