@@ -268,6 +268,22 @@ int tgs_bind_backward(void* stream, int P, const float* raw_quats, const float* 
                       const float* g_opacity, const float* g_scales, const float* g_quats, const float* g_points,
                       float* d_density, float* d_scales, float* d_quats, float* d_deltas);
 
+/* The same for the TWO-group models of the editing stages (EditTetGS, Edit_core/tetgs_scene/tetgs_edit_2d.py:280-318; Edit3DTetGS,
+ * tetgs_edit_3d.py:272-331), whose properties concatenate [keep, edit] and then apply the activation on every access, with the keep group frozen
+ * (requires_grad=False, tetgs_edit_2d.py:237-262).  The forward writes rows [0, Pk) from the keep group and rows [Pk, Pk + Pe) from the
+ * edit group of opacity[Pk+Pe,1] scales[Pk+Pe,3] quats[Pk+Pe,4] points[Pk+Pe,3] in one launch (a NULL output is skipped).  Edit
+ * positions: edit_points[Pe,3] (EditTetGS.points, tetgs_edit_2d.py:281-283), or -- edit_points NULL -- ori_edit_points[Pe,3] +
+ * edit_normals[Pe,3] * edit_offsets[Pe,1] (Edit3DTetGS.points, tetgs_edit_3d.py:273-278).  The backward takes the FULL [Pk+Pe]
+ * forward outputs and incoming gradients and writes gradients of the edit group only (Pe rows): d_points[Pe,3] for plain edit
+ * positions or d_offsets[Pe,1] for normal-bound ones; a NULL d_* is skipped. */
+int tgs_bind_groups_forward(void* stream, int Pk, int Pe, const float* keep_density, const float* keep_scales, const float* keep_quats, const float* keep_points,
+                            const float* edit_density, const float* edit_scales, const float* edit_quats, const float* edit_points,
+                            const float* ori_edit_points, const float* edit_normals, const float* edit_offsets,
+                            float* opacity, float* scales, float* quats, float* points);
+int tgs_bind_groups_backward(void* stream, int Pk, int Pe, const float* edit_quats, const float* edit_normals, const float* opacity, const float* scales,
+                             const float* g_opacity, const float* g_scales, const float* g_quats, const float* g_points,
+                             float* d_density, float* d_scales, float* d_quats, float* d_points, float* d_offsets);
+
 /* ---- "next" row 4: simple-knn ----
  * distCUDA2 (Edit_core/thirdparties/simple-knn/spatial.cu:15-26 -> SimpleKNN::knn, simple_knn.cu:185-221):
  * mean_dist2[i] = mean of the 3 smallest squared distances from points[i] to the other points (FLT_MAX terms, i.e.

@@ -14,39 +14,73 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libtgs_oracle.so")
+_LIB64_PATH = os.path.join(_HERE, "libtgs_oracle_f64.so")      # the same C text with real = double (tgs_oracle.c: TGS_ORACLE_F64)
+_LIBFMA_PATH = os.path.join(_HERE, "libtgs_oracle_fma.so")     # fp32 with FMA contraction allowed (what nvcc does to the reference by default)
 _lib = None
+_lib64 = None
+_libfma = None
 
 
 def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "tgs_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-s", "libtgs_oracle.so"])
+    for path in (_LIB_PATH, _LIB64_PATH, _LIBFMA_PATH):
+        if force or not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", _HERE, "-s", os.path.basename(path)])
     return _LIB_PATH
+
+
+def _bind(path: str, real, with_pergauss: bool):
+    L = C.CDLL(path)
+    fp, ip, vp = C.POINTER(real), C.POINTER(C.c_int), C.c_void_p
+    L.tgs_oracle_forward.restype = vp
+    L.tgs_oracle_forward.argtypes = [C.c_int, C.c_int, C.c_int, fp, C.c_int, C.c_int, fp, fp, fp, fp, fp,
+                                     real, fp, fp, fp, fp, fp, real, real, fp, ip]
+    L.tgs_oracle_backward.restype = None
+    L.tgs_oracle_backward.argtypes = [vp, fp, fp, fp, fp, fp, real, fp, fp, fp, fp, fp, real, real] + [fp] * 10
+    if with_pergauss:
+        L.tgs_oracle_backward_pergauss_f64.restype = None
+        L.tgs_oracle_backward_pergauss_f64.argtypes = [vp, fp, fp, fp, real, fp, fp, fp, fp, fp, real, real, fp, fp, fp, fp, fp, fp, fp]
+    L.tgs_oracle_free.argtypes = [vp]
+    L.tgs_oracle_free.restype = None
+    L.tgs_oracle_num_rendered.argtypes = [vp]
+    L.tgs_oracle_num_rendered.restype = C.c_int64
+    L.tgs_oracle_field.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
+    L.tgs_oracle_field.restype = vp
+    L.tgs_oracle_threads.restype = C.c_int
+    return L
+
+
+def lib64():
+    """libtgs_oracle_f64.so: every float of the interface and the state is a double."""
+    global _lib64
+    if _lib64 is None:
+        build()
+        _lib64 = _bind(_LIB64_PATH, C.c_double, False)
+    return _lib64
+
+
+def libfma():
+    """libtgs_oracle_fma.so: fp32, the compiler may contract a*b+c into one fma (-ffp-contract=fast -mfma), as nvcc does by default with
+    the reference's kernels: a second, equally legitimate rounding of the reference's arithmetic."""
+    global _libfma
+    if _libfma is None:
+        build()
+        _libfma = _bind(_LIBFMA_PATH, C.c_float, False)
+    return _libfma
+
+
+def _variant_lib(variant: str):
+    return {"f32": lib, "f64": lib64, "f32_fma": libfma}[variant]()
 
 
 def lib():
     global _lib
     if _lib is None:
         build()
-        L = C.CDLL(_LIB_PATH)
-        fp, ip, vp = C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_void_p
-        L.tgs_oracle_forward.restype = vp
-        L.tgs_oracle_forward.argtypes = [C.c_int, C.c_int, C.c_int, fp, C.c_int, C.c_int, fp, fp, fp, fp, fp,
-                                         C.c_float, fp, fp, fp, fp, fp, C.c_float, C.c_float, fp, ip]
-        L.tgs_oracle_backward.restype = None
-        L.tgs_oracle_backward.argtypes = [vp, fp, fp, fp, fp, fp, C.c_float, fp, fp, fp, fp, fp, C.c_float,
-                                          C.c_float] + [fp] * 10
-        L.tgs_oracle_backward_pergauss_f64.restype = None
-        L.tgs_oracle_backward_pergauss_f64.argtypes = [vp, fp, fp, fp, C.c_float, fp, fp, fp, fp, fp, C.c_float, C.c_float, fp, fp, fp, fp, fp, fp, fp]
-        L.tgs_oracle_free.argtypes = [vp]
-        L.tgs_oracle_free.restype = None
-        L.tgs_oracle_num_rendered.argtypes = [vp]
-        L.tgs_oracle_num_rendered.restype = C.c_int64
-        L.tgs_oracle_field.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
-        L.tgs_oracle_field.restype = vp
+        L = _bind(_LIB_PATH, C.c_float, True)
+        fp = C.POINTER(C.c_float)
         L.tgs_oracle_mark_visible.argtypes = [C.c_int, fp, fp, fp, C.POINTER(C.c_uint8)]
         L.tgs_oracle_mark_visible.restype = None
-        L.tgs_oracle_threads.restype = C.c_int
         _lib = L
     return _lib
 
@@ -54,14 +88,22 @@ def lib():
 def _f(a: Optional[np.ndarray]):
     if a is None:
         return None
-    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
-    return a.ctypes.data_as(C.POINTER(C.c_float))
+    assert a.dtype in (np.float32, np.float64) and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.POINTER(C.c_float if a.dtype == np.float32 else C.c_double))
 
 
 def _c32(a):
     return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
 
 
+def _conv(f64: bool):
+    """inputs are ALWAYS the fp32 values (rounded to float first, then widened exactly for the f64 library)"""
+    if not f64:
+        return _c32
+    return lambda a: None if a is None else np.ascontiguousarray(np.ascontiguousarray(a, dtype=np.float32), dtype=np.float64)
+
+
+_REAL_FIELDS = ("depths", "means2D", "cov3D", "conic_opacity", "rgb", "final_T")
 _FIELDS = {"depths": np.float32, "means2D": np.float32, "cov3D": np.float32, "conic_opacity": np.float32,
            "rgb": np.float32, "clamped": np.uint8, "tiles_touched": np.uint32, "point_offsets": np.uint32,
            "radii": np.int32, "point_list": np.uint32, "point_keys": np.uint64, "ranges": np.uint32,
@@ -71,16 +113,19 @@ _FIELDS = {"depths": np.float32, "means2D": np.float32, "cov3D": np.float32, "co
 class OracleState:
     """Owns the C state of one forward pass (the reference's three byte buffers)."""
 
-    def __init__(self, handle, keep):
+    def __init__(self, handle, keep, variant: str = "f32"):
         self._h = handle
         self._keep = keep
+        self.variant = variant
+        self.f64 = variant == "f64"
+        self._L = _variant_lib(variant)
 
     def field(self, name: str) -> np.ndarray:
         cnt = C.c_int64()
-        p = lib().tgs_oracle_field(self._h, name.encode(), C.byref(cnt))
+        p = self._L.tgs_oracle_field(self._h, name.encode(), C.byref(cnt))
         if cnt.value < 0:
             raise KeyError(name)
-        dt = np.dtype(_FIELDS[name])
+        dt = np.dtype(np.float64 if (self.f64 and name in _REAL_FIELDS) else _FIELDS[name])
         if cnt.value == 0:
             return np.zeros(0, dt)
         buf = (C.c_char * (cnt.value * dt.itemsize)).from_address(p)
@@ -88,12 +133,12 @@ class OracleState:
 
     @property
     def num_rendered(self) -> int:
-        return int(lib().tgs_oracle_num_rendered(self._h))
+        return int(self._L.tgs_oracle_num_rendered(self._h))
 
     def __del__(self):
         try:
             if self._h:
-                lib().tgs_oracle_free(self._h)
+                self._L.tgs_oracle_free(self._h)
                 self._h = None
         except Exception:
             pass
@@ -101,45 +146,58 @@ class OracleState:
 
 def forward(*, bg, means3D, opacities, viewmatrix, projmatrix, campos, tanfovx, tanfovy, image_height,
             image_width, sh_degree=0, shs=None, colors_precomp=None, scales=None, rotations=None,
-            cov3D_precomp=None, scale_modifier=1.0):
+            cov3D_precomp=None, scale_modifier=1.0, variant: str = "f32"):
     """Returns (color[3,H,W], radii[P], OracleState).  Mirrors Rasterizer::forward
-    (cuda_rasterizer/rasterizer_impl.cu:198-336)."""
-    means3D = _c32(means3D)
+    (cuda_rasterizer/rasterizer_impl.cu:198-336).  ``variant``: "f32" (the restatement, no FMA contraction), "f32_fma" (contraction
+    allowed), "f64" (the same C text compiled with real = double on the same fp32 inputs -- scalars are rounded to fp32 first as well:
+    the reference's function in exact arithmetic)."""
+    f64 = variant == "f64"
+    cv = _conv(f64)
+    L = _variant_lib(variant)
+    rdt = np.float64 if f64 else np.float32
+    r32 = lambda v: float(np.float32(v))
+    means3D = cv(means3D)
     P = means3D.shape[0]
-    shs, colors_precomp, scales, rotations, cov3D_precomp = map(_c32, (shs, colors_precomp, scales, rotations, cov3D_precomp))
+    shs, colors_precomp, scales, rotations, cov3D_precomp = map(cv, (shs, colors_precomp, scales, rotations, cov3D_precomp))
     M = shs.shape[1] if shs is not None and shs.shape[0] != 0 else 0
-    bg, opacities, viewmatrix, projmatrix, campos = map(_c32, (bg, opacities, viewmatrix, projmatrix, campos))
+    bg, opacities, viewmatrix, projmatrix, campos = map(cv, (bg, opacities, viewmatrix, projmatrix, campos))
     H, W = int(image_height), int(image_width)
-    color = np.zeros((3, H, W), np.float32)
+    color = np.zeros((3, H, W), rdt)
     radii = np.zeros(P, np.int32)
     keep = (bg, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, campos)
-    h = lib().tgs_oracle_forward(P, int(sh_degree), M, _f(bg), W, H, _f(means3D), _f(shs), _f(colors_precomp),
-                                 _f(opacities), _f(scales), float(scale_modifier), _f(rotations), _f(cov3D_precomp),
-                                 _f(viewmatrix), _f(projmatrix), _f(campos), float(tanfovx), float(tanfovy),
-                                 _f(color), radii.ctypes.data_as(C.POINTER(C.c_int)))
-    return color, radii, OracleState(h, keep)
+    h = L.tgs_oracle_forward(P, int(sh_degree), M, _f(bg), W, H, _f(means3D), _f(shs), _f(colors_precomp),
+                             _f(opacities), _f(scales), r32(scale_modifier), _f(rotations), _f(cov3D_precomp),
+                             _f(viewmatrix), _f(projmatrix), _f(campos), r32(tanfovx), r32(tanfovy),
+                             _f(color), radii.ctypes.data_as(C.POINTER(C.c_int)))
+    return color, radii, OracleState(h, keep, variant)
 
 
 def backward(state: OracleState, dL_dout_color, *, bg, means3D, viewmatrix, projmatrix, campos, tanfovx, tanfovy,
              shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None,
              scale_modifier=1.0, f64_pergauss: bool = False) -> Dict[str, np.ndarray]:
-    """Returns the 8 tensors of RasterizeGaussiansBackwardCUDA (rasterize_points.cu:195) plus dL_dconic."""
-    means3D = _c32(means3D)
+    """Returns the 8 tensors of RasterizeGaussiansBackwardCUDA (rasterize_points.cu:195) plus dL_dconic.  The precision is the
+    state's (a state from forward(f64=True) is back-propagated in double)."""
+    f64 = state.f64
+    cv = _conv(f64)
+    L = state._L
+    rdt = np.float64 if f64 else np.float32
+    r32 = lambda v: float(np.float32(v))
+    means3D = cv(means3D)
     P = means3D.shape[0]
-    shs, colors_precomp, scales, rotations, cov3D_precomp = map(_c32, (shs, colors_precomp, scales, rotations, cov3D_precomp))
+    shs, colors_precomp, scales, rotations, cov3D_precomp = map(cv, (shs, colors_precomp, scales, rotations, cov3D_precomp))
     M = shs.shape[1] if shs is not None and shs.shape[0] != 0 else 0
-    bg, viewmatrix, projmatrix, campos, dL = map(_c32, (bg, viewmatrix, projmatrix, campos, dL_dout_color))
-    z = lambda *s: np.zeros(s, np.float32)
+    bg, viewmatrix, projmatrix, campos, dL = map(cv, (bg, viewmatrix, projmatrix, campos, dL_dout_color))
+    z = lambda *s: np.zeros(s, rdt)
     out = {"dL_dmeans2D": z(P, 3), "dL_dconic": z(P, 4), "dL_dopacity": z(P, 1), "dL_dcolors": z(P, 3),
            "dL_dmeans3D": z(P, 3), "dL_dcov3D": z(P, 6), "dL_dsh": z(P, M, 3), "dL_dscales": z(P, 3),
            "dL_drotations": z(P, 4)}
-    lib().tgs_oracle_backward(state._h, _f(bg), _f(means3D), _f(shs), _f(colors_precomp), _f(scales),
-                              float(scale_modifier), _f(rotations), _f(cov3D_precomp), _f(viewmatrix), _f(projmatrix),
-                              _f(campos), float(tanfovx), float(tanfovy), _f(dL), _f(out["dL_dmeans2D"]),
-                              _f(out["dL_dconic"]), _f(out["dL_dopacity"]), _f(out["dL_dcolors"]),
-                              _f(out["dL_dmeans3D"]), _f(out["dL_dcov3D"]), _f(out["dL_dsh"]), _f(out["dL_dscales"]),
-                              _f(out["dL_drotations"]))
-    if f64_pergauss:
+    L.tgs_oracle_backward(state._h, _f(bg), _f(means3D), _f(shs), _f(colors_precomp), _f(scales),
+                          r32(scale_modifier), _f(rotations), _f(cov3D_precomp), _f(viewmatrix), _f(projmatrix),
+                          _f(campos), r32(tanfovx), r32(tanfovy), _f(dL), _f(out["dL_dmeans2D"]),
+                          _f(out["dL_dconic"]), _f(out["dL_dopacity"]), _f(out["dL_dcolors"]),
+                          _f(out["dL_dmeans3D"]), _f(out["dL_dcov3D"]), _f(out["dL_dsh"]), _f(out["dL_dscales"]),
+                          _f(out["dL_drotations"]))
+    if f64_pergauss and state.variant == "f32":
         # the per-Gaussian formulas re-evaluated in double on the same fp32 inputs: fp32 rounding noise estimate
         z3, z6, z4 = z(P, 3), z(P, 6), z(P, 4)
         zs = z(P, 3)

@@ -28,21 +28,38 @@
 #include <omp.h>
 #endif
 
+/* `real` is float: the reference's arithmetic.  -DTGS_ORACLE_F64 compiles the SAME text with real = double
+ * (libtgs_oracle_f64.so: every array of the interface and of the state is double, the fp32 literals and the fp32
+ * depth bits of the sort key stay what they are): the reference's function in exact arithmetic on the same fp32
+ * inputs, used by the tests to measure the fp32 reference's own distance from it. */
+#ifdef TGS_ORACLE_F64
+typedef double real;
+#define r_sqrt sqrt
+#define r_exp exp
+#define r_ceil ceil
+#else
+typedef float real;
+#define r_sqrt sqrtf
+#define r_exp expf
+#define r_ceil ceilf
+#endif
+#define RS sizeof(real)
+
 #define BLOCK_X 16 /* CR/config.h:16 */
 #define BLOCK_Y 16 /* CR/config.h:17 */
 #define BLOCK_SIZE (BLOCK_X * BLOCK_Y)
 
 /* CR/auxiliary.h:22-39 */
-static const float SH_C0 = 0.28209479177387814f;
-static const float SH_C1 = 0.4886025119029199f;
-static const float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+static const real SH_C0 = 0.28209479177387814f;
+static const real SH_C1 = 0.4886025119029199f;
+static const real SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
                                -1.0925484305920792f, 0.5462742152960396f};
-static const float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+static const real SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
                                0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
                                -0.5900435899266435f};
 
-typedef struct { float m[3][3]; } mat3; /* m[col][row] */
-typedef struct { float x, y, z; } vec3;
+typedef struct { real m[3][3]; } mat3; /* m[col][row] */
+typedef struct { real x, y, z; } vec3;
 
 /* glm mat3 * mat3, type_mat3x3.inl:486-518 */
 static mat3 m3mul(const mat3* a, const mat3* b)
@@ -61,40 +78,40 @@ static mat3 m3t(const mat3* a)
     return r;
 }
 /* glm::mat3(a,b,c, d,e,f, g,h,i): arguments fill column 0 first */
-static mat3 m3make(float a, float b, float c, float d, float e, float f, float g, float h, float i)
+static mat3 m3make(real a, real b, real c, real d, real e, real f, real g, real h, real i)
 {
     mat3 r = {{{a, b, c}, {d, e, f}, {g, h, i}}};
     return r;
 }
-static float fminf_(float a, float b) { return a < b ? a : b; }
-static float fmaxf_(float a, float b) { return a > b ? a : b; }
+static real fminf_(real a, real b) { return a < b ? a : b; }
+static real fmaxf_(real a, real b) { return a > b ? a : b; }
 
 /* CR/auxiliary.h:41-44 : literals are double, so the expression is evaluated in double */
-static float ndc2Pix(float v, int S) { return (float)((((double)v + 1.0) * (double)S - 1.0) * 0.5); }
+static real ndc2Pix(real v, int S) { return (real)((((double)v + 1.0) * (double)S - 1.0) * 0.5); }
 
 /* CR/auxiliary.h:46-56 */
-static void getRect(float px, float py, int max_radius, uint32_t* rmin, uint32_t* rmax, uint32_t gx,
+static void getRect(real px, real py, int max_radius, uint32_t* rmin, uint32_t* rmax, uint32_t gx,
                     uint32_t gy)
 {
     int v;
-    v = (int)((px - (float)max_radius) / (float)BLOCK_X); if (v < 0) v = 0;
+    v = (int)((px - (real)max_radius) / (real)BLOCK_X); if (v < 0) v = 0;
     rmin[0] = (uint32_t)v < gx ? (uint32_t)v : gx;
-    v = (int)((py - (float)max_radius) / (float)BLOCK_Y); if (v < 0) v = 0;
+    v = (int)((py - (real)max_radius) / (real)BLOCK_Y); if (v < 0) v = 0;
     rmin[1] = (uint32_t)v < gy ? (uint32_t)v : gy;
-    v = (int)((px + (float)max_radius + (float)BLOCK_X - 1.0f) / (float)BLOCK_X); if (v < 0) v = 0;
+    v = (int)((px + (real)max_radius + (real)BLOCK_X - 1.0f) / (real)BLOCK_X); if (v < 0) v = 0;
     rmax[0] = (uint32_t)v < gx ? (uint32_t)v : gx;
-    v = (int)((py + (float)max_radius + (float)BLOCK_Y - 1.0f) / (float)BLOCK_Y); if (v < 0) v = 0;
+    v = (int)((py + (real)max_radius + (real)BLOCK_Y - 1.0f) / (real)BLOCK_Y); if (v < 0) v = 0;
     rmax[1] = (uint32_t)v < gy ? (uint32_t)v : gy;
 }
 
 /* CR/auxiliary.h:58-77 */
-static vec3 transformPoint4x3(vec3 p, const float* m)
+static vec3 transformPoint4x3(vec3 p, const real* m)
 {
     vec3 t = {m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12], m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
               m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14]};
     return t;
 }
-static void transformPoint4x4(vec3 p, const float* m, float* o)
+static void transformPoint4x4(vec3 p, const real* m, real* o)
 {
     o[0] = m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12];
     o[1] = m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13];
@@ -102,7 +119,7 @@ static void transformPoint4x4(vec3 p, const float* m, float* o)
     o[3] = m[3] * p.x + m[7] * p.y + m[11] * p.z + m[15];
 }
 /* CR/auxiliary.h:89-97 */
-static vec3 transformVec4x3Transpose(vec3 p, const float* m)
+static vec3 transformVec4x3Transpose(vec3 p, const real* m)
 {
     vec3 t = {m[0] * p.x + m[1] * p.y + m[2] * p.z, m[4] * p.x + m[5] * p.y + m[6] * p.z,
               m[8] * p.x + m[9] * p.y + m[10] * p.z};
@@ -111,8 +128,8 @@ static vec3 transformVec4x3Transpose(vec3 p, const float* m)
 /* CR/auxiliary.h:107-117 */
 static vec3 dnormvdv3(vec3 v, vec3 dv)
 {
-    float sum2 = v.x * v.x + v.y * v.y + v.z * v.z;
-    float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+    real sum2 = v.x * v.x + v.y * v.y + v.z * v.z;
+    real invsum32 = 1.0f / r_sqrt(sum2 * sum2 * sum2);
     vec3 r;
     r.x = ((+sum2 - v.x * v.x) * dv.x - v.y * v.x * dv.y - v.z * v.x * dv.z) * invsum32;
     r.y = (-v.x * v.y * dv.x + (sum2 - v.y * v.y) * dv.y - v.z * v.y * dv.z) * invsum32;
@@ -126,11 +143,11 @@ typedef struct tgs_oracle_state {
     uint32_t gx, gy;
     int64_t R;
     int has_sh, has_colors_precomp, has_cov_precomp;
-    float* depths;          /* P   */
-    float* means2D;         /* 2P  */
-    float* cov3D;           /* 6P  */
-    float* conic_opacity;   /* 4P  */
-    float* rgb;             /* 3P  */
+    real* depths;          /* P   */
+    real* means2D;         /* 2P  */
+    real* cov3D;           /* 6P  */
+    real* conic_opacity;   /* 4P  */
+    real* rgb;             /* 3P  */
     uint8_t* clamped;       /* 3P  */
     uint32_t* tiles_touched;/* P   */
     uint32_t* point_offsets;/* P inclusive scan */
@@ -138,7 +155,7 @@ typedef struct tgs_oracle_state {
     uint32_t* point_list;   /* R   */
     uint64_t* point_keys;   /* R   */
     uint32_t* ranges;       /* 2T  */
-    float* final_T;         /* N   */
+    real* final_T;         /* N   */
     uint32_t* n_contrib;    /* N   */
 } tgs_oracle_state;
 
@@ -152,13 +169,13 @@ void tgs_oracle_free(tgs_oracle_state* s)
 }
 
 /* CR/forward.cu:118-152 */
-static void computeCov3D(const float* scale, float mod, const float* rot, float* cov3D)
+static void computeCov3D(const real* scale, real mod, const real* rot, real* cov3D)
 {
     mat3 S = m3make(1, 0, 0, 0, 1, 0, 0, 0, 1);
     S.m[0][0] = mod * scale[0];
     S.m[1][1] = mod * scale[1];
     S.m[2][2] = mod * scale[2];
-    float r = rot[0], x = rot[1], y = rot[2], z = rot[3]; /* not normalised: forward.cu:127 */
+    real r = rot[0], x = rot[1], y = rot[2], z = rot[3]; /* not normalised: forward.cu:127 */
     mat3 R = m3make(1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
                     2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
                     2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y));
@@ -170,15 +187,15 @@ static void computeCov3D(const float* scale, float mod, const float* rot, float*
 }
 
 /* shared by CR/forward.cu:74-113 and CR/backward.cu:163-198 */
-static void cov2d_common(vec3 mean, float fx, float fy, float tan_fovx, float tan_fovy, const float* cov3D,
-                         const float* vm, vec3* t_out, float* txtz_o, float* tytz_o, mat3* J, mat3* Wm,
+static void cov2d_common(vec3 mean, real fx, real fy, real tan_fovx, real tan_fovy, const real* cov3D,
+                         const real* vm, vec3* t_out, real* txtz_o, real* tytz_o, mat3* J, mat3* Wm,
                          mat3* Vrk, mat3* T, mat3* cov)
 {
     vec3 t = transformPoint4x3(mean, vm);
-    const float limx = 1.3f * tan_fovx;
-    const float limy = 1.3f * tan_fovy;
-    const float txtz = t.x / t.z;
-    const float tytz = t.y / t.z;
+    const real limx = 1.3f * tan_fovx;
+    const real limy = 1.3f * tan_fovy;
+    const real txtz = t.x / t.z;
+    const real tytz = t.y / t.z;
     t.x = fminf_(limx, fmaxf_(-limx, txtz)) * t.z;
     t.y = fminf_(limy, fmaxf_(-limy, tytz)) * t.z;
     *J = m3make(fx / t.z, 0.0f, -(fx * t.x) / (t.z * t.z), 0.0f, fy / t.z, -(fy * t.y) / (t.z * t.z), 0, 0, 0);
@@ -192,20 +209,20 @@ static void cov2d_common(vec3 mean, float fx, float fy, float tan_fovx, float ta
 }
 
 /* CR/forward.cu:20-71 */
-static void colorFromSH(int idx, int deg, int max_coeffs, const float* means, const float* campos,
-                        const float* shs, uint8_t* clamped, float* out)
+static void colorFromSH(int idx, int deg, int max_coeffs, const real* means, const real* campos,
+                        const real* shs, uint8_t* clamped, real* out)
 {
-    float dx = means[3 * idx] - campos[0], dy = means[3 * idx + 1] - campos[1], dz = means[3 * idx + 2] - campos[2];
-    float len = sqrtf(dx * dx + dy * dy + dz * dz);
-    float x = dx / len, y = dy / len, z = dz / len;
-    const float* sh = shs + (size_t)idx * max_coeffs * 3;
+    real dx = means[3 * idx] - campos[0], dy = means[3 * idx + 1] - campos[1], dz = means[3 * idx + 2] - campos[2];
+    real len = r_sqrt(dx * dx + dy * dy + dz * dz);
+    real x = dx / len, y = dy / len, z = dz / len;
+    const real* sh = shs + (size_t)idx * max_coeffs * 3;
     for (int c = 0; c < 3; c++) {
 #define SH(k) sh[3 * (k) + c]
-        float result = SH_C0 * SH(0);
+        real result = SH_C0 * SH(0);
         if (deg > 0) {
             result = result - SH_C1 * y * SH(1) + SH_C1 * z * SH(2) - SH_C1 * x * SH(3);
             if (deg > 1) {
-                float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                real xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
                 result = result + SH_C2[0] * xy * SH(4) + SH_C2[1] * yz * SH(5) +
                          SH_C2[2] * (2.0f * zz - xx - yy) * SH(6) + SH_C2[3] * xz * SH(7) +
                          SH_C2[4] * (xx - yy) * SH(8);
@@ -247,12 +264,12 @@ static uint32_t getHigherMsb(uint32_t n)
  * CR/rasterizer_impl.cu:70-138 (duplicateWithKeys, identifyTileRanges), CR/forward.cu:261-374 (render).
  * Pointers that the reference receives as nullptr (absent inputs) are NULL here.
  */
-tgs_oracle_state* tgs_oracle_forward(int P, int D, int M, const float* background, int W, int H,
-                                     const float* means3D, const float* shs, const float* colors_precomp,
-                                     const float* opacities, const float* scales, float scale_modifier,
-                                     const float* rotations, const float* cov3D_precomp,
-                                     const float* viewmatrix, const float* projmatrix, const float* cam_pos,
-                                     float tan_fovx, float tan_fovy, float* out_color, int* radii_out)
+tgs_oracle_state* tgs_oracle_forward(int P, int D, int M, const real* background, int W, int H,
+                                     const real* means3D, const real* shs, const real* colors_precomp,
+                                     const real* opacities, const real* scales, real scale_modifier,
+                                     const real* rotations, const real* cov3D_precomp,
+                                     const real* viewmatrix, const real* projmatrix, const real* cam_pos,
+                                     real tan_fovx, real tan_fovy, real* out_color, int* radii_out)
 {
     tgs_oracle_state* s = (tgs_oracle_state*)calloc(1, sizeof(*s));
     const size_t N = (size_t)W * H;
@@ -262,44 +279,44 @@ tgs_oracle_state* tgs_oracle_forward(int P, int D, int M, const float* backgroun
     const size_t T = (size_t)s->gx * s->gy;
     s->has_sh = shs != NULL; s->has_colors_precomp = colors_precomp != NULL; s->has_cov_precomp = cov3D_precomp != NULL;
     size_t Pa = P > 0 ? (size_t)P : 1;
-    s->depths = calloc(Pa, 4); s->means2D = calloc(Pa, 8); s->cov3D = calloc(Pa, 24);
-    s->conic_opacity = calloc(Pa, 16); s->rgb = calloc(Pa, 12); s->clamped = calloc(Pa, 3);
+    s->depths = calloc(Pa, RS); s->means2D = calloc(Pa, 2 * RS); s->cov3D = calloc(Pa, 6 * RS);
+    s->conic_opacity = calloc(Pa, 4 * RS); s->rgb = calloc(Pa, 3 * RS); s->clamped = calloc(Pa, 3);
     s->tiles_touched = calloc(Pa, 4); s->point_offsets = calloc(Pa, 4); s->radii = calloc(Pa, 4);
-    s->ranges = calloc(T ? T : 1, 8); s->final_T = calloc(N ? N : 1, 4); s->n_contrib = calloc(N ? N : 1, 4);
+    s->ranges = calloc(T ? T : 1, 8); s->final_T = calloc(N ? N : 1, RS); s->n_contrib = calloc(N ? N : 1, 4);
 
-    const float focal_y = H / (2.0f * tan_fovy); /* rasterizer_impl.cu:222-223 */
-    const float focal_x = W / (2.0f * tan_fovx);
+    const real focal_y = H / (2.0f * tan_fovy); /* rasterizer_impl.cu:222-223 */
+    const real focal_x = W / (2.0f * tan_fovx);
 
     /* ---- preprocessCUDA, forward.cu:155-256 ---- */
     for (int idx = 0; idx < P; idx++) {
         s->radii[idx] = 0; s->tiles_touched[idx] = 0;
         vec3 p_orig = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
         /* in_frustum, auxiliary.h:139-164 */
-        float p_hom[4]; transformPoint4x4(p_orig, projmatrix, p_hom);
-        float p_w = 1.0f / (p_hom[3] + 0.0000001f);
-        float p_proj_x = p_hom[0] * p_w, p_proj_y = p_hom[1] * p_w;
+        real p_hom[4]; transformPoint4x4(p_orig, projmatrix, p_hom);
+        real p_w = 1.0f / (p_hom[3] + 0.0000001f);
+        real p_proj_x = p_hom[0] * p_w, p_proj_y = p_hom[1] * p_w;
         vec3 p_view = transformPoint4x3(p_orig, viewmatrix);
         if (p_view.z <= 0.2f) continue;
 
-        const float* cov3D;
+        const real* cov3D;
         if (cov3D_precomp) cov3D = cov3D_precomp + 6 * (size_t)idx;
         else { computeCov3D(scales + 3 * (size_t)idx, scale_modifier, rotations + 4 * (size_t)idx, s->cov3D + 6 * (size_t)idx); cov3D = s->cov3D + 6 * (size_t)idx; }
 
-        vec3 t; float txtz, tytz; mat3 J, Wm, Vrk, Tm, cov;
+        vec3 t; real txtz, tytz; mat3 J, Wm, Vrk, Tm, cov;
         cov2d_common(p_orig, focal_x, focal_y, tan_fovx, tan_fovy, cov3D, viewmatrix, &t, &txtz, &tytz, &J, &Wm, &Vrk, &Tm, &cov);
         cov.m[0][0] += 0.3f; cov.m[1][1] += 0.3f; /* forward.cu:110-111 */
-        float cx = cov.m[0][0], cy = cov.m[0][1], cz = cov.m[1][1];
+        real cx = cov.m[0][0], cy = cov.m[0][1], cz = cov.m[1][1];
 
-        float det = (cx * cz - cy * cy);
+        real det = (cx * cz - cy * cy);
         if (det == 0.0f) continue;
-        float det_inv = 1.f / det;
-        float conic[3] = {cz * det_inv, -cy * det_inv, cx * det_inv};
+        real det_inv = 1.f / det;
+        real conic[3] = {cz * det_inv, -cy * det_inv, cx * det_inv};
 
-        float mid = 0.5f * (cx + cz);
-        float lambda1 = mid + sqrtf(fmaxf_(0.1f, mid * mid - det));
-        float lambda2 = mid - sqrtf(fmaxf_(0.1f, mid * mid - det));
-        float my_radius = ceilf(3.f * sqrtf(fmaxf_(lambda1, lambda2)));
-        float pix = ndc2Pix(p_proj_x, W), piy = ndc2Pix(p_proj_y, H);
+        real mid = 0.5f * (cx + cz);
+        real lambda1 = mid + r_sqrt(fmaxf_(0.1f, mid * mid - det));
+        real lambda2 = mid - r_sqrt(fmaxf_(0.1f, mid * mid - det));
+        real my_radius = r_ceil(3.f * r_sqrt(fmaxf_(lambda1, lambda2)));
+        real pix = ndc2Pix(p_proj_x, W), piy = ndc2Pix(p_proj_y, H);
         uint32_t rmin[2], rmax[2];
         getRect(pix, piy, (int)my_radius, rmin, rmax, s->gx, s->gy);
         if ((rmax[0] - rmin[0]) * (rmax[1] - rmin[1]) == 0) continue;
@@ -328,7 +345,8 @@ tgs_oracle_state* tgs_oracle_forward(int P, int D, int M, const float* backgroun
         uint32_t off = idx == 0 ? 0 : s->point_offsets[idx - 1];
         uint32_t rmin[2], rmax[2];
         getRect(s->means2D[2 * idx], s->means2D[2 * idx + 1], s->radii[idx], rmin, rmax, s->gx, s->gy);
-        uint32_t dbits; memcpy(&dbits, &s->depths[idx], 4);
+        const float d32 = (float)s->depths[idx]; /* the key holds the fp32 bit pattern of the depth */
+        uint32_t dbits; memcpy(&dbits, &d32, 4);
         for (uint32_t y = rmin[1]; y < rmax[1]; y++)
             for (uint32_t x = rmin[0]; x < rmax[0]; x++) {
                 uint64_t key = (uint64_t)(y * s->gx + x); key <<= 32; key |= dbits;
@@ -352,7 +370,7 @@ tgs_oracle_state* tgs_oracle_forward(int P, int D, int M, const float* backgroun
     }
 
     /* ---- renderCUDA, forward.cu:261-374 ---- */
-    const float* features = colors_precomp ? colors_precomp : s->rgb;
+    const real* features = colors_precomp ? colors_precomp : s->rgb;
     const int gx = (int)s->gx, gy = (int)s->gy;
 #pragma omp parallel for schedule(dynamic, 1) collapse(2)
     for (int ty = 0; ty < gy; ty++)
@@ -363,18 +381,18 @@ tgs_oracle_state* tgs_oracle_forward(int P, int D, int M, const float* backgroun
                     int px = tx * BLOCK_X + lx, py = ty * BLOCK_Y + ly;
                     if (!(px < W && py < H)) continue;
                     size_t pix_id = (size_t)W * py + px;
-                    float pixfx = (float)px, pixfy = (float)py;
-                    float Tr = 1.0f; uint32_t contributor = 0, last_contributor = 0; float C[3] = {0, 0, 0};
+                    real pixfx = (real)px, pixfy = (real)py;
+                    real Tr = 1.0f; uint32_t contributor = 0, last_contributor = 0; real C[3] = {0, 0, 0};
                     for (uint32_t k = r0; k < r1; k++) {
                         contributor++;
                         uint32_t id = s->point_list[k];
-                        float dx = s->means2D[2 * id] - pixfx, dy = s->means2D[2 * id + 1] - pixfy;
-                        const float* co = s->conic_opacity + 4 * (size_t)id;
-                        float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                        real dx = s->means2D[2 * id] - pixfx, dy = s->means2D[2 * id + 1] - pixfy;
+                        const real* co = s->conic_opacity + 4 * (size_t)id;
+                        real power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
                         if (power > 0.0f) continue;
-                        float alpha = fminf_(0.99f, co[3] * expf(power));
+                        real alpha = fminf_(0.99f, co[3] * r_exp(power));
                         if (alpha < 1.0f / 255.0f) continue;
-                        float test_T = Tr * (1 - alpha);
+                        real test_T = Tr * (1 - alpha);
                         if (test_T < 0.0001f) break; /* done = true: later entries never touch this pixel */
                         for (int ch = 0; ch < 3; ch++) C[ch] += features[3 * (size_t)id + ch] * alpha * Tr;
                         Tr = test_T; last_contributor = contributor;
@@ -387,29 +405,29 @@ tgs_oracle_state* tgs_oracle_forward(int P, int D, int M, const float* backgroun
 }
 
 /* CR/backward.cu:20-139 */
-static void colorFromSH_bwd(int idx, int deg, int max_coeffs, const float* means, const float* campos,
-                            const float* shs, const uint8_t* clamped, const float* dL_dcolor, float* dL_dmeans,
-                            float* dL_dshs)
+static void colorFromSH_bwd(int idx, int deg, int max_coeffs, const real* means, const real* campos,
+                            const real* shs, const uint8_t* clamped, const real* dL_dcolor, real* dL_dmeans,
+                            real* dL_dshs)
 {
     vec3 dir_orig = {means[3 * idx] - campos[0], means[3 * idx + 1] - campos[1], means[3 * idx + 2] - campos[2]};
-    float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
-    float x = dir_orig.x / len, y = dir_orig.y / len, z = dir_orig.z / len;
-    const float* sh = shs + (size_t)idx * max_coeffs * 3;
-    float* dL_dsh = dL_dshs + (size_t)idx * max_coeffs * 3;
-    float dRGB[3];
+    real len = r_sqrt(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
+    real x = dir_orig.x / len, y = dir_orig.y / len, z = dir_orig.z / len;
+    const real* sh = shs + (size_t)idx * max_coeffs * 3;
+    real* dL_dsh = dL_dshs + (size_t)idx * max_coeffs * 3;
+    real dRGB[3];
     for (int c = 0; c < 3; c++) dRGB[c] = dL_dcolor[3 * idx + c] * (clamped[3 * idx + c] ? 0.f : 1.f);
-    float ddir[3] = {0, 0, 0};
-    float gx[3] = {0, 0, 0}, gy[3] = {0, 0, 0}, gz[3] = {0, 0, 0}; /* dRGBdx, dRGBdy, dRGBdz */
+    real ddir[3] = {0, 0, 0};
+    real gx[3] = {0, 0, 0}, gy[3] = {0, 0, 0}, gz[3] = {0, 0, 0}; /* dRGBdx, dRGBdy, dRGBdz */
 #define SH(k) sh[3 * (k) + c]
 #define DSH(k, v) for (int c = 0; c < 3; c++) dL_dsh[3 * (k) + c] = (v) * dRGB[c]
     DSH(0, SH_C0);
     if (deg > 0) {
-        float d1 = -SH_C1 * y, d2 = SH_C1 * z, d3 = -SH_C1 * x;
+        real d1 = -SH_C1 * y, d2 = SH_C1 * z, d3 = -SH_C1 * x;
         DSH(1, d1); DSH(2, d2); DSH(3, d3);
         for (int c = 0; c < 3; c++) { gx[c] = -SH_C1 * SH(3); gy[c] = -SH_C1 * SH(1); gz[c] = SH_C1 * SH(2); }
         if (deg > 1) {
-            float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-            float d4 = SH_C2[0] * xy, d5 = SH_C2[1] * yz, d6 = SH_C2[2] * (2.f * zz - xx - yy), d7 = SH_C2[3] * xz, d8 = SH_C2[4] * (xx - yy);
+            real xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            real d4 = SH_C2[0] * xy, d5 = SH_C2[1] * yz, d6 = SH_C2[2] * (2.f * zz - xx - yy), d7 = SH_C2[3] * xz, d8 = SH_C2[4] * (xx - yy);
             DSH(4, d4); DSH(5, d5); DSH(6, d6); DSH(7, d7); DSH(8, d8);
             for (int c = 0; c < 3; c++) {
                 gx[c] += SH_C2[0] * y * SH(4) + SH_C2[2] * 2.f * -x * SH(6) + SH_C2[3] * z * SH(7) + SH_C2[4] * 2.f * x * SH(8);
@@ -417,9 +435,9 @@ static void colorFromSH_bwd(int idx, int deg, int max_coeffs, const float* means
                 gz[c] += SH_C2[1] * y * SH(5) + SH_C2[2] * 2.f * 2.f * z * SH(6) + SH_C2[3] * x * SH(7);
             }
             if (deg > 2) {
-                float d9 = SH_C3[0] * y * (3.f * xx - yy), d10 = SH_C3[1] * xy * z, d11 = SH_C3[2] * y * (4.f * zz - xx - yy);
-                float d12 = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy), d13 = SH_C3[4] * x * (4.f * zz - xx - yy);
-                float d14 = SH_C3[5] * z * (xx - yy), d15 = SH_C3[6] * x * (xx - 3.f * yy);
+                real d9 = SH_C3[0] * y * (3.f * xx - yy), d10 = SH_C3[1] * xy * z, d11 = SH_C3[2] * y * (4.f * zz - xx - yy);
+                real d12 = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy), d13 = SH_C3[4] * x * (4.f * zz - xx - yy);
+                real d14 = SH_C3[5] * z * (xx - yy), d15 = SH_C3[6] * x * (xx - 3.f * yy);
                 DSH(9, d9); DSH(10, d10); DSH(11, d11); DSH(12, d12); DSH(13, d13); DSH(14, d14); DSH(15, d15);
                 for (int c = 0; c < 3; c++) {
                     gx[c] += (SH_C3[0] * SH(9) * 3.f * 2.f * xy + SH_C3[1] * SH(10) * yz + SH_C3[2] * SH(11) * -2.f * xy +
@@ -447,29 +465,29 @@ static void colorFromSH_bwd(int idx, int deg, int max_coeffs, const float* means
 }
 
 /* CR/backward.cu:278-341 */
-static void computeCov3D_bwd(int idx, const float* scale, float mod, const float* rot, const float* dL_dcov3Ds,
-                             float* dL_dscales, float* dL_drots)
+static void computeCov3D_bwd(int idx, const real* scale, real mod, const real* rot, const real* dL_dcov3Ds,
+                             real* dL_dscales, real* dL_drots)
 {
-    float r = rot[0], x = rot[1], y = rot[2], z = rot[3];
+    real r = rot[0], x = rot[1], y = rot[2], z = rot[3];
     mat3 R = m3make(1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
                     2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
                     2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y));
     mat3 S = m3make(1, 0, 0, 0, 1, 0, 0, 0, 1);
-    float sx = mod * scale[0], sy = mod * scale[1], sz = mod * scale[2];
+    real sx = mod * scale[0], sy = mod * scale[1], sz = mod * scale[2];
     S.m[0][0] = sx; S.m[1][1] = sy; S.m[2][2] = sz;
     mat3 Mx = m3mul(&S, &R);
-    const float* d = dL_dcov3Ds + 6 * (size_t)idx;
+    const real* d = dL_dcov3Ds + 6 * (size_t)idx;
     mat3 dSig = m3make(d[0], 0.5f * d[1], 0.5f * d[2], 0.5f * d[1], d[3], 0.5f * d[4], 0.5f * d[2], 0.5f * d[4], d[5]);
     /* dL_dM = 2.0f * M * dL_dSigma : (2.0f * M) first (scalar*mat), then the product */
     mat3 M2; for (int c = 0; c < 3; c++) for (int w = 0; w < 3; w++) M2.m[c][w] = 2.0f * Mx.m[c][w];
     mat3 dM = m3mul(&M2, &dSig);
     mat3 Rt = m3t(&R), dMt = m3t(&dM);
-    float* ds = dL_dscales + 3 * (size_t)idx;
+    real* ds = dL_dscales + 3 * (size_t)idx;
     ds[0] = Rt.m[0][0] * dMt.m[0][0] + Rt.m[0][1] * dMt.m[0][1] + Rt.m[0][2] * dMt.m[0][2];
     ds[1] = Rt.m[1][0] * dMt.m[1][0] + Rt.m[1][1] * dMt.m[1][1] + Rt.m[1][2] * dMt.m[1][2];
     ds[2] = Rt.m[2][0] * dMt.m[2][0] + Rt.m[2][1] * dMt.m[2][1] + Rt.m[2][2] * dMt.m[2][2];
     for (int w = 0; w < 3; w++) { dMt.m[0][w] *= sx; dMt.m[1][w] *= sy; dMt.m[2][w] *= sz; }
-    float* dq = dL_drots + 4 * (size_t)idx;
+    real* dq = dL_drots + 4 * (size_t)idx;
 #define A(c, w) dMt.m[c][w]
     dq[0] = 2 * z * (A(0, 1) - A(1, 0)) + 2 * y * (A(2, 0) - A(0, 2)) + 2 * x * (A(1, 2) - A(2, 1));
     dq[1] = 2 * y * (A(1, 0) + A(0, 1)) + 2 * z * (A(2, 0) + A(0, 2)) + 2 * r * (A(1, 2) - A(2, 1)) - 4 * x * (A(2, 2) + A(1, 1));
@@ -483,24 +501,30 @@ static void computeCov3D_bwd(int idx, const float* scale, float mod, const float
  * preprocessCUDA :346-396.  All outputs must be zero-initialised by the caller exactly as
  * DGR/rasterize_points.cu:151-159 does (torch::zeros); dL_dconic is [P,4], dL_dmean2D is [P,3].
  */
-void tgs_oracle_backward(const tgs_oracle_state* s, const float* background, const float* means3D,
-                         const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
-                         const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
-                         const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy,
-                         const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
-                         float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
-                         float* dL_drot)
+void tgs_oracle_backward(const tgs_oracle_state* s, const real* background, const real* means3D,
+                         const real* shs, const real* colors_precomp, const real* scales, real scale_modifier,
+                         const real* rotations, const real* cov3D_precomp, const real* viewmatrix,
+                         const real* projmatrix, const real* campos, real tan_fovx, real tan_fovy,
+                         const real* dL_dpix, real* dL_dmean2D, real* dL_dconic, real* dL_dopacity,
+                         real* dL_dcolor, real* dL_dmean3D, real* dL_dcov3D, real* dL_dsh, real* dL_dscale,
+                         real* dL_drot)
 {
     const int P = s->P, W = s->W, H = s->H, D = s->D, M = s->M;
     const size_t N = (size_t)W * H;
-    const float focal_y = H / (2.0f * tan_fovy);
-    const float focal_x = W / (2.0f * tan_fovx);
-    const float* colors = colors_precomp ? colors_precomp : s->rgb;
+    const real focal_y = H / (2.0f * tan_fovy);
+    const real focal_x = W / (2.0f * tan_fovx);
+    const real* colors = colors_precomp ? colors_precomp : s->rgb;
     const int gx = (int)s->gx, gy = (int)s->gy;
 
     /* 9 accumulators per Gaussian, double (see header): col3, mean2D xy, conic xyw, opacity */
     double* acc = (double*)calloc((size_t)(P > 0 ? P : 1) * 9, sizeof(double));
-    const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);
+#ifdef TGS_ORACLE_F32_ACCUM
+    /* The reference's own accumulation: fp32 atomicAdd, order undefined (CR/backward.cu:523-554).  Here in a FIXED order so that tests are
+     * reproducible: per (tile, list entry) an fp32 sum over the tile's pixels in pixel order, then per Gaussian an fp32 sum over its
+     * instances in list order.  One more legitimate rounding of the reference's arithmetic (libtgs_oracle_fma.so). */
+    real* part = (real*)calloc((size_t)(s->R > 0 ? s->R : 1) * 9, sizeof(real));
+#endif
+    const real ddelx_dx = (real)(0.5 * W), ddely_dy = (real)(0.5 * H);
 
 #pragma omp parallel for schedule(dynamic, 1) collapse(2)
     for (int ty = 0; ty < gy; ty++)
@@ -511,93 +535,104 @@ void tgs_oracle_backward(const tgs_oracle_state* s, const float* background, con
                     int px = tx * BLOCK_X + lx, py = ty * BLOCK_Y + ly;
                     if (!(px < W && py < H)) continue;
                     size_t pix_id = (size_t)W * py + px;
-                    float pixfx = (float)px, pixfy = (float)py;
-                    const float T_final = s->final_T[pix_id];
-                    float Tr = T_final;
+                    real pixfx = (real)px, pixfy = (real)py;
+                    const real T_final = s->final_T[pix_id];
+                    real Tr = T_final;
                     uint32_t contributor = r1 - r0;
                     const uint32_t last_contributor = s->n_contrib[pix_id];
-                    float accum_rec[3] = {0, 0, 0}, dL_dpixel[3], last_alpha = 0, last_color[3] = {0, 0, 0};
+                    real accum_rec[3] = {0, 0, 0}, dL_dpixel[3], last_alpha = 0, last_color[3] = {0, 0, 0};
                     for (int i = 0; i < 3; i++) dL_dpixel[i] = dL_dpix[i * N + pix_id];
                     for (uint32_t k = r1; k-- > r0;) { /* back to front: backward.cu:472-488 */
                         contributor--;
                         if (contributor >= last_contributor) continue;
                         uint32_t id = s->point_list[k];
-                        float dx = s->means2D[2 * id] - pixfx, dy = s->means2D[2 * id + 1] - pixfy;
-                        const float* co = s->conic_opacity + 4 * (size_t)id;
-                        float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                        real dx = s->means2D[2 * id] - pixfx, dy = s->means2D[2 * id + 1] - pixfy;
+                        const real* co = s->conic_opacity + 4 * (size_t)id;
+                        real power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
                         if (power > 0.0f) continue;
-                        const float G = expf(power);
-                        const float alpha = fminf_(0.99f, co[3] * G);
+                        const real G = r_exp(power);
+                        const real alpha = fminf_(0.99f, co[3] * G);
                         if (alpha < 1.0f / 255.0f) continue;
                         Tr = Tr / (1.f - alpha);
-                        const float dchannel_dcolor = alpha * Tr;
-                        float dL_dalpha = 0.0f;
+                        const real dchannel_dcolor = alpha * Tr;
+                        real dL_dalpha = 0.0f;
+#ifdef TGS_ORACLE_F32_ACCUM
+                        real* a = part + 9 * (size_t)k;
+#define ACC_ADD(j, v) a[j] += (v)
+#else
                         double* a = acc + 9 * (size_t)id;
+#define ACC_ADD(j, v) _Pragma("omp atomic") a[j] += (double)(v)
+#endif
                         for (int ch = 0; ch < 3; ch++) {
-                            const float c = colors[3 * (size_t)id + ch];
+                            const real c = colors[3 * (size_t)id + ch];
                             accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
                             last_color[ch] = c;
-                            const float dL_dchannel = dL_dpixel[ch];
+                            const real dL_dchannel = dL_dpixel[ch];
                             dL_dalpha += (c - accum_rec[ch]) * dL_dchannel;
-                            float v = dchannel_dcolor * dL_dchannel;
-#pragma omp atomic
-                            a[ch] += (double)v;
+                            real v = dchannel_dcolor * dL_dchannel;
+                            ACC_ADD(ch, v);
                         }
                         dL_dalpha *= Tr;
                         last_alpha = alpha;
-                        float bg_dot_dpixel = 0;
+                        real bg_dot_dpixel = 0;
                         for (int i = 0; i < 3; i++) bg_dot_dpixel += background[i] * dL_dpixel[i];
                         dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
-                        const float dL_dG = co[3] * dL_dalpha;
-                        const float gdx = G * dx, gdy = G * dy;
-                        const float dG_ddelx = -gdx * co[0] - gdy * co[1];
-                        const float dG_ddely = -gdy * co[2] - gdx * co[1];
-                        float v3 = dL_dG * dG_ddelx * ddelx_dx, v4 = dL_dG * dG_ddely * ddely_dy;
-                        float v5 = -0.5f * gdx * dx * dL_dG, v6 = -0.5f * gdx * dy * dL_dG, v7 = -0.5f * gdy * dy * dL_dG;
-                        float v8 = G * dL_dalpha;
-#pragma omp atomic
-                        a[3] += (double)v3;
-#pragma omp atomic
-                        a[4] += (double)v4;
-#pragma omp atomic
-                        a[5] += (double)v5;
-#pragma omp atomic
-                        a[6] += (double)v6;
-#pragma omp atomic
-                        a[7] += (double)v7;
-#pragma omp atomic
-                        a[8] += (double)v8;
+                        const real dL_dG = co[3] * dL_dalpha;
+                        const real gdx = G * dx, gdy = G * dy;
+                        const real dG_ddelx = -gdx * co[0] - gdy * co[1];
+                        const real dG_ddely = -gdy * co[2] - gdx * co[1];
+                        real v3 = dL_dG * dG_ddelx * ddelx_dx, v4 = dL_dG * dG_ddely * ddely_dy;
+                        real v5 = -0.5f * gdx * dx * dL_dG, v6 = -0.5f * gdx * dy * dL_dG, v7 = -0.5f * gdy * dy * dL_dG;
+                        real v8 = G * dL_dalpha;
+                        ACC_ADD(3, v3);
+                        ACC_ADD(4, v4);
+                        ACC_ADD(5, v5);
+                        ACC_ADD(6, v6);
+                        ACC_ADD(7, v7);
+                        ACC_ADD(8, v8);
                     }
                 }
         }
+#undef ACC_ADD
+#ifdef TGS_ORACLE_F32_ACCUM
+    {
+        real* acc32 = (real*)calloc((size_t)(P > 0 ? P : 1) * 9, sizeof(real));
+        for (int64_t k = 0; k < s->R; k++) {
+            const uint32_t id = s->point_list[k];
+            for (int j = 0; j < 9; j++) acc32[9 * (size_t)id + j] += part[9 * (size_t)k + j];
+        }
+        for (size_t i = 0; i < (size_t)P * 9; i++) acc[i] = (double)acc32[i];
+        free(acc32); free(part);
+    }
+#endif
     for (int i = 0; i < P; i++) {
         const double* a = acc + 9 * (size_t)i;
-        dL_dcolor[3 * i] += (float)a[0]; dL_dcolor[3 * i + 1] += (float)a[1]; dL_dcolor[3 * i + 2] += (float)a[2];
-        dL_dmean2D[3 * i] += (float)a[3]; dL_dmean2D[3 * i + 1] += (float)a[4];
-        dL_dconic[4 * i] += (float)a[5]; dL_dconic[4 * i + 1] += (float)a[6]; dL_dconic[4 * i + 3] += (float)a[7];
-        dL_dopacity[i] += (float)a[8];
+        dL_dcolor[3 * i] += (real)a[0]; dL_dcolor[3 * i + 1] += (real)a[1]; dL_dcolor[3 * i + 2] += (real)a[2];
+        dL_dmean2D[3 * i] += (real)a[3]; dL_dmean2D[3 * i + 1] += (real)a[4];
+        dL_dconic[4 * i] += (real)a[5]; dL_dconic[4 * i + 1] += (real)a[6]; dL_dconic[4 * i + 3] += (real)a[7];
+        dL_dopacity[i] += (real)a[8];
     }
     free(acc);
 
-    const float* cov3Ds = cov3D_precomp ? cov3D_precomp : s->cov3D;
+    const real* cov3Ds = cov3D_precomp ? cov3D_precomp : s->cov3D;
     /* ---- computeCov2DCUDA, backward.cu:144-274 ---- */
     for (int idx = 0; idx < P; idx++) {
         if (!(s->radii[idx] > 0)) continue;
-        const float* cov3D = cov3Ds + 6 * (size_t)idx;
+        const real* cov3D = cov3Ds + 6 * (size_t)idx;
         vec3 mean = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
-        float dLc[3] = {dL_dconic[4 * idx], dL_dconic[4 * idx + 1], dL_dconic[4 * idx + 3]};
-        vec3 t; float txtz, tytz; mat3 J, Wm, Vrk, T, cov2D;
+        real dLc[3] = {dL_dconic[4 * idx], dL_dconic[4 * idx + 1], dL_dconic[4 * idx + 3]};
+        vec3 t; real txtz, tytz; mat3 J, Wm, Vrk, T, cov2D;
         cov2d_common(mean, focal_x, focal_y, tan_fovx, tan_fovy, cov3D, viewmatrix, &t, &txtz, &tytz, &J, &Wm, &Vrk, &T, &cov2D);
-        const float limx = 1.3f * tan_fovx, limy = 1.3f * tan_fovy;
-        const float x_grad_mul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
-        const float y_grad_mul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
-        float a = cov2D.m[0][0] += 0.3f;
-        float b = cov2D.m[0][1];
-        float c = cov2D.m[1][1] += 0.3f;
-        float denom = a * c - b * b;
-        float dL_da = 0, dL_db = 0, dL_dc = 0;
-        float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
-        float* dcov = dL_dcov3D + 6 * (size_t)idx;
+        const real limx = 1.3f * tan_fovx, limy = 1.3f * tan_fovy;
+        const real x_grad_mul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+        const real y_grad_mul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+        real a = cov2D.m[0][0] += 0.3f;
+        real b = cov2D.m[0][1];
+        real c = cov2D.m[1][1] += 0.3f;
+        real denom = a * c - b * b;
+        real dL_da = 0, dL_db = 0, dL_dc = 0;
+        real denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+        real* dcov = dL_dcov3D + 6 * (size_t)idx;
 #define Tm(c_, r_) T.m[c_][r_]
         if (denom2inv != 0) {
             dL_da = denom2inv * (-c * c * dLc[0] + 2 * b * c * dLc[1] + (denom - a * c) * dLc[2]);
@@ -613,24 +648,24 @@ void tgs_oracle_backward(const tgs_oracle_state* s, const float* background, con
             for (int i = 0; i < 6; i++) dcov[i] = 0;
         }
 #define V(c_, r_) Vrk.m[c_][r_]
-        float dL_dT00 = 2 * (Tm(0, 0) * V(0, 0) + Tm(0, 1) * V(0, 1) + Tm(0, 2) * V(0, 2)) * dL_da + (Tm(1, 0) * V(0, 0) + Tm(1, 1) * V(0, 1) + Tm(1, 2) * V(0, 2)) * dL_db;
-        float dL_dT01 = 2 * (Tm(0, 0) * V(1, 0) + Tm(0, 1) * V(1, 1) + Tm(0, 2) * V(1, 2)) * dL_da + (Tm(1, 0) * V(1, 0) + Tm(1, 1) * V(1, 1) + Tm(1, 2) * V(1, 2)) * dL_db;
-        float dL_dT02 = 2 * (Tm(0, 0) * V(2, 0) + Tm(0, 1) * V(2, 1) + Tm(0, 2) * V(2, 2)) * dL_da + (Tm(1, 0) * V(2, 0) + Tm(1, 1) * V(2, 1) + Tm(1, 2) * V(2, 2)) * dL_db;
-        float dL_dT10 = 2 * (Tm(1, 0) * V(0, 0) + Tm(1, 1) * V(0, 1) + Tm(1, 2) * V(0, 2)) * dL_dc + (Tm(0, 0) * V(0, 0) + Tm(0, 1) * V(0, 1) + Tm(0, 2) * V(0, 2)) * dL_db;
-        float dL_dT11 = 2 * (Tm(1, 0) * V(1, 0) + Tm(1, 1) * V(1, 1) + Tm(1, 2) * V(1, 2)) * dL_dc + (Tm(0, 0) * V(1, 0) + Tm(0, 1) * V(1, 1) + Tm(0, 2) * V(1, 2)) * dL_db;
-        float dL_dT12 = 2 * (Tm(1, 0) * V(2, 0) + Tm(1, 1) * V(2, 1) + Tm(1, 2) * V(2, 2)) * dL_dc + (Tm(0, 0) * V(2, 0) + Tm(0, 1) * V(2, 1) + Tm(0, 2) * V(2, 2)) * dL_db;
+        real dL_dT00 = 2 * (Tm(0, 0) * V(0, 0) + Tm(0, 1) * V(0, 1) + Tm(0, 2) * V(0, 2)) * dL_da + (Tm(1, 0) * V(0, 0) + Tm(1, 1) * V(0, 1) + Tm(1, 2) * V(0, 2)) * dL_db;
+        real dL_dT01 = 2 * (Tm(0, 0) * V(1, 0) + Tm(0, 1) * V(1, 1) + Tm(0, 2) * V(1, 2)) * dL_da + (Tm(1, 0) * V(1, 0) + Tm(1, 1) * V(1, 1) + Tm(1, 2) * V(1, 2)) * dL_db;
+        real dL_dT02 = 2 * (Tm(0, 0) * V(2, 0) + Tm(0, 1) * V(2, 1) + Tm(0, 2) * V(2, 2)) * dL_da + (Tm(1, 0) * V(2, 0) + Tm(1, 1) * V(2, 1) + Tm(1, 2) * V(2, 2)) * dL_db;
+        real dL_dT10 = 2 * (Tm(1, 0) * V(0, 0) + Tm(1, 1) * V(0, 1) + Tm(1, 2) * V(0, 2)) * dL_dc + (Tm(0, 0) * V(0, 0) + Tm(0, 1) * V(0, 1) + Tm(0, 2) * V(0, 2)) * dL_db;
+        real dL_dT11 = 2 * (Tm(1, 0) * V(1, 0) + Tm(1, 1) * V(1, 1) + Tm(1, 2) * V(1, 2)) * dL_dc + (Tm(0, 0) * V(1, 0) + Tm(0, 1) * V(1, 1) + Tm(0, 2) * V(1, 2)) * dL_db;
+        real dL_dT12 = 2 * (Tm(1, 0) * V(2, 0) + Tm(1, 1) * V(2, 1) + Tm(1, 2) * V(2, 2)) * dL_dc + (Tm(0, 0) * V(2, 0) + Tm(0, 1) * V(2, 1) + Tm(0, 2) * V(2, 2)) * dL_db;
 #undef V
 #undef Tm
 #define Wg(c_, r_) Wm.m[c_][r_]
-        float dL_dJ00 = Wg(0, 0) * dL_dT00 + Wg(0, 1) * dL_dT01 + Wg(0, 2) * dL_dT02;
-        float dL_dJ02 = Wg(2, 0) * dL_dT00 + Wg(2, 1) * dL_dT01 + Wg(2, 2) * dL_dT02;
-        float dL_dJ11 = Wg(1, 0) * dL_dT10 + Wg(1, 1) * dL_dT11 + Wg(1, 2) * dL_dT12;
-        float dL_dJ12 = Wg(2, 0) * dL_dT10 + Wg(2, 1) * dL_dT11 + Wg(2, 2) * dL_dT12;
+        real dL_dJ00 = Wg(0, 0) * dL_dT00 + Wg(0, 1) * dL_dT01 + Wg(0, 2) * dL_dT02;
+        real dL_dJ02 = Wg(2, 0) * dL_dT00 + Wg(2, 1) * dL_dT01 + Wg(2, 2) * dL_dT02;
+        real dL_dJ11 = Wg(1, 0) * dL_dT10 + Wg(1, 1) * dL_dT11 + Wg(1, 2) * dL_dT12;
+        real dL_dJ12 = Wg(2, 0) * dL_dT10 + Wg(2, 1) * dL_dT11 + Wg(2, 2) * dL_dT12;
 #undef Wg
-        float tz = 1.f / t.z, tz2 = tz * tz, tz3 = tz2 * tz;
-        float dL_dtx = x_grad_mul * -focal_x * tz2 * dL_dJ02;
-        float dL_dty = y_grad_mul * -focal_y * tz2 * dL_dJ12;
-        float dL_dtz = -focal_x * tz2 * dL_dJ00 - focal_y * tz2 * dL_dJ11 + (2 * focal_x * t.x) * tz3 * dL_dJ02 + (2 * focal_y * t.y) * tz3 * dL_dJ12;
+        real tz = 1.f / t.z, tz2 = tz * tz, tz3 = tz2 * tz;
+        real dL_dtx = x_grad_mul * -focal_x * tz2 * dL_dJ02;
+        real dL_dty = y_grad_mul * -focal_y * tz2 * dL_dJ12;
+        real dL_dtz = -focal_x * tz2 * dL_dJ00 - focal_y * tz2 * dL_dJ11 + (2 * focal_x * t.x) * tz3 * dL_dJ02 + (2 * focal_y * t.y) * tz3 * dL_dJ12;
         vec3 dt = {dL_dtx, dL_dty, dL_dtz};
         vec3 dm = transformVec4x3Transpose(dt, viewmatrix);
         dL_dmean3D[3 * idx] = dm.x; dL_dmean3D[3 * idx + 1] = dm.y; dL_dmean3D[3 * idx + 2] = dm.z; /* assignment, :273 */
@@ -640,21 +675,22 @@ void tgs_oracle_backward(const tgs_oracle_state* s, const float* background, con
     for (int idx = 0; idx < P; idx++) {
         if (!(s->radii[idx] > 0)) continue;
         vec3 m = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
-        const float* proj = projmatrix;
-        float m_hom[4]; transformPoint4x4(m, proj, m_hom);
-        float m_w = 1.0f / (m_hom[3] + 0.0000001f);
-        float mul1 = (proj[0] * m.x + proj[4] * m.y + proj[8] * m.z + proj[12]) * m_w * m_w;
-        float mul2 = (proj[1] * m.x + proj[5] * m.y + proj[9] * m.z + proj[13]) * m_w * m_w;
-        float g2x = dL_dmean2D[3 * idx], g2y = dL_dmean2D[3 * idx + 1];
-        float dmx = (proj[0] * m_w - proj[3] * mul1) * g2x + (proj[1] * m_w - proj[3] * mul2) * g2y;
-        float dmy = (proj[4] * m_w - proj[7] * mul1) * g2x + (proj[5] * m_w - proj[7] * mul2) * g2y;
-        float dmz = (proj[8] * m_w - proj[11] * mul1) * g2x + (proj[9] * m_w - proj[11] * mul2) * g2y;
+        const real* proj = projmatrix;
+        real m_hom[4]; transformPoint4x4(m, proj, m_hom);
+        real m_w = 1.0f / (m_hom[3] + 0.0000001f);
+        real mul1 = (proj[0] * m.x + proj[4] * m.y + proj[8] * m.z + proj[12]) * m_w * m_w;
+        real mul2 = (proj[1] * m.x + proj[5] * m.y + proj[9] * m.z + proj[13]) * m_w * m_w;
+        real g2x = dL_dmean2D[3 * idx], g2y = dL_dmean2D[3 * idx + 1];
+        real dmx = (proj[0] * m_w - proj[3] * mul1) * g2x + (proj[1] * m_w - proj[3] * mul2) * g2y;
+        real dmy = (proj[4] * m_w - proj[7] * mul1) * g2x + (proj[5] * m_w - proj[7] * mul2) * g2y;
+        real dmz = (proj[8] * m_w - proj[11] * mul1) * g2x + (proj[9] * m_w - proj[11] * mul2) * g2y;
         dL_dmean3D[3 * idx] += dmx; dL_dmean3D[3 * idx + 1] += dmy; dL_dmean3D[3 * idx + 2] += dmz;
         if (shs) colorFromSH_bwd(idx, D, M, means3D, campos, shs, s->clamped, dL_dcolor, dL_dmean3D, dL_dsh);
         if (scales) computeCov3D_bwd(idx, scales + 3 * (size_t)idx, scale_modifier, rotations + 4 * (size_t)idx, dL_dcov3D, dL_dscale, dL_drot);
     }
 }
 
+#ifndef TGS_ORACLE_F64
 /*
  * The per-Gaussian half of the backward (computeCov2DCUDA + preprocessCUDA, backward.cu:144-396) evaluated in
  * DOUBLE on the same fp32 inputs (means, stored fp32 cov3D, the fp32 dL_dconic / dL_dmean2D / dL_dcolor of the
@@ -769,8 +805,10 @@ void tgs_oracle_backward_pergauss_f64(const tgs_oracle_state* s, const float* me
     }
 }
 
+#endif /* !TGS_ORACLE_F64 */
+
 /* CR/rasterizer_impl.cu:54-66,141-153 */
-void tgs_oracle_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present)
+void tgs_oracle_mark_visible(int P, const real* means3D, const real* viewmatrix, const real* projmatrix, uint8_t* present)
 {
     (void)projmatrix;
     for (int idx = 0; idx < P; idx++) {

@@ -776,8 +776,8 @@ def test_run_views_at_the_benchmark_configuration(gpu_device):
         off += k
     # ... and against the ORACLE, not only against this library's own per-view path: a two-view batch (views 0 and 5 of the orbit) through
     # the same whole-batch entry points, images and per-view dL/d means2D per view, the accumulated parameter gradients against the SUM of
-    # the oracle's per-view gradients (summed in float64).  The cancellation-prone tensors get the tolerance the single-view comparison
-    # gives them (twice the oracle's own fp32-vs-double error, util.compare), on the sum.
+    # the oracle's per-view gradients (summed in float64).  The bar is util.compare's, on the sum: max(1e-4, 2 x the distance of the
+    # reference's fp32 arithmetic from the same function in double -- here of the summed fp32 results from the summed double results).
     pick = [0, 5]
     refs = [util.oracle_run(util.scene_input(cloud, cams[v]), dL.cpu().numpy()) for v in pick]
     batch2 = SyncFreeBatch()
@@ -796,14 +796,16 @@ def test_run_views_at_the_benchmark_configuration(gpu_device):
         ref_sum = sum(np.asarray(r[key[n]], np.float64).reshape(-1) for r in refs)
         rep[key[n] + "_sum"] = util.rel_l2(flat.flat[off:off + k].cpu().numpy(), ref_sum)
         tol[key[n] + "_sum"] = util.REL_TOL
-        if key[n] in util.NOISY:
-            f64_sum = sum(np.asarray(r["f64_" + key[n]], np.float64).reshape(-1) for r in refs)
+        if rep[key[n] + "_sum"] > util.REL_TOL:
+            for r in refs:
+                util.reference_noise_of(r)
+            f64_sum = sum(np.asarray(r["_f64"][key[n]], np.float64).reshape(-1) for r in refs)
             tol[key[n] + "_sum"] = max(util.REL_TOL, 2.0 * util.rel_l2(ref_sum, f64_sum))
         off += k
     util.record_parity("config4_two_view_batch_vs_oracle_sum", rep)
     print({k: f"{v:.2e}" for k, v in rep.items()})
     for k, v in rep.items():
-        assert v <= util.DIRECT_FACTOR * tol.get(k, util.REL_TOL), (k, v, tol.get(k))
+        assert v <= tol.get(k, util.REL_TOL), (k, v, tol.get(k))
 
 
 def test_speculative_forward_is_the_complete_frame(gpu_device):

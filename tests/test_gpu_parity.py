@@ -348,16 +348,17 @@ def test_hip_vs_independent_fp64_autograd(mode, seed, gpu_device):
         assert v <= util.REL_TOL, (k, v)
 
 
-def test_fuzz_miss_rate_vs_oracle(gpu_device):
-    """The fuzz as a tracked, asserted number (round 2 kept it in a text file): 128 random scenes against the CPU oracle with the direct
-    comparison of the cancellation-prone tensors held to 1 x their tolerance.  A miss is one near-threshold fragment or one needle-shaped
-    splat over the fp32 bar (DESIGN.md section 3); the accurate-math build misses as often.  Measured: 3 of 128 (2.3 %, profiles/parity_r03.json);
-    asserted: at most 5 of 128, so that one more near-threshold scene after a change of summation order does not stop the suite."""
+def test_fuzz_vs_oracle_has_no_miss(gpu_device):
+    """128 random scenes against the CPU oracle at the bar of util.compare -- every tensor within max(1e-4, 2 x the distance of the
+    reference's own fp32 arithmetic from exact arithmetic on that scene, measured with the oracle's C text compiled in double) -- and NO
+    failure budget: zero misses.  (Round 3 asserted "<= 5 of 128" at a blanket tolerance; the three-way adjudication of round 4,
+    profiles/r04_adjudication.txt, showed that in most scenes over 1e-4 the fp32 ORACLE is the side further from exact arithmetic, and
+    the per-Gaussian chain of the HIP path was moved to double where it was not.)"""
     from tests import fuzz
-    res = fuzz.run(seed=2026, n_scenes=128, direct_factor=1.0, log=lambda *a: None)
-    util.record_parity("fuzz_128_scenes_direct_1x", res)
+    res = fuzz.run(seed=2026, n_scenes=128, log=lambda *a: None)
+    util.record_parity("fuzz_128_scenes", res)
     print({k: v for k, v in res.items() if k != "largest_ok"})
-    assert res["misses"] <= 5, res
+    assert res["misses"] == 0, res
 
 
 @pytest.mark.parametrize("P,W,H,deg,mode,scale_mult", [(20_000, 320, 200, 3, "sh", 1.0), (60_000, 500, 333, 1, "precomp", 2.0), (3_000, 100, 60, 2, "sh", 6.0)])

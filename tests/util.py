@@ -61,8 +61,8 @@ def oracle_run(inp: dict, dL: Optional[np.ndarray] = None):
                depths=st.field("depths"), conic_opacity=st.field("conic_opacity").reshape(-1, 4),
                rgb=st.field("rgb").reshape(-1, 3), tiles_touched=st.field("tiles_touched"))
     if dL is not None:
-        out.update(oracle.backward(st, dL, f64_pergauss=True, **kw))
-    out["_st"], out["_kw"] = st, kw
+        out.update(oracle.backward(st, dL, **kw))
+    out["_st"], out["_kw"], out["_dL"], out["_opacities"], out["_sh_degree"] = st, kw, dL, inp["opacities"], int(inp["sh_degree"])
     return out
 
 
@@ -215,12 +215,30 @@ def record_parity(name: str, rep: dict, extra: Optional[dict] = None) -> None:
         pass
 
 
-DIRECT_FACTOR = 1.5     # direct comparison of the cancellation-prone tensors against the oracle: this multiple of their tolerance (round 2: 3)
+def reference_noise_of(ref: dict) -> dict:
+    """{tensor: rel_l2(reference arithmetic in fp32, the same function in double)} of the scene behind an oracle result (tests.util.oracle_run):
+    the larger of the two fp32 builds of oracle/tgs_oracle.c (no FMA contraction + double accumulation / contraction + the reference's fp32
+    accumulation) against the double build.  Computed on demand and cached in ``ref``."""
+    if "_noise" not in ref:
+        from oracle import oracle
+        kw = ref["_kw"]
+        inp = dict(kw, opacities=ref["_opacities"], image_height=ref["n_contrib"].shape[0], image_width=ref["n_contrib"].shape[1], sh_degree=ref["_sh_degree"])
+        outs = {}
+        for variant in ("f64", "f32_fma"):
+            color, _, s2 = oracle.forward(variant=variant, **inp)
+            outs[variant] = dict(oracle.backward(s2, ref["_dL"], **kw), color=color)
+        f64 = outs["f64"]
+        ref["_noise"] = {k: max(rel_l2(ref[k], f64[k]), rel_l2(outs["f32_fma"][k], f64[k])) for k in ("color", "dL_dconic") + GRAD_KEYS if k in ref and k in f64}
+        ref["_f64"] = f64
+    return ref["_noise"]
 
 
-def compare(mine: dict, ref: dict, golden_out: Optional[dict] = None, nc_frac: float = 0.999, check_lists: bool = True,
-            direct_factor: float = DIRECT_FACTOR):
-    """Asserts the SURVEY.md section 8d parity bar; returns {tensor: rel_l2} for reporting."""
+def compare(mine: dict, ref: dict, golden_out: Optional[dict] = None, nc_frac: float = 0.999, check_lists: bool = True):
+    """Asserts the parity bar; returns {tensor: rel_l2} for reporting.
+
+    The bar (round 4, no failure budget anywhere):  rel_l2(HIP, reference fp32) <= max(1e-4, 2 x the reference arithmetic's own distance from
+    exact arithmetic)  for the colour and every gradient.  Against the ORACLE that distance is measured on the very scene, on demand
+    (reference_noise_of: the oracle's C text compiled in double); against a FIXTURE it is what the fixture recorded (tolerance())."""
     H, W = ref["n_contrib"].shape
     rep = {}
     assert int(mine["num_rendered"]) <= int(ref["num_rendered"]), "more instances than the reference"   # exact relation: check_point_lists
@@ -234,35 +252,32 @@ def compare(mine: dict, ref: dict, golden_out: Optional[dict] = None, nc_frac: f
         frac = float((last_contributor_ids(mine) == last_contributor_ids(ref)).mean())
         rep["n_contrib_equal"] = frac
         assert frac >= nc_frac, f"last contributor equal on {frac:.5f} of pixels"
+    against_oracle = "_st" in ref
+
+    def bar(k: str) -> float:
+        if against_oracle:
+            return max(REL_TOL, 2.0 * reference_noise_of(ref).get(k, 0.0))
+        return tolerance(k, golden_out)
+
     e = rel_l2(mine["color"], ref["color"]); rep["color"] = e
-    assert e <= REL_TOL, f"color rel-L2 {e:.3e}"
-    # Against the oracle (not a fixture) the cancellation-prone tensors are checked in two steps, because the map
-    # dL_dconic -> dL_dcov3D/scales/rotations amplifies last-bit differences of its INPUT (the reference suffers the
-    # same from its atomics order): (1) the render-pass gradients themselves, (2) the per-Gaussian half evaluated in
-    # double on the kernel's OWN render-pass gradients.
-    split = "_st" in ref and "dL_dconic" in mine
-    pg = None
-    if split:
-        from oracle import oracle
-        e = rel_l2(np.asarray(mine["dL_dconic"]).reshape(-1, 4), ref["dL_dconic"]); rep["dL_dconic"] = e
-        assert e <= REL_TOL, f"dL_dconic rel-L2 {e:.3e}"
-        pg = oracle.pergauss_f64(ref["_st"], mine["dL_dmeans2D"], mine["dL_dconic"], mine["dL_dcolors"], **ref["_kw"])
-    for k in GRAD_KEYS:
+    assert e <= REL_TOL or e <= bar("color"), f"color rel-L2 {e:.3e}"
+    keys = GRAD_KEYS + (("dL_dconic",) if against_oracle and "dL_dconic" in mine else ())
+    for k in keys:
         if k in mine and k in ref:
             a, b = np.asarray(mine[k]), np.asarray(ref[k])
             if k == "dL_dmeans2D":
                 assert np.all(a[:, 2] == 0)
+            if k == "dL_dconic":
+                a = a.reshape(-1, 4)
             e = rel_l2(a, b); rep[k] = e
-            tol = tolerance(k, golden_out)
-            if k in NOISY and ("f64_" + k) in ref:   # the oracle's own fp32 rounding noise on these formulas
-                tol = max(tol, 2.0 * rel_l2(ref[k], ref["f64_" + k]))
-            if split and k in NOISY:
-                e2 = rel_l2(a, pg[k]); rep[k + "|own_inputs"] = e2
-                assert e2 <= tol, f"{k} (per-Gaussian half on own inputs) rel-L2 {e2:.3e} > {tol:.1e}"
-                assert e <= direct_factor * tol, f"{k} rel-L2 {e:.3e} (direct comparison, bound {direct_factor * tol:.1e})"
-            else:
-                assert e <= tol, f"{k} rel-L2 {e:.3e} > {tol:.1e}"
-            assert np.all(a[~vis] == 0), f"{k}: culled Gaussians must have zero gradient"
+            if e > REL_TOL:                                  # only then is the scene's own noise floor needed (two more oracle runs)
+                tol = bar(k)
+                rep[k + "|bar"] = tol
+                if against_oracle:
+                    rep[k + "|vs_f64"] = rel_l2(a, ref["_f64"][k])
+                assert e <= tol, f"{k} rel-L2 {e:.3e} > {tol:.2e} = max(1e-4, 2 x reference-vs-exact)" + (f"; HIP vs exact {rep[k + '|vs_f64']:.2e}" if against_oracle else "")
+            if k != "dL_dconic":
+                assert np.all(a[~vis] == 0), f"{k}: culled Gaussians must have zero gradient"
     return rep
 
 

@@ -96,3 +96,77 @@ def gaussian_bind(all_densities: Optional[torch.Tensor] = None, raw_scales: Opti
     if all(t is None for t in (all_densities, raw_scales, raw_quaternions, ori_points)):
         raise ValueError("gaussian_bind: nothing to do")
     return _Bind.apply(all_densities, raw_scales, raw_quaternions, ori_points, normals, offsets)
+
+
+# ---- the two-group models of the editing stages -------------------------------------------------------------------------------------------
+_lib.tgs_bind_groups_forward.restype = C.c_int
+_lib.tgs_bind_groups_forward.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 15
+_lib.tgs_bind_groups_backward.restype = C.c_int
+_lib.tgs_bind_groups_backward.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 13
+
+
+class _BindGroups(torch.autograd.Function):
+    """inputs: keep (density, scales, quats, points) -- frozen --, edit (density, scales, quats, points | ori, normals, offsets)"""
+
+    @staticmethod
+    def forward(ctx, kd, ks, kq, kp, ed, es, eq, ep, eo, en, eoff):
+        dev = kd.device
+        Pk, Pe = int(kd.shape[0]), int(ed.shape[0])
+        kd, ks, kq, kp = _f32(kd, "all_keep_densities", 1, Pk, dev), _f32(ks, "_keep_scales", 3, Pk, dev), _f32(kq, "_keep_quaternions", 4, Pk, dev), _f32(kp, "_keep_points", 3, Pk, dev)
+        ed, es, eq = _f32(ed, "all_edit_densities", 1, Pe, dev), _f32(es, "_edit_scales", 3, Pe, dev), _f32(eq, "_edit_quaternions", 4, Pe, dev)
+        ep = _f32(ep, "_edit_points", 3, Pe, dev)
+        eo, en, eoff = _f32(eo, "ori_edit_points", 3, Pe, dev), _f32(en, "_edit_normals", 3, Pe, dev), _f32(eoff, "_edit_points (offsets)", 1, Pe, dev)
+        P = Pk + Pe
+        new = lambda cols: torch.empty((P, cols), dtype=torch.float32, device=dev)
+        opacity, scales, quats, points = new(1), new(3), new(4), new(3)
+        with torch.cuda.device(dev):
+            r = _lib.tgs_bind_groups_forward(torch.cuda.current_stream(dev).cuda_stream, Pk, Pe, _p(kd), _p(ks), _p(kq), _p(kp), _p(ed), _p(es), _p(eq), _p(ep),
+                                             _p(eo), _p(en), _p(eoff), _p(opacity), _p(scales), _p(quats), _p(points))
+        if r < 0:
+            raise _rast_c._err(r)
+        e = torch.Tensor([])
+        ctx.save_for_backward(eq, en if en is not None else e, opacity, scales)
+        ctx.sizes = (Pk, Pe)
+        return opacity, scales, quats, points
+
+    @staticmethod
+    def backward(ctx, g_opacity, g_scales, g_quats, g_points):
+        eq, en, opacity, scales = ctx.saved_tensors
+        en = en if en.numel() else None
+        Pk, Pe = ctx.sizes
+        dev = eq.device
+        need = ctx.needs_input_grad            # (kd, ks, kq, kp, ed, es, eq, ep, eo, en, eoff)
+        c = lambda g: None if g is None else g.contiguous()
+        g_opacity, g_scales, g_quats, g_points = c(g_opacity), c(g_scales), c(g_quats), c(g_points)
+        mk = lambda on, cols, g: torch.empty((Pe, cols), dtype=torch.float32, device=dev) if (on and g is not None) else None
+        d_d, d_s, d_q = mk(need[4], 1, g_opacity), mk(need[5], 3, g_scales), mk(need[6], 4, g_quats)
+        d_p, d_off = mk(need[7], 3, g_points), mk(need[10], 1, g_points)
+        if any(t is not None for t in (d_d, d_s, d_q, d_p, d_off)):
+            with torch.cuda.device(dev):
+                r = _lib.tgs_bind_groups_backward(torch.cuda.current_stream(dev).cuda_stream, Pk, Pe, _p(eq), _p(en), _p(opacity), _p(scales), _p(g_opacity), _p(g_scales),
+                                                  _p(g_quats), _p(g_points), _p(d_d), _p(d_s), _p(d_q), _p(d_p), _p(d_off))
+            if r < 0:
+                raise _rast_c._err(r)
+        # the keep group is frozen (requires_grad=False, tetgs_edit_2d.py:237-262); ori_edit_points / _edit_normals are buffers (tetgs_edit_3d.py:121-136)
+        return None, None, None, None, d_d, d_s, d_q, d_p, None, None, d_off
+
+
+def gaussian_bind_groups(*, keep_points: torch.Tensor, keep_densities: torch.Tensor, keep_scales: torch.Tensor, keep_quaternions: torch.Tensor,
+                         edit_densities: torch.Tensor, edit_scales: torch.Tensor, edit_quaternions: torch.Tensor,
+                         edit_points: Optional[torch.Tensor] = None, ori_edit_points: Optional[torch.Tensor] = None,
+                         edit_normals: Optional[torch.Tensor] = None, edit_offsets: Optional[torch.Tensor] = None
+                         ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """(strengths [Pk+Pe,1], scaling [Pk+Pe,3], quaternions [Pk+Pe,4], points [Pk+Pe,3]) of ``EditTetGS`` (tetgs_edit_2d.py:280-318:
+    ``edit_points`` [Pe,3]) and ``Edit3DTetGS`` (tetgs_edit_3d.py:272-331: ``ori_edit_points`` + ``edit_normals`` * ``edit_offsets`` [Pe,1]) --
+    the properties those classes build with ``torch.cat([keep, edit])`` + activation on every access -- in one kernel, keep rows first.
+    Differentiable with respect to the edit group only: the keep group is frozen in the reference (``requires_grad=False``); a keep
+    tensor that requires a gradient is an error here rather than a silently missing gradient."""
+    for name, t in (("keep_points", keep_points), ("keep_densities", keep_densities), ("keep_scales", keep_scales), ("keep_quaternions", keep_quaternions)):
+        if t.requires_grad:
+            raise RuntimeError(f"gaussian_bind_groups: {name} requires a gradient, but the keep group is frozen (tetgs_edit_2d.py:237-262); "
+                               "bind a learnable group with gaussian_bind")
+    plain, bound = edit_points is not None, any(t is not None for t in (ori_edit_points, edit_normals, edit_offsets))
+    if plain == bound or (bound and any(t is None for t in (ori_edit_points, edit_normals, edit_offsets))):
+        raise ValueError("gaussian_bind_groups: give either edit_points [Pe,3], or ori_edit_points + edit_normals + edit_offsets")
+    return _BindGroups.apply(keep_densities, keep_scales, keep_quaternions, keep_points, edit_densities, edit_scales, edit_quaternions, edit_points,
+                             ori_edit_points, edit_normals, edit_offsets)

@@ -36,17 +36,18 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found (need ROCm; set HIPCC=/path/to/hipcc)")
 
 
-def _stale() -> bool:
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "tgs_raster.h")]
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+HASH_FILE = os.path.join(LIBDIR, ".source_hash")            # the hash of the sources the library next to it was built from
+
+
+def _sources_present() -> bool:
+    return os.path.isdir(CSRC) and os.path.exists(os.path.join(HERE, "..", "include", "tgs_raster.h"))
 
 
 def source_hash() -> str:
-    """sha256 (first 16 hex digits) over the kernel / ABI sources: profiles/*_counters.json carry it, and bench.py only quotes counter figures
-    (instructions, HBM traffic per launch) whose hash equals the sources it is running."""
+    """sha256 (first 16 hex digits) over the kernel / ABI sources and the compile flags: profiles/*_counters.json carry it, and bench.py only
+    quotes counter figures (instructions, HBM traffic per launch) whose hash equals the sources it is running; the build stores it next to
+    the library, and a library whose stored hash differs from the sources is STALE whatever its mtime says (a copy to another machine keeps
+    no meaningful mtimes)."""
     import hashlib
     h = hashlib.sha256()
     files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".cpp"))) 
@@ -54,6 +55,27 @@ def source_hash() -> str:
         h.update(f.encode()); h.update(open(os.path.join(CSRC, f), "rb").read())
     h.update(open(os.path.join(HERE, "..", "include", "tgs_raster.h"), "rb").read())
     return h.hexdigest()[:16]
+
+
+def _stored_hash(path: str):
+    try:
+        return open(path).read().split()
+    except OSError:
+        return []
+
+
+def _hash_line() -> list:
+    return [source_hash(), " ".join(FLAGS).replace(" ", "|")]
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    if not _sources_present():                   # a binary-only install (wheel): nothing to compare with, nothing to rebuild from
+        return False
+    if os.path.basename(LIB) != "libtgs_raster.so":
+        return False                             # a named variant (TGS_LIB_NAME) is rebuilt on request only
+    return _stored_hash(HASH_FILE) != _hash_line()
 
 
 class _BuildLock:
@@ -107,12 +129,16 @@ def _build_native_locked(verbose: bool) -> str:
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
     os.replace(tmp, LIB)                                    # atomic: a process that is loading the old file keeps its mapping
+    if os.path.basename(LIB) == "libtgs_raster.so":
+        with open(HASH_FILE, "w") as f:
+            f.write(" ".join(_hash_line()) + "\n")
     return LIB
 
 
 EXT_SRC = os.path.join(CSRC, "tgs_torch_ext.cpp")
 EXT_NAME = "_Cext"
 EXT_DIR = os.path.join(HERE, "diff_gaussian_rasterization")
+EXT_HASH_FILE = os.path.join(EXT_DIR, ".source_hash")
 
 
 def ext_path() -> str:
@@ -126,8 +152,7 @@ def build_torch_ext(force: bool = False, verbose: bool = False) -> str:
     CUDAExtension recipe (setup.py:17-34) without hipify."""
     lib = build_native(force=force, verbose=verbose)
     out = ext_path()
-    deps = [EXT_SRC, os.path.join(HERE, "..", "include", "tgs_raster.h")]
-    fresh = lambda: os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps)
+    fresh = lambda: os.path.exists(out) and (not _sources_present() or _stored_hash(EXT_HASH_FILE) == _hash_line())
     if not force and fresh():
         return out
     with _BuildLock():
@@ -159,6 +184,8 @@ def _build_torch_ext_locked(lib: str, out: str, verbose: bool) -> str:
     if r.returncode != 0:
         raise RuntimeError(f"building {EXT_NAME} failed:\n{r.stdout}\n{r.stderr}")
     os.replace(out + f".tmp{os.getpid()}", out)
+    with open(EXT_HASH_FILE, "w") as f:
+        f.write(" ".join(_hash_line()) + "\n")
     return out
 
 

@@ -25,6 +25,21 @@ __device__ __forceinline__ void check_tile_bound(const ImgState& s)
     if (blockIdx.x == 0 && threadIdx.x == 0 && s.meta->n_nonempty > gridDim.x) atomicOr(&s.meta->error, META_ERR_TILE_BOUND);
 }
 
+// A tile's share of dL_dconic (one of xx, xy, yy) = -0.5 * opacity * (the f64 LDS sum of w d d over the tile's pixels), stored in the slab
+// row as hi + lo (two floats: the row's padding holds the three lo parts -- no extra byte moves).  dL_dconic is the one input of the
+// per-Gaussian chain that chain amplifies (a needle-shaped splat: x 1e2 .. 1e4 into dL_dcov3D / dL_dscale / dL_drot); with fp32 rows
+// and an fp32 sum over a splat's tiles the HIP path sat 1e-4 from exact arithmetic on such splats -- as far as the reference's own
+// fp32 atomics, but not the same way.  hi + lo rows summed in double (slab_sum) leave the per-pixel fp32 products as the only rounding.
+struct ConicHiLo { float hi, lo; };
+__device__ __forceinline__ ConicHiLo conic_hilo(float op, double sum)
+{
+    const double t = -0.5 * (double)op * sum;
+    ConicHiLo r;
+    r.hi = (float)t;
+    r.lo = (float)(t - (double)r.hi);
+    return r;
+}
+
 __global__ __launch_bounds__(256) void k_render_bwd_det(const ImgState s, const BinState b, int W, int H, uint32_t gx,
                                                     const float* __restrict__ bg, const float* __restrict__ dL_dpix)
 {
@@ -172,6 +187,7 @@ __global__ __launch_bounds__(256) void k_render_bwd_det(const ImgState s, const 
         if (threadIdx.x < cnt) {
             const uint32_t j = threadIdx.x;
             float r[NACC];
+            double rc[3] = {0.0, 0.0, 0.0};                  // the conic sums: hi + lo (slab row layout, tgs_device.hpp)
 #pragma unroll
             for (int k = 0; k < NACC; k++) r[k] = 0.f;
 #pragma unroll
@@ -179,10 +195,15 @@ __global__ __launch_bounds__(256) void k_render_bwd_det(const ImgState s, const 
                 if ((touched[w][j >> 6] >> (j & 63)) & 1ull) {
 #pragma unroll
                     for (int k = 0; k < NACC; k++) r[k] += wacc[w][k][j];
+#pragma unroll
+                    for (int k = 0; k < 3; k++) rc[k] += (double)wacc[w][5 + k][j];
                 }
             }
+            float lo[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) { r[5 + k] = (float)rc[k]; lo[k] = (float)(rc[k] - (double)r[5 + k]); }
             float4* row = b.slab + (size_t)sSlot[j] * SLAB_ROW;
-            row[0] = make_float4(r[0], r[1], r[2], r[3]); row[1] = make_float4(r[4], r[5], r[6], r[7]); row[2] = make_float4(r[8], 0.f, 0.f, 0.f);
+            row[0] = make_float4(r[0], r[1], r[2], r[3]); row[1] = make_float4(r[4], r[5], r[6], r[7]); row[2] = make_float4(r[8], lo[0], lo[1], lo[2]);
         }
     }
     stamp(s, tile, 3);
@@ -345,8 +366,9 @@ __device__ __forceinline__ void bwd_light_group(const ImgState& s, const BinStat
         const float Sx = (float)acc[3][j], Sy = (float)acc[4][j];
         float4* row = b.slab + (size_t)sSlot[j] * SLAB_ROW;
         row[0] = make_float4((float)acc[0][j], (float)acc[1][j], (float)acc[2][j], op * (-Sx * cxx - Sy * cxy) * ddelx_dx);
-        row[1] = make_float4(op * (-Sy * cyy - Sx * cxy) * ddely_dy, -0.5f * op * (float)acc[5][j], -0.5f * op * (float)acc[6][j], -0.5f * op * (float)acc[7][j]);
-        row[2] = make_float4((float)acc[8][j], 0.f, 0.f, 0.f);
+        const ConicHiLo c5 = conic_hilo(op, acc[5][j]), c6 = conic_hilo(op, acc[6][j]), c7 = conic_hilo(op, acc[7][j]);
+        row[1] = make_float4(op * (-Sy * cyy - Sx * cxy) * ddely_dy, c5.hi, c6.hi, c7.hi);
+        row[2] = make_float4((float)acc[8][j], c5.lo, c6.lo, c7.lo);
     }
     stamp_if(s, tile, 3, active && lt == 0);
 }
@@ -531,8 +553,9 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
             const float Sx = (float)acc[3][j], Sy = (float)acc[4][j];
             float4* row = b.slab + (size_t)sSlot[rnd][j] * SLAB_ROW;
             row[0] = make_float4((float)acc[0][j], (float)acc[1][j], (float)acc[2][j], op * (-Sx * cxx - Sy * cxy) * ddelx_dx);
-            row[1] = make_float4(op * (-Sy * cyy - Sx * cxy) * ddely_dy, -0.5f * op * (float)acc[5][j], -0.5f * op * (float)acc[6][j], -0.5f * op * (float)acc[7][j]);
-            row[2] = make_float4((float)acc[8][j], 0.f, 0.f, 0.f);
+            const ConicHiLo c5 = conic_hilo(op, acc[5][j]), c6 = conic_hilo(op, acc[6][j]), c7 = conic_hilo(op, acc[7][j]);
+            row[1] = make_float4(op * (-Sy * cyy - Sx * cxy) * ddely_dy, c5.hi, c6.hi, c7.hi);
+            row[2] = make_float4((float)acc[8][j], c5.lo, c6.lo, c7.lo);
 #pragma unroll
             for (int k = 0; k < NACC; k++) acc[k][j] = 0.0;
         }
@@ -559,35 +582,49 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
 // and the nine totals are formed with wave_sum.  Fixed order either way.  Call from convergent code.
 constexpr uint32_t SLAB_COOP = 128;
 // (tiles, off): the Gaussian's tiles_touched and offsets of this view, fetched by the caller
-__device__ __forceinline__ void slab_sum(bool live, uint32_t tiles_in, uint32_t off_in, const BinState& b, float (&a)[NACC])
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// cn[0..2]: the conic sums (xx, xy, yy) in double from the rows' hi + lo parts (conic_hilo); a[5..7] are their fp32 roundings
+__device__ __forceinline__ void slab_sum(bool live, uint32_t tiles_in, uint32_t off_in, const BinState& b, float (&a)[NACC], double (&cn)[3])
 {
     const int lane = threadIdx.x & 63;
     const uint32_t tiles = live ? tiles_in : 0u, off = live ? off_in : 0u;
 #pragma unroll
     for (int c = 0; c < NACC; c++) a[c] = 0.f;
+    cn[0] = cn[1] = cn[2] = 0.0;
     unsigned long long big = __builtin_amdgcn_ballot_w64(tiles >= SLAB_COOP);
     while (big) {
         const int src = __builtin_ctzll(big);
         big &= big - 1;
         const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)tiles, src), o = (uint32_t)__builtin_amdgcn_readlane((int)off, src);
         float p[NACC];
+        double pc[3] = {0.0, 0.0, 0.0};
 #pragma unroll
         for (int c = 0; c < NACC; c++) p[c] = 0.f;
         for (uint32_t k = lane; k < n; k += 64) {
             const float4* row = b.slab + (size_t)(o + k) * SLAB_ROW;
             const float4 r0 = row[0], r1 = row[1], r2 = row[2];
-            p[0] += r0.x; p[1] += r0.y; p[2] += r0.z; p[3] += r0.w; p[4] += r1.x; p[5] += r1.y; p[6] += r1.z; p[7] += r1.w; p[8] += r2.x;
+            p[0] += r0.x; p[1] += r0.y; p[2] += r0.z; p[3] += r0.w; p[4] += r1.x; p[8] += r2.x;
+            pc[0] += (double)r1.y + (double)r2.y; pc[1] += (double)r1.z + (double)r2.z; pc[2] += (double)r1.w + (double)r2.w;
         }
 #pragma unroll
-        for (int c = 0; c < NACC; c++) { const float tot = wave_sum(p[c]); if (lane == src) a[c] = tot; }
+        for (int c = 0; c < NACC; c++) { if (c >= 5 && c <= 7) continue; const float tot = wave_sum(p[c]); if (lane == src) a[c] = tot; }
+#pragma unroll
+        for (int c = 0; c < 3; c++) { const double tot = wave_sum_f64(pc[c]); if (lane == src) cn[c] = tot; }
     }
     if (tiles < SLAB_COOP) {
         const float4* row = b.slab + (size_t)off * SLAB_ROW;
         for (uint32_t k = 0; k < tiles; k++, row += SLAB_ROW) {
             const float4 r0 = row[0], r1 = row[1], r2 = row[2];
-            a[0] += r0.x; a[1] += r0.y; a[2] += r0.z; a[3] += r0.w; a[4] += r1.x; a[5] += r1.y; a[6] += r1.z; a[7] += r1.w; a[8] += r2.x;
+            a[0] += r0.x; a[1] += r0.y; a[2] += r0.z; a[3] += r0.w; a[4] += r1.x; a[8] += r2.x;
+            cn[0] += (double)r1.y + (double)r2.y; cn[1] += (double)r1.z + (double)r2.z; cn[2] += (double)r1.w + (double)r2.w;
         }
     }
+    a[5] = (float)cn[0]; a[6] = (float)cn[1]; a[7] = (float)cn[2];
 }
 
 // computeColorFromSH backward (backward.cu:20-139) of one Gaussian in one view: from the summed colour gradient rgb[0..2] and the clamp
@@ -649,6 +686,130 @@ __device__ __forceinline__ void sh_backward_terms(int D, const ShRow& sh, uint32
     dmean[2] += (-ox * oz * ddx - oy * oz * ddy + (sum2 - oz * oz) * ddz) * invsum32;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The per-Gaussian chain dL_dconic, dL_dmean2D -> dL_dcov3D, dL_dmean3D, dL_dscale, dL_drot (computeCov2DCUDA backward.cu:144-274, the
+// projection part of preprocessCUDA :369-387, computeCov3D :278-341) in DOUBLE (round 4).
+// These are the formulas whose fp32 evaluation cancels -- (denom - a c), T T^T differences, the quaternion derivative of a needle -- and
+// the three-way adjudication of round 4 (tests/adjudicate.py: HIP / fp32 oracle / the oracle's text in double) showed the fp32 version of
+// this chain further from exact arithmetic than the reference's on 3 of 896 fuzz scenes (one needle-shaped splat each, e.g. dL_dcov3D
+// 2.3e-4 against the reference's 2.8e-5).  gfx950 issues f64 FMA at half the f32 rate and the kernels around this are HBM-bound: ~400
+// double operations per Gaussian and view are invisible in time (measured: DESIGN.md section 3), and the result is the reference's
+// FUNCTION evaluated on the fp32 inputs to < 1e-12, rounded once.  TGS_PERGAUSS_F64=0 restores the fp32 restatement for A/B.
+// ---------------------------------------------------------------------------------------------
+#ifndef TGS_PERGAUSS_F64
+#define TGS_PERGAUSS_F64 1
+#endif
+
+template <bool HAS_SCALE_ROT>
+__device__ __forceinline__ void cov_chain_bwd_f64(float mxf, float myf, float mzf, const float (&cov3d)[6], const CamParams& cam, const ViewMat& V, const ViewMat& PM,
+                                                  const double (&dLconic)[3], float g2xf, float g2yf, const float* __restrict__ scales3,
+                                                  const float* __restrict__ rot4, float (&dmean)[3], float (&dcov)[6], float (&dscale)[3], float (&drot)[4])
+{
+    typedef double R;
+    const R mx = mxf, my = myf, mz = mzf;
+    const float* vm = V.m;
+    R tx = (R)vm[0] * mx + (R)vm[4] * my + (R)vm[8] * mz + (R)vm[12];
+    R ty = (R)vm[1] * mx + (R)vm[5] * my + (R)vm[9] * mz + (R)vm[13];
+    const R tz = (R)vm[2] * mx + (R)vm[6] * my + (R)vm[10] * mz + (R)vm[14];
+    const R limx = (R)(1.3f * cam.tan_fovx), limy = (R)(1.3f * cam.tan_fovy);
+    const R txtz = tx / tz, tytz = ty / tz;
+    tx = fmin(limx, fmax(-limx, txtz)) * tz;
+    ty = fmin(limy, fmax(-limy, tytz)) * tz;
+    const R xg = (txtz < -limx || txtz > limx) ? 0.0 : 1.0, yg = (tytz < -limy || tytz > limy) ? 0.0 : 1.0;
+    const R fx = cam.focal_x, fy = cam.focal_y;
+    const R iz = 1.0 / tz, iz2 = iz * iz, iz3 = iz2 * iz;
+    // J (rows): [fx/tz, 0, -fx tx/tz^2], [0, fy/tz, -fy ty/tz^2];  T = W J in GLM terms: T.m[c][r] of the fp32 code.  Written out:
+    // t0[k] = T.m[0][k], t1[k] = T.m[1][k]  (k = 0..2): the two rows of J applied to the columns of the view rotation
+    const R j00 = fx * iz, j02 = -(fx * tx) * iz2, j11 = fy * iz, j12 = -(fy * ty) * iz2;
+    const R w[3][3] = {{vm[0], vm[4], vm[8]}, {vm[1], vm[5], vm[9]}, {vm[2], vm[6], vm[10]}};     // W.m[c][r] of compute_cov2d
+    R t0[3], t1[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { t0[k] = w[0][k] * j00 + w[2][k] * j02; t1[k] = w[1][k] * j11 + w[2][k] * j12; }
+    const R v[3][3] = {{cov3d[0], cov3d[1], cov3d[2]}, {cov3d[1], cov3d[3], cov3d[4]}, {cov3d[2], cov3d[4], cov3d[5]}};
+    R r0[3], r1[3];                                        // V t0, V t1
+#pragma unroll
+    for (int k = 0; k < 3; k++) { r0[k] = v[k][0] * t0[0] + v[k][1] * t0[1] + v[k][2] * t0[2]; r1[k] = v[k][0] * t1[0] + v[k][1] * t1[1] + v[k][2] * t1[2]; }
+    const R ca = t0[0] * r0[0] + t0[1] * r0[1] + t0[2] * r0[2] + (R)0.3f;
+    const R cb = t0[0] * r1[0] + t0[1] * r1[1] + t0[2] * r1[2];
+    const R cc = t1[0] * r1[0] + t1[1] * r1[1] + t1[2] * r1[2] + (R)0.3f;
+    const R g0 = dLconic[0], g1 = dLconic[1], g2 = dLconic[2];
+    const R denom = ca * cc - cb * cb;
+    const R d2i = 1.0 / (denom * denom + (R)0.0000001f);
+    R dLa = 0, dLb = 0, dLc = 0, dc[6] = {0, 0, 0, 0, 0, 0};
+    if (d2i != 0) {
+        dLa = d2i * (-cc * cc * g0 + 2 * cb * cc * g1 + (denom - ca * cc) * g2);
+        dLc = d2i * (-ca * ca * g2 + 2 * ca * cb * g1 + (denom - ca * cc) * g0);
+        dLb = d2i * 2 * (cb * cc * g0 - (denom + 2 * cb * cb) * g1 + ca * cb * g2);
+        dc[0] = t0[0] * t0[0] * dLa + t0[0] * t1[0] * dLb + t1[0] * t1[0] * dLc;
+        dc[3] = t0[1] * t0[1] * dLa + t0[1] * t1[1] * dLb + t1[1] * t1[1] * dLc;
+        dc[5] = t0[2] * t0[2] * dLa + t0[2] * t1[2] * dLb + t1[2] * t1[2] * dLc;
+        dc[1] = 2 * t0[0] * t0[1] * dLa + (t0[0] * t1[1] + t0[1] * t1[0]) * dLb + 2 * t1[0] * t1[1] * dLc;
+        dc[2] = 2 * t0[0] * t0[2] * dLa + (t0[0] * t1[2] + t0[2] * t1[0]) * dLb + 2 * t1[0] * t1[2] * dLc;
+        dc[4] = 2 * t0[2] * t0[1] * dLa + (t0[1] * t1[2] + t0[2] * t1[1]) * dLb + 2 * t1[1] * t1[2] * dLc;
+    }
+    // dL_dT (backward.cu:231-242): dT0[k] = 2 (V t0)[k] dLa + (V t1)[k] dLb,  dT1[k] = 2 (V t1)[k] dLc + (V t0)[k] dLb
+    R dT0[3], dT1[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { dT0[k] = 2 * r0[k] * dLa + r1[k] * dLb; dT1[k] = 2 * r1[k] * dLc + r0[k] * dLb; }
+    const R dJ00 = w[0][0] * dT0[0] + w[0][1] * dT0[1] + w[0][2] * dT0[2];
+    const R dJ02 = w[2][0] * dT0[0] + w[2][1] * dT0[1] + w[2][2] * dT0[2];
+    const R dJ11 = w[1][0] * dT1[0] + w[1][1] * dT1[1] + w[1][2] * dT1[2];
+    const R dJ12 = w[2][0] * dT1[0] + w[2][1] * dT1[1] + w[2][2] * dT1[2];
+    const R dtx = xg * -fx * iz2 * dJ02, dty = yg * -fy * iz2 * dJ12;
+    const R dtz = -fx * iz2 * dJ00 - fy * iz2 * dJ11 + (2 * fx * tx) * iz3 * dJ02 + (2 * fy * ty) * iz3 * dJ12;
+    R dm[3] = {vm[0] * dtx + vm[1] * dty + vm[2] * dtz, vm[4] * dtx + vm[5] * dty + vm[6] * dtz, vm[8] * dtx + vm[9] * dty + vm[10] * dtz};
+    // the projection part (backward.cu:369-387) is well-conditioned: fp32, in the reference's operation order
+    const float* pj = PM.m;
+    const float m_w = 1.0f / ((pj[3] * mxf + pj[7] * myf + pj[11] * mzf + pj[15]) + 0.0000001f);
+    const float mul1 = (pj[0] * mxf + pj[4] * myf + pj[8] * mzf + pj[12]) * m_w * m_w, mul2 = (pj[1] * mxf + pj[5] * myf + pj[9] * mzf + pj[13]) * m_w * m_w;
+    dm[0] += (R)((pj[0] * m_w - pj[3] * mul1) * g2xf + (pj[1] * m_w - pj[3] * mul2) * g2yf);
+    dm[1] += (R)((pj[4] * m_w - pj[7] * mul1) * g2xf + (pj[5] * m_w - pj[7] * mul2) * g2yf);
+    dm[2] += (R)((pj[8] * m_w - pj[11] * mul1) * g2xf + (pj[9] * m_w - pj[11] * mul2) * g2yf);
+#pragma unroll
+    for (int k = 0; k < 3; k++) dmean[k] = (float)dm[k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) dcov[k] = (float)dc[k];
+    if (HAS_SCALE_ROT) {
+        // computeCov3D backward (backward.cu:278-341): M = S R, dM = (2 M) dSig, dMt = dM^T in GLM's column-major products
+        const R q0 = rot4[0], qx = rot4[1], qy = rot4[2], qz = rot4[3];
+        const R Rg[3][3] = {{1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - q0 * qz), 2 * (qx * qz + q0 * qy)},
+                            {2 * (qx * qy + q0 * qz), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - q0 * qx)},
+                            {2 * (qx * qz - q0 * qy), 2 * (qy * qz + q0 * qx), 1 - 2 * (qx * qx + qy * qy)}};      // Rg[c][w]: GLM column c, row w
+        const R sc[3] = {(R)cam.scale_modifier * (R)scales3[0], (R)cam.scale_modifier * (R)scales3[1], (R)cam.scale_modifier * (R)scales3[2]};
+        const R dS[3][3] = {{dc[0], 0.5 * dc[1], 0.5 * dc[2]}, {0.5 * dc[1], dc[3], 0.5 * dc[4]}, {0.5 * dc[2], 0.5 * dc[4], dc[5]}};
+        // GLM product (a * b).m[c][w] = sum_k a.m[k][w] b.m[c][k]; S is diagonal, so Mx = S * R has Mx.m[c][w] = s_w Rg[c][w]
+        // dMt.m[c][w] = dM.m[w][c] = sum_k 2 s_c Rg[k][c] dS[w][k], formed column by column; dscale[c] needs column c before, the
+        // quaternion derivative (linear in the entries A(c, w) = s_c dMt.m[c][w]) is accumulated as the entries appear: 3 live doubles, not 9
+        R dq[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            R col[3];
+#pragma unroll
+            for (int wi = 0; wi < 3; wi++) col[wi] = 2 * sc[c] * (Rg[0][c] * dS[wi][0] + Rg[1][c] * dS[wi][1] + Rg[2][c] * dS[wi][2]);
+            dscale[c] = (float)(Rg[0][c] * col[0] + Rg[1][c] * col[1] + Rg[2][c] * col[2]);
+            const R A0 = col[0] * sc[c], A1 = col[1] * sc[c], A2 = col[2] * sc[c];         // A(c, 0..2)
+            if (c == 0) {        // A(0,0) A(0,1) A(0,2)
+                dq[0] += 2 * qz * A1 - 2 * qy * A2;
+                dq[1] += 2 * qy * A1 + 2 * qz * A2;
+                dq[2] += 2 * qx * A1 - 2 * q0 * A2 - 4 * qy * A0;
+                dq[3] += 2 * q0 * A1 + 2 * qx * A2 - 4 * qz * A0;
+            } else if (c == 1) { // A(1,0) A(1,1) A(1,2)
+                dq[0] += -2 * qz * A0 + 2 * qx * A2;
+                dq[1] += 2 * qy * A0 + 2 * q0 * A2 - 4 * qx * A1;
+                dq[2] += 2 * qx * A0 + 2 * qz * A2;
+                dq[3] += -2 * q0 * A0 + 2 * qy * A2 - 4 * qz * A1;
+            } else {             // A(2,0) A(2,1) A(2,2)
+                dq[0] += 2 * qy * A0 - 2 * qx * A1;
+                dq[1] += 2 * qz * A0 - 2 * q0 * A1 - 4 * qx * A2;
+                dq[2] += 2 * q0 * A0 + 2 * qz * A1 - 4 * qy * A2;
+                dq[3] += 2 * qx * A0 + 2 * qy * A1;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) drot[k] = (float)dq[k];
+    }
+}
+
 struct GaussTerms {
     float a[NACC];                 // sums of the tile partials: colour rgb, mean2D xy, conic xx xy yy, opacity
     float dmean[3], dcov[6], dscale[3], drot[4];
@@ -663,7 +824,8 @@ __device__ __forceinline__ void pergauss_terms(int idx, bool live, int D, const 
     float (&a)[NACC] = t.a;
     float (&dmean)[3] = t.dmean; float (&dcov)[6] = t.dcov; float (&dscale)[3] = t.dscale; float (&drot)[4] = t.drot;
     float (&coef)[16] = t.coef; float (&dRGB)[3] = t.dRGB;
-    slab_sum(live, tiles_in, off_in, b, a);                // convergent: the wave helps its splats that touch many tiles
+    double cn[3];
+    slab_sum(live, tiles_in, off_in, b, a, cn);            // convergent: the wave helps its splats that touch many tiles
 #pragma unroll
     for (int k = 0; k < 3; k++) { dmean[k] = 0.f; dscale[k] = 0.f; dRGB[k] = 0.f; }
 #pragma unroll
@@ -675,6 +837,16 @@ __device__ __forceinline__ void pergauss_terms(int idx, bool live, int D, const 
     if (!live) return;
     const size_t i3 = 3 * (size_t)idx;
     const float mx = in.means3D[i3], my = in.means3D[i3 + 1], mz = in.means3D[i3 + 2];
+#if TGS_PERGAUSS_F64
+    {
+        float cov3d[6];
+        const float* csrc = HAS_SCALE_ROT ? (g.cov3D + 6 * (size_t)idx) : (cov3D_precomp + 6 * (size_t)idx);
+#pragma unroll
+        for (int i = 0; i < 6; i++) cov3d[i] = csrc[i];
+        cov_chain_bwd_f64<HAS_SCALE_ROT>(mx, my, mz, cov3d, cam, V, PM, cn, a[3], a[4], HAS_SCALE_ROT ? in.scales + i3 : nullptr,
+                                         HAS_SCALE_ROT ? in.rotations + 4 * (size_t)idx : nullptr, dmean, dcov, dscale, drot);
+    }
+#else
     {
         // ---- computeCov2DCUDA (backward.cu:144-274) ----
         float cov3d[6];
@@ -769,6 +941,7 @@ __device__ __forceinline__ void pergauss_terms(int idx, bool live, int D, const 
 #undef A
         }
     }
+#endif
     if (HAS_SH) {
             asm volatile("" ::: "memory");            // keep the 48 SH reads below from being hoisted over the covariance math (VGPR pressure)
             sh_backward_terms(D, sh, g.clamped[idx], a[0], a[1], a[2], mx, my, mz, camx, camy, camz, coef, dRGB, dmean);
@@ -884,10 +1057,21 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
     const bool live = in_range && in.radii[idx] > 0;        // backward.cu:156,367
     float mx = 0.f, my = 0.f, mz = 0.f;
     float dRGB[3] = {0.f, 0.f, 0.f};
-    slab_sum(live, live ? g.tiles_touched[idx] : 0u, live ? g.offsets[idx] : 0u, b, a);   // sum of this Gaussian's tile partials (wave-cooperative for big splats)
+    double cn[3];
+    slab_sum(live, live ? g.tiles_touched[idx] : 0u, live ? g.offsets[idx] : 0u, b, a, cn);   // sum of this Gaussian's tile partials (wave-cooperative for big splats)
     if (live) {
         mx = in.means3D[i3]; my = in.means3D[i3 + 1]; mz = in.means3D[i3 + 2];
 
+#if TGS_PERGAUSS_F64
+        {
+            float cov3d[6];
+            const float* csrc = HAS_SCALE_ROT ? (g.cov3D + 6 * (size_t)idx) : (in.cov3D_precomp + 6 * (size_t)idx);
+#pragma unroll
+            for (int i = 0; i < 6; i++) cov3d[i] = csrc[i];
+            cov_chain_bwd_f64<HAS_SCALE_ROT>(mx, my, mz, cov3d, cam, V, PM, cn, a[3], a[4], HAS_SCALE_ROT ? in.scales + i3 : nullptr,
+                                             HAS_SCALE_ROT ? in.rotations + 4 * (size_t)idx : nullptr, dmean, dcov, dscale, drot);
+        }
+#else
         // ---- computeCov2DCUDA (backward.cu:144-274) ----
         float cov3d[6];
         const float* csrc = HAS_SCALE_ROT ? (g.cov3D + 6 * (size_t)idx) : (in.cov3D_precomp + 6 * (size_t)idx);
@@ -980,7 +1164,8 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
             drot[3] = 2 * r * (A(0, 1) - A(1, 0)) + 2 * x * (A(2, 0) + A(0, 2)) + 2 * y * (A(1, 2) + A(2, 1)) - 4 * z * (A(1, 1) + A(0, 0));
 #undef A
         }
-    }
+    #endif
+}
 
     if (HAS_SH) {
         // computeColorFromSH backward (backward.cu:20-139); culled Gaussians write zeros.

@@ -199,7 +199,9 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_sh_rgb_dcrest(const ShDcRestArgs 
     const size_t blk_f4 = (size_t)PRE_BLOCK * a.Mr * 3 / 4, base4 = (size_t)blockIdx.x * blk_f4, total4 = ((size_t)a.P * a.Mr * 3 + 3) / 4;
     float camx = 0.f, camy = 0.f, camz = 0.f;
     if (a.camera) { camx = a.camera[0]; camy = a.camera[1]; camz = a.camera[2]; }
-    const bool tail_ok = ((size_t)a.P * a.Mr * 3) % 4 == 0;  // (a last partial float4 would read past the tensor: such shapes take the direct path)
+    // a last partial float4 would read past the tensor, and a row slice such as rest[1:] (Mr = 15: 180 B in) is not 16-byte aligned: such
+    // shapes / views take the direct path
+    const bool tail_ok = ((size_t)a.P * a.Mr * 3) % 4 == 0 && ((reinterpret_cast<uintptr_t>(a.rest) | reinterpret_cast<uintptr_t>(a.dL_drest)) & 15) == 0;
     const bool do_stage = staged && tail_ok;
     if (do_stage) {
         const float4* s4 = reinterpret_cast<const float4*>(a.rest);

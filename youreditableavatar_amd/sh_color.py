@@ -170,3 +170,84 @@ def points_rgb(sh_coordinates: torch.Tensor, sh_levels: int, positions: Optional
     if directions is not None:
         return _SHColor.apply(sh_coordinates, None, None, directions, sh_levels)
     raise ValueError("Either camera_centers or directions must be provided.")
+
+
+class _SHColorGroups(torch.autograd.Function):
+    """colours of the keep and the edit group into ONE [Pk+Pe,3] tensor (two launches of the dc / rest kernel, no torch.cat); gradients for
+    the edit group only"""
+
+    @staticmethod
+    def forward(ctx, keep_dc, keep_rest, keep_pos, edit_dc, edit_rest, edit_pos, camera_center, keep_levels, edit_levels):
+        dev = edit_dc.device
+        cam = _check(camera_center.reshape(-1), "camera_centers", dev)
+        p = lambda t: None if t is None else t.data_ptr()
+        groups = []
+        for dc, rest, pos, levels, tag in ((keep_dc, keep_rest, keep_pos, int(keep_levels), "keep"), (edit_dc, edit_rest, edit_pos, int(edit_levels), "edit")):
+            dc = _check(dc, f"{tag}_sh_coordinates_dc", dev)
+            if dc.dim() != 3 or dc.shape[1] != 1 or dc.shape[2] != 3:
+                raise RuntimeError(f"{tag}_sh_coordinates_dc must have dimensions (num_points, 1, 3)")
+            n = int(dc.shape[0])
+            rest = _check(rest, f"{tag}_sh_coordinates_rest", dev) if (rest is not None and rest.numel() and levels > 1) else None
+            if rest is not None and (rest.dim() != 3 or rest.shape[0] != n or rest.shape[2] != 3):
+                raise RuntimeError(f"{tag}_sh_coordinates_rest must have dimensions (num_points, M - 1, 3)")
+            pos = _check(pos, f"{tag} positions", dev)
+            if pos.shape[0] != n or pos.dim() != 2 or pos.shape[1] not in (1, 3):
+                raise RuntimeError(f"{tag} positions must have dimensions (num_points, 3) -- or (num_points, 1): tetgs_edit_3d.py:556-572")
+            # Edit3DTetGS hands get_points_rgb its [Pe,1] normal offsets as `positions` (tetgs_edit_3d.py:556,572): `positions - camera_centers`
+            # broadcasts them to [Pe,3].  Reproduced, not "fixed" (SURVEY.md section 8f).
+            groups.append((dc, rest, pos.expand(n, 3).contiguous() if pos.shape[1] == 1 else pos, levels, n, int(pos.shape[1])))
+        (kdc, krest, kpos, klev, Pk, _), (edc, erest, epos, elev, Pe, ecols) = groups
+        colors = torch.empty((Pk + Pe, 3), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream(dev).cuda_stream
+            r = _lib.tgs_sh_rgb_dcrest_forward(st, Pk, int(krest.shape[1]) if krest is not None else 0, klev, p(kdc), p(krest), p(kpos), p(cam), None, colors.data_ptr())
+            if r >= 0:
+                r = _lib.tgs_sh_rgb_dcrest_forward(st, Pe, int(erest.shape[1]) if erest is not None else 0, elev, p(edc), p(erest), p(epos), p(cam), None,
+                                                   colors.data_ptr() + 12 * Pk)
+        if r < 0:
+            raise _rast_c._err(r)
+        e = torch.Tensor([])
+        ctx.save_for_backward(edc, erest if erest is not None else e, epos, cam)
+        ctx.info = (Pk, Pe, elev, ecols)
+        return colors
+
+    @staticmethod
+    def backward(ctx, grad_colors):
+        edc, erest, epos, cam = ctx.saved_tensors
+        Pk, Pe, elev, ecols = ctx.info
+        dev = edc.device
+        erest = erest if erest.numel() else None
+        g = _check(grad_colors, "grad_colors", dev)
+        need = ctx.needs_input_grad             # (keep_dc, keep_rest, keep_pos, edit_dc, edit_rest, edit_pos, cam, ., .)
+        d_dc = torch.empty_like(edc)
+        d_rest = torch.empty_like(erest) if erest is not None else None
+        d_pos = torch.empty_like(epos) if need[5] else None
+        p = lambda t: None if t is None else t.data_ptr()
+        with torch.cuda.device(dev):
+            r = _lib.tgs_sh_rgb_dcrest_backward(torch.cuda.current_stream(dev).cuda_stream, Pe, int(erest.shape[1]) if erest is not None else 0, elev, p(edc), p(erest),
+                                                p(epos), p(cam), None, g.data_ptr() + 12 * Pk, d_dc.data_ptr(), p(d_rest), p(d_pos), None)
+        if r < 0:
+            raise _rast_c._err(r)
+        if d_pos is not None and ecols == 1:
+            d_pos = d_pos.sum(dim=1, keepdim=True)      # the adjoint of the [Pe,1] -> [Pe,3] broadcast
+        return None, None, None, d_dc, d_rest, d_pos, None, None, None
+
+
+def points_rgb_groups(*, keep_sh_dc: torch.Tensor, keep_sh_rest: Optional[torch.Tensor], keep_sh_levels: int, keep_positions: torch.Tensor,
+                      edit_sh_dc: torch.Tensor, edit_sh_rest: Optional[torch.Tensor], edit_sh_levels: int, edit_positions: torch.Tensor,
+                      camera_centers: torch.Tensor) -> torch.Tensor:
+    """``splat_colors`` of the editing stages' render call (tetgs_edit_2d.py:548-565, tetgs_edit_3d.py:566-582): ``get_points_rgb`` of the keep
+    group at ``keep_sh_levels`` and of the edit group at ``edit_sh_levels`` (each from its dc / rest parameters), written into one
+    [Pk+Pe,3] tensor, keep rows first -- without the two ``torch.cat([dc, rest])``, the ``torch.cat`` of the colours and the keep group's
+    backward.  Gradients reach the edit group's dc / rest (and positions, when they require one); the keep group is frozen in the
+    reference.  ``edit_positions`` may be [Pe,1] as ``Edit3DTetGS`` passes it (the offsets along the normals, broadcast against the camera
+    centre -- the reference's behaviour, kept).  With ``edit_sh_levels == 1`` the edit rest parameter gets no gradient (``None``)."""
+    for name, t in (("keep_sh_dc", keep_sh_dc), ("keep_sh_rest", keep_sh_rest), ("keep_positions", keep_positions)):
+        if t is not None and t.requires_grad:
+            raise RuntimeError(f"points_rgb_groups: {name} requires a gradient, but the keep group is frozen (tetgs_edit_2d.py:237-262)")
+    for lev, rest, tag in ((keep_sh_levels, keep_sh_rest, "keep"), (edit_sh_levels, edit_sh_rest, "edit")):
+        if lev > 1 and (rest is None or rest.shape[1] < lev ** 2 - 1):
+            raise ValueError(f"{tag}_sh_rest must hold at least {tag}_sh_levels**2 - 1 coefficient rows")
+    if camera_centers is None or camera_centers.numel() != 3:
+        raise ValueError("one camera centre ([3] or [1,3]) is required")
+    return _SHColorGroups.apply(keep_sh_dc, keep_sh_rest, keep_positions, edit_sh_dc, edit_sh_rest, edit_positions, camera_centers, keep_sh_levels, edit_sh_levels)
