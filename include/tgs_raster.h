@@ -133,7 +133,11 @@ typedef struct {
                                   -1: default (1 in the *_views entry points, 0 in the single-view ones; TGS_LIGHT_TILES overrides both).
                                   A backward sets light tiles apart only for a frame whose FORWARD did (the forward records their descriptors):
                                   pass the same options to both; light_tiles = 1 on a frame rendered without is reported as TGS_FRAME_TILE_BOUND */
-    int32_t reserved;
+    int32_t side_stream;       /* single-view forwards with SH colours (M = 16): 1: the 192-B SH rows are read and the colours evaluated by a kernel of
+                                  their own on a library-owned side stream (one per calling thread and device), behind the per-Gaussian stage
+                                  and beside the latency-bound binning chain, joined in front of the tile sort's gather; 2: everything on the
+                                  caller's stream; 0 / -1: default (2 -- the fork / join across streams costs more than the overlap gains on
+                                  gfx950; TGS_SIDE_STREAM=1 in the environment turns it on).  Same results either way */
 } tgs_options_t;
 /* What a forward learned about its frame (filled when non-NULL; the synchronous and the speculative forward read the frame's Meta,
  * the sync-free one cannot: num_rendered / nonempty_tiles are -1 there). */

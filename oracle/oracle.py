@@ -16,14 +16,16 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libtgs_oracle.so")
 _LIB64_PATH = os.path.join(_HERE, "libtgs_oracle_f64.so")      # the same C text with real = double (tgs_oracle.c: TGS_ORACLE_F64)
 _LIBFMA_PATH = os.path.join(_HERE, "libtgs_oracle_fma.so")     # fp32 with FMA contraction allowed (what nvcc does to the reference by default)
+_LIBEX2_PATH = os.path.join(_HERE, "libtgs_oracle_ex2.so")     # fp32, exp as 2^(x log2 e) (how GPU math libraries evaluate expf)
 _lib = None
 _lib64 = None
 _libfma = None
+_libex2 = None
 
 
 def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "tgs_oracle.c")
-    for path in (_LIB_PATH, _LIB64_PATH, _LIBFMA_PATH):
+    for path in (_LIB_PATH, _LIB64_PATH, _LIBFMA_PATH, _LIBEX2_PATH):
         if force or not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
             subprocess.check_call(["make", "-C", _HERE, "-s", os.path.basename(path)])
     return _LIB_PATH
@@ -69,8 +71,18 @@ def libfma():
     return _libfma
 
 
+def libex2():
+    """libtgs_oracle_ex2.so: fp32 with exp(x) evaluated as exp2f(x * log2 e), the product rounded to fp32 -- how GPU math libraries evaluate
+    expf (CUDA documents its expf at up to 2 ulp; glibc's is below 1): a third legitimate rounding of the reference's arithmetic."""
+    global _libex2
+    if _libex2 is None:
+        build()
+        _libex2 = _bind(_LIBEX2_PATH, C.c_float, False)
+    return _libex2
+
+
 def _variant_lib(variant: str):
-    return {"f32": lib, "f64": lib64, "f32_fma": libfma}[variant]()
+    return {"f32": lib, "f64": lib64, "f32_fma": libfma, "f32_ex2": libex2}[variant]()
 
 
 def lib():
@@ -149,7 +161,7 @@ def forward(*, bg, means3D, opacities, viewmatrix, projmatrix, campos, tanfovx, 
             cov3D_precomp=None, scale_modifier=1.0, variant: str = "f32"):
     """Returns (color[3,H,W], radii[P], OracleState).  Mirrors Rasterizer::forward
     (cuda_rasterizer/rasterizer_impl.cu:198-336).  ``variant``: "f32" (the restatement, no FMA contraction), "f32_fma" (contraction
-    allowed), "f64" (the same C text compiled with real = double on the same fp32 inputs -- scalars are rounded to fp32 first as well:
+    allowed, fp32 accumulation of the cross-pixel sums), "f32_ex2" (exp as 2^(x log2 e)), "f64" (the same C text compiled with real = double on the same fp32 inputs -- scalars are rounded to fp32 first as well:
     the reference's function in exact arithmetic)."""
     f64 = variant == "f64"
     cv = _conv(f64)

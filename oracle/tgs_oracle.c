@@ -40,7 +40,14 @@ typedef double real;
 #else
 typedef float real;
 #define r_sqrt sqrtf
+#ifdef TGS_ORACLE_EXP2
+/* exp the way GPUs evaluate it: 2^(x * log2 e) with the product rounded to fp32 (CUDA's expf: ex2.approx on a scaled argument, documented
+ * at up to 2 ulp; glibc's expf is < 1 ulp).  A third legitimate rounding of the reference's arithmetic (libtgs_oracle_ex2.so). */
+static inline float exp_via_exp2(float x) { return exp2f(x * 1.44269504088896340736f); }
+#define r_exp exp_via_exp2
+#else
 #define r_exp expf
+#endif
 #define r_ceil ceilf
 #endif
 #define RS sizeof(real)

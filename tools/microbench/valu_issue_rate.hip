@@ -14,12 +14,17 @@ constexpr int PER_TRIP = 32;
 // MODE 0: v_fma_f32 (8 independent accumulators)      MODE 1: v_mul_f32_dpp quad_perm (8 independent)
 // MODE 2: v_exp_f32 (8 independent)                    MODE 3: the render-loop mix: 6 fma/mul + 1 dpp + 1 exp per 8
 // MODE 4: v_cndmask_b32_dpp + v_fma (the chain step)   MODE 5: dependent v_fma_f32 chain (1 accumulator)
+// MODE 6 / 7 (round 4): the render mix of MODE 3 with the SCALAR density of the real loops beside it -- k_render_fwd carries 0.71 scalar
+// instructions per vector instruction (s_and / s_or / s_andn2_b64 on the lane masks done / live / fail / upd / stop, s_mov_b64 vcc in
+// front of every v_cndmask_b32_dpp), k_render_bwd 0.37 (profiles/r03_f_sq_counters.json): 6 resp. 3 scalar instructions per 8 vector ones.
+// One scalar unit serves a CU's four SIMDs; if it co-limits the loops, the VECTOR rate of these modes falls below MODE 3's.
 template <int MODE>
 __global__ __launch_bounds__(256) void k_valu(float* out, float seed, unsigned long long* clocks)
 {
     extern __shared__ float lds_pad[];       // dynamic LDS only caps the number of resident workgroups per CU
     float a0 = seed + threadIdx.x, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
     const float m = 0.999f, c = 1e-3f;
+    unsigned long long m0 = __builtin_amdgcn_ballot_w64(a0 > 3.f), m1 = __builtin_amdgcn_ballot_w64(a0 > 5.f), m2 = ~m0;     // lane masks in SGPR pairs
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
 #pragma unroll 1
     for (int it = 0; it < ITERS; it++) {
@@ -38,13 +43,23 @@ __global__ __launch_bounds__(256) void k_valu(float* out, float seed, unsigned l
         } else if (MODE == 4) {
 #define CH CND(a0) FMA(a1) CND(a2) FMA(a3) CND(a4) FMA(a5) CND(a6) FMA(a7)
             asm volatile(CH CH CH CH OPS);
-        } else {
+        } else if (MODE == 5) {
 #define D8 FMA(a0) FMA(a0) FMA(a0) FMA(a0) FMA(a0) FMA(a0) FMA(a0) FMA(a0)
             asm volatile(D8 D8 D8 D8 OPS);
+        } else {
+#define SAND "s_and_b64 %[s0], %[s0], %[s1]\n\t"
+#define SOR "s_or_b64 %[s1], %[s1], %[s2]\n\t"
+#define SAN2 "s_andn2_b64 %[s2], %[s2], %[s0]\n\t"
+#define SMOV "s_mov_b64 vcc, %[s0]\n\t"
+#define OPSS : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [a4] "+v"(a4), [a5] "+v"(a5), [a6] "+v"(a6), [a7] "+v"(a7), [s0] "+s"(m0), [s1] "+s"(m1), [s2] "+s"(m2) : [m] "v"(m), [c] "v"(c) : "vcc"
+#define MIXS6 FMA(a0) SAND FMA(a1) SOR FMA(a2) SMOV DPP(a3) SAN2 FMA(a4) SAND FMA(a5) EXP(a6) SOR FMA(a7)
+#define MIXS3 FMA(a0) SAND FMA(a1) FMA(a2) SMOV DPP(a3) FMA(a4) FMA(a5) SOR EXP(a6) FMA(a7)
+            if (MODE == 6) asm volatile(MIXS6 MIXS6 MIXS6 MIXS6 OPSS);
+            else asm volatile(MIXS3 MIXS3 MIXS3 MIXS3 OPSS);
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-    out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+    out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)__builtin_popcountll(m0 ^ m1 ^ m2);
     if (threadIdx.x == 0) { clocks[2 * blockIdx.x] = t1 - t0; clocks[2 * blockIdx.x + 1] = r1 - r0; }
 }
 
@@ -56,11 +71,12 @@ int main()
     hipMalloc(&d_clk, (size_t)CUS * 8 * ROUNDS * 16);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const char* names[] = {"v_fma_f32 x8 independent", "v_mul_f32_dpp quad_perm x8 independent", "v_exp_f32 x8 independent",
-                           "render mix: 6 fma + 1 mul_dpp + 1 exp", "chain step: v_cndmask_b32_dpp + v_fma_f32 alternating", "v_fma_f32 dependent chain"};
+                           "render mix: 6 fma + 1 mul_dpp + 1 exp", "chain step: v_cndmask_b32_dpp + v_fma_f32 alternating", "v_fma_f32 dependent chain",
+                           "render mix + 6 SALU per 8 VALU (k_render_fwd: 0.71)", "render mix + 3 SALU per 8 VALU (k_render_bwd: 0.37)"};
     printf("# tools/microbench/valu_issue_rate.hip on MI355X (gfx950): 256-thread workgroups (one wave per SIMD each), W workgroups resident per CU\n"
-           "# (capped through dynamic LDS), %d x %d wave64 vector instructions per wave; G winstr/s = wave-instructions retired chip-wide per second;\n"
+           "# (capped through dynamic LDS), %d x %d wave64 vector instructions per wave; G winstr/s = VECTOR wave-instructions retired chip-wide per second (the scalar ones of modes 6 / 7 ride beside them, uncounted);\n"
            "# cyc/instr/SIMD = in-kernel cycles (s_memtime) / (W * instructions per wave): 2.0 = the SIMD-32 execute rate, 4.0 = one wave alone.\n", ITERS, PER_TRIP);
-    for (int mode = 0; mode < 6; mode++) {
+    for (int mode = 0; mode < 8; mode++) {
         for (int W : {1, 2, 4, 8}) {
             const size_t lds = (size_t)(160 * 1024 / W) - 1024;          // W workgroups fit one CU's 160 KiB, W + 1 do not
             const int grid = CUS * W * ROUNDS;
@@ -70,11 +86,13 @@ int main()
             hipFuncSetAttribute((const void*)k_valu<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
             hipFuncSetAttribute((const void*)k_valu<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
             hipFuncSetAttribute((const void*)k_valu<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+            hipFuncSetAttribute((const void*)k_valu<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+            hipFuncSetAttribute((const void*)k_valu<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
             float ms = 0;
             for (int rep = 0; rep < 3; rep++) {
                 hipEventRecord(e0);
 #define L(M) hipLaunchKernelGGL(k_valu<M>, dim3(grid), dim3(256), lds, 0, d_out, 1.0f, d_clk)
-                switch (mode) { case 0: L(0); break; case 1: L(1); break; case 2: L(2); break; case 3: L(3); break; case 4: L(4); break; default: L(5); }
+                switch (mode) { case 0: L(0); break; case 1: L(1); break; case 2: L(2); break; case 3: L(3); break; case 4: L(4); break; case 5: L(5); break; case 6: L(6); break; default: L(7); }
                 hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
             }
             std::vector<unsigned long long> clk((size_t)grid * 2);

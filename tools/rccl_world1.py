@@ -33,8 +33,8 @@ batch = SyncFreeBatch(streams=4)
 pend = []
 
 
-def step(reduce):
-    batch.run_views(S, L["means3D"], L["opacities"], L["shs"], L["scales"], L["rotations"], None, accumulate=False, upstream_view=lambda v, image: dL, grad_chunks=4,
+def step(reduce, chunks=4):
+    batch.run_views(S, L["means3D"], L["opacities"], L["shs"], L["scales"], L["rotations"], None, accumulate=False, upstream_view=lambda v, image: dL, grad_chunks=chunks,
                     on_chunk=(lambda first, count: pend.extend(flat.all_reduce_rows(first, count, even_alone=True))) if reduce else (lambda f, c: None))
     n = len(pend)
     for w in pend:
@@ -43,25 +43,37 @@ def step(reduce):
     return n
 
 
-def timed(reduce, n, warm):
+def timed(reduce, n, warm, chunks=4):
     for _ in range(warm):
-        step(reduce)
+        step(reduce, chunks)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(n):
-        handles = step(reduce)
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / n * 1e3, handles
+    ts = []
+    for _ in range(3):                                      # median of three blocks
+        t0 = time.perf_counter()
+        for _ in range(n):
+            handles = step(reduce, chunks)
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) / n * 1e3)
+    return sorted(ts)[1], handles
 
 
 ms_r, handles = timed(True, 10, 4)
 ms_n, _ = timed(False, 10, 2)
+# where the difference comes from: the same step with 1 / 2 / 4 Gaussian ranges, with and without the collectives (a sum over one rank moves no
+# byte: what is left is RCCL's launch + the stream hand-over per collective, and the cost of cutting the per-Gaussian pass into ranges)
+table = {}
+for c in (1, 2, 4):
+    table[str(c)] = {"with_reduce": round(timed(True, 8, 2, c)[0], 4), "without": round(timed(False, 8, 2, c)[0], 4)}
+per_collective_us = round((table["4"]["with_reduce"] - table["4"]["without"]) / 4 * 1e3, 1)
 ref = flat.flat.clone()
 step(True)
 torch.cuda.synchronize()
 same = bool(torch.equal(ref, flat.flat))
 print(json.dumps({"ms_per_step_with_reduce": round(ms_r, 4), "ms_per_step_without": round(ms_n, 4), "backend": str(dist.get_backend()), "collective_handles_per_step": handles,
                   "gradients_unchanged_by_the_one_rank_sum": same, "frames_rerendered": batch.rejected,
+                  "ms_per_step_by_ranges": table, "rccl_cost_per_collective_us_at_world_1": per_collective_us,
+                  "range_cutting_cost_frac": round(table["4"]["without"] / table["1"]["without"] - 1.0, 4),
                   "what": f"8-view step of config {cfg_i} with its gradients all-reduced in 4 Gaussian ranges through RCCL at world size 1 (one coalesced collective per range, "
-                          "overlapped with the per-Gaussian pass): the N > 1 control flow on the production backend; no data crosses xGMI"}), flush=True)
+                          "overlapped with the per-Gaussian pass): the N > 1 control flow on the production backend; no data crosses xGMI.  ms_per_step_by_ranges separates "
+                          "the cost of cutting the per-Gaussian pass into ranges (without) from RCCL's per-collective launch + stream hand-over (with - without)"}), flush=True)
 dist.destroy_process_group()

@@ -286,6 +286,7 @@ __device__ __forceinline__ void bwd_light_group(const ImgState& s, const BinStat
     }
     __syncthreads();                                        // (the null record was written in front of the kernel's first barrier)
     float vone = 1.0f, vzero = 0.0f;
+    const QuadMasks qm = quad_masks();
     asm volatile("" : "+v"(vone), "+v"(vzero));
     const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);   // backward.cu:460-461
     const float bgr = bg[0], bgg = bg[1], bgb = bg[2];
@@ -335,7 +336,7 @@ __device__ __forceinline__ void bwd_light_group(const ImgState& s, const BinStat
                 float Town, inv_om, Aown;
                 float sdot = c0_ * dpx0;
                 sdot += c1_ * dpx1; sdot += c2_ * dpx2;
-                bwd_chain4s(aeff, sdot, T, arA, Town, inv_om, Aown, vone, vzero);
+                bwd_chain4s(aeff, sdot, T, arA, Town, inv_om, Aown, vone, vzero, qm);
                 const float dchannel_dcolor = aeff * Town;
                 float dL_dalpha = sdot - Aown;
                 dL_dalpha = dL_dalpha * Town - tfinal_bg * inv_om;
@@ -433,6 +434,7 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
     const float tfinal_bg = T_final * bg_dot_dpixel;
     float arA = 0.f;                                        // dL_dpixel . accum_rec with (last_alpha, last_color) already applied (bwd_chain4s)
     float vone = 1.0f, vzero = 0.0f;                        // identity elements, pinned to VGPRs for the DPP selects
+    const QuadMasks qm = quad_masks();
     asm volatile("" : "+v"(vone), "+v"(vzero));
     const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);   // backward.cu:460-461
 
@@ -510,7 +512,7 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
                 float Town, inv_om, Aown;
                 float sdot = c0 * dpx0;
                 sdot += c1 * dpx1; sdot += c2 * dpx2;               // dL_dpixel . colour of this entry
-                bwd_chain4s(aeff, sdot, T, arA, Town, inv_om, Aown, vone, vzero);
+                bwd_chain4s(aeff, sdot, T, arA, Town, inv_om, Aown, vone, vzero, qm);
                 // this lane's (pixel, entry) terms, backward.cu:507-555 (all zero for a skipped entry).  Everything that is
                 // constant per entry -- opacity, the conic, -0.5, the ndc scale -- is applied once per entry at the flush
                 // (flush_row), so a lane only forms the moments of w = G * dL_dalpha over dx, dy.
@@ -700,10 +702,11 @@ __device__ __forceinline__ void sh_backward_terms(int D, const ShRow& sh, uint32
 #define TGS_PERGAUSS_F64 1
 #endif
 
-template <bool HAS_SCALE_ROT>
-__device__ __forceinline__ void cov_chain_bwd_f64(float mxf, float myf, float mzf, const float (&cov3d)[6], const CamParams& cam, const ViewMat& V, const ViewMat& PM,
-                                                  const double (&dLconic)[3], float g2xf, float g2yf, const float* __restrict__ scales3,
-                                                  const float* __restrict__ rot4, float (&dmean)[3], float (&dcov)[6], float (&dscale)[3], float (&drot)[4])
+// (1) computeCov2DCUDA + the projection part: per view.  dc: dL_dcov3D of this view in double (reference layout: off-diagonals doubled).
+// ACCUMULATE: dc += this view's share (the batch kernels' running sum over the views) instead of dc = it.
+template <bool ACCUMULATE>
+__device__ __forceinline__ void cov2d_chain_bwd_f64(float mxf, float myf, float mzf, const float (&cov3d)[6], const CamParams& cam, const ViewMat& V, const ViewMat& PM,
+                                                    const double (&dLconic)[3], float g2xf, float g2yf, float (&dmean)[3], double (&dc)[6])
 {
     typedef double R;
     const R mx = mxf, my = myf, mz = mzf;
@@ -721,10 +724,10 @@ __device__ __forceinline__ void cov_chain_bwd_f64(float mxf, float myf, float mz
     // J (rows): [fx/tz, 0, -fx tx/tz^2], [0, fy/tz, -fy ty/tz^2];  T = W J in GLM terms: T.m[c][r] of the fp32 code.  Written out:
     // t0[k] = T.m[0][k], t1[k] = T.m[1][k]  (k = 0..2): the two rows of J applied to the columns of the view rotation
     const R j00 = fx * iz, j02 = -(fx * tx) * iz2, j11 = fy * iz, j12 = -(fy * ty) * iz2;
-    const R w[3][3] = {{vm[0], vm[4], vm[8]}, {vm[1], vm[5], vm[9]}, {vm[2], vm[6], vm[10]}};     // W.m[c][r] of compute_cov2d
+#define w_(c_, r_) ((R)vm[(c_) + 4 * (r_)])                // W.m[c][r] of compute_cov2d = vm[c + 4 r]; converted at each use (uniform: one v_cvt)
     R t0[3], t1[3];
 #pragma unroll
-    for (int k = 0; k < 3; k++) { t0[k] = w[0][k] * j00 + w[2][k] * j02; t1[k] = w[1][k] * j11 + w[2][k] * j12; }
+    for (int k = 0; k < 3; k++) { t0[k] = w_(0, k) * j00 + w_(2, k) * j02; t1[k] = w_(1, k) * j11 + w_(2, k) * j12; }
     const R v[3][3] = {{cov3d[0], cov3d[1], cov3d[2]}, {cov3d[1], cov3d[3], cov3d[4]}, {cov3d[2], cov3d[4], cov3d[5]}};
     R r0[3], r1[3];                                        // V t0, V t1
 #pragma unroll
@@ -735,47 +738,56 @@ __device__ __forceinline__ void cov_chain_bwd_f64(float mxf, float myf, float mz
     const R g0 = dLconic[0], g1 = dLconic[1], g2 = dLconic[2];
     const R denom = ca * cc - cb * cb;
     const R d2i = 1.0 / (denom * denom + (R)0.0000001f);
-    R dLa = 0, dLb = 0, dLc = 0, dc[6] = {0, 0, 0, 0, 0, 0};
+    R dLa = 0, dLb = 0, dLc = 0;
+    if (!ACCUMULATE) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) dc[k] = 0;
+    }
     if (d2i != 0) {
         dLa = d2i * (-cc * cc * g0 + 2 * cb * cc * g1 + (denom - ca * cc) * g2);
         dLc = d2i * (-ca * ca * g2 + 2 * ca * cb * g1 + (denom - ca * cc) * g0);
         dLb = d2i * 2 * (cb * cc * g0 - (denom + 2 * cb * cb) * g1 + ca * cb * g2);
-        dc[0] = t0[0] * t0[0] * dLa + t0[0] * t1[0] * dLb + t1[0] * t1[0] * dLc;
-        dc[3] = t0[1] * t0[1] * dLa + t0[1] * t1[1] * dLb + t1[1] * t1[1] * dLc;
-        dc[5] = t0[2] * t0[2] * dLa + t0[2] * t1[2] * dLb + t1[2] * t1[2] * dLc;
-        dc[1] = 2 * t0[0] * t0[1] * dLa + (t0[0] * t1[1] + t0[1] * t1[0]) * dLb + 2 * t1[0] * t1[1] * dLc;
-        dc[2] = 2 * t0[0] * t0[2] * dLa + (t0[0] * t1[2] + t0[2] * t1[0]) * dLb + 2 * t1[0] * t1[2] * dLc;
-        dc[4] = 2 * t0[2] * t0[1] * dLa + (t0[1] * t1[2] + t0[2] * t1[1]) * dLb + 2 * t1[1] * t1[2] * dLc;
+        dc[0] += t0[0] * t0[0] * dLa + t0[0] * t1[0] * dLb + t1[0] * t1[0] * dLc;
+        dc[3] += t0[1] * t0[1] * dLa + t0[1] * t1[1] * dLb + t1[1] * t1[1] * dLc;
+        dc[5] += t0[2] * t0[2] * dLa + t0[2] * t1[2] * dLb + t1[2] * t1[2] * dLc;
+        dc[1] += 2 * t0[0] * t0[1] * dLa + (t0[0] * t1[1] + t0[1] * t1[0]) * dLb + 2 * t1[0] * t1[1] * dLc;
+        dc[2] += 2 * t0[0] * t0[2] * dLa + (t0[0] * t1[2] + t0[2] * t1[0]) * dLb + 2 * t1[0] * t1[2] * dLc;
+        dc[4] += 2 * t0[2] * t0[1] * dLa + (t0[1] * t1[2] + t0[2] * t1[1]) * dLb + 2 * t1[1] * t1[2] * dLc;
     }
     // dL_dT (backward.cu:231-242): dT0[k] = 2 (V t0)[k] dLa + (V t1)[k] dLb,  dT1[k] = 2 (V t1)[k] dLc + (V t0)[k] dLb
     R dT0[3], dT1[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) { dT0[k] = 2 * r0[k] * dLa + r1[k] * dLb; dT1[k] = 2 * r1[k] * dLc + r0[k] * dLb; }
-    const R dJ00 = w[0][0] * dT0[0] + w[0][1] * dT0[1] + w[0][2] * dT0[2];
-    const R dJ02 = w[2][0] * dT0[0] + w[2][1] * dT0[1] + w[2][2] * dT0[2];
-    const R dJ11 = w[1][0] * dT1[0] + w[1][1] * dT1[1] + w[1][2] * dT1[2];
-    const R dJ12 = w[2][0] * dT1[0] + w[2][1] * dT1[1] + w[2][2] * dT1[2];
+    const R dJ00 = w_(0, 0) * dT0[0] + w_(0, 1) * dT0[1] + w_(0, 2) * dT0[2];
+    const R dJ02 = w_(2, 0) * dT0[0] + w_(2, 1) * dT0[1] + w_(2, 2) * dT0[2];
+    const R dJ11 = w_(1, 0) * dT1[0] + w_(1, 1) * dT1[1] + w_(1, 2) * dT1[2];
+    const R dJ12 = w_(2, 0) * dT1[0] + w_(2, 1) * dT1[1] + w_(2, 2) * dT1[2];
     const R dtx = xg * -fx * iz2 * dJ02, dty = yg * -fy * iz2 * dJ12;
     const R dtz = -fx * iz2 * dJ00 - fy * iz2 * dJ11 + (2 * fx * tx) * iz3 * dJ02 + (2 * fy * ty) * iz3 * dJ12;
-    R dm[3] = {vm[0] * dtx + vm[1] * dty + vm[2] * dtz, vm[4] * dtx + vm[5] * dty + vm[6] * dtz, vm[8] * dtx + vm[9] * dty + vm[10] * dtz};
-    // the projection part (backward.cu:369-387) is well-conditioned: fp32, in the reference's operation order
+    // the view-space part rounded once; the projection part (backward.cu:369-387) is well-conditioned: fp32, in the reference's operation order
+    const float dm0 = (float)(vm[0] * dtx + vm[1] * dty + vm[2] * dtz), dm1 = (float)(vm[4] * dtx + vm[5] * dty + vm[6] * dtz), dm2 = (float)(vm[8] * dtx + vm[9] * dty + vm[10] * dtz);
     const float* pj = PM.m;
     const float m_w = 1.0f / ((pj[3] * mxf + pj[7] * myf + pj[11] * mzf + pj[15]) + 0.0000001f);
     const float mul1 = (pj[0] * mxf + pj[4] * myf + pj[8] * mzf + pj[12]) * m_w * m_w, mul2 = (pj[1] * mxf + pj[5] * myf + pj[9] * mzf + pj[13]) * m_w * m_w;
-    dm[0] += (R)((pj[0] * m_w - pj[3] * mul1) * g2xf + (pj[1] * m_w - pj[3] * mul2) * g2yf);
-    dm[1] += (R)((pj[4] * m_w - pj[7] * mul1) * g2xf + (pj[5] * m_w - pj[7] * mul2) * g2yf);
-    dm[2] += (R)((pj[8] * m_w - pj[11] * mul1) * g2xf + (pj[9] * m_w - pj[11] * mul2) * g2yf);
-#pragma unroll
-    for (int k = 0; k < 3; k++) dmean[k] = (float)dm[k];
-#pragma unroll
-    for (int k = 0; k < 6; k++) dcov[k] = (float)dc[k];
-    if (HAS_SCALE_ROT) {
-        // computeCov3D backward (backward.cu:278-341): M = S R, dM = (2 M) dSig, dMt = dM^T in GLM's column-major products
+    dmean[0] = dm0 + ((pj[0] * m_w - pj[3] * mul1) * g2xf + (pj[1] * m_w - pj[3] * mul2) * g2yf);
+    dmean[1] = dm1 + ((pj[4] * m_w - pj[7] * mul1) * g2xf + (pj[5] * m_w - pj[7] * mul2) * g2yf);
+    dmean[2] = dm2 + ((pj[8] * m_w - pj[11] * mul1) * g2xf + (pj[9] * m_w - pj[11] * mul2) * g2yf);
+#undef w_
+}
+
+// (2) computeCov3D backward (backward.cu:278-341): M = S R, dM = (2 M) dSig, dMt = dM^T in GLM's column-major products.  LINEAR in dc and
+// independent of the view: the batch kernels run it ONCE on the sum of the views' dc (the reference runs it per view and lets autograd add
+// the results: the same sum up to fp32 rounding of the addends).
+__device__ __forceinline__ void cov3d_bwd_f64(const double (&dc)[6], float scale_modifier, const float* __restrict__ scales3, const float* __restrict__ rot4,
+                                              float (&dscale)[3], float (&drot)[4])
+{
+    typedef double R;
+    {
         const R q0 = rot4[0], qx = rot4[1], qy = rot4[2], qz = rot4[3];
         const R Rg[3][3] = {{1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - q0 * qz), 2 * (qx * qz + q0 * qy)},
                             {2 * (qx * qy + q0 * qz), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - q0 * qx)},
                             {2 * (qx * qz - q0 * qy), 2 * (qy * qz + q0 * qx), 1 - 2 * (qx * qx + qy * qy)}};      // Rg[c][w]: GLM column c, row w
-        const R sc[3] = {(R)cam.scale_modifier * (R)scales3[0], (R)cam.scale_modifier * (R)scales3[1], (R)cam.scale_modifier * (R)scales3[2]};
+        const R sc[3] = {(R)scale_modifier * (R)scales3[0], (R)scale_modifier * (R)scales3[1], (R)scale_modifier * (R)scales3[2]};
         const R dS[3][3] = {{dc[0], 0.5 * dc[1], 0.5 * dc[2]}, {0.5 * dc[1], dc[3], 0.5 * dc[4]}, {0.5 * dc[2], 0.5 * dc[4], dc[5]}};
         // GLM product (a * b).m[c][w] = sum_k a.m[k][w] b.m[c][k]; S is diagonal, so Mx = S * R has Mx.m[c][w] = s_w Rg[c][w]
         // dMt.m[c][w] = dM.m[w][c] = sum_k 2 s_c Rg[k][c] dS[w][k], formed column by column; dscale[c] needs column c before, the
@@ -813,13 +825,16 @@ __device__ __forceinline__ void cov_chain_bwd_f64(float mxf, float myf, float mz
 struct GaussTerms {
     float a[NACC];                 // sums of the tile partials: colour rgb, mean2D xy, conic xx xy yy, opacity
     float dmean[3], dcov[6], dscale[3], drot[4];
+
     float coef[16], dRGB[3];       // dL_dsh[k][c] = coef[k] * dRGB[c]
 };
 
+// TGS_PERGAUSS_F64: dL_dcov3D of the view is ADDED to dcacc (double; the caller's running sum over the views) and the scale / rotation
+// gradients are left to the caller (finish_cov3d, once behind the view loop); t.dcov / t.dscale / t.drot stay zero
 template <bool HAS_SH, bool HAS_SCALE_ROT, typename ShRow>
 __device__ __forceinline__ void pergauss_terms(int idx, bool live, int D, const ShRow& sh, const BwdIn& in, const float* __restrict__ cov3D_precomp,
                                                const CamParams& cam, const ViewMat& V, const ViewMat& PM, float camx, float camy, float camz,
-                                               const GeomState& g, const BinState& b, uint32_t tiles_in, uint32_t off_in, GaussTerms& t)
+                                               const GeomState& g, const BinState& b, uint32_t tiles_in, uint32_t off_in, GaussTerms& t, double (&dcacc)[6])
 {
     float (&a)[NACC] = t.a;
     float (&dmean)[3] = t.dmean; float (&dcov)[6] = t.dcov; float (&dscale)[3] = t.dscale; float (&drot)[4] = t.drot;
@@ -843,8 +858,7 @@ __device__ __forceinline__ void pergauss_terms(int idx, bool live, int D, const 
         const float* csrc = HAS_SCALE_ROT ? (g.cov3D + 6 * (size_t)idx) : (cov3D_precomp + 6 * (size_t)idx);
 #pragma unroll
         for (int i = 0; i < 6; i++) cov3d[i] = csrc[i];
-        cov_chain_bwd_f64<HAS_SCALE_ROT>(mx, my, mz, cov3d, cam, V, PM, cn, a[3], a[4], HAS_SCALE_ROT ? in.scales + i3 : nullptr,
-                                         HAS_SCALE_ROT ? in.rotations + 4 * (size_t)idx : nullptr, dmean, dcov, dscale, drot);
+        cov2d_chain_bwd_f64<true>(mx, my, mz, cov3d, cam, V, PM, cn, a[3], a[4], dmean, dcacc);
     }
 #else
     {
@@ -946,6 +960,18 @@ __device__ __forceinline__ void pergauss_terms(int idx, bool live, int D, const 
             asm volatile("" ::: "memory");            // keep the 48 SH reads below from being hoisted over the covariance math (VGPR pressure)
             sh_backward_terms(D, sh, g.clamped[idx], a[0], a[1], a[2], mx, my, mz, camx, camy, camz, coef, dRGB, dmean);
     }
+}
+
+// behind the view loop of a batch kernel: dL_dcov3D = the double sum rounded once, and the scale / rotation gradients from that sum
+template <bool HAS_SCALE_ROT>
+__device__ __forceinline__ void finish_cov3d(const BwdIn& in, float scale_modifier, int idx, bool in_range, const double (&dcsum)[6], float (&dcov)[6], float (&dscale)[3],
+                                             float (&drot)[4])
+{
+#if TGS_PERGAUSS_F64
+#pragma unroll
+    for (int k = 0; k < 6; k++) dcov[k] = (float)dcsum[k];
+    if (HAS_SCALE_ROT && in_range) cov3d_bwd_f64(dcsum, scale_modifier, in.scales + 3 * (size_t)idx, in.rotations + 4 * (size_t)idx, dscale, drot);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1068,8 +1094,11 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
             const float* csrc = HAS_SCALE_ROT ? (g.cov3D + 6 * (size_t)idx) : (in.cov3D_precomp + 6 * (size_t)idx);
 #pragma unroll
             for (int i = 0; i < 6; i++) cov3d[i] = csrc[i];
-            cov_chain_bwd_f64<HAS_SCALE_ROT>(mx, my, mz, cov3d, cam, V, PM, cn, a[3], a[4], HAS_SCALE_ROT ? in.scales + i3 : nullptr,
-                                             HAS_SCALE_ROT ? in.rotations + 4 * (size_t)idx : nullptr, dmean, dcov, dscale, drot);
+            double dc64[6];
+            cov2d_chain_bwd_f64<false>(mx, my, mz, cov3d, cam, V, PM, cn, a[3], a[4], dmean, dc64);
+#pragma unroll
+            for (int k = 0; k < 6; k++) dcov[k] = (float)dc64[k];
+            if (HAS_SCALE_ROT) cov3d_bwd_f64(dc64, cam.scale_modifier, in.scales + i3, in.rotations + 4 * (size_t)idx, dscale, drot);
         }
 #else
         // ---- computeCov2DCUDA (backward.cu:144-274) ----
@@ -1329,6 +1358,7 @@ __global__ __launch_bounds__(PRE_BLOCK, 2) void k_preprocess_bwd_batch(const Bwd
 #pragma unroll
     for (int i = 0; i < 48; i++) o48[i] = 0.f;
     float dopacity = 0.f, dmean[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dscale[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
+    double dcsum[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};      // dL_dcov3D summed over the views in double (TGS_PERGAUSS_F64: cov3d_bwd_f64 runs once, behind the loop)
 #pragma unroll 1
     for (int v = 0; v < views.n; v++) {
         const BatchView& vw = views.v[v];
@@ -1338,7 +1368,7 @@ __global__ __launch_bounds__(PRE_BLOCK, 2) void k_preprocess_bwd_batch(const Bwd
         if (__builtin_amdgcn_ballot_w64(live) != 0) {
             const ViewMat V = load_mat(vw.cam.view), PM = load_mat(vw.cam.proj);
             pergauss_terms<HAS_SH, HAS_SCALE_ROT>(idx, live, in.D, [&](int i) { return sh_row[i]; }, in, in.cov3D_precomp, vw.cam, V, PM, vw.cam.campos[0], vw.cam.campos[1],
-                                                  vw.cam.campos[2], vw.g, vw.b, pv_lds[v][1][threadIdx.x], pv_lds[v][2][threadIdx.x], t);
+                                                  vw.cam.campos[2], vw.g, vw.b, pv_lds[v][1][threadIdx.x], pv_lds[v][2][threadIdx.x], t, dcsum);
         } else {
             t.a[0] = t.a[1] = t.a[2] = t.a[3] = t.a[4] = 0.f;
         }
@@ -1351,8 +1381,10 @@ __global__ __launch_bounds__(PRE_BLOCK, 2) void k_preprocess_bwd_batch(const Bwd
             dopacity += t.a[8];
 #pragma unroll
             for (int k = 0; k < 3; k++) { dmean[k] += t.dmean[k]; dscale[k] += t.dscale[k]; }
+#if !TGS_PERGAUSS_F64
 #pragma unroll
             for (int k = 0; k < 6; k++) dcov[k] += t.dcov[k];
+#endif
 #pragma unroll
             for (int k = 0; k < 4; k++) drot[k] += t.drot[k];
             if (HAS_SH) {
@@ -1361,6 +1393,7 @@ __global__ __launch_bounds__(PRE_BLOCK, 2) void k_preprocess_bwd_batch(const Bwd
             }
         }
     }
+    finish_cov3d<HAS_SCALE_ROT>(in, views.v[0].cam.scale_modifier, idx, in_range, dcsum, dcov, dscale, drot);
     if (HAS_SH) {
         if (sh_staged) store_sh_rows_staged(in, sh_lds, [&](int i) { return o48[i]; }, blk);
         else if (in_range) {
@@ -1474,6 +1507,7 @@ __global__ __launch_bounds__(PRE_BLOCK, TGS_SPLIT_WAVES) void k_preprocess_bwd_b
         __syncthreads();                                   // (B) the dL_dsh rows are staged
     } else {
         float dopacity = 0.f, dmean[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dscale[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
+        double dcsum[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll 1
         for (int v = 0; v < views.n; v++) {
             const BatchView& vw = views.v[v];
@@ -1483,7 +1517,7 @@ __global__ __launch_bounds__(PRE_BLOCK, TGS_SPLIT_WAVES) void k_preprocess_bwd_b
             if (__builtin_amdgcn_ballot_w64(live) != 0) {
                 const ViewMat V = load_mat(vw.cam.view), PM = load_mat(vw.cam.proj);
                 pergauss_terms<false, HAS_SCALE_ROT>(idx, live, in.D, [&](int) { return 0.f; }, in, in.cov3D_precomp, vw.cam, V, PM, vw.cam.campos[0], vw.cam.campos[1],
-                                                     vw.cam.campos[2], vw.g, vw.b, pv_lds[v][1][gl], pv_lds[v][2][gl], t);
+                                                     vw.cam.campos[2], vw.g, vw.b, pv_lds[v][1][gl], pv_lds[v][2][gl], t, dcsum);
             } else {
                 t.a[3] = t.a[4] = 0.f;
             }
@@ -1495,12 +1529,15 @@ __global__ __launch_bounds__(PRE_BLOCK, TGS_SPLIT_WAVES) void k_preprocess_bwd_b
                 dopacity += t.a[8];
 #pragma unroll
                 for (int k = 0; k < 3; k++) { dmean[k] += t.dmean[k]; dscale[k] += t.dscale[k]; }
+#if !TGS_PERGAUSS_F64
 #pragma unroll
                 for (int k = 0; k < 6; k++) dcov[k] += t.dcov[k];
+#endif
 #pragma unroll
                 for (int k = 0; k < 4; k++) drot[k] += t.drot[k];
             }
         }
+        finish_cov3d<HAS_SCALE_ROT>(in, views.v[0].cam.scale_modifier, idx, in_range, dcsum, dcov, dscale, drot);
         __syncthreads();                                   // (A)
         if (in_range) {
             dmean[0] += dm_lds[0][gl]; dmean[1] += dm_lds[1][gl]; dmean[2] += dm_lds[2][gl];

@@ -58,6 +58,9 @@ struct GeomState {
     uint32_t* tiles_touched;  //                                    (geomState.tiles_touched)
     uint32_t* offsets;        // EXCLUSIVE scan of tiles_touched    (geomState.point_offsets is inclusive)
     uint32_t* block_sums;     // per PRE_BLOCK partial sums / their exclusive scan
+    uint32_t* block_flags;    // per PRE_BLOCK: 1 if a Gaussian of the block was culled although `prefiltered` is set (auxiliary.h:156-160); every
+                              // block of k_preprocess_fwd* writes its own word and k_scan ORs them into Meta::error -- no atomic on Meta
+                              // before the scan, so the preprocess kernel itself can clear Meta (no memset launch in front of a frame)
 };
 struct ImgState {
     Meta* meta;
@@ -100,7 +103,7 @@ __host__ __device__ inline size_t geom_carve(GeomState& g, char* base, size_t P,
     (void)has_sh;
     carve(p, g.pack, 4 * P); carve(p, g.live, P); carve(p, g.depth, P); carve(p, g.cov3D, has_scale_rot ? 6 * P : 0);
     carve(p, g.clamped, P); carve(p, g.rect, P); carve(p, g.tiles_touched, P); carve(p, g.offsets, P);
-    carve(p, g.block_sums, n_blocks(P) + 1);
+    carve(p, g.block_sums, n_blocks(P) + 1); carve(p, g.block_flags, n_blocks(P) + 1);
     return (size_t)(p - base) + 256;
 }
 __host__ __device__ inline size_t img_carve(ImgState& s, char* base, size_t N, size_t T)
@@ -360,6 +363,16 @@ __device__ __forceinline__ void stage_conic_b(float4& rb) { rb.x *= -0.5f * LOG2
 constexpr unsigned long long QUAD_LT1 = 0x1111111111111111ull;   // lanes with (lane & 3) < 1
 constexpr unsigned long long QUAD_LT2 = 0x3333333333333333ull;
 constexpr unsigned long long QUAD_LT3 = 0x7777777777777777ull;
+// The three lane masks as OPAQUE values in SGPR pairs, made once per kernel (round 4): handed to the chains as literal constants, the
+// compiler re-assembled each 64-bit mask from its 32-bit half inside the render loops -- three s_mov_b32 per pass beside the three
+// s_mov_b64 vcc the chain itself needs (k_render_fwd: 25 scalar instructions beside 33 vector ones per pass, VERDICT of round 3).
+struct QuadMasks { unsigned long long lt1, lt2, lt3; };
+__device__ __forceinline__ QuadMasks quad_masks()
+{
+    QuadMasks m{QUAD_LT1, QUAD_LT2, QUAD_LT3};
+    asm volatile("" : "+s"(m.lt1), "+s"(m.lt2), "+s"(m.lt3));
+    return m;
+}
 
 // Back-to-front walk of one pixel through the 4 entries held by the lanes of its quad (backward.cu:505-531), for the ONE scalar
 // the backward needs from accum_rec: dL_dalpha = sum_ch (c_ch - accum_rec_ch) * dL_dpixel_ch (backward.cu:520-527) = s - A with
@@ -370,7 +383,7 @@ constexpr unsigned long long QUAD_LT3 = 0x7777777777777777ull;
 //   out: Town = T after this lane's entry, inv = 1/(1-a), Aown = A seen by this lane's entry; T / A advanced
 // Lane e applies entries 0..e-1 in order (one rounding per step); lanes with e <= k take the identity (1, 0) for step k through
 // v_cndmask_b32_dpp.
-__device__ __forceinline__ void bwd_chain4s(float a, float s, float& T, float& A, float& Town, float& inv, float& Aown, float one, float zero)
+__device__ __forceinline__ void bwd_chain4s(float a, float s, float& T, float& A, float& Town, float& inv, float& Aown, float one, float zero, const QuadMasks& qm)
 {
     float om, m, so, t, q;
 #define TGS_STEP(K, LT, SRC, QINIT)                                                           \
@@ -394,7 +407,7 @@ __device__ __forceinline__ void bwd_chain4s(float a, float s, float& T, float& A
         "v_mov_b32_dpp %[T], %[Town]" TGS_QP(3)
         : [om] "=&v"(om), [m] "=&v"(m), [so] "=&v"(so), [t] "=&v"(t), [q] "=&v"(q), [Town] "=&v"(Town), [inv] "=&v"(inv), [o] "=&v"(Aown),
           [T] "+v"(T), [A] "+v"(A)
-        : [a] "v"(a), [s] "v"(s), [one] "v"(one), [zero] "v"(zero), [lt1] "s"(QUAD_LT1), [lt2] "s"(QUAD_LT2), [lt3] "s"(QUAD_LT3)
+        : [a] "v"(a), [s] "v"(s), [one] "v"(one), [zero] "v"(zero), [lt1] "s"(qm.lt1), [lt2] "s"(qm.lt2), [lt3] "s"(qm.lt3)
         : "vcc");
 #undef TGS_STEP
 }
@@ -403,7 +416,7 @@ __device__ __forceinline__ void bwd_chain4s(float a, float s, float& T, float& A
 // entry (1 for a skipped one), T = transmittance in front of the group (uniform over the quad).
 //   y = T * p_0 * ... * p_{e-1}  (transmittance in front of this lane's entry, the reference's left-to-right products),
 //   x = y * p_e                   (the reference's test_T).
-__device__ __forceinline__ void fwd_chain4(float p, float T, float& y, float& x, float one)
+__device__ __forceinline__ void fwd_chain4(float p, float T, float& y, float& x, float one, const QuadMasks& qm)
 {
     asm volatile(
         "s_mov_b64 vcc, %[lt1]\n\t"
@@ -418,7 +431,7 @@ __device__ __forceinline__ void fwd_chain4(float p, float T, float& y, float& x,
         "v_mul_f32 %[y], %[y], %[x]\n\t"
         "v_mul_f32 %[x], %[y], %[p]\n\t"
         : [y] "=&v"(y), [x] "=&v"(x)
-        : [p] "v"(p), [T] "v"(T), [one] "v"(one), [lt1] "s"(QUAD_LT1), [lt2] "s"(QUAD_LT2), [lt3] "s"(QUAD_LT3)
+        : [p] "v"(p), [T] "v"(T), [one] "v"(one), [lt1] "s"(qm.lt1), [lt2] "s"(qm.lt2), [lt3] "s"(qm.lt3)
         : "vcc");
 }
 // c <- max of c over the quad; x3 <- x of the quad's lane 3
@@ -800,6 +813,8 @@ struct FwdIn {
     float* out_color;
     int* radii;
     int prune;        // 1 (default): rectangle tiles the splat cannot reach with alpha >= 1/255 get no instance (tgs_set_instance_pruning)
+    int defer_colour; // 1: the SH colours of this frame are evaluated by k_sh_colors_deferred on a side stream (tgs_api.hip): the per-Gaussian
+                      // stage runs WITHOUT the 192-B SH rows and leaves the colour slots of the pack line at zero
 };
 struct BwdIn {
     int P, D, M;

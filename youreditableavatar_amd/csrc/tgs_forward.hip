@@ -153,7 +153,7 @@ struct PreColor { bool valid; float c0, c1, c2; uint32_t clampbits; };
 
 template <bool HAS_SH, bool HAS_SCALE_ROT>
 __device__ __forceinline__ uint32_t preprocess_fwd_one(const FwdIn& in, int* __restrict__ radii, const CamParams& cam, const GeomState& g, const ImgState& s,
-                                                       const float4* sh_lds, bool sh_staged, int idx, const PreColor& pre)
+                                                       const float4* sh_lds, bool sh_staged, int idx, const PreColor& pre, bool& prefilter_violation)
 {
 #pragma clang fp contract(off)      // projection, covariance, radius and colour un-fused: the oracle's (and the reference's source's) operation order
     uint32_t tiles = 0;
@@ -173,7 +173,7 @@ __device__ __forceinline__ uint32_t preprocess_fwd_one(const FwdIn& in, int* __r
         const float* vm = V.m;
         const float view_z = vm[2] * mx + vm[6] * my + vm[10] * mz + vm[14];
         bool ok = !(view_z <= 0.2f);
-        if (!ok && in.prefiltered) atomicOr(&s.meta->error, 1u);
+        prefilter_violation = !ok && in.prefiltered;      // -> GeomState::block_flags (block_sum_tiles), OR-ed into Meta::error by k_scan
         if (ok) {
             float cov3d[6];
             if (HAS_SCALE_ROT) {
@@ -230,8 +230,10 @@ __device__ __forceinline__ uint32_t preprocess_fwd_one(const FwdIn& in, int* __r
                             sh_to_color(in.D, shv, mx - camx, my - camy, mz - camz, col0, col1, col2, clampbits);
                             g.clamped[idx] = (uint8_t)clampbits;
                         }
-                    } else {
+                    } else if (in.colors_precomp) {
                         col0 = in.colors_precomp[3 * (size_t)idx]; col1 = in.colors_precomp[3 * (size_t)idx + 1]; col2 = in.colors_precomp[3 * (size_t)idx + 2];
+                    } else {
+                        col0 = col1 = col2 = 0.f;              // FwdIn::defer_colour: k_sh_colors_deferred fills the slots (and g.clamped) behind this kernel
                     }
                     g.depth[idx] = view_z;
                     my_radius_i = (int)my_radius;
@@ -275,14 +277,21 @@ __device__ __forceinline__ uint32_t preprocess_fwd_one(const FwdIn& in, int* __r
     return tiles;
 }
 
-// per-block sum of tiles_touched (first level of the offsets scan)
-__device__ __forceinline__ void block_sum_tiles(uint32_t tiles, uint32_t* __restrict__ block_sums)
+// per-block sum of tiles_touched (first level of the offsets scan) and the block's prefiltered-violation flag; block 0 also clears the
+// frame's Meta (nothing else touches Meta before k_scan: the host-side memset in front of every frame is gone)
+__device__ __forceinline__ void block_sum_tiles(uint32_t tiles, bool violation, const GeomState& g, const ImgState& s)
 {
     __shared__ uint32_t wsum[PRE_BLOCK / WAVE];
+    __shared__ uint32_t wflag[PRE_BLOCK / WAVE];
     const uint32_t w = wave_sum_u32(tiles);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = w;
+    const bool any = __builtin_amdgcn_ballot_w64(violation) != 0ull;
+    if ((threadIdx.x & 63) == 0) { wsum[threadIdx.x >> 6] = w; wflag[threadIdx.x >> 6] = any ? 1u : 0u; }
     __syncthreads();
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (threadIdx.x == 0) {
+        g.block_sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        g.block_flags[blockIdx.x] = wflag[0] | wflag[1] | wflag[2] | wflag[3];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < sizeof(Meta) / sizeof(uint32_t)) reinterpret_cast<uint32_t*>(s.meta)[threadIdx.x] = 0u;
 }
 
 // SH rows of the workgroup's 256 Gaussians (M = 16: 192 B each, 48 KB in all) are fetched with fully coalesced
@@ -353,8 +362,29 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd(const FwdIn in, co
     PreColor pre[1];
     pre[0].valid = false;
     if (HAS_SH && in.M == 16) sh_colors_half_staged<1>(in, &vw, idx, sh_lds, pre);
-    const uint32_t tiles = preprocess_fwd_one<HAS_SH, HAS_SCALE_ROT>(in, vw.radii, vw.cam, vw.g, vw.s, sh_lds, false, idx, pre[0]);
-    block_sum_tiles(tiles, vw.g.block_sums);
+    bool bad = false;
+    const uint32_t tiles = preprocess_fwd_one<HAS_SH, HAS_SCALE_ROT>(in, vw.radii, vw.cam, vw.g, vw.s, sh_lds, false, idx, pre[0], bad);
+    block_sum_tiles(tiles, bad, vw.g, vw.s);
+}
+
+// The SH colours of ONE view apart from its geometry (single-view forwards, tgs_api.hip: forward_impl).  preprocessCUDA reads 236 B per
+// Gaussian of which 192 are the SH row, needed by nothing before k_finalize -- while the binning chain behind the per-Gaussian stage
+// (k_bin_count -> k_bin_colscan -> k_scan -> k_scatter, ~55 us at config 3) keeps at most 128 workgroups on a 256-CU chip.  So the
+// per-Gaussian stage runs without the rows (k_preprocess_fwd<false, .> with FwdIn::defer_colour) and this kernel evaluates the colours
+// on a library-owned side stream BEHIND it and UNDER the chain: it stores 12 B into each pack line (slots r, g, b, which the geometry
+// kernel left at zero -- hence behind it) and the clamp bits; k_finalize waits for it.  Same arithmetic, same bits (sh_to_color).
+__global__ __launch_bounds__(PRE_BLOCK) void k_sh_colors_deferred(const FwdIn in, const FwdView vw)
+{
+    const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
+    __shared__ float4 sh_lds[SH_HALF * 12];
+    PreColor pre[1];
+    sh_colors_half_staged<1>(in, &vw, idx, sh_lds, pre);   // (a Gaussian behind the near plane keeps colour 0: its pack line is never read)
+    if (idx < in.P) {
+        float* pk = reinterpret_cast<float*>(vw.g.pack + 4 * (size_t)idx);
+        *reinterpret_cast<float2*>(pk + 6) = make_float2(pre[0].c0, pre[0].c1);     // pack[4 idx + 1].zw
+        pk[8] = pre[0].c2;                                                          // pack[4 idx + 2].x
+        vw.g.clamped[idx] = (uint8_t)pre[0].clampbits;
+    }
 }
 
 // Two views of a batch in one launch (tgs_forward_views, the default group): the 192-B SH row -- more than half of what the stage
@@ -371,8 +401,9 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd_pair(const FwdIn i
 #pragma unroll
     for (int v = 0; v < 2; v++) {
         const FwdView& vw = v == 0 ? v0 : v1;
-        const uint32_t tiles = preprocess_fwd_one<HAS_SH, HAS_SCALE_ROT>(in, vw.radii, vw.cam, vw.g, vw.s, sh_lds, false, idx, pre[v]);
-        block_sum_tiles(tiles, vw.g.block_sums);
+        bool bad = false;
+        const uint32_t tiles = preprocess_fwd_one<HAS_SH, HAS_SCALE_ROT>(in, vw.radii, vw.cam, vw.g, vw.s, sh_lds, false, idx, pre[v], bad);
+        block_sum_tiles(tiles, bad, vw.g, vw.s);
         __syncthreads();                                   // wsum is reused by the next view
     }
 }
@@ -391,8 +422,9 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd_batch(const FwdIn 
 #pragma unroll 1
     for (int v = 0; v < views.n; v++) {
         const FwdView& vw = views.v[v];
-        const uint32_t tiles = preprocess_fwd_one<HAS_SH, HAS_SCALE_ROT>(in, vw.radii, vw.cam, vw.g, vw.s, sh_lds, sh_staged, idx, pre);
-        block_sum_tiles(tiles, vw.g.block_sums);
+        bool bad = false;
+        const uint32_t tiles = preprocess_fwd_one<HAS_SH, HAS_SCALE_ROT>(in, vw.radii, vw.cam, vw.g, vw.s, sh_lds, sh_staged, idx, pre, bad);
+        block_sum_tiles(tiles, bad, vw.g, vw.s);
         __syncthreads();                                   // wsum is reused by the next view
     }
 }
@@ -432,22 +464,25 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const 
     __shared__ uint32_t ovf_n;
     if (blockIdx.x == 0) {
         unsigned long long carry = 0;
+        uint32_t flags = 0;                                 // OR of the blocks' prefiltered-violation flags
         for (uint32_t base = 0; base < nblocks; base += SCAN_THREADS * SCAN_ITEMS) {
             uint32_t v[SCAN_ITEMS];
             unsigned long long sum = 0;
             const uint32_t i0 = base + threadIdx.x * SCAN_ITEMS;
 #pragma unroll
-            for (int k = 0; k < SCAN_ITEMS; k++) { v[k] = (i0 + k < nblocks) ? g.block_sums[i0 + k] : 0u; sum += v[k]; }
+            for (int k = 0; k < SCAN_ITEMS; k++) { v[k] = (i0 + k < nblocks) ? g.block_sums[i0 + k] : 0u; sum += v[k]; flags |= (i0 + k < nblocks) ? g.block_flags[i0 + k] : 0u; }
             unsigned long long tot;
             unsigned long long ex = block_exscan_u64(sum, lds, tot) + carry;
 #pragma unroll
             for (int k = 0; k < SCAN_ITEMS; k++) { if (i0 + k < nblocks) g.block_sums[i0 + k] = (uint32_t)ex; ex += v[k]; }
             carry += tot;
         }
+        const int any_flag = __syncthreads_or((int)flags);
         if (threadIdx.x == 0) {
             s.meta->R = carry;
-            uint32_t err = s.meta->error;                   // (bit 0: a prefiltered Gaussian was culled, set by k_preprocess_fwd)
-            if (carry > r_capacity) { atomicOr(&s.meta->error, META_ERR_CAPACITY); err |= META_ERR_CAPACITY; }   // tgs_forward_async: the frame does not fit
+            uint32_t err = any_flag ? 1u : 0u;              // bit 0: a prefiltered Gaussian was culled (k_preprocess_fwd* -> block_flags)
+            if (carry > r_capacity) err |= META_ERR_CAPACITY;                                                    // tgs_forward_async: the frame does not fit
+            if (err) atomicOr(&s.meta->error, err);         // (the tile pass of workgroup 1 may OR META_ERR_CAPACITY concurrently)
             if (host_meta) { host_meta->R = carry; host_meta->error = err; }
         }
     } else {
@@ -1018,16 +1053,24 @@ constexpr int FQ_NULL = FQ_CH;
 
 // one block, one staged round: this wave's pass over the entries of the round that reach its block (forward.cu:325-362
 // semantics: the kernel's header).  Returns true when the block's last live pixel ended.
+#ifndef TGS_FWD_LEAN_MASKS
+#define TGS_FWD_LEAN_MASKS 0
+#endif
 __device__ __forceinline__ bool fwd_q_block_round(const float4* sA, const float4* sB, const float* sC, const uint2* sQ, unsigned short* list,
                                                   unsigned short (*ql)[QL_ROW_F], uint32_t cnt, int blk, int lane, uint32_t cbase, float pixfx, float pixfy,
-                                                  float vone, bool& done, float& T, float& C0, float& C1, float& C2, uint32_t& last_contributor)
+                                                  float vone, const QuadMasks& qm, bool& done, float& T, float& C0, float& C1, float& C2, uint32_t& last_contributor)
 {
     const int qd = lane >> 4, e = lane & 3;
-    const uint32_t n = build_own_list_q<FQ_CH>(list, sQ, cnt, blk, lane);
+#if TGS_FWD_LEAN_MASKS
+    float nd = done ? 0.0f : 1.0f;
+#endif
+    // (both counts are wave-uniform -- sums of ballot popcounts -- but reach the loops in VGPRs: readfirstlane makes the loop tests scalar
+    // compares instead of lane-mask algebra on the exec mask, 7 scalar instructions per pass less)
+    const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)build_own_list_q<FQ_CH>(list, sQ, cnt, blk, lane));
     const unsigned short* myq = &ql[qd][e];
 #pragma unroll 1
     for (uint32_t c0 = 0; c0 < n; c0 += QCH_F) {
-        const uint32_t nq = build_chunk_quadrant_lists_128(ql, list, c0, n, lane, FQ_NULL);
+        const uint32_t nq = (uint32_t)__builtin_amdgcn_readfirstlane((int)build_chunk_quadrant_lists_128(ql, list, c0, n, lane, FQ_NULL));
 #pragma unroll 1
         for (uint32_t k = 0; k < nq; k += 4) {
             const uint32_t j = myq[k];
@@ -1042,10 +1085,34 @@ __device__ __forceinline__ bool fwd_q_block_round(const float4* sA, const float4
             const float power2 = -0.5f * (a.z * dx * dx + bb.x * dy * dy) - a.w * dx * dy;
             const float alpha = fminf(0.99f, bb.y * expf(power2));
 #endif
+#if TGS_FWD_LEAN_MASKS
+            // The same decisions with the lane masks kept out of the scalar unit (round 4).  `nd` = 1.0 while the pixel is open, 0.0 once it
+            // is done; a done pixel, a power > 0 and an alpha below 1/255 all end as a3 = 0 (-> 1 - a3 = 1.0 exactly, w = 0).  The
+            // termination test needs no `live &&`: T never falls below 1e-4 while a pixel is open (it closes on the first entry that would
+            // take it there), so x < 1e-4 can only be a live entry or a lane behind one in the same group -- whose y is smaller, and the
+            // quad maximum picks the first.  Every select reads the compare in front of it (vcc): no s_and / s_or / s_xor on 64-bit masks.
+            float al = alpha * nd;
+            al = (power2 > 0.0f) ? 0.0f : al;
+            const float a3 = (al < 1.0f / 255.0f) ? 0.0f : al;
+            const float pown = 1.0f - a3;
+            float y, x, x3;
+            fwd_chain4(pown, T, y, x, vone, qm);
+            const bool fail = x < 0.0001f;
+            float cand = fail ? y : -1.0f;
+            const float wy = a3 * y;
+            const float w = fail ? 0.0f : wy;
+            quad_max_bcast3(cand, x, x3);
+            C0 += bb.z * w; C1 += bb.w * w; C2 += cc * w;
+            last_contributor = (w > 0.0f) ? cbase + j : last_contributor;
+            const bool stop = cand >= 0.0f;
+            T = stop ? cand : x3;
+            nd = stop ? 0.0f : nd;
+            if (__builtin_amdgcn_ballot_w64(nd != 0.0f) == 0) { done = true; return true; }
+#else
             const bool live = !done && !(power2 > 0.0f) && !(alpha < 1.0f / 255.0f);
             const float pown = live ? 1.f - alpha : 1.0f;
             float y, x, x3;
-            fwd_chain4(pown, T, y, x, vone);
+            fwd_chain4(pown, T, y, x, vone, qm);
             const bool fail = live && (x < 0.0001f);
             const bool upd = live && !fail;
             float cand = fail ? y : -1.0f;
@@ -1057,8 +1124,12 @@ __device__ __forceinline__ bool fwd_q_block_round(const float4* sA, const float4
             T = stop ? cand : x3;
             done = done || stop;
             if (__builtin_amdgcn_ballot_w64(!done) == 0) return true;
+#endif
         }
     }
+#if TGS_FWD_LEAN_MASKS
+    done = nd == 0.0f;
+#endif
     return false;
 }
 
@@ -1112,6 +1183,7 @@ __global__ __launch_bounds__(FQ_THREADS, 8) void k_render_fwd(const ImgState s, 
     const int qd = lane >> 4, pq = (lane >> 2) & 3;
     float vone = 1.0f;
     asm volatile("" : "+v"(vone));
+    const QuadMasks qm = quad_masks();
     if (threadIdx.x == 0) { sA[FQ_NULL] = make_float4(0.f, 0.f, 0.f, 0.f); sB[FQ_NULL] = make_float4(0.f, 0.f, 0.f, 0.f); sC[FQ_NULL] = 0.f; }
 
     if (blockIdx.x >= heavy_wgs) {
@@ -1149,7 +1221,7 @@ __global__ __launch_bounds__(FQ_THREADS, 8) void k_render_fwd(const ImgState s, 
             if (__builtin_amdgcn_ballot_w64(!done) == 0) continue;      // a block outside the image
             float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
             uint32_t last_contributor = 0;
-            fwd_q_block_round(sA, sB, sC, sQ, lists[wv], qlists[wv], n, blk, lane, 1u, (float)px, (float)py, vone, done, T, C0, C1, C2, last_contributor);
+            fwd_q_block_round(sA, sB, sC, sQ, lists[wv], qlists[wv], n, blk, lane, 1u, (float)px, (float)py, vone, qm, done, T, C0, C1, C2, last_contributor);
             wq = max(wq, fwd_q_block_store(s, out_color, W, H, px, py, inside, lane, bg0, bg1, bg2, T, C0, C1, C2, last_contributor));
         }
         if (lane == 0) wave_qmax[wv] = wq;
@@ -1209,7 +1281,7 @@ __global__ __launch_bounds__(FQ_THREADS, 8) void k_render_fwd(const ImgState s, 
         }
         __syncthreads();
         if (base + FQ_CH < rg.y) TGS_FQ_FETCH(base + FQ_CH)
-        if (wave_live && fwd_q_block_round(sA, sB, sC, sQ, lists[wv], qlists[wv], cnt, blk, lane, base - rg.x + 1, pixfx, pixfy, vone, done, T, C0, C1, C2, last_contributor))
+        if (wave_live && fwd_q_block_round(sA, sB, sC, sQ, lists[wv], qlists[wv], cnt, blk, lane, base - rg.x + 1, pixfx, pixfy, vone, qm, done, T, C0, C1, C2, last_contributor))
             wave_live = false;
     }
 #undef TGS_FQ_FETCH
@@ -1239,13 +1311,19 @@ __global__ __launch_bounds__(256) void k_mark_visible(int P, const float* __rest
 void launch_preprocess_fwd(hipStream_t st, const FwdIn& in, const CamParams& cam, const GeomState& g, const ImgState& s)
 {
     const dim3 grid((unsigned)n_blocks(in.P)), blk(PRE_BLOCK);
-    const bool sh = in.colors_precomp == nullptr, sr = in.cov3D_precomp == nullptr;
+    const bool sh = in.colors_precomp == nullptr && !in.defer_colour, sr = in.cov3D_precomp == nullptr;
     FwdView vw;
     vw.cam = cam; vw.g = g; vw.s = s; vw.radii = in.radii;
     if (sh && sr) hipLaunchKernelGGL((k_preprocess_fwd<true, true>), grid, blk, 0, st, in, vw);
     else if (sh) hipLaunchKernelGGL((k_preprocess_fwd<true, false>), grid, blk, 0, st, in, vw);
     else if (sr) hipLaunchKernelGGL((k_preprocess_fwd<false, true>), grid, blk, 0, st, in, vw);
     else hipLaunchKernelGGL((k_preprocess_fwd<false, false>), grid, blk, 0, st, in, vw);
+}
+void launch_sh_colors_deferred(hipStream_t st, const FwdIn& in, const CamParams& cam, const GeomState& g, const ImgState& s)
+{
+    FwdView vw;
+    vw.cam = cam; vw.g = g; vw.s = s; vw.radii = in.radii;
+    hipLaunchKernelGGL(k_sh_colors_deferred, dim3((unsigned)n_blocks(in.P)), dim3(PRE_BLOCK), 0, st, in, vw);
 }
 void launch_preprocess_fwd_batch(hipStream_t st, const FwdIn& in, const FwdViews& views)
 {

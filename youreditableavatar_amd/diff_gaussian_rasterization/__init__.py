@@ -141,12 +141,17 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.nonempty_tiles, ctx.mid_tiles, ctx.light = tiles, mid_tiles, light
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img)
         ctx.mark_non_differentiable(radii)
+        # autograd otherwise hands backward() a zero tensor for the int32 `radii` output on every step: a P-element fill kernel (5 us at
+        # 500 k Gaussians) in front of every backward pass
+        ctx.set_materialize_grads(False)
         return color, radii
 
     @staticmethod
     def backward(ctx, grad_out_color, _grad_radii):
         rs = ctx.raster_settings
         colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img = ctx.saved_tensors
+        if grad_out_color is None:                           # the image did not take part in the loss (gradients not materialised, see forward)
+            grad_out_color = torch.zeros((3, int(rs.image_height), int(rs.image_width)), dtype=torch.float32, device=means3D.device)
         # native argument order (__init__.py:109-129)
         args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
                 rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, sh, rs.sh_degree, rs.campos, geom, ctx.num_rendered,
