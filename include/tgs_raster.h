@@ -29,8 +29,9 @@
  * tgs_options_t (the *_opt entry points below; NULL = defaults) -- instance pruning, the deterministic backward, the LDS sort budget,
  * the forward group and the bounds on the tiles with instances.  Two threads that render through one library with different options
  * do not see each other's (tests/test_gpu_api.py::test_two_threads_with_different_options).
- * The setters tgs_set_sort_lds_cap / tgs_set_instance_pruning / tgs_set_forward_group / tgs_set_deterministic / tgs_set_tile_bound
- * are TEST-ONLY shims: process-wide (tile bound: per thread) defaults that a call WITHOUT options falls back to.  Also process-wide:
+ * (The seven process- / thread-wide setters of rounds 1-2 -- tgs_set_sort_lds_cap / _instance_pruning / _forward_group / _deterministic /
+ * _tile_bound / _render_streams and tgs_last_nonempty_tiles -- are NOT part of this boundary any more: they are declared in
+ * include/tgs_raster_testing.h, test-only shims that store defaults for calls made WITHOUT options.)  Process-wide:
  * the optional bench profiler (tgs_profile_*) and two tuning variables of the environment, read once: TGS_BIN_WGS (binning chunks per
  * view, default 128) and TGS_FORWARD_GROUP.  Per calling thread: the message of tgs_last_error(), tgs_set_render_streams (experiment),
  * and the pinned 64-byte staging slot + event of the speculative forward (one per thread and device).
@@ -358,27 +359,6 @@ int tgs_backward_render_opt(const tgs_options_t* opt, void* stream, int P, int64
 size_t tgs_sizeof_view(void);
 size_t tgs_sizeof_options(void);
 
-/* ---- test-only shims: defaults for calls WITHOUT options (see the top of this file) ---- */
-/* Test-only shim (process-wide, default on): a splat gets no tile instance in a tile of its 3-sigma rectangle where it stays below
- * alpha = 1/255 on every pixel (the reference creates the instance, rasterizer_impl.cu:98-109, and skips it pixel by pixel,
- * forward.cu:340-343).  Images and gradients do not change; num_rendered and the internal n_contrib (a list position) do.
- * Off = the reference's instance lists, e.g. to count fragments the way the reference's state defines them. */
-void tgs_set_instance_pruning(int on);
-/* Experiment knob (per calling thread): tgs_forward_views puts k_render_fwd of view k on streams[k mod n] -- behind an event on the
- * view's own stream -- so that binning (L2 atomics, latency) and compositing (VALU) of different views run on streams of their own.
- * n = 0 restores one stream per view. */
-int tgs_set_render_streams(void* const* streams, int n);
-/* Test-only shim, per calling thread: the same bound for the single-view sync-free entry points (tgs_forward_async, tgs_forward_speculative -- which
- * repeats the stages behind the scan with exact sizes when the guess was too small -- and tgs_backward / tgs_backward_render /
- * tgs_backward_accumulate of a frame KNOWN to have at most that many non-empty tiles).  0 (default): none.  It stays set until changed. */
-void tgs_set_tile_bound(int64_t n_tiles_with_instances);
-/* Non-empty tiles of the last frame this thread rendered with tgs_forward or tgs_forward_speculative (their Meta read-back); -1 if none. */
-int64_t tgs_last_nonempty_tiles(void);
-
-/* Test-only shim (process-wide): views per launch of the per-Gaussian forward stage inside tgs_forward_views (1..8, default 2).  Groups
- * read the SH rows once per group; measured with four streams, pairs pay (-2 % per frame) and larger groups do not (the views of a
- * group start their remaining stages together). */
-void tgs_set_forward_group(int views_per_launch);
 int tgs_backward_render(void* stream, int P, int64_t R, const float* background, int width, int height,
                         const void* binning_buffer, const void* img_buffer, const float* dL_dpix);
 int tgs_backward_batch(void* stream, int P, int D, int M, int n_views, const tgs_view_t* views,
@@ -409,14 +389,6 @@ int tgs_l1_ssim(void* stream, int planes, int height, int width, const float* im
 int tgs_l1_ssim_backward(void* stream, int planes, int height, int width, const float* img, const float* gt, float dssim_factor,
                          const float* upstream, float* dL_dimg, const void* workspace, size_t workspace_bytes);
 
-/* Test-only shim (process-wide): longest tile list that is depth-sorted inside LDS; longer lists take the
- * multi-workgroup global-memory path.  Power of two in [2, 8192]; default 8192. */
-int tgs_set_sort_lds_cap(unsigned cap);
-
-/* Test-only shim, process-wide switch for the backward render kernel: 1 = fixed summation order inside a tile (gradients
- * bitwise reproducible run to run, about 2.5x slower in that kernel), 0 = LDS float atomics inside a tile
- * (default), -1 = follow the environment variable TGS_DETERMINISTIC.  Neither mode uses global atomics. */
-void tgs_set_deterministic(int on);
 
 /* Hardware self-test of the wave-level 36-value reduction used by the backward render kernel:
  * in[64][36] (one row per lane) -> out[4][9], out[e][k] = sum over lanes of in[lane][e*9+k]. */

@@ -1,5 +1,5 @@
-"""CPU: the C-ABI library loads and exports every symbol include/tgs_raster.h declares; the product
-never links, imports or falls back to anything under oracle/."""
+"""CPU: the C-ABI library loads and exports every symbol include/*.h declares (tgs_raster.h: the drop-in boundary; tgs_raster_testing.h:
+the test-only shims); the product never links, imports or falls back to anything under oracle/."""
 import ctypes
 import os
 import re
@@ -10,10 +10,11 @@ import pytest
 from tests.util import ROOT
 
 HEADER = os.path.join(ROOT, "include", "tgs_raster.h")
+TESTING_HEADER = os.path.join(ROOT, "include", "tgs_raster_testing.h")
 
 
-def declared_functions():
-    src = open(HEADER).read()
+def declared_functions(header=HEADER):
+    src = open(header).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(tgs_[a-z0-9_]+)\s*\(", src)) - {"tgs_alloc_fn"})
 
@@ -32,11 +33,16 @@ def test_header_declares_the_boundary():
     for cite in ("rasterizer.h:33-58", "rasterizer.h:60-85", "rasterizer.h:24-31", "rasterize_points.cu"):
         assert cite in text
     assert "torch" not in text.lower().replace("torch::zeros", "")   # no torch types in the signatures
+    # the process- / thread-wide setters of rounds 1-2 are not part of the boundary: test-only header
+    shims = declared_functions(TESTING_HEADER)
+    assert set(shims) == {"tgs_set_instance_pruning", "tgs_set_render_streams", "tgs_set_tile_bound", "tgs_last_nonempty_tiles", "tgs_set_forward_group",
+                          "tgs_set_sort_lds_cap", "tgs_set_deterministic"}
+    assert not (set(shims) & set(fns))
 
 
 def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(lib_path())
-    for f in declared_functions():
+    for f in declared_functions() + declared_functions(TESTING_HEADER):
         assert hasattr(lib, f), f"libtgs_raster.so does not export {f}"
     lib.tgs_abi_version.restype = ctypes.c_int
     header_version = int(re.search(r"#define TGS_ABI_VERSION (\d+)", open(HEADER).read()).group(1))

@@ -36,13 +36,8 @@ def test_mid_size_golden(name, gpu_device):
     """The HIP path against the mid-size emulated-reference fixtures (20k Gaussians / 256x256; BASELINE config 2 at 800x800): with instance
     pruning off the integer state is the reference's (num_rendered, tiles_touched, ranges; n_contrib and the per-tile lists up to the
     near-coincident depths a last-bit difference in view-space z may swap); with the default pruning image and gradients."""
-    from diff_gaussian_rasterization import _C
     inp, dL, fx = util.load_mid_golden(name)
-    _C.set_instance_pruning(False)
-    try:
-        full = util.hip_run(inp, None)
-    finally:
-        _C.set_instance_pruning(True)
+    full = util.hip_run(inp, None, pruning=False)           # explicit per-call option (tgs_options_t), no process-wide knob
     rep = util.compare_mid(full, fx, exact_lists=True)
     mine = util.hip_run(inp, dL)
     rep.update(util.compare_mid(mine, fx, exact_lists=False))
@@ -120,16 +115,13 @@ def test_tile_grid_beyond_one_lds_table(gpu_device):
 def test_backward_is_bitwise_reproducible(gpu_device):
     """Deterministic mode: no float atomics anywhere, two runs give identical bits (the reference's do not)."""
     from youreditableavatar_amd import scenes
-    from diff_gaussian_rasterization import _C
-    _C.set_deterministic(True)
     cloud = scenes.make_cloud(20_000, 3, seed=3, scale_mult=3.0)
     cam = scenes.orbit_camera(256, 192)
     inp = util.scene_input(cloud, cam)
     dL = scenes.upstream_gradient(256, 192)
-    a = util.hip_run(inp, dL, introspect=False)
-    b = util.hip_run(inp, dL, introspect=False)
-    _C.set_deterministic(False)
-    c = util.hip_run(inp, dL, introspect=False)
+    a = util.hip_run(inp, dL, introspect=False, deterministic=True)
+    b = util.hip_run(inp, dL, introspect=False, deterministic=True)
+    c = util.hip_run(inp, dL, introspect=False, deterministic=False)
     for k in ("color",) + util.GRAD_KEYS:
         assert np.array_equal(a[k], b[k]), k
         assert util.rel_l2(c[k], a[k]) <= 1e-5, k          # the default (LDS-atomic) kernel agrees with it
@@ -137,13 +129,8 @@ def test_backward_is_bitwise_reproducible(gpu_device):
 
 @pytest.mark.parametrize("name", ["g01_sh3_scale_rot", "g08_opaque_termination", "g09_giant_splat", "g13_dense_2k"])
 def test_golden_deterministic_kernel(name, gpu_device):
-    from diff_gaussian_rasterization import _C
     inp, gold = util.load_golden(name)
-    _C.set_deterministic(True)
-    try:
-        mine = util.hip_run(inp, inp["dL_dout_color"])
-    finally:
-        _C.set_deterministic(False)
+    mine = util.hip_run(inp, inp["dL_dout_color"], deterministic=True)
     ref = dict(gold)
     ref["n_contrib"] = gold["n_contrib"].reshape(int(inp["image_height"]), int(inp["image_width"]))
     util.compare(mine, ref, gold)
@@ -164,7 +151,6 @@ def test_wave_reduce36_on_hardware(gpu_device):
 def test_tile_list_overflow_path(cap, gpu_device):
     """Lists longer than the LDS budget are sorted in global memory by many workgroups; with the budget
     lowered to ``cap`` entries nearly every tile takes that path.  Results must not change."""
-    from diff_gaussian_rasterization import _C
     from youreditableavatar_amd import scenes
     cloud = scenes.make_cloud(20_000, 1, seed=77, scale_mult=3.0, n_oversized=20, oversize=30.0)
     cam = scenes.orbit_camera(200, 136, azimuth_deg=10.0)
@@ -173,11 +159,7 @@ def test_tile_list_overflow_path(cap, gpu_device):
     ref = util.oracle_run(inp, dL)
     lens = ref["ranges"][:, 1] - ref["ranges"][:, 0]
     assert lens.max() > 512                      # the scene really has long lists
-    _C.set_sort_lds_cap(cap)
-    try:
-        mine = util.hip_run(inp, dL)
-    finally:
-        _C.set_sort_lds_cap(8192)
+    mine = util.hip_run(inp, dL, sort_lds_cap=cap)
     util.compare(mine, ref)
     base = util.hip_run(inp, dL)
     assert np.array_equal(mine["point_list"], base["point_list"])
@@ -218,17 +200,10 @@ def test_instance_pruning_off_gives_the_reference_lists(gpu_device):
     """tgs_set_instance_pruning(0): every tile of the 3-sigma rectangle gets its instance like in the reference
     (rasterizer_impl.cu:98-109) -- num_rendered, tiles_touched, ranges and n_contrib equal the golden state; the image and the
     gradients are the pruned path's up to summation order."""
-    from diff_gaussian_rasterization import _C
     inp, gold = util.load_golden("g13_dense_2k")
     H, W = int(inp["image_height"]), int(inp["image_width"])
-    _C.set_deterministic(True)
-    try:
-        pruned = util.hip_run(inp, inp["dL_dout_color"])
-        _C.set_instance_pruning(False)
-        full = util.hip_run(inp, inp["dL_dout_color"])
-    finally:
-        _C.set_instance_pruning(True)
-        _C.set_deterministic(False)
+    pruned = util.hip_run(inp, inp["dL_dout_color"], deterministic=True)
+    full = util.hip_run(inp, inp["dL_dout_color"], deterministic=True, pruning=False)
     assert full["num_rendered"] == int(gold["num_rendered"]) > pruned["num_rendered"]
     assert np.array_equal(full["tiles_touched"], gold["tiles_touched"])
     assert (full["n_contrib"] == gold["n_contrib"].reshape(H, W)).mean() >= 0.999
@@ -245,7 +220,6 @@ def test_instance_pruning_off_with_large_splats(gpu_device):
     """The same switch on a scene whose splats mostly cover 5..64 tiles (64-bit live-tile masks, wave-cooperative k_scatter) and
     some more than 64: with pruning off every tile of every rectangle has its instance -- num_rendered, tiles_touched and the tile
     ranges equal the oracle's (the reference's definition); with pruning on the lists are the oracle's minus non-contributors."""
-    from diff_gaussian_rasterization import _C
     from youreditableavatar_amd import scenes
     cloud = scenes.make_cloud(20_000, 2, seed=97, scale_mult=4.0, n_oversized=5, oversize=20.0)
     cam = scenes.orbit_camera(320, 208, azimuth_deg=65.0)
@@ -256,11 +230,7 @@ def test_instance_pruning_off_with_large_splats(gpu_device):
     assert ((tt > 4) & (tt <= 64)).sum() > 2000 and (tt > 64).sum() >= 5
     pruned = util.hip_run(inp, dL)
     util.compare(pruned, ref)
-    _C.set_instance_pruning(False)
-    try:
-        full = util.hip_run(inp, dL)
-    finally:
-        _C.set_instance_pruning(True)
+    full = util.hip_run(inp, dL, pruning=False)
     assert full["num_rendered"] == ref["num_rendered"] > pruned["num_rendered"]
     assert np.array_equal(full["tiles_touched"], ref["tiles_touched"])
     assert np.array_equal(full["ranges"].reshape(-1, 2), ref["ranges"].reshape(-1, 2))

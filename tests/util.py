@@ -85,7 +85,7 @@ def scene_input(cloud: dict, cam, mode: str = "sh", cov_mode: str = "scale_rot")
 
 def hip_run(inp: dict, dL: Optional[np.ndarray] = None, device="cuda:0", debug=False, introspect=True, pruning: Optional[bool] = None,
             deterministic: Optional[bool] = None, light_tiles: Optional[bool] = None, light_tiles_bwd: Optional[bool] = None,
-            backward_twice: bool = False, side_stream: Optional[bool] = None) -> Dict[str, np.ndarray]:
+            backward_twice: bool = False, side_stream: Optional[bool] = None, sort_lds_cap: int = 0) -> Dict[str, np.ndarray]:
     """The HIP path through the reference's ``_C`` surface (the compiled module over the C ABI of include/tgs_raster.h).  ``pruning`` /
     ``deterministic`` / ``light_tiles``: explicit per-call options (tgs_options_t); None = the library defaults.  ``light_tiles_bwd``: another
     light-group option for the backward than the forward had; ``backward_twice``: back-propagate the same frame a second time (its result is
@@ -99,7 +99,7 @@ def hip_run(inp: dict, dL: Optional[np.ndarray] = None, device="cuda:0", debug=F
     H, W, D = int(inp["image_height"]), int(inp["image_width"]), int(inp["sh_degree"])
     sm, tfx, tfy = float(inp.get("scale_modifier", 1.0)), float(inp["tanfovx"]), float(inp["tanfovy"])
     R, color, radii, geom, binning, img = _C.rasterize_gaussians(bg, means3D, colors, opac, scales, rots, sm, cov, view, proj,
-                                                                 tfx, tfy, H, W, sh, D, campos, False, debug, pruning=pruning, light_tiles=light_tiles,
+                                                                 tfx, tfy, H, W, sh, D, campos, False, debug, pruning=pruning, light_tiles=light_tiles, sort_lds_cap=int(sort_lds_cap),
                                                                  **({} if side_stream is None else {"side_stream": side_stream}))
     P = means3D.shape[0]
     out = dict(color=color.cpu().numpy(), radii=radii.cpu().numpy(), num_rendered=R)

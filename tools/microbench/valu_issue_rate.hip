@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void k_valu(float* out, float seed, unsigned l
 #define SOR "s_or_b64 %[s1], %[s1], %[s2]\n\t"
 #define SAN2 "s_andn2_b64 %[s2], %[s2], %[s0]\n\t"
 #define SMOV "s_mov_b64 vcc, %[s0]\n\t"
-#define OPSS : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [a4] "+v"(a4), [a5] "+v"(a5), [a6] "+v"(a6), [a7] "+v"(a7), [s0] "+s"(m0), [s1] "+s"(m1), [s2] "+s"(m2) : [m] "v"(m), [c] "v"(c) : "vcc"
+#define OPSS : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [a4] "+v"(a4), [a5] "+v"(a5), [a6] "+v"(a6), [a7] "+v"(a7), [s0] "+s"(m0), [s1] "+s"(m1), [s2] "+s"(m2) : [m] "v"(m), [c] "v"(c) : "vcc", "scc"
 #define MIXS6 FMA(a0) SAND FMA(a1) SOR FMA(a2) SMOV DPP(a3) SAN2 FMA(a4) SAND FMA(a5) EXP(a6) SOR FMA(a7)
 #define MIXS3 FMA(a0) SAND FMA(a1) FMA(a2) SMOV DPP(a3) FMA(a4) FMA(a5) SOR EXP(a6) FMA(a7)
             if (MODE == 6) asm volatile(MIXS6 MIXS6 MIXS6 MIXS6 OPSS);

@@ -1,23 +1,14 @@
-# round 4, step e: find what stalled step d -- every command under its own timeout, one small probe per suspect
+# round 4, step e: full GPU suite (per-test timeout), SALU microbenchmark, A/B by library on one box (r03 / f32 chain / lean masks), drop-in with and without the side stream
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r04_e; mkdir -p $O; cd $R
-probe() { name=$1; shift; timeout 120 "$@" > $O/$name.txt 2>&1; echo "$name rc=$? $(tail -1 $O/$name.txt | cut -c1-200)"; }
-cat > /tmp/p1.py <<'PY'
-import sys, numpy as np, torch
-sys.path.insert(0, ".")
-from youreditableavatar_amd import scenes
-from tests import util
-cloud = scenes.make_cloud(3000, 3, seed=42, scale_mult=3.0)
-cam = scenes.orbit_camera(160, 128, azimuth_deg=15.0)
-inp = util.scene_input(cloud, cam)
-dL = scenes.upstream_gradient(160, 128)
-side = None if sys.argv[1] == "none" else bool(int(sys.argv[1]))
-for i in range(3):
-    out = util.hip_run(inp, dL, side_stream=side)
-print("ok", sys.argv[1], float(out["color"].sum()), int(out["num_rendered"]))
-PY
-TGS_SIDE_STREAM=0 probe side_env_off python /tmp/p1.py none
-probe side_off python /tmp/p1.py 0
-probe side_on python /tmp/p1.py 1
-probe side_default python /tmp/p1.py none
-probe smoke python -c "import __graft_entry__ as g; g.smoke()"
-timeout 1500 python -m pytest tests -m gpu -x -q --timeout 200 > $O/pytest.txt 2>&1; tail -8 $O/pytest.txt | cut -c1-300
+timeout 60 python -c "from oracle import oracle; oracle.build(force=True)" < /dev/null
+timeout 1500 python -m pytest tests -m gpu -x -q --timeout 400 > $O/pytest.txt 2>&1 < /dev/null; tail -6 $O/pytest.txt | cut -c1-400
+(cd tools/microbench && timeout 120 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -Wno-unused-value valu_issue_rate.hip -o valu_issue_rate && timeout 200 ./valu_issue_rate) > $O/valu_issue_rate.txt 2>&1 < /dev/null; grep "W=8\|W=4" $O/valu_issue_rate.txt | cut -c1-200
+timeout 900 bash tools/libs.sh "default libtgs_raster_r03.so libtgs_raster_f32chain.so libtgs_raster_lean.so default libtgs_raster_r03.so libtgs_raster_f32chain.so libtgs_raster_lean.so" > $O/ab.txt 2>&1 < /dev/null; cat $O/ab.txt
+for i in 1 2; do
+  for lib in default lean r03; do
+    if [ $lib = default ]; then unset TGS_LIBRARY; else export TGS_LIBRARY=youreditableavatar_amd/lib/libtgs_raster_$lib.so; fi
+    echo "dropin $lib $(timeout 120 python tools/dropin_loop.py 200 2>/dev/null < /dev/null | tail -1)"
+  done
+  unset TGS_LIBRARY
+  echo "dropin side-stream on $(TGS_SIDE_STREAM=1 timeout 120 python tools/dropin_loop.py 200 2>/dev/null < /dev/null | tail -1)"
+done

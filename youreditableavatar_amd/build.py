@@ -53,7 +53,10 @@ def source_hash() -> str:
     files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".cpp"))) 
     for f in files:
         h.update(f.encode()); h.update(open(os.path.join(CSRC, f), "rb").read())
-    h.update(open(os.path.join(HERE, "..", "include", "tgs_raster.h"), "rb").read())
+    for hname in ("tgs_raster.h", "tgs_raster_testing.h"):
+        hp = os.path.join(HERE, "..", "include", hname)
+        if os.path.exists(hp):
+            h.update(open(hp, "rb").read())
     return h.hexdigest()[:16]
 
 

@@ -2,6 +2,7 @@
 // Host orchestration counterpart of cuda_rasterizer/rasterizer_impl.cu:141-434.
 #include "tgs_device.hpp"
 #include "../../include/tgs_raster.h"
+#include "../../include/tgs_raster_testing.h"   // the test-only shims are defined in this file
 
 #include <cstdarg>
 #include <cstdio>
@@ -267,7 +268,9 @@ static uint32_t bounded_tiles(const Opts& o, size_t T) { return (o.tile_bound > 
 static uint32_t bounded_mid(const Opts& o, size_t T)
 {
     const uint32_t tb = bounded_tiles(o, T);
-    return (o.tile_bound > 0 && o.mid_bound > 0 && (uint64_t)o.mid_bound < tb) ? (uint32_t)o.mid_bound : tb;
+    // the SAME predicate as the forward's (forward_impl: `classes`): a mid bound is only enforced -- by k_scan, which rejects a frame with more
+    // such tiles -- together with a tile bound below the tile count; without that enforcement the backward must not size its grid by it
+    return (tb < (uint32_t)T && o.mid_bound > 0 && (uint64_t)o.mid_bound < tb) ? (uint32_t)o.mid_bound : tb;
 }
 
 // One library-owned non-blocking stream + two events per calling thread and device: the fork / join of the deferred SH colours

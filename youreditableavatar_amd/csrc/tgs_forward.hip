@@ -490,6 +490,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const 
         // super-chunk of 8192 tiles are pulled into LDS with 8 independent loads per thread, and the scan, the
         // longest-list search and the length histogram then run out of LDS.
         constexpr uint32_t SC = SCAN_THREADS * TI;
+        // 32 KB (TI = 8) or 64 KB (TI = 16) of static LDS besides the small arrays: more than the 64 KB a workgroup gets on other targets --
+        // this kernel (like the binning chunks' 96-KB tables) is written for gfx950's 160 KB per CU and nothing else (build.py: --offload-arch=gfx950)
+        static_assert(SC * sizeof(uint32_t) + 4096 <= 160 * 1024, "k_scan: the tile counters of one super-chunk must fit gfx950's 160 KB of LDS");
         __shared__ uint32_t lc[SC];
         __shared__ uint32_t hist[34];
         __shared__ uint32_t cls[2];                         // (n_mid, n_nonempty) for the second pass
@@ -536,7 +539,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const 
                 if (b2 == 8) { s.meta->n_mid = acc + h; cls[0] = acc + h; too_many = too_many || acc + h > mid_bound; }
                 acc += h;
             }
-            s.meta->pad[1] = light ? 1u : 0u;               // light_desc is valid for this frame (the backward may be called with other options)
+            s.meta->pad[1] = 1u;                            // light_desc is valid for EVERY frame since round 4 (a backward may be called with other options
+                                                            // than its forward: with the descriptors always there its grid is valid for either outcome)
             if (too_many) atomicOr(&s.meta->error, META_ERR_CAPACITY);
             if (host_meta) host_meta->pad[0] = too_many ? 1u : 0u;   // (a word of its own: workgroup 0 writes host_meta->error)
         }
@@ -553,7 +557,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const 
                     const uint32_t c = r[k].y - r[k].x, pos = atomicAdd(&hist[c ? 32 - __builtin_clz(c) : 0], 1u);
                     s.tile_order[pos] = sc + i;
                     s.tile_desc[pos] = make_uint4(sc + i, r[k].x, r[k].y, 0u);
-                    if (light && pos >= cls[0] && pos < cls[1]) s.light_desc[pos - cls[0]] = make_uint4(sc + i, r[k].x, r[k].y, 0u);   // (only when the render kernels will form light groups)
+                    if (pos >= cls[0] && pos < cls[1]) s.light_desc[pos - cls[0]] = make_uint4(sc + i, r[k].x, r[k].y, 0u);   // (always: one 16-B store per tile below 128 entries)
                 }
             }
         }
@@ -767,25 +771,6 @@ __global__ __launch_bounds__(BIN_THREADS) void k_scatter(int P, uint32_t chunk, 
 
 // the per-instance record of sorted entry `pos` of a tile (what renderCUDA fetches per entry: forward.cu:315-321,355 and
 // backward.cu:470-480) from the Gaussian's 64-B pack line p0..p3
-__device__ __forceinline__ void finalize_entry(float4 p0, float4 p1, float4 p2, float4 p3, uint32_t pos, uint32_t tile, uint32_t gx, const BinState& b)
-{
-    const uint32_t rmin = __float_as_uint(p2.y), rmax = __float_as_uint(p2.z);
-    const uint32_t minx = rmin & 0xffffu, miny = rmin >> 16, maxx = rmax & 0xffffu, maxy = rmax >> 16;
-    const uint32_t tx = tile % gx, ty = tile / gx;
-    b.recA[pos] = p0;
-    b.recB[pos] = p1;
-    const unsigned long long qm = quadrant_mask(make_float2(p0.x, p0.y), make_float4(p0.z, p0.w, p1.x, p1.y), tx, ty);
-    b.recC[pos] = make_float2(p2.x, __uint_as_float(blocks_of_quadrants(qm)));
-    b.qmask[pos] = make_uint2((uint32_t)qm, (uint32_t)(qm >> 32));
-    // row of this instance in the gradient slab: the Gaussian's rows are its LIVE tiles in rectangle order
-    const uint32_t rw = maxx - minx, k = (ty - miny) * rw + (tx - minx);
-    uint32_t ord = k;
-    if (rw * (maxy - miny) <= (uint32_t)COOP_TILES) {       // p3: 64-bit mask of the rectangle's live tiles
-        const unsigned long long live = (unsigned long long)__float_as_uint(p3.x) | ((unsigned long long)__float_as_uint(p3.y) << 32);
-        ord = (uint32_t)__builtin_popcountll(live & ((1ull << k) - 1ull));
-    }
-    b.slot[pos] = __float_as_uint(p2.w) + ord;
-}
 
 // Per-tile sort in LDS, tiles visited in tile_order (longest lists first).  Three classes by list length n, all in ONE launch of
 // 1024-thread workgroups (the classes are latency bound on their longest lists; launched one after the other their critical paths add up:
@@ -893,7 +878,53 @@ __device__ __forceinline__ void ovf_global(const ImgState& s, const BinState& b,
     cmp_swap(b.keys + rg.x, i, l, n);
 }
 
-__device__ __forceinline__ void ovf_worker(const ImgState& s, const BinState& b, unsigned long long* lk, uint32_t w, uint32_t nw, uint32_t cap)
+#ifndef TGS_FUSED_FINALIZE
+#define TGS_FUSED_FINALIZE 0          // measured (round 4, A/B by library): the fused form saves 2 us per frame alone on the GPU and LOSES 1-2 % of the 8-view step
+#endif
+__device__ __forceinline__ void finalize_entry(float4 p0, float4 p1, float4 p2, float4 p3, uint32_t pos, uint32_t tile, uint32_t gx, const BinState& b)
+{
+    const uint32_t rmin = __float_as_uint(p2.y), rmax = __float_as_uint(p2.z);
+    const uint32_t minx = rmin & 0xffffu, miny = rmin >> 16, maxx = rmax & 0xffffu, maxy = rmax >> 16;
+    const uint32_t tx = tile % gx, ty = tile / gx;
+    b.recA[pos] = p0;
+    b.recB[pos] = p1;
+    const unsigned long long qm = quadrant_mask(make_float2(p0.x, p0.y), make_float4(p0.z, p0.w, p1.x, p1.y), tx, ty);
+    b.recC[pos] = make_float2(p2.x, __uint_as_float(blocks_of_quadrants(qm)));
+    b.qmask[pos] = make_uint2((uint32_t)qm, (uint32_t)(qm >> 32));
+    // row of this instance in the gradient slab: the Gaussian's rows are its LIVE tiles in rectangle order
+    const uint32_t rw = maxx - minx, k = (ty - miny) * rw + (tx - minx);
+    uint32_t ord = k;
+    if (rw * (maxy - miny) <= (uint32_t)COOP_TILES) {       // p3: 64-bit mask of the rectangle's live tiles
+        const unsigned long long live = (unsigned long long)__float_as_uint(p3.x) | ((unsigned long long)__float_as_uint(p3.y) << 32);
+        ord = (uint32_t)__builtin_popcountll(live & ((1ull << k) - 1ull));
+    }
+    b.slot[pos] = __float_as_uint(p2.w) + ord;
+}
+
+// Round 4 experiment (-DTGS_FUSED_FINALIZE=1; the review of round 3 asked for it): the gather behind the sort (k_finalize) runs in the sorting
+// workgroup itself, on the keys it still holds in LDS / registers: the sorted keys are stored once and never read back, the tile is known (no
+// tile_of array), one launch + its boundary are gone.  Parity-green (GPU suite), and measured: sort + gather 48.2 us as one kernel against
+// 26.3 + 24.2 + a boundary as two with the GPU to itself (drop-in frame 0.366 either way), but 1-2 % SLOWER on the 8-view step (0.2459 vs
+// 0.2405 ms per frame, twice): the 1024-thread sorting workgroups are a worse home for a latency-bound gather than 256-thread ones spread
+// evenly over all instances, and with four streams sharing the GPU the separate gather kernel fills the sort's tail.  Default off.  NT threads share a list; two entries per thread and step so that two
+// 64-B line gathers are in flight per lane.  key_at(i): sorted key i of the list; start: the list's first position in the binning buffer.
+template <int NT, typename KeyAt>
+__device__ __forceinline__ void finalize_list(const GeomState& g, const BinState& b, KeyAt key_at, uint32_t start, uint32_t n, uint32_t tile, uint32_t gx, uint32_t tid)
+{
+    for (uint32_t i = tid; i < n; i += 2 * NT) {
+        const uint32_t i1 = i + NT;
+        const bool two = i1 < n;
+        const uint32_t id0 = (uint32_t)key_at(i), id1 = two ? (uint32_t)key_at(i1) : id0;
+        const float4* pa = g.pack + 4 * (size_t)id0;
+        const float4* pb = g.pack + 4 * (size_t)id1;
+        const float4 a0 = pa[0], a1 = pa[1], a2 = pa[2], a3 = pa[3];
+        const float4 c0 = pb[0], c1 = pb[1], c2 = pb[2], c3 = pb[3];
+        finalize_entry(a0, a1, a2, a3, start + i, tile, gx, b);
+        if (two) finalize_entry(c0, c1, c2, c3, start + i1, tile, gx, b);
+    }
+}
+
+__device__ __forceinline__ void ovf_worker(const GeomState& g, const ImgState& s, const BinState& b, unsigned long long* lk, uint32_t w, uint32_t nw, uint32_t cap, uint32_t gx)
 {
     const uint32_t n_ovf = s.meta->n_overflow;              // written by k_scan
     for (uint32_t ot = w; ot < n_ovf; ot += nw) {           // one workgroup per overflow tile: no dependency on any other workgroup
@@ -913,11 +944,14 @@ __device__ __forceinline__ void ovf_worker(const ImgState& s, const BinState& b,
             for (uint32_t blk = 0; blk < bpt; blk++) ovf_local(s, b, lk, ot, blk, k, cap);
         }
         ovf_wg_sync();
+#if TGS_FUSED_FINALIZE
+        finalize_list<OVF_THREADS>(g, b, [&](uint32_t i) { return b.keys[rg.x + i]; }, rg.x, rg.y - rg.x, s.ovf_tiles[ot], gx, threadIdx.x);   // (sorted in global memory)
+#endif
     }
 }
 
-__global__ __launch_bounds__(1024) void k_tile_sort(const ImgState s, const BinState b, uint32_t sort_cap, uint32_t heavy_blocks, uint32_t mid_blocks,
-                                                    uint32_t small_blocks, uint32_t ovf_blocks)
+__global__ __launch_bounds__(1024) void k_tile_sort(const GeomState g, const ImgState s, const BinState b, uint32_t gx, uint32_t sort_cap, uint32_t heavy_blocks,
+                                                    uint32_t mid_blocks, uint32_t small_blocks, uint32_t ovf_blocks)
 {
     extern __shared__ unsigned long long lk[];
     __shared__ uint32_t grp_npad[4];
@@ -926,7 +960,7 @@ __global__ __launch_bounds__(1024) void k_tile_sort(const ImgState s, const BinS
     const uint32_t n_heavy = min(s.meta->n_heavy, n_nonempty), n_mid = min(max(s.meta->n_mid, n_heavy), n_nonempty);
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (blockIdx.x >= heavy_blocks + mid_blocks + small_blocks) {          // the grid's tail: workers of the lists beyond the LDS sort
-        ovf_worker(s, b, lk, blockIdx.x - (heavy_blocks + mid_blocks + small_blocks), ovf_blocks, sort_cap);
+        ovf_worker(g, s, b, lk, blockIdx.x - (heavy_blocks + mid_blocks + small_blocks), ovf_blocks, sort_cap, gx);
         return;
     }
     if (blockIdx.x < heavy_blocks) {
@@ -934,20 +968,29 @@ __global__ __launch_bounds__(1024) void k_tile_sort(const ImgState s, const BinS
         if (t >= n_heavy) return;
         const uint4 td = s.tile_desc[t];
         const uint32_t n = td.z - td.y;
+#if !TGS_FUSED_FINALIZE
         for (uint32_t i = threadIdx.x; i < n; i += 1024) b.tile_of[td.y + i] = td.x;
-        if (n < 2 || n > sort_cap) return;                  // (longer lists: the overflow workers)
+#endif
+        if (n > sort_cap) return;                           // (longer lists: the overflow workers -- they sort AND finalize them)
         for (uint32_t i = threadIdx.x; i < n; i += 1024) lk[i] = b.keys[td.y + i];
         __syncthreads();
-        sort_tile_lds<1024>(lk, threadIdx.x, n, next_pow2(n));
-        for (uint32_t i = threadIdx.x; i < n; i += 1024) b.keys[td.y + i] = lk[i];
+        if (n >= 2) {
+            sort_tile_lds<1024>(lk, threadIdx.x, n, next_pow2(n));
+            for (uint32_t i = threadIdx.x; i < n; i += 1024) b.keys[td.y + i] = lk[i];
+        }
+#if TGS_FUSED_FINALIZE
+        finalize_list<1024>(g, b, [&](uint32_t i) { return lk[i]; }, td.y, n, td.x, gx, threadIdx.x);
+#endif
     } else if (blockIdx.x < heavy_blocks + mid_blocks) {
         const uint32_t grp = threadIdx.x >> 8, tid = threadIdx.x & 255u;
         const uint32_t t = n_heavy + (blockIdx.x - heavy_blocks) * 4 + grp;
         if (n_heavy + (blockIdx.x - heavy_blocks) * 4 >= n_mid) return;          // the whole workgroup is behind the class
         uint32_t n = 0, start = 0, tile = 0;
         if (t < n_mid) { const uint4 td = s.tile_desc[t]; tile = td.x; start = td.y; n = td.z - td.y; }
+#if !TGS_FUSED_FINALIZE
         for (uint32_t i = tid; i < n; i += 256) b.tile_of[start + i] = tile;
-        if (n > 1024u || n > sort_cap) n = 0;               // (cannot happen by the class boundary; keeps the LDS segment safe)
+#endif
+        if (n > 1024u || n > sort_cap) n = 0;               // (a list beyond sort_cap belongs to the overflow workers; n > 1024 cannot happen by the class boundary)
         unsigned long long* seg = lk + grp * 1024;
         for (uint32_t i = tid; i < n; i += 256) seg[i] = b.keys[start + i];
         if (tid == 0) grp_npad[grp] = n < 2 ? 2u : next_pow2(n);
@@ -955,17 +998,41 @@ __global__ __launch_bounds__(1024) void k_tile_sort(const ImgState s, const BinS
         const uint32_t npad_wg = max(max(grp_npad[0], grp_npad[1]), max(grp_npad[2], grp_npad[3]));
         sort_tile_lds<256>(seg, tid, n, npad_wg);
         for (uint32_t i = tid; i < n; i += 256) b.keys[start + i] = seg[i];
+#if TGS_FUSED_FINALIZE
+        finalize_list<256>(g, b, [&](uint32_t i) { return seg[i]; }, start, n, tile, gx, tid);
+#endif
     } else {
         const uint32_t t = n_mid + (blockIdx.x - heavy_blocks - mid_blocks) * 16 + wv;
         if (t >= n_nonempty) return;                        // wave-uniform: no workgroup barrier below
         const uint4 td = s.tile_desc[t];
         const uint32_t n = td.z - td.y;
+#if !TGS_FUSED_FINALIZE
         for (uint32_t i = lane; i < n; i += 64) b.tile_of[td.y + i] = td.x;
         if (n < 2 || n > sort_cap || n > SORT_CHUNK) return;    // (n < 128 by the class boundary in k_scan)
+#else
+        if (n > sort_cap || n > SORT_CHUNK) return;             // (beyond sort_cap: the overflow workers; n < 128 by the class boundary in k_scan)
+#endif
         unsigned long long k0, k1;                          // global memory -> registers -> global memory: no LDS
         regs_load_chunk(b.keys + td.y, 0u, n, lane, k0, k1);
-        regs_sort128(k0, k1, lane);
-        regs_store_chunk(b.keys + td.y, 0u, n, lane, k0, k1);
+        if (n >= 2) {
+            regs_sort128(k0, k1, lane);
+            regs_store_chunk(b.keys + td.y, 0u, n, lane, k0, k1);
+        }
+#if TGS_FUSED_FINALIZE
+        {   // lane l holds sorted entries 2 l and 2 l + 1
+            const uint32_t e0 = 2u * lane, e1 = e0 + 1u;
+            const bool h0 = e0 < n, h1 = e1 < n;
+            const uint32_t id0 = h0 ? (uint32_t)k0 : 0u, id1 = h1 ? (uint32_t)k1 : id0;
+            if (h0) {
+                const float4* pa = g.pack + 4 * (size_t)id0;
+                const float4* pb = g.pack + 4 * (size_t)id1;
+                const float4 a0 = pa[0], a1 = pa[1], a2 = pa[2], a3 = pa[3];
+                const float4 c0 = pb[0], c1 = pb[1], c2 = pb[2], c3 = pb[3];
+                finalize_entry(a0, a1, a2, a3, td.y + e0, td.x, gx, b);
+                if (h1) finalize_entry(c0, c1, c2, c3, td.y + e1, td.x, gx, b);
+            }
+        }
+#endif
     }
 }
 
@@ -1288,8 +1355,13 @@ __global__ __launch_bounds__(FQ_THREADS, 8) void k_render_fwd(const ImgState s, 
     const uint32_t m = fwd_q_block_store(s, out_color, W, H, px, py, inside, lane, bg0, bg1, bg2, T, C0, C1, C2, last_contributor);
     if (lane == 0) wave_qmax[wv] = m;
     __syncthreads();
-    // deepest blended position of the tile (its descriptor's .w, zero from k_scan): the maximum over the four quarters
-    if (threadIdx.x == 0) atomicMax(reinterpret_cast<uint32_t*>(&s.tile_desc[ht8]) + 3, max(max(wave_qmax[0], wave_qmax[1]), max(wave_qmax[2], wave_qmax[3])));
+    // deepest blended position of the tile (its descriptor's .w, zero from k_scan): the maximum over the four quarters -- in BOTH copies of
+    // the descriptor when the tile is a light one composited here by quarters (light == 0): a backward that sets light tiles apart reads light_desc
+    if (threadIdx.x == 0) {
+        const uint32_t q = max(max(wave_qmax[0], wave_qmax[1]), max(wave_qmax[2], wave_qmax[3]));
+        atomicMax(reinterpret_cast<uint32_t*>(&s.tile_desc[ht8]) + 3, q);
+        if (ht8 >= ff.w) atomicMax(reinterpret_cast<uint32_t*>(&s.light_desc[ht8 - ff.w]) + 3, q);
+    }
     stamp_max(s, tile, 1);                                  // (diagnostic builds: the last quarter's end; a frame's stamps start at zero only in a fresh buffer)
 }
 
@@ -1409,10 +1481,12 @@ void launch_tile_sort(hipStream_t st, const GeomState& g, const ImgState& s, con
         const uint32_t ovf_blocks = (m && m->n_overflow == 0) ? 0u : OVF_WORKERS;
         if (ovf_blocks > 0 && bytes < (size_t)sort_cap * 8) bytes = (size_t)sort_cap * 8;
         if (heavy + mid_blocks + small_blocks + ovf_blocks > 0)
-            hipLaunchKernelGGL(k_tile_sort, dim3(heavy + mid_blocks + small_blocks + ovf_blocks), dim3(1024), bytes, st, s, b, sort_cap, heavy, mid_blocks,
+            hipLaunchKernelGGL(k_tile_sort, dim3(heavy + mid_blocks + small_blocks + ovf_blocks), dim3(1024), bytes, st, g, s, b, gx, sort_cap, heavy, mid_blocks,
                                small_blocks, ovf_blocks);
     }
+#if !TGS_FUSED_FINALIZE
     if (r_bound > 0) hipLaunchKernelGGL(k_finalize, dim3((unsigned)((r_bound + 256 * FIN_E - 1) / (256 * FIN_E))), dim3(256), 0, st, g, s, b, gx, T);
+#endif
 }
 // mid_bound (sync-free, with a tile bound): upper bound on the tiles with >= LIGHT_MAX instances (k_scan rejects a frame with more)
 void launch_render_fwd(hipStream_t st, const ImgState& s, const BinState& b, int W, int H, uint32_t gx, uint32_t T, const Meta* m,

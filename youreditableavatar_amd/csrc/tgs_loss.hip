@@ -287,38 +287,41 @@ __device__ __forceinline__ bool strip_geom(StripGeom& g, int H, int W, int nstri
 
 // one input row of the stats pass in phase P (= row counter mod 11): horizontal window of the five maps, scatter into the running sums,
 // finish output row r - 5
+// Round 4: FOUR maps, not five.  The SSIM map needs E[x^2] and E[y^2] only through sigma1^2 + sigma2^2 = E[x^2] + E[y^2] - mu1^2 - mu2^2
+// (loss_utils.py:53-58: D2 = sigma1_sq + sigma2_sq + C2), so the two windows are one window over x^2 + y^2: one map less in the vertical
+// scatter (11 FMAs per row) and 11 running sums less per lane (86 -> 75 VGPRs: six waves per SIMD instead of five).
 template <int P>
-__device__ __forceinline__ void stats_row(float x, float y, int r, const StripGeom& g, const LossWin& win, float (&V)[5][NTAP], int W,
+__device__ __forceinline__ void stats_row(float x, float y, int r, const StripGeom& g, const LossWin& win, float (&V)[4][NTAP], int W,
                                           float* __restrict__ dM1, float* __restrict__ dX2, float* __restrict__ dXY, float& s_map)
 {
-    float hx = 0.f, hy = 0.f, hxx = 0.f, hyy = 0.f, hxy = 0.f;
+    float hx = 0.f, hy = 0.f, hss = 0.f, hxy = 0.f;
     float xs = x, ys = y;
 #pragma unroll
     for (int j = 0; j < NTAP; j++) {                        // lane L holds column c; after j shifts xs = x(c - j): the window of output column c - 5
         const float w = win.w[j];
         const float wx = w * xs, wy = w * ys;
-        hx += wx; hy += wy; hxx += wx * xs; hyy += wy * ys; hxy += wx * ys;
+        hx += wx; hy += wy; hss += wx * xs; hss += wy * ys; hxy += wx * ys;
         if (j + 1 < NTAP) { xs = wave_shr1(xs); ys = wave_shr1(ys); }
     }
     {   // tap 0 opens the running sums of output row r + 5 (slot (P + 10) % 11, finished and read 11 rows ago): an assignment, no zeroing pass
         const float w = win.w[0];
         const int sl = (P + NTAP - 1) % NTAP;
-        V[0][sl] = w * hx; V[1][sl] = w * hy; V[2][sl] = w * hxx; V[3][sl] = w * hyy; V[4][sl] = w * hxy;
+        V[0][sl] = w * hx; V[1][sl] = w * hy; V[2][sl] = w * hss; V[3][sl] = w * hxy;
     }
 #pragma unroll
     for (int k = 1; k < NTAP; k++) {                        // this row is tap k of output row r + 5 - k, whose running sums sit in slot (P + 10 - k) % 11
         const float w = win.w[k];
         const int sl = (P + NTAP - 1 - k) % NTAP;
-        V[0][sl] += w * hx; V[1][sl] += w * hy; V[2][sl] += w * hxx; V[3][sl] += w * hyy; V[4][sl] += w * hxy;
+        V[0][sl] += w * hx; V[1][sl] += w * hy; V[2][sl] += w * hss; V[3][sl] += w * hxy;
     }
     const int ro = r - LR;
     if (ro >= g.y0 && ro < g.y1) {                          // (uniform over the wave)
-        const float m1 = V[0][P], m2 = V[1][P], X2 = V[2][P], Y2 = V[3][P], XY = V[4][P];
+        const float m1 = V[0][P], m2 = V[1][P], SS = V[2][P], XY = V[3][P];
         // loss_utils.py:49-58
         const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
         const float m11 = m1 * m1, m22 = m2 * m2, m12 = m1 * m2;
-        const float s1 = X2 - m11, s2 = Y2 - m22, s12 = XY - m12;
-        const float N1 = 2.f * m12 + C1, N2 = 2.f * s12 + C2, D1 = m11 + m22 + C1, D2 = s1 + s2 + C2;
+        const float s12 = XY - m12;
+        const float N1 = 2.f * m12 + C1, N2 = 2.f * s12 + C2, D1 = m11 + m22 + C1, D2 = (SS - m11 - m22) + C2;      // sigma1^2 + sigma2^2 + C2
         const float iD1 = __builtin_amdgcn_rcpf(D1), iD2 = __builtin_amdgcn_rcpf(D2), q = iD1 * iD2;     // v_rcp_f32 (1 ulp); D1, D2 >= C1, C2 > 0
         const float map = N1 * N2 * q;
         if (g.out_ok) {
@@ -337,9 +340,9 @@ __global__ __launch_bounds__(256) void k_ssim_stats_stream(int H, int W, int nst
     StripGeom g;
     const size_t pidx = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * (gridDim.x * 4) + blockIdx.x * 4 + (threadIdx.x >> 6);
     if (!strip_geom(g, H, W, nstrips)) { if ((threadIdx.x & 63) == 0) partial[pidx] = make_float2(0.f, 0.f); return; }
-    float V[5][NTAP];
+    float V[4][NTAP];
 #pragma unroll
-    for (int m = 0; m < 5; m++)
+    for (int m = 0; m < 4; m++)
 #pragma unroll
         for (int k = 0; k < NTAP; k++) V[m][k] = 0.f;
     float s_map = 0.f, s_l1 = 0.f;

@@ -88,8 +88,6 @@ def _load() -> C.CDLL:
     lib.tgs_set_instance_pruning.argtypes = [it]
     lib.tgs_set_forward_group.restype = None
     lib.tgs_set_forward_group.argtypes = [it]
-    lib.tgs_set_tile_bound.restype = None
-    lib.tgs_set_tile_bound.argtypes = [C.c_int64]
     lib.tgs_last_nonempty_tiles.restype = C.c_int64
     lib.tgs_last_nonempty_tiles.argtypes = []
     lib.tgs_set_deterministic.restype = None
@@ -127,6 +125,10 @@ _ext = _load_ext()
 STAGES = ("preprocess_fwd", "scan", "scatter", "tile_sort", "render_fwd", "render_bwd", "preprocess_bwd")
 
 
+# ---- test-only shims (include/tgs_raster_testing.h): process-wide DEFAULTS for calls made without explicit options.  Every entry point of this
+# module passes an explicit tgs_options_t (options(...)); a field left at None / 0 there falls back to what these setters stored.  There is no
+# shim for the tile bound any more: with explicit options a tile_bound of 0 means "none", so a thread-wide default could never take effect
+# through these bindings -- pass tile_bound= to the call.
 def set_sort_lds_cap(cap: int) -> None:
     """Test knob: tile lists longer than ``cap`` (power of two <= 8192) take the global-memory sort path."""
     if _lib.tgs_set_sort_lds_cap(int(cap)) < 0:
@@ -142,12 +144,6 @@ def set_instance_pruning(on: bool) -> None:
 def set_forward_group(views_per_launch: int) -> None:
     """Views per launch of the per-Gaussian forward stage inside forward_views (1..8; default 1)."""
     _lib.tgs_set_forward_group(int(views_per_launch))
-
-
-def set_tile_bound(n_tiles: int) -> None:
-    """tgs_set_tile_bound (this thread): bound on the tiles with instances for the sync-free / speculative forward and for the backward of
-    a frame known to stay below it; 0: none.  Stays set until changed."""
-    _lib.tgs_set_tile_bound(int(n_tiles))
 
 
 def last_nonempty_tiles() -> int:

@@ -264,8 +264,14 @@ class SyncFreeBatch:
     return_meta=True)`` and returns its ``(image, radii, meta)``; ``upstream(v, image)`` returns dL/d image (it runs
     again for a re-rendered view)."""
 
-    def __init__(self, headroom: float = 1.25, granule: int = 1 << 16, streams: int = 4, deferred: bool = True, split: bool = False):
+    def __init__(self, headroom: float = 1.25, granule: int = 1 << 16, streams: int = 4, deferred: bool = True, split: bool = False,
+                 deterministic: Optional[bool] = None, forward_group: int = 0, pruning: Optional[bool] = None, light_tiles: Optional[bool] = None):
         self.headroom, self.granule = float(headroom), int(granule)
+        # explicit per-call options of the whole-batch entry points (tgs_options_t: the bitwise-reproducible per-pixel backward, views per
+        # launch of the per-Gaussian forward stage, instance pruning, light tiles); None: the library's defaults -- no process-wide setter
+        self.options = (_C.options(deterministic=deterministic, forward_group=forward_group, pruning=pruning, light_tiles=light_tiles)
+                        if (deterministic is not None or forward_group or pruning is not None or light_tiles is not None) else None)
+        self._deterministic, self._pruning = deterministic, pruning      # the per-view fallback path (first batch, re-rendered views) gets the same
         self.bound: Optional[int] = None        # largest num_rendered seen (decays slowly)
         self.tile_bound: Optional[int] = None   # largest number of tiles with instances seen (decays slowly): sizes the sync-free grids
         self.class_bound = [0, 0]               # the same for the tiles with >= 1024 / >= 128 instances (classes of the tile sort)
@@ -366,7 +372,7 @@ class SyncFreeBatch:
                 R, color, radii, geom, binning, img = _C.rasterize_gaussians(rs.bg, means3D.detach(), colors_precomp[v] if precomp else e, opacities.detach(),
                                                                            scales.detach(), rotations.detach(), rs.scale_modifier, e, rs.viewmatrix, rs.projmatrix,
                                                                            rs.tanfovx, rs.tanfovy, H, W, e if precomp else shs.detach(), D, rs.campos,
-                                                                           rs.prefiltered, rs.debug)
+                                                                           rs.prefiltered, rs.debug, pruning=self._pruning)
                 out[v] = (R, color, radii, geom, binning, img)
             return out
 
@@ -382,7 +388,8 @@ class SyncFreeBatch:
                 into["sh"] = shs.grad
             return _C.rasterize_gaussians_backward_accumulate(rs.bg, means3D.detach(), radii, colors_precomp[v] if precomp else e, scales.detach(),
                                                               rotations.detach(), rs.scale_modifier, e, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, g,
-                                                              e if precomp else shs.detach(), D, rs.campos, geom, R, binning, img, rs.debug, into)
+                                                              e if precomp else shs.detach(), D, rs.campos, geom, R, binning, img, rs.debug, into,
+                                                              deterministic=self._deterministic)
 
         def grad_of(dL, v):
             return dL if dL.dim() == 3 else dL[v]
@@ -469,7 +476,7 @@ class SyncFreeBatch:
             _C.set_render_streams([st.cuda_stream for st in ren_lanes] if split else [])
             try:
                 _C.forward_views([st.cuda_stream for st in bin_lanes], cap, P, D, M, means3D.data_ptr(), None if precomp else shs.data_ptr(), opacities.data_ptr(),
-                                 scales.data_ptr(), rs0.scale_modifier, rotations.data_ptr(), arr, V, prefiltered=rs0.prefiltered)
+                                 scales.data_ptr(), rs0.scale_modifier, rotations.data_ptr(), arr, V, prefiltered=rs0.prefiltered, opt=self.options)
             finally:
                 _C.set_render_streams([])
             images = pool["images"]
@@ -508,7 +515,7 @@ class SyncFreeBatch:
                 # The per-Gaussian pass of the views whose per-pixel backward finishes first runs on a stream of its own BESIDE the per-pixel
                 # backwards of the remaining views (it is bound by HBM latency, they by vector issue and LDS); the pass at the end of the step,
                 # alone on the GPU, then covers the remaining views only.
-                _C.backward_render_views(bw_handles, P, arr, first)
+                _C.backward_render_views(bw_handles, P, arr, first, opt=self.options)
                 ps = self._pass_stream.setdefault(dev, torch.cuda.Stream(device=dev))
                 for st in (ren_lanes if upstream_view is not None else lanes):
                     ev = torch.cuda.Event()
@@ -520,11 +527,11 @@ class SyncFreeBatch:
                 ev_a = torch.cuda.Event()
                 ev_a.record(ps)
                 rest = C.cast(C.addressof(arr) + first * C.sizeof(_C._ViewT), C.c_void_p)
-                _C.backward_render_views(bw_handles, P, rest, V - first)
+                _C.backward_render_views(bw_handles, P, rest, V - first, opt=self.options)
                 join()
                 main.wait_event(ev_a)
             else:
-                _C.backward_render_views(bw_handles, P, arr, V)
+                _C.backward_render_views(bw_handles, P, arr, V, opt=self.options)
                 join()
             def verdict():
                 """waits for the Meta records (the one host wait of the batch: they left right behind the forwards) -> (views to render again, largest count)"""
