@@ -34,7 +34,7 @@ VALU_PEAK_GWIPS = 1228.8
 # render loops' mix (6 fma/mul + 1 DPP + 1 transcendental per 8: DPP operations issue at half rate, v_exp_f32 at a quarter)
 VALU_MEASURED_FMA_GWIPS = 955.5
 VALU_MEASURED_MIX_GWIPS = 628.4
-PROFILE_SET = "r03_f"          # profiles/<set>_{hbm,sq}_counters.json: the PMC passes the roofline object quotes (tools/profile_round.sh); only
+PROFILE_SET = "r04_a"          # profiles/<set>_{hbm,sq}_counters.json: the PMC passes the roofline object quotes (tools/profile_round.sh); only
                                # used while their csrc_sha16 equals the hash of the sources this run executes (build.source_hash)
 
 
@@ -66,8 +66,10 @@ def parse():
                     "alive-pair count) that are reported beside the headline at N = 1")
     ap.add_argument("--cpu-splat-only", action="store_true", help="internal: run only the PyTorch point-splat CPU baseline of BASELINE config 1 and print its JSON "
                     "(cpu_baseline starts this as a child process with a time limit)")
-    ap.add_argument("--grad-chunks", type=int, default=4, help="N > 1: the step's per-Gaussian pass runs in this many Gaussian ranges and each range's all-reduce "
-                    "starts behind its launch (1 = one blocking all-reduce behind the whole pass)")
+    ap.add_argument("--grad-chunks", type=int, default=2, help="N > 1: the step's per-Gaussian pass runs in this many Gaussian ranges and each range's all-reduce "
+                    "starts behind its launch (1 = one blocking all-reduce behind the whole pass).  Default 2 since round 4: cutting the pass costs 1 % "
+                    "with two ranges and 4.6 % with four, a collective 13-42 us at world size 1 (secondary.rccl_world1), and the all-reduce is longer "
+                    "than the whole pass -- two ranges expose the least (DESIGN.md section 7)")
     return ap.parse_args()
 
 

@@ -156,6 +156,42 @@ def test_debug_mode_and_prefiltered_error(gpu_device, tmp_path, monkeypatch):
     assert (tmp_path / "snapshot_fw.dump").exists()
 
 
+@pytest.mark.parametrize("where", [0, 70_000, 199_999])
+def test_prefiltered_violation_travels_through_the_block_flags(where, gpu_device):
+    """Round 4: the prefiltered-violation flag is no atomic on Meta any more (the per-Gaussian stage clears Meta itself) but one word per
+    256-Gaussian block, OR-ed by k_scan -- across several scan iterations at 200 k Gaussians (782 blocks).  One culled Gaussian anywhere
+    must raise, in the synchronous forward, in the speculative one (second call on the same sizes) and in the whole-batch path; the same
+    cloud without `prefiltered` renders, and twice in a row (Meta really is cleared per frame: no stale flag)."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from youreditableavatar_amd import scenes
+    from youreditableavatar_amd.multiview import FlatGradients, SyncFreeBatch
+    P = 200_000
+    cam = scenes.orbit_camera(320, 200, azimuth_deg=12.0)
+    cloud = scenes.make_cloud(P, 0, seed=5, scale_mult=1.0)
+    behind = (np.concatenate([cloud["means3D"], np.ones((P, 1), np.float32)], 1) @ cam.viewmatrix)[:, 2] <= 0.2
+    cloud["means3D"][behind] *= 0.2                                  # every Gaussian in front of the near plane ...
+    assert not ((np.concatenate([cloud["means3D"], np.ones((P, 1), np.float32)], 1) @ cam.viewmatrix)[:, 2] <= 0.2).any()
+    L = _leaves(cloud, gpu_device)
+    rs_ok = _settings(cam, 0, gpu_device)._replace(prefiltered=True)
+    kw = lambda LL: dict(means3D=LL["means3D"], means2D=torch.zeros(P, 3, device=gpu_device), opacities=LL["opacities"], shs=LL["shs"], scales=LL["scales"], rotations=LL["rotations"])
+    for _ in range(3):                                              # synchronous, then speculative: no violation, no stale flag
+        img, _r = GaussianRasterizer(rs_ok)(**kw(L))
+    bad = dict(cloud); bad["means3D"] = cloud["means3D"].copy(); bad["means3D"][where] = cam.campos * 2.0      # ... except this one
+    Lb = _leaves(bad, gpu_device)
+    for _ in range(2):                                              # (the first call of a size is synchronous, the second speculative)
+        with pytest.raises(RuntimeError, match="filtered although prefiltered"):
+            GaussianRasterizer(rs_ok)(**kw(Lb))
+    img2, _r = GaussianRasterizer(rs_ok)(**kw(L))                    # and the flag does not stick
+    assert torch.equal(img, img2)
+    names = ("means3D", "opacities", "scales", "rotations", "shs")
+    FlatGradients([Lb[n] for n in names])
+    batch = SyncFreeBatch(granule=256, streams=2)
+    dL = torch.from_numpy(scenes.upstream_gradient(320, 200, seed=1)).to(gpu_device)
+    with pytest.raises(RuntimeError, match="filtered although prefiltered"):
+        for _ in range(3):                                          # (the first batch takes the per-view fallback, the later ones the sync-free path)
+            batch.run_views([rs_ok, rs_ok], Lb["means3D"], Lb["opacities"], Lb["shs"], Lb["scales"], Lb["rotations"], lambda im: dL, accumulate=False)
+
+
 @pytest.mark.parametrize("cfg", [2, 3])
 def test_baseline_config_full_size_vs_oracle(cfg, gpu_device):
     """BASELINE.json configs 2 (100k / 800x800 / SH3) and 3 (500k / 1920x1080 / SH3) at FULL size against the CPU oracle."""

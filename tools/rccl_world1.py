@@ -1,5 +1,5 @@
 """The N > 1 step's collective path through the REAL backend at world size 1 (the pool has one GPU per box): backend "nccl" = RCCL, the
-gradients of the 8-view step of config 3 all-reduced in 4 Gaussian ranges behind the per-Gaussian pass (SyncFreeBatch.run_views(grad_chunks,
+gradients of the 8-view step of config 3 all-reduced in 2 Gaussian ranges (bench.py's --grad-chunks default) behind the per-Gaussian pass (SyncFreeBatch.run_views(grad_chunks,
 on_chunk) + FlatGradients.all_reduce_rows(even_alone=True)).  A sum over one rank moves no data between GPUs: this times RCCL's launches and
 the stream choreography, not xGMI.  Stand-alone (bench.py runs it as a child process with a time limit and copies the JSON line into
 secondary.rccl_world1, so that a problem in the collective library cannot take the bench line down).   python tools/rccl_world1.py [config]"""
@@ -33,7 +33,7 @@ batch = SyncFreeBatch(streams=4)
 pend = []
 
 
-def step(reduce, chunks=4):
+def step(reduce, chunks=2):
     batch.run_views(S, L["means3D"], L["opacities"], L["shs"], L["scales"], L["rotations"], None, accumulate=False, upstream_view=lambda v, image: dL, grad_chunks=chunks,
                     on_chunk=(lambda first, count: pend.extend(flat.all_reduce_rows(first, count, even_alone=True))) if reduce else (lambda f, c: None))
     n = len(pend)
@@ -43,7 +43,7 @@ def step(reduce, chunks=4):
     return n
 
 
-def timed(reduce, n, warm, chunks=4):
+def timed(reduce, n, warm, chunks=2):
     for _ in range(warm):
         step(reduce, chunks)
     torch.cuda.synchronize()
@@ -65,6 +65,7 @@ table = {}
 for c in (1, 2, 4):
     table[str(c)] = {"with_reduce": round(timed(True, 8, 2, c)[0], 4), "without": round(timed(False, 8, 2, c)[0], 4)}
 per_collective_us = round((table["4"]["with_reduce"] - table["4"]["without"]) / 4 * 1e3, 1)
+cut2 = round(table["2"]["without"] / table["1"]["without"] - 1.0, 4)
 ref = flat.flat.clone()
 step(True)
 torch.cuda.synchronize()
@@ -72,8 +73,9 @@ same = bool(torch.equal(ref, flat.flat))
 print(json.dumps({"ms_per_step_with_reduce": round(ms_r, 4), "ms_per_step_without": round(ms_n, 4), "backend": str(dist.get_backend()), "collective_handles_per_step": handles,
                   "gradients_unchanged_by_the_one_rank_sum": same, "frames_rerendered": batch.rejected,
                   "ms_per_step_by_ranges": table, "rccl_cost_per_collective_us_at_world_1": per_collective_us,
-                  "range_cutting_cost_frac": round(table["4"]["without"] / table["1"]["without"] - 1.0, 4),
-                  "what": f"8-view step of config {cfg_i} with its gradients all-reduced in 4 Gaussian ranges through RCCL at world size 1 (one coalesced collective per range, "
+                  "range_cutting_cost_frac": {"2": cut2, "4": round(table["4"]["without"] / table["1"]["without"] - 1.0, 4)},
+                  "overhead_frac_of_the_default_two_ranges": round(table["2"]["with_reduce"] / table["1"]["without"] - 1.0, 4),
+                  "what": f"8-view step of config {cfg_i} with its gradients all-reduced in 2 Gaussian ranges (the default of bench.py --grad-chunks) through RCCL at world size 1 (one coalesced collective per range, "
                           "overlapped with the per-Gaussian pass): the N > 1 control flow on the production backend; no data crosses xGMI.  ms_per_step_by_ranges separates "
                           "the cost of cutting the per-Gaussian pass into ranges (without) from RCCL's per-collective launch + stream hand-over (with - without)"}), flush=True)
 dist.destroy_process_group()
