@@ -822,6 +822,19 @@ __device__ __forceinline__ void cov3d_bwd_f64(const double (&dc)[6], float scale
     }
 }
 
+// the Gaussian's 3D covariance as the forward used it: evaluated again from scale and rotation (compute_cov3d, bit-identical), or the caller's
+template <bool HAS_SCALE_ROT>
+__device__ __forceinline__ void load_cov3d(const BwdIn& in, float scale_modifier, int idx, float (&cov3d)[6])
+{
+    if (HAS_SCALE_ROT) {
+        const size_t i3 = 3 * (size_t)idx;
+        compute_cov3d(scale_modifier, in.scales[i3], in.scales[i3 + 1], in.scales[i3 + 2], reinterpret_cast<const float4*>(in.rotations)[idx], cov3d);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 6; i++) cov3d[i] = in.cov3D_precomp[6 * (size_t)idx + i];
+    }
+}
+
 struct GaussTerms {
     float a[NACC];                 // sums of the tile partials: colour rgb, mean2D xy, conic xx xy yy, opacity
     float dmean[3], dcov[6], dscale[3], drot[4];
@@ -834,7 +847,8 @@ struct GaussTerms {
 template <bool HAS_SH, bool HAS_SCALE_ROT, typename ShRow>
 __device__ __forceinline__ void pergauss_terms(int idx, bool live, int D, const ShRow& sh, const BwdIn& in, const float* __restrict__ cov3D_precomp,
                                                const CamParams& cam, const ViewMat& V, const ViewMat& PM, float camx, float camy, float camz,
-                                               const GeomState& g, const BinState& b, uint32_t tiles_in, uint32_t off_in, GaussTerms& t, double (&dcacc)[6])
+                                               const GeomState& g, const BinState& b, uint32_t tiles_in, uint32_t off_in, float mx, float my, float mz,
+                                               const float (&cov3d)[6], GaussTerms& t, double (&dcacc)[6])
 {
     float (&a)[NACC] = t.a;
     float (&dmean)[3] = t.dmean; float (&dcov)[6] = t.dcov; float (&dscale)[3] = t.dscale; float (&drot)[4] = t.drot;
@@ -851,22 +865,11 @@ __device__ __forceinline__ void pergauss_terms(int idx, bool live, int D, const 
     for (int k = 0; k < 16; k++) coef[k] = 0.f;
     if (!live) return;
     const size_t i3 = 3 * (size_t)idx;
-    const float mx = in.means3D[i3], my = in.means3D[i3 + 1], mz = in.means3D[i3 + 2];
 #if TGS_PERGAUSS_F64
-    {
-        float cov3d[6];
-        const float* csrc = HAS_SCALE_ROT ? (g.cov3D + 6 * (size_t)idx) : (cov3D_precomp + 6 * (size_t)idx);
-#pragma unroll
-        for (int i = 0; i < 6; i++) cov3d[i] = csrc[i];
-        cov2d_chain_bwd_f64<true>(mx, my, mz, cov3d, cam, V, PM, cn, a[3], a[4], dmean, dcacc);
-    }
+    cov2d_chain_bwd_f64<true>(mx, my, mz, cov3d, cam, V, PM, cn, a[3], a[4], dmean, dcacc);
 #else
     {
         // ---- computeCov2DCUDA (backward.cu:144-274) ----
-        float cov3d[6];
-        const float* csrc = HAS_SCALE_ROT ? (g.cov3D + 6 * (size_t)idx) : (cov3D_precomp + 6 * (size_t)idx);
-#pragma unroll
-        for (int i = 0; i < 6; i++) cov3d[i] = csrc[i];
         const Cov2D c2 = compute_cov2d(mx, my, mz, cov3d, cam, V);
         const float limx = 1.3f * cam.tan_fovx, limy = 1.3f * cam.tan_fovy;
         const float x_grad_mul = (c2.txtz < -limx || c2.txtz > limx) ? 0.f : 1.f;
@@ -1091,9 +1094,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
 #if TGS_PERGAUSS_F64
         {
             float cov3d[6];
-            const float* csrc = HAS_SCALE_ROT ? (g.cov3D + 6 * (size_t)idx) : (in.cov3D_precomp + 6 * (size_t)idx);
-#pragma unroll
-            for (int i = 0; i < 6; i++) cov3d[i] = csrc[i];
+            load_cov3d<HAS_SCALE_ROT>(in, cam.scale_modifier, idx, cov3d);
             double dc64[6];
             cov2d_chain_bwd_f64<false>(mx, my, mz, cov3d, cam, V, PM, cn, a[3], a[4], dmean, dc64);
 #pragma unroll
@@ -1103,9 +1104,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
 #else
         // ---- computeCov2DCUDA (backward.cu:144-274) ----
         float cov3d[6];
-        const float* csrc = HAS_SCALE_ROT ? (g.cov3D + 6 * (size_t)idx) : (in.cov3D_precomp + 6 * (size_t)idx);
-#pragma unroll
-        for (int i = 0; i < 6; i++) cov3d[i] = csrc[i];
+        load_cov3d<HAS_SCALE_ROT>(in, cam.scale_modifier, idx, cov3d);
         const Cov2D c2 = compute_cov2d(mx, my, mz, cov3d, cam, V);
         const float limx = 1.3f * cam.tan_fovx, limy = 1.3f * cam.tan_fovy;
         const float x_grad_mul = (c2.txtz < -limx || c2.txtz > limx) ? 0.f : 1.f;
@@ -1359,6 +1358,12 @@ __global__ __launch_bounds__(PRE_BLOCK, 2) void k_preprocess_bwd_batch(const Bwd
     for (int i = 0; i < 48; i++) o48[i] = 0.f;
     float dopacity = 0.f, dmean[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dscale[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
     double dcsum[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};      // dL_dcov3D summed over the views in double (TGS_PERGAUSS_F64: cov3d_bwd_f64 runs once, behind the loop)
+    // view-independent inputs of the geometry chain, once: the mean and the 3D covariance (evaluated as the forward did, compute_cov3d)
+    float gmx = 0.f, gmy = 0.f, gmz = 0.f, cov3d[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (in_range) {
+        gmx = in.means3D[3 * (size_t)idx]; gmy = in.means3D[3 * (size_t)idx + 1]; gmz = in.means3D[3 * (size_t)idx + 2];
+        load_cov3d<HAS_SCALE_ROT>(in, views.v[0].cam.scale_modifier, idx, cov3d);
+    }
 #pragma unroll 1
     for (int v = 0; v < views.n; v++) {
         const BatchView& vw = views.v[v];
@@ -1368,7 +1373,7 @@ __global__ __launch_bounds__(PRE_BLOCK, 2) void k_preprocess_bwd_batch(const Bwd
         if (__builtin_amdgcn_ballot_w64(live) != 0) {
             const ViewMat V = load_mat(vw.cam.view), PM = load_mat(vw.cam.proj);
             pergauss_terms<HAS_SH, HAS_SCALE_ROT>(idx, live, in.D, [&](int i) { return sh_row[i]; }, in, in.cov3D_precomp, vw.cam, V, PM, vw.cam.campos[0], vw.cam.campos[1],
-                                                  vw.cam.campos[2], vw.g, vw.b, pv_lds[v][1][threadIdx.x], pv_lds[v][2][threadIdx.x], t, dcsum);
+                                                  vw.cam.campos[2], vw.g, vw.b, pv_lds[v][1][threadIdx.x], pv_lds[v][2][threadIdx.x], gmx, gmy, gmz, cov3d, t, dcsum);
         } else {
             t.a[0] = t.a[1] = t.a[2] = t.a[3] = t.a[4] = 0.f;
         }
@@ -1446,12 +1451,16 @@ constexpr int SPLIT_G = PRE_BLOCK / 2;                      // Gaussians per wor
 #ifndef TGS_SPLIT_WAVES
 #define TGS_SPLIT_WAVES 3
 #endif
+#ifndef TGS_EXP_SKIP_HALF
+#define TGS_EXP_SKIP_HALF 0            // timing experiments only: 1 = the colour half walks no view, 2 = the geometry half walks none (WRONG gradients)
+#endif
 template <bool HAS_SCALE_ROT>
 __global__ __launch_bounds__(PRE_BLOCK, TGS_SPLIT_WAVES) void k_preprocess_bwd_batch_split(const BwdIn in, const BatchViews views)
 {
     __shared__ float4 sh_lds[SPLIT_G * 12];                 // the SH rows of the 128 Gaussians in, their dL_dsh rows out
     __shared__ uint32_t pv_lds[BATCH_VIEWS][3][SPLIT_G];    // radii / tiles_touched / offsets of every Gaussian in every view (as in the one-thread kernel), shared by its two threads
     __shared__ float dm_lds[3][SPLIT_G];                    // the colour half's share of dL_dmean3D
+    __shared__ float gc_lds[9][SPLIT_G];                    // geometry half: mean and 3D covariance of its Gaussian
     const bool colour = threadIdx.x >= SPLIT_G;             // wave-uniform
     const int gl = threadIdx.x & (SPLIT_G - 1);             // Gaussian of the workgroup
     const size_t gbase = ((size_t)in.block0 * 2 + blockIdx.x) * SPLIT_G;
@@ -1483,7 +1492,7 @@ __global__ __launch_bounds__(PRE_BLOCK, TGS_SPLIT_WAVES) void k_preprocess_bwd_b
         for (int i = 0; i < 48; i++) o48[i] = 0.f;
         float dmean[3] = {0.f, 0.f, 0.f};
 #pragma unroll 1
-        for (int v = 0; v < views.n; v++) {
+        for (int v = 0; v < (TGS_EXP_SKIP_HALF == 1 ? 0 : views.n); v++) {
             const BatchView& vw = views.v[v];
             const bool rejected = (vw.meta->error & META_ERR_CAPACITY) != 0u;
             const bool live = in_range && !rejected && (int)pv_lds[v][0][gl] > 0;
@@ -1508,16 +1517,31 @@ __global__ __launch_bounds__(PRE_BLOCK, TGS_SPLIT_WAVES) void k_preprocess_bwd_b
     } else {
         float dopacity = 0.f, dmean[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dscale[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
         double dcsum[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        // view-independent inputs of the chain, once: the mean and the 3D covariance (compute_cov3d, as the forward evaluated it).  Parked in
+        // LDS, each thread its own nine words (no barrier): held in registers across the view loop they push the kernel over the 168 VGPRs of
+        // three waves per SIMD.
+        if (in_range) {
+            float cov3d[6];
+            load_cov3d<HAS_SCALE_ROT>(in, views.v[0].cam.scale_modifier, idx, cov3d);
+#pragma unroll
+            for (int k = 0; k < 3; k++) gc_lds[k][gl] = in.means3D[3 * (size_t)idx + k];
+#pragma unroll
+            for (int k = 0; k < 6; k++) gc_lds[3 + k][gl] = cov3d[k];
+        }
 #pragma unroll 1
-        for (int v = 0; v < views.n; v++) {
+        for (int v = 0; v < (TGS_EXP_SKIP_HALF == 2 ? 0 : views.n); v++) {
             const BatchView& vw = views.v[v];
             const bool rejected = (vw.meta->error & META_ERR_CAPACITY) != 0u;
             const bool live = in_range && !rejected && (int)pv_lds[v][0][gl] > 0;
             GaussTerms t;
             if (__builtin_amdgcn_ballot_w64(live) != 0) {
                 const ViewMat V = load_mat(vw.cam.view), PM = load_mat(vw.cam.proj);
+                asm volatile("" ::: "memory");             // (read the nine words here, not in front of the loop)
+                float cov3d[6];
+#pragma unroll
+                for (int k = 0; k < 6; k++) cov3d[k] = gc_lds[3 + k][gl];
                 pergauss_terms<false, HAS_SCALE_ROT>(idx, live, in.D, [&](int) { return 0.f; }, in, in.cov3D_precomp, vw.cam, V, PM, vw.cam.campos[0], vw.cam.campos[1],
-                                                     vw.cam.campos[2], vw.g, vw.b, pv_lds[v][1][gl], pv_lds[v][2][gl], t, dcsum);
+                                                     vw.cam.campos[2], vw.g, vw.b, pv_lds[v][1][gl], pv_lds[v][2][gl], gc_lds[0][gl], gc_lds[1][gl], gc_lds[2][gl], cov3d, t, dcsum);
             } else {
                 t.a[3] = t.a[4] = 0.f;
             }

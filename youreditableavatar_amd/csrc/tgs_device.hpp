@@ -52,7 +52,7 @@ struct GeomState {
     float4* pack;
     uint2* live;              // the same mask once more, compact (the binning kernels read 20 B per Gaussian instead of its pack line)
     float* depth;             // view-space z                       (geomState.depths)
-    float* cov3D;             // 6 floats, scale/rot path only      (geomState.cov3D)
+    // (geomState.cov3D has no counterpart: the backward evaluates compute_cov3d again)
     uint8_t* clamped;         // 3 clamp bits per Gaussian          (geomState.clamped)
     ushort4* rect;            // tile rectangle (minx, miny, maxx, maxy)
     uint32_t* tiles_touched;  //                                    (geomState.tiles_touched)
@@ -100,8 +100,8 @@ __host__ __device__ inline size_t n_blocks(size_t P) { return (P + PRE_BLOCK - 1
 __host__ __device__ inline size_t geom_carve(GeomState& g, char* base, size_t P, bool has_sh, bool has_scale_rot)
 {
     char* p = base;
-    (void)has_sh;
-    carve(p, g.pack, 4 * P); carve(p, g.live, P); carve(p, g.depth, P); carve(p, g.cov3D, has_scale_rot ? 6 * P : 0);
+    (void)has_sh; (void)has_scale_rot;
+    carve(p, g.pack, 4 * P); carve(p, g.live, P); carve(p, g.depth, P);
     carve(p, g.clamped, P); carve(p, g.rect, P); carve(p, g.tiles_touched, P); carve(p, g.offsets, P);
     carve(p, g.block_sums, n_blocks(P) + 1); carve(p, g.block_flags, n_blocks(P) + 1);
     return (size_t)(p - base) + 256;
@@ -800,6 +800,21 @@ __device__ __forceinline__ mat3 quat_to_R(float r, float x, float y, float z)
     return m3make(1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
                   2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
                   2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y));
+}
+// computeCov3D (forward.cu:118-152): the six upper-triangle entries of Sigma = (S R)^T (S R) from the scale (times the modifier) and the
+// un-normalised quaternion.  ONE function for the forward and for both backward kernels: the backward evaluates it again instead of
+// reading a copy the forward would have to store (24 B per Gaussian and view written, 24 B read -- and undefined for a Gaussian outside
+// the view's frustum), and the two must agree to the bit.
+__device__ __forceinline__ void compute_cov3d(float scale_modifier, float s0, float s1, float s2, float4 q, float (&cov3d)[6])
+{
+#pragma clang fp contract(off)
+    const float sx = scale_modifier * s0, sy = scale_modifier * s1, sz = scale_modifier * s2;
+    const mat3 S = m3make(sx, 0.f, 0.f, 0.f, sy, 0.f, 0.f, 0.f, sz);
+    const mat3 R = quat_to_R(q.x, q.y, q.z, q.w);
+    const mat3 Mx = m3mul(S, R);
+    const mat3 Sg = m3mul(m3t(Mx), Mx);
+    cov3d[0] = Sg.m[0][0]; cov3d[1] = Sg.m[0][1]; cov3d[2] = Sg.m[0][2];
+    cov3d[3] = Sg.m[1][1]; cov3d[4] = Sg.m[1][2]; cov3d[5] = Sg.m[2][2];
 }
 #endif  // __HIPCC__
 

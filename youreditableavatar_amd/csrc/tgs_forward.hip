@@ -177,18 +177,8 @@ __device__ __forceinline__ uint32_t preprocess_fwd_one(const FwdIn& in, int* __r
         if (ok) {
             float cov3d[6];
             if (HAS_SCALE_ROT) {
-                // computeCov3D (forward.cu:118-152)
-                const float sx = cam.scale_modifier * in.scales[3 * (size_t)idx], sy = cam.scale_modifier * in.scales[3 * (size_t)idx + 1],
-                            sz = cam.scale_modifier * in.scales[3 * (size_t)idx + 2];
-                const float4 q = reinterpret_cast<const float4*>(in.rotations)[idx];
-                mat3 S = m3make(sx, 0.f, 0.f, 0.f, sy, 0.f, 0.f, 0.f, sz);
-                mat3 R = quat_to_R(q.x, q.y, q.z, q.w);
-                mat3 Mx = m3mul(S, R);
-                mat3 Sg = m3mul(m3t(Mx), Mx);
-                cov3d[0] = Sg.m[0][0]; cov3d[1] = Sg.m[0][1]; cov3d[2] = Sg.m[0][2];
-                cov3d[3] = Sg.m[1][1]; cov3d[4] = Sg.m[1][2]; cov3d[5] = Sg.m[2][2];
-#pragma unroll
-                for (int i = 0; i < 6; i++) g.cov3D[6 * (size_t)idx + i] = cov3d[i];
+                compute_cov3d(cam.scale_modifier, in.scales[3 * (size_t)idx], in.scales[3 * (size_t)idx + 1], in.scales[3 * (size_t)idx + 2],
+                              reinterpret_cast<const float4*>(in.rotations)[idx], cov3d);     // (not stored: the backward evaluates it again)
             } else {
 #pragma unroll
                 for (int i = 0; i < 6; i++) cov3d[i] = in.cov3D_precomp[6 * (size_t)idx + i];
