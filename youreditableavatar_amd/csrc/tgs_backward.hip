@@ -591,6 +591,8 @@ __device__ __forceinline__ double wave_sum_f64(double v)
     return v;
 }
 // cn[0..2]: the conic sums (xx, xy, yy) in double from the rows' hi + lo parts (conic_hilo); a[5..7] are their fp32 roundings
+// PAIRS: two rows per trip of the lane's own loop (24 registers in flight instead of 12: the one-view kernel has them, the batch kernels have not)
+template <bool PAIRS>
 __device__ __forceinline__ void slab_sum(bool live, uint32_t tiles_in, uint32_t off_in, const BinState& b, float (&a)[NACC], double (&cn)[3])
 {
     const int lane = threadIdx.x & 63;
@@ -618,12 +620,28 @@ __device__ __forceinline__ void slab_sum(bool live, uint32_t tiles_in, uint32_t 
 #pragma unroll
         for (int c = 0; c < 3; c++) { const double tot = wave_sum_f64(pc[c]); if (lane == src) cn[c] = tot; }
     }
-    if (tiles < SLAB_COOP) {
+    if (!PAIRS && tiles < SLAB_COOP) {
         const float4* row = b.slab + (size_t)off * SLAB_ROW;
         for (uint32_t k = 0; k < tiles; k++, row += SLAB_ROW) {
             const float4 r0 = row[0], r1 = row[1], r2 = row[2];
             a[0] += r0.x; a[1] += r0.y; a[2] += r0.z; a[3] += r0.w; a[4] += r1.x; a[8] += r2.x;
             cn[0] += (double)r1.y + (double)r2.y; cn[1] += (double)r1.z + (double)r2.z; cn[2] += (double)r1.w + (double)r2.w;
+        }
+    }
+    if (PAIRS && tiles < SLAB_COOP) {
+        // two rows per trip, their loads issued together (slab_sum_rgb); same order of the additions
+        const float4* row = b.slab + (size_t)off * SLAB_ROW;
+        for (uint32_t k = 0; k < tiles; k += 2) {
+            const float4* ra = row + (size_t)k * SLAB_ROW;
+            const float4* rb = row + (size_t)min(k + 1u, tiles - 1u) * SLAB_ROW;
+            const float4 r0 = ra[0], r1 = ra[1], r2 = ra[2], t0 = rb[0], t1 = rb[1], t2 = rb[2];
+            asm volatile("" ::: "memory");                  // (the loads stay here: the compiler sinks the second row's into its branch)
+            a[0] += r0.x; a[1] += r0.y; a[2] += r0.z; a[3] += r0.w; a[4] += r1.x; a[8] += r2.x;
+            cn[0] += (double)r1.y + (double)r2.y; cn[1] += (double)r1.z + (double)r2.z; cn[2] += (double)r1.w + (double)r2.w;
+            if (k + 1u < tiles) {
+                a[0] += t0.x; a[1] += t0.y; a[2] += t0.z; a[3] += t0.w; a[4] += t1.x; a[8] += t2.x;
+                cn[0] += (double)t1.y + (double)t2.y; cn[1] += (double)t1.z + (double)t2.z; cn[2] += (double)t1.w + (double)t2.w;
+            }
         }
     }
     a[5] = (float)cn[0]; a[6] = (float)cn[1]; a[7] = (float)cn[2];
@@ -854,7 +872,7 @@ __device__ __forceinline__ void pergauss_terms(int idx, bool live, int D, const 
     float (&dmean)[3] = t.dmean; float (&dcov)[6] = t.dcov; float (&dscale)[3] = t.dscale; float (&drot)[4] = t.drot;
     float (&coef)[16] = t.coef; float (&dRGB)[3] = t.dRGB;
     double cn[3];
-    slab_sum(live, tiles_in, off_in, b, a, cn);            // convergent: the wave helps its splats that touch many tiles
+    slab_sum<false>(live, tiles_in, off_in, b, a, cn);     // convergent: the wave helps its splats that touch many tiles
 #pragma unroll
     for (int k = 0; k < 3; k++) { dmean[k] = 0.f; dscale[k] = 0.f; dRGB[k] = 0.f; }
 #pragma unroll
@@ -1019,12 +1037,20 @@ __device__ __forceinline__ void store_sh_rows_staged(const BwdIn& in, float4* sh
     for (int q = 0; q < 12; q++) sh_lds[threadIdx.x * 12 + q] = make_float4(o48(4 * q), o48(4 * q + 1), o48(4 * q + 2), o48(4 * q + 3));
     __syncthreads();
     float4* d4 = reinterpret_cast<float4*>(in.dL_dsh);
+    float4 prev[12];
+    if (in.accumulate) {                                   // (uniform) the twelve reads in flight together
+#pragma unroll
+        for (int q = 0; q < 12; q++) { const size_t i = base4 + q * PRE_BLOCK + threadIdx.x; prev[q] = d4[i < total4 ? i : total4 - 1]; }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 12; q++) prev[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 #pragma unroll
     for (int q = 0; q < 12; q++) {
         const size_t i = base4 + q * PRE_BLOCK + threadIdx.x;
         if (i < total4) {
             float4 o = sh_lds[q * PRE_BLOCK + threadIdx.x];
-            if (in.accumulate) { const float4 p = d4[i]; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+            if (in.accumulate) { o.x += prev[q].x; o.y += prev[q].y; o.z += prev[q].z; o.w += prev[q].w; }
             d4[i] = o;
         }
     }
@@ -1033,8 +1059,13 @@ __device__ __forceinline__ void load_sh_rows_staged(const BwdIn& in, float4* sh_
 {
     const size_t base4 = (size_t)blk * PRE_BLOCK * 12, total4 = (size_t)in.P * 12;
     const float4* s4 = reinterpret_cast<const float4*>(in.shs);
+    // into registers first, then into LDS: written as `if (i < total4) sh_lds[..] = s4[i]` every load is waited for on its own before its
+    // LDS write -- twelve memory latencies in a row at the head of the workgroup
+    float4 r[12];
 #pragma unroll
-    for (int q = 0; q < 12; q++) { const size_t i = base4 + q * PRE_BLOCK + threadIdx.x; if (i < total4) sh_lds[q * PRE_BLOCK + threadIdx.x] = s4[i]; }
+    for (int q = 0; q < 12; q++) { const size_t i = base4 + q * PRE_BLOCK + threadIdx.x; r[q] = s4[i < total4 ? i : total4 - 1]; }
+#pragma unroll
+    for (int q = 0; q < 12; q++) sh_lds[q * PRE_BLOCK + threadIdx.x] = r[q];
     __syncthreads();
 }
 
@@ -1070,8 +1101,11 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
     const size_t base4 = (size_t)blockIdx.x * PRE_BLOCK * 12, total4 = (size_t)in.P * 12;
     if (sh_staged) {
         const float4* s4 = reinterpret_cast<const float4*>(in.shs);
+        float4 r[12];                                           // registers first: the twelve loads in flight together (load_sh_rows_staged)
 #pragma unroll
-        for (int q = 0; q < 12; q++) { const size_t i = base4 + q * PRE_BLOCK + threadIdx.x; if (i < total4) sh_lds[q * PRE_BLOCK + threadIdx.x] = s4[i]; }
+        for (int q = 0; q < 12; q++) { const size_t i = base4 + q * PRE_BLOCK + threadIdx.x; r[q] = s4[i < total4 ? i : total4 - 1]; }
+#pragma unroll
+        for (int q = 0; q < 12; q++) sh_lds[q * PRE_BLOCK + threadIdx.x] = r[q];
         __syncthreads();
     }
     const bool in_range = idx < in.P;
@@ -1087,7 +1121,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
     float mx = 0.f, my = 0.f, mz = 0.f;
     float dRGB[3] = {0.f, 0.f, 0.f};
     double cn[3];
-    slab_sum(live, live ? g.tiles_touched[idx] : 0u, live ? g.offsets[idx] : 0u, b, a, cn);   // sum of this Gaussian's tile partials (wave-cooperative for big splats)
+    slab_sum<true>(live, live ? g.tiles_touched[idx] : 0u, live ? g.offsets[idx] : 0u, b, a, cn);   // sum of this Gaussian's tile partials (wave-cooperative for big splats)
     if (live) {
         mx = in.means3D[i3]; my = in.means3D[i3 + 1]; mz = in.means3D[i3 + 2];
 
@@ -1279,12 +1313,20 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
             }
             __syncthreads();
             float4* d4 = reinterpret_cast<float4*>(in.dL_dsh);
+            float4 prev[12];
+            if (in.accumulate) {                               // (uniform) the twelve reads in flight together
+#pragma unroll
+                for (int q = 0; q < 12; q++) { const size_t i = base4 + q * PRE_BLOCK + threadIdx.x; prev[q] = d4[i < total4 ? i : total4 - 1]; }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 12; q++) prev[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
 #pragma unroll
             for (int q = 0; q < 12; q++) {
                 const size_t i = base4 + q * PRE_BLOCK + threadIdx.x;
                 if (i < total4) {
                     float4 o = sh_lds[q * PRE_BLOCK + threadIdx.x];
-                    if (in.accumulate) { const float4 p = d4[i]; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+                    if (in.accumulate) { o.x += prev[q].x; o.y += prev[q].y; o.z += prev[q].z; o.w += prev[q].w; }
                     d4[i] = o;
                 }
             }
@@ -1350,8 +1392,13 @@ __global__ __launch_bounds__(PRE_BLOCK, 2) void k_preprocess_bwd_batch(const Bwd
             pr[v] = pt[v] = po[v] = 0u;
             if (v < views.n && in_range) { pr[v] = (uint32_t)views.v[v].radii[idx]; pt[v] = views.v[v].g.tiles_touched[idx]; po[v] = views.v[v].g.offsets[idx]; }
         }
+        // a frame tgs_forward_async could not fit contributes nothing: its radii count as 0.  Read here, with the loads above, and not at the
+        // head of every trip of the view loop -- there it was one more memory round trip in front of the trip's slab rows.
+        uint32_t rej[BATCH_VIEWS];
 #pragma unroll
-        for (int v = 0; v < BATCH_VIEWS; v++) { pv_lds[v][0][threadIdx.x] = pr[v]; pv_lds[v][1][threadIdx.x] = pt[v]; pv_lds[v][2][threadIdx.x] = po[v]; }
+        for (int v = 0; v < BATCH_VIEWS; v++) rej[v] = v < views.n ? (views.v[v].meta->error & META_ERR_CAPACITY) : 0u;
+#pragma unroll
+        for (int v = 0; v < BATCH_VIEWS; v++) { pv_lds[v][0][threadIdx.x] = rej[v] ? 0u : pr[v]; pv_lds[v][1][threadIdx.x] = pt[v]; pv_lds[v][2][threadIdx.x] = po[v]; }
     }
     float o48[48];                                         // dL_dsh row accumulated over the views (dead code without SH)
 #pragma unroll
@@ -1367,8 +1414,7 @@ __global__ __launch_bounds__(PRE_BLOCK, 2) void k_preprocess_bwd_batch(const Bwd
 #pragma unroll 1
     for (int v = 0; v < views.n; v++) {
         const BatchView& vw = views.v[v];
-        const bool rejected = (vw.meta->error & META_ERR_CAPACITY) != 0u;       // tgs_forward_async could not fit this frame: it contributes nothing
-        const bool live = in_range && !rejected && (int)pv_lds[v][0][threadIdx.x] > 0;
+        const bool live = in_range && (int)pv_lds[v][0][threadIdx.x] > 0;        // (0 for every Gaussian of a rejected frame)
         GaussTerms t;
         if (__builtin_amdgcn_ballot_w64(live) != 0) {
             const ViewMat V = load_mat(vw.cam.view), PM = load_mat(vw.cam.proj);
@@ -1441,9 +1487,28 @@ __device__ __forceinline__ void slab_sum_rgb(bool live, uint32_t tiles_in, uint3
         const float t0 = wave_sum(p0), t1 = wave_sum(p1), t2 = wave_sum(p2);
         if (lane == src) { rgb[0] = t0; rgb[1] = t1; rgb[2] = t2; }
     }
-    if (tiles < SLAB_COOP) {
+#ifndef TGS_RGB_GROUP
+#define TGS_RGB_GROUP 4
+#endif
+    if (TGS_RGB_GROUP == 1 && tiles < SLAB_COOP) {
         const float4* row = b.slab + (size_t)off * SLAB_ROW;
         for (uint32_t k = 0; k < tiles; k++, row += SLAB_ROW) { const float4 r0 = row[0]; rgb[0] += r0.x; rgb[1] += r0.y; rgb[2] += r0.z; }
+    }
+    if (TGS_RGB_GROUP == 4 && tiles < SLAB_COOP) {
+        // Four rows per trip, their loads issued together: row after row a lane pays one memory latency per tile of its splat and the wave
+        // waits for its lane with the most (a 3 x 3 rectangle: nine in a row, per view).  The rows past the last are the last one again
+        // (an address that is valid, so that no load sits under a branch of its own) and are not added.  Same order of the additions.
+        const float4* row = b.slab + (size_t)off * SLAB_ROW;
+        for (uint32_t k = 0; k < tiles; k += 4) {
+            const uint32_t last = tiles - 1u;
+            const float4 q0 = row[(size_t)k * SLAB_ROW], q1 = row[(size_t)min(k + 1u, last) * SLAB_ROW], q2 = row[(size_t)min(k + 2u, last) * SLAB_ROW],
+                         q3 = row[(size_t)min(k + 3u, last) * SLAB_ROW];
+            asm volatile("" ::: "memory");                  // (the loads stay here: the compiler sinks each into the branch that uses it)
+            rgb[0] += q0.x; rgb[1] += q0.y; rgb[2] += q0.z;
+            if (k + 1u < tiles) { rgb[0] += q1.x; rgb[1] += q1.y; rgb[2] += q1.z; }
+            if (k + 2u < tiles) { rgb[0] += q2.x; rgb[1] += q2.y; rgb[2] += q2.z; }
+            if (k + 3u < tiles) { rgb[0] += q3.x; rgb[1] += q3.y; rgb[2] += q3.z; }
+        }
     }
 }
 
@@ -1466,27 +1531,64 @@ __global__ __launch_bounds__(PRE_BLOCK, TGS_SPLIT_WAVES) void k_preprocess_bwd_b
     const size_t gbase = ((size_t)in.block0 * 2 + blockIdx.x) * SPLIT_G;
     const int idx = (int)(gbase + gl);
     const bool in_range = idx < in.P;
-    {   // SH rows: 128 x 12 float4, 6 coalesced 16-B loads per thread
-        const float4* s4 = reinterpret_cast<const float4*>(in.shs);
+    // Prologue: EVERY load of it is issued before the first of them is waited for -- the six 16-B pieces of the SH rows (128 x 12 float4,
+    // coalesced), radii / tiles_touched / offsets and the rejected flag of half of the views (waves 0-1 take views [0, 4), waves 2-3 views
+    // [4, 8) of their Gaussian), the mean, and (geometry half) scale and rotation.  Indices are clamped instead of the loads predicated: a
+    // load under `if (i < n)` whose value goes to LDS is waited for inside its branch, one memory latency after the other.
+    constexpr int HV = BATCH_VIEWS / 2;
+    const int ic = in_range ? idx : 0;
+    tgs_v4f shr[6];                                        // (first-class vectors, not float4 structs: those went through scratch around the asm statement below)
+    {
+        const tgs_v4f* s4 = reinterpret_cast<const tgs_v4f*>(in.shs);
         const size_t base4 = gbase * 12, total4 = (size_t)in.P * 12;
 #pragma unroll
-        for (int q = 0; q < 6; q++) { const size_t i = base4 + q * PRE_BLOCK + threadIdx.x; if (i < total4) sh_lds[q * PRE_BLOCK + threadIdx.x] = s4[i]; }
+        for (int q = 0; q < 6; q++) { const size_t i = base4 + q * PRE_BLOCK + threadIdx.x; shr[q] = s4[i < total4 ? i : total4 - 1]; }
+    }
+    uint32_t pr[HV], pt[HV], po[HV], rej[HV];
+    const int vfirst = __builtin_amdgcn_readfirstlane(colour ? HV : 0);      // (wave-uniform: the views' pointers come by scalar loads)
+#pragma unroll
+    for (int j = 0; j < HV; j++) {
+        const int v = vfirst + j, vc = v < views.n ? v : 0;
+        pr[j] = (uint32_t)views.v[vc].radii[ic]; pt[j] = views.v[vc].g.tiles_touched[ic]; po[j] = views.v[vc].g.offsets[ic];
+        rej[j] = views.v[vc].meta->error & META_ERR_CAPACITY;            // a frame tgs_forward_async could not fit contributes nothing: its radii count as 0
+    }
+    const float mx = in.means3D[3 * (size_t)ic], my = in.means3D[3 * (size_t)ic + 1], mz = in.means3D[3 * (size_t)ic + 2];
+    float sc[3] = {0.f, 0.f, 0.f}, cpre[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    tgs_v4f rq = {0.f, 0.f, 0.f, 0.f};
+    if (HAS_SCALE_ROT) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) sc[k] = in.scales[3 * (size_t)ic + k];
+        rq = reinterpret_cast<const tgs_v4f*>(in.rotations)[ic];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 6; k++) cpre[k] = in.cov3D_precomp[6 * (size_t)ic + k];
+    }
+    asm volatile("" ::: "memory");                         // (every load above is issued before the first wait: the compiler sinks those the covariance block uses into it)
+#pragma unroll
+    for (int q = 0; q < 6; q++) sh_lds[q * PRE_BLOCK + threadIdx.x] = make_float4(shr[q].x, shr[q].y, shr[q].z, shr[q].w);
+#pragma unroll
+    for (int j = 0; j < HV; j++) {
+        const int v = vfirst + j;
+        const bool on = in_range && v < views.n && !rej[j];
+        pv_lds[v][0][gl] = on ? pr[j] : 0u; pv_lds[v][1][gl] = on ? pt[j] : 0u; pv_lds[v][2][gl] = on ? po[j] : 0u;
     }
     if (!colour) {
-        uint32_t pr[BATCH_VIEWS], pt[BATCH_VIEWS], po[BATCH_VIEWS];
+        // view-independent inputs of the geometry chain, once: the mean and the 3D covariance (compute_cov3d, as the forward evaluated it).
+        // Parked in LDS, each thread its own nine words: held in registers across the view loop they push the kernel over the 168 VGPRs of
+        // three waves per SIMD.
+        float cov3d[6];
+        if (HAS_SCALE_ROT) compute_cov3d(views.v[0].cam.scale_modifier, sc[0], sc[1], sc[2], make_float4(rq.x, rq.y, rq.z, rq.w), cov3d);
+        else {
 #pragma unroll
-        for (int v = 0; v < BATCH_VIEWS; v++) {
-            pr[v] = pt[v] = po[v] = 0u;
-            if (v < views.n && in_range) { pr[v] = (uint32_t)views.v[v].radii[idx]; pt[v] = views.v[v].g.tiles_touched[idx]; po[v] = views.v[v].g.offsets[idx]; }
+            for (int k = 0; k < 6; k++) cov3d[k] = cpre[k];
         }
+        gc_lds[0][gl] = mx; gc_lds[1][gl] = my; gc_lds[2][gl] = mz;
 #pragma unroll
-        for (int v = 0; v < BATCH_VIEWS; v++) { pv_lds[v][0][gl] = pr[v]; pv_lds[v][1][gl] = pt[v]; pv_lds[v][2][gl] = po[v]; }
+        for (int k = 0; k < 6; k++) gc_lds[3 + k][gl] = cov3d[k];
     }
     __syncthreads();
     if (colour) {
         const float* sh_row = reinterpret_cast<const float*>(&sh_lds[gl * 12]);
-        float mx = 0.f, my = 0.f, mz = 0.f;
-        if (in_range) { mx = in.means3D[3 * (size_t)idx]; my = in.means3D[3 * (size_t)idx + 1]; mz = in.means3D[3 * (size_t)idx + 2]; }
         float o48[48];
 #pragma unroll
         for (int i = 0; i < 48; i++) o48[i] = 0.f;
@@ -1494,8 +1596,7 @@ __global__ __launch_bounds__(PRE_BLOCK, TGS_SPLIT_WAVES) void k_preprocess_bwd_b
 #pragma unroll 1
         for (int v = 0; v < (TGS_EXP_SKIP_HALF == 1 ? 0 : views.n); v++) {
             const BatchView& vw = views.v[v];
-            const bool rejected = (vw.meta->error & META_ERR_CAPACITY) != 0u;
-            const bool live = in_range && !rejected && (int)pv_lds[v][0][gl] > 0;
+            const bool live = in_range && (int)pv_lds[v][0][gl] > 0;
             if (__builtin_amdgcn_ballot_w64(live) == 0) continue;
             float rgb[3];
             slab_sum_rgb(live, pv_lds[v][1][gl], pv_lds[v][2][gl], vw.b, rgb);
@@ -1517,22 +1618,10 @@ __global__ __launch_bounds__(PRE_BLOCK, TGS_SPLIT_WAVES) void k_preprocess_bwd_b
     } else {
         float dopacity = 0.f, dmean[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dscale[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
         double dcsum[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        // view-independent inputs of the chain, once: the mean and the 3D covariance (compute_cov3d, as the forward evaluated it).  Parked in
-        // LDS, each thread its own nine words (no barrier): held in registers across the view loop they push the kernel over the 168 VGPRs of
-        // three waves per SIMD.
-        if (in_range) {
-            float cov3d[6];
-            load_cov3d<HAS_SCALE_ROT>(in, views.v[0].cam.scale_modifier, idx, cov3d);
-#pragma unroll
-            for (int k = 0; k < 3; k++) gc_lds[k][gl] = in.means3D[3 * (size_t)idx + k];
-#pragma unroll
-            for (int k = 0; k < 6; k++) gc_lds[3 + k][gl] = cov3d[k];
-        }
 #pragma unroll 1
         for (int v = 0; v < (TGS_EXP_SKIP_HALF == 2 ? 0 : views.n); v++) {
             const BatchView& vw = views.v[v];
-            const bool rejected = (vw.meta->error & META_ERR_CAPACITY) != 0u;
-            const bool live = in_range && !rejected && (int)pv_lds[v][0][gl] > 0;
+            const bool live = in_range && (int)pv_lds[v][0][gl] > 0;
             GaussTerms t;
             if (__builtin_amdgcn_ballot_w64(live) != 0) {
                 const ViewMat V = load_mat(vw.cam.view), PM = load_mat(vw.cam.proj);
@@ -1575,12 +1664,20 @@ __global__ __launch_bounds__(PRE_BLOCK, TGS_SPLIT_WAVES) void k_preprocess_bwd_b
     {   // dL_dsh rows out: 6 coalesced 16-B stores per thread
         float4* d4 = reinterpret_cast<float4*>(in.dL_dsh);
         const size_t base4 = gbase * 12, total4 = (size_t)in.P * 12;
+        float4 prev[6];
+        if (in.accumulate) {                               // (uniform) the six reads in flight together
+#pragma unroll
+            for (int q = 0; q < 6; q++) { const size_t i = base4 + q * PRE_BLOCK + threadIdx.x; prev[q] = d4[i < total4 ? i : total4 - 1]; }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 6; q++) prev[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
         for (int q = 0; q < 6; q++) {
             const size_t i = base4 + q * PRE_BLOCK + threadIdx.x;
             if (i < total4) {
                 float4 o = sh_lds[q * PRE_BLOCK + threadIdx.x];
-                if (in.accumulate) { const float4 p = d4[i]; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+                if (in.accumulate) { o.x += prev[q].x; o.y += prev[q].y; o.z += prev[q].z; o.w += prev[q].w; }
                 d4[i] = o;
             }
         }
