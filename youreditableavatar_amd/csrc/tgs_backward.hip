@@ -629,7 +629,7 @@ __device__ __forceinline__ void slab_sum(bool live, uint32_t tiles_in, uint32_t 
         }
     }
     if (PAIRS && tiles < SLAB_COOP) {
-        // two rows per trip, their loads issued together (slab_sum_rgb); same order of the additions
+        // two rows per trip, their loads issued together (as in slab_sum_rgb_pre); same order of the additions
         const float4* row = b.slab + (size_t)off * SLAB_ROW;
         for (uint32_t k = 0; k < tiles; k += 2) {
             const float4* ra = row + (size_t)k * SLAB_ROW;
@@ -882,7 +882,7 @@ __device__ __forceinline__ void pergauss_terms(int idx, bool live, int D, const 
 #pragma unroll
     for (int k = 0; k < 16; k++) coef[k] = 0.f;
     if (!live) return;
-    const size_t i3 = 3 * (size_t)idx;
+    const size_t i3 = 3 * (size_t)idx; (void)i3;
 #if TGS_PERGAUSS_F64
     cov2d_chain_bwd_f64<true>(mx, my, mz, cov3d, cam, V, PM, cn, a[3], a[4], dmean, dcacc);
 #else
@@ -1471,8 +1471,12 @@ __global__ __launch_bounds__(PRE_BLOCK, 2) void k_preprocess_bwd_batch(const Bwd
 // on the GPU at the end of the step); split, the kernel needs 168 and three waves per SIMD are resident, each with half the work: 239 us
 // (forced into 128 VGPRs for four waves it spills 144 B and takes 307).  The halves meet once, at the end: the colour half's share of
 // dL_dmean3D goes through LDS to the geometry half, which stores the parameter gradients.
-// a[0..2] of slab_sum only: the colour sums of the Gaussian's slab rows (their first 16 bytes)
-__device__ __forceinline__ void slab_sum_rgb(bool live, uint32_t tiles_in, uint32_t off_in, const BinState& b, float (&rgb)[3])
+// The colour sums of the Gaussian's slab rows (a[0..2] of slab_sum: the rows' first 16 bytes), four rows per trip with their loads issued
+// together: row after row a lane pays one memory latency per tile of its splat and the wave waits for its lane with the most (a 3 x 3
+// rectangle: nine in a row, per view).  The rows past the last are the last one again (a valid address, so that no load sits under a branch
+// of its own: a load under `if` is waited for inside it) and are not added.  Same order of the additions as slab_sum.
+// The splat's first four rows come in registers (q0..q3: asked for one view ahead by the split pass).
+__device__ __forceinline__ void slab_sum_rgb_pre(bool live, uint32_t tiles_in, uint32_t off_in, const BinState& b, tgs_v4f q0, tgs_v4f q1, tgs_v4f q2, tgs_v4f q3, float (&rgb)[3])
 {
     const int lane = threadIdx.x & 63;
     const uint32_t tiles = live ? tiles_in : 0u, off = live ? off_in : 0u;
@@ -1487,27 +1491,21 @@ __device__ __forceinline__ void slab_sum_rgb(bool live, uint32_t tiles_in, uint3
         const float t0 = wave_sum(p0), t1 = wave_sum(p1), t2 = wave_sum(p2);
         if (lane == src) { rgb[0] = t0; rgb[1] = t1; rgb[2] = t2; }
     }
-#ifndef TGS_RGB_GROUP
-#define TGS_RGB_GROUP 4
-#endif
-    if (TGS_RGB_GROUP == 1 && tiles < SLAB_COOP) {
-        const float4* row = b.slab + (size_t)off * SLAB_ROW;
-        for (uint32_t k = 0; k < tiles; k++, row += SLAB_ROW) { const float4 r0 = row[0]; rgb[0] += r0.x; rgb[1] += r0.y; rgb[2] += r0.z; }
-    }
-    if (TGS_RGB_GROUP == 4 && tiles < SLAB_COOP) {
-        // Four rows per trip, their loads issued together: row after row a lane pays one memory latency per tile of its splat and the wave
-        // waits for its lane with the most (a 3 x 3 rectangle: nine in a row, per view).  The rows past the last are the last one again
-        // (an address that is valid, so that no load sits under a branch of its own) and are not added.  Same order of the additions.
-        const float4* row = b.slab + (size_t)off * SLAB_ROW;
-        for (uint32_t k = 0; k < tiles; k += 4) {
+    if (tiles > 0u && tiles < SLAB_COOP) {
+        rgb[0] += q0.x; rgb[1] += q0.y; rgb[2] += q0.z;
+        if (1u < tiles) { rgb[0] += q1.x; rgb[1] += q1.y; rgb[2] += q1.z; }
+        if (2u < tiles) { rgb[0] += q2.x; rgb[1] += q2.y; rgb[2] += q2.z; }
+        if (3u < tiles) { rgb[0] += q3.x; rgb[1] += q3.y; rgb[2] += q3.z; }
+        const tgs_v4f* row = reinterpret_cast<const tgs_v4f*>(b.slab) + (size_t)off * SLAB_ROW;
+        for (uint32_t k = 4; k < tiles; k += 4) {
             const uint32_t last = tiles - 1u;
-            const float4 q0 = row[(size_t)k * SLAB_ROW], q1 = row[(size_t)min(k + 1u, last) * SLAB_ROW], q2 = row[(size_t)min(k + 2u, last) * SLAB_ROW],
-                         q3 = row[(size_t)min(k + 3u, last) * SLAB_ROW];
-            asm volatile("" ::: "memory");                  // (the loads stay here: the compiler sinks each into the branch that uses it)
-            rgb[0] += q0.x; rgb[1] += q0.y; rgb[2] += q0.z;
-            if (k + 1u < tiles) { rgb[0] += q1.x; rgb[1] += q1.y; rgb[2] += q1.z; }
-            if (k + 2u < tiles) { rgb[0] += q2.x; rgb[1] += q2.y; rgb[2] += q2.z; }
-            if (k + 3u < tiles) { rgb[0] += q3.x; rgb[1] += q3.y; rgb[2] += q3.z; }
+            const tgs_v4f r0 = row[(size_t)k * SLAB_ROW], r1 = row[(size_t)min(k + 1u, last) * SLAB_ROW], r2 = row[(size_t)min(k + 2u, last) * SLAB_ROW],
+                          r3 = row[(size_t)min(k + 3u, last) * SLAB_ROW];
+            asm volatile("" ::: "memory");
+            rgb[0] += r0.x; rgb[1] += r0.y; rgb[2] += r0.z;
+            if (k + 1u < tiles) { rgb[0] += r1.x; rgb[1] += r1.y; rgb[2] += r1.z; }
+            if (k + 2u < tiles) { rgb[0] += r2.x; rgb[1] += r2.y; rgb[2] += r2.z; }
+            if (k + 3u < tiles) { rgb[0] += r3.x; rgb[1] += r3.y; rgb[2] += r3.z; }
         }
     }
 }
@@ -1526,7 +1524,8 @@ __global__ __launch_bounds__(PRE_BLOCK, TGS_SPLIT_WAVES) void k_preprocess_bwd_b
     __shared__ uint32_t pv_lds[BATCH_VIEWS][3][SPLIT_G];    // radii / tiles_touched / offsets of every Gaussian in every view (as in the one-thread kernel), shared by its two threads
     __shared__ float dm_lds[3][SPLIT_G];                    // the colour half's share of dL_dmean3D
     __shared__ float gc_lds[9][SPLIT_G];                    // geometry half: mean and 3D covariance of its Gaussian
-    const bool colour = threadIdx.x >= SPLIT_G;             // wave-uniform
+    const bool colour = threadIdx.x >= SPLIT_G;             // wave-uniform  (odd workgroups with the roles of their wave pairs swapped -- in case a
+                                                            // workgroup's wave i always lands on SIMD i -- measured no different: 0.1962 / 0.1965 ms)
     const int gl = threadIdx.x & (SPLIT_G - 1);             // Gaussian of the workgroup
     const size_t gbase = ((size_t)in.block0 * 2 + blockIdx.x) * SPLIT_G;
     const int idx = (int)(gbase + gl);
@@ -1593,19 +1592,42 @@ __global__ __launch_bounds__(PRE_BLOCK, TGS_SPLIT_WAVES) void k_preprocess_bwd_b
 #pragma unroll
         for (int i = 0; i < 48; i++) o48[i] = 0.f;
         float dmean[3] = {0.f, 0.f, 0.f};
+        // One view AHEAD: the first four slab rows of the Gaussian, its clamp bits and the camera position of view v + 1 are asked for before
+        // view v is evaluated -- a trip of this loop was [rows' memory round trip] + [~300 instructions], one after the other, at three waves
+        // per SIMD; now the round trip of the next view runs under the arithmetic of this one.
+        tgs_v4f nq0 = {0.f, 0.f, 0.f, 0.f}, nq1 = nq0, nq2 = nq0, nq3 = nq0;
+        uint32_t ncl = 0u;
+        float ncx = 0.f, ncy = 0.f, ncz = 0.f;
+        auto ask = [&](int v) {
+            const BatchView& w = views.v[v];
+            const uint32_t tl = pv_lds[v][1][gl], of = pv_lds[v][2][gl];
+            ncl = w.g.clamped[ic];
+            ncx = w.cam.campos[0]; ncy = w.cam.campos[1]; ncz = w.cam.campos[2];
+            if ((int)pv_lds[v][0][gl] > 0 && tl > 0u && tl < SLAB_COOP) {      // (0 radii outside the range and in rejected frames: no row is touched)
+                const tgs_v4f* row = reinterpret_cast<const tgs_v4f*>(w.b.slab) + (size_t)of * SLAB_ROW;
+                const uint32_t last = tl - 1u;
+                nq0 = row[0]; nq1 = row[(size_t)min(1u, last) * SLAB_ROW]; nq2 = row[(size_t)min(2u, last) * SLAB_ROW]; nq3 = row[(size_t)min(3u, last) * SLAB_ROW];
+            }
+        };
+        const int nv = TGS_EXP_SKIP_HALF == 1 ? 0 : views.n;
+        if (nv > 0) ask(0);
 #pragma unroll 1
-        for (int v = 0; v < (TGS_EXP_SKIP_HALF == 1 ? 0 : views.n); v++) {
+        for (int v = 0; v < nv; v++) {
             const BatchView& vw = views.v[v];
             const bool live = in_range && (int)pv_lds[v][0][gl] > 0;
+            const tgs_v4f q0 = nq0, q1 = nq1, q2 = nq2, q3 = nq3;
+            const uint32_t cl = ncl;
+            const float cpx = ncx, cpy = ncy, cpz = ncz;
+            if (v + 1 < nv) ask(v + 1);
+            asm volatile("" ::: "memory");                 // (the next view's loads stay here)
             if (__builtin_amdgcn_ballot_w64(live) == 0) continue;
             float rgb[3];
-            slab_sum_rgb(live, pv_lds[v][1][gl], pv_lds[v][2][gl], vw.b, rgb);
+            slab_sum_rgb_pre(live, pv_lds[v][1][gl], pv_lds[v][2][gl], vw.b, q0, q1, q2, q3, rgb);
             if (live) {
                 float coef[16], dRGB[3];
 #pragma unroll
                 for (int k = 0; k < 16; k++) coef[k] = 0.f;
-                sh_backward_terms(in.D, [&](int i) { return sh_row[i]; }, vw.g.clamped[idx], rgb[0], rgb[1], rgb[2], mx, my, mz, vw.cam.campos[0], vw.cam.campos[1],
-                                  vw.cam.campos[2], coef, dRGB, dmean);
+                sh_backward_terms(in.D, [&](int i) { return sh_row[i]; }, cl, rgb[0], rgb[1], rgb[2], mx, my, mz, cpx, cpy, cpz, coef, dRGB, dmean);
 #pragma unroll
                 for (int i = 0; i < 48; i++) o48[i] += coef[i / 3] * dRGB[i % 3];
             }

@@ -151,9 +151,28 @@ __device__ __forceinline__ void sh_to_color(int D, const float (&shv)[48], float
 // a view's colour of one Gaussian, evaluated before the per-view stage (sh_colors_half_staged); valid == false: evaluate in place
 struct PreColor { bool valid; float c0, c1, c2; uint32_t clampbits; };
 
+// The view-independent inputs of a Gaussian, asked for ONCE at the head of the kernel, all together and for every view the kernel walks: read
+// where they are used, the mean is one memory round trip (the frustum test waits for it), scale / rotation / opacity a second one behind
+// the test, per view.  (Index clamped, not predicated: the values of a thread past P are never used.)
+struct GaussIn { float mx, my, mz, s0, s1, s2, opac; tgs_v4f q; };
+template <bool HAS_SCALE_ROT>
+__device__ __forceinline__ GaussIn load_gauss_in(const FwdIn& in, int idx)
+{
+    const size_t ic = idx < in.P ? (size_t)idx : 0;
+    GaussIn gi;
+    gi.mx = in.means3D[3 * ic]; gi.my = in.means3D[3 * ic + 1]; gi.mz = in.means3D[3 * ic + 2];
+    gi.opac = in.opacities[ic];
+    gi.s0 = gi.s1 = gi.s2 = 0.f; gi.q = tgs_v4f{0.f, 0.f, 0.f, 0.f};
+    if (HAS_SCALE_ROT) {
+        gi.s0 = in.scales[3 * ic]; gi.s1 = in.scales[3 * ic + 1]; gi.s2 = in.scales[3 * ic + 2];
+        gi.q = reinterpret_cast<const tgs_v4f*>(in.rotations)[ic];
+    }
+    return gi;
+}
+
 template <bool HAS_SH, bool HAS_SCALE_ROT>
 __device__ __forceinline__ uint32_t preprocess_fwd_one(const FwdIn& in, int* __restrict__ radii, const CamParams& cam, const GeomState& g, const ImgState& s,
-                                                       const float4* sh_lds, bool sh_staged, int idx, const PreColor& pre, bool& prefilter_violation)
+                                                       const float4* sh_lds, bool sh_staged, int idx, const GaussIn& gi, const PreColor& pre, bool& prefilter_violation)
 {
 #pragma clang fp contract(off)      // projection, covariance, radius and colour un-fused: the oracle's (and the reference's source's) operation order
     uint32_t tiles = 0;
@@ -162,7 +181,7 @@ __device__ __forceinline__ uint32_t preprocess_fwd_one(const FwdIn& in, int* __r
     if (idx < in.P) {
         int my_radius_i = 0;
         uint32_t minx = 0, miny = 0, maxx = 0, maxy = 0;
-        const float mx = in.means3D[3 * (size_t)idx], my = in.means3D[3 * (size_t)idx + 1], mz = in.means3D[3 * (size_t)idx + 2];
+        const float mx = gi.mx, my = gi.my, mz = gi.mz;
         // in_frustum (auxiliary.h:139-164)
         const float* pm = PM.m;
         const float hx = pm[0] * mx + pm[4] * my + pm[8] * mz + pm[12];
@@ -177,8 +196,7 @@ __device__ __forceinline__ uint32_t preprocess_fwd_one(const FwdIn& in, int* __r
         if (ok) {
             float cov3d[6];
             if (HAS_SCALE_ROT) {
-                compute_cov3d(cam.scale_modifier, in.scales[3 * (size_t)idx], in.scales[3 * (size_t)idx + 1], in.scales[3 * (size_t)idx + 2],
-                              reinterpret_cast<const float4*>(in.rotations)[idx], cov3d);     // (not stored: the backward evaluates it again)
+                compute_cov3d(cam.scale_modifier, gi.s0, gi.s1, gi.s2, make_float4(gi.q.x, gi.q.y, gi.q.z, gi.q.w), cov3d);     // (not stored: the backward evaluates it again)
             } else {
 #pragma unroll
                 for (int i = 0; i < 6; i++) cov3d[i] = in.cov3D_precomp[6 * (size_t)idx + i];
@@ -231,7 +249,7 @@ __device__ __forceinline__ uint32_t preprocess_fwd_one(const FwdIn& in, int* __r
                     // (tile_reachable: the conservative test that masks the 4x4 blocks for the render kernels, applied to the whole
                     // tile, so nothing that could be blended is lost) gets no instance at all -- no count, no key, no sort, no record
                     // (about a fifth of them).  The live tiles of a rectangle of <= COOP_TILES tiles are a 64-bit mask, row-major.
-                    const float opac = in.opacities[idx];
+                    const float opac = gi.opac;
                     unsigned long long live_mask = 0ull;
                     if (tiles <= (uint32_t)RANK_TILES) {
                         uint32_t kx = 0, ky = 0;
@@ -290,8 +308,11 @@ __device__ __forceinline__ void stage_sh_rows(const FwdIn& in, float4* sh_lds)
 {
     const float4* s4 = reinterpret_cast<const float4*>(in.shs);
     const size_t base4 = (size_t)blockIdx.x * PRE_BLOCK * 12, total4 = (size_t)in.P * 12;
+    float4 r[12];                                           // registers first, the twelve loads in flight together: a load under `if` that feeds an LDS write is waited for inside its branch
 #pragma unroll
-    for (int q = 0; q < 12; q++) { const size_t i = base4 + q * PRE_BLOCK + threadIdx.x; if (i < total4) sh_lds[q * PRE_BLOCK + threadIdx.x] = nt_load4(&s4[i]); }
+    for (int q = 0; q < 12; q++) { const size_t i = base4 + q * PRE_BLOCK + threadIdx.x; r[q] = nt_load4(&s4[i < total4 ? i : total4 - 1]); }
+#pragma unroll
+    for (int q = 0; q < 12; q++) sh_lds[q * PRE_BLOCK + threadIdx.x] = r[q];
     __syncthreads();
 }
 
@@ -303,20 +324,20 @@ __device__ __forceinline__ void stage_sh_rows(const FwdIn& in, float4* sh_lds)
 // view gets no colour (it is never read).
 constexpr int SH_HALF = PRE_BLOCK / 2;
 template <int NV>
-__device__ __forceinline__ void sh_colors_half_staged(const FwdIn& in, const FwdView* __restrict__ views, int idx, float4* sh_lds, PreColor (&pre)[NV])
+__device__ __forceinline__ void sh_colors_half_staged(const FwdIn& in, const FwdView* __restrict__ views, int idx, const GaussIn& gi, float4* sh_lds, PreColor (&pre)[NV])
 {
     const float4* s4 = reinterpret_cast<const float4*>(in.shs);
     const size_t base4 = (size_t)blockIdx.x * PRE_BLOCK * 12, total4 = (size_t)in.P * 12;
     constexpr int PER = SH_HALF * 12 / PRE_BLOCK;            // float4 per thread and half (6)
     float4 r0[PER], r1[PER];
+    // (both halves' loads are issued before the first half goes to LDS, indices clamped: the second half's were behind the wait for the first)
 #pragma unroll
-    for (int q = 0; q < PER; q++) { const size_t i = base4 + q * PRE_BLOCK + threadIdx.x; r0[q] = i < total4 ? nt_load4(&s4[i]) : make_float4(0.f, 0.f, 0.f, 0.f); }
+    for (int q = 0; q < PER; q++) { const size_t i = base4 + q * PRE_BLOCK + threadIdx.x; r0[q] = nt_load4(&s4[i < total4 ? i : total4 - 1]); }
+#pragma unroll
+    for (int q = 0; q < PER; q++) { const size_t i = base4 + SH_HALF * 12 + q * PRE_BLOCK + threadIdx.x; r1[q] = nt_load4(&s4[i < total4 ? i : total4 - 1]); }
 #pragma unroll
     for (int q = 0; q < PER; q++) sh_lds[q * PRE_BLOCK + threadIdx.x] = r0[q];
-#pragma unroll
-    for (int q = 0; q < PER; q++) { const size_t i = base4 + SH_HALF * 12 + q * PRE_BLOCK + threadIdx.x; r1[q] = i < total4 ? nt_load4(&s4[i]) : make_float4(0.f, 0.f, 0.f, 0.f); }
-    float mx = 0.f, my = 0.f, mz = 0.f;
-    if (idx < in.P) { mx = in.means3D[3 * (size_t)idx]; my = in.means3D[3 * (size_t)idx + 1]; mz = in.means3D[3 * (size_t)idx + 2]; }
+    const float mx = gi.mx, my = gi.my, mz = gi.mz;
     auto eval = [&]() {
         float shv[48];
         const int ncoef = (in.D + 1) * (in.D + 1);
@@ -351,9 +372,10 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd(const FwdIn in, co
     __shared__ float4 sh_lds[HAS_SH ? SH_HALF * 12 : 1];
     PreColor pre[1];
     pre[0].valid = false;
-    if (HAS_SH && in.M == 16) sh_colors_half_staged<1>(in, &vw, idx, sh_lds, pre);
+    const GaussIn gi = load_gauss_in<HAS_SCALE_ROT>(in, idx);
+    if (HAS_SH && in.M == 16) sh_colors_half_staged<1>(in, &vw, idx, gi, sh_lds, pre);
     bool bad = false;
-    const uint32_t tiles = preprocess_fwd_one<HAS_SH, HAS_SCALE_ROT>(in, vw.radii, vw.cam, vw.g, vw.s, sh_lds, false, idx, pre[0], bad);
+    const uint32_t tiles = preprocess_fwd_one<HAS_SH, HAS_SCALE_ROT>(in, vw.radii, vw.cam, vw.g, vw.s, sh_lds, false, idx, gi, pre[0], bad);
     block_sum_tiles(tiles, bad, vw.g, vw.s);
 }
 
@@ -368,7 +390,8 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_sh_colors_deferred(const FwdIn in
     const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
     __shared__ float4 sh_lds[SH_HALF * 12];
     PreColor pre[1];
-    sh_colors_half_staged<1>(in, &vw, idx, sh_lds, pre);   // (a Gaussian behind the near plane keeps colour 0: its pack line is never read)
+    const GaussIn gi = load_gauss_in<false>(in, idx);
+    sh_colors_half_staged<1>(in, &vw, idx, gi, sh_lds, pre);   // (a Gaussian behind the near plane keeps colour 0: its pack line is never read)
     if (idx < in.P) {
         float* pk = reinterpret_cast<float*>(vw.g.pack + 4 * (size_t)idx);
         *reinterpret_cast<float2*>(pk + 6) = make_float2(pre[0].c0, pre[0].c1);     // pack[4 idx + 1].zw
@@ -387,12 +410,13 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd_pair(const FwdIn i
     const FwdView vws[2] = {v0, v1};
     PreColor pre[2];
     pre[0].valid = pre[1].valid = false;
-    if (HAS_SH && in.M == 16) sh_colors_half_staged<2>(in, vws, idx, sh_lds, pre);
+    const GaussIn gi = load_gauss_in<HAS_SCALE_ROT>(in, idx);
+    if (HAS_SH && in.M == 16) sh_colors_half_staged<2>(in, vws, idx, gi, sh_lds, pre);
 #pragma unroll
     for (int v = 0; v < 2; v++) {
         const FwdView& vw = v == 0 ? v0 : v1;
         bool bad = false;
-        const uint32_t tiles = preprocess_fwd_one<HAS_SH, HAS_SCALE_ROT>(in, vw.radii, vw.cam, vw.g, vw.s, sh_lds, false, idx, pre[v], bad);
+        const uint32_t tiles = preprocess_fwd_one<HAS_SH, HAS_SCALE_ROT>(in, vw.radii, vw.cam, vw.g, vw.s, sh_lds, false, idx, gi, pre[v], bad);
         block_sum_tiles(tiles, bad, vw.g, vw.s);
         __syncthreads();                                   // wsum is reused by the next view
     }
@@ -406,6 +430,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd_batch(const FwdIn 
     const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
     __shared__ float4 sh_lds[HAS_SH ? PRE_BLOCK * 12 : 1];
     const bool sh_staged = HAS_SH && in.M == 16;
+    const GaussIn gi = load_gauss_in<HAS_SCALE_ROT>(in, idx);
     if (sh_staged) stage_sh_rows(in, sh_lds);
     PreColor pre;
     pre.valid = false;
@@ -413,7 +438,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd_batch(const FwdIn 
     for (int v = 0; v < views.n; v++) {
         const FwdView& vw = views.v[v];
         bool bad = false;
-        const uint32_t tiles = preprocess_fwd_one<HAS_SH, HAS_SCALE_ROT>(in, vw.radii, vw.cam, vw.g, vw.s, sh_lds, sh_staged, idx, pre, bad);
+        const uint32_t tiles = preprocess_fwd_one<HAS_SH, HAS_SCALE_ROT>(in, vw.radii, vw.cam, vw.g, vw.s, sh_lds, sh_staged, idx, gi, pre, bad);
         block_sum_tiles(tiles, bad, vw.g, vw.s);
         __syncthreads();                                   // wsum is reused by the next view
     }
@@ -511,7 +536,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const 
                     const uint32_t t = sc + i0 + k;
                     s.ranges[t] = make_uint2((uint32_t)ex, (uint32_t)(ex + v[k]));
                     if (v[k] > sort_cap) s.ovf_tiles[atomicAdd(&ovf_n, 1u)] = t;
-                    atomicAdd(&hist[v[k] ? 32 - __builtin_clz(v[k]) : 0], 1u);
+                    atomicAdd(&hist[v[k] ? 32 - __builtin_clz(v[k]) : 0], 1u);     // (one LDS atomic per lane: aggregated per wave and bucket by ballots the pass took 27 us instead of 18)
                 }
                 ex += v[k];
             }
@@ -723,7 +748,15 @@ __global__ __launch_bounds__(BIN_THREADS) void k_scatter(int P, uint32_t chunk, 
     const uint32_t* row = s.bin_table + (size_t)w * T;
     for (uint32_t band0 = 0; band0 < T; band0 += band) {
         const uint32_t nb = min(band, T - band0);
-        for (uint32_t i = threadIdx.x; i < nb; i += BIN_THREADS) bin_lds[i] = s.ranges[band0 + i].x + row[band0 + i];
+        // cursors of the band: eight tiles per thread and trip with their sixteen loads in flight together (one tile per trip is one memory
+        // round trip per trip: eight in a row at 1080p, a third of this kernel's time alone on the GPU)
+        for (uint32_t i0 = threadIdx.x; i0 < nb; i0 += 8 * BIN_THREADS) {
+            uint32_t st[8], cu[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const uint32_t ic = min(i0 + u * BIN_THREADS, nb - 1u); st[u] = s.ranges[band0 + ic].x; cu[u] = row[band0 + ic]; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const uint32_t i = i0 + u * BIN_THREADS; if (i < nb) bin_lds[i] = st[u] + cu[u]; }
+        }
         __syncthreads();
         int par = 0;
         uint32_t n_tiles = 0, n_depth = 0, n_bsum = 0; ushort4 n_r = make_ushort4(0, 0, 0, 0); uint2 n_live = make_uint2(0u, 0u);
@@ -1043,9 +1076,9 @@ __global__ __launch_bounds__(256) void k_finalize(const GeomState g, const ImgSt
     uint32_t id[FIN_E], tile[FIN_E];
 #pragma unroll
     for (int e = 0; e < FIN_E; e++) {
-        const uint32_t p = p0 + e * 256;
-        id[e] = p < R ? (uint32_t)b.keys[p] : 0u;
-        tile[e] = p < R ? b.tile_of[p] : 0u;
+        const uint32_t pc = min(p0 + e * 256, R - 1u);        // clamped, not predicated: a load under its own branch is waited for inside it, and the
+        id[e] = (uint32_t)b.keys[pc];                           // FIN_E key loads (then the pack lines) are meant to be in flight together
+        tile[e] = b.tile_of[pc];
     }
     float4 q0[FIN_E], q1[FIN_E], q2[FIN_E], q3[FIN_E];
 #pragma unroll
