@@ -1099,17 +1099,34 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
     __shared__ float4 sh_lds[HAS_SH ? PRE_BLOCK * 12 : 1];
     const bool sh_staged = HAS_SH && in.M == 16;
     const size_t base4 = (size_t)blockIdx.x * PRE_BLOCK * 12, total4 = (size_t)in.P * 12;
+    const bool in_range = idx < in.P;
+    const size_t ic = in_range ? (size_t)idx : 0, i3 = 3 * ic;
+    // Every load that depends on nothing but the index is issued here, together, before the first wait: radius / tiles_touched / offset of the
+    // view, the mean, scale and rotation (or the caller's covariance) and the twelve pieces of the SH rows.  Read where they are used they
+    // were six memory round trips one after the other: rows, radius, tiles and offset, [slab rows], mean / scale / rotation, scale / rotation again.
+    const int rad = in.radii[ic];
+    const uint32_t tl = g.tiles_touched[ic], of = g.offsets[ic];
+    const float mx = in.means3D[i3], my = in.means3D[i3 + 1], mz = in.means3D[i3 + 2];
+    float scv[3] = {0.f, 0.f, 0.f}, cpre[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    tgs_v4f rq = {0.f, 0.f, 0.f, 0.f};
+    if (HAS_SCALE_ROT) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) scv[k] = in.scales[i3 + k];
+        rq = reinterpret_cast<const tgs_v4f*>(in.rotations)[ic];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 6; k++) cpre[k] = in.cov3D_precomp[6 * ic + k];
+    }
     if (sh_staged) {
-        const float4* s4 = reinterpret_cast<const float4*>(in.shs);
-        float4 r[12];                                           // registers first: the twelve loads in flight together (load_sh_rows_staged)
+        const tgs_v4f* s4 = reinterpret_cast<const tgs_v4f*>(in.shs);
+        tgs_v4f r[12];
 #pragma unroll
         for (int q = 0; q < 12; q++) { const size_t i = base4 + q * PRE_BLOCK + threadIdx.x; r[q] = s4[i < total4 ? i : total4 - 1]; }
+        asm volatile("" ::: "memory");                      // (all of the above is asked for before the first wait)
 #pragma unroll
-        for (int q = 0; q < 12; q++) sh_lds[q * PRE_BLOCK + threadIdx.x] = r[q];
+        for (int q = 0; q < 12; q++) sh_lds[q * PRE_BLOCK + threadIdx.x] = make_float4(r[q].x, r[q].y, r[q].z, r[q].w);
         __syncthreads();
     }
-    const bool in_range = idx < in.P;
-    const size_t i3 = 3 * (size_t)(in_range ? idx : 0);
     float a[NACC];
 #pragma unroll
     for (int k = 0; k < NACC; k++) a[k] = 0.f;
@@ -1117,23 +1134,25 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
     float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float dscale[3] = {0.f, 0.f, 0.f};
     float drot[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool live = in_range && in.radii[idx] > 0;        // backward.cu:156,367
-    float mx = 0.f, my = 0.f, mz = 0.f;
+    const bool live = in_range && rad > 0;                  // backward.cu:156,367
     float dRGB[3] = {0.f, 0.f, 0.f};
     double cn[3];
-    slab_sum<true>(live, live ? g.tiles_touched[idx] : 0u, live ? g.offsets[idx] : 0u, b, a, cn);   // sum of this Gaussian's tile partials (wave-cooperative for big splats)
+    slab_sum<true>(live, live ? tl : 0u, live ? of : 0u, b, a, cn);   // sum of this Gaussian's tile partials (wave-cooperative for big splats)
     if (live) {
-        mx = in.means3D[i3]; my = in.means3D[i3 + 1]; mz = in.means3D[i3 + 2];
-
 #if TGS_PERGAUSS_F64
         {
             float cov3d[6];
-            load_cov3d<HAS_SCALE_ROT>(in, cam.scale_modifier, idx, cov3d);
+            const float rqv[4] = {rq.x, rq.y, rq.z, rq.w};
+            if (HAS_SCALE_ROT) compute_cov3d(cam.scale_modifier, scv[0], scv[1], scv[2], make_float4(rq.x, rq.y, rq.z, rq.w), cov3d);
+            else {
+#pragma unroll
+                for (int k = 0; k < 6; k++) cov3d[k] = cpre[k];
+            }
             double dc64[6];
             cov2d_chain_bwd_f64<false>(mx, my, mz, cov3d, cam, V, PM, cn, a[3], a[4], dmean, dc64);
 #pragma unroll
             for (int k = 0; k < 6; k++) dcov[k] = (float)dc64[k];
-            if (HAS_SCALE_ROT) cov3d_bwd_f64(dc64, cam.scale_modifier, in.scales + i3, in.rotations + 4 * (size_t)idx, dscale, drot);
+            if (HAS_SCALE_ROT) cov3d_bwd_f64(dc64, cam.scale_modifier, scv, rqv, dscale, drot);
         }
 #else
         // ---- computeCov2DCUDA (backward.cu:144-274) ----

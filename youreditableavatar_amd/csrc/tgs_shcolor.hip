@@ -85,8 +85,11 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_sh_rgb(const ShArgs a)
     if (a.camera) { camx = a.camera[0]; camy = a.camera[1]; camz = a.camera[2]; }
     if (staged) {
         const float4* s4 = reinterpret_cast<const float4*>(a.sh);
+        float4 t[12];                                       // registers first: the twelve loads in flight together (see k_sh_rgb_dcrest)
 #pragma unroll
-        for (int q = 0; q < 12; q++) { const size_t i = base4 + q * PRE_BLOCK + threadIdx.x; if (i < total4) sh_lds[q * PRE_BLOCK + threadIdx.x] = s4[i]; }
+        for (int q = 0; q < 12; q++) { const size_t i = base4 + q * PRE_BLOCK + threadIdx.x; t[q] = s4[i < total4 ? i : total4 - 1]; }
+#pragma unroll
+        for (int q = 0; q < 12; q++) sh_lds[q * PRE_BLOCK + threadIdx.x] = t[q];
         __syncthreads();
     }
     float shv[48];
@@ -205,7 +208,15 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_sh_rgb_dcrest(const ShDcRestArgs 
     const bool do_stage = staged && tail_ok;
     if (do_stage) {
         const float4* s4 = reinterpret_cast<const float4*>(a.rest);
-        for (size_t q = threadIdx.x; q < blk_f4; q += PRE_BLOCK) if (base4 + q < total4) rest_lds[q] = nt_load4(s4 + base4 + q);
+        // six pieces per thread and trip with their loads in flight together (clamped indices; a load under `if` that feeds an LDS write is
+        // waited for inside its branch: the block's 45 KB came in as a dozen memory round trips in a row)
+        for (size_t q0 = threadIdx.x; q0 < blk_f4; q0 += 6 * PRE_BLOCK) {
+            float4 t[6];
+#pragma unroll
+            for (int u = 0; u < 6; u++) { const size_t q = q0 + (size_t)u * PRE_BLOCK, qq = base4 + (q < blk_f4 ? q : q0); t[u] = nt_load4(s4 + (qq < total4 ? qq : total4 - 1)); }
+#pragma unroll
+            for (int u = 0; u < 6; u++) { const size_t q = q0 + (size_t)u * PRE_BLOCK; if (q < blk_f4 && base4 + q < total4) rest_lds[q] = t[u]; }
+        }
         __syncthreads();
     }
     float shv[48];
