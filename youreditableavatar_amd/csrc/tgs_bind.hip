@@ -29,25 +29,36 @@ struct BindArgs {
     float* d_points;                                                                        // [P,3] (grouped backward with plain edit positions)
 };
 
+// (All three kernels: every load first, then the arithmetic, then every store.  Written group by group -- load, compute, store, next group --
+// each load is waited for before the store in front of the next one is issued (the pointers may alias as far as the compiler knows): ten
+// memory round trips in a row per thread for 88 bytes.)
 __global__ __launch_bounds__(256) void k_bind_fwd(const BindArgs a)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= a.P) return;
-    if (a.raw_density) a.opacity[i] = 1.0f / (1.0f + expf(-a.raw_density[i]));
+    const size_t i3 = 3 * (size_t)i;
+    float dn = 0.f, sc[3] = {0.f, 0.f, 0.f}, op[3] = {0.f, 0.f, 0.f}, nr[3] = {0.f, 0.f, 0.f}, d = 0.f;
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.raw_density) dn = a.raw_density[i];
     if (a.raw_scales) {
 #pragma unroll
-        for (int c = 0; c < 3; c++) a.scales[3 * (size_t)i + c] = expf(a.raw_scales[3 * (size_t)i + c]);
+        for (int c = 0; c < 3; c++) sc[c] = a.raw_scales[i3 + c];
     }
-    if (a.raw_quats) {
-        const float4 q = reinterpret_cast<const float4*>(a.raw_quats)[i];
-        const float inv = 1.0f / fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
-        reinterpret_cast<float4*>(a.quats)[i] = make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
-    }
+    if (a.raw_quats) q = reinterpret_cast<const float4*>(a.raw_quats)[i];
     if (a.ori_points) {
-        const float d = a.deltas[i];
+        d = a.deltas[i];
 #pragma unroll
-        for (int c = 0; c < 3; c++) a.points[3 * (size_t)i + c] = a.ori_points[3 * (size_t)i + c] + a.normals[3 * (size_t)i + c] * d;
+        for (int c = 0; c < 3; c++) { op[c] = a.ori_points[i3 + c]; nr[c] = a.normals[i3 + c]; }
     }
+    const float o = 1.0f / (1.0f + expf(-dn));
+    const float e0 = expf(sc[0]), e1 = expf(sc[1]), e2 = expf(sc[2]);
+    const float inv = 1.0f / fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+    const float p0 = op[0] + nr[0] * d, p1 = op[1] + nr[1] * d, p2 = op[2] + nr[2] * d;
+    asm volatile("" :: "v"(o), "v"(e0), "v"(e1), "v"(e2), "v"(inv), "v"(p0), "v"(p1), "v"(p2), "v"(q.x), "v"(q.y), "v"(q.z), "v"(q.w));      // (evaluated HERE: sunk into the branches below, each waits for the store in front of it)
+    if (a.raw_density) a.opacity[i] = o;
+    if (a.raw_scales) { a.scales[i3] = e0; a.scales[i3 + 1] = e1; a.scales[i3 + 2] = e2; }
+    if (a.raw_quats) reinterpret_cast<float4*>(a.quats)[i] = make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
+    if (a.ori_points) { a.points[i3] = p0; a.points[i3 + 1] = p1; a.points[i3 + 2] = p2; }
 }
 
 // Two groups into one set of outputs: rows [0, Pk) from the keep group, rows [Pk, Pk + Pe) from the edit group.  Positions: the keep
@@ -65,30 +76,40 @@ __global__ __launch_bounds__(256) void k_bind_groups_fwd(const BindGroupArgs a)
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= a.Pk + a.Pe) return;
     const bool ed = i >= a.Pk;
-    const size_t j = ed ? (size_t)(i - a.Pk) : (size_t)i;                                   // row inside the group
+    const size_t j = ed ? (size_t)(i - a.Pk) : (size_t)i, j3 = 3 * j, i3 = 3 * (size_t)i;          // row inside the group
     const float* dn = ed ? a.edit_density : a.keep_density;
     const float* sc = ed ? a.edit_scales : a.keep_scales;
     const float* qu = ed ? a.edit_quats : a.keep_quats;
-    if (a.opacity) a.opacity[i] = 1.0f / (1.0f + expf(-dn[j]));
+    const bool plain = !ed || a.edit_points;                                                      // positions copied / ori + normal * offset
+    float dv = 0.f, sv[3] = {0.f, 0.f, 0.f}, pv[3] = {0.f, 0.f, 0.f}, nv[3] = {0.f, 0.f, 0.f}, off = 0.f;
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.opacity) dv = dn[j];
     if (a.scales) {
 #pragma unroll
-        for (int c = 0; c < 3; c++) a.scales[3 * (size_t)i + c] = expf(sc[3 * j + c]);
+        for (int c = 0; c < 3; c++) sv[c] = sc[j3 + c];
     }
-    if (a.quats) {
-        const float4 q = reinterpret_cast<const float4*>(qu)[j];
-        const float inv = 1.0f / fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
-        reinterpret_cast<float4*>(a.quats)[i] = make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
-    }
+    if (a.quats) q = reinterpret_cast<const float4*>(qu)[j];
     if (a.points) {
-        if (!ed || a.edit_points) {
+        if (plain) {
             const float* src = ed ? a.edit_points : a.keep_points;
 #pragma unroll
-            for (int c = 0; c < 3; c++) a.points[3 * (size_t)i + c] = src[3 * j + c];
+            for (int c = 0; c < 3; c++) pv[c] = src[j3 + c];
         } else {
-            const float d = a.edit_offsets[j];
+            off = a.edit_offsets[j];
 #pragma unroll
-            for (int c = 0; c < 3; c++) a.points[3 * (size_t)i + c] = a.ori_edit_points[3 * j + c] + a.edit_normals[3 * j + c] * d;
+            for (int c = 0; c < 3; c++) { pv[c] = a.ori_edit_points[j3 + c]; nv[c] = a.edit_normals[j3 + c]; }
         }
+    }
+    const float o = 1.0f / (1.0f + expf(-dv));
+    const float e0 = expf(sv[0]), e1 = expf(sv[1]), e2 = expf(sv[2]);
+    const float inv = 1.0f / fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+    asm volatile("" :: "v"(o), "v"(e0), "v"(e1), "v"(e2), "v"(inv), "v"(pv[0]), "v"(pv[1]), "v"(pv[2]), "v"(nv[0]), "v"(nv[1]), "v"(nv[2]), "v"(off));
+    if (a.opacity) a.opacity[i] = o;
+    if (a.scales) { a.scales[i3] = e0; a.scales[i3 + 1] = e1; a.scales[i3 + 2] = e2; }
+    if (a.quats) reinterpret_cast<float4*>(a.quats)[i] = make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
+    if (a.points) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) a.points[i3 + c] = plain ? pv[c] : pv[c] + nv[c] * off;
     }
 }
 
@@ -96,28 +117,38 @@ __global__ __launch_bounds__(256) void k_bind_bwd(const BindArgs a)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= a.P) return;
-    if (a.d_points) {                                                                       // plain positions of a group: the gradient's rows
+    const size_t i3 = 3 * (size_t)i;
+    const bool need_gp = a.d_points || a.d_deltas;
+    float gp[3] = {0.f, 0.f, 0.f}, nr[3] = {0.f, 0.f, 0.f}, gs[3] = {0.f, 0.f, 0.f}, sv[3] = {0.f, 0.f, 0.f}, o = 0.f, go = 0.f;
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f), g = q;
+    if (need_gp) {
 #pragma unroll
-        for (int c = 0; c < 3; c++) a.d_points[3 * (size_t)i + c] = a.g_points[3 * (size_t)i + c];
-    }
-    if (a.d_density) { const float o = a.opacity[i]; a.d_density[i] = a.g_opacity[i] * o * (1.0f - o); }            // sigmoid' from its output
-    if (a.d_scales) {
-#pragma unroll
-        for (int c = 0; c < 3; c++) a.d_scales[3 * (size_t)i + c] = a.g_scales[3 * (size_t)i + c] * a.scales[3 * (size_t)i + c];   // exp' = its output
-    }
-    if (a.d_quats) {    // d(x / |x|) = (g - n (n . g)) / |x|   (the max(., 1e-12) branch has zero measure)
-        const float4 q = reinterpret_cast<const float4*>(a.raw_quats)[i], g = reinterpret_cast<const float4*>(a.g_quats)[i];
-        const float inv = 1.0f / fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
-        const float nx = q.x * inv, ny = q.y * inv, nz = q.z * inv, nw = q.w * inv;
-        const float dot = nx * g.x + ny * g.y + nz * g.z + nw * g.w;
-        reinterpret_cast<float4*>(a.d_quats)[i] = make_float4((g.x - nx * dot) * inv, (g.y - ny * dot) * inv, (g.z - nz * dot) * inv, (g.w - nw * dot) * inv);
+        for (int c = 0; c < 3; c++) gp[c] = a.g_points[i3 + c];
     }
     if (a.d_deltas) {
-        float s = 0.f;
 #pragma unroll
-        for (int c = 0; c < 3; c++) s += a.g_points[3 * (size_t)i + c] * a.normals[3 * (size_t)i + c];
-        a.d_deltas[i] = s;
+        for (int c = 0; c < 3; c++) nr[c] = a.normals[i3 + c];
     }
+    if (a.d_density) { o = a.opacity[i]; go = a.g_opacity[i]; }
+    if (a.d_scales) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) { gs[c] = a.g_scales[i3 + c]; sv[c] = a.scales[i3 + c]; }
+    }
+    if (a.d_quats) { q = reinterpret_cast<const float4*>(a.raw_quats)[i]; g = reinterpret_cast<const float4*>(a.g_quats)[i]; }
+    const float dd = go * o * (1.0f - o);                                                   // sigmoid' from its output
+    const float ds0 = gs[0] * sv[0], ds1 = gs[1] * sv[1], ds2 = gs[2] * sv[2];             // exp' = its output
+    // d(x / |x|) = (g - n (n . g)) / |x|   (the max(., 1e-12) branch has zero measure)
+    const float inv = 1.0f / fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+    const float nx = q.x * inv, ny = q.y * inv, nz = q.z * inv, nw = q.w * inv;
+    const float dot = nx * g.x + ny * g.y + nz * g.z + nw * g.w;
+    const float dq0 = (g.x - nx * dot) * inv, dq1 = (g.y - ny * dot) * inv, dq2 = (g.z - nz * dot) * inv, dq3 = (g.w - nw * dot) * inv;
+    const float dl = gp[0] * nr[0] + gp[1] * nr[1] + gp[2] * nr[2];
+    asm volatile("" :: "v"(dd), "v"(ds0), "v"(ds1), "v"(ds2), "v"(dq0), "v"(dq1), "v"(dq2), "v"(dq3), "v"(dl), "v"(gp[0]), "v"(gp[1]), "v"(gp[2]));   // (evaluated here, not in the branches below)
+    if (a.d_points) { a.d_points[i3] = gp[0]; a.d_points[i3 + 1] = gp[1]; a.d_points[i3 + 2] = gp[2]; }      // plain positions of a group: the gradient's rows
+    if (a.d_density) a.d_density[i] = dd;
+    if (a.d_scales) { a.d_scales[i3] = ds0; a.d_scales[i3 + 1] = ds1; a.d_scales[i3 + 2] = ds2; }
+    if (a.d_quats) reinterpret_cast<float4*>(a.d_quats)[i] = make_float4(dq0, dq1, dq2, dq3);
+    if (a.d_deltas) a.d_deltas[i] = dl;
 }
 
 }  // namespace tgs

@@ -83,6 +83,11 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_sh_rgb(const ShArgs a)
     const size_t base4 = (size_t)blockIdx.x * PRE_BLOCK * 12, total4 = (size_t)a.P * 12;
     float camx = 0.f, camy = 0.f, camz = 0.f;
     if (a.camera) { camx = a.camera[0]; camy = a.camera[1]; camz = a.camera[2]; }
+    const size_t i3 = 3 * (size_t)(in_range ? idx : 0);     // the Gaussian's position / direction: asked for with the rows, not behind the barrier
+    const float* pd = a.positions ? a.positions : a.directions;
+    const float pd0 = pd[i3], pd1 = pd[i3 + 1], pd2 = pd[i3 + 2];
+    float up0 = 0.f, up1 = 0.f, up2 = 0.f;
+    if (BWD) { up0 = a.dL_dcolors[i3]; up1 = a.dL_dcolors[i3 + 1]; up2 = a.dL_dcolors[i3 + 2]; }
     if (staged) {
         const float4* s4 = reinterpret_cast<const float4*>(a.sh);
         float4 t[12];                                       // registers first: the twelve loads in flight together (see k_sh_rgb_dcrest)
@@ -108,11 +113,11 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_sh_rgb(const ShArgs a)
             for (int q = 0; q < 48; q++) if (q < ncoef * 3) shv[q] = sh[q];
         }
         if (a.positions) {      // torch.nn.functional.normalize: v / max(|v|, 1e-12)
-            vx = a.positions[3 * (size_t)idx] - camx; vy = a.positions[3 * (size_t)idx + 1] - camy; vz = a.positions[3 * (size_t)idx + 2] - camz;
+            vx = pd0 - camx; vy = pd1 - camy; vz = pd2 - camz;
             inv_len = 1.0f / fmaxf(sqrtf(vx * vx + vy * vy + vz * vz), 1e-12f);
             x = vx * inv_len; y = vy * inv_len; z = vz * inv_len;
         } else {
-            x = a.directions[3 * (size_t)idx]; y = a.directions[3 * (size_t)idx + 1]; z = a.directions[3 * (size_t)idx + 2];
+            x = pd0; y = pd1; z = pd2;
         }
     }
     float bs[16];
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_sh_rgb(const ShArgs a)
     float dRGB[3] = {0.f, 0.f, 0.f};
     if (in_range) {
 #pragma unroll
-        for (int c = 0; c < 3; c++) dRGB[c] = (res[c] + 0.5f >= 0.f) ? a.dL_dcolors[3 * (size_t)idx + c] : 0.f;   // clamp_min passes the gradient where x >= min
+        for (int c = 0; c < 3; c++) dRGB[c] = (res[c] + 0.5f >= 0.f) ? (c == 0 ? up0 : c == 1 ? up1 : up2) : 0.f;   // clamp_min passes the gradient where x >= min
     }
     if (in_range && (a.dL_dpositions || a.dL_ddirections)) {
         // d colour / d direction (cuda_rasterizer/backward.cu:60-123 polynomials), then through the normalisation
@@ -206,6 +211,14 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_sh_rgb_dcrest(const ShDcRestArgs 
     // shapes / views take the direct path
     const bool tail_ok = ((size_t)a.P * a.Mr * 3) % 4 == 0 && ((reinterpret_cast<uintptr_t>(a.rest) | reinterpret_cast<uintptr_t>(a.dL_drest)) & 15) == 0;
     const bool do_stage = staged && tail_ok;
+    // the Gaussian's own 12-B inputs are asked for before the rows are staged (index clamped), not behind the barrier one after the other
+    const size_t i3 = 3 * (size_t)(in_range ? idx : 0);
+    const float dc0 = a.dc[i3], dc1 = a.dc[i3 + 1], dc2 = a.dc[i3 + 2];
+    const float* pd = a.positions ? a.positions : a.directions;
+    const float pd0 = pd[i3], pd1 = pd[i3 + 1], pd2 = pd[i3 + 2];
+    float up0 = 0.f, up1 = 0.f, up2 = 0.f;
+    if (BWD) { up0 = a.dL_dcolors[i3]; up1 = a.dL_dcolors[i3 + 1]; up2 = a.dL_dcolors[i3 + 2]; }
+    asm volatile("" ::: "memory");
     if (do_stage) {
         const float4* s4 = reinterpret_cast<const float4*>(a.rest);
         // six pieces per thread and trip with their loads in flight together (clamped indices; a load under `if` that feeds an LDS write is
@@ -224,18 +237,18 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_sh_rgb_dcrest(const ShDcRestArgs 
     for (int q = 0; q < 48; q++) shv[q] = 0.f;
     float x = 0.f, y = 0.f, z = 1.f, vx = 0.f, vy = 0.f, vz = 0.f, inv_len = 0.f;
     if (in_range) {
-        shv[0] = a.dc[3 * (size_t)idx]; shv[1] = a.dc[3 * (size_t)idx + 1]; shv[2] = a.dc[3 * (size_t)idx + 2];
+        shv[0] = dc0; shv[1] = dc1; shv[2] = dc2;
         if (use_rest) {
             const float* r = do_stage ? reinterpret_cast<const float*>(rest_lds) + (size_t)threadIdx.x * a.Mr * 3 : a.rest + (size_t)idx * a.Mr * 3;
 #pragma unroll
             for (int q = 0; q < 45; q++) if (q < nrest * 3) shv[3 + q] = r[q];
         }
         if (a.positions) {      // torch.nn.functional.normalize: v / max(|v|, 1e-12)
-            vx = a.positions[3 * (size_t)idx] - camx; vy = a.positions[3 * (size_t)idx + 1] - camy; vz = a.positions[3 * (size_t)idx + 2] - camz;
+            vx = pd0 - camx; vy = pd1 - camy; vz = pd2 - camz;
             inv_len = 1.0f / fmaxf(sqrtf(vx * vx + vy * vy + vz * vz), 1e-12f);
             x = vx * inv_len; y = vy * inv_len; z = vz * inv_len;
         } else {
-            x = a.directions[3 * (size_t)idx]; y = a.directions[3 * (size_t)idx + 1]; z = a.directions[3 * (size_t)idx + 2];
+            x = pd0; y = pd1; z = pd2;
         }
     }
     float bs[16];
@@ -255,7 +268,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_sh_rgb_dcrest(const ShDcRestArgs 
     float dRGB[3] = {0.f, 0.f, 0.f};
     if (in_range) {
 #pragma unroll
-        for (int c = 0; c < 3; c++) dRGB[c] = (res[c] + 0.5f >= 0.f) ? a.dL_dcolors[3 * (size_t)idx + c] : 0.f;
+        for (int c = 0; c < 3; c++) dRGB[c] = (res[c] + 0.5f >= 0.f) ? (c == 0 ? up0 : c == 1 ? up1 : up2) : 0.f;
         a.dL_ddc[3 * (size_t)idx] = SH_C0 * dRGB[0]; a.dL_ddc[3 * (size_t)idx + 1] = SH_C0 * dRGB[1]; a.dL_ddc[3 * (size_t)idx + 2] = SH_C0 * dRGB[2];
     }
     if (in_range && (a.dL_dpositions || a.dL_ddirections)) {
