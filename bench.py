@@ -67,8 +67,8 @@ def parse():
     ap.add_argument("--cpu-splat-only", action="store_true", help="internal: run only the PyTorch point-splat CPU baseline of BASELINE config 1 and print its JSON "
                     "(cpu_baseline starts this as a child process with a time limit)")
     ap.add_argument("--grad-chunks", type=int, default=2, help="N > 1: the step's per-Gaussian pass runs in this many Gaussian ranges and each range's all-reduce "
-                    "starts behind its launch (1 = one blocking all-reduce behind the whole pass).  Default 2 since round 4: cutting the pass costs 1 % "
-                    "with two ranges and 4.6 % with four, a collective 13-42 us at world size 1 (secondary.rccl_world1), and the all-reduce is longer "
+                    "starts behind its launch (1 = one blocking all-reduce behind the whole pass).  Default 2 since round 4: cutting the pass costs 1 %% "
+                    "with two ranges and 4.6 %% with four, a collective 13-42 us at world size 1 (secondary.rccl_world1), and the all-reduce is longer "
                     "than the whole pass -- two ranges expose the least (DESIGN.md section 7)")
     return ap.parse_args()
 
