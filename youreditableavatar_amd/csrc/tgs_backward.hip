@@ -714,11 +714,8 @@ __device__ __forceinline__ void sh_backward_terms(int D, const ShRow& sh, uint32
 // this chain further from exact arithmetic than the reference's on 3 of 896 fuzz scenes (one needle-shaped splat each, e.g. dL_dcov3D
 // 2.3e-4 against the reference's 2.8e-5).  gfx950 issues f64 FMA at half the f32 rate and the kernels around this are HBM-bound: ~400
 // double operations per Gaussian and view are invisible in time (measured: DESIGN.md section 3), and the result is the reference's
-// FUNCTION evaluated on the fp32 inputs to < 1e-12, rounded once.  TGS_PERGAUSS_F64=0 restores the fp32 restatement for A/B.
+// FUNCTION evaluated on the fp32 inputs to < 1e-12, rounded once.
 // ---------------------------------------------------------------------------------------------
-#ifndef TGS_PERGAUSS_F64
-#define TGS_PERGAUSS_F64 1
-#endif
 
 // (1) computeCov2DCUDA + the projection part: per view.  dc: dL_dcov3D of this view in double (reference layout: off-diagonals doubled).
 // ACCUMULATE: dc += this view's share (the batch kernels' running sum over the views) instead of dc = it.
@@ -860,13 +857,12 @@ struct GaussTerms {
     float coef[16], dRGB[3];       // dL_dsh[k][c] = coef[k] * dRGB[c]
 };
 
-// TGS_PERGAUSS_F64: dL_dcov3D of the view is ADDED to dcacc (double; the caller's running sum over the views) and the scale / rotation
-// gradients are left to the caller (finish_cov3d, once behind the view loop); t.dcov / t.dscale / t.drot stay zero
-template <bool HAS_SH, bool HAS_SCALE_ROT, typename ShRow>
-__device__ __forceinline__ void pergauss_terms(int idx, bool live, int D, const ShRow& sh, const BwdIn& in, const float* __restrict__ cov3D_precomp,
-                                               const CamParams& cam, const ViewMat& V, const ViewMat& PM, float camx, float camy, float camz,
-                                               const GeomState& g, const BinState& b, uint32_t tiles_in, uint32_t off_in, float mx, float my, float mz,
-                                               const float (&cov3d)[6], GaussTerms& t, double (&dcacc)[6])
+// One view's terms of a Gaussian in the batch kernels.  dL_dcov3D of the view is ADDED to dcacc (double; the caller's running sum over the
+// views) and the scale / rotation gradients are left to the caller (finish_cov3d, once behind the view loop): t.dcov / t.dscale / t.drot stay zero
+template <bool HAS_SH, typename ShRow>
+__device__ __forceinline__ void pergauss_terms(int idx, bool live, int D, const ShRow& sh, const CamParams& cam, const ViewMat& V, const ViewMat& PM,
+                                               float camx, float camy, float camz, const GeomState& g, const BinState& b, uint32_t tiles_in, uint32_t off_in,
+                                               float mx, float my, float mz, const float (&cov3d)[6], GaussTerms& t, double (&dcacc)[6])
 {
     float (&a)[NACC] = t.a;
     float (&dmean)[3] = t.dmean; float (&dcov)[6] = t.dcov; float (&dscale)[3] = t.dscale; float (&drot)[4] = t.drot;
@@ -882,101 +878,7 @@ __device__ __forceinline__ void pergauss_terms(int idx, bool live, int D, const 
 #pragma unroll
     for (int k = 0; k < 16; k++) coef[k] = 0.f;
     if (!live) return;
-    const size_t i3 = 3 * (size_t)idx; (void)i3;
-#if TGS_PERGAUSS_F64
     cov2d_chain_bwd_f64<true>(mx, my, mz, cov3d, cam, V, PM, cn, a[3], a[4], dmean, dcacc);
-#else
-    {
-        // ---- computeCov2DCUDA (backward.cu:144-274) ----
-        const Cov2D c2 = compute_cov2d(mx, my, mz, cov3d, cam, V);
-        const float limx = 1.3f * cam.tan_fovx, limy = 1.3f * cam.tan_fovy;
-        const float x_grad_mul = (c2.txtz < -limx || c2.txtz > limx) ? 0.f : 1.f;
-        const float y_grad_mul = (c2.tytz < -limy || c2.tytz > limy) ? 0.f : 1.f;
-        const float ca = c2.cov.m[0][0] + 0.3f, cb = c2.cov.m[0][1], cc = c2.cov.m[1][1] + 0.3f;
-        const float dLc0 = a[5], dLc1 = a[6], dLc2 = a[7];    // dL_dconic .x .y .w
-        const float denom = ca * cc - cb * cb;
-        float dL_da = 0, dL_db = 0, dL_dc = 0;
-        const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
-#define Tm(c_, r_) c2.T.m[c_][r_]
-        if (denom2inv != 0) {
-            dL_da = denom2inv * (-cc * cc * dLc0 + 2 * cb * cc * dLc1 + (denom - ca * cc) * dLc2);
-            dL_dc = denom2inv * (-ca * ca * dLc2 + 2 * ca * cb * dLc1 + (denom - ca * cc) * dLc0);
-            dL_db = denom2inv * 2 * (cb * cc * dLc0 - (denom + 2 * cb * cb) * dLc1 + ca * cb * dLc2);
-            dcov[0] = (Tm(0, 0) * Tm(0, 0) * dL_da + Tm(0, 0) * Tm(1, 0) * dL_db + Tm(1, 0) * Tm(1, 0) * dL_dc);
-            dcov[3] = (Tm(0, 1) * Tm(0, 1) * dL_da + Tm(0, 1) * Tm(1, 1) * dL_db + Tm(1, 1) * Tm(1, 1) * dL_dc);
-            dcov[5] = (Tm(0, 2) * Tm(0, 2) * dL_da + Tm(0, 2) * Tm(1, 2) * dL_db + Tm(1, 2) * Tm(1, 2) * dL_dc);
-            dcov[1] = 2 * Tm(0, 0) * Tm(0, 1) * dL_da + (Tm(0, 0) * Tm(1, 1) + Tm(0, 1) * Tm(1, 0)) * dL_db + 2 * Tm(1, 0) * Tm(1, 1) * dL_dc;
-            dcov[2] = 2 * Tm(0, 0) * Tm(0, 2) * dL_da + (Tm(0, 0) * Tm(1, 2) + Tm(0, 2) * Tm(1, 0)) * dL_db + 2 * Tm(1, 0) * Tm(1, 2) * dL_dc;
-            dcov[4] = 2 * Tm(0, 2) * Tm(0, 1) * dL_da + (Tm(0, 1) * Tm(1, 2) + Tm(0, 2) * Tm(1, 1)) * dL_db + 2 * Tm(1, 1) * Tm(1, 2) * dL_dc;
-        }
-#define Vk(c_, r_) c2.Vrk.m[c_][r_]
-        const float dL_dT00 = 2 * (Tm(0, 0) * Vk(0, 0) + Tm(0, 1) * Vk(0, 1) + Tm(0, 2) * Vk(0, 2)) * dL_da + (Tm(1, 0) * Vk(0, 0) + Tm(1, 1) * Vk(0, 1) + Tm(1, 2) * Vk(0, 2)) * dL_db;
-        const float dL_dT01 = 2 * (Tm(0, 0) * Vk(1, 0) + Tm(0, 1) * Vk(1, 1) + Tm(0, 2) * Vk(1, 2)) * dL_da + (Tm(1, 0) * Vk(1, 0) + Tm(1, 1) * Vk(1, 1) + Tm(1, 2) * Vk(1, 2)) * dL_db;
-        const float dL_dT02 = 2 * (Tm(0, 0) * Vk(2, 0) + Tm(0, 1) * Vk(2, 1) + Tm(0, 2) * Vk(2, 2)) * dL_da + (Tm(1, 0) * Vk(2, 0) + Tm(1, 1) * Vk(2, 1) + Tm(1, 2) * Vk(2, 2)) * dL_db;
-        const float dL_dT10 = 2 * (Tm(1, 0) * Vk(0, 0) + Tm(1, 1) * Vk(0, 1) + Tm(1, 2) * Vk(0, 2)) * dL_dc + (Tm(0, 0) * Vk(0, 0) + Tm(0, 1) * Vk(0, 1) + Tm(0, 2) * Vk(0, 2)) * dL_db;
-        const float dL_dT11 = 2 * (Tm(1, 0) * Vk(1, 0) + Tm(1, 1) * Vk(1, 1) + Tm(1, 2) * Vk(1, 2)) * dL_dc + (Tm(0, 0) * Vk(1, 0) + Tm(0, 1) * Vk(1, 1) + Tm(0, 2) * Vk(1, 2)) * dL_db;
-        const float dL_dT12 = 2 * (Tm(1, 0) * Vk(2, 0) + Tm(1, 1) * Vk(2, 1) + Tm(1, 2) * Vk(2, 2)) * dL_dc + (Tm(0, 0) * Vk(2, 0) + Tm(0, 1) * Vk(2, 1) + Tm(0, 2) * Vk(2, 2)) * dL_db;
-#undef Vk
-#undef Tm
-#define Wg(c_, r_) c2.W.m[c_][r_]
-        const float dL_dJ00 = Wg(0, 0) * dL_dT00 + Wg(0, 1) * dL_dT01 + Wg(0, 2) * dL_dT02;
-        const float dL_dJ02 = Wg(2, 0) * dL_dT00 + Wg(2, 1) * dL_dT01 + Wg(2, 2) * dL_dT02;
-        const float dL_dJ11 = Wg(1, 0) * dL_dT10 + Wg(1, 1) * dL_dT11 + Wg(1, 2) * dL_dT12;
-        const float dL_dJ12 = Wg(2, 0) * dL_dT10 + Wg(2, 1) * dL_dT11 + Wg(2, 2) * dL_dT12;
-#undef Wg
-        const float tz = 1.f / c2.tz, tz2 = tz * tz, tz3 = tz2 * tz;
-        const float h_x = cam.focal_x, h_y = cam.focal_y;
-        const float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
-        const float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
-        const float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * c2.tx) * tz3 * dL_dJ02 + (2 * h_y * c2.ty) * tz3 * dL_dJ12;
-        const float* vm = V.m;                                  // transformVec4x3Transpose (auxiliary.h:89-97)
-        dmean[0] = vm[0] * dL_dtx + vm[1] * dL_dty + vm[2] * dL_dtz;
-        dmean[1] = vm[4] * dL_dtx + vm[5] * dL_dty + vm[6] * dL_dtz;
-        dmean[2] = vm[8] * dL_dtx + vm[9] * dL_dty + vm[10] * dL_dtz;
-
-        // ---- preprocessCUDA backward (backward.cu:346-396) ----
-        const float* proj = PM.m;
-        const float m_hom_w = proj[3] * mx + proj[7] * my + proj[11] * mz + proj[15];
-        const float m_w = 1.0f / (m_hom_w + 0.0000001f);
-        const float mul1 = (proj[0] * mx + proj[4] * my + proj[8] * mz + proj[12]) * m_w * m_w;
-        const float mul2 = (proj[1] * mx + proj[5] * my + proj[9] * mz + proj[13]) * m_w * m_w;
-        const float g2x = a[3], g2y = a[4];
-        dmean[0] += (proj[0] * m_w - proj[3] * mul1) * g2x + (proj[1] * m_w - proj[3] * mul2) * g2y;
-        dmean[1] += (proj[4] * m_w - proj[7] * mul1) * g2x + (proj[5] * m_w - proj[7] * mul2) * g2y;
-        dmean[2] += (proj[8] * m_w - proj[11] * mul1) * g2x + (proj[9] * m_w - proj[11] * mul2) * g2y;
-
-        if (HAS_SCALE_ROT) {
-            // computeCov3D backward (backward.cu:278-341)
-            const float s0 = in.scales[i3], s1 = in.scales[i3 + 1], s2 = in.scales[i3 + 2];
-            const float4 q = reinterpret_cast<const float4*>(in.rotations)[idx];
-            const float r = q.x, x = q.y, y = q.z, z = q.w;
-            const mat3 R = quat_to_R(r, x, y, z);
-            const float sx = cam.scale_modifier * s0, sy = cam.scale_modifier * s1, sz = cam.scale_modifier * s2;
-            const mat3 S = m3make(sx, 0.f, 0.f, 0.f, sy, 0.f, 0.f, 0.f, sz);
-            const mat3 Mx = m3mul(S, R);
-            const mat3 dSig = m3make(dcov[0], 0.5f * dcov[1], 0.5f * dcov[2], 0.5f * dcov[1], dcov[3], 0.5f * dcov[4], 0.5f * dcov[2], 0.5f * dcov[4], dcov[5]);
-            mat3 M2;
-#pragma unroll
-            for (int c = 0; c < 3; c++)
-#pragma unroll
-                for (int w = 0; w < 3; w++) M2.m[c][w] = 2.0f * Mx.m[c][w];
-            const mat3 dM = m3mul(M2, dSig);
-            const mat3 Rt = m3t(R);
-            mat3 dMt = m3t(dM);
-            dscale[0] = Rt.m[0][0] * dMt.m[0][0] + Rt.m[0][1] * dMt.m[0][1] + Rt.m[0][2] * dMt.m[0][2];
-            dscale[1] = Rt.m[1][0] * dMt.m[1][0] + Rt.m[1][1] * dMt.m[1][1] + Rt.m[1][2] * dMt.m[1][2];
-            dscale[2] = Rt.m[2][0] * dMt.m[2][0] + Rt.m[2][1] * dMt.m[2][1] + Rt.m[2][2] * dMt.m[2][2];
-#pragma unroll
-            for (int w = 0; w < 3; w++) { dMt.m[0][w] *= sx; dMt.m[1][w] *= sy; dMt.m[2][w] *= sz; }
-#define A(c_, w_) dMt.m[c_][w_]
-            drot[0] = 2 * z * (A(0, 1) - A(1, 0)) + 2 * y * (A(2, 0) - A(0, 2)) + 2 * x * (A(1, 2) - A(2, 1));
-            drot[1] = 2 * y * (A(1, 0) + A(0, 1)) + 2 * z * (A(2, 0) + A(0, 2)) + 2 * r * (A(1, 2) - A(2, 1)) - 4 * x * (A(2, 2) + A(1, 1));
-            drot[2] = 2 * x * (A(1, 0) + A(0, 1)) + 2 * r * (A(2, 0) - A(0, 2)) + 2 * z * (A(1, 2) + A(2, 1)) - 4 * y * (A(2, 2) + A(0, 0));
-            drot[3] = 2 * r * (A(0, 1) - A(1, 0)) + 2 * x * (A(2, 0) + A(0, 2)) + 2 * y * (A(1, 2) + A(2, 1)) - 4 * z * (A(1, 1) + A(0, 0));
-#undef A
-        }
-    }
-#endif
     if (HAS_SH) {
             asm volatile("" ::: "memory");            // keep the 48 SH reads below from being hoisted over the covariance math (VGPR pressure)
             sh_backward_terms(D, sh, g.clamped[idx], a[0], a[1], a[2], mx, my, mz, camx, camy, camz, coef, dRGB, dmean);
@@ -988,11 +890,9 @@ template <bool HAS_SCALE_ROT>
 __device__ __forceinline__ void finish_cov3d(const BwdIn& in, float scale_modifier, int idx, bool in_range, const double (&dcsum)[6], float (&dcov)[6], float (&dscale)[3],
                                              float (&drot)[4])
 {
-#if TGS_PERGAUSS_F64
 #pragma unroll
     for (int k = 0; k < 6; k++) dcov[k] = (float)dcsum[k];
     if (HAS_SCALE_ROT && in_range) cov3d_bwd_f64(dcsum, scale_modifier, in.scales + 3 * (size_t)idx, in.rotations + 4 * (size_t)idx, dscale, drot);
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1139,7 +1039,6 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
     double cn[3];
     slab_sum<true>(live, live ? tl : 0u, live ? of : 0u, b, a, cn);   // sum of this Gaussian's tile partials (wave-cooperative for big splats)
     if (live) {
-#if TGS_PERGAUSS_F64
         {
             float cov3d[6];
             const float rqv[4] = {rq.x, rq.y, rq.z, rq.w};
@@ -1154,98 +1053,6 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
             for (int k = 0; k < 6; k++) dcov[k] = (float)dc64[k];
             if (HAS_SCALE_ROT) cov3d_bwd_f64(dc64, cam.scale_modifier, scv, rqv, dscale, drot);
         }
-#else
-        // ---- computeCov2DCUDA (backward.cu:144-274) ----
-        float cov3d[6];
-        load_cov3d<HAS_SCALE_ROT>(in, cam.scale_modifier, idx, cov3d);
-        const Cov2D c2 = compute_cov2d(mx, my, mz, cov3d, cam, V);
-        const float limx = 1.3f * cam.tan_fovx, limy = 1.3f * cam.tan_fovy;
-        const float x_grad_mul = (c2.txtz < -limx || c2.txtz > limx) ? 0.f : 1.f;
-        const float y_grad_mul = (c2.tytz < -limy || c2.tytz > limy) ? 0.f : 1.f;
-        const float ca = c2.cov.m[0][0] + 0.3f, cb = c2.cov.m[0][1], cc = c2.cov.m[1][1] + 0.3f;
-        const float dLc0 = a[5], dLc1 = a[6], dLc2 = a[7];    // dL_dconic .x .y .w
-        const float denom = ca * cc - cb * cb;
-        float dL_da = 0, dL_db = 0, dL_dc = 0;
-        const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
-#define Tm(c_, r_) c2.T.m[c_][r_]
-        if (denom2inv != 0) {
-            dL_da = denom2inv * (-cc * cc * dLc0 + 2 * cb * cc * dLc1 + (denom - ca * cc) * dLc2);
-            dL_dc = denom2inv * (-ca * ca * dLc2 + 2 * ca * cb * dLc1 + (denom - ca * cc) * dLc0);
-            dL_db = denom2inv * 2 * (cb * cc * dLc0 - (denom + 2 * cb * cb) * dLc1 + ca * cb * dLc2);
-            dcov[0] = (Tm(0, 0) * Tm(0, 0) * dL_da + Tm(0, 0) * Tm(1, 0) * dL_db + Tm(1, 0) * Tm(1, 0) * dL_dc);
-            dcov[3] = (Tm(0, 1) * Tm(0, 1) * dL_da + Tm(0, 1) * Tm(1, 1) * dL_db + Tm(1, 1) * Tm(1, 1) * dL_dc);
-            dcov[5] = (Tm(0, 2) * Tm(0, 2) * dL_da + Tm(0, 2) * Tm(1, 2) * dL_db + Tm(1, 2) * Tm(1, 2) * dL_dc);
-            dcov[1] = 2 * Tm(0, 0) * Tm(0, 1) * dL_da + (Tm(0, 0) * Tm(1, 1) + Tm(0, 1) * Tm(1, 0)) * dL_db + 2 * Tm(1, 0) * Tm(1, 1) * dL_dc;
-            dcov[2] = 2 * Tm(0, 0) * Tm(0, 2) * dL_da + (Tm(0, 0) * Tm(1, 2) + Tm(0, 2) * Tm(1, 0)) * dL_db + 2 * Tm(1, 0) * Tm(1, 2) * dL_dc;
-            dcov[4] = 2 * Tm(0, 2) * Tm(0, 1) * dL_da + (Tm(0, 1) * Tm(1, 2) + Tm(0, 2) * Tm(1, 1)) * dL_db + 2 * Tm(1, 1) * Tm(1, 2) * dL_dc;
-        }
-#define Vk(c_, r_) c2.Vrk.m[c_][r_]
-        const float dL_dT00 = 2 * (Tm(0, 0) * Vk(0, 0) + Tm(0, 1) * Vk(0, 1) + Tm(0, 2) * Vk(0, 2)) * dL_da + (Tm(1, 0) * Vk(0, 0) + Tm(1, 1) * Vk(0, 1) + Tm(1, 2) * Vk(0, 2)) * dL_db;
-        const float dL_dT01 = 2 * (Tm(0, 0) * Vk(1, 0) + Tm(0, 1) * Vk(1, 1) + Tm(0, 2) * Vk(1, 2)) * dL_da + (Tm(1, 0) * Vk(1, 0) + Tm(1, 1) * Vk(1, 1) + Tm(1, 2) * Vk(1, 2)) * dL_db;
-        const float dL_dT02 = 2 * (Tm(0, 0) * Vk(2, 0) + Tm(0, 1) * Vk(2, 1) + Tm(0, 2) * Vk(2, 2)) * dL_da + (Tm(1, 0) * Vk(2, 0) + Tm(1, 1) * Vk(2, 1) + Tm(1, 2) * Vk(2, 2)) * dL_db;
-        const float dL_dT10 = 2 * (Tm(1, 0) * Vk(0, 0) + Tm(1, 1) * Vk(0, 1) + Tm(1, 2) * Vk(0, 2)) * dL_dc + (Tm(0, 0) * Vk(0, 0) + Tm(0, 1) * Vk(0, 1) + Tm(0, 2) * Vk(0, 2)) * dL_db;
-        const float dL_dT11 = 2 * (Tm(1, 0) * Vk(1, 0) + Tm(1, 1) * Vk(1, 1) + Tm(1, 2) * Vk(1, 2)) * dL_dc + (Tm(0, 0) * Vk(1, 0) + Tm(0, 1) * Vk(1, 1) + Tm(0, 2) * Vk(1, 2)) * dL_db;
-        const float dL_dT12 = 2 * (Tm(1, 0) * Vk(2, 0) + Tm(1, 1) * Vk(2, 1) + Tm(1, 2) * Vk(2, 2)) * dL_dc + (Tm(0, 0) * Vk(2, 0) + Tm(0, 1) * Vk(2, 1) + Tm(0, 2) * Vk(2, 2)) * dL_db;
-#undef Vk
-#undef Tm
-#define Wg(c_, r_) c2.W.m[c_][r_]
-        const float dL_dJ00 = Wg(0, 0) * dL_dT00 + Wg(0, 1) * dL_dT01 + Wg(0, 2) * dL_dT02;
-        const float dL_dJ02 = Wg(2, 0) * dL_dT00 + Wg(2, 1) * dL_dT01 + Wg(2, 2) * dL_dT02;
-        const float dL_dJ11 = Wg(1, 0) * dL_dT10 + Wg(1, 1) * dL_dT11 + Wg(1, 2) * dL_dT12;
-        const float dL_dJ12 = Wg(2, 0) * dL_dT10 + Wg(2, 1) * dL_dT11 + Wg(2, 2) * dL_dT12;
-#undef Wg
-        const float tz = 1.f / c2.tz, tz2 = tz * tz, tz3 = tz2 * tz;
-        const float h_x = cam.focal_x, h_y = cam.focal_y;
-        const float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
-        const float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
-        const float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * c2.tx) * tz3 * dL_dJ02 + (2 * h_y * c2.ty) * tz3 * dL_dJ12;
-        const float* vm = V.m;                                  // transformVec4x3Transpose (auxiliary.h:89-97)
-        dmean[0] = vm[0] * dL_dtx + vm[1] * dL_dty + vm[2] * dL_dtz;
-        dmean[1] = vm[4] * dL_dtx + vm[5] * dL_dty + vm[6] * dL_dtz;
-        dmean[2] = vm[8] * dL_dtx + vm[9] * dL_dty + vm[10] * dL_dtz;
-
-        // ---- preprocessCUDA backward (backward.cu:346-396) ----
-        const float* proj = PM.m;
-        const float m_hom_w = proj[3] * mx + proj[7] * my + proj[11] * mz + proj[15];
-        const float m_w = 1.0f / (m_hom_w + 0.0000001f);
-        const float mul1 = (proj[0] * mx + proj[4] * my + proj[8] * mz + proj[12]) * m_w * m_w;
-        const float mul2 = (proj[1] * mx + proj[5] * my + proj[9] * mz + proj[13]) * m_w * m_w;
-        const float g2x = a[3], g2y = a[4];
-        dmean[0] += (proj[0] * m_w - proj[3] * mul1) * g2x + (proj[1] * m_w - proj[3] * mul2) * g2y;
-        dmean[1] += (proj[4] * m_w - proj[7] * mul1) * g2x + (proj[5] * m_w - proj[7] * mul2) * g2y;
-        dmean[2] += (proj[8] * m_w - proj[11] * mul1) * g2x + (proj[9] * m_w - proj[11] * mul2) * g2y;
-
-        if (HAS_SCALE_ROT) {
-            // computeCov3D backward (backward.cu:278-341)
-            const float s0 = in.scales[i3], s1 = in.scales[i3 + 1], s2 = in.scales[i3 + 2];
-            const float4 q = reinterpret_cast<const float4*>(in.rotations)[idx];
-            const float r = q.x, x = q.y, y = q.z, z = q.w;
-            const mat3 R = quat_to_R(r, x, y, z);
-            const float sx = cam.scale_modifier * s0, sy = cam.scale_modifier * s1, sz = cam.scale_modifier * s2;
-            const mat3 S = m3make(sx, 0.f, 0.f, 0.f, sy, 0.f, 0.f, 0.f, sz);
-            const mat3 Mx = m3mul(S, R);
-            const mat3 dSig = m3make(dcov[0], 0.5f * dcov[1], 0.5f * dcov[2], 0.5f * dcov[1], dcov[3], 0.5f * dcov[4], 0.5f * dcov[2], 0.5f * dcov[4], dcov[5]);
-            mat3 M2;
-#pragma unroll
-            for (int c = 0; c < 3; c++)
-#pragma unroll
-                for (int w = 0; w < 3; w++) M2.m[c][w] = 2.0f * Mx.m[c][w];
-            const mat3 dM = m3mul(M2, dSig);
-            const mat3 Rt = m3t(R);
-            mat3 dMt = m3t(dM);
-            dscale[0] = Rt.m[0][0] * dMt.m[0][0] + Rt.m[0][1] * dMt.m[0][1] + Rt.m[0][2] * dMt.m[0][2];
-            dscale[1] = Rt.m[1][0] * dMt.m[1][0] + Rt.m[1][1] * dMt.m[1][1] + Rt.m[1][2] * dMt.m[1][2];
-            dscale[2] = Rt.m[2][0] * dMt.m[2][0] + Rt.m[2][1] * dMt.m[2][1] + Rt.m[2][2] * dMt.m[2][2];
-#pragma unroll
-            for (int w = 0; w < 3; w++) { dMt.m[0][w] *= sx; dMt.m[1][w] *= sy; dMt.m[2][w] *= sz; }
-#define A(c_, w_) dMt.m[c_][w_]
-            drot[0] = 2 * z * (A(0, 1) - A(1, 0)) + 2 * y * (A(2, 0) - A(0, 2)) + 2 * x * (A(1, 2) - A(2, 1));
-            drot[1] = 2 * y * (A(1, 0) + A(0, 1)) + 2 * z * (A(2, 0) + A(0, 2)) + 2 * r * (A(1, 2) - A(2, 1)) - 4 * x * (A(2, 2) + A(1, 1));
-            drot[2] = 2 * x * (A(1, 0) + A(0, 1)) + 2 * r * (A(2, 0) - A(0, 2)) + 2 * z * (A(1, 2) + A(2, 1)) - 4 * y * (A(2, 2) + A(0, 0));
-            drot[3] = 2 * r * (A(0, 1) - A(1, 0)) + 2 * x * (A(2, 0) + A(0, 2)) + 2 * y * (A(1, 2) + A(2, 1)) - 4 * z * (A(1, 1) + A(0, 0));
-#undef A
-        }
-    #endif
 }
 
     if (HAS_SH) {
@@ -1423,7 +1230,7 @@ __global__ __launch_bounds__(PRE_BLOCK, 2) void k_preprocess_bwd_batch(const Bwd
 #pragma unroll
     for (int i = 0; i < 48; i++) o48[i] = 0.f;
     float dopacity = 0.f, dmean[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dscale[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
-    double dcsum[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};      // dL_dcov3D summed over the views in double (TGS_PERGAUSS_F64: cov3d_bwd_f64 runs once, behind the loop)
+    double dcsum[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};      // dL_dcov3D summed over the views in double (cov3d_bwd_f64 runs once, behind the loop)
     // view-independent inputs of the geometry chain, once: the mean and the 3D covariance (evaluated as the forward did, compute_cov3d)
     float gmx = 0.f, gmy = 0.f, gmz = 0.f, cov3d[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (in_range) {
@@ -1437,8 +1244,8 @@ __global__ __launch_bounds__(PRE_BLOCK, 2) void k_preprocess_bwd_batch(const Bwd
         GaussTerms t;
         if (__builtin_amdgcn_ballot_w64(live) != 0) {
             const ViewMat V = load_mat(vw.cam.view), PM = load_mat(vw.cam.proj);
-            pergauss_terms<HAS_SH, HAS_SCALE_ROT>(idx, live, in.D, [&](int i) { return sh_row[i]; }, in, in.cov3D_precomp, vw.cam, V, PM, vw.cam.campos[0], vw.cam.campos[1],
-                                                  vw.cam.campos[2], vw.g, vw.b, pv_lds[v][1][threadIdx.x], pv_lds[v][2][threadIdx.x], gmx, gmy, gmz, cov3d, t, dcsum);
+            pergauss_terms<HAS_SH>(idx, live, in.D, [&](int i) { return sh_row[i]; }, vw.cam, V, PM, vw.cam.campos[0], vw.cam.campos[1],
+                                   vw.cam.campos[2], vw.g, vw.b, pv_lds[v][1][threadIdx.x], pv_lds[v][2][threadIdx.x], gmx, gmy, gmz, cov3d, t, dcsum);
         } else {
             t.a[0] = t.a[1] = t.a[2] = t.a[3] = t.a[4] = 0.f;
         }
@@ -1451,10 +1258,6 @@ __global__ __launch_bounds__(PRE_BLOCK, 2) void k_preprocess_bwd_batch(const Bwd
             dopacity += t.a[8];
 #pragma unroll
             for (int k = 0; k < 3; k++) { dmean[k] += t.dmean[k]; dscale[k] += t.dscale[k]; }
-#if !TGS_PERGAUSS_F64
-#pragma unroll
-            for (int k = 0; k < 6; k++) dcov[k] += t.dcov[k];
-#endif
 #pragma unroll
             for (int k = 0; k < 4; k++) drot[k] += t.drot[k];
             if (HAS_SH) {
@@ -1670,8 +1473,8 @@ __global__ __launch_bounds__(PRE_BLOCK, TGS_SPLIT_WAVES) void k_preprocess_bwd_b
                 float cov3d[6];
 #pragma unroll
                 for (int k = 0; k < 6; k++) cov3d[k] = gc_lds[3 + k][gl];
-                pergauss_terms<false, HAS_SCALE_ROT>(idx, live, in.D, [&](int) { return 0.f; }, in, in.cov3D_precomp, vw.cam, V, PM, vw.cam.campos[0], vw.cam.campos[1],
-                                                     vw.cam.campos[2], vw.g, vw.b, pv_lds[v][1][gl], pv_lds[v][2][gl], gc_lds[0][gl], gc_lds[1][gl], gc_lds[2][gl], cov3d, t, dcsum);
+                pergauss_terms<false>(idx, live, in.D, [&](int) { return 0.f; }, vw.cam, V, PM, vw.cam.campos[0], vw.cam.campos[1],
+                                      vw.cam.campos[2], vw.g, vw.b, pv_lds[v][1][gl], pv_lds[v][2][gl], gc_lds[0][gl], gc_lds[1][gl], gc_lds[2][gl], cov3d, t, dcsum);
             } else {
                 t.a[3] = t.a[4] = 0.f;
             }
@@ -1683,10 +1486,6 @@ __global__ __launch_bounds__(PRE_BLOCK, TGS_SPLIT_WAVES) void k_preprocess_bwd_b
                 dopacity += t.a[8];
 #pragma unroll
                 for (int k = 0; k < 3; k++) { dmean[k] += t.dmean[k]; dscale[k] += t.dscale[k]; }
-#if !TGS_PERGAUSS_F64
-#pragma unroll
-                for (int k = 0; k < 6; k++) dcov[k] += t.dcov[k];
-#endif
 #pragma unroll
                 for (int k = 0; k < 4; k++) drot[k] += t.drot[k];
             }
