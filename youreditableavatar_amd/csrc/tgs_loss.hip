@@ -256,6 +256,8 @@ __global__ __launch_bounds__(256) void k_ssim_grad(int H, int W, const float* __
 // per CU at 42 KB of LDS each, three barriers per tile; 1.9 / 2.7 TB/s of their algorithmic bytes at 3 x 2048 x 2048).  Cost of the scheme:
 // 64 / 54 of the input loads (neighbouring strips overlap by 10 columns, L2 hits) and 10 warm-up rows per segment.
 // The tiled kernels remain for A/B runs (TGS_LOSS_TILED=1).
+// Measured and not kept (round 4): TWO columns per lane (one wave shift per map and tap instead of two, halo 10 of 128 columns instead of 10 of
+// 64; bit-equal): 125 / 106 VGPRs instead of 75 / 68, half as many waves -- 113 + 95 us instead of 104 + 78 at 3 x 2048 x 2048.
 // =====================================================================================================================================
 constexpr int SS_OUT = WAVE - 2 * LR;       // 54 output columns per wave
 #ifndef TGS_SS_SEG
