@@ -17,15 +17,18 @@ _LIB_PATH = os.path.join(_HERE, "libtgs_oracle.so")
 _LIB64_PATH = os.path.join(_HERE, "libtgs_oracle_f64.so")      # the same C text with real = double (tgs_oracle.c: TGS_ORACLE_F64)
 _LIBFMA_PATH = os.path.join(_HERE, "libtgs_oracle_fma.so")     # fp32 with FMA contraction allowed (what nvcc does to the reference by default)
 _LIBEX2_PATH = os.path.join(_HERE, "libtgs_oracle_ex2.so")     # fp32, exp as 2^(x log2 e) (how GPU math libraries evaluate expf)
+_LIBIN_PATH = os.path.join(_HERE, "libtgs_oracle_in.so")       # fp32, the compositing loop's two cut-offs moved by 1e-6 towards more blended pairs (TGS_ORACLE_CUT=+1)
+_LIBOUT_PATH = os.path.join(_HERE, "libtgs_oracle_out.so")     # ... towards fewer (TGS_ORACLE_CUT=-1)
 _lib = None
 _lib64 = None
 _libfma = None
 _libex2 = None
+_libcut = {}
 
 
 def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "tgs_oracle.c")
-    for path in (_LIB_PATH, _LIB64_PATH, _LIBFMA_PATH, _LIBEX2_PATH):
+    for path in (_LIB_PATH, _LIB64_PATH, _LIBFMA_PATH, _LIBEX2_PATH, _LIBIN_PATH, _LIBOUT_PATH):
         if force or not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
             subprocess.check_call(["make", "-C", _HERE, "-s", os.path.basename(path)])
     return _LIB_PATH
@@ -81,8 +84,18 @@ def libex2():
     return _libex2
 
 
+def libcut(which: str):
+    """libtgs_oracle_in.so / libtgs_oracle_out.so: fp32 with the cut-offs alpha >= 1/255 and T >= 1e-4 of the compositing loop moved by 1e-6 of
+    their value towards more ("in") / fewer ("out") blended pairs -- decisions that fp32's own evaluation noise makes either way; the tests
+    take the spread as part of the reference arithmetic's own distance from its function."""
+    if which not in _libcut:
+        build()
+        _libcut[which] = _bind(_LIBIN_PATH if which == "in" else _LIBOUT_PATH, C.c_float, False)
+    return _libcut[which]
+
+
 def _variant_lib(variant: str):
-    return {"f32": lib, "f64": lib64, "f32_fma": libfma, "f32_ex2": libex2}[variant]()
+    return {"f32": lib, "f64": lib64, "f32_fma": libfma, "f32_ex2": libex2, "f32_in": lambda: libcut("in"), "f32_out": lambda: libcut("out")}[variant]()
 
 
 def lib():

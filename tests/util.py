@@ -218,18 +218,21 @@ def record_parity(name: str, rep: dict, extra: Optional[dict] = None) -> None:
 
 def reference_noise_of(ref: dict) -> dict:
     """{tensor: rel_l2(reference arithmetic in fp32, the same function in double)} of the scene behind an oracle result (tests.util.oracle_run):
-    the largest of the three fp32 builds of oracle/tgs_oracle.c (no FMA contraction + double accumulation / contraction + the reference's fp32
-    accumulation / exp as 2^(x log2 e) like a GPU math library) against the double build.  Computed on demand and cached in ``ref``."""
+    the largest of the FIVE fp32 builds of oracle/tgs_oracle.c (no FMA contraction + double accumulation / contraction + the reference's fp32
+    accumulation / exp as 2^(x log2 e) like a GPU math library / the compositing loop's two cut-offs, alpha >= 1/255 and T >= 1e-4, moved by
+    1e-6 of their value either way: pairs that fp32's own evaluation noise decides either way) against the double build.  Computed on demand
+    and cached in ``ref``."""
     if "_noise" not in ref:
         from oracle import oracle
         kw = ref["_kw"]
         inp = dict(kw, opacities=ref["_opacities"], image_height=ref["n_contrib"].shape[0], image_width=ref["n_contrib"].shape[1], sh_degree=ref["_sh_degree"])
         outs = {}
-        for variant in ("f64", "f32_fma", "f32_ex2"):
+        fp32_variants = ("f32_fma", "f32_ex2", "f32_in", "f32_out")
+        for variant in ("f64",) + fp32_variants:
             color, _, s2 = oracle.forward(variant=variant, **inp)
             outs[variant] = dict(oracle.backward(s2, ref["_dL"], **kw), color=color)
         f64 = outs["f64"]
-        ref["_noise"] = {k: max(rel_l2(ref[k], f64[k]), rel_l2(outs["f32_fma"][k], f64[k]), rel_l2(outs["f32_ex2"][k], f64[k]))
+        ref["_noise"] = {k: max([rel_l2(ref[k], f64[k])] + [rel_l2(outs[v][k], f64[k]) for v in fp32_variants])
                          for k in ("color", "dL_dconic") + GRAD_KEYS if k in ref and k in f64}
         ref["_f64"] = f64
     return ref["_noise"]
@@ -239,7 +242,7 @@ def compare(mine: dict, ref: dict, golden_out: Optional[dict] = None, nc_frac: f
     """Asserts the parity bar; returns {tensor: rel_l2} for reporting.
 
     The bar (round 4, no failure budget anywhere), for the colour and every gradient:  bar = max(1e-4, 2 x eta), eta = the reference
-    arithmetic's own distance from exact arithmetic on this very scene (reference_noise_of: the largest of three fp32 roundings of the
+    arithmetic's own distance from exact arithmetic on this very scene (reference_noise_of: the largest of five fp32 builds of the
     oracle's C text against the same text compiled in double).  A tensor passes when rel_l2(HIP, fp32 oracle) <= bar -- or, where the fp32
     oracle itself is the outlier among roundings, when rel_l2(HIP, the double evaluation) <= bar; which of the two applied is recorded
     (`|vs_f64`).  Against a FIXTURE the bar is what the fixture recorded (tolerance())."""
