@@ -17,7 +17,7 @@ _LIB_PATH = os.path.join(_HERE, "libtgs_oracle.so")
 _LIB64_PATH = os.path.join(_HERE, "libtgs_oracle_f64.so")      # the same C text with real = double (tgs_oracle.c: TGS_ORACLE_F64)
 _LIBFMA_PATH = os.path.join(_HERE, "libtgs_oracle_fma.so")     # fp32 with FMA contraction allowed (what nvcc does to the reference by default)
 _LIBEX2_PATH = os.path.join(_HERE, "libtgs_oracle_ex2.so")     # fp32, exp as 2^(x log2 e) (how GPU math libraries evaluate expf)
-_LIBIN_PATH = os.path.join(_HERE, "libtgs_oracle_in.so")       # fp32, the compositing loop's two cut-offs moved by 1e-6 towards more blended pairs (TGS_ORACLE_CUT=+1)
+_LIBIN_PATH = os.path.join(_HERE, "libtgs_oracle_in.so")       # fp32, every pair inside fp32's noise band of the loop's cut-offs decided as blended (TGS_ORACLE_CUT=+1)
 _LIBOUT_PATH = os.path.join(_HERE, "libtgs_oracle_out.so")     # ... towards fewer (TGS_ORACLE_CUT=-1)
 _lib = None
 _lib64 = None
@@ -85,8 +85,9 @@ def libex2():
 
 
 def libcut(which: str):
-    """libtgs_oracle_in.so / libtgs_oracle_out.so: fp32 with the cut-offs alpha >= 1/255 and T >= 1e-4 of the compositing loop moved by 1e-6 of
-    their value towards more ("in") / fewer ("out") blended pairs -- decisions that fp32's own evaluation noise makes either way; the tests
+    """libtgs_oracle_in.so / libtgs_oracle_out.so: fp32 with every pair that lies inside fp32's own evaluation noise of the compositing loop's cut-off alpha >= 1/255
+    (|alpha * 255 - 1| <= max(1e-6, 8 ulp of the sum of the quadratic form's term magnitudes)) decided as blended ("in") / skipped ("out"), and T >= 1e-4
+    moved by 1e-6 of its value the same way -- decisions that fp32's own evaluation noise makes either way; the tests
     take the spread as part of the reference arithmetic's own distance from its function."""
     if which not in _libcut:
         build()

@@ -4,7 +4,8 @@ The HIP path and the fp32 oracle are two roundings of one function.  Where they 
 further from that function in exact arithmetic.  ``oracle/tgs_oracle.c`` compiles to six libraries from one text: fp32 without FMA
 contraction (the restatement), fp32 with contraction and the reference's fp32 accumulation of the cross-pixel sums (what nvcc and
 atomicAdd do to the reference), fp32 with exp evaluated as 2^(x log2 e) (what a GPU math library does), fp32 with the compositing loop's
-two cut-offs (alpha >= 1/255, T >= 1e-4) moved by 1e-6 of their value towards more / fewer blended pairs (the function is discontinuous
+two cut-offs decided the other way -- every pair within fp32's evaluation noise of alpha >= 1/255 (max(1e-6, 8 ulp of the sum of the quadratic
+form's term magnitudes), relative) blended / skipped, T >= 1e-4 moved by 1e-6 of its value -- (the function is discontinuous
 there, and fp32's own evaluation noise -- 4e-7 of alpha on the pair that prompted this -- decides such pairs either way), and **double** (every intermediate
 and every array; the fp32 literals, the fp32 inputs and the fp32 depth bits of the sort key stay).  For every tensor this module reports
 
@@ -42,7 +43,7 @@ def oracle_variant(inp: dict, dL: Optional[np.ndarray], variant: str) -> Dict[st
 
 def reference_noise(inp: dict, dL: np.ndarray, ref32: Optional[dict] = None) -> Dict[str, float]:
     """{tensor: distance of the reference's fp32 arithmetic from the same function in double}: the largest of the five fp32 builds
-    (no FMA contraction / contraction + fp32 accumulation / exp as 2^(x log2 e) / the loop's two cut-offs moved by 1e-6 either way);
+    (no FMA contraction / contraction + fp32 accumulation / exp as 2^(x log2 e) / the loop's two cut-offs decided either way inside fp32's noise band: tgs_oracle.c, TGS_ORACLE_CUT);
     ``ref32``: an existing fp32 result (tests.util.oracle_run) to reuse."""
     f64 = oracle_variant(inp, dL, "f64")
     a = ref32 if ref32 is not None else oracle_variant(inp, dL, "f32")

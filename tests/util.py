@@ -219,8 +219,8 @@ def record_parity(name: str, rep: dict, extra: Optional[dict] = None) -> None:
 def reference_noise_of(ref: dict) -> dict:
     """{tensor: rel_l2(reference arithmetic in fp32, the same function in double)} of the scene behind an oracle result (tests.util.oracle_run):
     the largest of the FIVE fp32 builds of oracle/tgs_oracle.c (no FMA contraction + double accumulation / contraction + the reference's fp32
-    accumulation / exp as 2^(x log2 e) like a GPU math library / the compositing loop's two cut-offs, alpha >= 1/255 and T >= 1e-4, moved by
-    1e-6 of their value either way: pairs that fp32's own evaluation noise decides either way) against the double build.  Computed on demand
+    accumulation / exp as 2^(x log2 e) like a GPU math library / the compositing loop's two cut-offs, alpha >= 1/255 and T >= 1e-4, decided
+    either way for every pair inside fp32's own evaluation noise of them: tgs_oracle.c, TGS_ORACLE_CUT) against the double build.  Computed on demand
     and cached in ``ref``."""
     if "_noise" not in ref:
         from oracle import oracle
