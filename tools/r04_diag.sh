@@ -1,4 +1,3 @@
 R=$GRAFT_REPO_ROOT; cd $R
 timeout 120 python -c "from oracle import oracle; oracle.build(force=True)" < /dev/null
-timeout 800 python tests/tools/diag_pixels.py 37 89 2>&1 < /dev/null | grep -v Warning | cut -c1-200
-timeout 800 python tests/tools/diag_scene.py 37 89 2>&1 < /dev/null | grep -v Warning | cut -c1-300
+timeout 800 python -m pytest tests/test_gpu_parity.py -m gpu -x -q --timeout 400 -k "cutoff_flip" -s 2>&1 < /dev/null | grep -v Warning | tail -8 | cut -c1-250
