@@ -90,3 +90,23 @@ def test_oracle_mark_visible():
     z = (np.concatenate([m, np.ones((500, 1), np.float32)], 1) @ cam.viewmatrix)[:, 2]
     assert np.array_equal(vis, z > 0.2)
     assert not vis[::2].any() and vis[1::2].all()
+
+
+def test_oracle_cutoff_builds_move_only_undecidable_pairs():
+    """The two cut-off builds of the oracle (tgs_oracle.c: TGS_ORACLE_CUT; part of the reference-noise measure of the parity bar) against the
+    plain fp32 build on the two fuzz scenes that prompted them: the build that decides pairs inside fp32's noise band of alpha >= 1/255 as
+    BLENDED moves dL_dconic by what one edge pair of a large splat is worth (6.7e-4 / 1.1e-4), the build that decides them as SKIPPED is the
+    plain build there (those pairs are skipped by it already) -- and on a scene without such a pair all three are the same function."""
+    from tests import fuzz, adjudicate
+    for seed, scene, lo, hi in ((23, 93, 5e-4, 8e-4), (37, 89, 8e-5, 2e-4)):
+        rng = np.random.default_rng(seed)
+        for it in range(scene + 1):
+            desc, inp, dL = fuzz.random_scene(rng, it)
+        plain, more, fewer = (adjudicate.oracle_variant(inp, dL, v) for v in ("f32", "f32_in", "f32_out"))
+        d_in, d_out = util.rel_l2(more["dL_dconic"], plain["dL_dconic"]), util.rel_l2(fewer["dL_dconic"], plain["dL_dconic"])
+        assert lo <= d_in <= hi and d_out <= 1e-6, (desc, d_in, d_out)
+    inp, gold = util.load_golden(util.golden_names()[0])
+    dL = inp["dL_dout_color"]
+    plain, more, fewer = (adjudicate.oracle_variant(inp, dL, v) for v in ("f32", "f32_in", "f32_out"))
+    for k in ("color", "dL_dconic", "dL_dmeans2D"):
+        assert util.rel_l2(more[k], plain[k]) <= 1e-4 and util.rel_l2(fewer[k], plain[k]) <= 1e-4, k
