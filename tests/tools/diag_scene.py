@@ -27,7 +27,7 @@ for it in range(max(want) + 1):
             tot = np.abs(ref["dL_dconic"]).sum()
             for g in top:
                 print(f"    gaussian {g}: |d dL_dconic| {d[g]:.3e} of {np.abs(ref['dL_dconic'][g]).sum():.3e} (tensor total {tot:.3e}); tiles_touched hip {int(mine['tiles_touched'][g])} oracle {int(ref['tiles_touched'][g]) if 'tiles_touched' in ref else -1};"
-                      f" opacity {float(inp['opacities'][g]):.4f} radius {int(mine['radii'][g])}")
+                      f" opacity {float(np.ravel(inp['opacities'])[g]):.4f} radius {int(mine['radii'][g])}")
             if "n_contrib" in ref:
                 bad = np.argwhere(mine["n_contrib"] != ref["n_contrib"])
                 print(f"    pixels with another n_contrib: {len(bad)}" + (f", first {bad[:4].tolist()} hip {[int(mine['n_contrib'][tuple(b)]) for b in bad[:4]]} oracle {[int(ref['n_contrib'][tuple(b)]) for b in bad[:4]]}" if len(bad) else ""))
