@@ -1257,9 +1257,7 @@ __global__ __launch_bounds__(PRE_BLOCK, 2) void k_preprocess_bwd_batch(const Bwd
         if (live) {
             dopacity += t.a[8];
 #pragma unroll
-            for (int k = 0; k < 3; k++) { dmean[k] += t.dmean[k]; dscale[k] += t.dscale[k]; }
-#pragma unroll
-            for (int k = 0; k < 4; k++) drot[k] += t.drot[k];
+            for (int k = 0; k < 3; k++) dmean[k] += t.dmean[k];
             if (HAS_SH) {
 #pragma unroll
                 for (int i = 0; i < 48; i++) o48[i] += t.coef[i / 3] * t.dRGB[i % 3];
@@ -1482,12 +1480,10 @@ __global__ __launch_bounds__(PRE_BLOCK, TGS_SPLIT_WAVES) void k_preprocess_bwd_b
                 const size_t i3 = 3 * (size_t)idx;
                 vw.dL_dmean2D[i3] = live ? t.a[3] : 0.f; vw.dL_dmean2D[i3 + 1] = live ? t.a[4] : 0.f; vw.dL_dmean2D[i3 + 2] = 0.f;
             }
-            if (live) {
+            if (live) {                                    // (scale / rotation gradients: once, from dcsum, behind the loop)
                 dopacity += t.a[8];
 #pragma unroll
-                for (int k = 0; k < 3; k++) { dmean[k] += t.dmean[k]; dscale[k] += t.dscale[k]; }
-#pragma unroll
-                for (int k = 0; k < 4; k++) drot[k] += t.drot[k];
+                for (int k = 0; k < 3; k++) dmean[k] += t.dmean[k];
             }
         }
         finish_cov3d<HAS_SCALE_ROT>(in, views.v[0].cam.scale_modifier, idx, in_range, dcsum, dcov, dscale, drot);

@@ -565,7 +565,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const 
             const uint32_t n = min(SC, T - sc);
             uint2 r[TI];
 #pragma unroll
-            for (int k = 0; k < TI; k++) { const uint32_t i = k * SCAN_THREADS + threadIdx.x; r[k] = i < n ? s.ranges[sc + i] : make_uint2(0u, 0u); }
+            for (int k = 0; k < TI; k++) { const uint32_t i = k * SCAN_THREADS + threadIdx.x; r[k] = s.ranges[sc + min(i, n - 1u)]; }   // (clamped, not predicated: under `i < n ?` each of the TI loads is waited for on its own)
 #pragma unroll
             for (int k = 0; k < TI; k++) {
                 const uint32_t i = k * SCAN_THREADS + threadIdx.x;

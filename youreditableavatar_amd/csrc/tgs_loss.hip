@@ -256,6 +256,8 @@ __global__ __launch_bounds__(256) void k_ssim_grad(int H, int W, const float* __
 // per CU at 42 KB of LDS each, three barriers per tile; 1.9 / 2.7 TB/s of their algorithmic bytes at 3 x 2048 x 2048).  Cost of the scheme:
 // 64 / 54 of the input loads (neighbouring strips overlap by 10 columns, L2 hits) and 10 warm-up rows per segment.
 // The tiled kernels remain for A/B runs (TGS_LOSS_TILED=1).
+// Round 4: the row loads are unconditional (clamped into the image, times 0 or 1) and the row loop walks whole groups of 11 rows: under `if`
+// each pair of loads was waited for with vmcnt(0) -- one memory round trip per row instead of three rows in flight: 104 + 78 -> 96.5 + 76 us.
 // Measured and not kept (round 4): TWO columns per lane (one wave shift per map and tap instead of two, halo 10 of 128 columns instead of 10 of
 // 64; bit-equal): 125 / 106 VGPRs instead of 75 / 68, half as many waves -- 113 + 95 us instead of 104 + 78 at 3 x 2048 x 2048.
 // =====================================================================================================================================
@@ -348,21 +350,26 @@ __global__ __launch_bounds__(256) void k_ssim_stats_stream(int H, int W, int nst
 #pragma unroll
         for (int k = 0; k < NTAP; k++) V[m][k] = 0.f;
     float s_map = 0.f, s_l1 = 0.f;
-    const float* px = img + g.plane + g.col_in;
-    const float* py = gt + g.plane + g.col_in;
-    auto ld = [&](const float* p, int r) { return (g.in_x && r >= 0 && r < H) ? p[(size_t)r * W] : 0.f; };
+    // Loads are UNCONDITIONAL (row and column clamped into the image, the value replaced by the padding's zero afterwards) and the row loop
+    // walks whole groups of 11 rows without a test per row: with the load under `if (inside)` -- or the step under `if (r <= r_last)` --
+    // the compiler waits with vmcnt(0) behind every pair of loads, i.e. for the row it has just asked for, and the three rows "in flight"
+    // were one memory round trip per row.  Rows past the segment's last (at most 10, in the last group) are evaluated and never stored.
+    const int colc = min(max(g.col_in, 0), W - 1);
+    const float* px = img + g.plane + colc;
+    const float* py = gt + g.plane + colc;
+    // (times 0 or 1, not a select: a select is turned back into a load under a branch, waited for inside it)
+    auto ld = [&](const float* p, int r) { return p[(size_t)min(max(r, 0), H - 1) * W] * ((g.in_x && r >= 0 && r < H) ? 1.f : 0.f); };
     const int r_first = g.y0 - LR, r_last = g.y1 + LR - 1;  // input rows this segment needs (zero padding outside the image)
     float xa = ld(px, r_first), ya = ld(py, r_first), xb = ld(px, r_first + 1), yb = ld(py, r_first + 1), xc = ld(px, r_first + 2), yc = ld(py, r_first + 2);
-    int r = r_first;
 #define TGS_STATS_STEP(P)                                                                                                   \
-    if (r <= r_last) {                                                                                                      \
+    {                                                                                                                       \
+        const int rr = r + P;                                                                                               \
         const float x = xa, y = ya;                                                                                         \
-        xa = xb; ya = yb; xb = xc; yb = yc; xc = ld(px, r + 3); yc = ld(py, r + 3);     /* three rows in flight */          \
-        if (g.own_col && r >= g.y0 && r < g.y1) s_l1 += fabsf(x - y);                                                       \
-        stats_row<P>(x, y, r, g, win, V, W, dM1, dX2, dXY, s_map);                                                          \
-        r++;                                                                                                                \
+        xa = xb; ya = yb; xb = xc; yb = yc; xc = ld(px, rr + 3); yc = ld(py, rr + 3);   /* three rows in flight */          \
+        s_l1 += (g.own_col && rr >= g.y0 && rr < g.y1) ? fabsf(x - y) : 0.f;                                                \
+        stats_row<P>(x, y, rr, g, win, V, W, dM1, dX2, dXY, s_map);                                                         \
     }
-    while (r <= r_last) {
+    for (int r = r_first; r <= r_last; r += NTAP) {
         TGS_STATS_STEP(0) TGS_STATS_STEP(1) TGS_STATS_STEP(2) TGS_STATS_STEP(3) TGS_STATS_STEP(4) TGS_STATS_STEP(5)
         TGS_STATS_STEP(6) TGS_STATS_STEP(7) TGS_STATS_STEP(8) TGS_STATS_STEP(9) TGS_STATS_STEP(10)
     }
@@ -414,27 +421,28 @@ __global__ __launch_bounds__(256) void k_ssim_grad_stream(int H, int W, int nstr
     for (int m = 0; m < 3; m++)
 #pragma unroll
         for (int k = 0; k < NTAP; k++) V[m][k] = 0.f;
-    const float* p0 = dM1 + g.plane + g.col_in;
-    const float* p1 = dX2 + g.plane + g.col_in;
-    const float* p2 = dXY + g.plane + g.col_in;
+    const int colc = min(max(g.col_in, 0), W - 1);
+    const float* p0 = dM1 + g.plane + colc;
+    const float* p1 = dX2 + g.plane + colc;
+    const float* p2 = dXY + g.plane + colc;
     const bool oc = g.col_out >= 0 && g.col_out < W;
     const float* qx = img + g.plane + (oc ? g.col_out : 0);
     const float* qy = gt + g.plane + (oc ? g.col_out : 0);
-    auto ld = [&](const float* p, int r) { return (g.in_x && r >= 0 && r < H) ? p[(size_t)r * W] : 0.f; };
-    auto ldo = [&](const float* p, int r) { return (oc && r >= 0 && r < H) ? p[(size_t)r * W] : 0.f; };       // the image at the OUTPUT pixel of row r - 5
+    // (unconditional clamped loads, whole groups of 11 rows: see k_ssim_stats_stream)
+    auto ld = [&](const float* p, int r) { return p[(size_t)min(max(r, 0), H - 1) * W] * ((g.in_x && r >= 0 && r < H) ? 1.f : 0.f); };
+    auto ldo = [&](const float* p, int r) { return p[(size_t)min(max(r, 0), H - 1) * W] * ((oc && r >= 0 && r < H) ? 1.f : 0.f); };       // the image at the OUTPUT pixel of row r - 5
     const int r_first = g.y0 - LR, r_last = g.y1 + LR - 1;
     float a0 = ld(p0, r_first), b0 = ld(p1, r_first), c0 = ld(p2, r_first), x0 = ldo(qx, r_first - LR), y0v = ldo(qy, r_first - LR);
     float a1 = ld(p0, r_first + 1), b1 = ld(p1, r_first + 1), c1 = ld(p2, r_first + 1), x1 = ldo(qx, r_first + 1 - LR), y1v = ldo(qy, r_first + 1 - LR);
-    int r = r_first;
 #define TGS_GRAD_STEP(P)                                                                                                    \
-    if (r <= r_last) {                                                                                                      \
+    {                                                                                                                       \
+        const int rr = r + P;                                                                                               \
         const float a = a0, b = b0, c = c0, xo = x0, yo = y0v;                                                              \
         a0 = a1; b0 = b1; c0 = c1; x0 = x1; y0v = y1v;                                                                      \
-        a1 = ld(p0, r + 2); b1 = ld(p1, r + 2); c1 = ld(p2, r + 2); x1 = ldo(qx, r + 2 - LR); y1v = ldo(qy, r + 2 - LR);    \
-        grad_row<P>(a, b, c, xo, yo, r, g, win, V, W, gs, gl, grad);                                                         \
-        r++;                                                                                                                \
+        a1 = ld(p0, rr + 2); b1 = ld(p1, rr + 2); c1 = ld(p2, rr + 2); x1 = ldo(qx, rr + 2 - LR); y1v = ldo(qy, rr + 2 - LR); \
+        grad_row<P>(a, b, c, xo, yo, rr, g, win, V, W, gs, gl, grad);                                                        \
     }
-    while (r <= r_last) {
+    for (int r = r_first; r <= r_last; r += NTAP) {
         TGS_GRAD_STEP(0) TGS_GRAD_STEP(1) TGS_GRAD_STEP(2) TGS_GRAD_STEP(3) TGS_GRAD_STEP(4) TGS_GRAD_STEP(5)
         TGS_GRAD_STEP(6) TGS_GRAD_STEP(7) TGS_GRAD_STEP(8) TGS_GRAD_STEP(9) TGS_GRAD_STEP(10)
     }
