@@ -281,7 +281,7 @@ class SyncFreeBatch:
         # run_views(upstream_view=...): half of the streams bin (per-Gaussian forward .. finalize), the other half composite
         # (k_render_fwd, the loss, k_render_bwd): kernels bound by the L2 atomics / by latency next to kernels bound by VALU issue
         self.split = bool(split)
-        self.split_pass = False                 # experiment (measured slower): per-Gaussian pass of the first round of views beside the remaining per-pixel backwards
+        self.split_pass = False                 # experiment (measured slower in round 2, DESIGN_HISTORY.md, and again at the end of round 4 with the faster pass: 1.90 against 1.82 ms per 8-view step): per-Gaussian pass of the first round of views beside the remaining per-pixel backwards
         self._pass_stream = {}
         self._host: Optional[torch.Tensor] = None
         self._side = {}
