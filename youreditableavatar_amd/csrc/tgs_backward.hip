@@ -478,13 +478,16 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
     {
         const uint32_t cnt0 = min((uint32_t)BCH, qmax);
         if (ht < cnt0) stage(0);
-        if (qmax > BCH && ht < qmax - BCH) fetch(rg.x + qmax - BCH - 1 - ht);
     }
     __syncthreads();
     int rnd = 0;
     unsigned long long busy = 0ull;                        // (diagnostic builds only: tests/tools/timeline.py)
     for (uint32_t qhi = qmax; qhi > 0; qhi = qhi > BCH ? qhi - BCH : 0, rnd ^= 1) {
         const uint32_t cnt = min((uint32_t)BCH, qhi);
+        // The records of the round AFTER this one are asked for here, behind the barrier and in front of this round's arithmetic.  Asked for
+        // in front of the barrier (until round 4) they were waited for AT it: __syncthreads() is a workgroup fence, i.e. s_waitcnt vmcnt(0)
+        // before s_barrier -- the prefetch bought nothing and every round paid a memory round trip with all sixteen waves idle.
+        if (qhi > BCH && ht < qhi - BCH) fetch(rg.x + qhi - BCH - 1 - ht);
         const unsigned long long tb0 = busy_clock();
         {
             const uint32_t nl = build_own_list_q<BCH>(lists[wv], sQ, cnt, wv, lane);
@@ -564,7 +567,6 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
         if (qhi > BCH) {                                    // stage the next round (its records were prefetched into registers)
             const uint32_t qn = qhi - BCH, cntn = min((uint32_t)BCH, qn);
             if (ht < cntn) stage(rnd ^ 1);
-            if (qn > BCH && ht < qn - BCH) fetch(rg.x + qn - BCH - 1 - ht);
             __syncthreads();
         }
     }
