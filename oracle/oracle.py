@@ -19,6 +19,7 @@ _LIBFMA_PATH = os.path.join(_HERE, "libtgs_oracle_fma.so")     # fp32 with FMA c
 _LIBEX2_PATH = os.path.join(_HERE, "libtgs_oracle_ex2.so")     # fp32, exp as 2^(x log2 e) (how GPU math libraries evaluate expf)
 _LIBIN_PATH = os.path.join(_HERE, "libtgs_oracle_in.so")       # fp32, every pair inside fp32's noise band of the loop's cut-offs decided as blended (TGS_ORACLE_CUT=+1)
 _LIBOUT_PATH = os.path.join(_HERE, "libtgs_oracle_out.so")     # ... towards fewer (TGS_ORACLE_CUT=-1)
+_LIB64S_PATH = os.path.join(_HERE, "libtgs_oracle_f64s.so")    # double arithmetic, the per-Gaussian state rounded to fp32 where the reference stores it
 _lib = None
 _lib64 = None
 _libfma = None
@@ -28,7 +29,7 @@ _libcut = {}
 
 def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "tgs_oracle.c")
-    for path in (_LIB_PATH, _LIB64_PATH, _LIBFMA_PATH, _LIBEX2_PATH, _LIBIN_PATH, _LIBOUT_PATH):
+    for path in (_LIB_PATH, _LIB64_PATH, _LIBFMA_PATH, _LIBEX2_PATH, _LIBIN_PATH, _LIBOUT_PATH, _LIB64S_PATH):
         if force or not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
             subprocess.check_call(["make", "-C", _HERE, "-s", os.path.basename(path)])
     return _LIB_PATH
@@ -95,8 +96,21 @@ def libcut(which: str):
     return _libcut[which]
 
 
+_lib64s = None
+
+
+def lib64s():
+    """libtgs_oracle_f64s.so: the double build with cov3D / means2D / conic_opacity / rgb rounded to fp32 where the reference stores them
+    (its geomState is fp32): exact arithmetic on the reference's own data layout."""
+    global _lib64s
+    if _lib64s is None:
+        build()
+        _lib64s = _bind(_LIB64S_PATH, C.c_double, False)
+    return _lib64s
+
+
 def _variant_lib(variant: str):
-    return {"f32": lib, "f64": lib64, "f32_fma": libfma, "f32_ex2": libex2, "f32_in": lambda: libcut("in"), "f32_out": lambda: libcut("out")}[variant]()
+    return {"f32": lib, "f64": lib64, "f32_fma": libfma, "f32_ex2": libex2, "f32_in": lambda: libcut("in"), "f32_out": lambda: libcut("out"), "f64_s32": lib64s}[variant]()
 
 
 def lib():
@@ -143,7 +157,7 @@ class OracleState:
         self._h = handle
         self._keep = keep
         self.variant = variant
-        self.f64 = variant == "f64"
+        self.f64 = variant in ("f64", "f64_s32")
         self._L = _variant_lib(variant)
 
     def field(self, name: str) -> np.ndarray:
@@ -177,7 +191,7 @@ def forward(*, bg, means3D, opacities, viewmatrix, projmatrix, campos, tanfovx, 
     (cuda_rasterizer/rasterizer_impl.cu:198-336).  ``variant``: "f32" (the restatement, no FMA contraction), "f32_fma" (contraction
     allowed, fp32 accumulation of the cross-pixel sums), "f32_ex2" (exp as 2^(x log2 e)), "f64" (the same C text compiled with real = double on the same fp32 inputs -- scalars are rounded to fp32 first as well:
     the reference's function in exact arithmetic)."""
-    f64 = variant == "f64"
+    f64 = variant in ("f64", "f64_s32")
     cv = _conv(f64)
     L = _variant_lib(variant)
     rdt = np.float64 if f64 else np.float32

@@ -88,6 +88,13 @@ def run_fuzz(seed: int, n_scenes: int, light_tiles=None, log=print) -> dict:
             if r["hip_vs_ref"] > util.REL_TOL:
                 bar = max(util.REL_TOL, 2.0 * r["ref_vs_f64"])
                 verdict = "ok" if r["hip_vs_ref"] <= bar else ("ok (within the bar of exact arithmetic)" if r["hip_vs_f64"] <= bar else "MISS")
+                if verdict == "MISS" and k in util.PERGAUSS_KEYS and "dL_dconic" in mine:
+                    # the per-Gaussian half on the product's own per-pixel gradients, in double (tests/util.py: compare, third route)
+                    r["hip_vs_own_chain"] = util.rel_l2(np.asarray(mine[k]).reshape(np.asarray(ref[k]).shape), util.own_chain(mine, ref)[k])
+                    upstream_ok = all(tw[u]["hip_vs_ref"] <= max(util.REL_TOL, 2.0 * tw[u]["ref_vs_f64"]) or tw[u]["hip_vs_f64"] <= max(util.REL_TOL, 2.0 * tw[u]["ref_vs_f64"])
+                                      for u in ("dL_dmeans2D", "dL_dconic", "dL_dcolors") if u in tw)
+                    if upstream_ok and r["hip_vs_own_chain"] <= util.CHAIN_TOL:
+                        verdict = f"ok (the per-Gaussian half is exact on its own inputs: {r['hip_vs_own_chain']:.1e}; their noise, inside the bar, amplified)"
                 misses += verdict == "MISS"
                 hip_farther += r["hip_vs_f64"] > r["ref_vs_f64"]
                 over.append((seed, it, desc, k, r, verdict))

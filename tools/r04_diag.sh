@@ -1,3 +1,5 @@
-R=$GRAFT_REPO_ROOT; cd $R
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r04_soak3; mkdir -p $O; cd $R
 timeout 120 python -c "from oracle import oracle; oracle.build(force=True)" < /dev/null
-timeout 800 python -m pytest tests/test_gpu_parity.py -m gpu -x -q --timeout 400 -k "cutoff_flip" -s 2>&1 < /dev/null | grep -v Warning | tail -8 | cut -c1-250
+for seed in 54 58; do
+  timeout 600 python -m tests.adjudicate $seed 96 > $O/seed_${seed}b.txt 2>&1 < /dev/null; grep "MISS\|own inputs" $O/seed_${seed}b.txt | cut -c1-330; tail -1 $O/seed_${seed}b.txt | cut -c1-150
+done
