@@ -1,7 +1,7 @@
 """Three-way adjudication of a parity difference (test infrastructure).
 
 The HIP path and the fp32 oracle are two roundings of one function.  Where they differ by more than 1e-4 the question is which side is
-further from that function in exact arithmetic.  ``oracle/tgs_oracle.c`` compiles to six libraries from one text: fp32 without FMA
+further from that function in exact arithmetic.  ``oracle/tgs_oracle.c`` compiles to seven libraries from one text (six enter the measure below; `f64_s32`, double arithmetic on fp32-rounded state, is a diagnostic variant): fp32 without FMA
 contraction (the restatement), fp32 with contraction and the reference's fp32 accumulation of the cross-pixel sums (what nvcc and
 atomicAdd do to the reference), fp32 with exp evaluated as 2^(x log2 e) (what a GPU math library does), fp32 with the compositing loop's
 two cut-offs decided the other way -- every pair within fp32's evaluation noise of alpha >= 1/255 (max(1e-6, 8 ulp of the sum of the quadratic

@@ -260,7 +260,8 @@ def compare(mine: dict, ref: dict, golden_out: Optional[dict] = None, nc_frac: f
     arithmetic's own distance from exact arithmetic on this very scene (reference_noise_of: the largest of five fp32 builds of the
     oracle's C text against the same text compiled in double).  A tensor passes when rel_l2(HIP, fp32 oracle) <= bar -- or, where the fp32
     oracle itself is the outlier among roundings, when rel_l2(HIP, the double evaluation) <= bar; which of the two applied is recorded
-    (`|vs_f64`).  Against a FIXTURE the bar is what the fixture recorded (tolerance())."""
+    (`|vs_f64`).  For the four per-Gaussian tensors there is a third route (`|vs_own_chain`): within CHAIN_TOL of the reference's per-Gaussian
+    half evaluated in double on the product's own per-pixel gradients, which must pass the bar themselves.  Against a FIXTURE the bar is what the fixture recorded (tolerance())."""
     H, W = ref["n_contrib"].shape
     rep = {}
     assert int(mine["num_rendered"]) <= int(ref["num_rendered"]), "more instances than the reference"   # exact relation: check_point_lists
