@@ -59,7 +59,6 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to smoke-test the N>1 control flow)")
     ap.add_argument("--same-device", action="store_true", help="testing only: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--cpu-frames", type=int, default=3)
-    ap.add_argument("--split-pass", action="store_true", help="experiment: per-Gaussian pass of the first round of views beside the per-pixel backwards of the rest")
     ap.add_argument("--order", default="random", choices=["random", "morton"], help="index order of the synthetic Gaussians: the generator's random permutation "
                     "(default, the headline) or a 3-D Morton curve (neighbours in index are neighbours in space, like mesh-bound Gaussians); not the headline")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads (drop-in API per frame, the trainers' protocol at 2048x2048, grown splats, "
@@ -165,8 +164,6 @@ def main():
         return rast(means3D=means3D, means2D=means2D, opacities=opac, colors_precomp=colors_pre[view], scales=scales, rotations=rots)
 
     batch = SyncFreeBatch(streams=a.streams, split=a.split_streams) if (fused and not a.sync_per_frame) else None
-    if batch is not None:
-        batch.split_pass = a.split_pass
 
     VPG = a.views_per_gpu
 

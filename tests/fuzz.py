@@ -37,18 +37,24 @@ def run(seed: int, n_scenes: int, log=print, light_tiles=None) -> dict:
     """-> {scenes, misses, miss_rate, worst_rel_l2, worst (text), largest_ok: per-tensor maximum over the scenes that passed,
     over_1e4: how many (scene, tensor) pairs needed the scene's own noise floor, hip_closer_to_exact: in how many of those the HIP result
     is closer to exact arithmetic than the fp32 oracle, passed_through_exact_only: how many passed by their distance to the double evaluation
-    while further than the bar from the fp32 oracle}
+    while further than the bar from the fp32 oracle, scenes_beyond_the_oracle_route: scenes in which some tensor passed by the second
+    or third route of util.compare, routes: {route: tensors over 1e-4 that passed by it}}
     light_tiles: tgs_options_t::light_tiles for forward and backward (None: the entry points' default)"""
     import re
     rng = np.random.default_rng(seed)
     misses, worst, worst_txt, largest = 0, 0.0, "", {}
     over = closer = via_exact = 0
+    scenes_beyond, routes = 0, {}
     for it in range(n_scenes):
         desc, inp, dL = random_scene(rng, it)
         ref = util.oracle_run(inp, dL)
         mine = util.hip_run(inp, dL, light_tiles=light_tiles)
         try:
             rep = util.compare(mine, ref)
+            scenes_beyond += rep.get("routes_beyond_oracle", 0) > 0
+            for k, v in rep.items():
+                if k.endswith("|route"):
+                    routes[v] = routes.get(v, 0) + 1
             for k, v in rep.items():
                 if "|" in k:
                     continue
@@ -68,4 +74,5 @@ def run(seed: int, n_scenes: int, log=print, light_tiles=None) -> dict:
                 worst, worst_txt = val, txt
             log("MISS", txt)
     return dict(scenes=n_scenes, misses=misses, miss_rate=misses / max(n_scenes, 1), worst_rel_l2=worst, worst=worst_txt, seed=seed,
-                over_1e4=over, hip_closer_to_exact=closer, passed_through_exact_only=via_exact, largest_ok={k: float(f"{v:.3g}") for k, v in largest.items()})
+                over_1e4=over, hip_closer_to_exact=closer, passed_through_exact_only=via_exact,
+                scenes_beyond_the_oracle_route=scenes_beyond, routes=routes, largest_ok={k: float(f"{v:.3g}") for k, v in largest.items()})

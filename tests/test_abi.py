@@ -46,7 +46,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, f), f"libtgs_raster.so does not export {f}"
     lib.tgs_abi_version.restype = ctypes.c_int
     header_version = int(re.search(r"#define TGS_ABI_VERSION (\d+)", open(HEADER).read()).group(1))
-    assert lib.tgs_abi_version() == header_version == 2
+    assert lib.tgs_abi_version() == header_version == 3
 
 
 def test_bindings_check_abi_version_and_struct_sizes():
@@ -54,7 +54,7 @@ def test_bindings_check_abi_version_and_struct_sizes():
     both compare the ABI version and sizeof(tgs_view_t) / sizeof(tgs_options_t) with the library's at import."""
     import ctypes as C
     from diff_gaussian_rasterization import _C
-    assert _C.ABI_VERSION == 2 and _C._ext.abi_version() == 2 and _C._ext.compiled_abi_version() == 2
+    assert _C.ABI_VERSION == 3 and _C._ext.abi_version() == 3 and _C._ext.compiled_abi_version() == 3
     assert _C._lib.tgs_sizeof_view() == C.sizeof(_C._ViewT) == _C._ext.sizeof_view()
     assert _C._lib.tgs_sizeof_options() == C.sizeof(_C._OptionsT)
     o = _C.options(tile_bound=640, pruning=False, deterministic=True, sort_lds_cap=512)

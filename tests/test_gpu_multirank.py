@@ -83,6 +83,10 @@ if world > 1 or alone:
     dist.init_process_group(backend, timeout=datetime.timedelta(seconds=180), **kw)
 P, W, H, D, V = 7000, 208, 144, 2, 6
 cloud = scenes.make_cloud(P, D, seed=77, scale_mult=3.0)
+ACT = os.environ.get("TGS_ACTIVE_DEGREE")               # render below the stored degree and reduce the live SH rows only
+ACT = None if ACT is None else int(ACT)
+if ACT is not None:
+    D = ACT
 t = lambda a, rg=False: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev).requires_grad_(rg)
 names = ("means3D", "opacities", "scales", "rotations", "shs")
 L = {n: t(cloud[n], True) for n in names}
@@ -98,7 +102,7 @@ batch = SyncFreeBatch(granule=256, streams=2)
 pending, calls, n_handles = [], [], []
 def on_chunk(first, count):
     calls.append((first, count))
-    pending.extend(flat.all_reduce_rows(first, count, even_alone=alone))
+    pending.extend(flat.all_reduce_rows(first, count, even_alone=alone, sh_degree=ACT))
 res = {}
 for step in range(4):
     if step == 3 and rank == world - 1:
@@ -194,3 +198,27 @@ def test_range_wise_reduce_through_rccl_at_world_size_one(gpu_device, tmp_path):
         assert np.array_equal(plain[f"flat{step}"], rccl[f"flat{step}"]), step
         assert np.array_equal(plain[f"calls{step}"], rccl[f"calls{step}"]) and len(rccl[f"calls{step}"]) == 3
     assert int(rccl["rejected"]) >= 1
+
+
+@pytest.mark.timeout(700)
+@pytest.mark.parametrize("active", [0, 1])
+def test_live_sh_rows_reduce_through_rccl_and_two_ranks(gpu_device, tmp_path, active):
+    """SH stored for degree 2, the step rendered at degree 0 / 1 (the reference's sh_levels schedule): FlatGradients.all_reduce_rows(sh_degree=)
+    reduces the (D + 1)^2 live coefficients through staging slices.  Through RCCL at world size 1 the gradients equal the run without a
+    process group bit for bit (pack, sum over one rank, unpack = identity; dead coefficients stay exactly zero); two ranks over gloo end
+    with the unsharded step's gradients."""
+    env = dict(TGS_ACTIVE_DEGREE=str(active))
+    plain = _launch_workers(tmp_path, 1, "plain", env)[0]
+    rccl = _launch_workers(tmp_path, 1, "rccl", dict(env, TGS_BACKEND="nccl", TGS_EVEN_ALONE="1"))[0]
+    two = _launch_workers(tmp_path, 2, "w2", env)
+    assert list(rccl["handles"]) == [3, 3, 3, 3]
+    live = (active + 1) ** 2
+    for step in range(4):
+        want = plain[f"flat{step}"]
+        sh = want[-7000 * 27:].reshape(7000, 9, 3)          # the SH parameter is the last one of the flat buffer
+        assert np.abs(sh[:, :live]).max() > 0 and np.all(sh[:, live:] == 0)
+        assert np.array_equal(want, rccl[f"flat{step}"]), step
+        for r in range(2):
+            assert util.rel_l2(two[r][f"flat{step}"], want) <= 2e-6, (step, r)
+            assert np.all(two[r][f"flat{step}"][-7000 * 27:].reshape(7000, 9, 3)[:, live:] == 0)
+        assert np.array_equal(two[0][f"flat{step}"], two[1][f"flat{step}"])

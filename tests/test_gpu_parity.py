@@ -286,21 +286,27 @@ def test_random_small_scenes_vs_oracle(seed, gpu_device):
     print(seed, P, W, H, D, sm, {k: f"{v:.1e}" for k, v in rep.items() if k in ("color", "lists_equal", "instances_dropped", "n_contrib_equal")})
 
 
-@pytest.mark.parametrize("mode,seed", [("sh", 91), ("precomp", 92)])
+@pytest.mark.parametrize("mode,seed", [("sh", 91), ("precomp", 92), ("sh", "cfg1"), ("precomp", "cfg1")])
 def test_hip_vs_independent_fp64_autograd(mode, seed, gpu_device):
     """The HIP path against oracle/torch_splat.py -- a forward written from the textbook formulas (Sigma = R S^2 R^T, EWA projection,
     front-to-back compositing) and differentiated by autograd in float64, i.e. code that shares NOTHING with the reference-derived C
-    oracle or the emulated-reference fixtures -- at 6000 Gaussians / 256 x 256, both colour modes.  The bar is the plain 1e-4 on every
-    tensor, no relaxation: exact arithmetic is the yardstick here, and the fp32 paths sit 1e-6 .. 2e-5 from it on this scene."""
+    oracle or the emulated-reference fixtures -- at 6000 Gaussians / 256 x 256 / SH 3 and (round 5) at BASELINE configuration 1 exactly
+    (10 k Gaussians, 256 x 256, SH degree 0: scenes.config_scene(1)), both colour modes.  The bar is the plain 1e-4 on every
+    tensor, no relaxation: exact arithmetic is the yardstick here, and the fp32 paths sit 1e-6 .. 2e-5 from it on these scenes."""
     from oracle import torch_splat
     from youreditableavatar_amd import scenes
-    cloud = scenes.make_cloud(6000, 3, seed=seed, scale_mult=3.0)
-    cam = scenes.orbit_camera(256, 256, azimuth_deg=33.0)
-    dL = scenes.upstream_gradient(256, 256, seed=5)
+    if seed == "cfg1":
+        cloud, cams, dL = scenes.config_scene(1)
+        cam, name, min_r = cams[0], "cfg1_10k_256_sh0", 10_000
+    else:
+        cloud = scenes.make_cloud(6000, 3, seed=seed, scale_mult=3.0)
+        cam = scenes.orbit_camera(256, 256, azimuth_deg=33.0)
+        dL = scenes.upstream_gradient(256, 256, seed=5)
+        name, min_r = "6000_256", 40_000
     ref = torch_splat.run_scene(cloud, cam, dL, mode=mode)
     inp = util.scene_input(cloud, cam, mode)
     full = util.hip_run(inp, None, pruning=False)           # the reference's instance lists: n_contrib is comparable as a list position
-    assert int(full["num_rendered"]) == int(ref["num_rendered"]) > 40_000
+    assert int(full["num_rendered"]) == int(ref["num_rendered"]) > min_r
     assert np.array_equal(full["radii"], ref["radii"])
     assert (full["n_contrib"].astype(np.int64) == ref["n_contrib"]).mean() >= 0.999
     assert util.rel_l2(full["final_T"], ref["final_T"]) <= 1e-5
@@ -312,7 +318,7 @@ def test_hip_vs_independent_fp64_autograd(mode, seed, gpu_device):
     for a, b in pairs:
         rep[a] = util.rel_l2(mine[a], ref[b])
     rep["dL_dmeans2D"] = util.rel_l2(mine["dL_dmeans2D"][:, :2], ref["grad_means2D"][:, :2])
-    util.record_parity(f"fp64_autograd_{mode}_6000_256", rep)
+    util.record_parity(f"fp64_autograd_{mode}_{name}", rep)
     print(mode, {k: f"{v:.2e}" for k, v in rep.items()})
     for k, v in rep.items():
         assert v <= util.REL_TOL, (k, v)
@@ -329,6 +335,8 @@ def test_fuzz_vs_oracle_has_no_miss(gpu_device):
     util.record_parity("fuzz_128_scenes", res)
     print({k: v for k, v in res.items() if k != "largest_ok"})
     assert res["misses"] == 0, res
+    # the criterion is frozen (round 5): the routes beyond "within the bar of the fp32 oracle" stay the exception -- at most 2 % of the scenes
+    assert res["scenes_beyond_the_oracle_route"] <= 0.02 * res["scenes"], res
 
 
 @pytest.mark.parametrize("seed,scene,tensor,flipped,bound", [(23, 93, "dL_dconic", "f32_in", 2e-5), (37, 89, "dL_dconic", "f32_in", 5e-5)])

@@ -33,9 +33,9 @@ class OracleRasterize(torch.autograd.Function):
         return t(r["dL_dmeans3D"]), t(r["dL_dopacity"]), t(r["dL_dscales"]), t(r["dL_drotations"]), t(r["dL_dsh"]), None, None
 
 
-def _scene():
+def _scene(stored_degree=1):
     from youreditableavatar_amd import scenes
-    cloud = scenes.make_cloud(300, 1, seed=4, scale_mult=6.0)
+    cloud = scenes.make_cloud(300, stored_degree, seed=4, scale_mult=6.0)
     cams = [scenes.orbit_camera(48, 32, azimuth_deg=k * 60.0) for k in range(5)]     # 5 views: uneven shards on 2 ranks
     dLs = [scenes.upstream_gradient(48, 32, seed=100 + k) for k in range(5)]
     return cloud, cams, dLs
@@ -45,16 +45,17 @@ def _params(cloud):
     return [torch.tensor(cloud[k], requires_grad=True) for k in ("means3D", "opacities", "scales", "rotations", "shs")]
 
 
-def _step(rank, world, port, out_q):
+def _step(rank, world, port, out_q, stored_degree=1, active_degree=None):
     from youreditableavatar_amd import multiview
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     os.environ["OMP_NUM_THREADS"] = "1"
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    cloud, cams, dLs = _scene()
+    cloud, cams, dLs = _scene(stored_degree)
     params = _params(cloud)
     grads = multiview.FlatGradients(params)
-    mine = multiview.render_batch_sharded(lambda v: OracleRasterize.apply(*params, cams[v], cloud["sh_degree"]),
-                                          lambda v, img: torch.from_numpy(dLs[v]), len(cams), grads)
+    deg = cloud["sh_degree"] if active_degree is None else active_degree
+    mine = multiview.render_batch_sharded(lambda v: OracleRasterize.apply(*params, cams[v], deg),
+                                          lambda v, img: torch.from_numpy(dLs[v]), len(cams), grads, sh_degree=active_degree)
     out_q.put((rank, mine, grads.flat.clone().numpy()))
     dist.barrier()
     dist.destroy_process_group()
@@ -92,6 +93,38 @@ def test_sharded_step_equals_unsharded_sum():
     assert np.abs(ref).max() > 0
 
 
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("active", [0, 1])
+def test_sharded_step_with_live_sh_rows_only_equals_unsharded_sum(active):
+    """SH stored for degree 3, rendered at degree 0 / 1 (the reference's sh_levels schedule: refine_3dgs.py:165-166, paint_2dgs.py:61-63):
+    the step reduces the (D + 1)^2 live coefficients only and every rank still ends with the whole batch's gradient."""
+    from youreditableavatar_amd import multiview
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_step, args=(r, 2, port, q, 3, active)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(2)], key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    cloud, cams, dLs = _scene(3)
+    params = _params(cloud)
+    grads = multiview.FlatGradients(params)
+    multiview.render_batch_sharded(lambda v: OracleRasterize.apply(*params, cams[v], active),
+                                   lambda v, img: torch.from_numpy(dLs[v]), len(cams), grads, rank=0, world_size=1)
+    ref = grads.flat.numpy()
+    live = (active + 1) ** 2
+    gsh = params[4].grad.numpy()
+    assert np.abs(gsh[:, :live]).max() > 0 and np.all(gsh[:, live:] == 0)  # the premise: dead coefficients have exactly zero gradient
+    for _rank, _mine, flat in res:
+        assert np.allclose(flat, ref, rtol=1e-5, atol=1e-9)
+    assert np.array_equal(res[0][2], res[1][2])
+    assert grads.reduced_bytes(sh_degree=active) == 300 * 4 * (3 + 1 + 3 + 4 + 3 * live)
+    assert grads.reduced_bytes() == 300 * 4 * (3 + 1 + 3 + 4 + 48)
+
+
 def test_shard_views_partitions():
     from youreditableavatar_amd.multiview import shard_views
     for V, Wd in [(64, 8), (5, 2), (7, 8), (0, 4), (8, 8)]:
@@ -113,20 +146,26 @@ def test_flat_gradients_are_views():
     assert fg.all_reduce() is None          # no process group: no-op
 
 
-def _rows_step(rank, world, port, out_q):
+def _rows_step(rank, world, port, out_q, sh_degree=None):
     """every rank fills its flat buffer with rank-dependent values and reduces it range by range (FlatGradients.all_reduce_rows)"""
     from youreditableavatar_amd import multiview
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     P = 1000
     params = [torch.zeros(P, 3, requires_grad=True), torch.zeros(P, 1, requires_grad=True), torch.zeros(P, 16, 3, requires_grad=True)]
+    if sh_degree is not None:                            # the model's own two SH parameters as well (tetgs_model.py:234-239)
+        params += [torch.zeros(P, 1, 3, requires_grad=True), torch.zeros(P, 15, 3, requires_grad=True)]
     fg = multiview.FlatGradients(params)
     g = torch.Generator().manual_seed(7 + rank)
     fg.flat.copy_(torch.randn(fg.flat.numel(), generator=g))
+    if sh_degree is not None:                            # coefficients above the active degree have zero gradient on every rank
+        live = (sh_degree + 1) ** 2
+        params[2].grad[:, live:] = 0
+        params[4].grad[:, live - 1:] = 0
     mine = fg.flat.clone()
     works = []
     for first in range(0, P, 256):                       # ranges of 256 Gaussians, the last one ragged
-        works += fg.all_reduce_rows(first, min(256, P - first))
+        works += fg.all_reduce_rows(first, min(256, P - first), sh_degree=sh_degree)
     for w in works:
         w.wait()
     out_q.put((rank, mine.numpy(), fg.flat.clone().numpy()))
@@ -149,6 +188,31 @@ def test_all_reduce_by_gaussian_ranges_equals_one_all_reduce():
     total = res[0][1] + res[1][1]
     for _rank, _mine, reduced in res:
         assert np.array_equal(reduced, total)           # every element reduced exactly once
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+def test_all_reduce_of_live_sh_rows_by_ranges(deg):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rows_step, args=(r, 2, port, q, deg)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(2)], key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    total = res[0][1] + res[1][1]
+    for _rank, _mine, reduced in res:
+        assert np.array_equal(reduced, total)           # live coefficients summed exactly once, dead ones still zero
+
+
+def test_sh_live_rule():
+    from youreditableavatar_amd.multiview import FlatGradients as F
+    assert F._sh_live((10, 16, 3), 0) == 1 and F._sh_live((10, 16, 3), 1) == 4 and F._sh_live((10, 16, 3), 2) == 9 and F._sh_live((10, 16, 3), 3) is None
+    assert F._sh_live((10, 15, 3), 0) == 0 and F._sh_live((10, 15, 3), 1) == 3 and F._sh_live((10, 15, 3), 3) is None
+    assert F._sh_live((10, 1, 3), 0) is None and F._sh_live((10, 3), 0) is None and F._sh_live((10, 4), 0) is None and F._sh_live((10, 16, 3), None) is None
 
 
 def test_row_slices_cover_the_flat_buffer_once():

@@ -38,6 +38,6 @@ def test_wheel_provides_the_reference_import_names(tmp_path):
     env["PYTHONPATH"] = str(site)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path), env=env)
     assert r.returncode == 0, r.stderr[-2000:]
-    assert "('image_height', 'image_width') GaussianRasterizer True 2" in r.stdout
+    assert "('image_height', 'image_width') GaussianRasterizer True 3" in r.stdout
     for d in ("build", "youreditableavatar_amd.egg-info"):                            # pip's in-tree leftovers
         subprocess.run(["rm", "-rf", os.path.join(util.ROOT, d)])

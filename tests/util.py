@@ -85,7 +85,7 @@ def scene_input(cloud: dict, cam, mode: str = "sh", cov_mode: str = "scale_rot")
 
 def hip_run(inp: dict, dL: Optional[np.ndarray] = None, device="cuda:0", debug=False, introspect=True, pruning: Optional[bool] = None,
             deterministic: Optional[bool] = None, light_tiles: Optional[bool] = None, light_tiles_bwd: Optional[bool] = None,
-            backward_twice: bool = False, side_stream: Optional[bool] = None, sort_lds_cap: int = 0) -> Dict[str, np.ndarray]:
+            backward_twice: bool = False, sort_lds_cap: int = 0) -> Dict[str, np.ndarray]:
     """The HIP path through the reference's ``_C`` surface (the compiled module over the C ABI of include/tgs_raster.h).  ``pruning`` /
     ``deterministic`` / ``light_tiles``: explicit per-call options (tgs_options_t); None = the library defaults.  ``light_tiles_bwd``: another
     light-group option for the backward than the forward had; ``backward_twice``: back-propagate the same frame a second time (its result is
@@ -99,8 +99,7 @@ def hip_run(inp: dict, dL: Optional[np.ndarray] = None, device="cuda:0", debug=F
     H, W, D = int(inp["image_height"]), int(inp["image_width"]), int(inp["sh_degree"])
     sm, tfx, tfy = float(inp.get("scale_modifier", 1.0)), float(inp["tanfovx"]), float(inp["tanfovy"])
     R, color, radii, geom, binning, img = _C.rasterize_gaussians(bg, means3D, colors, opac, scales, rots, sm, cov, view, proj,
-                                                                 tfx, tfy, H, W, sh, D, campos, False, debug, pruning=pruning, light_tiles=light_tiles, sort_lds_cap=int(sort_lds_cap),
-                                                                 **({} if side_stream is None else {"side_stream": side_stream}))
+                                                                 tfx, tfy, H, W, sh, D, campos, False, debug, pruning=pruning, light_tiles=light_tiles, sort_lds_cap=int(sort_lds_cap))
     P = means3D.shape[0]
     out = dict(color=color.cpu().numpy(), radii=radii.cpu().numpy(), num_rendered=R)
     has_sh, has_sr = inp.get("shs") is not None, inp.get("scales") is not None
@@ -253,15 +252,25 @@ def reference_noise_of(ref: dict) -> dict:
     return ref["_noise"]
 
 
+BAR_CAP = 1e-3          # the bar never grows beyond this, however noisy the reference's own fp32 arithmetic is on a scene (round 5: frozen)
+ROUTES = ("oracle", "f64", "own_chain")
+
+
 def compare(mine: dict, ref: dict, golden_out: Optional[dict] = None, nc_frac: float = 0.999, check_lists: bool = True):
     """Asserts the parity bar; returns {tensor: rel_l2} for reporting.
 
-    The bar (round 4, no failure budget anywhere), for the colour and every gradient:  bar = max(1e-4, 2 x eta), eta = the reference
-    arithmetic's own distance from exact arithmetic on this very scene (reference_noise_of: the largest of five fp32 builds of the
-    oracle's C text against the same text compiled in double).  A tensor passes when rel_l2(HIP, fp32 oracle) <= bar -- or, where the fp32
-    oracle itself is the outlier among roundings, when rel_l2(HIP, the double evaluation) <= bar; which of the two applied is recorded
-    (`|vs_f64`).  For the four per-Gaussian tensors there is a third route (`|vs_own_chain`): within CHAIN_TOL of the reference's per-Gaussian
-    half evaluated in double on the product's own per-pixel gradients, which must pass the bar themselves.  Against a FIXTURE the bar is what the fixture recorded (tolerance())."""
+    The bar (FROZEN in round 5: no new routes, no new oracle builds), for the colour and every gradient:
+        bar = min(max(1e-4, 2 x eta), BAR_CAP = 1e-3)
+    eta = the reference arithmetic's own distance from exact arithmetic on this very scene (reference_noise_of: the largest of five fp32
+    builds of the oracle's C text against the same text compiled in double).  A tensor passes by ONE of three routes, recorded per tensor as
+    `<tensor>|route`:
+      "oracle"     rel_l2(HIP, fp32 oracle) <= bar                                   (every tensor at every BASELINE configuration: <= 1e-4)
+      "f64"        rel_l2(HIP, the double evaluation) <= bar -- the fp32 oracle is ONE rounding of the reference's function; a result within
+                   the bar of that function in exact arithmetic is as good a rounding of it as the bar allows the reference to be
+      "own_chain"  the four per-Gaussian tensors only: within CHAIN_TOL of the reference's per-Gaussian half evaluated in double on the
+                   product's own per-pixel gradients, which must pass the bar themselves
+    `routes_beyond_oracle` counts the tensors of the scene that needed the second or third route; the fuzz test holds a budget on the
+    scenes that do (tests/test_gpu_parity.py).  Against a FIXTURE the bar is what the fixture recorded (tolerance()): fixed, no routes."""
     H, W = ref["n_contrib"].shape
     rep = {}
     assert int(mine["num_rendered"]) <= int(ref["num_rendered"]), "more instances than the reference"   # exact relation: check_point_lists
@@ -279,12 +288,13 @@ def compare(mine: dict, ref: dict, golden_out: Optional[dict] = None, nc_frac: f
 
     def bar(k: str) -> float:
         if against_oracle:
-            return max(REL_TOL, 2.0 * reference_noise_of(ref).get(k, 0.0))
+            return min(max(REL_TOL, 2.0 * reference_noise_of(ref).get(k, 0.0)), BAR_CAP)
         return tolerance(k, golden_out)
 
     e = rel_l2(mine["color"], ref["color"]); rep["color"] = e
     assert e <= REL_TOL or e <= bar("color"), f"color rel-L2 {e:.3e}"
     keys = GRAD_KEYS + (("dL_dconic",) if against_oracle and "dL_dconic" in mine else ())
+    beyond = 0
     for k in keys:
         if k in mine and k in ref:
             a, b = np.asarray(mine[k]), np.asarray(ref[k])
@@ -293,14 +303,16 @@ def compare(mine: dict, ref: dict, golden_out: Optional[dict] = None, nc_frac: f
             if k == "dL_dconic":
                 a = a.reshape(-1, 4)
             e = rel_l2(a, b); rep[k] = e
-            if e > REL_TOL:                                  # only then is the scene's own noise floor needed (three more oracle runs)
+            if e > REL_TOL:                                  # only then is the scene's own noise floor needed (five more oracle runs)
                 tol = bar(k)
                 rep[k + "|bar"] = tol
                 if against_oracle:
-                    # the fp32 oracle is ONE rounding of the reference's function; a result that is within the bar of that function evaluated
-                    # in double is as good a rounding of it as the bar allows the reference itself to be
                     e64 = rep[k + "|vs_f64"] = rel_l2(a, ref["_f64"][k])
-                    if not (e <= tol or e64 <= tol) and k in PERGAUSS_KEYS:
+                    if e <= tol:
+                        route = "oracle"
+                    elif e64 <= tol:
+                        route = "f64"
+                    elif k in PERGAUSS_KEYS:
                         # Third route, per-Gaussian tensors only: dL_dmeans3D / dL_dcov3D / dL_dscales / dL_drotations are a function of the
                         # per-pixel pass's outputs (dL_dmeans2D, dL_dconic, dL_dcolors), and for splats several times wider than the image that
                         # function multiplies their fp32 noise by hundreds.  When those three pass the bar themselves (asserted in this loop) and
@@ -309,13 +321,18 @@ def compare(mine: dict, ref: dict, golden_out: Optional[dict] = None, nc_frac: f
                         ech = rep[k + "|vs_own_chain"] = rel_l2(a, own_chain(mine, ref)[k])
                         assert ech <= CHAIN_TOL, (f"{k}: rel-L2 to the fp32 oracle {e:.3e}, to exact arithmetic {e64:.3e} (bar {tol:.2e}) and to the per-Gaussian half "
                                                   f"in double on the product's own per-pixel gradients {ech:.3e} (bar {CHAIN_TOL:.0e})")
-                        continue
-                    assert e <= tol or e64 <= tol, (f"{k}: rel-L2 to the fp32 oracle {e:.3e} and to exact arithmetic {e64:.3e} both exceed {tol:.2e} = "
-                                                    "max(1e-4, 2 x the reference arithmetic's own distance from exact arithmetic)")
+                        route = "own_chain"
+                    else:
+                        raise AssertionError(f"{k}: rel-L2 to the fp32 oracle {e:.3e} and to exact arithmetic {e64:.3e} both exceed {tol:.2e} = "
+                                             "min(max(1e-4, 2 x the reference arithmetic's own distance from exact arithmetic), 1e-3)")
+                    rep[k + "|route"] = route
+                    beyond += route != "oracle"
                 else:
                     assert e <= tol, f"{k} rel-L2 {e:.3e} > {tol:.2e}"
-            if k != "dL_dconic":
+            if k != "dL_dconic":                             # (on every route)
                 assert np.all(a[~vis] == 0), f"{k}: culled Gaussians must have zero gradient"
+    if against_oracle:
+        rep["routes_beyond_oracle"] = beyond
     return rep
 
 

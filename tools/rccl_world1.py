@@ -31,11 +31,16 @@ for k in range(8):
 dL = g(scenes.upstream_gradient(W, H, seed=4321))
 batch = SyncFreeBatch(streams=4)
 pend = []
+S_full = S
+# the same views at active SH degree 0 (the inpainting stage, paint_2dgs.py:61-63: 16 800 of the reference's ~22 800 rasterizer iterations):
+# only the live coefficient of the stored [P,16,3] gradient is reduced -- 56 B per Gaussian instead of 236
+S_deg0 = [s._replace(sh_degree=0) for s in S]
+active = None
 
 
 def step(reduce, chunks=2):
     batch.run_views(S, L["means3D"], L["opacities"], L["shs"], L["scales"], L["rotations"], None, accumulate=False, upstream_view=lambda v, image: dL, grad_chunks=chunks,
-                    on_chunk=(lambda first, count: pend.extend(flat.all_reduce_rows(first, count, even_alone=True))) if reduce else (lambda f, c: None))
+                    on_chunk=(lambda first, count: pend.extend(flat.all_reduce_rows(first, count, even_alone=True, sh_degree=active))) if reduce else (lambda f, c: None))
     n = len(pend)
     for w in pend:
         w.wait()
@@ -70,8 +75,19 @@ ref = flat.flat.clone()
 step(True)
 torch.cuda.synchronize()
 same = bool(torch.equal(ref, flat.flat))
+# active degree 0: the live-row reduce
+S, active = S_deg0, 0
+d0_r, _ = timed(True, 10, 4)
+d0_n, _ = timed(False, 10, 2)
+ref0 = flat.flat.clone()
+step(True)
+torch.cuda.synchronize()
+same0 = bool(torch.equal(ref0, flat.flat))
+deg0 = {"ms_per_step_with_reduce": round(d0_r, 4), "ms_per_step_without": round(d0_n, 4), "bytes_reduced_per_step": flat.reduced_bytes(sh_degree=0),
+        "bytes_of_the_whole_buffer": flat.reduced_bytes(), "gradients_unchanged_by_the_one_rank_sum": same0}
+S, active = S_full, None
 print(json.dumps({"ms_per_step_with_reduce": round(ms_r, 4), "ms_per_step_without": round(ms_n, 4), "backend": str(dist.get_backend()), "collective_handles_per_step": handles,
-                  "gradients_unchanged_by_the_one_rank_sum": same, "frames_rerendered": batch.rejected,
+                  "gradients_unchanged_by_the_one_rank_sum": same, "frames_rerendered": batch.rejected, "active_sh_degree_0": deg0,
                   "ms_per_step_by_ranges": table, "rccl_cost_per_collective_us_at_world_1": per_collective_us,
                   "range_cutting_cost_frac": {"2": cut2, "4": round(table["4"]["without"] / table["1"]["without"] - 1.0, 4)},
                   "overhead_frac_of_the_default_two_ranges": round(table["2"]["with_reduce"] / table["1"]["without"] - 1.0, 4),

@@ -10,7 +10,6 @@
 
 namespace tgs {
 void launch_preprocess_fwd(hipStream_t, const FwdIn&, const CamParams&, const GeomState&, const ImgState&);
-void launch_sh_colors_deferred(hipStream_t, const FwdIn&, const CamParams&, const GeomState&, const ImgState&);
 void launch_preprocess_fwd_batch(hipStream_t, const FwdIn&, const FwdViews&);
 void launch_scan(hipStream_t, const GeomState&, const ImgState&, uint32_t nblocks, uint32_t T, uint32_t sort_cap, unsigned long long r_capacity,
                  uint32_t tile_bound, uint32_t heavy_bound, uint32_t mid_bound, Meta* host_meta, int light);
@@ -59,7 +58,6 @@ struct Opts {
     uint32_t sort_cap;
     int64_t tile_bound, heavy_bound, mid_bound;
     int light;
-    int side_stream;                                        // single-view forwards: SH colours on a side stream under the binning chain
 };
 static thread_local int64_t t_tile_bound = 0;               // tgs_set_tile_bound (test-only shim): default tile bound of this thread's calls without options
 // batch: the *_views entry points (several views in flight on several streams), where the light groups pay: +4 % on the 8-view step of
@@ -74,8 +72,6 @@ static Opts resolve_options(const tgs_options_t* o, bool batch = false)
     r.tile_bound = t_tile_bound; r.heavy_bound = 0; r.mid_bound = 0;
     static const int env_light = [] { const char* e = getenv("TGS_LIGHT_TILES"); return e ? atoi(e) : -1; }();     // A/B knob, read once
     r.light = env_light >= 0 ? (env_light ? 1 : 0) : (batch ? TGS_LIGHT_TILES_DEFAULT : 0);
-    static const int env_side = [] { const char* e = getenv("TGS_SIDE_STREAM"); return e ? atoi(e) : -1; }();        // A/B knob, read once
-    r.side_stream = env_side >= 0 ? (env_side ? 1 : 0) : 0;   // default OFF: measured slower (round 4, DESIGN.md section 4: 0.382 vs 0.368 ms per drop-in frame)
     if (!o) return r;
     const size_t n = o->struct_size;
 #define TGS_HAS(f) (n >= offsetof(tgs_options_t, f) + sizeof(o->f))
@@ -87,7 +83,6 @@ static Opts resolve_options(const tgs_options_t* o, bool batch = false)
     if (TGS_HAS(heavy_bound) && o->heavy_bound > 0) r.heavy_bound = o->heavy_bound;
     if (TGS_HAS(mid_bound) && o->mid_bound > 0) r.mid_bound = o->mid_bound;
     if (TGS_HAS(light_tiles) && o->light_tiles >= 0) r.light = o->light_tiles ? 1 : 0;
-    if (TGS_HAS(side_stream) && o->side_stream > 0) r.side_stream = o->side_stream == 1 ? 1 : 0;
 #undef TGS_HAS
     return r;
 }
@@ -273,22 +268,6 @@ static uint32_t bounded_mid(const Opts& o, size_t T)
     return (tb < (uint32_t)T && o.mid_bound > 0 && (uint64_t)o.mid_bound < tb) ? (uint32_t)o.mid_bound : tb;
 }
 
-// One library-owned non-blocking stream + two events per calling thread and device: the fork / join of the deferred SH colours
-// (k_sh_colors_deferred).  Created on first use, never destroyed (a handful per process).
-struct SideStream { int dev; hipStream_t st; hipEvent_t fork, join; };
-static SideStream* side_stream()
-{
-    static thread_local std::vector<SideStream> t_side;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    for (auto& x : t_side) if (x.dev == dev) return &x;
-    SideStream n; n.dev = dev;
-    if (hipStreamCreateWithFlags(&n.st, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&n.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&n.join, hipEventDisableTiming) != hipSuccess) return nullptr;
-    t_side.push_back(n);
-    return &t_side.back();
-}
-
 static int64_t forward_impl(const Opts& opt, Meta* host_meta, hipStream_t render_stream, tgs_frame_info_t* info, int preprocessed, int64_t r_capacity, int64_t* speculative_true_R, tgs_alloc_fn alloc, void* alloc_ctx, void* stream, int P, int D, int M, const float* background, int width,
                     int height, const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
                     const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
@@ -345,26 +324,15 @@ static int64_t forward_impl(const Opts& opt, Meta* host_meta, hipStream_t render
     FwdIn in;
     in.P = P; in.D = D; in.M = M; in.means3D = means3D; in.shs = shs; in.colors_precomp = colors_precomp; in.opacities = opacities;
     in.scales = scales; in.rotations = rotations; in.cov3D_precomp = cov3D_precomp; in.background = background;
-    in.prefiltered = prefiltered; in.out_color = out_color; in.radii = radii; in.prune = opt.prune; in.defer_colour = 0;
+    in.prefiltered = prefiltered; in.out_color = out_color; in.radii = radii; in.prune = opt.prune;
 
     uint64_t R = 0;
     Meta meta;
     memset(&meta, 0, sizeof(meta));
-    SideStream* side = nullptr;                             // non-NULL: the colours of this frame are in flight on the side stream
     if (!preprocessed) {
-        if (has_sh && M == 16 && opt.side_stream && !debug) side = side_stream();
-        in.defer_colour = side ? 1 : 0;
         STAGE_BEGIN(TGS_STAGE_PREPROCESS_FWD);
         launch_preprocess_fwd(st, in, cam, g, s);
         STAGE_CHECK("preprocess", TGS_STAGE_PREPROCESS_FWD);
-        if (side) {
-            // fork: the colour kernel starts behind the geometry kernel (it fills slots that kernel zeroed) and runs beside the binning
-            // chain; join: in front of the tile sort's gather (k_finalize), or at the end of a frame without instances
-            HIP_TRY(hipEventRecord(side->fork, st));
-            HIP_TRY(hipStreamWaitEvent(side->st, side->fork, 0));
-            launch_sh_colors_deferred(side->st, in, cam, g, s);
-            HIP_TRY(hipEventRecord(side->join, side->st));
-        }
     }
     SpecSlot* spec = nullptr;
     if (async && speculative_true_R) {
@@ -410,8 +378,6 @@ static int64_t forward_impl(const Opts& opt, Meta* host_meta, hipStream_t render
         launch_scatter(st, P, g, s, b, cam.gx, (uint32_t)T);
         STAGE_CHECK("scatter", TGS_STAGE_SCATTER);
     }
-    if (side) HIP_TRY(hipStreamWaitEvent(st, side->join, 0));   // the colours are in the pack lines before anything gathers them (and before this
-                                                                // call's buffers can be reused by later work on the caller's stream)
     if (R > 0) {
         STAGE_BEGIN(TGS_STAGE_TILE_SORT);
         launch_tile_sort(st, g, s, b, cam.gx, (uint32_t)T, R, known, sort_cap, tb, hb, mb);

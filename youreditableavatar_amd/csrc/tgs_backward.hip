@@ -533,9 +533,6 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
                 // every row adds for its own entries: lane (pixel i, slot e) takes components i, 4 + i (and 8 if i == 0) of entry j
                 const float s0 = pq == 0 ? v[0] : pq == 1 ? v[1] : pq == 2 ? v[2] : v[3];
                 const float s1 = pq == 0 ? v[4] : pq == 1 ? v[5] : pq == 2 ? v[6] : v[7];
-#ifdef TGS_EXP_NOATOM
-                asm volatile("" :: "v"(s0), "v"(s1), "v"(v[8]));
-#else
                 // rows whose list is shorter than the longest of the chunk idle on the null record: their sums are zero, and without this
                 // test all of them would add into the ONE spare column -- same-address LDS atomics serialise
                 if (j != (uint32_t)BNULL) {
@@ -543,7 +540,6 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
                     atomicAdd(&acc[4 + pq][j], (double)s1);
                     if (pq == 0) atomicAdd(&acc[8][j], (double)v[8]);
                 }
-#endif
             }
             }
         }
@@ -1336,9 +1332,6 @@ constexpr int SPLIT_G = PRE_BLOCK / 2;                      // Gaussians per wor
 #ifndef TGS_SPLIT_WAVES
 #define TGS_SPLIT_WAVES 3
 #endif
-#ifndef TGS_EXP_SKIP_HALF
-#define TGS_EXP_SKIP_HALF 0            // timing experiments only: 1 = the colour half walks no view, 2 = the geometry half walks none (WRONG gradients)
-#endif
 template <bool HAS_SCALE_ROT>
 __global__ __launch_bounds__(PRE_BLOCK, TGS_SPLIT_WAVES) void k_preprocess_bwd_batch_split(const BwdIn in, const BatchViews views)
 {
@@ -1431,7 +1424,7 @@ __global__ __launch_bounds__(PRE_BLOCK, TGS_SPLIT_WAVES) void k_preprocess_bwd_b
                 nq0 = row[0]; nq1 = row[(size_t)min(1u, last) * SLAB_ROW]; nq2 = row[(size_t)min(2u, last) * SLAB_ROW]; nq3 = row[(size_t)min(3u, last) * SLAB_ROW];
             }
         };
-        const int nv = TGS_EXP_SKIP_HALF == 1 ? 0 : views.n;
+        const int nv = views.n;
         if (nv > 0) ask(0);
 #pragma unroll 1
         for (int v = 0; v < nv; v++) {
@@ -1463,7 +1456,7 @@ __global__ __launch_bounds__(PRE_BLOCK, TGS_SPLIT_WAVES) void k_preprocess_bwd_b
         float dopacity = 0.f, dmean[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dscale[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
         double dcsum[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll 1
-        for (int v = 0; v < (TGS_EXP_SKIP_HALF == 2 ? 0 : views.n); v++) {
+        for (int v = 0; v < views.n; v++) {
             const BatchView& vw = views.v[v];
             const bool live = in_range && (int)pv_lds[v][0][gl] > 0;
             GaussTerms t;
@@ -1568,8 +1561,7 @@ void launch_preprocess_bwd_batch(hipStream_t st, const BwdIn& in, const BatchVie
 {
     const dim3 grid((unsigned)(in.nblocks > 0 ? in.nblocks : n_blocks(in.P))), blk(PRE_BLOCK);
     const bool sh = in.shs != nullptr, sr = in.scales != nullptr;
-    static const bool split = [] { const char* e = getenv("TGS_SPLIT_PASS"); return !e || atoi(e) != 0; }();    // (TGS_SPLIT_PASS=0: the one-thread kernel, for A/B runs)
-    if (sh && in.M == 16 && split) {                        // two threads per Gaussian: 128 Gaussians per workgroup
+    if (sh && in.M == 16) {                                 // two threads per Gaussian: 128 Gaussians per workgroup (the one-thread kernel below: per-view colours, other M)
         const dim3 grid2(2 * grid.x);
         if (sr) hipLaunchKernelGGL((k_preprocess_bwd_batch_split<true>), grid2, blk, 0, st, in, views);
         else hipLaunchKernelGGL((k_preprocess_bwd_batch_split<false>), grid2, blk, 0, st, in, views);

@@ -241,7 +241,7 @@ __device__ __forceinline__ uint32_t preprocess_fwd_one(const FwdIn& in, int* __r
                     } else if (in.colors_precomp) {
                         col0 = in.colors_precomp[3 * (size_t)idx]; col1 = in.colors_precomp[3 * (size_t)idx + 1]; col2 = in.colors_precomp[3 * (size_t)idx + 2];
                     } else {
-                        col0 = col1 = col2 = 0.f;              // FwdIn::defer_colour: k_sh_colors_deferred fills the slots (and g.clamped) behind this kernel
+                        col0 = col1 = col2 = 0.f;
                     }
                     g.depth[idx] = view_z;
                     my_radius_i = (int)my_radius;
@@ -377,27 +377,6 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd(const FwdIn in, co
     bool bad = false;
     const uint32_t tiles = preprocess_fwd_one<HAS_SH, HAS_SCALE_ROT>(in, vw.radii, vw.cam, vw.g, vw.s, sh_lds, false, idx, gi, pre[0], bad);
     block_sum_tiles(tiles, bad, vw.g, vw.s);
-}
-
-// The SH colours of ONE view apart from its geometry (single-view forwards, tgs_api.hip: forward_impl).  preprocessCUDA reads 236 B per
-// Gaussian of which 192 are the SH row, needed by nothing before k_finalize -- while the binning chain behind the per-Gaussian stage
-// (k_bin_count -> k_bin_colscan -> k_scan -> k_scatter, ~55 us at config 3) keeps at most 128 workgroups on a 256-CU chip.  So the
-// per-Gaussian stage runs without the rows (k_preprocess_fwd<false, .> with FwdIn::defer_colour) and this kernel evaluates the colours
-// on a library-owned side stream BEHIND it and UNDER the chain: it stores 12 B into each pack line (slots r, g, b, which the geometry
-// kernel left at zero -- hence behind it) and the clamp bits; k_finalize waits for it.  Same arithmetic, same bits (sh_to_color).
-__global__ __launch_bounds__(PRE_BLOCK) void k_sh_colors_deferred(const FwdIn in, const FwdView vw)
-{
-    const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
-    __shared__ float4 sh_lds[SH_HALF * 12];
-    PreColor pre[1];
-    const GaussIn gi = load_gauss_in<false>(in, idx);
-    sh_colors_half_staged<1>(in, &vw, idx, gi, sh_lds, pre);   // (a Gaussian behind the near plane keeps colour 0: its pack line is never read)
-    if (idx < in.P) {
-        float* pk = reinterpret_cast<float*>(vw.g.pack + 4 * (size_t)idx);
-        *reinterpret_cast<float2*>(pk + 6) = make_float2(pre[0].c0, pre[0].c1);     // pack[4 idx + 1].zw
-        pk[8] = pre[0].c2;                                                          // pack[4 idx + 2].x
-        vw.g.clamped[idx] = (uint8_t)pre[0].clampbits;
-    }
 }
 
 // Two views of a batch in one launch (tgs_forward_views, the default group): the 192-B SH row -- more than half of what the stage
@@ -902,9 +881,6 @@ __device__ __forceinline__ void ovf_global(const ImgState& s, const BinState& b,
     cmp_swap(b.keys + rg.x, i, l, n);
 }
 
-#ifndef TGS_FUSED_FINALIZE
-#define TGS_FUSED_FINALIZE 0          // measured (round 4, A/B by library): the fused form saves 2 us per frame alone on the GPU and LOSES 1-2 % of the 8-view step
-#endif
 __device__ __forceinline__ void finalize_entry(float4 p0, float4 p1, float4 p2, float4 p3, uint32_t pos, uint32_t tile, uint32_t gx, const BinState& b)
 {
     const uint32_t rmin = __float_as_uint(p2.y), rmax = __float_as_uint(p2.z);
@@ -923,29 +899,6 @@ __device__ __forceinline__ void finalize_entry(float4 p0, float4 p1, float4 p2, 
         ord = (uint32_t)__builtin_popcountll(live & ((1ull << k) - 1ull));
     }
     b.slot[pos] = __float_as_uint(p2.w) + ord;
-}
-
-// Round 4 experiment (-DTGS_FUSED_FINALIZE=1; the review of round 3 asked for it): the gather behind the sort (k_finalize) runs in the sorting
-// workgroup itself, on the keys it still holds in LDS / registers: the sorted keys are stored once and never read back, the tile is known (no
-// tile_of array), one launch + its boundary are gone.  Parity-green (GPU suite), and measured: sort + gather 48.2 us as one kernel against
-// 26.3 + 24.2 + a boundary as two with the GPU to itself (drop-in frame 0.366 either way), but 1-2 % SLOWER on the 8-view step (0.2459 vs
-// 0.2405 ms per frame, twice): the 1024-thread sorting workgroups are a worse home for a latency-bound gather than 256-thread ones spread
-// evenly over all instances, and with four streams sharing the GPU the separate gather kernel fills the sort's tail.  Default off.  NT threads share a list; two entries per thread and step so that two
-// 64-B line gathers are in flight per lane.  key_at(i): sorted key i of the list; start: the list's first position in the binning buffer.
-template <int NT, typename KeyAt>
-__device__ __forceinline__ void finalize_list(const GeomState& g, const BinState& b, KeyAt key_at, uint32_t start, uint32_t n, uint32_t tile, uint32_t gx, uint32_t tid)
-{
-    for (uint32_t i = tid; i < n; i += 2 * NT) {
-        const uint32_t i1 = i + NT;
-        const bool two = i1 < n;
-        const uint32_t id0 = (uint32_t)key_at(i), id1 = two ? (uint32_t)key_at(i1) : id0;
-        const float4* pa = g.pack + 4 * (size_t)id0;
-        const float4* pb = g.pack + 4 * (size_t)id1;
-        const float4 a0 = pa[0], a1 = pa[1], a2 = pa[2], a3 = pa[3];
-        const float4 c0 = pb[0], c1 = pb[1], c2 = pb[2], c3 = pb[3];
-        finalize_entry(a0, a1, a2, a3, start + i, tile, gx, b);
-        if (two) finalize_entry(c0, c1, c2, c3, start + i1, tile, gx, b);
-    }
 }
 
 __device__ __forceinline__ void ovf_worker(const GeomState& g, const ImgState& s, const BinState& b, unsigned long long* lk, uint32_t w, uint32_t nw, uint32_t cap, uint32_t gx)
@@ -968,9 +921,6 @@ __device__ __forceinline__ void ovf_worker(const GeomState& g, const ImgState& s
             for (uint32_t blk = 0; blk < bpt; blk++) ovf_local(s, b, lk, ot, blk, k, cap);
         }
         ovf_wg_sync();
-#if TGS_FUSED_FINALIZE
-        finalize_list<OVF_THREADS>(g, b, [&](uint32_t i) { return b.keys[rg.x + i]; }, rg.x, rg.y - rg.x, s.ovf_tiles[ot], gx, threadIdx.x);   // (sorted in global memory)
-#endif
     }
 }
 
@@ -992,9 +942,7 @@ __global__ __launch_bounds__(1024) void k_tile_sort(const GeomState g, const Img
         if (t >= n_heavy) return;
         const uint4 td = s.tile_desc[t];
         const uint32_t n = td.z - td.y;
-#if !TGS_FUSED_FINALIZE
         for (uint32_t i = threadIdx.x; i < n; i += 1024) b.tile_of[td.y + i] = td.x;
-#endif
         if (n > sort_cap) return;                           // (longer lists: the overflow workers -- they sort AND finalize them)
         for (uint32_t i = threadIdx.x; i < n; i += 1024) lk[i] = b.keys[td.y + i];
         __syncthreads();
@@ -1002,18 +950,13 @@ __global__ __launch_bounds__(1024) void k_tile_sort(const GeomState g, const Img
             sort_tile_lds<1024>(lk, threadIdx.x, n, next_pow2(n));
             for (uint32_t i = threadIdx.x; i < n; i += 1024) b.keys[td.y + i] = lk[i];
         }
-#if TGS_FUSED_FINALIZE
-        finalize_list<1024>(g, b, [&](uint32_t i) { return lk[i]; }, td.y, n, td.x, gx, threadIdx.x);
-#endif
     } else if (blockIdx.x < heavy_blocks + mid_blocks) {
         const uint32_t grp = threadIdx.x >> 8, tid = threadIdx.x & 255u;
         const uint32_t t = n_heavy + (blockIdx.x - heavy_blocks) * 4 + grp;
         if (n_heavy + (blockIdx.x - heavy_blocks) * 4 >= n_mid) return;          // the whole workgroup is behind the class
         uint32_t n = 0, start = 0, tile = 0;
         if (t < n_mid) { const uint4 td = s.tile_desc[t]; tile = td.x; start = td.y; n = td.z - td.y; }
-#if !TGS_FUSED_FINALIZE
         for (uint32_t i = tid; i < n; i += 256) b.tile_of[start + i] = tile;
-#endif
         if (n > 1024u || n > sort_cap) n = 0;               // (a list beyond sort_cap belongs to the overflow workers; n > 1024 cannot happen by the class boundary)
         unsigned long long* seg = lk + grp * 1024;
         for (uint32_t i = tid; i < n; i += 256) seg[i] = b.keys[start + i];
@@ -1022,41 +965,19 @@ __global__ __launch_bounds__(1024) void k_tile_sort(const GeomState g, const Img
         const uint32_t npad_wg = max(max(grp_npad[0], grp_npad[1]), max(grp_npad[2], grp_npad[3]));
         sort_tile_lds<256>(seg, tid, n, npad_wg);
         for (uint32_t i = tid; i < n; i += 256) b.keys[start + i] = seg[i];
-#if TGS_FUSED_FINALIZE
-        finalize_list<256>(g, b, [&](uint32_t i) { return seg[i]; }, start, n, tile, gx, tid);
-#endif
     } else {
         const uint32_t t = n_mid + (blockIdx.x - heavy_blocks - mid_blocks) * 16 + wv;
         if (t >= n_nonempty) return;                        // wave-uniform: no workgroup barrier below
         const uint4 td = s.tile_desc[t];
         const uint32_t n = td.z - td.y;
-#if !TGS_FUSED_FINALIZE
         for (uint32_t i = lane; i < n; i += 64) b.tile_of[td.y + i] = td.x;
         if (n < 2 || n > sort_cap || n > SORT_CHUNK) return;    // (n < 128 by the class boundary in k_scan)
-#else
-        if (n > sort_cap || n > SORT_CHUNK) return;             // (beyond sort_cap: the overflow workers; n < 128 by the class boundary in k_scan)
-#endif
         unsigned long long k0, k1;                          // global memory -> registers -> global memory: no LDS
         regs_load_chunk(b.keys + td.y, 0u, n, lane, k0, k1);
         if (n >= 2) {
             regs_sort128(k0, k1, lane);
             regs_store_chunk(b.keys + td.y, 0u, n, lane, k0, k1);
         }
-#if TGS_FUSED_FINALIZE
-        {   // lane l holds sorted entries 2 l and 2 l + 1
-            const uint32_t e0 = 2u * lane, e1 = e0 + 1u;
-            const bool h0 = e0 < n, h1 = e1 < n;
-            const uint32_t id0 = h0 ? (uint32_t)k0 : 0u, id1 = h1 ? (uint32_t)k1 : id0;
-            if (h0) {
-                const float4* pa = g.pack + 4 * (size_t)id0;
-                const float4* pb = g.pack + 4 * (size_t)id1;
-                const float4 a0 = pa[0], a1 = pa[1], a2 = pa[2], a3 = pa[3];
-                const float4 c0 = pb[0], c1 = pb[1], c2 = pb[2], c3 = pb[3];
-                finalize_entry(a0, a1, a2, a3, td.y + e0, td.x, gx, b);
-                if (h1) finalize_entry(c0, c1, c2, c3, td.y + e1, td.x, gx, b);
-            }
-        }
-#endif
     }
 }
 
@@ -1144,17 +1065,11 @@ constexpr int FQ_NULL = FQ_CH;
 
 // one block, one staged round: this wave's pass over the entries of the round that reach its block (forward.cu:325-362
 // semantics: the kernel's header).  Returns true when the block's last live pixel ended.
-#ifndef TGS_FWD_LEAN_MASKS
-#define TGS_FWD_LEAN_MASKS 0
-#endif
 __device__ __forceinline__ bool fwd_q_block_round(const float4* sA, const float4* sB, const float* sC, const uint2* sQ, unsigned short* list,
                                                   unsigned short (*ql)[QL_ROW_F], uint32_t cnt, int blk, int lane, uint32_t cbase, float pixfx, float pixfy,
                                                   float vone, const QuadMasks& qm, bool& done, float& T, float& C0, float& C1, float& C2, uint32_t& last_contributor)
 {
     const int qd = lane >> 4, e = lane & 3;
-#if TGS_FWD_LEAN_MASKS
-    float nd = done ? 0.0f : 1.0f;
-#endif
     // (both counts are wave-uniform -- sums of ballot popcounts -- but reach the loops in VGPRs: readfirstlane makes the loop tests scalar
     // compares instead of lane-mask algebra on the exec mask, 7 scalar instructions per pass less)
     const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)build_own_list_q<FQ_CH>(list, sQ, cnt, blk, lane));
@@ -1176,30 +1091,6 @@ __device__ __forceinline__ bool fwd_q_block_round(const float4* sA, const float4
             const float power2 = -0.5f * (a.z * dx * dx + bb.x * dy * dy) - a.w * dx * dy;
             const float alpha = fminf(0.99f, bb.y * expf(power2));
 #endif
-#if TGS_FWD_LEAN_MASKS
-            // The same decisions with the lane masks kept out of the scalar unit (round 4).  `nd` = 1.0 while the pixel is open, 0.0 once it
-            // is done; a done pixel, a power > 0 and an alpha below 1/255 all end as a3 = 0 (-> 1 - a3 = 1.0 exactly, w = 0).  The
-            // termination test needs no `live &&`: T never falls below 1e-4 while a pixel is open (it closes on the first entry that would
-            // take it there), so x < 1e-4 can only be a live entry or a lane behind one in the same group -- whose y is smaller, and the
-            // quad maximum picks the first.  Every select reads the compare in front of it (vcc): no s_and / s_or / s_xor on 64-bit masks.
-            float al = alpha * nd;
-            al = (power2 > 0.0f) ? 0.0f : al;
-            const float a3 = (al < 1.0f / 255.0f) ? 0.0f : al;
-            const float pown = 1.0f - a3;
-            float y, x, x3;
-            fwd_chain4(pown, T, y, x, vone, qm);
-            const bool fail = x < 0.0001f;
-            float cand = fail ? y : -1.0f;
-            const float wy = a3 * y;
-            const float w = fail ? 0.0f : wy;
-            quad_max_bcast3(cand, x, x3);
-            C0 += bb.z * w; C1 += bb.w * w; C2 += cc * w;
-            last_contributor = (w > 0.0f) ? cbase + j : last_contributor;
-            const bool stop = cand >= 0.0f;
-            T = stop ? cand : x3;
-            nd = stop ? 0.0f : nd;
-            if (__builtin_amdgcn_ballot_w64(nd != 0.0f) == 0) { done = true; return true; }
-#else
             const bool live = !done && !(power2 > 0.0f) && !(alpha < 1.0f / 255.0f);
             const float pown = live ? 1.f - alpha : 1.0f;
             float y, x, x3;
@@ -1215,12 +1106,8 @@ __device__ __forceinline__ bool fwd_q_block_round(const float4* sA, const float4
             T = stop ? cand : x3;
             done = done || stop;
             if (__builtin_amdgcn_ballot_w64(!done) == 0) return true;
-#endif
         }
     }
-#if TGS_FWD_LEAN_MASKS
-    done = nd == 0.0f;
-#endif
     return false;
 }
 
@@ -1407,19 +1294,13 @@ __global__ __launch_bounds__(256) void k_mark_visible(int P, const float* __rest
 void launch_preprocess_fwd(hipStream_t st, const FwdIn& in, const CamParams& cam, const GeomState& g, const ImgState& s)
 {
     const dim3 grid((unsigned)n_blocks(in.P)), blk(PRE_BLOCK);
-    const bool sh = in.colors_precomp == nullptr && !in.defer_colour, sr = in.cov3D_precomp == nullptr;
+    const bool sh = in.colors_precomp == nullptr, sr = in.cov3D_precomp == nullptr;
     FwdView vw;
     vw.cam = cam; vw.g = g; vw.s = s; vw.radii = in.radii;
     if (sh && sr) hipLaunchKernelGGL((k_preprocess_fwd<true, true>), grid, blk, 0, st, in, vw);
     else if (sh) hipLaunchKernelGGL((k_preprocess_fwd<true, false>), grid, blk, 0, st, in, vw);
     else if (sr) hipLaunchKernelGGL((k_preprocess_fwd<false, true>), grid, blk, 0, st, in, vw);
     else hipLaunchKernelGGL((k_preprocess_fwd<false, false>), grid, blk, 0, st, in, vw);
-}
-void launch_sh_colors_deferred(hipStream_t st, const FwdIn& in, const CamParams& cam, const GeomState& g, const ImgState& s)
-{
-    FwdView vw;
-    vw.cam = cam; vw.g = g; vw.s = s; vw.radii = in.radii;
-    hipLaunchKernelGGL(k_sh_colors_deferred, dim3((unsigned)n_blocks(in.P)), dim3(PRE_BLOCK), 0, st, in, vw);
 }
 void launch_preprocess_fwd_batch(hipStream_t st, const FwdIn& in, const FwdViews& views)
 {
@@ -1508,9 +1389,7 @@ void launch_tile_sort(hipStream_t st, const GeomState& g, const ImgState& s, con
             hipLaunchKernelGGL(k_tile_sort, dim3(heavy + mid_blocks + small_blocks + ovf_blocks), dim3(1024), bytes, st, g, s, b, gx, sort_cap, heavy, mid_blocks,
                                small_blocks, ovf_blocks);
     }
-#if !TGS_FUSED_FINALIZE
     if (r_bound > 0) hipLaunchKernelGGL(k_finalize, dim3((unsigned)((r_bound + 256 * FIN_E - 1) / (256 * FIN_E))), dim3(256), 0, st, g, s, b, gx, T);
-#endif
 }
 // mid_bound (sync-free, with a tile bound): upper bound on the tiles with >= LIGHT_MAX instances (k_scan rejects a frame with more)
 void launch_render_fwd(hipStream_t st, const ImgState& s, const BinState& b, int W, int H, uint32_t gx, uint32_t T, const Meta* m,

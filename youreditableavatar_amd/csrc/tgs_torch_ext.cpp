@@ -61,7 +61,7 @@ int sh_coeffs(const torch::Tensor& sh) { return (sh.dim() > 1 && sh.size(0) != 0
 
 // keyword-only extensions -> tgs_options_t (None / 0 = library defaults)
 tgs_options_t make_options(int64_t tile_bound, c10::optional<bool> pruning, c10::optional<bool> deterministic, int64_t sort_lds_cap, int64_t mid_bound,
-                           c10::optional<bool> light_tiles, c10::optional<bool> side_stream = c10::nullopt)
+                           c10::optional<bool> light_tiles)
 {
     tgs_options_t o;
     memset(&o, 0, sizeof(o));
@@ -72,7 +72,6 @@ tgs_options_t make_options(int64_t tile_bound, c10::optional<bool> pruning, c10:
     o.tile_bound = tile_bound > 0 ? tile_bound : 0;
     o.mid_bound = mid_bound > 0 ? mid_bound : 0;
     o.light_tiles = light_tiles ? (*light_tiles ? 1 : 0) : -1;
-    o.side_stream = side_stream ? (*side_stream ? 1 : 2) : 0;
     return o;
 }
 
@@ -85,7 +84,7 @@ py::tuple rasterize_gaussians(const torch::Tensor& background, const torch::Tens
                               const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix, float tan_fovx, float tan_fovy, int image_height,
                               int image_width, const torch::Tensor& sh, int degree, const torch::Tensor& campos, bool prefiltered, bool debug,
                               c10::optional<int64_t> r_capacity, c10::optional<int64_t> r_guess, int64_t tile_bound, c10::optional<bool> pruning,
-                              int64_t sort_lds_cap, bool info, int64_t mid_bound, c10::optional<bool> light_tiles, c10::optional<bool> side_stream)
+                              int64_t sort_lds_cap, bool info, int64_t mid_bound, c10::optional<bool> light_tiles)
 {
     if (means3D.dim() != 2 || means3D.size(1) != 3) throw std::runtime_error("means3D must have dimensions (num_points, 3)");   // rasterize_points.cu:57-59
     const c10::Device dev = require_gpu(means3D);
@@ -100,7 +99,7 @@ py::tuple rasterize_gaussians(const torch::Tensor& background, const torch::Tens
         sc(scales, dev, "scales"), rot(rotations, dev, "rotations"), cov(cov3D_precomp, dev, "cov3D_precomp"), view(viewmatrix, dev, "viewmatrix"),
         proj(projmatrix, dev, "projmatrix"), shs(sh, dev, "sh"), cam(campos, dev, "campos");
     void* stream = (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream();
-    const tgs_options_t opt = make_options(tile_bound, pruning, c10::nullopt, sort_lds_cap, mid_bound, light_tiles, side_stream);
+    const tgs_options_t opt = make_options(tile_bound, pruning, c10::nullopt, sort_lds_cap, mid_bound, light_tiles);
     tgs_frame_info_t fi;
     const int mode = r_guess ? TGS_FWD_SPECULATIVE : (r_capacity ? TGS_FWD_ASYNC : TGS_FWD_SYNC);
     int64_t r;
@@ -182,7 +181,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
           py::arg("rotations"), py::arg("scale_modifier"), py::arg("cov3D_precomp"), py::arg("viewmatrix"), py::arg("projmatrix"), py::arg("tan_fovx"),
           py::arg("tan_fovy"), py::arg("image_height"), py::arg("image_width"), py::arg("sh"), py::arg("degree"), py::arg("campos"), py::arg("prefiltered"),
           py::arg("debug"), py::arg("r_capacity") = py::none(), py::arg("r_guess") = py::none(), py::arg("tile_bound") = 0, py::arg("pruning") = py::none(),
-          py::arg("sort_lds_cap") = 0, py::arg("info") = false, py::arg("mid_bound") = 0, py::arg("light_tiles") = py::none(), py::arg("side_stream") = py::none());
+          py::arg("sort_lds_cap") = 0, py::arg("info") = false, py::arg("mid_bound") = 0, py::arg("light_tiles") = py::none());
     m.def("rasterize_gaussians_backward", &rasterize_gaussians_backward, py::arg("background"), py::arg("means3D"), py::arg("radii"), py::arg("colors"),
           py::arg("scales"), py::arg("rotations"), py::arg("scale_modifier"), py::arg("cov3D_precomp"), py::arg("viewmatrix"), py::arg("projmatrix"),
           py::arg("tan_fovx"), py::arg("tan_fovy"), py::arg("dL_dout_color"), py::arg("sh"), py::arg("degree"), py::arg("campos"), py::arg("geomBuffer"),

@@ -21,7 +21,7 @@ from .. import build as _build
 _LIB_PATH = os.environ.get("TGS_LIBRARY") or _build.LIB       # TGS_LIBRARY: another build of the same ABI (A/B measurements on one box)
 
 
-ABI_VERSION = 2                # TGS_ABI_VERSION of include/tgs_raster.h this binding is written against
+ABI_VERSION = 3                # TGS_ABI_VERSION of include/tgs_raster.h this binding is written against
 
 
 def _load() -> C.CDLL:
@@ -189,7 +189,7 @@ class _OptionsT(C.Structure):
     """tgs_options_t (include/tgs_raster.h): everything that tunes one call, passed explicitly -- nothing process-wide is touched"""
     _fields_ = [("struct_size", C.c_uint32), ("instance_pruning", C.c_int32), ("deterministic", C.c_int32), ("forward_group", C.c_int32),
                 ("sort_lds_cap", C.c_uint32), ("tile_bound", C.c_int64), ("heavy_bound", C.c_int64), ("mid_bound", C.c_int64),
-                ("light_tiles", C.c_int32), ("side_stream", C.c_int32)]
+                ("light_tiles", C.c_int32)]
 
 
 class _FrameInfoT(C.Structure):

@@ -55,9 +55,17 @@ class FlatGradients:
     def zero_(self) -> None:
         self.flat.zero_()
 
-    def all_reduce(self, group=None, async_op: bool = False):
-        """Sum over ranks (no-op without an initialised process group or with world size 1)."""
+    def all_reduce(self, group=None, async_op: bool = False, sh_degree: Optional[int] = None):
+        """Sum over ranks (no-op without an initialised process group or with world size 1).  ``sh_degree``: the step's active SH degree --
+        SH parameters stored for a higher one are reduced over their live coefficients only (all_reduce_rows)."""
         if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+            return None
+        if sh_degree is not None and any(self._sh_live(p.shape, sh_degree) is not None for p in self.params):
+            works = self.all_reduce_rows(0, int(self.params[0].shape[0]), group=group, sh_degree=sh_degree)
+            if async_op:
+                return works[0] if len(works) == 1 else _PackedReduce(works, [])
+            for w in works:
+                w.wait()
             return None
         return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
 
@@ -71,11 +79,49 @@ class FlatGradients:
             off += p.numel()
         return out
 
-    def all_reduce_rows(self, first: int, count: int, group=None, even_alone: bool = False):
+    # ---- live SH rows ------------------------------------------------------------------------------------------------------------
+    # 192 of the 236 B a Gaussian's gradients take on the SH path are dL_dsh, and the reference trains most of its iterations below the
+    # stored degree: the refine stage raises `sh_levels` step by step (refine_3dgs.py:165-166), the inpainting stage stays at one level
+    # (paint_2dgs.py:61-63).  Coefficients above the active degree get exactly zero gradient on every rank (backward.cu:20-139 writes
+    # only the active ones), so their sum over ranks is known without moving a byte: only the (D + 1)^2 live coefficients of each SH
+    # parameter are reduced -- packed into a contiguous staging slice, reduced, unpacked on wait().
+    @staticmethod
+    def _sh_live(shape, sh_degree: Optional[int]) -> Optional[int]:
+        """Live leading entries of dim 1 of a parameter [P, M, 3] at the active SH degree: a full coefficient tensor (M a square:
+        tetgs_model.py:268-272's `sh_coordinates`) keeps (D + 1)^2, a "rest" tensor (M + 1 a square: `_sh_coordinates_rest`, :234-239)
+        keeps (D + 1)^2 - 1; None: not an SH parameter / every entry is live."""
+        if sh_degree is None or len(shape) != 3 or int(shape[2]) != 3:
+            return None
+        M, n = int(shape[1]), (int(sh_degree) + 1) ** 2
+        r = int(round(M ** 0.5))
+        if r * r == M:
+            return None if n >= M else n
+        r1 = int(round((M + 1) ** 0.5))
+        if r1 * r1 == M + 1:
+            return None if n - 1 >= M else n - 1
+        return None
+
+    def reduced_bytes(self, count: Optional[int] = None, sh_degree: Optional[int] = None) -> int:
+        """Bytes per rank that all_reduce_rows(first, count, sh_degree=...) hands to the collective (count None: all Gaussians)."""
+        total = 0
+        for p in self.params:
+            P = max(int(p.shape[0]), 1)
+            row = p.numel() // P
+            live = self._sh_live(p.shape, sh_degree)
+            if live is not None:
+                row = live * 3
+            total += row * (P if count is None else int(count)) * p.element_size()
+        return total
+
+    def all_reduce_rows(self, first: int, count: int, group=None, even_alone: bool = False, sh_degree: Optional[int] = None):
         """Asynchronous sum over ranks of the gradients of Gaussians [first, first + count) -- one coalesced collective over the
         parameters' slices (a single RCCL group launch), enqueued behind whatever the current stream holds, so it runs beside the kernels
         that follow (the per-Gaussian pass over the next range, ``SyncFreeBatch.run_views(grad_chunks=..., on_chunk=...)``).  Returns the
         handles to ``wait()`` on before the gradients are used (empty without a process group).
+
+        ``sh_degree``: the ACTIVE SH degree of the step.  SH parameters stored for a higher degree are reduced over their live
+        coefficients only (see above): 44 + 12 (D + 1)^2 bytes per Gaussian instead of 236 -- 28 MB instead of 118 MB per step at 500 k
+        Gaussians and degree 0.  Every rank must pass the same value.
 
         Coalesced or one collective per slice is decided ONCE per backend, before anything is issued and identically on every rank
         (``_coalesced_all_reduce_supported``): no exception handling around collectives that may already be in flight -- a fallback taken
@@ -83,15 +129,56 @@ class FlatGradients:
         too (tests: the RCCL path on a one-GPU box)."""
         if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not even_alone):
             return []
-        pieces = [t for t in self.row_slices(first, count) if t.numel()]
+        pieces, packed, off = [], [], 0
+        for i, p in enumerate(self.params):
+            P = max(int(p.shape[0]), 1)
+            row = p.numel() // P
+            live = self._sh_live(p.shape, sh_degree)
+            if live is None:
+                t = self.flat[off + first * row: off + (first + count) * row]
+                if t.numel():
+                    pieces.append(t)
+            elif live > 0 and count > 0:
+                src = self.flat[off + first * row: off + (first + count) * row].view(count, int(p.shape[1]), 3)[:, :live, :]
+                stage = self._staging(i, first, count * live * 3)
+                stage.view(count, live, 3).copy_(src)
+                pieces.append(stage)
+                packed.append((src, stage.view(count, live, 3)))
+            off += p.numel()
         if not pieces:
             return []
         if _coalesced_all_reduce_supported(group):
             with dist._coalescing_manager(group=group, async_ops=True) as cm:
                 for t in pieces:
                     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-            return [cm]
-        return [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True) for t in pieces]
+            works = [cm]
+        else:
+            works = [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True) for t in pieces]
+        return [_PackedReduce(works, packed)] if packed else works
+
+    def _staging(self, index: int, first: int, numel: int) -> torch.Tensor:
+        """contiguous staging slice for the live coefficients of parameter `index`, range starting at `first` (kept from step to step;
+        one per range: several ranges are in flight at once)"""
+        pool = self.__dict__.setdefault("_stage", {})
+        t = pool.get((index, first))
+        if t is None or t.numel() != numel:
+            t = pool[(index, first)] = torch.empty(numel, dtype=self.flat.dtype, device=self.flat.device)
+        return t
+
+
+class _PackedReduce:
+    """Handle of a range whose SH parameters were reduced through staging slices: wait() waits for the collectives, then puts the summed
+    live coefficients back into the flat buffer (on the current stream, behind the wait)."""
+
+    def __init__(self, works, packed):
+        self.works, self.packed = works, packed
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        for dst, stage in self.packed:
+            dst.copy_(stage)
+        return True
 
 
 _COALESCE_DECISION = {}
@@ -112,12 +199,13 @@ def _coalesced_all_reduce_supported(group=None) -> bool:
 
 def render_batch_sharded(render_view: Callable[[int], torch.Tensor], upstream: Callable[[int, torch.Tensor], torch.Tensor],
                          num_views: int, grads: FlatGradients, group=None, rank: Optional[int] = None,
-                         world_size: Optional[int] = None) -> List[int]:
+                         world_size: Optional[int] = None, sh_degree: Optional[int] = None) -> List[int]:
     """One data-parallel step over a batch of ``num_views`` views.
 
     ``render_view(v)`` returns the image of view ``v`` (built on the parameters held by ``grads``);
     ``upstream(v, image)`` returns dL/d image.  After the call every rank's ``grads.flat`` holds the
-    gradient of the whole batch.  Returns the views this rank rendered."""
+    gradient of the whole batch.  Returns the views this rank rendered.  ``sh_degree``: the active SH degree the views are rendered
+    with (the same on every rank) -- only the live SH coefficients are reduced (FlatGradients.all_reduce_rows)."""
     if rank is None:
         rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
     if world_size is None:
@@ -127,7 +215,7 @@ def render_batch_sharded(render_view: Callable[[int], torch.Tensor], upstream: C
     for v in mine:
         img = render_view(v)
         img.backward(upstream(v, img.detach()))
-    grads.all_reduce(group)
+    grads.all_reduce(group, sh_degree=sh_degree)
     return list(mine)
 
 
@@ -281,8 +369,6 @@ class SyncFreeBatch:
         # run_views(upstream_view=...): half of the streams bin (per-Gaussian forward .. finalize), the other half composite
         # (k_render_fwd, the loss, k_render_bwd): kernels bound by the L2 atomics / by latency next to kernels bound by VALU issue
         self.split = bool(split)
-        self.split_pass = False                 # experiment (measured slower in round 2, DESIGN_HISTORY.md, and again at the end of round 4 with the faster pass: 1.90 against 1.82 ms per 8-view step): per-Gaussian pass of the first round of views beside the remaining per-pixel backwards
-        self._pass_stream = {}
         self._host: Optional[torch.Tensor] = None
         self._side = {}
         self._cooldown = 0                      # batches left to render synchronously (unused since overflow lists are sorted on the device; kept for callers that set it)
@@ -509,30 +595,8 @@ class SyncFreeBatch:
                     arr[v].dL_dpix = g.data_ptr()
                 self._keep = dLs                                 # (alive until the next batch)
             bw_handles = [st.cuda_stream for st in ren_lanes] if upstream_view is not None else handles
-            first = len(bw_handles)                         # views of the lanes' first round
-            early = self.split_pass and V > first and not precomp
-            if early:
-                # The per-Gaussian pass of the views whose per-pixel backward finishes first runs on a stream of its own BESIDE the per-pixel
-                # backwards of the remaining views (it is bound by HBM latency, they by vector issue and LDS); the pass at the end of the step,
-                # alone on the GPU, then covers the remaining views only.
-                _C.backward_render_views(bw_handles, P, arr, first, opt=self.options)
-                ps = self._pass_stream.setdefault(dev, torch.cuda.Stream(device=dev))
-                for st in (ren_lanes if upstream_view is not None else lanes):
-                    ev = torch.cuda.Event()
-                    ev.record(st)
-                    ps.wait_event(ev)
-                _C.backward_batch_raw(ps.cuda_stream, P, D, M, arr, first, means3D.data_ptr(), shs.data_ptr(), scales.data_ptr(), rs0.scale_modifier,
-                                      rotations.data_ptr(), opacities.grad.data_ptr(), means3D.grad.data_ptr(), shs.grad.data_ptr(), scales.grad.data_ptr(),
-                                      rotations.grad.data_ptr(), accumulate)
-                ev_a = torch.cuda.Event()
-                ev_a.record(ps)
-                rest = C.cast(C.addressof(arr) + first * C.sizeof(_C._ViewT), C.c_void_p)
-                _C.backward_render_views(bw_handles, P, rest, V - first, opt=self.options)
-                join()
-                main.wait_event(ev_a)
-            else:
-                _C.backward_render_views(bw_handles, P, arr, V, opt=self.options)
-                join()
+            _C.backward_render_views(bw_handles, P, arr, V, opt=self.options)
+            join()
             def verdict():
                 """waits for the Meta records (the one host wait of the batch: they left right behind the forwards) -> (views to render again, largest count)"""
                 for ev in ready:
@@ -556,11 +620,10 @@ class SyncFreeBatch:
             known = verdict() if on_chunk is not None else None
             eager = known is not None and not known[0]
             # the one per-Gaussian pass of the step, range by range: a range's gradients are final behind its launch
-            last_arr, last_n, last_acc = (rest, V - first, True) if early else (arr, V, accumulate)
             for g0, gcount in ranges:
-                _C.backward_batch_raw(main.cuda_stream, P, D, M, last_arr, last_n, means3D.data_ptr(), None if precomp else shs.data_ptr(), scales.data_ptr(),
+                _C.backward_batch_raw(main.cuda_stream, P, D, M, arr, V, means3D.data_ptr(), None if precomp else shs.data_ptr(), scales.data_ptr(),
                                       rs0.scale_modifier, rotations.data_ptr(), opacities.grad.data_ptr(), means3D.grad.data_ptr(),
-                                      None if precomp else shs.grad.data_ptr(), scales.grad.data_ptr(), rotations.grad.data_ptr(), last_acc, g0, gcount)
+                                      None if precomp else shs.grad.data_ptr(), scales.grad.data_ptr(), rotations.grad.data_ptr(), accumulate, g0, gcount)
                 if eager:
                     on_chunk(g0, gcount)
         self.viewspace_grads = pool["g2d"]
