@@ -344,11 +344,15 @@ def main():
                 except (OSError, StopIteration, KeyError, ValueError):
                     pass
             Rb = sum(Rb_view[v] for s in range(a.steps) for v in views_of(s)) / frames_rank     # instances the timed path really bins
-            # `achieved` / `frac`: SURVEY.md 8d's bytes for this launch with the REFERENCE's instance count (pruning off) -- for k_render_bwd
-            # 40 R (list read) + 20 N (pixels in) + 44 P (the per-Gaussian sums it produces).  Beside it `bytes_own_layout`: what this library's
-            # layout really moves for the launch (48-B records + quadrant mask + slot in, one 48-B slab row per binned instance out).
+            # `achieved` / `frac` (round 5, ADVICE): SURVEY.md 8d's per-unit bytes x the units THIS launch processes -- for k_render_bwd 40 B per
+            # instance the kernel walks (the binned ones: instance pruning leaves out a fifth of the reference's) + 20 N (pixels in) + 44 P (the
+            # per-Gaussian sums it produces).  Beside it the same with the reference's instance count (`frac_reference_instances`: what rounds 3-4
+            # quoted as `frac`; it counts bytes this kernel never moves) and `bytes_own_layout`: what this library's layout really moves for the
+            # launch (48-B records + quadrant mask + slot in, one 48-B slab row per binned instance out).
             alg_8d = dict(alg)
-            alg_8d["render_bwd"] = 40 * Rm + 20 * Npix + 44 * P
+            alg_8d["render_bwd"] = 40 * Rb + 20 * Npix + 44 * P
+            alg_8d["render_fwd"] = 40 * Rb + 20 * Npix
+            a8_ref = {"render_bwd": 40 * Rm + 20 * Npix + 44 * P, "render_fwd": 40 * Rm + 20 * Npix}.get(dom, alg[dom])
             alg_b = dict(alg)
             alg_b["render_fwd"] = 48 * Rb + 20 * Npix
             alg_b["render_bwd"] = (48 + 4 + 48) * Rb + 20 * Npix          # records + quadrant mask + slot in, one 48-B slab row out; pixels in
@@ -356,7 +360,8 @@ def main():
             a8, ab = alg_8d.get(dom, alg[dom]), alg_b.get(dom, alg[dom])
             roof = {"kernel": "k_" + dom, "bound": "hbm", "achieved": round(a8 / (t_alone * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(a8 / (t_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": int(a8), "bytes_model": "SURVEY.md 8d terms of this launch with the reference's instance count (instance pruning off)",
+                    "algorithmic_bytes_per_launch": int(a8), "bytes_model": "SURVEY.md 8d per-unit bytes x the units this launch processes (its binned instances, pixels, Gaussians)",
+                    "frac_reference_instances": round(a8_ref / (t_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                     "bytes_own_layout": int(ab), "frac_own_layout": round(ab / (t_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                     "instances_reference": int(Rm), "instances": int(Rb),
                     "avg_launch_ms": round(t_alone, 4), "duration": "kernel alone on the GPU (one-stream pass of this run, HIP events on the launch stream)",
@@ -484,6 +489,33 @@ def secondary_workloads(a, cloud, dev, D, W, H, headline_ms):
         img.backward(dL)
     res["dropin_api"] = {"ms_per_frame": round(timed(dropin, 40, 20), 4), "what": f"GaussianRasterizer + autograd, one view per step, {W}x{H}, SH degree {D} in the rasterizer",
                          "vs_headline_batch_path": round(timed(dropin, 20, 0, 1) / headline_ms, 2)}
+    # Host share of the same loop ON THIS BOX (round 5): the wall time per frame beside (a) the GPU's own span of the loop -- HIP events behind the
+    # first launch and the last completion on the loop's stream -- and (b) the sum of the library's stage times of an instrumented pass (tgs_profile_*:
+    # events around every stage; the caller's own kernels -- the zero fill of means2D -- are not in it).  wall - gpu_span is time the GPU waited for the host.
+    try:
+        n = 40
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        dropin(0)
+        e0.record()                                         # (behind the first frame: the GPU is busy from here on if the host keeps up)
+        for i in range(1, n + 1):
+            dropin(i)
+        e1.record()
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / (n + 1) * 1e3
+        span = e0.elapsed_time(e1) / n
+        _C.profile_begin(64 * n)
+        for i in range(n):
+            dropin(i)
+        torch.cuda.synchronize()
+        pr = _C.profile_end()
+        ksum = sum(ms for ms, c in pr.values() if c) / n
+        res["dropin_api"].update({"gpu_span_ms_per_frame": round(span, 4), "wall_ms_per_frame_same_loop": round(wall, 4),
+                                  "host_share_ms_per_frame": round(max(wall - span, 0.0), 4), "library_stage_sum_ms_per_frame": round(ksum, 4),
+                                  "stages_ms": {k: round(ms / max(c, 1) , 4) for k, (ms, c) in pr.items() if c}})
+    except Exception as ex:                                 # noqa: BLE001 -- a secondary measurement must not take the line down
+        res["dropin_api"]["host_share_error"] = repr(ex)[:200]
     # ---- the trainers' protocol at 2048 x 2048
     TW = TH = 2048
     gt = torch.rand(3, TH, TW, device=dev)

@@ -33,8 +33,8 @@
  * _tile_bound / _render_streams and tgs_last_nonempty_tiles -- are NOT part of this boundary any more: they are declared in
  * include/tgs_raster_testing.h, test-only shims that store defaults for calls made WITHOUT options.)  Process-wide:
  * the optional bench profiler (tgs_profile_*) and two tuning variables of the environment, read once: TGS_BIN_WGS (binning chunks per
- * view, default 128) and TGS_FORWARD_GROUP.  Per calling thread: the message of tgs_last_error(), tgs_set_render_streams (experiment),
- * and the pinned 64-byte staging slot + event of the speculative forward (one per thread and device).
+ * view, default 128) and TGS_FORWARD_GROUP.  Per calling thread: the message of tgs_last_error() and the pinned 64-byte staging
+ * slot + event of the speculative forward (one per thread and device).
  */
 #ifndef TGS_RASTER_H
 #define TGS_RASTER_H

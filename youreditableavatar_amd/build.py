@@ -25,8 +25,11 @@ ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 # Per-source flags (none at the moment; the hook stays for A/B builds of one file)
 EXTRA_FLAGS = {}
-# experiment knobs, e.g. TGS_DEFINES="-DTGS_FAST_MATH=0" python -m youreditableavatar_amd.build --force
-FLAGS += os.environ.get("TGS_DEFINES", "").split()
+# experiment knobs, e.g. TGS_LIB_NAME=libtgs_raster_x.so TGS_DEFINES="-DTGS_STAMPS=1" python -m youreditableavatar_amd.build --force.  They apply
+# to a NAMED variant only: TGS_DEFINES left in the environment of an ordinary import must not change what the default library is built from
+# (or make a fresh one look stale).
+if os.environ.get("TGS_LIB_NAME"):
+    FLAGS += os.environ.get("TGS_DEFINES", "").split()
 
 
 def hipcc() -> str:
@@ -69,6 +72,21 @@ def _stored_hash(path: str):
 
 def _hash_line() -> list:
     return [source_hash(), " ".join(FLAGS).replace(" ", "|")]
+
+
+EXT_CXX_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden"]
+
+
+def _ext_hash_line() -> list:
+    """what the compiled `_C` glue depends on: the sources, ITS compiler flags (g++, not hipcc's), and the torch / Python ABI it was built
+    against -- after a torch upgrade in the same tree the old module must not be loaded"""
+    import sysconfig
+    try:
+        import torch
+        tv = torch.__version__
+    except Exception:                                    # noqa: BLE001
+        tv = "no-torch"
+    return [source_hash(), "|".join(EXT_CXX_FLAGS), f"torch={tv}", f"abi={sysconfig.get_config_var('SOABI')}"]
 
 
 def _stale() -> bool:
@@ -155,7 +173,7 @@ def build_torch_ext(force: bool = False, verbose: bool = False) -> str:
     CUDAExtension recipe (setup.py:17-34) without hipify."""
     lib = build_native(force=force, verbose=verbose)
     out = ext_path()
-    fresh = lambda: os.path.exists(out) and (not _sources_present() or _stored_hash(EXT_HASH_FILE) == _hash_line())
+    fresh = lambda: os.path.exists(out) and (not _sources_present() or _stored_hash(EXT_HASH_FILE) == _ext_hash_line())
     if not force and fresh():
         return out
     with _BuildLock():
@@ -177,7 +195,7 @@ def _build_torch_ext_locked(lib: str, out: str, verbose: bool) -> str:
     except ImportError:
         pass                                             # torch ships pybind11 headers as well
     tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
-    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+    cmd = [cxx, *EXT_CXX_FLAGS, "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
            f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", f"-DTORCH_EXTENSION_NAME={EXT_NAME}", "-DTORCH_API_INCLUDE_EXTENSION_H",
            "-Wno-deprecated-declarations", *inc, EXT_SRC, "-o", out + f".tmp{os.getpid()}", f"-L{LIBDIR}", f"-l:{os.path.basename(lib)}", f"-L{tlib}", "-ltorch_python", "-ltorch",
            "-ltorch_cpu", "-ltorch_hip", "-lc10", "-lc10_hip", "-Wl,-rpath,$ORIGIN/../lib", f"-Wl,-rpath,{tlib}"]
@@ -188,7 +206,7 @@ def _build_torch_ext_locked(lib: str, out: str, verbose: bool) -> str:
         raise RuntimeError(f"building {EXT_NAME} failed:\n{r.stdout}\n{r.stderr}")
     os.replace(out + f".tmp{os.getpid()}", out)
     with open(EXT_HASH_FILE, "w") as f:
-        f.write(" ".join(_hash_line()) + "\n")
+        f.write(" ".join(_ext_hash_line()) + "\n")
     return out
 
 

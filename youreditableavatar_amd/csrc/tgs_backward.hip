@@ -391,8 +391,7 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
 
     const uint4 td = s.tile_desc[blockIdx.x];               // (in flight beside the frame's flags)
     // candidate light tile of this thread's quarter: light group g is workgroup gridDim.x - 1 - g and takes light tiles 3 g .. 3 g + 2
-    // (light groups only if the frame's forward wrote light_desc -- Meta::pad[1], k_scan: a caller may back-propagate with other options)
-    if (light && __builtin_nontemporal_load(&s.meta->pad[1]) == 0u) light = 0;
+    // (every forward records the light tiles' descriptors -- k_scan, k_render_fwd --, so a backward may set them apart whatever its forward did)
     const uint32_t lgroup = gridDim.x - 1u - blockIdx.x, lsub = threadIdx.x >> 8, li = (uint32_t)BWD_LIGHT_PER_WG * lgroup + lsub;
     const uint4 tdl = (light && lsub < (uint32_t)BWD_LIGHT_PER_WG && li < n_tiles) ? s.light_desc[li] : make_uint4(0u, 0u, 0u, 0u);
     const uint4 ff = frame_counts(s);
@@ -495,9 +494,11 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
 #pragma unroll 1
             for (uint32_t c0 = 0; c0 < nl; c0 += QCH) {
             const uint32_t nq = build_chunk_quadrant_lists<TGS_BWD_BOUNDED>(qlists[wv], lists[wv], c0, nl, lane, BNULL, qhi - 1, qlast);
+            uint32_t jn = myq[0];                           // the index one pass ahead (null slots behind the list's end, up to QL_ROW)
 #pragma unroll 1
             for (uint32_t k = 0; k < nq; k += 4) {          // 4 entries of its own quadrant list per row and pass
-                const uint32_t j = myq[k];
+                const uint32_t j = jn;
+                jn = myq[k + 4];
                 const float4 a = sA[j];                     // mean2D, conic xx / xy pre-scaled for exp2 (stage_conic)
                 const float4 bb = sB[j];                    // conic yy pre-scaled, opacity, colour r g
                 const float c0 = bb.z, c1 = bb.w, c2 = sC[j];

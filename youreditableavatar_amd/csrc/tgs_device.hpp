@@ -36,11 +36,20 @@ struct Meta {                 // lives at the start of the image buffer
     uint32_t n_nonempty;      // tiles with at least one instance (they come first in tile_order)
     uint32_t n_heavy;         // tiles with >= 1024 instances (first in tile_order): sorted by 1024-thread workgroups
     uint32_t n_mid;           // tiles with >= 128 instances (heavy ones included); the rest are sorted one wave per tile
-    uint32_t pad[8];          // [0]: a tile bound was exceeded (k_scan, mirrored to host_meta); [1]: light_desc holds this frame's light tiles
+    uint32_t pad[8];          // [0]: a tile bound was exceeded (k_scan, mirrored to host_meta)
 };
 
 constexpr uint32_t META_ERR_CAPACITY = 2u;
 constexpr uint32_t META_ERR_TILE_BOUND = 4u;   // a per-pixel backward was launched over fewer tiles than hold instances (caller's tile bound too small): TGS_FRAME_TILE_BOUND
+
+// scratch of the binning chain's scan (round 5), cleared with Meta by block 0 of the per-Gaussian forward stage
+struct ScanAux {
+    uint32_t hist[40];        // tiles per list-length bucket (0: empty, b: 2^(b-1) <= n < 2^b), added up by k_bin_colscan's workgroups
+    uint32_t cursor[40];      // k_scan: positions handed out inside each bucket's stretch of tile_order
+    uint32_t done;            // k_scan: tile workgroups that have finished (the last one copies the frame's Meta to the host)
+    uint32_t pad[47];
+};
+static_assert(sizeof(ScanAux) == 512, "ScanAux: 128 words, cleared by the first 128 threads of a block");
 
 struct GeomState {
     // One 64-byte line per Gaussian with everything the per-tile gather needs (geomState.means2D,
@@ -64,6 +73,7 @@ struct GeomState {
 };
 struct ImgState {
     Meta* meta;
+    ScanAux* aux;             // (behind Meta: both are cleared in front of a frame)
     uint2* ranges;            // per tile [start, end)              (imgState.ranges)
     uint32_t* tile_count;     // per tile: number of instances (k_bin_colscan)
     uint32_t* bin_table;      // [BIN_WGS_MAX][T]: instances of binning chunk w in tile t (k_bin_count), then their first position
@@ -109,7 +119,7 @@ __host__ __device__ inline size_t geom_carve(GeomState& g, char* base, size_t P,
 __host__ __device__ inline size_t img_carve(ImgState& s, char* base, size_t N, size_t T)
 {
     char* p = base;
-    carve(p, s.meta, 1); carve(p, s.ranges, T); carve(p, s.tile_count, T); carve(p, s.bin_table, (size_t)BIN_WGS_MAX * T);
+    carve(p, s.meta, 1); carve(p, s.aux, 1); carve(p, s.ranges, T); carve(p, s.tile_count, T); carve(p, s.bin_table, (size_t)BIN_WGS_MAX * T);
     carve(p, s.ovf_tiles, T); carve(p, s.tile_order, T); carve(p, s.tile_desc, T); carve(p, s.light_desc, T);
     carve(p, s.final_T, N); carve(p, s.n_contrib, N);
     carve(p, s.stamps, 8 * T);
@@ -251,24 +261,100 @@ __device__ __forceinline__ void build_quad_lists(QuadLists& L, uint32_t qm, int 
 // (build_chunk_quadrant_lists) and the wave runs max_q ceil(n_q / 4) passes over them.
 constexpr int QCH = 64;                    // block-list entries split per chunk
 constexpr int QL_ROW = QCH + 8;            // one quadrant list: <= 64 entries + null padding up to the longest list of the chunk
-template <int CH>
-__device__ __forceinline__ uint32_t build_own_list_q(unsigned short* list, const uint2* qmasks, uint32_t cnt, int blk, int lane)
+
+// ---- list building, round 5 -------------------------------------------------------------------------------------------
+// Cost decomposition on the MI355X (profiles/r05_render_decomposition.txt): building the lists twice costs k_render_fwd +12.4 us of 56
+// and k_render_bwd +8 us of 97 -- a fifth of the forward is ordered compaction.  The compiler's code for `ballot; if (on) list[base +
+// mbcnt] = x; base += popcount` was 9-11 vector instructions per list and 64 entries (two compares of the same bit, address
+// arithmetic in three steps) plus 5 per list for the null padding; written out it is 5 + 1 LDS write, and the padding is ONE 16-byte
+// store per lane in front of the appends (LDS operations of a wave execute in order, so the appends overwrite what they need).
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)p; }   // byte offset of a __shared__ object (low word of its flat address)
+
+// Appends `val` (low 16 bits) of every lane whose `ent` has a bit of BITS set to the u16 list at LDS byte address `base` (wave-uniform),
+// in lane order; returns how many (wave-uniform, in an SGPR).  The ranks are only needed by the lanes that write: mbcnt runs under their exec.
+template <uint32_t BITS>
+__device__ __forceinline__ uint32_t ql_append(uint32_t ent, uint32_t val, uint32_t base)
 {
-    uint32_t base = 0;
+    uint32_t t, r, n;
+    unsigned long long sv;
+    asm volatile(
+        "v_and_b32 %[t], %[bits], %[ent]\n\t"
+        "v_cmp_ne_u32 vcc, 0, %[t]\n\t"
+        "s_and_saveexec_b64 %[sv], vcc\n\t"
+        "s_bcnt1_i32_b64 %[n], vcc\n\t"
+        "v_mbcnt_lo_u32_b32 %[r], vcc_lo, 0\n\t"
+        "v_mbcnt_hi_u32_b32 %[r], vcc_hi, %[r]\n\t"
+        "v_lshl_add_u32 %[r], %[r], 1, %[base]\n\t"
+        "ds_write_b16 %[r], %[val]\n\t"
+        "s_mov_b64 exec, %[sv]\n\t"
+        : [t] "=&v"(t), [r] "=&v"(r), [sv] "=&s"(sv), [n] "=&s"(n)
+        : [ent] "v"(ent), [val] "v"(val), [base] "s"(base), [bits] "i"(BITS)
+        : "vcc", "scc", "memory");
+    return n;
+}
+// ... and only if (int)val > thr (the backward's bound: list position in front of the quadrant's deepest last contributor)
+template <uint32_t BITS>
+__device__ __forceinline__ uint32_t ql_append_above(uint32_t ent, uint32_t val, uint32_t base, int thr)
+{
+    uint32_t t, r, n;
+    unsigned long long sv, m;
+    asm volatile(
+        "v_and_b32 %[t], %[bits], %[ent]\n\t"
+        "v_cmp_ne_u32 vcc, 0, %[t]\n\t"
+        "v_cmp_gt_i32 %[m], %[val], %[thr]\n\t"
+        "s_and_b64 vcc, vcc, %[m]\n\t"
+        "s_and_saveexec_b64 %[sv], vcc\n\t"
+        "s_bcnt1_i32_b64 %[n], vcc\n\t"
+        "v_mbcnt_lo_u32_b32 %[r], vcc_lo, 0\n\t"
+        "v_mbcnt_hi_u32_b32 %[r], vcc_hi, %[r]\n\t"
+        "v_lshl_add_u32 %[r], %[r], 1, %[base]\n\t"
+        "ds_write_b16 %[r], %[val]\n\t"
+        "s_mov_b64 exec, %[sv]\n\t"
+        : [t] "=&v"(t), [r] "=&v"(r), [sv] "=&s"(sv), [m] "=&s"(m), [n] "=&s"(n)
+        : [ent] "v"(ent), [val] "v"(val), [base] "s"(base), [thr] "s"(thr), [bits] "i"(BITS)
+        : "vcc", "scc", "memory");
+    return n;
+}
+// the wave's four quadrant lists <- the null slot everywhere (ROW u16 each, contiguous, 16-B aligned)
+template <int ROW>
+__device__ __forceinline__ void ql_fill_null(unsigned short (*ql)[ROW], int lane, int null_slot)
+{
+    static_assert((4 * ROW * 2) % 16 == 0 && 4 * ROW * 2 / 16 <= 128, "quadrant lists: whole 16-byte pieces, at most two per lane");
+    constexpr int N16 = 4 * ROW * 2 / 16;
+    const uint32_t nn = (uint32_t)null_slot * 0x10001u;
+    uint4* p = reinterpret_cast<uint4*>(&ql[0][0]);
+    if (N16 >= 64 || lane < N16) p[lane] = make_uint4(nn, nn, nn, nn);
+    if (N16 > 64 && lane < N16 - 64) p[64 + lane] = make_uint4(nn, nn, nn, nn);
+}
+
+// The block's list of a staged round: entries [0, cnt) whose 64-bit quadrant mask names one of the block's four quadrants, in slot
+// order, each as slot | nibble << 10.  CH: capacity of the staged arrays (a multiple of 64: a lane past cnt reads a stale mask and drops it).
+template <int CH>
+__device__ __forceinline__ uint32_t build_own_list_q(unsigned short* list, const uint2* qmasks, uint32_t cnt_in, int blk_in, int lane)
+{
+    static_assert(CH % 64 == 0, "whole 64-entry groups");
+    const uint32_t blk = (uint32_t)__builtin_amdgcn_readfirstlane(blk_in), cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt_in);
     // block (bx, by) = blk: quadrant rows 2 by, 2 by + 1 and columns 2 bx, 2 bx + 1 of the 8x8 grid -> nibble bit 2*(lower) + (right)
     const uint32_t* half = reinterpret_cast<const uint32_t*>(qmasks) + (blk >> 3);
-    const uint32_t sh = 16u * (uint32_t)((blk >> 2) & 1) + 2u * (uint32_t)(blk & 3);
-#pragma unroll 1
-    for (uint32_t k0 = 0; k0 < cnt; k0 += 64) {            // (rolled: unrolled, the 8 slot addresses are hoisted into VGPRs the render loops need)
-        const uint32_t slot = k0 + lane;
-        const uint32_t w = slot < cnt ? half[2 * slot] >> sh : 0u;
-        const uint32_t nib = (w & 3u) | ((w >> 6) & 12u);
-        const bool on = nib != 0u;
-        const unsigned long long bal = __builtin_amdgcn_ballot_w64(on);
-        if (on) list[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (unsigned short)(slot | (nib << 10));
-        base += (uint32_t)__builtin_popcountll(bal);
+    const uint32_t sh = 16u * ((blk >> 2) & 1u) + 2u * (blk & 3u);
+    const uint32_t lb = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr(list));
+    // all groups' masks are asked for at once: one LDS round trip for the round instead of one per 64 entries (a wave builds its lists
+    // right behind the staging barrier, when every other wave of the workgroup does the same: nobody covers anybody's latency)
+    constexpr int NG = CH / 64;
+    uint32_t w[NG];
+#pragma unroll
+    for (int g = 0; g < NG; g++) w[g] = half[2 * (64 * g + lane)];
+    uint32_t n = 0;
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+        if (64u * g < cnt) {                                // (wave-uniform)
+            const uint32_t slot = 64u * g + lane;
+            const uint32_t wg = slot < cnt ? w[g] : 0u;
+            const uint32_t ent = slot | (__builtin_amdgcn_ubfe(wg, sh, 2u) << 10) | (__builtin_amdgcn_ubfe(wg, sh + 8u, 2u) << 12);
+            n += ql_append<0x3c00u>(ent, ent, lb + 2u * n);
+        }
     }
-    return base;
+    return n;
 }
 // quadrant lists of block-list entries [c0, min(c0 + 64, n)); returns the longest list's length.  BOUNDED (backward): an entry whose
 // list position top - slot is not in front of the quadrant's deepest last contributor (bound[q]) is left out -- no pixel of the
@@ -277,23 +363,26 @@ template <bool BOUNDED = false>
 __device__ __forceinline__ uint32_t build_chunk_quadrant_lists(unsigned short (*ql)[QL_ROW], const unsigned short* list, uint32_t c0, uint32_t n, int lane,
                                                               int null_slot, uint32_t top = 0u, const uint32_t* bound = nullptr)
 {
+    const uint32_t qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr(&ql[0][0]));
+    ql_fill_null<QL_ROW>(ql, lane, null_slot);
     const uint32_t ent = c0 + lane < n ? list[c0 + lane] : 0u;
-    const uint32_t nib = ent >> 10, slot = ent & 1023u;
-    uint32_t nmax = 0;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        bool on = (nib >> q) & 1u;
-        if (BOUNDED) on = on && (top - slot < bound[q]);
-        const unsigned long long bal = __builtin_amdgcn_ballot_w64(on);
-        const uint32_t cq = (uint32_t)__builtin_popcountll(bal);
-        if (on) ql[q][__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (unsigned short)slot;
-        if (cq + lane < (uint32_t)QL_ROW) ql[q][cq + lane] = (unsigned short)null_slot;      // short lists idle on the null record
-        nmax = max(nmax, cq);
+    const uint32_t slot = ent & 1023u;
+    uint32_t c[4];
+    if (BOUNDED) {      // top - slot < bound[q]  <=>  slot > top - bound[q]   (slot <= top < 2^31)
+        c[0] = ql_append_above<0x0400u>(ent, slot, qb, (int)top - (int)bound[0]);
+        c[1] = ql_append_above<0x0800u>(ent, slot, qb + 2u * QL_ROW, (int)top - (int)bound[1]);
+        c[2] = ql_append_above<0x1000u>(ent, slot, qb + 4u * QL_ROW, (int)top - (int)bound[2]);
+        c[3] = ql_append_above<0x2000u>(ent, slot, qb + 6u * QL_ROW, (int)top - (int)bound[3]);
+    } else {
+        c[0] = ql_append<0x0400u>(ent, slot, qb);
+        c[1] = ql_append<0x0800u>(ent, slot, qb + 2u * QL_ROW);
+        c[2] = ql_append<0x1000u>(ent, slot, qb + 4u * QL_ROW);
+        c[3] = ql_append<0x2000u>(ent, slot, qb + 6u * QL_ROW);
     }
-    return nmax;
+    return max(max(c[0], c[1]), max(c[2], c[3]));
 }
 
-// The forward's variant: chunks of 128 block-list entries (two ballots per quadrant).  Longer chunks even out the four rows of a wave --
+// The forward's variant: chunks of 128 block-list entries (two appends per quadrant).  Longer chunks even out the four rows of a wave --
 // tools/culling_potential.py at config 3: 325 k wave passes with 64-entry chunks, 304 k with 128 -- and halve the number of list builds;
 // the forward has the LDS for the longer rows (the backward, at 2 x 75.6 KB per CU, does not).
 constexpr int QCH_F = 128;
@@ -301,28 +390,20 @@ constexpr int QL_ROW_F = QCH_F + 8;
 __device__ __forceinline__ uint32_t build_chunk_quadrant_lists_128(unsigned short (*ql)[QL_ROW_F], const unsigned short* list, uint32_t c0, uint32_t n, int lane,
                                                                   int null_slot)
 {
-    uint32_t cq[4] = {0u, 0u, 0u, 0u};
+    const uint32_t qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr(&ql[0][0]));
+    ql_fill_null<QL_ROW_F>(ql, lane, null_slot);
+    uint32_t c[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         const uint32_t i = c0 + 64u * h + lane;
         const uint32_t ent = i < n ? list[i] : 0u;
-        const uint32_t nib = ent >> 10, slot = ent & 1023u;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const bool on = (nib >> q) & 1u;
-            const unsigned long long bal = __builtin_amdgcn_ballot_w64(on);
-            if (on) ql[q][cq[q] + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (unsigned short)slot;
-            cq[q] += (uint32_t)__builtin_popcountll(bal);
-        }
+        const uint32_t slot = ent & 1023u;
+        c[0] += ql_append<0x0400u>(ent, slot, qb + 2u * c[0]);
+        c[1] += ql_append<0x0800u>(ent, slot, qb + 2u * QL_ROW_F + 2u * c[1]);
+        c[2] += ql_append<0x1000u>(ent, slot, qb + 4u * QL_ROW_F + 2u * c[2]);
+        c[3] += ql_append<0x2000u>(ent, slot, qb + 6u * QL_ROW_F + 2u * c[3]);
     }
-    uint32_t nmax = 0;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {                          // short lists idle on the null record up to the longest list of the chunk
-        if (cq[q] + lane < (uint32_t)QL_ROW_F) ql[q][cq[q] + lane] = (unsigned short)null_slot;
-        if (cq[q] + 64u + lane < (uint32_t)QL_ROW_F) ql[q][cq[q] + 64u + lane] = (unsigned short)null_slot;
-        nmax = max(nmax, cq[q]);
-    }
-    return nmax;
+    return max(max(c[0], c[1]), max(c[2], c[3]));
 }
 
 // 16-bit block mask -> 4-bit quadrant mask (quadrant q: bit0 = right half, bit1 = lower half)
@@ -828,8 +909,6 @@ struct FwdIn {
     float* out_color;
     int* radii;
     int prune;        // 1 (default): rectangle tiles the splat cannot reach with alpha >= 1/255 get no instance (tgs_set_instance_pruning)
-    int defer_colour; // 1: the SH colours of this frame are evaluated by k_sh_colors_deferred on a side stream (tgs_api.hip): the per-Gaussian
-                      // stage runs WITHOUT the 192-B SH rows and leaves the colour slots of the pack line at zero
 };
 struct BwdIn {
     int P, D, M;

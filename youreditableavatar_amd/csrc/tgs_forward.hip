@@ -300,6 +300,7 @@ __device__ __forceinline__ void block_sum_tiles(uint32_t tiles, bool violation, 
         g.block_flags[blockIdx.x] = wflag[0] | wflag[1] | wflag[2] | wflag[3];
     }
     if (blockIdx.x == 0 && threadIdx.x < sizeof(Meta) / sizeof(uint32_t)) reinterpret_cast<uint32_t*>(s.meta)[threadIdx.x] = 0u;
+    if (blockIdx.x == 0 && threadIdx.x < sizeof(ScanAux) / sizeof(uint32_t)) reinterpret_cast<uint32_t*>(s.aux)[threadIdx.x] = 0u;
 }
 
 // SH rows of the workgroup's 256 Gaussians (M = 16: 192 B each, 48 KB in all) are fetched with fully coalesced
@@ -424,7 +425,19 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd_batch(const FwdIn 
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_scan: block 0 scans the per-block sums, block 1 scans the tile counts.
+// k_scan: workgroup 0 scans the per-block sums (-> Gaussian offsets, R); workgroups 1.. take SCAN_THREADS tiles each (-> ranges, tile order,
+// descriptors, the frame's counts).
+//
+// Round 5.  Until round 4 ONE workgroup walked all tiles: scan, length histogram, then a second pass that took every tile's position in
+// tile_order with a returning LDS atomic -- 15.3 us at 1920 x 1080 (8160 tiles), a quarter of the binning chain, with 255 CUs idle.  Now
+//   * k_bin_colscan, which forms every tile's count anyway, also adds the tiles of its 64 to a global histogram of list-length buckets
+//     (ScanAux::hist: one atomic per workgroup and occupied bucket), so the bucket sizes of the WHOLE frame are known when k_scan starts;
+//   * a tile workgroup needs nothing from its peers: the instances in front of its first tile it sums itself from tile_count (at most
+//     T - 1024 values out of L2), the bucket stretches of tile_order follow from the histogram, and its tiles' places inside a stretch
+//     come from ONE returning global atomic per workgroup and bucket (ScanAux::cursor) on top of a local rank (order inside a bucket
+//     does not matter);
+//   * longest list / overflow tiles go to Meta with global atomics (a few per workgroup); the copy of Meta in pinned host memory is
+//     completed by whichever tile workgroup finishes last (ScanAux::done: a count, nobody waits for anybody).
 // ---------------------------------------------------------------------------------------------
 constexpr int SCAN_THREADS = 1024;
 constexpr int SCAN_ITEMS = 4;
@@ -442,20 +455,17 @@ __device__ __forceinline__ unsigned long long block_exscan_u64(unsigned long lon
     total = tot;
     return base + inc - v;
 }
+__device__ __forceinline__ uint32_t length_bucket(uint32_t n) { return n ? 32u - (uint32_t)__builtin_clz(n) : 0u; }
 
-// host_meta (may be NULL): a copy of Meta in pinned, device-visible HOST memory, written by the two workgroups themselves -- the speculative
+// host_meta (may be NULL): a copy of Meta in pinned, device-visible HOST memory, written by the kernel itself -- the speculative
 // forward's read-back without a copy engine or blit kernel in the stream (a D2H blit between k_scan and k_scatter cost 4 us + a 6-us gap)
 // tile_bound: the sync-free grids behind the scan cover that many entries of tile_order; a frame with more non-empty tiles is rejected
 // like one that exceeds r_capacity (T: no bound)
-// TI: tile counters per thread and super-chunk of the tile pass (8: 8192 tiles per iteration, 16: 16 384 -- a 2048 x 2048 image in ONE
-// iteration instead of two: the iterations are serial round trips of a single workgroup, 30 -> see DESIGN.md us at that size)
-template <int TI>
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const ImgState s, uint32_t nblocks, uint32_t T, uint32_t sort_cap, unsigned long long r_capacity, uint32_t tile_bound,
                                                        uint32_t heavy_bound, uint32_t mid_bound, Meta* host_meta, int light)
 {
     __shared__ unsigned long long lds[SCAN_THREADS / WAVE];
     __shared__ uint32_t lds_max[SCAN_THREADS / WAVE];
-    __shared__ uint32_t ovf_n;
     if (blockIdx.x == 0) {
         unsigned long long carry = 0;
         uint32_t flags = 0;                                 // OR of the blocks' prefiltered-violation flags
@@ -476,98 +486,69 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const 
             s.meta->R = carry;
             uint32_t err = any_flag ? 1u : 0u;              // bit 0: a prefiltered Gaussian was culled (k_preprocess_fwd* -> block_flags)
             if (carry > r_capacity) err |= META_ERR_CAPACITY;                                                    // tgs_forward_async: the frame does not fit
-            if (err) atomicOr(&s.meta->error, err);         // (the tile pass of workgroup 1 may OR META_ERR_CAPACITY concurrently)
+            if (err) atomicOr(&s.meta->error, err);         // (a tile workgroup may OR META_ERR_CAPACITY concurrently)
             if (host_meta) { host_meta->R = carry; host_meta->error = err; }
         }
-    } else {
-        // Tile pass.  One workgroup is latency bound, so every global access is issued 8-deep: the counters of a
-        // super-chunk of 8192 tiles are pulled into LDS with 8 independent loads per thread, and the scan, the
-        // longest-list search and the length histogram then run out of LDS.
-        constexpr uint32_t SC = SCAN_THREADS * TI;
-        // 32 KB (TI = 8) or 64 KB (TI = 16) of static LDS besides the small arrays: more than the 64 KB a workgroup gets on other targets --
-        // this kernel (like the binning chunks' 96-KB tables) is written for gfx950's 160 KB per CU and nothing else (build.py: --offload-arch=gfx950)
-        static_assert(SC * sizeof(uint32_t) + 4096 <= 160 * 1024, "k_scan: the tile counters of one super-chunk must fit gfx950's 160 KB of LDS");
-        __shared__ uint32_t lc[SC];
-        __shared__ uint32_t hist[34];
-        __shared__ uint32_t cls[2];                         // (n_mid, n_nonempty) for the second pass
-        if (threadIdx.x == 0) ovf_n = 0;
-        if (threadIdx.x < 34) hist[threadIdx.x] = 0;
-        __syncthreads();
-        unsigned long long carry = 0;
-        uint32_t mx = 0;
-        for (uint32_t sc = 0; sc < T; sc += SC) {
-            const uint32_t n = min(SC, T - sc);
-            uint32_t v[TI];
-#pragma unroll
-            for (int k = 0; k < TI; k++) { const uint32_t i = k * SCAN_THREADS + threadIdx.x; v[k] = i < n ? s.tile_count[sc + i] : 0u; }
-#pragma unroll
-            for (int k = 0; k < TI; k++) lc[k * SCAN_THREADS + threadIdx.x] = v[k];
-            __syncthreads();
-            unsigned long long sum = 0;
-            const uint32_t i0 = threadIdx.x * TI;
-#pragma unroll
-            for (int k = 0; k < TI; k++) { v[k] = lc[i0 + k]; sum += v[k]; mx = v[k] > mx ? v[k] : mx; }
-            unsigned long long tot;
-            unsigned long long ex = block_exscan_u64(sum, lds, tot) + carry;
-#pragma unroll
-            for (int k = 0; k < TI; k++) {
-                if (i0 + k < n) {
-                    const uint32_t t = sc + i0 + k;
-                    s.ranges[t] = make_uint2((uint32_t)ex, (uint32_t)(ex + v[k]));
-                    if (v[k] > sort_cap) s.ovf_tiles[atomicAdd(&ovf_n, 1u)] = t;
-                    atomicAdd(&hist[v[k] ? 32 - __builtin_clz(v[k]) : 0], 1u);     // (one LDS atomic per lane.  Measured alternatives, round 4: aggregated per wave and bucket by ballots 27 us
-                                                                                    // instead of 18; one counter per bucket AND lane + a scan over them 21.6 us: the same-address adds are not what the pass waits for)
-                }
-                ex += v[k];
-            }
-            carry += tot;
-            __syncthreads();
-        }
-        // tiles by descending list length (power-of-two buckets; order inside a bucket does not matter)
-        if (threadIdx.x == 0) {
-            uint32_t acc = 0;
-            bool too_many = false;                          // more tiles (of a class) than the grids behind the scan cover
-            for (int b2 = 33; b2-- > 0;) {
-                const uint32_t h = hist[b2]; hist[b2] = acc;
-                if (b2 == 1) { s.meta->n_nonempty = acc + h; cls[1] = acc + h; too_many = too_many || acc + h > tile_bound; }
-                if (b2 == 11) { s.meta->n_heavy = acc + h; too_many = too_many || acc + h > heavy_bound; }
-                if (b2 == 8) { s.meta->n_mid = acc + h; cls[0] = acc + h; too_many = too_many || acc + h > mid_bound; }
-                acc += h;
-            }
-            s.meta->pad[1] = 1u;                            // light_desc is valid for EVERY frame since round 4 (a backward may be called with other options
-                                                            // than its forward: with the descriptors always there its grid is valid for either outcome)
-            if (too_many) atomicOr(&s.meta->error, META_ERR_CAPACITY);
-            if (host_meta) host_meta->pad[0] = too_many ? 1u : 0u;   // (a word of its own: workgroup 0 writes host_meta->error)
-        }
-        __syncthreads();
-        for (uint32_t sc = 0; sc < T; sc += SC) {
-            const uint32_t n = min(SC, T - sc);
-            uint2 r[TI];
-#pragma unroll
-            for (int k = 0; k < TI; k++) { const uint32_t i = k * SCAN_THREADS + threadIdx.x; r[k] = s.ranges[sc + min(i, n - 1u)]; }   // (clamped, not predicated: under `i < n ?` each of the TI loads is waited for on its own)
-#pragma unroll
-            for (int k = 0; k < TI; k++) {
-                const uint32_t i = k * SCAN_THREADS + threadIdx.x;
-                if (i < n) {
-                    const uint32_t c = r[k].y - r[k].x, pos = atomicAdd(&hist[c ? 32 - __builtin_clz(c) : 0], 1u);
-                    s.tile_order[pos] = sc + i;
-                    s.tile_desc[pos] = make_uint4(sc + i, r[k].x, r[k].y, 0u);
-                    if (pos >= cls[0] && pos < cls[1]) s.light_desc[pos - cls[0]] = make_uint4(sc + i, r[k].x, r[k].y, 0u);   // (always: one 16-B store per tile below 128 entries)
-                }
-            }
-        }
-        mx = wave_max_u32(mx);
-        if ((threadIdx.x & 63) == 0) lds_max[threadIdx.x >> 6] = mx;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t m = 0;
-            for (int i = 0; i < SCAN_THREADS / WAVE; i++) m = lds_max[i] > m ? lds_max[i] : m;
-            s.meta->max_count = m;
-            s.meta->n_overflow = ovf_n;
-            if (host_meta) {
-                host_meta->max_count = m; host_meta->n_overflow = ovf_n;
-                host_meta->n_nonempty = s.meta->n_nonempty; host_meta->n_heavy = s.meta->n_heavy; host_meta->n_mid = s.meta->n_mid;   // (this thread wrote them above)
-            }
+        return;
+    }
+    // ---- SCAN_THREADS tiles, one per thread
+    __shared__ uint32_t hist[40], start[40], lcount[40], gbase[40];
+    __shared__ uint32_t cls[3];                            // n_nonempty, n_heavy, n_mid of the frame
+    const uint32_t w = blockIdx.x - 1u, t0 = w * SCAN_THREADS, t = t0 + threadIdx.x;
+    const bool in = t < T;
+    // (a) instances in front of this workgroup's first tile: its own sum over tile_count[0, t0) -- w loads per thread, all in flight
+    unsigned long long before = 0;
+    for (uint32_t k = 0; k < w; k++) before += s.tile_count[k * SCAN_THREADS + threadIdx.x];
+    const uint32_t c = in ? s.tile_count[t] : 0u;
+    if (threadIdx.x < 40) { hist[threadIdx.x] = threadIdx.x < 34 ? __builtin_nontemporal_load(&s.aux->hist[threadIdx.x]) : 0u; lcount[threadIdx.x] = 0u; }
+    unsigned long long tot, pre_tot;
+    const unsigned long long pre = block_exscan_u64(before, lds, pre_tot);    // (only the total is used; the barriers inside also publish hist / lcount)
+    (void)pre;
+    const unsigned long long ex = block_exscan_u64((unsigned long long)c, lds, tot) + pre_tot;
+    if (in) s.ranges[t] = make_uint2((uint32_t)ex, (uint32_t)(ex + c));
+    // (b) the frame's bucket stretches: tiles by descending list length (power-of-two buckets; order inside a bucket does not matter)
+    const uint32_t bkt = length_bucket(c);
+    if (threadIdx.x < 34) {
+        uint32_t acc = 0;
+        for (uint32_t b2 = 33; b2 > threadIdx.x; b2--) acc += hist[b2];
+        start[threadIdx.x] = acc;
+        if (threadIdx.x == 1) cls[0] = acc + hist[1];      // tiles with at least one instance
+        if (threadIdx.x == 11) cls[1] = acc + hist[11];    // ... with >= 1024
+        if (threadIdx.x == 8) cls[2] = acc + hist[8];      // ... with >= 128
+    }
+    // (c) rank among this workgroup's tiles of the same bucket, then ONE global returning atomic per occupied bucket
+    const uint32_t lrank = in ? atomicAdd(&lcount[bkt], 1u) : 0u;
+    __syncthreads();
+    if (threadIdx.x < 34) gbase[threadIdx.x] = lcount[threadIdx.x] ? atomicAdd(&s.aux->cursor[threadIdx.x], lcount[threadIdx.x]) : 0u;
+    __syncthreads();
+    const uint32_t n_nonempty = cls[0], n_heavy = cls[1], n_mid = cls[2];
+    if (in) {
+        const uint32_t pos = start[bkt] + gbase[bkt] + lrank;
+        s.tile_order[pos] = t;
+        s.tile_desc[pos] = make_uint4(t, (uint32_t)ex, (uint32_t)(ex + c), 0u);
+        if (pos >= n_mid && pos < n_nonempty) s.light_desc[pos - n_mid] = make_uint4(t, (uint32_t)ex, (uint32_t)(ex + c), 0u);   // (always: one 16-B store per tile below 128 entries)
+        if (c > sort_cap) s.ovf_tiles[atomicAdd(&s.meta->n_overflow, 1u)] = t;
+    }
+    uint32_t mx = wave_max_u32(c);
+    if ((threadIdx.x & 63) == 0) lds_max[threadIdx.x >> 6] = mx;
+    if (w == 0 && threadIdx.x == 0) {                      // the frame's class counts (from the histogram: every tile workgroup knows them, the first one publishes them)
+        s.meta->n_nonempty = n_nonempty; s.meta->n_heavy = n_heavy; s.meta->n_mid = n_mid;
+        const bool too_many = n_nonempty > tile_bound || n_heavy > heavy_bound || n_mid > mid_bound;   // more tiles (of a class) than the grids behind the scan cover
+        if (too_many) atomicOr(&s.meta->error, META_ERR_CAPACITY);
+        if (host_meta) { host_meta->pad[0] = too_many ? 1u : 0u; host_meta->n_nonempty = n_nonempty; host_meta->n_heavy = n_heavy; host_meta->n_mid = n_mid; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t m = 0;
+        for (int i = 0; i < SCAN_THREADS / WAVE; i++) m = lds_max[i] > m ? lds_max[i] : m;
+        if (m) atomicMax(&s.meta->max_count, m);
+        // the last tile workgroup to get here completes the host's copy (max_count / n_overflow are final once every workgroup has added its share)
+        __threadfence();
+        const uint32_t nw = gridDim.x - 1u;
+        if (atomicAdd(&s.aux->done, 1u) == nw - 1u && host_meta) {
+            __threadfence();
+            host_meta->max_count = atomicMax(&s.meta->max_count, 0u);
+            host_meta->n_overflow = atomicAdd(&s.meta->n_overflow, 0u);
         }
     }
 }
@@ -676,7 +657,9 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(int P, uint32_t chunk
 __global__ __launch_bounds__(256) void k_bin_colscan(const ImgState s, uint32_t T, uint32_t nchunks)
 {
     __shared__ uint32_t part[4][WAVE];
+    __shared__ uint32_t bh[34];
     const int q = threadIdx.x >> 6, l = threadIdx.x & 63;
+    if (threadIdx.x < 34) bh[threadIdx.x] = 0u;
     const uint32_t t = blockIdx.x * WAVE + l;
     const uint32_t per = (nchunks + 3) / 4, w0 = min(nchunks, q * per), w1 = min(nchunks, w0 + per);
     uint32_t* col = s.bin_table + t;
@@ -695,8 +678,13 @@ __global__ __launch_bounds__(256) void k_bin_colscan(const ImgState s, uint32_t 
         for (int i = 0; i < q; i++) run += part[i][l];
 #pragma unroll
         for (int k = 0; k < BIN_WGS_MAX / 4; k++) { if (w0 + k < w1) col[(size_t)(w0 + k) * T] = run; run += c[k]; }
-        if (q == 3) s.tile_count[t] = run;
+        if (q == 3) {
+            s.tile_count[t] = run;
+            atomicAdd(&bh[length_bucket(run)], 1u);         // the frame's histogram of list lengths (k_scan: tile order), first per workgroup in LDS
+        }
     }
+    __syncthreads();
+    if (threadIdx.x < 34 && bh[threadIdx.x]) atomicAdd(&s.aux->hist[threadIdx.x], bh[threadIdx.x]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1077,9 +1065,11 @@ __device__ __forceinline__ bool fwd_q_block_round(const float4* sA, const float4
 #pragma unroll 1
     for (uint32_t c0 = 0; c0 < n; c0 += QCH_F) {
         const uint32_t nq = (uint32_t)__builtin_amdgcn_readfirstlane((int)build_chunk_quadrant_lists_128(ql, list, c0, n, lane, FQ_NULL));
+        uint32_t jn = myq[0];                               // the index one pass ahead: the pass itself then waits for ONE LDS round trip (the records), not two
 #pragma unroll 1
         for (uint32_t k = 0; k < nq; k += 4) {
-            const uint32_t j = myq[k];
+            const uint32_t j = jn;
+            jn = myq[k + 4];                                // (behind the list's end: null slots up to QL_ROW_F)
             const float4 a = sA[j];
             const float4 bb = sB[j];
             const float cc = sC[j];
@@ -1321,8 +1311,8 @@ void launch_preprocess_fwd_batch(hipStream_t st, const FwdIn& in, const FwdViews
 void launch_scan(hipStream_t st, const GeomState& g, const ImgState& s, uint32_t nblocks, uint32_t T, uint32_t sort_cap, unsigned long long r_capacity,
                  uint32_t tile_bound, uint32_t heavy_bound, uint32_t mid_bound, Meta* host_meta, int light)
 {
-    if (T > SCAN_THREADS * 8) hipLaunchKernelGGL(k_scan<16>, dim3(2), dim3(SCAN_THREADS), 0, st, g, s, nblocks, T, sort_cap, r_capacity, tile_bound, heavy_bound, mid_bound, host_meta, light);
-    else hipLaunchKernelGGL(k_scan<8>, dim3(2), dim3(SCAN_THREADS), 0, st, g, s, nblocks, T, sort_cap, r_capacity, tile_bound, heavy_bound, mid_bound, host_meta, light);
+    hipLaunchKernelGGL(k_scan, dim3(1u + (T + SCAN_THREADS - 1) / SCAN_THREADS), dim3(SCAN_THREADS), 0, st, g, s, nblocks, T, sort_cap, r_capacity, tile_bound, heavy_bound, mid_bound,
+                       host_meta, light);
 }
 // Binning chunks: `nchunks` workgroups of BIN_THREADS threads, `chunk` Gaussians each (a multiple of BIN_THREADS)
 void bin_shape(int P, uint32_t T, uint32_t& nchunks, uint32_t& chunk, uint32_t& band, size_t& lds)

@@ -61,9 +61,17 @@ class _Speculation:
     The guess is a slowly decaying maximum of the counts seen (trainers sample views in random order -- refine.py:257-266 -- so the last
     call's count alone misses on every small-to-large transition, and a miss enqueues scatter / sort / render twice) plus 15 % headroom.
     Three misses in a row switch speculation off for that key for the next 64 calls (e.g. frames that need the host-sized overflow
-    sort, which always miss)."""
+    sort, which always miss).
 
-    HEADROOM, DECAY, MAX_MISSES, COOLDOWN, GRANULE = 1.15, 0.97, 3, 64, 65536
+    Round 5: the maximum decays by 0.1 % per call, not 3 %.  At 3 % the 15 % of headroom are gone five calls after the largest view, so a
+    camera set whose instance counts differ by more than that (the 16 views of bench.py's drop-in loop do: an ellipsoid seen end-on and
+    side-on) missed whenever a large view came round again -- scatter / sort / render enqueued twice, ~130 us -- and spent most frames in
+    the 64-call cool-down on the synchronous forward (rocprofv3 of tools/dropin_loop.py: the device-to-host copy of the synchronous path in
+    65 of 100 frames).  What a generous guess costs is memory for the binning buffer (112 B per instance of the largest view) and
+    workgroups that return at once.  A miss also lifts the bound 10 % above the count that caused it (a run of growing views -- the first
+    calls of a camera set -- then misses once or twice, not on every view), and the cool-down is 16 calls after four misses in a row."""
+
+    HEADROOM, DECAY, MAX_MISSES, COOLDOWN, GRANULE = 1.15, 0.999, 4, 16, 65536
 
     def __init__(self):
         self.state = {}
@@ -94,9 +102,11 @@ class _Speculation:
 
     def update(self, key, true_count, guess, tiles=-1, tile_guess=0, mid_tiles=-1):
         st = self.state.setdefault(key, [0, 0, 0, 0, 0])      # [bound, consecutive misses, calls left without speculation, bound on the tiles, light tiles of the last frame]
-        st[0] = max(int(true_count), int(st[0] * self.DECAY))
+        missed_now = guess is not None and (true_count > guess or (tile_guess > 0 and tiles > tile_guess))
+        lift = 1.1 if missed_now else 1.0
+        st[0] = max(int(true_count * lift), int(st[0] * self.DECAY))
         if tiles >= 0:
-            st[3] = max(int(tiles), int(st[3] * self.DECAY))
+            st[3] = max(int(tiles * lift), int(st[3] * self.DECAY))
             if mid_tiles >= 0:
                 st[4] = max(0, int(tiles) - int(mid_tiles))
         if guess is not None:
