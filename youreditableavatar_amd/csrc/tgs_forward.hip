@@ -543,12 +543,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const 
         for (int i = 0; i < SCAN_THREADS / WAVE; i++) m = lds_max[i] > m ? lds_max[i] : m;
         if (m) atomicMax(&s.meta->max_count, m);
         // the last tile workgroup to get here completes the host's copy (max_count / n_overflow are final once every workgroup has added its share)
-        __threadfence();
-        const uint32_t nw = gridDim.x - 1u;
-        if (atomicAdd(&s.aux->done, 1u) == nw - 1u && host_meta) {
+        if (host_meta) {
             __threadfence();
-            host_meta->max_count = atomicMax(&s.meta->max_count, 0u);
-            host_meta->n_overflow = atomicAdd(&s.meta->n_overflow, 0u);
+            const uint32_t nw = gridDim.x - 1u;
+            if (atomicAdd(&s.aux->done, 1u) == nw - 1u) {
+                __threadfence();
+                host_meta->max_count = atomicMax(&s.meta->max_count, 0u);
+                host_meta->n_overflow = atomicAdd(&s.meta->n_overflow, 0u);
+            }
         }
     }
 }
