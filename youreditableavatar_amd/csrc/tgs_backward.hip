@@ -237,6 +237,82 @@ constexpr int BCH = TGS_BCH;               // list entries per round
 constexpr int BNULL = BCH;
 
 // ---------------------------------------------------------------------------------------------
+// The passes of one wave over the current chunk's quadrant lists (heavy path and light groups alike): every 16-lane row takes 4 entries of ITS list
+// per pass.  Round 5 -- inside a pass every vector instruction counts (profiles/r05_render_decomposition.txt):
+//   * the lists hold byte offsets into the 16-byte record arrays (slot << 4): no shift in front of the record reads, one for the 4- and 8-byte arrays;
+//   * "list position in front of the pixel's last contributor" (backward.cu:487) is ONE signed compare of the offset with a per-lane threshold;
+//   * the cross-pixel sums arrive in the lanes that add them (row_stride4_sum9_banked): no selects.
+// ---------------------------------------------------------------------------------------------
+struct alignas(16) BwdShared {
+    float4 sA[BCH + 1];                                    // staged records: mean2D, conic xx / xy (pre-scaled for exp2); slot BNULL = the null record
+    float4 sB[BCH + 1];                                    // conic yy, opacity, colour r g
+    float sC[BCH + 4];                                     // colour b  (+ 4: what follows stays 16-byte aligned)
+    double acc[NACC][BCH + 1];                             // per-round sums (f64: ds_add_f64 runs ~20x the rate of ds_add_f32 on gfx950); column BNULL swallows the padding entries
+    uint32_t sSlot[2][BCH];                                // double-buffered, like sFl: the flush of round r overlaps the staging of r+1,
+    float2 sFl[2][BCH];                                    // and these are written by the OTHER half of the workgroup: (conic yy, opacity) for the flush
+    uint2 sQ[BCH];                                         // quadrant masks of the staged entries
+    alignas(16) unsigned short lists[16][BCH + 8];         // one list per block (= per wave): slot | quadrant nibble << 10
+    alignas(16) unsigned short qlists[16][4][QL_ROW];      // per wave: the current chunk's four quadrant lists (byte offsets: slot << 4)
+};
+static_assert(offsetof(BwdShared, sSlot) < 65536 && sizeof(BwdShared) <= 80 * 1024, "k_render_bwd: records + accumulator inside a 16-bit LDS offset; two workgroups per CU");
+struct BwdPixel { float fx, fy, d0, d1, d2, tfinal_bg; int thr16; uint32_t acc_off; };   // per lane: pixel centre, dL_dpixel, T_final * (bg . dL_dpixel), threshold, byte offset of acc[pixel-of-quadrant]
+__device__ __forceinline__ void bwd_passes(const unsigned short* myq, uint32_t nq, const float4* sA, const float4* sB, const float* sC, double (*acc)[BCH + 1], uint32_t base16,
+                                           const BwdPixel& px, bool first_bank, float& T, float& arA, float vone, float vzero, const QuadMasks& qm)
+{
+    const char* cA = reinterpret_cast<const char*>(sA);
+    const char* cB = reinterpret_cast<const char*>(sB);
+    const char* cC = reinterpret_cast<const char*>(sC);
+    char* cAcc = reinterpret_cast<char*>(&acc[0][0]);
+    uint32_t jn = myq[0];                                   // the index one pass ahead (null slots behind the list's end, up to QL_ROW)
+#pragma unroll 1
+    for (uint32_t k = 0; k < nq; k += 4) {
+        const uint32_t jl16 = jn;
+        jn = myq[k + 4];
+        const uint32_t j16 = jl16 + base16;
+        const float4 a = *reinterpret_cast<const float4*>(cA + j16);       // mean2D, conic xx / xy pre-scaled for exp2 (stage_conic)
+        const float4 bb = *reinterpret_cast<const float4*>(cB + j16);      // conic yy pre-scaled, opacity, colour r g
+        const float c0 = bb.z, c1 = bb.w, c2 = *reinterpret_cast<const float*>(cC + (j16 >> 2));
+        const float dx = a.x - px.fx, dy = a.y - px.fy;
+        const float power2 = (a.z * dx + a.w * dy) * dx + (bb.x * dy) * dy;   // log2(e) * power of forward.cu:336
+        const float G = __builtin_amdgcn_exp2f(power2);
+        const float alpha = fminf(0.99f, bb.y * G);
+        // "contributor >= last_contributor" skip of backward.cu:487 as offset > threshold.  A padding entry has opacity 0 and fails the alpha test.
+        const bool valid = ((int)jl16 > px.thr16) && !(power2 > 0.0f) && !(alpha < 1.0f / 255.0f);
+        if (__builtin_amdgcn_ballot_w64(valid) == 0) continue;
+        const float aeff = valid ? alpha : 0.f;             // a skipped entry is walked as alpha = 0, G = 0
+        const float Geff = valid ? G : 0.f;
+        // the quad walks the pixel's state through the group's 4 entries (bwd_chain4s, tgs_device.hpp)
+        float Town, inv_om, Aown;
+        float sdot = c0 * px.d0;
+        sdot += c1 * px.d1; sdot += c2 * px.d2;             // dL_dpixel . colour of this entry
+        bwd_chain4s(aeff, sdot, T, arA, Town, inv_om, Aown, vone, vzero, qm);
+        // this lane's (pixel, entry) terms, backward.cu:507-555 (all zero for a skipped entry).  Everything that is constant per entry --
+        // opacity, the conic, -0.5, the ndc scale -- is applied once per entry at the flush, so a lane only forms the moments of
+        // w = G * dL_dalpha over dx, dy.
+        const float dchannel_dcolor = aeff * Town;
+        float dL_dalpha = sdot - Aown;                      // sum_ch (c_ch - accum_rec_ch) * dL_dpixel_ch
+        dL_dalpha = dL_dalpha * Town - px.tfinal_bg * inv_om;   // ... + (-T_final / (1 - alpha)) * bg_dot_dpixel
+        const float w = Geff * dL_dalpha;
+        const float wdx = w * dx, wdy = w * dy;
+        float v[NACC];
+        v[0] = dchannel_dcolor * px.d0; v[1] = dchannel_dcolor * px.d1; v[2] = dchannel_dcolor * px.d2;
+        v[3] = wdx; v[4] = wdy;
+        v[5] = wdx * dx; v[6] = wdx * dy; v[7] = wdy * dy;
+        v[8] = w;
+        float s0, s1;
+        row_stride4_sum9_banked(v, s0, s1);                 // lane (pixel i, slot e): s0 = component i, s1 = component 4 + i of entry e; v[8] complete
+        // rows whose list is shorter than the longest of the chunk idle on the null record: their sums are zero, and without this
+        // test all of them would add into the ONE spare column -- same-address LDS atomics serialise
+        if (j16 != (uint32_t)BNULL * 16u) {
+            double* p = reinterpret_cast<double*>(cAcc + px.acc_off + (j16 >> 1));
+            atomicAdd(p, (double)s0);
+            atomicAdd(p + 4 * (BCH + 1), (double)s1);
+            if (first_bank) atomicAdd(reinterpret_cast<double*>(cAcc + 8u * (BCH + 1) * 8u + (j16 >> 1)), (double)v[8]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Light groups of k_render_bwd: THREE light tiles (fewer than LIGHT_MAX instances, one round) per workgroup -- the staging arrays hold
 // BCH = 384 = 3 x 128 entries --, tile q on waves 4q .. 4q+3 (waves 12..15 only meet the barriers), wave w of a tile walking its blocks
 // 4w .. 4w+3 one after the other (the forward gives a light tile a 256-thread workgroup of its own: k_render_fwd; why light tiles are set apart: tgs_device.hpp, LIGHT_MAX).  Same arithmetic per (pixel, entry) pair, same f64
@@ -255,20 +331,23 @@ __device__ __forceinline__ void bwd_light_group(const ImgState& s, const BinStat
     stamp_if(s, tile, 2, active && lt == 0);
     const size_t N = (size_t)W * H;
     const uint32_t qmax = active ? min(td.w, n) : 0u;                  // deepest position any pixel of the tile blended (k_render_fwd wrote it into the descriptor)
-    // pixel inputs of this wave's four blocks (5 loads each, all in flight together)
-    float Tf[4], d0[4], d1[4], d2[4];
-    uint32_t lc[4];
-#pragma unroll
-    for (int bi = 0; bi < 4; bi++) {
+    // pixel inputs of a block (5 loads), asked for ONE BLOCK AHEAD: block 0's here, block bi + 1's in front of block bi's passes (round 5: all four
+    // blocks' inputs held at once were 20 VGPRs -- with the pass's own registers the light path spilled them right behind their loads)
+    struct PixIn { float Tf, d0, d1, d2; uint32_t lc; };
+    auto load_block = [&](int bi) {
         const int blk = 4 * w4 + bi;
         const int px = tx * TILE + (blk & 3) * 4 + (qd & 1) * 2 + (pq & 1);
         const int py = ty * TILE + (blk >> 2) * 4 + (qd >> 1) * 2 + (pq >> 1);
         const bool inside = active && px < W && py < H;
-        const size_t pix_id = (size_t)W * py + px;
-        Tf[bi] = inside ? s.final_T[pix_id] : 0.f;
-        lc[bi] = inside ? s.n_contrib[pix_id] : 0u;
-        d0[bi] = inside ? dL_dpix[pix_id] : 0.f; d1[bi] = inside ? dL_dpix[N + pix_id] : 0.f; d2[bi] = inside ? dL_dpix[2 * N + pix_id] : 0.f;
-    }
+        const size_t pix_id = inside ? (size_t)W * py + px : 0;          // (clamped, not predicated: the five loads are in flight together)
+        const float m = inside ? 1.f : 0.f;
+        PixIn r;
+        r.Tf = s.final_T[pix_id] * m;
+        r.lc = inside ? s.n_contrib[pix_id] : 0u;
+        r.d0 = dL_dpix[pix_id] * m; r.d1 = dL_dpix[N + pix_id] * m; r.d2 = dL_dpix[2 * N + pix_id] * m;
+        return r;
+    };
+    PixIn nxt = load_block(0);
     // rows of the never-visited tail are zero
     for (uint32_t q = qmax + lt; q < n; q += 256) {
         float4* row = b.slab + (size_t)b.slot[td.y + q] * SLAB_ROW;
@@ -299,13 +378,17 @@ __device__ __forceinline__ void bwd_light_group(const ImgState& s, const BinStat
         const int px = tx * TILE + (blk & 3) * 4 + (qd & 1) * 2 + (pq & 1);
         const int py = ty * TILE + (blk >> 2) * 4 + (qd >> 1) * 2 + (pq >> 1);
         const float pixfx = (float)px, pixfy = (float)py;
-        const float T_final = Tf[bi], dpx0 = d0[bi], dpx1 = d1[bi], dpx2 = d2[bi];
-        const uint32_t last_contributor = lc[bi];
+        const PixIn cur = nxt;
+        if (bi < 3) nxt = load_block(bi + 1);
+        asm volatile("" ::: "memory");                      // (the next block's loads stay here, in front of this block's passes)
+        const float T_final = cur.Tf, dpx0 = cur.d0, dpx1 = cur.d1, dpx2 = cur.d2;
+        const uint32_t last_contributor = cur.lc;
         float T = T_final;
         float bg_dot_dpixel = 0.f;                          // backward.cu:533-535
         bg_dot_dpixel += bgr * dpx0; bg_dot_dpixel += bgg * dpx1; bg_dot_dpixel += bgb * dpx2;
         const float tfinal_bg = T_final * bg_dot_dpixel;
         float arA = 0.f;
+        const BwdPixel pxl = {pixfx, pixfy, dpx0, dpx1, dpx2, tfinal_bg, ((int)qmax - 1 - (int)last_contributor) * 16, (uint32_t)pq * (uint32_t)((BCH + 1) * 8)};
         uint32_t qlast[4];
         {
             uint32_t m = last_contributor;
@@ -318,44 +401,8 @@ __device__ __forceinline__ void bwd_light_group(const ImgState& s, const BinStat
         const uint32_t nl = build_own_list_q<LIGHT_MAX>(lists[wv], sQ + base, qmax, blk, lane);
 #pragma unroll 1
         for (uint32_t c0 = 0; c0 < nl; c0 += QCH) {
-            const uint32_t nq = build_chunk_quadrant_lists<TGS_BWD_BOUNDED>(qlists[wv], lists[wv], c0, nl, lane, (int)null_local, qmax - 1, qlast);
-#pragma unroll 1
-            for (uint32_t k = 0; k < nq; k += 4) {          // the pass of the heavy path (backward.cu:507-555 per pair: see there)
-                const uint32_t jl = myq[k], j = jl + base;
-                const float4 a = sA[j];
-                const float4 bb = sB[j];
-                const float c0_ = bb.z, c1_ = bb.w, c2_ = sC[j];
-                const float dx = a.x - pixfx, dy = a.y - pixfy;
-                const float power2 = (a.z * dx + a.w * dy) * dx + (bb.x * dy) * dy;
-                const float G = __builtin_amdgcn_exp2f(power2);
-                const float alpha = fminf(0.99f, bb.y * G);
-                const bool valid = (qmax - 1 - jl < last_contributor) && !(power2 > 0.0f) && !(alpha < 1.0f / 255.0f);
-                if (__builtin_amdgcn_ballot_w64(valid) == 0) continue;
-                const float aeff = valid ? alpha : 0.f;
-                const float Geff = valid ? G : 0.f;
-                float Town, inv_om, Aown;
-                float sdot = c0_ * dpx0;
-                sdot += c1_ * dpx1; sdot += c2_ * dpx2;
-                bwd_chain4s(aeff, sdot, T, arA, Town, inv_om, Aown, vone, vzero, qm);
-                const float dchannel_dcolor = aeff * Town;
-                float dL_dalpha = sdot - Aown;
-                dL_dalpha = dL_dalpha * Town - tfinal_bg * inv_om;
-                const float w = Geff * dL_dalpha;
-                const float wdx = w * dx, wdy = w * dy;
-                float v[NACC];
-                v[0] = dchannel_dcolor * dpx0; v[1] = dchannel_dcolor * dpx1; v[2] = dchannel_dcolor * dpx2;
-                v[3] = wdx; v[4] = wdy;
-                v[5] = wdx * dx; v[6] = wdx * dy; v[7] = wdy * dy;
-                v[8] = w;
-                row_stride4_sum9(v);
-                const float s0 = pq == 0 ? v[0] : pq == 1 ? v[1] : pq == 2 ? v[2] : v[3];
-                const float s1 = pq == 0 ? v[4] : pq == 1 ? v[5] : pq == 2 ? v[6] : v[7];
-                if (j != (uint32_t)BNULL) {
-                    atomicAdd(&acc[pq][j], (double)s0);
-                    atomicAdd(&acc[4 + pq][j], (double)s1);
-                    if (pq == 0) atomicAdd(&acc[8][j], (double)v[8]);
-                }
-            }
+            const uint32_t nq = build_chunk_quadrant_lists<TGS_BWD_BOUNDED, 4>(qlists[wv], lists[wv], c0, nl, lane, (int)null_local, qmax - 1, qlast);
+            bwd_passes(myq, nq, sA, sB, sC, acc, base * 16u, pxl, pq == 0, T, arA, vone, vzero, qm);
         }
     }
     }
@@ -379,15 +426,10 @@ __device__ __forceinline__ void bwd_light_group(const ImgState& s, const BinStat
 __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s, const BinState b, int W, int H, uint32_t gx,
                                                             const float* __restrict__ bg, const float* __restrict__ dL_dpix, int light, uint32_t n_tiles)
 {
-    __shared__ float4 sA[BCH + 1];
-    __shared__ float4 sB[BCH + 1];
-    __shared__ float sC[BCH + 1];
-    __shared__ uint32_t sSlot[2][BCH];                     // double-buffered, like sFl: the flush of round r overlaps the staging of r+1,
-    __shared__ float2 sFl[2][BCH];                         // and these are written by the OTHER half of the workgroup: (conic yy, opacity) for the flush
-    __shared__ double acc[NACC][BCH + 1];                  // per-round sums (f64: ds_add_f64 runs ~20x the rate of ds_add_f32 on gfx950); column BNULL swallows the padding entries
-    __shared__ uint2 sQ[BCH];                              // quadrant masks of the staged entries
-    __shared__ __attribute__((aligned(16))) unsigned short lists[16][BCH + 8];   // one list per block (= per wave): slot | quadrant nibble << 10
-    __shared__ __attribute__((aligned(16))) unsigned short qlists[16][4][QL_ROW]; // per wave: the current chunk's four quadrant lists
+    // ONE object, members in the order of their use in a pass: the arrays a pass addresses (records, accumulator) sit in the first 64 KB of the
+    // workgroup's LDS, so their base is an instruction's 16-bit offset and not a VGPR (the compiler orders separate __shared__ arrays by size)
+    __shared__ BwdShared S;
+    auto& sA = S.sA; auto& sB = S.sB; auto& sC = S.sC; auto& sSlot = S.sSlot; auto& sFl = S.sFl; auto& acc = S.acc; auto& sQ = S.sQ; auto& lists = S.lists; auto& qlists = S.qlists;
 
     const uint4 td = s.tile_desc[blockIdx.x];               // (in flight beside the frame's flags)
     // candidate light tile of this thread's quarter: light group g is workgroup gridDim.x - 1 - g and takes light tiles 3 g .. 3 g + 2
@@ -481,7 +523,10 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
     __syncthreads();
     int rnd = 0;
     unsigned long long busy = 0ull;                        // (diagnostic builds only: tests/tools/timeline.py)
-    for (uint32_t qhi = qmax; qhi > 0; qhi = qhi > BCH ? qhi - BCH : 0, rnd ^= 1) {
+    // slot t of a round is list position qhi - 1 - t, blended by this pixel iff that is < last_contributor  <=>  16 t > 16 (qhi - 1 - last_contributor):
+    // the threshold of the first round, lowered by a round's worth of slots behind every round (last_contributor itself is not needed again)
+    int thr16 = ((int)qmax - 1 - (int)last_contributor) * 16;
+    for (uint32_t qhi = qmax; qhi > 0; qhi = qhi > BCH ? qhi - BCH : 0, rnd ^= 1, thr16 -= BCH * 16) {
         const uint32_t cnt = min((uint32_t)BCH, qhi);
         // The records of the round AFTER this one are asked for here, behind the barrier and in front of this round's arithmetic.  Asked for
         // in front of the barrier (until round 4) they were waited for AT it: __syncthreads() is a workgroup fence, i.e. s_waitcnt vmcnt(0)
@@ -491,57 +536,11 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
         {
             const uint32_t nl = build_own_list_q<BCH>(lists[wv], sQ, cnt, wv, lane);
             const unsigned short* myq = &qlists[wv][qd][e];
+            const BwdPixel pxl = {pixfx, pixfy, dpx0, dpx1, dpx2, tfinal_bg, thr16, (uint32_t)pq * (uint32_t)((BCH + 1) * 8)};
 #pragma unroll 1
             for (uint32_t c0 = 0; c0 < nl; c0 += QCH) {
-            const uint32_t nq = build_chunk_quadrant_lists<TGS_BWD_BOUNDED>(qlists[wv], lists[wv], c0, nl, lane, BNULL, qhi - 1, qlast);
-            uint32_t jn = myq[0];                           // the index one pass ahead (null slots behind the list's end, up to QL_ROW)
-#pragma unroll 1
-            for (uint32_t k = 0; k < nq; k += 4) {          // 4 entries of its own quadrant list per row and pass
-                const uint32_t j = jn;
-                jn = myq[k + 4];
-                const float4 a = sA[j];                     // mean2D, conic xx / xy pre-scaled for exp2 (stage_conic)
-                const float4 bb = sB[j];                    // conic yy pre-scaled, opacity, colour r g
-                const float c0 = bb.z, c1 = bb.w, c2 = sC[j];
-                const float dx = a.x - pixfx, dy = a.y - pixfy;
-                const float power2 = (a.z * dx + a.w * dy) * dx + (bb.x * dy) * dy;   // log2(e) * power of forward.cu:336
-                const float G = __builtin_amdgcn_exp2f(power2);
-                const float alpha = fminf(0.99f, bb.y * G);
-                // list position of slot j is qhi-1-j; "contributor >= last_contributor" skip of backward.cu:487.  A padding
-                // entry (j == BNULL) has opacity 0 and fails the alpha test.
-                const bool valid = (qhi - 1 - j < last_contributor) && !(power2 > 0.0f) && !(alpha < 1.0f / 255.0f);
-                if (__builtin_amdgcn_ballot_w64(valid) == 0) continue;
-                const float aeff = valid ? alpha : 0.f;     // a skipped entry is walked as alpha = 0, G = 0
-                const float Geff = valid ? G : 0.f;
-                // the quad walks the pixel's state through the group's 4 entries (bwd_chain4s, tgs_device.hpp)
-                float Town, inv_om, Aown;
-                float sdot = c0 * dpx0;
-                sdot += c1 * dpx1; sdot += c2 * dpx2;               // dL_dpixel . colour of this entry
-                bwd_chain4s(aeff, sdot, T, arA, Town, inv_om, Aown, vone, vzero, qm);
-                // this lane's (pixel, entry) terms, backward.cu:507-555 (all zero for a skipped entry).  Everything that is
-                // constant per entry -- opacity, the conic, -0.5, the ndc scale -- is applied once per entry at the flush
-                // (flush_row), so a lane only forms the moments of w = G * dL_dalpha over dx, dy.
-                const float dchannel_dcolor = aeff * Town;
-                float dL_dalpha = sdot - Aown;                     // sum_ch (c_ch - accum_rec_ch) * dL_dpixel_ch
-                dL_dalpha = dL_dalpha * Town - tfinal_bg * inv_om;      // ... + (-T_final / (1 - alpha)) * bg_dot_dpixel
-                const float w = Geff * dL_dalpha;
-                const float wdx = w * dx, wdy = w * dy;
-                float v[NACC];
-                v[0] = dchannel_dcolor * dpx0; v[1] = dchannel_dcolor * dpx1; v[2] = dchannel_dcolor * dpx2;
-                v[3] = wdx; v[4] = wdy;
-                v[5] = wdx * dx; v[6] = wdx * dy; v[7] = wdy * dy;
-                v[8] = w;
-                row_stride4_sum9(v);                        // the quadrant's 4 pixels: the 4 lanes of the row that share an entry slot
-                // every row adds for its own entries: lane (pixel i, slot e) takes components i, 4 + i (and 8 if i == 0) of entry j
-                const float s0 = pq == 0 ? v[0] : pq == 1 ? v[1] : pq == 2 ? v[2] : v[3];
-                const float s1 = pq == 0 ? v[4] : pq == 1 ? v[5] : pq == 2 ? v[6] : v[7];
-                // rows whose list is shorter than the longest of the chunk idle on the null record: their sums are zero, and without this
-                // test all of them would add into the ONE spare column -- same-address LDS atomics serialise
-                if (j != (uint32_t)BNULL) {
-                    atomicAdd(&acc[pq][j], (double)s0);
-                    atomicAdd(&acc[4 + pq][j], (double)s1);
-                    if (pq == 0) atomicAdd(&acc[8][j], (double)v[8]);
-                }
-            }
+            const uint32_t nq = build_chunk_quadrant_lists<TGS_BWD_BOUNDED, 4>(qlists[wv], lists[wv], c0, nl, lane, BNULL, qhi - 1, qlast);
+            bwd_passes(myq, nq, sA, sB, sC, acc, 0u, pxl, pq == 0, T, arA, vone, vzero, qm);
             }
         }
         busy += busy_clock() - tb0;

@@ -292,16 +292,16 @@ __device__ __forceinline__ uint32_t ql_append(uint32_t ent, uint32_t val, uint32
         : "vcc", "scc", "memory");
     return n;
 }
-// ... and only if (int)val > thr (the backward's bound: list position in front of the quadrant's deepest last contributor)
+// ... and only if (int)key > thr (the backward's bound: list position in front of the quadrant's deepest last contributor)
 template <uint32_t BITS>
-__device__ __forceinline__ uint32_t ql_append_above(uint32_t ent, uint32_t val, uint32_t base, int thr)
+__device__ __forceinline__ uint32_t ql_append_above(uint32_t ent, uint32_t key, uint32_t val, uint32_t base, int thr)
 {
     uint32_t t, r, n;
     unsigned long long sv, m;
     asm volatile(
         "v_and_b32 %[t], %[bits], %[ent]\n\t"
         "v_cmp_ne_u32 vcc, 0, %[t]\n\t"
-        "v_cmp_gt_i32 %[m], %[val], %[thr]\n\t"
+        "v_cmp_gt_i32 %[m], %[key], %[thr]\n\t"
         "s_and_b64 vcc, vcc, %[m]\n\t"
         "s_and_saveexec_b64 %[sv], vcc\n\t"
         "s_bcnt1_i32_b64 %[n], vcc\n\t"
@@ -311,7 +311,7 @@ __device__ __forceinline__ uint32_t ql_append_above(uint32_t ent, uint32_t val, 
         "ds_write_b16 %[r], %[val]\n\t"
         "s_mov_b64 exec, %[sv]\n\t"
         : [t] "=&v"(t), [r] "=&v"(r), [sv] "=&s"(sv), [m] "=&s"(m), [n] "=&s"(n)
-        : [ent] "v"(ent), [val] "v"(val), [base] "s"(base), [thr] "s"(thr), [bits] "i"(BITS)
+        : [ent] "v"(ent), [key] "v"(key), [val] "v"(val), [base] "s"(base), [thr] "s"(thr), [bits] "i"(BITS)
         : "vcc", "scc", "memory");
     return n;
 }
@@ -359,25 +359,27 @@ __device__ __forceinline__ uint32_t build_own_list_q(unsigned short* list, const
 // quadrant lists of block-list entries [c0, min(c0 + 64, n)); returns the longest list's length.  BOUNDED (backward): an entry whose
 // list position top - slot is not in front of the quadrant's deepest last contributor (bound[q]) is left out -- no pixel of the
 // quadrant blended it (backward.cu:487).
-template <bool BOUNDED = false>
+// The lists hold slot << SHIFT (null_slot << SHIFT behind the end): the backward stores byte offsets into its 16-byte record arrays (SHIFT = 4),
+// so a pass addresses its records without a shift.
+template <bool BOUNDED = false, int SHIFT = 0>
 __device__ __forceinline__ uint32_t build_chunk_quadrant_lists(unsigned short (*ql)[QL_ROW], const unsigned short* list, uint32_t c0, uint32_t n, int lane,
                                                               int null_slot, uint32_t top = 0u, const uint32_t* bound = nullptr)
 {
     const uint32_t qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr(&ql[0][0]));
-    ql_fill_null<QL_ROW>(ql, lane, null_slot);
+    ql_fill_null<QL_ROW>(ql, lane, null_slot << SHIFT);
     const uint32_t ent = c0 + lane < n ? list[c0 + lane] : 0u;
-    const uint32_t slot = ent & 1023u;
+    const uint32_t slot = ent & 1023u, val = slot << SHIFT;
     uint32_t c[4];
     if (BOUNDED) {      // top - slot < bound[q]  <=>  slot > top - bound[q]   (slot <= top < 2^31)
-        c[0] = ql_append_above<0x0400u>(ent, slot, qb, (int)top - (int)bound[0]);
-        c[1] = ql_append_above<0x0800u>(ent, slot, qb + 2u * QL_ROW, (int)top - (int)bound[1]);
-        c[2] = ql_append_above<0x1000u>(ent, slot, qb + 4u * QL_ROW, (int)top - (int)bound[2]);
-        c[3] = ql_append_above<0x2000u>(ent, slot, qb + 6u * QL_ROW, (int)top - (int)bound[3]);
+        c[0] = ql_append_above<0x0400u>(ent, slot, val, qb, (int)top - (int)bound[0]);
+        c[1] = ql_append_above<0x0800u>(ent, slot, val, qb + 2u * QL_ROW, (int)top - (int)bound[1]);
+        c[2] = ql_append_above<0x1000u>(ent, slot, val, qb + 4u * QL_ROW, (int)top - (int)bound[2]);
+        c[3] = ql_append_above<0x2000u>(ent, slot, val, qb + 6u * QL_ROW, (int)top - (int)bound[3]);
     } else {
-        c[0] = ql_append<0x0400u>(ent, slot, qb);
-        c[1] = ql_append<0x0800u>(ent, slot, qb + 2u * QL_ROW);
-        c[2] = ql_append<0x1000u>(ent, slot, qb + 4u * QL_ROW);
-        c[3] = ql_append<0x2000u>(ent, slot, qb + 6u * QL_ROW);
+        c[0] = ql_append<0x0400u>(ent, val, qb);
+        c[1] = ql_append<0x0800u>(ent, val, qb + 2u * QL_ROW);
+        c[2] = ql_append<0x1000u>(ent, val, qb + 4u * QL_ROW);
+        c[3] = ql_append<0x2000u>(ent, val, qb + 6u * QL_ROW);
     }
     return max(max(c[0], c[1]), max(c[2], c[3]));
 }
@@ -387,21 +389,22 @@ __device__ __forceinline__ uint32_t build_chunk_quadrant_lists(unsigned short (*
 // the forward has the LDS for the longer rows (the backward, at 2 x 75.6 KB per CU, does not).
 constexpr int QCH_F = 128;
 constexpr int QL_ROW_F = QCH_F + 8;
+template <int SHIFT = 0>
 __device__ __forceinline__ uint32_t build_chunk_quadrant_lists_128(unsigned short (*ql)[QL_ROW_F], const unsigned short* list, uint32_t c0, uint32_t n, int lane,
                                                                   int null_slot)
 {
     const uint32_t qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr(&ql[0][0]));
-    ql_fill_null<QL_ROW_F>(ql, lane, null_slot);
+    ql_fill_null<QL_ROW_F>(ql, lane, null_slot << SHIFT);
     uint32_t c[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         const uint32_t i = c0 + 64u * h + lane;
         const uint32_t ent = i < n ? list[i] : 0u;
-        const uint32_t slot = ent & 1023u;
-        c[0] += ql_append<0x0400u>(ent, slot, qb + 2u * c[0]);
-        c[1] += ql_append<0x0800u>(ent, slot, qb + 2u * QL_ROW_F + 2u * c[1]);
-        c[2] += ql_append<0x1000u>(ent, slot, qb + 4u * QL_ROW_F + 2u * c[2]);
-        c[3] += ql_append<0x2000u>(ent, slot, qb + 6u * QL_ROW_F + 2u * c[3]);
+        const uint32_t val = (ent & 1023u) << SHIFT;
+        c[0] += ql_append<0x0400u>(ent, val, qb + 2u * c[0]);
+        c[1] += ql_append<0x0800u>(ent, val, qb + 2u * QL_ROW_F + 2u * c[1]);
+        c[2] += ql_append<0x1000u>(ent, val, qb + 4u * QL_ROW_F + 2u * c[2]);
+        c[3] += ql_append<0x2000u>(ent, val, qb + 6u * QL_ROW_F + 2u * c[3]);
     }
     return max(max(c[0], c[1]), max(c[2], c[3]));
 }
@@ -467,18 +470,18 @@ __device__ __forceinline__ QuadMasks quad_masks()
 __device__ __forceinline__ void bwd_chain4s(float a, float s, float& T, float& A, float& Town, float& inv, float& Aown, float one, float zero, const QuadMasks& qm)
 {
     float om, m, so, t, q;
-#define TGS_STEP(K, LT, SRC, QINIT)                                                           \
+#define TGS_STEP(K, LT, SRC, SO, QSTEP)                                                       \
         "s_mov_b64 vcc, %[" #LT "]\n\t"                                                       \
-        "v_cndmask_b32_dpp %[so], %[om], %[one], vcc" TGS_QP(K)                               \
+        "v_cndmask_b32_dpp %[" #SO "], %[om], %[one], vcc" TGS_QP(K)                           \
         "v_cndmask_b32_dpp %[t], %[m], %[zero], vcc" TGS_QP(K)                                \
-        QINIT                                                                                 \
-        "v_fma_f32 %[o], %[" #SRC "], %[so], %[t]\n\t"
+        QSTEP                                                                                 \
+        "v_fma_f32 %[o], %[" #SRC "], %[" #SO "], %[t]\n\t"
     asm volatile(
         "v_sub_f32 %[om], 1.0, %[a]\n\t"
         "v_mul_f32 %[m], %[a], %[s]\n\t"
-        TGS_STEP(0, lt1, A, "v_mov_b32 %[q], %[so]\n\t")
-        TGS_STEP(1, lt2, o, "v_mul_f32 %[q], %[q], %[so]\n\t")
-        TGS_STEP(2, lt3, o, "v_mul_f32 %[q], %[q], %[so]\n\t")
+        TGS_STEP(0, lt1, A, q, "")                        // (step 0's factor IS the running product: written into q directly, round 5)
+        TGS_STEP(1, lt2, o, so, "v_mul_f32 %[q], %[q], %[so]\n\t")
+        TGS_STEP(2, lt3, o, so, "v_mul_f32 %[q], %[q], %[so]\n\t")
         "v_mul_f32 %[so], %[q], %[om]\n\t"               // prod_{k<=e} (1 - a_k)
         "v_rcp_f32 %[so], %[so]\n\t"
         "v_fma_f32 %[t], %[o], %[om], %[m]\n\t"          // state behind this lane's own entry
@@ -528,15 +531,23 @@ __device__ __forceinline__ void quad_max_bcast3(float& c, float x, float& x3)
         : [x] "v"(x));
 }
 
-// x_i <- sum of x_i over the 4 lanes {l, l+4, l+8, l+12} of each row, for 9 values: 18 v_add_f32_dpp
-__device__ __forceinline__ void row_stride4_sum9(float (&v)[9])
+// The nine sums of a pass over the quadrant's 4 pixels -- the 4 lanes {l, l+4, l+8, l+12} of a row that share an entry slot -- in 18
+// v_add_f32_dpp, delivered WHERE THEY ARE ADDED: lane (pixel i, slot e) of a row takes components i and 4 + i of entry e (and 8 if i == 0).
+// Level 1 (row_ror:4) on all nine; level 2 (row_ror:8) writes component c's total into ONE register per group of four with bank_mask
+// = the bank (lanes 4 i .. 4 i + 3: pixel i) that adds it -- the six v_cndmask that picked a lane's components out of nine full sums
+// (until round 4) are gone; v8 is complete in every lane.
+__device__ __forceinline__ void row_stride4_sum9_banked(float (&v)[9], float& s0, float& s1)
 {
-#define TGS_ROR(I, N) "v_add_f32_dpp %" #I ", %" #I ", %" #I " row_ror:" #N " row_mask:0xf bank_mask:0xf\n\t"
+#define TGS_ROR4(I) "v_add_f32_dpp %" #I ", %" #I ", %" #I " row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+#define TGS_ROR8B(D, I, B) "v_add_f32_dpp %[" #D "], %" #I ", %" #I " row_ror:8 row_mask:0xf bank_mask:" #B "\n\t"
     asm volatile("s_nop 1\n\t"
-                 TGS_ROR(0, 4) TGS_ROR(1, 4) TGS_ROR(2, 4) TGS_ROR(3, 4) TGS_ROR(4, 4) TGS_ROR(5, 4) TGS_ROR(6, 4) TGS_ROR(7, 4) TGS_ROR(8, 4)
-                 TGS_ROR(0, 8) TGS_ROR(1, 8) TGS_ROR(2, 8) TGS_ROR(3, 8) TGS_ROR(4, 8) TGS_ROR(5, 8) TGS_ROR(6, 8) TGS_ROR(7, 8) TGS_ROR(8, 8)
-                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]));
-#undef TGS_ROR
+                 TGS_ROR4(0) TGS_ROR4(1) TGS_ROR4(2) TGS_ROR4(3) TGS_ROR4(4) TGS_ROR4(5) TGS_ROR4(6) TGS_ROR4(7) TGS_ROR4(8)
+                 TGS_ROR8B(s0, 0, 0x1) TGS_ROR8B(s0, 1, 0x2) TGS_ROR8B(s0, 2, 0x4) TGS_ROR8B(s0, 3, 0x8)
+                 TGS_ROR8B(s1, 4, 0x1) TGS_ROR8B(s1, 5, 0x2) TGS_ROR8B(s1, 6, 0x4) TGS_ROR8B(s1, 7, 0x8)
+                 "v_add_f32_dpp %8, %8, %8 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), [s0] "=&v"(s0), [s1] "=&v"(s1));
+#undef TGS_ROR4
+#undef TGS_ROR8B
 }
 
 // (error, n_nonempty) of the frame's Meta in ONE load -- the render kernels need both before anything else, and as two loads with a
