@@ -465,37 +465,7 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
     const size_t pix_id = (size_t)W * py + px, N = (size_t)W * H;
     if (threadIdx.x == 0) { sA[BNULL] = make_float4(0.f, 0.f, 0.f, 0.f); sB[BNULL] = make_float4(0.f, 0.f, 0.f, 0.f); sC[BNULL] = 0.f; }
 
-    const float T_final = inside ? s.final_T[pix_id] : 0.f;
-    float T = T_final;
-    const uint32_t last_contributor = inside ? s.n_contrib[pix_id] : 0u;
-    float dpx0 = 0.f, dpx1 = 0.f, dpx2 = 0.f;
-    if (inside) { dpx0 = dL_dpix[pix_id]; dpx1 = dL_dpix[N + pix_id]; dpx2 = dL_dpix[2 * N + pix_id]; }
-    float bg_dot_dpixel = 0.f;                              // backward.cu:533-535
-    bg_dot_dpixel += bg[0] * dpx0; bg_dot_dpixel += bg[1] * dpx1; bg_dot_dpixel += bg[2] * dpx2;
-    const float tfinal_bg = T_final * bg_dot_dpixel;
-    float arA = 0.f;                                        // dL_dpixel . accum_rec with (last_alpha, last_color) already applied (bwd_chain4s)
-    float vone = 1.0f, vzero = 0.0f;                        // identity elements, pinned to VGPRs for the DPP selects
-    const QuadMasks qm = quad_masks();
-    asm volatile("" : "+v"(vone), "+v"(vzero));
-    const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);   // backward.cu:460-461
-
     const uint32_t qmax = min(td.w, n);                     // deepest position any pixel of the tile blended (k_render_fwd wrote it into the descriptor: no dependent load)
-    uint32_t qlast[4];                                      // the same per quadrant of this wave's block (wave-uniform)
-    {
-        uint32_t m = last_contributor;                      // max over the row's 4 pixels (lanes 4 apart), then one lane per row
-        m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x124, 0xf, 0xf, false));     // row_ror:4
-        m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x128, 0xf, 0xf, false));     // row_ror:8
-#pragma unroll
-        for (int q = 0; q < 4; q++) qlast[q] = (uint32_t)__builtin_amdgcn_readlane((int)m, 16 * q);
-    }
-    __syncthreads();                                        // the null record is in LDS
-
-    // rows of the never-visited tail are zero
-    for (uint32_t q = qmax + threadIdx.x; q < n; q += BWD_THREADS) {
-        float4* row = b.slab + (size_t)b.slot[rg.x + q] * SLAB_ROW;
-        row[0] = make_float4(0.f, 0.f, 0.f, 0.f); row[1] = make_float4(0.f, 0.f, 0.f, 0.f); row[2] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-
     // Register-staged prefetch of the next round, split over the two halves of the workgroup so that it costs 6 VGPRs, not 11
     // (64 VGPRs keep two workgroups per CU): thread t < BCH carries recA + the quadrant mask of entry t, thread BCH + t recB + recC + slot.
     const bool upper = threadIdx.x >= BCH;
@@ -506,14 +476,47 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
         if (!upper) { r4 = b.recA[pos]; r2 = b.qmask[pos]; }
         else { r4 = b.recB[pos]; r2 = make_uint2(__float_as_uint(b.recC[pos].x), b.slot[pos]); }
     };
+    // Everything the descriptor alone decides is asked for HERE, together: the pixel state AND the first round's records (round 5: the records were
+    // asked for behind a barrier that waited for the pixel state -- two memory round trips in a row at the head of every one of 2 900 workgroups).
+    const size_t pixc = inside ? pix_id : 0;                // (clamped, not predicated: the loads are in flight together)
+    const float inm = inside ? 1.f : 0.f;
+    const float T_final = s.final_T[pixc] * inm;
+    const uint32_t last_contributor = inside ? s.n_contrib[pixc] : 0u;
+    float dpx0 = dL_dpix[pixc] * inm, dpx1 = dL_dpix[N + pixc] * inm, dpx2 = dL_dpix[2 * N + pixc] * inm;
+    if (ht < qmax) fetch(rg.x + qmax - 1 - ht);
+    asm volatile("" ::: "memory");
+    float T = T_final;
+    float bg_dot_dpixel = 0.f;                              // backward.cu:533-535
+    bg_dot_dpixel += bg[0] * dpx0; bg_dot_dpixel += bg[1] * dpx1; bg_dot_dpixel += bg[2] * dpx2;
+    const float tfinal_bg = T_final * bg_dot_dpixel;
+    float arA = 0.f;                                        // dL_dpixel . accum_rec with (last_alpha, last_color) already applied (bwd_chain4s)
+    float vone = 1.0f, vzero = 0.0f;                        // identity elements, pinned to VGPRs for the DPP selects
+    const QuadMasks qm = quad_masks();
+    asm volatile("" : "+v"(vone), "+v"(vzero));
+    const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);   // backward.cu:460-461
+
+    uint32_t qlast[4];                                      // the deepest blended position per quadrant of this wave's block (wave-uniform)
+    {
+        uint32_t m = last_contributor;                      // max over the row's 4 pixels (lanes 4 apart), then one lane per row
+        m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x124, 0xf, 0xf, false));     // row_ror:4
+        m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x128, 0xf, 0xf, false));     // row_ror:8
+#pragma unroll
+        for (int q = 0; q < 4; q++) qlast[q] = (uint32_t)__builtin_amdgcn_readlane((int)m, 16 * q);
+    }
+    // (no barrier here: the null record, written by thread 0 above, is first read behind the staging barrier below)
+
+    // rows of the never-visited tail are zero
+    for (uint32_t q = qmax + threadIdx.x; q < n; q += BWD_THREADS) {
+        float4* row = b.slab + (size_t)b.slot[rg.x + q] * SLAB_ROW;
+        row[0] = make_float4(0.f, 0.f, 0.f, 0.f); row[1] = make_float4(0.f, 0.f, 0.f, 0.f); row[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
     auto stage = [&](int buf) {
         uint32_t h = ht;
         asm volatile("" : "+v"(h));                        // keeps the five LDS addresses from being hoisted into (spilled) VGPRs
         if (!upper) { stage_conic_a(r4); sA[h] = r4; sQ[h] = r2; }
         else { sFl[buf][h] = make_float2(r4.x, r4.y); stage_conic_b(r4); sB[h] = r4; sC[h] = __uint_as_float(r2.x); sSlot[buf][h] = r2.y; }
     };
-    if (ht < qmax) fetch(rg.x + qmax - 1 - ht);
-
     // Two barriers per round: [compute r] | flush r + zero its accumulator column + stage r+1 | [compute r+1] ...
     for (uint32_t i = threadIdx.x; i < NACC * (BCH + 1); i += BWD_THREADS) (&acc[0][0])[i] = 0.0;
     {
