@@ -17,10 +17,16 @@ c = scenes.orbit_camera(W, H, azimuth_deg=0.0)
 dL = g(scenes.upstream_gradient(W, H))
 args = (g(c.bg), g(cloud["means3D"]), e, g(cloud["opacities"]), g(cloud["scales"]), g(cloud["rotations"]), 1.0, e, g(c.viewmatrix), g(c.projmatrix),
         c.tanfovx, c.tanfovy, H, W, g(cloud["shs"]), D, g(c.campos), False, False)
+INFO = os.environ.get("STAGE_INFO") == "1"       # like the drop-in: the forward's class counts size the backward's grids (tile_bound / mid_bound)
 def frame():
-    R, color, radii, geom, binning, img = _C.rasterize_gaussians(*args)
+    kw = {}
+    if INFO:
+        R, color, radii, geom, binning, img, _, (tiles, mid) = _C.rasterize_gaussians(*args, info=True)
+        kw = dict(tile_bound=tiles, mid_bound=max(mid, 1))
+    else:
+        R, color, radii, geom, binning, img = _C.rasterize_gaussians(*args)
     _C.rasterize_gaussians_backward(args[0], args[1], radii, e, args[4], args[5], 1.0, e, args[8], args[9], c.tanfovx, c.tanfovy, dL, args[14], D, args[16],
-                                    geom, R, binning, img, False)
+                                    geom, R, binning, img, False, **kw)
     return R, img, geom, binning
 for i in range(3):
     frame()
