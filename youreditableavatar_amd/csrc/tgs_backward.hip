@@ -243,11 +243,34 @@ constexpr int BNULL = BCH;
 //   * "list position in front of the pixel's last contributor" (backward.cu:487) is ONE signed compare of the offset with a per-lane threshold;
 //   * the cross-pixel sums arrive in the lanes that add them (row_stride4_sum9_banked): no selects.
 // ---------------------------------------------------------------------------------------------
+// Per-round sums of a tile's staged entries, f64 (ds_add_f64 runs ~20x the rate of ds_add_f32 on gfx950), in 16-BYTE cells like the records, so that
+// a list's byte offset (slot << 4) addresses them without a shift: cell v[i][j] holds components i and 4 + i of entry j -- the two sums the lane
+// of pixel i of a quadrant adds (row_stride4_sum9_banked) --, cell t[j] component 8 and, in its spare half, the record's colour b (the ninth float
+// of a record; the other eight are sA / sB).  Column BNULL swallows the padding entries.
+struct AccTail { double w; float cb; uint32_t pad; };
+constexpr int ACC_PLANE = 2 * (BCH + 1) + 1;       // doubles per pixel-of-quadrant plane: an ODD number of 8-byte slots, so that the four planes' cells of one
+                                                   // entry fall into both halves of the 16-byte bank groups (with an even stride the 64 lanes' atomics used every
+                                                   // second 8-byte slot: twice the bank conflicts of the old 8-byte layout, measured + 1 us)
+struct alignas(16) BwdAcc { double v[4][ACC_PLANE]; AccTail t[BCH + 1]; };
+static_assert(sizeof(AccTail) == 16 && offsetof(BwdAcc, t) == 4 * ACC_PLANE * 8 && offsetof(BwdAcc, t) % 16 == 0, "BwdAcc: 16-byte cells");
+__device__ __forceinline__ double acc_get(const BwdAcc& A, int c, uint32_t j) { return c < 8 ? A.v[c & 3][2 * j + (c >> 2)] : A.t[j].w; }
+__device__ __forceinline__ void acc_clear(BwdAcc& A, uint32_t j)
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++) { A.v[i][2 * j] = 0.0; A.v[i][2 * j + 1] = 0.0; }
+    A.t[j].w = 0.0;
+}
+// (zero every sum of the accumulator, all threads of the workgroup; the colour halves of the tail cells are not touched)
+__device__ __forceinline__ void acc_clear_all(BwdAcc& A, uint32_t tid, uint32_t nthreads)
+{
+    double* v = &A.v[0][0];
+    for (uint32_t i = tid; i < 4u * ACC_PLANE; i += nthreads) v[i] = 0.0;
+    for (uint32_t i = tid; i < (uint32_t)(BCH + 1); i += nthreads) A.t[i].w = 0.0;
+}
 struct alignas(16) BwdShared {
     float4 sA[BCH + 1];                                    // staged records: mean2D, conic xx / xy (pre-scaled for exp2); slot BNULL = the null record
     float4 sB[BCH + 1];                                    // conic yy, opacity, colour r g
-    float sC[BCH + 4];                                     // colour b  (+ 4: what follows stays 16-byte aligned)
-    double acc[NACC][BCH + 1];                             // per-round sums (f64: ds_add_f64 runs ~20x the rate of ds_add_f32 on gfx950); column BNULL swallows the padding entries
+    BwdAcc acc;                                            // per-round sums + colour b (above)
     uint32_t sSlot[2][BCH];                                // double-buffered, like sFl: the flush of round r overlaps the staging of r+1,
     float2 sFl[2][BCH];                                    // and these are written by the OTHER half of the workgroup: (conic yy, opacity) for the flush
     uint2 sQ[BCH];                                         // quadrant masks of the staged entries
@@ -256,29 +279,25 @@ struct alignas(16) BwdShared {
 };
 static_assert(offsetof(BwdShared, sSlot) < 65536 && sizeof(BwdShared) <= 80 * 1024, "k_render_bwd: records + accumulator inside a 16-bit LDS offset; two workgroups per CU");
 struct BwdPixel { float fx, fy, d0, d1, d2, tfinal_bg; int thr16; uint32_t acc_off; };   // per lane: pixel centre, dL_dpixel, T_final * (bg . dL_dpixel), threshold, byte offset of acc[pixel-of-quadrant]
-__device__ __forceinline__ void bwd_passes(const unsigned short* myq, uint32_t nq, const float4* sA, const float4* sB, const float* sC, double (*acc)[BCH + 1], uint32_t base16,
+__device__ __forceinline__ void bwd_passes(const unsigned short* myq, uint32_t nq, const float4* sA, const float4* sB, BwdAcc& acc, uint32_t base16,
                                            const BwdPixel& px, bool first_bank, float& T, float& arA, float vone, float vzero, const QuadMasks& qm)
 {
     const char* cA = reinterpret_cast<const char*>(sA);
     const char* cB = reinterpret_cast<const char*>(sB);
-    const char* cC = reinterpret_cast<const char*>(sC);
-    char* cAcc = reinterpret_cast<char*>(&acc[0][0]);
-    uint32_t jn = myq[0];                                   // the index one pass ahead (null slots behind the list's end, up to QL_ROW)
-#pragma unroll 1
-    for (uint32_t k = 0; k < nq; k += 4) {
-        const uint32_t jl16 = jn;
-        jn = myq[k + 4];
+    char* cAcc = reinterpret_cast<char*>(&acc);
+    // One pass over the entries at list offset jl16 of every row (skipped as a whole when no lane has anything to add).
+    auto pass = [&](const uint32_t jl16) __attribute__((always_inline)) {
         const uint32_t j16 = jl16 + base16;
         const float4 a = *reinterpret_cast<const float4*>(cA + j16);       // mean2D, conic xx / xy pre-scaled for exp2 (stage_conic)
         const float4 bb = *reinterpret_cast<const float4*>(cB + j16);      // conic yy pre-scaled, opacity, colour r g
-        const float c0 = bb.z, c1 = bb.w, c2 = *reinterpret_cast<const float*>(cC + (j16 >> 2));
+        const float c0 = bb.z, c1 = bb.w, c2 = *reinterpret_cast<const float*>(cAcc + offsetof(BwdAcc, t) + offsetof(AccTail, cb) + j16);
         const float dx = a.x - px.fx, dy = a.y - px.fy;
         const float power2 = (a.z * dx + a.w * dy) * dx + (bb.x * dy) * dy;   // log2(e) * power of forward.cu:336
         const float G = __builtin_amdgcn_exp2f(power2);
         const float alpha = fminf(0.99f, bb.y * G);
         // "contributor >= last_contributor" skip of backward.cu:487 as offset > threshold.  A padding entry has opacity 0 and fails the alpha test.
         const bool valid = ((int)jl16 > px.thr16) && !(power2 > 0.0f) && !(alpha < 1.0f / 255.0f);
-        if (__builtin_amdgcn_ballot_w64(valid) == 0) continue;
+        if (__builtin_amdgcn_ballot_w64(valid) == 0) return;
         const float aeff = valid ? alpha : 0.f;             // a skipped entry is walked as alpha = 0, G = 0
         const float Geff = valid ? G : 0.f;
         // the quad walks the pixel's state through the group's 4 entries (bwd_chain4s, tgs_device.hpp)
@@ -304,11 +323,27 @@ __device__ __forceinline__ void bwd_passes(const unsigned short* myq, uint32_t n
         // rows whose list is shorter than the longest of the chunk idle on the null record: their sums are zero, and without this
         // test all of them would add into the ONE spare column -- same-address LDS atomics serialise
         if (j16 != (uint32_t)BNULL * 16u) {
-            double* p = reinterpret_cast<double*>(cAcc + px.acc_off + (j16 >> 1));
+            double* p = reinterpret_cast<double*>(cAcc + px.acc_off + j16);
             atomicAdd(p, (double)s0);
-            atomicAdd(p + 4 * (BCH + 1), (double)s1);
-            if (first_bank) atomicAdd(reinterpret_cast<double*>(cAcc + 8u * (BCH + 1) * 8u + (j16 >> 1)), (double)v[8]);
+            atomicAdd(p + 1, (double)s1);
+            if (first_bank) atomicAdd(reinterpret_cast<double*>(cAcc + offsetof(BwdAcc, t) + j16), (double)v[8]);
         }
+    };
+    // Two passes per trip, the offsets one pass ahead in alternating registers (null slots behind the list's end, up to QL_ROW): no register move
+    // and one address step per two passes.  The empty asm keeps an offset a 32-bit value: without it the compiler carries the 16-bit load through
+    // the loop and masks it with 0xffff in front of every use -- ds_read_u16 has zero-extended it already.
+    nq = (uint32_t)__builtin_amdgcn_readfirstlane((int)nq);         // (the same in every lane: the loop test is scalar)
+    uint32_t ja = myq[0];
+    asm("" : "+v"(ja));
+#pragma unroll 1
+    for (uint32_t k = 0; k < nq; k += 8) {
+        uint32_t jb = myq[k + 4];
+        asm("" : "+v"(jb));
+        pass(ja);
+        if (k + 4 >= nq) break;
+        ja = myq[k + 8];
+        asm("" : "+v"(ja));
+        pass(jb);
     }
 }
 
@@ -319,8 +354,8 @@ __device__ __forceinline__ void bwd_passes(const unsigned short* myq, uint32_t n
 // LDS accumulator and flush as the heavy path; the pixel inputs of a wave's four blocks are fetched up front.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void bwd_light_group(const ImgState& s, const BinState& b, int W, int H, uint32_t gx, const float* __restrict__ bg,
-                                                const float* __restrict__ dL_dpix, uint4 td, bool active, float4* sA, float4* sB, float* sC, uint32_t* sSlot,
-                                                double (*acc)[BCH + 1], uint2* sQ, unsigned short (*lists)[BCH + 8], unsigned short (*qlists)[4][QL_ROW])
+                                                const float* __restrict__ dL_dpix, uint4 td, bool active, float4* sA, float4* sB, uint32_t* sSlot,
+                                                BwdAcc& acc, uint2* sQ, unsigned short (*lists)[BCH + 8], unsigned short (*qlists)[4][QL_ROW])
 {
     const int sub = threadIdx.x >> 8, lt = threadIdx.x & 255;
     const int wv = threadIdx.x >> 6, w4 = wv & 3, lane = threadIdx.x & 63;
@@ -359,9 +394,9 @@ __device__ __forceinline__ void bwd_light_group(const ImgState& s, const BinStat
         if (ht < qmax) {
             const uint32_t pos = td.y + qmax - 1 - ht;
             if (!upper) { float4 r4 = b.recA[pos]; const uint2 q = b.qmask[pos]; stage_conic_a(r4); sA[base + ht] = r4; sQ[base + ht] = q; }
-            else { float4 r4 = b.recB[pos]; const float c = b.recC[pos].x; const uint32_t sl = b.slot[pos]; stage_conic_b(r4); sB[base + ht] = r4; sC[base + ht] = c; sSlot[base + ht] = sl; }
+            else { float4 r4 = b.recB[pos]; const float c = b.recC[pos].x; const uint32_t sl = b.slot[pos]; stage_conic_b(r4); sB[base + ht] = r4; acc.t[base + ht].cb = c; sSlot[base + ht] = sl; }
         }
-        for (uint32_t i = threadIdx.x; i < NACC * (BCH + 1); i += BWD_THREADS) (&acc[0][0])[i] = 0.0;
+        acc_clear_all(acc, threadIdx.x, BWD_THREADS);
     }
     __syncthreads();                                        // (the null record was written in front of the kernel's first barrier)
     float vone = 1.0f, vzero = 0.0f;
@@ -388,7 +423,7 @@ __device__ __forceinline__ void bwd_light_group(const ImgState& s, const BinStat
         bg_dot_dpixel += bgr * dpx0; bg_dot_dpixel += bgg * dpx1; bg_dot_dpixel += bgb * dpx2;
         const float tfinal_bg = T_final * bg_dot_dpixel;
         float arA = 0.f;
-        const BwdPixel pxl = {pixfx, pixfy, dpx0, dpx1, dpx2, tfinal_bg, ((int)qmax - 1 - (int)last_contributor) * 16, (uint32_t)pq * (uint32_t)((BCH + 1) * 8)};
+        const BwdPixel pxl = {pixfx, pixfy, dpx0, dpx1, dpx2, tfinal_bg, ((int)qmax - 1 - (int)last_contributor) * 16, (uint32_t)pq * (uint32_t)(ACC_PLANE * 8)};
         uint32_t qlast[4];
         {
             uint32_t m = last_contributor;
@@ -402,7 +437,7 @@ __device__ __forceinline__ void bwd_light_group(const ImgState& s, const BinStat
 #pragma unroll 1
         for (uint32_t c0 = 0; c0 < nl; c0 += QCH) {
             const uint32_t nq = build_chunk_quadrant_lists<TGS_BWD_BOUNDED, 4>(qlists[wv], lists[wv], c0, nl, lane, (int)null_local, qmax - 1, qlast);
-            bwd_passes(myq, nq, sA, sB, sC, acc, base * 16u, pxl, pq == 0, T, arA, vone, vzero, qm);
+            bwd_passes(myq, nq, sA, sB, acc, base * 16u, pxl, pq == 0, T, arA, vone, vzero, qm);
         }
     }
     }
@@ -411,12 +446,12 @@ __device__ __forceinline__ void bwd_light_group(const ImgState& s, const BinStat
         const uint32_t j = base + lt;
         const float4 a = sA[j], bb = sB[j];
         const float cxx = a.z * UNSCALE_CONIC, cxy = a.w * UNSCALE_CONIC_XY, cyy = bb.x * UNSCALE_CONIC, op = bb.y;
-        const float Sx = (float)acc[3][j], Sy = (float)acc[4][j];
+        const float Sx = (float)acc_get(acc, 3, j), Sy = (float)acc_get(acc, 4, j);
         float4* row = b.slab + (size_t)sSlot[j] * SLAB_ROW;
-        row[0] = make_float4((float)acc[0][j], (float)acc[1][j], (float)acc[2][j], op * (-Sx * cxx - Sy * cxy) * ddelx_dx);
-        const ConicHiLo c5 = conic_hilo(op, acc[5][j]), c6 = conic_hilo(op, acc[6][j]), c7 = conic_hilo(op, acc[7][j]);
+        row[0] = make_float4((float)acc_get(acc, 0, j), (float)acc_get(acc, 1, j), (float)acc_get(acc, 2, j), op * (-Sx * cxx - Sy * cxy) * ddelx_dx);
+        const ConicHiLo c5 = conic_hilo(op, acc_get(acc, 5, j)), c6 = conic_hilo(op, acc_get(acc, 6, j)), c7 = conic_hilo(op, acc_get(acc, 7, j));
         row[1] = make_float4(op * (-Sy * cyy - Sx * cxy) * ddely_dy, c5.hi, c6.hi, c7.hi);
-        row[2] = make_float4((float)acc[8][j], c5.lo, c6.lo, c7.lo);
+        row[2] = make_float4((float)acc_get(acc, 8, j), c5.lo, c6.lo, c7.lo);
     }
     stamp_if(s, tile, 3, active && lt == 0);
 }
@@ -429,7 +464,7 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
     // ONE object, members in the order of their use in a pass: the arrays a pass addresses (records, accumulator) sit in the first 64 KB of the
     // workgroup's LDS, so their base is an instruction's 16-bit offset and not a VGPR (the compiler orders separate __shared__ arrays by size)
     __shared__ BwdShared S;
-    auto& sA = S.sA; auto& sB = S.sB; auto& sC = S.sC; auto& sSlot = S.sSlot; auto& sFl = S.sFl; auto& acc = S.acc; auto& sQ = S.sQ; auto& lists = S.lists; auto& qlists = S.qlists;
+    auto& sA = S.sA; auto& sB = S.sB; auto& sSlot = S.sSlot; auto& sFl = S.sFl; auto& acc = S.acc; auto& sQ = S.sQ; auto& lists = S.lists; auto& qlists = S.qlists;
 
     const uint4 td = s.tile_desc[blockIdx.x];               // (in flight beside the frame's flags)
     // candidate light tile of this thread's quarter: light group g is workgroup gridDim.x - 1 - g and takes light tiles 3 g .. 3 g + 2
@@ -444,8 +479,8 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
         if (blockIdx.x == 0 && threadIdx.x == 0 && n_ne + n_lgroups > gridDim.x) atomicOr(&s.meta->error, META_ERR_TILE_BOUND);
         if (blockIdx.x >= n_ne) {
             if (lgroup >= n_lgroups) return;                // (uniform over the workgroup)
-            if (threadIdx.x == 0) { sA[BNULL] = make_float4(0.f, 0.f, 0.f, 0.f); sB[BNULL] = make_float4(0.f, 0.f, 0.f, 0.f); sC[BNULL] = 0.f; }
-            bwd_light_group(s, b, W, H, gx, bg, dL_dpix, tdl, lsub < (uint32_t)BWD_LIGHT_PER_WG && li < n_light, sA, sB, sC, sSlot[0], acc, sQ, lists, qlists);
+            if (threadIdx.x == 0) { sA[BNULL] = make_float4(0.f, 0.f, 0.f, 0.f); sB[BNULL] = make_float4(0.f, 0.f, 0.f, 0.f); acc.t[BNULL].cb = 0.f; }
+            bwd_light_group(s, b, W, H, gx, bg, dL_dpix, tdl, lsub < (uint32_t)BWD_LIGHT_PER_WG && li < n_light, sA, sB, sSlot[0], acc, sQ, lists, qlists);
             return;
         }
     } else check_tile_bound(s);
@@ -463,7 +498,7 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
     set_wave_priority(n);
     stamp(s, tile, 2);
     const size_t pix_id = (size_t)W * py + px, N = (size_t)W * H;
-    if (threadIdx.x == 0) { sA[BNULL] = make_float4(0.f, 0.f, 0.f, 0.f); sB[BNULL] = make_float4(0.f, 0.f, 0.f, 0.f); sC[BNULL] = 0.f; }
+    if (threadIdx.x == 0) { sA[BNULL] = make_float4(0.f, 0.f, 0.f, 0.f); sB[BNULL] = make_float4(0.f, 0.f, 0.f, 0.f); acc.t[BNULL].cb = 0.f; }
 
     const uint32_t qmax = min(td.w, n);                     // deepest position any pixel of the tile blended (k_render_fwd wrote it into the descriptor: no dependent load)
     // Register-staged prefetch of the next round, split over the two halves of the workgroup so that it costs 6 VGPRs, not 11
@@ -515,10 +550,10 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
         uint32_t h = ht;
         asm volatile("" : "+v"(h));                        // keeps the five LDS addresses from being hoisted into (spilled) VGPRs
         if (!upper) { stage_conic_a(r4); sA[h] = r4; sQ[h] = r2; }
-        else { sFl[buf][h] = make_float2(r4.x, r4.y); stage_conic_b(r4); sB[h] = r4; sC[h] = __uint_as_float(r2.x); sSlot[buf][h] = r2.y; }
+        else { sFl[buf][h] = make_float2(r4.x, r4.y); stage_conic_b(r4); sB[h] = r4; acc.t[h].cb = __uint_as_float(r2.x); sSlot[buf][h] = r2.y; }
     };
     // Two barriers per round: [compute r] | flush r + zero its accumulator column + stage r+1 | [compute r+1] ...
-    for (uint32_t i = threadIdx.x; i < NACC * (BCH + 1); i += BWD_THREADS) (&acc[0][0])[i] = 0.0;
+    acc_clear_all(acc, threadIdx.x, BWD_THREADS);
     {
         const uint32_t cnt0 = min((uint32_t)BCH, qmax);
         if (ht < cnt0) stage(0);
@@ -539,11 +574,11 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
         {
             const uint32_t nl = build_own_list_q<BCH>(lists[wv], sQ, cnt, wv, lane);
             const unsigned short* myq = &qlists[wv][qd][e];
-            const BwdPixel pxl = {pixfx, pixfy, dpx0, dpx1, dpx2, tfinal_bg, thr16, (uint32_t)pq * (uint32_t)((BCH + 1) * 8)};
+            const BwdPixel pxl = {pixfx, pixfy, dpx0, dpx1, dpx2, tfinal_bg, thr16, (uint32_t)pq * (uint32_t)(ACC_PLANE * 8)};
 #pragma unroll 1
             for (uint32_t c0 = 0; c0 < nl; c0 += QCH) {
             const uint32_t nq = build_chunk_quadrant_lists<TGS_BWD_BOUNDED, 4>(qlists[wv], lists[wv], c0, nl, lane, BNULL, qhi - 1, qlast);
-            bwd_passes(myq, nq, sA, sB, sC, acc, 0u, pxl, pq == 0, T, arA, vone, vzero, qm);
+            bwd_passes(myq, nq, sA, sB, acc, 0u, pxl, pq == 0, T, arA, vone, vzero, qm);
             }
         }
         busy += busy_clock() - tb0;
@@ -554,14 +589,13 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
             // (sA[j] is restaged by this same thread below; sB[j] by thread BCH + j, possibly already: hence sFl)
             const float4 a = sA[j]; const float2 fl = sFl[rnd][j];
             const float cxx = a.z * UNSCALE_CONIC, cxy = a.w * UNSCALE_CONIC_XY, cyy = fl.x, op = fl.y;
-            const float Sx = (float)acc[3][j], Sy = (float)acc[4][j];
+            const float Sx = (float)acc_get(acc, 3, j), Sy = (float)acc_get(acc, 4, j);
             float4* row = b.slab + (size_t)sSlot[rnd][j] * SLAB_ROW;
-            row[0] = make_float4((float)acc[0][j], (float)acc[1][j], (float)acc[2][j], op * (-Sx * cxx - Sy * cxy) * ddelx_dx);
-            const ConicHiLo c5 = conic_hilo(op, acc[5][j]), c6 = conic_hilo(op, acc[6][j]), c7 = conic_hilo(op, acc[7][j]);
+            row[0] = make_float4((float)acc_get(acc, 0, j), (float)acc_get(acc, 1, j), (float)acc_get(acc, 2, j), op * (-Sx * cxx - Sy * cxy) * ddelx_dx);
+            const ConicHiLo c5 = conic_hilo(op, acc_get(acc, 5, j)), c6 = conic_hilo(op, acc_get(acc, 6, j)), c7 = conic_hilo(op, acc_get(acc, 7, j));
             row[1] = make_float4(op * (-Sy * cyy - Sx * cxy) * ddely_dy, c5.hi, c6.hi, c7.hi);
-            row[2] = make_float4((float)acc[8][j], c5.lo, c6.lo, c7.lo);
-#pragma unroll
-            for (int k = 0; k < NACC; k++) acc[k][j] = 0.0;
+            row[2] = make_float4((float)acc_get(acc, 8, j), c5.lo, c6.lo, c7.lo);
+            acc_clear(acc, j);
         }
         if (qhi > BCH) {                                    // stage the next round (its records were prefetched into registers)
             const uint32_t qn = qhi - BCH, cntn = min((uint32_t)BCH, qn);
