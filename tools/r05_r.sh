@@ -4,4 +4,6 @@ for rep in 1 2 3; do for lib in default base; do
   echo "$lib $(timeout 120 python tools/stage_times.py 2>/dev/null < /dev/null | tail -1 | cut -c40-330)"
 done; done
 unset TGS_LIBRARY
+timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -s -k "quadrant" 2>&1 | grep "quadrants named\|passed\|failed" | head -20
 timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -2
+TGS_LIBRARY=$R/youreditableavatar_amd/lib/libtgs_raster_base.so timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -s -k "quadrant" 2>&1 | grep "quadrants named\|passed\|failed" | head -20

@@ -39,10 +39,13 @@ __device__ __forceinline__ float conic_min_on_edge(float dfix, float lo, float h
     return 0.5f * (Pfix * dfix * dfix + Pvar * t * t) + B * dfix * t;
 }
 
-// 64-bit mask of the tile's 8x8 grid of 2x2-pixel quadrants (bit 8*R + C: quadrant row R, quadrant column C) that hold a pixel the
-// splat reaches with alpha >= 1/255, i.e. with f(d) <= tau (above).  Per pixel row the pixels with
-// f <= tau are an interval in x -- f is a convex parabola in dx for fixed dy -- so 16 square roots give the exact pixel footprint
-// (widened by 0.01 px), without a loop whose trip count differs between lanes.  NaNs and non-convex conics keep every quadrant.
+// 64-bit mask of the tile's 8x8 grid of 2x2-pixel quadrants (bit 8*R + C: quadrant row R, quadrant column C) that may hold a pixel the
+// splat reaches with alpha >= 1/255, i.e. with f(d) <= tau (above).  On a pixel row the pixels with f <= tau are an interval in x -- f is a
+// convex parabola in dx for fixed dy: |dx - c(dy)| <= w(dy), c = -B dy / A, w = sqrt(2 A tau - det dy^2) / A -- so 16 square roots give the
+// pixel footprint (widened by 0.01 px) without a loop whose trip count differs between lanes.  Round 5: ONE mask per quadrant row from the
+// hull of its two pixel rows' intervals (a superset of their union: conservative; a row the footprint misses has a NaN interval and drops out
+// of fminf / fmaxf), and the row's terms as fused multiply-adds of per-splat constants: ~270 vector instructions per instance instead of ~500
+// (k_finalize is bound by exactly these).  NaNs and non-convex conics keep every quadrant.
 __device__ __forceinline__ unsigned long long quadrant_mask(float2 xy, float4 co, uint32_t tx, uint32_t ty)
 {
     const float o255 = 255.0f * co.w;
@@ -50,28 +53,25 @@ __device__ __forceinline__ unsigned long long quadrant_mask(float2 xy, float4 co
     // (culling only: the hardware's 1-ulp log / sqrt / rcp are far inside the margins, and the IEEE-exact forms cost ~10 VALU each)
     const float tau = (fmaxf(__logf(o255), 0.f) + 0.01f) * 1.001f;
     const float A = co.x, B = co.y, Cc = co.z;
-    if (!(A * Cc - B * B > 0.f && A > 0.f && Cc > 0.f)) return ~0ull;
-    // f = 1/2 A dx^2 + (B dy) dx + 1/2 C dy^2 <= tau  <=>  dx in [(-B dy - s) / A, (-B dy + s) / A], s^2 = (B dy)^2 - A (C dy^2 - 2 tau)
-    const float rA = __builtin_amdgcn_rcpf(A);
+    const float det = A * Cc - B * B;
+    if (!(det > 0.f && A > 0.f && Cc > 0.f)) return ~0ull;
+    const float rA = __builtin_amdgcn_rcpf(A), K = 2.f * A * tau, sl = -B * rA;
     const float ox = xy.x - (float)(tx * TILE), y0 = (float)(ty * TILE) - xy.y;       // mean relative to the tile; first row relative to the mean
-    unsigned long long keep = 0ull;
+    uint32_t keep[2] = {0u, 0u};
 #pragma unroll
     for (int R = 0; R < 8; R++) {
-        uint32_t m8 = 0;
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const float dy = y0 + (float)(2 * R + h), gB = B * dy;
-            const float disc = gB * gB - A * (Cc * dy * dy - 2.f * tau);
-            if (disc < 0.f) continue;                   // the row misses the footprint (a NaN falls through and keeps the row)
-            const float sq = __builtin_amdgcn_sqrtf(disc);
-            const float lo = fmaxf(ox + (-gB - sq) * rA - 0.01f, 0.f), hi = fminf(ox + (-gB + sq) * rA + 0.01f, 15.f);   // pixel columns of the tile
-            const int il = (int)ceilf(lo), ih = (int)floorf(hi);
-            if (il > ih) continue;
-            m8 |= ((2u << (ih >> 1)) - 1u) & ~((1u << (il >> 1)) - 1u);
-        }
-        keep |= (unsigned long long)m8 << (8 * R);
+        const float dy0 = y0 + (float)(2 * R), dy1 = y0 + (float)(2 * R + 1);
+        const float d0 = fmaf(-det * dy0, dy0, K), d1 = fmaf(-det * dy1, dy1, K);      // A^2 w^2 of the two pixel rows; negative: the row misses
+        const float w0 = fmaf(__builtin_amdgcn_sqrtf(d0), rA, 0.01f), w1 = fmaf(__builtin_amdgcn_sqrtf(d1), rA, 0.01f);
+        const float c0 = fmaf(sl, dy0, ox), c1 = fmaf(sl, dy1, ox);                      // the rows' interval centres, in pixel columns of the tile
+        const float lo = fmaxf(fminf(c0 - w0, c1 - w1), 0.f), hi = fminf(fmaxf(c0 + w0, c1 + w1), 15.f);   // (all NaN -> 0 .. 15: NaN keeps the row)
+        const int il = (int)ceilf(lo), ih = (int)floorf(hi);
+        const uint32_t ql = (uint32_t)il >> 1, qh = (uint32_t)ih >> 1;
+        const uint32_t m8 = (2u << qh) - (1u << ql);         // bits ql .. qh (ql <= qh wherever `some` holds)
+        const bool some = !(fmaxf(d0, d1) < 0.f) && il <= ih;
+        keep[R >> 2] |= (some ? m8 : 0u) << (8 * (R & 3));
     }
-    return keep;
+    return (unsigned long long)keep[0] | ((unsigned long long)keep[1] << 32);
 }
 // the 4x4 blocks (bit 4*by + bx) with a live quadrant
 __device__ __forceinline__ uint32_t blocks_of_quadrants(unsigned long long qm)
