@@ -17,6 +17,7 @@ Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--config 3] [--mode 
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -34,7 +35,7 @@ VALU_PEAK_GWIPS = 1228.8
 # render loops' mix (6 fma/mul + 1 DPP + 1 transcendental per 8: DPP operations issue at half rate, v_exp_f32 at a quarter)
 VALU_MEASURED_FMA_GWIPS = 955.5
 VALU_MEASURED_MIX_GWIPS = 628.4
-PROFILE_SET = "r05_c"          # profiles/<set>_{hbm,sq}_counters.json: the PMC passes the roofline object quotes (tools/profile_round.sh); only
+PROFILE_SET = "r05_d"          # profiles/<set>_{hbm,sq}_counters.json: the PMC passes the roofline object quotes (tools/profile_round.sh); only
                                # used while their csrc_sha16 equals the hash of the sources this run executes (build.source_hash)
 
 
@@ -262,6 +263,12 @@ def main():
     n_blocks_t = 3 if a.steps >= 6 else 1
     bounds = [a.steps * i // n_blocks_t for i in range(n_blocks_t + 1)]
     block_s = []
+    # The interpreter's full garbage collection walks every object torch and the scene set-up have created -- ~65 ms on the round's boxes, at a
+    # step count the allocation counters decide (tools/trainer_protocol.py <deg> 20 8: one 60-70 ms step per ~150, none with the collector off),
+    # i.e. 3 ms per step of whichever 20-step block it falls into.  Collect now and move what is alive to the permanent generation: the
+    # collector stays ON for everything the timed steps allocate.
+    gc.collect()
+    gc.freeze()
     for bi in range(n_blocks_t):
         if dist is not None:
             dist.barrier()
@@ -464,6 +471,8 @@ def secondary_workloads(a, cloud, dev, D, W, H, headline_ms):
         # drop-in path are fresh torch tensors sized by the frame's instance count) reported 0.48 instead of 0.38 ms per frame now and then
         for i in range(warm):
             fn(i)
+        gc.collect()
+        gc.freeze()                                         # (see the headline's timed region: a full collection inside a 20-call block is 3 ms per call)
         out = []
         for b in range(blocks):
             torch.cuda.synchronize()

@@ -45,6 +45,23 @@ def step(i):
 for i in range(10):
     step(i)
 torch.cuda.synchronize()
+if len(sys.argv) > 3:
+    # diagnostic: python tools/trainer_protocol.py <deg> <steps per block> <blocks> -> ms per step of every block, the slowest step of each, and
+    # the speculative forward's state behind it ([bound, consecutive misses, calls left in cool-down, tile bound, light tiles of the last frame])
+    import youreditableavatar_amd.diff_gaussian_rasterization as dgr
+    blocks, k = int(sys.argv[3]), 10
+    if os.environ.get("TP_NOGC") == "1":
+        import gc; gc.collect(); gc.disable()
+    for b in range(blocks):
+        ts = []
+        for i in range(steps):
+            torch.cuda.synchronize(); t0 = time.perf_counter(); step(k); torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3); k += 1
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(steps):
+            step(k); k += 1
+        torch.cuda.synchronize()
+        print(f"block {b}: {(time.perf_counter() - t0) / steps * 1e3:.4f} ms per step back to back; step by step: median {sorted(ts)[len(ts) // 2]:.4f}, max {max(ts):.4f}; state {list(dgr._speculation.state.values())}")
+    sys.exit(0)
 t0 = time.perf_counter()
 for i in range(steps):
     step(10 + i)
