@@ -60,7 +60,7 @@ class _Speculation:
 
     The guess is a slowly decaying maximum of the counts seen (trainers sample views in random order -- refine.py:257-266 -- so the last
     call's count alone misses on every small-to-large transition, and a miss enqueues scatter / sort / render twice) plus 15 % headroom.
-    Three misses in a row switch speculation off for that key for the next 64 calls (e.g. frames that need the host-sized overflow
+    MAX_MISSES misses in a row switch speculation off for that key for the next COOLDOWN calls (e.g. frames that need the host-sized overflow
     sort, which always miss).
 
     Round 5: the maximum decays by 0.1 % per call, not 3 %.  At 3 % the 15 % of headroom are gone five calls after the largest view, so a
