@@ -627,7 +627,10 @@ __device__ __forceinline__ double wave_sum_f64(double v)
 }
 // cn[0..2]: the conic sums (xx, xy, yy) in double from the rows' hi + lo parts (conic_hilo); a[5..7] are their fp32 roundings
 // PAIRS: two rows per trip of the lane's own loop (24 registers in flight instead of 12: the one-view kernel has them, the batch kernels have not)
-template <bool PAIRS>
+#ifndef TGS_BATCH_SLAB_ROWS
+#define TGS_BATCH_SLAB_ROWS 4
+#endif
+template <int ROWS>                                        // rows of a small splat per trip of its loop: 1, 2 or 4 (their loads issued together)
 __device__ __forceinline__ void slab_sum(bool live, uint32_t tiles_in, uint32_t off_in, const BinState& b, float (&a)[NACC], double (&cn)[3])
 {
     const int lane = threadIdx.x & 63;
@@ -655,7 +658,7 @@ __device__ __forceinline__ void slab_sum(bool live, uint32_t tiles_in, uint32_t 
 #pragma unroll
         for (int c = 0; c < 3; c++) { const double tot = wave_sum_f64(pc[c]); if (lane == src) cn[c] = tot; }
     }
-    if (!PAIRS && tiles < SLAB_COOP) {
+    if (ROWS == 1 && tiles < SLAB_COOP) {
         const float4* row = b.slab + (size_t)off * SLAB_ROW;
         for (uint32_t k = 0; k < tiles; k++, row += SLAB_ROW) {
             const float4 r0 = row[0], r1 = row[1], r2 = row[2];
@@ -663,7 +666,7 @@ __device__ __forceinline__ void slab_sum(bool live, uint32_t tiles_in, uint32_t 
             cn[0] += (double)r1.y + (double)r2.y; cn[1] += (double)r1.z + (double)r2.z; cn[2] += (double)r1.w + (double)r2.w;
         }
     }
-    if (PAIRS && tiles < SLAB_COOP) {
+    if (ROWS == 2 && tiles < SLAB_COOP) {
         // two rows per trip, their loads issued together (as in slab_sum_rgb_pre); same order of the additions
         const float4* row = b.slab + (size_t)off * SLAB_ROW;
         for (uint32_t k = 0; k < tiles; k += 2) {
@@ -676,6 +679,34 @@ __device__ __forceinline__ void slab_sum(bool live, uint32_t tiles_in, uint32_t 
             if (k + 1u < tiles) {
                 a[0] += t0.x; a[1] += t0.y; a[2] += t0.z; a[3] += t0.w; a[4] += t1.x; a[8] += t2.x;
                 cn[0] += (double)t1.y + (double)t2.y; cn[1] += (double)t1.z + (double)t2.z; cn[2] += (double)t1.w + (double)t2.w;
+            }
+        }
+    }
+    if (ROWS == 4 && tiles < SLAB_COOP) {
+        // four rows per trip (the batch kernels: a splat's rows were one memory round trip EACH in their view loop, 2.5 rows per visible splat
+        // and view at config 3); rows past the last are the last one again (a valid address: no load under a branch of its own) and are not added
+        const tgs_v4f* row = reinterpret_cast<const tgs_v4f*>(b.slab) + (size_t)off * SLAB_ROW;
+        for (uint32_t k = 0; k < tiles; k += 4) {
+            const uint32_t last = tiles - 1u;
+            const tgs_v4f* pa = row + (size_t)k * SLAB_ROW;
+            const tgs_v4f* pb = row + (size_t)min(k + 1u, last) * SLAB_ROW;
+            const tgs_v4f* pc = row + (size_t)min(k + 2u, last) * SLAB_ROW;
+            const tgs_v4f* pd = row + (size_t)min(k + 3u, last) * SLAB_ROW;
+            const tgs_v4f r0 = pa[0], r1 = pa[1], r2 = pa[2], t0 = pb[0], t1 = pb[1], t2 = pb[2], u0 = pc[0], u1 = pc[1], u2 = pc[2], w0 = pd[0], w1 = pd[1], w2 = pd[2];
+            asm volatile("" ::: "memory");
+            a[0] += r0.x; a[1] += r0.y; a[2] += r0.z; a[3] += r0.w; a[4] += r1.x; a[8] += r2.x;
+            cn[0] += (double)r1.y + (double)r2.y; cn[1] += (double)r1.z + (double)r2.z; cn[2] += (double)r1.w + (double)r2.w;
+            if (k + 1u < tiles) {
+                a[0] += t0.x; a[1] += t0.y; a[2] += t0.z; a[3] += t0.w; a[4] += t1.x; a[8] += t2.x;
+                cn[0] += (double)t1.y + (double)t2.y; cn[1] += (double)t1.z + (double)t2.z; cn[2] += (double)t1.w + (double)t2.w;
+            }
+            if (k + 2u < tiles) {
+                a[0] += u0.x; a[1] += u0.y; a[2] += u0.z; a[3] += u0.w; a[4] += u1.x; a[8] += u2.x;
+                cn[0] += (double)u1.y + (double)u2.y; cn[1] += (double)u1.z + (double)u2.z; cn[2] += (double)u1.w + (double)u2.w;
+            }
+            if (k + 3u < tiles) {
+                a[0] += w0.x; a[1] += w0.y; a[2] += w0.z; a[3] += w0.w; a[4] += w1.x; a[8] += w2.x;
+                cn[0] += (double)w1.y + (double)w2.y; cn[1] += (double)w1.z + (double)w2.z; cn[2] += (double)w1.w + (double)w2.w;
             }
         }
     }
@@ -903,7 +934,7 @@ __device__ __forceinline__ void pergauss_terms(int idx, bool live, int D, const 
     float (&dmean)[3] = t.dmean; float (&dcov)[6] = t.dcov; float (&dscale)[3] = t.dscale; float (&drot)[4] = t.drot;
     float (&coef)[16] = t.coef; float (&dRGB)[3] = t.dRGB;
     double cn[3];
-    slab_sum<false>(live, tiles_in, off_in, b, a, cn);     // convergent: the wave helps its splats that touch many tiles
+    slab_sum<TGS_BATCH_SLAB_ROWS>(live, tiles_in, off_in, b, a, cn);     // convergent: the wave helps its splats that touch many tiles
 #pragma unroll
     for (int k = 0; k < 3; k++) { dmean[k] = 0.f; dscale[k] = 0.f; dRGB[k] = 0.f; }
 #pragma unroll
@@ -1072,7 +1103,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
     const bool live = in_range && rad > 0;                  // backward.cu:156,367
     float dRGB[3] = {0.f, 0.f, 0.f};
     double cn[3];
-    slab_sum<true>(live, live ? tl : 0u, live ? of : 0u, b, a, cn);   // sum of this Gaussian's tile partials (wave-cooperative for big splats)
+    slab_sum<2>(live, live ? tl : 0u, live ? of : 0u, b, a, cn);   // sum of this Gaussian's tile partials (wave-cooperative for big splats)
     if (live) {
         {
             float cov3d[6];
