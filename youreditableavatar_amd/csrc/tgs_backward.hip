@@ -626,11 +626,6 @@ __device__ __forceinline__ double wave_sum_f64(double v)
     return v;
 }
 // cn[0..2]: the conic sums (xx, xy, yy) in double from the rows' hi + lo parts (conic_hilo); a[5..7] are their fp32 roundings
-// PAIRS: two rows per trip of the lane's own loop (24 registers in flight instead of 12: the one-view kernel has them, the batch kernels have not)
-#ifndef TGS_BATCH_SLAB_ROWS
-#define TGS_BATCH_SLAB_ROWS 4
-#endif
-template <int ROWS>                                        // rows of a small splat per trip of its loop: 1, 2 or 4 (their loads issued together)
 __device__ __forceinline__ void slab_sum(bool live, uint32_t tiles_in, uint32_t off_in, const BinState& b, float (&a)[NACC], double (&cn)[3])
 {
     const int lane = threadIdx.x & 63;
@@ -658,33 +653,10 @@ __device__ __forceinline__ void slab_sum(bool live, uint32_t tiles_in, uint32_t 
 #pragma unroll
         for (int c = 0; c < 3; c++) { const double tot = wave_sum_f64(pc[c]); if (lane == src) cn[c] = tot; }
     }
-    if (ROWS == 1 && tiles < SLAB_COOP) {
-        const float4* row = b.slab + (size_t)off * SLAB_ROW;
-        for (uint32_t k = 0; k < tiles; k++, row += SLAB_ROW) {
-            const float4 r0 = row[0], r1 = row[1], r2 = row[2];
-            a[0] += r0.x; a[1] += r0.y; a[2] += r0.z; a[3] += r0.w; a[4] += r1.x; a[8] += r2.x;
-            cn[0] += (double)r1.y + (double)r2.y; cn[1] += (double)r1.z + (double)r2.z; cn[2] += (double)r1.w + (double)r2.w;
-        }
-    }
-    if (ROWS == 2 && tiles < SLAB_COOP) {
-        // two rows per trip, their loads issued together (as in slab_sum_rgb_pre); same order of the additions
-        const float4* row = b.slab + (size_t)off * SLAB_ROW;
-        for (uint32_t k = 0; k < tiles; k += 2) {
-            const float4* ra = row + (size_t)k * SLAB_ROW;
-            const float4* rb = row + (size_t)min(k + 1u, tiles - 1u) * SLAB_ROW;
-            const float4 r0 = ra[0], r1 = ra[1], r2 = ra[2], t0 = rb[0], t1 = rb[1], t2 = rb[2];
-            asm volatile("" ::: "memory");                  // (the loads stay here: the compiler sinks the second row's into its branch)
-            a[0] += r0.x; a[1] += r0.y; a[2] += r0.z; a[3] += r0.w; a[4] += r1.x; a[8] += r2.x;
-            cn[0] += (double)r1.y + (double)r2.y; cn[1] += (double)r1.z + (double)r2.z; cn[2] += (double)r1.w + (double)r2.w;
-            if (k + 1u < tiles) {
-                a[0] += t0.x; a[1] += t0.y; a[2] += t0.z; a[3] += t0.w; a[4] += t1.x; a[8] += t2.x;
-                cn[0] += (double)t1.y + (double)t2.y; cn[1] += (double)t1.z + (double)t2.z; cn[2] += (double)t1.w + (double)t2.w;
-            }
-        }
-    }
-    if (ROWS == 4 && tiles < SLAB_COOP) {
-        // four rows per trip (the batch kernels: a splat's rows were one memory round trip EACH in their view loop, 2.5 rows per visible splat
-        // and view at config 3); rows past the last are the last one again (a valid address: no load under a branch of its own) and are not added
+    if (tiles < SLAB_COOP) {
+        // four rows per trip, their loads issued together (round 5: row by row a splat's rows were one memory round trip EACH in the batch
+        // kernels' view loop -- 2.5 rows per visible splat and view at config 3: 197 -> 181 us per 8 views --, two per trip in the one-view
+        // kernel: 60.5 -> 59.5 us); same order of the additions; rows past the last are the last one again (a valid address: no load under a branch of its own) and are not added
         const tgs_v4f* row = reinterpret_cast<const tgs_v4f*>(b.slab) + (size_t)off * SLAB_ROW;
         for (uint32_t k = 0; k < tiles; k += 4) {
             const uint32_t last = tiles - 1u;
@@ -934,7 +906,7 @@ __device__ __forceinline__ void pergauss_terms(int idx, bool live, int D, const 
     float (&dmean)[3] = t.dmean; float (&dcov)[6] = t.dcov; float (&dscale)[3] = t.dscale; float (&drot)[4] = t.drot;
     float (&coef)[16] = t.coef; float (&dRGB)[3] = t.dRGB;
     double cn[3];
-    slab_sum<TGS_BATCH_SLAB_ROWS>(live, tiles_in, off_in, b, a, cn);     // convergent: the wave helps its splats that touch many tiles
+    slab_sum(live, tiles_in, off_in, b, a, cn);     // convergent: the wave helps its splats that touch many tiles
 #pragma unroll
     for (int k = 0; k < 3; k++) { dmean[k] = 0.f; dscale[k] = 0.f; dRGB[k] = 0.f; }
 #pragma unroll
@@ -1103,7 +1075,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
     const bool live = in_range && rad > 0;                  // backward.cu:156,367
     float dRGB[3] = {0.f, 0.f, 0.f};
     double cn[3];
-    slab_sum<2>(live, live ? tl : 0u, live ? of : 0u, b, a, cn);   // sum of this Gaussian's tile partials (wave-cooperative for big splats)
+    slab_sum(live, live ? tl : 0u, live ? of : 0u, b, a, cn);   // sum of this Gaussian's tile partials (wave-cooperative for big splats)
     if (live) {
         {
             float cov3d[6];
