@@ -617,7 +617,10 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
 // lane in tile order; one on >= SLAB_COOP tiles -- a per-lane loop of thousands of dependent iterations otherwise, the
 // tail of the whole kernel on scenes with oversized splats -- is summed by the whole wave: lane l takes rows l, l + 64, ...
 // and the nine totals are formed with wave_sum.  Fixed order either way.  Call from convergent code.
-constexpr uint32_t SLAB_COOP = 128;
+#ifndef TGS_SLAB_COOP
+#define TGS_SLAB_COOP 128
+#endif
+constexpr uint32_t SLAB_COOP = TGS_SLAB_COOP;
 // (tiles, off): the Gaussian's tiles_touched and offsets of this view, fetched by the caller
 __device__ __forceinline__ double wave_sum_f64(double v)
 {
