@@ -617,10 +617,23 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
 // lane in tile order; one on >= SLAB_COOP tiles -- a per-lane loop of thousands of dependent iterations otherwise, the
 // tail of the whole kernel on scenes with oversized splats -- is summed by the whole wave: lane l takes rows l, l + 64, ...
 // and the nine totals are formed with wave_sum.  Fixed order either way.  Call from convergent code.
-#ifndef TGS_SLAB_COOP
-#define TGS_SLAB_COOP 128
-#endif
-constexpr uint32_t SLAB_COOP = TGS_SLAB_COOP;
+constexpr uint32_t SLAB_COOP = 128;
+// Round 5: the threshold is chosen per WAVE.  A wave walks its lanes' own loops as long as ANY lane has rows left (four rows = one memory round
+// trip per trip), so a few large splats among small ones set the trip count for all 64 -- and a cooperative pass is one round trip per large
+// splat.  In round trips: threshold t costs (lanes with >= t rows) + t / 4; the cheapest of 16 / 32 / 64 / 128 is taken (all lanes at 20 rows:
+// 32 -- five trips, nobody cooperates; three lanes at 50 rows among small ones: 16 -- three passes + at most four trips).  Measured with a fixed
+// threshold (tools/stage_times.py, splats x4 / x8): 128 -> 88.6 / 122.5 us, 16 -> 74.3 / 103.5 us for the one-view kernel; x1 unchanged.
+// The same lanes meet in a wave of every kernel that sums a view's rows (64 consecutive Gaussians), so all of them decide alike.
+__device__ __forceinline__ uint32_t slab_coop_threshold(uint32_t tiles)
+{
+    const uint32_t n16 = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(tiles >= 16u)), n32 = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(tiles >= 32u));
+    const uint32_t n64 = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(tiles >= 64u)), n128 = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(tiles >= SLAB_COOP));
+    uint32_t thr = SLAB_COOP, best = n128 + SLAB_COOP / 4u;
+    if (n64 + 16u < best) { best = n64 + 16u; thr = 64u; }
+    if (n32 + 8u < best) { best = n32 + 8u; thr = 32u; }
+    if (n16 + 4u < best) { best = n16 + 4u; thr = 16u; }
+    return thr;
+}
 // (tiles, off): the Gaussian's tiles_touched and offsets of this view, fetched by the caller
 __device__ __forceinline__ double wave_sum_f64(double v)
 {
@@ -636,7 +649,8 @@ __device__ __forceinline__ void slab_sum(bool live, uint32_t tiles_in, uint32_t 
 #pragma unroll
     for (int c = 0; c < NACC; c++) a[c] = 0.f;
     cn[0] = cn[1] = cn[2] = 0.0;
-    unsigned long long big = __builtin_amdgcn_ballot_w64(tiles >= SLAB_COOP);
+    const uint32_t coop = slab_coop_threshold(tiles);
+    unsigned long long big = __builtin_amdgcn_ballot_w64(tiles >= coop);
     while (big) {
         const int src = __builtin_ctzll(big);
         big &= big - 1;
@@ -656,7 +670,7 @@ __device__ __forceinline__ void slab_sum(bool live, uint32_t tiles_in, uint32_t 
 #pragma unroll
         for (int c = 0; c < 3; c++) { const double tot = wave_sum_f64(pc[c]); if (lane == src) cn[c] = tot; }
     }
-    if (tiles < SLAB_COOP) {
+    if (tiles < coop) {
         // four rows per trip, their loads issued together (round 5: row by row a splat's rows were one memory round trip EACH in the batch
         // kernels' view loop -- 2.5 rows per visible splat and view at config 3: 197 -> 181 us per 8 views --, two per trip in the one-view
         // kernel: 60.5 -> 59.5 us); same order of the additions; rows past the last are the last one again (a valid address: no load under a branch of its own) and are not added
@@ -1342,7 +1356,8 @@ __device__ __forceinline__ void slab_sum_rgb_pre(bool live, uint32_t tiles_in, u
     const int lane = threadIdx.x & 63;
     const uint32_t tiles = live ? tiles_in : 0u, off = live ? off_in : 0u;
     rgb[0] = rgb[1] = rgb[2] = 0.f;
-    unsigned long long big = __builtin_amdgcn_ballot_w64(tiles >= SLAB_COOP);
+    const uint32_t coop = slab_coop_threshold(tiles);
+    unsigned long long big = __builtin_amdgcn_ballot_w64(tiles >= coop);
     while (big) {
         const int src = __builtin_ctzll(big);
         big &= big - 1;
@@ -1352,7 +1367,7 @@ __device__ __forceinline__ void slab_sum_rgb_pre(bool live, uint32_t tiles_in, u
         const float t0 = wave_sum(p0), t1 = wave_sum(p1), t2 = wave_sum(p2);
         if (lane == src) { rgb[0] = t0; rgb[1] = t1; rgb[2] = t2; }
     }
-    if (tiles > 0u && tiles < SLAB_COOP) {
+    if (tiles > 0u && tiles < coop) {
         rgb[0] += q0.x; rgb[1] += q0.y; rgb[2] += q0.z;
         if (1u < tiles) { rgb[0] += q1.x; rgb[1] += q1.y; rgb[2] += q1.z; }
         if (2u < tiles) { rgb[0] += q2.x; rgb[1] += q2.y; rgb[2] += q2.z; }
