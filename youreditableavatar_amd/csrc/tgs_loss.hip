@@ -57,8 +57,8 @@ __global__ __launch_bounds__(1024) void k_loss_reduce(int n, const float2* __res
 // round 5: the window's neighbours read from a wave-private LDS line instead of DPP shifts (stats 111.6 -> 99.4 us but 108 VGPRs, the gradient
 // pass slower: 60.5 -> 68.8 us), and segments short enough to fill six workgroup slots per CU in one round (43 rows: 109.6 -> 115.4 us -- the
 // ten warm-up rows per segment cost more than the occupancy returns).
-// Round 5: THE SUMS TRAVEL, not the inputs (stats_row): 109.6 -> 94 us for the statistics pass at 3 x 2048 x 2048; row addresses are a scalar
-// base + one 32-bit lane offset (at_b).  L1 + SSIM value and gradient 173.9 -> 161-163 us.
+// Round 5: THE SUMS TRAVEL, not the inputs (stats_row): 109.6 -> 94-99 us for the statistics pass at 3 x 2048 x 2048; row addresses are a scalar
+// base + one 32-bit lane offset (at_b).  L1 + SSIM value and gradient 173.9 -> 161-164 us.
 // =====================================================================================================================================
 constexpr int SS_OUT = WAVE - 2 * LR;       // 54 output columns per wave
 #ifndef TGS_SS_SEG
@@ -109,7 +109,8 @@ __device__ __forceinline__ void stats_row(float x, float y, int r, const StripGe
     const float ss = x * x + y * y, xy = x * y;
     float hx = win.w[0] * x, hy = win.w[0] * y, hss = win.w[0] * ss, hxy = win.w[0] * xy;           // (w[10] = w[0])
     // (one asm piece per tap, the four chains interleaved: a DPP read is at least three instructions behind the write it depends on -- the
-    //  hazard asks for two wait states --, whatever the compiler puts between the pieces; the s_nop covers the first piece's inputs.
+    //  hazard asks for two wait states -- INSIDE a piece; every piece opens with an s_nop for whatever the compiler put in front of it, a
+    //  register copy of a running sum included: its hazard recogniser does not look into inline asm.
     //  The products are formed tap by tap, not kept for the symmetric partner: 24 products alive cost two waves per SIMD.)
 #define TGS_TAP4(NOP, W)                                                                                                              \
     {                                                                                                                                  \
@@ -120,8 +121,8 @@ __device__ __forceinline__ void stats_row(float x, float y, int r, const StripGe
                 "v_add_f32_dpp %[hq], %[hq], %[pq] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                             \
             : [hx] "+&v"(hx), [hy] "+&v"(hy), [hs] "+&v"(hss), [hq] "+&v"(hxy) : [px] "v"(px_), [py] "v"(py_), [ps] "v"(ps_), [pq] "v"(pq_)); \
     }
-    TGS_TAP4("s_nop 1\n\t", win.w[1]) TGS_TAP4("", win.w[2]) TGS_TAP4("", win.w[3]) TGS_TAP4("", win.w[4]) TGS_TAP4("", win.w[5])
-    TGS_TAP4("", win.w[4]) TGS_TAP4("", win.w[3]) TGS_TAP4("", win.w[2]) TGS_TAP4("", win.w[1]) TGS_TAP4("", win.w[0])
+    TGS_TAP4("s_nop 1\n\t", win.w[1]) TGS_TAP4("s_nop 1\n\t", win.w[2]) TGS_TAP4("s_nop 1\n\t", win.w[3]) TGS_TAP4("s_nop 1\n\t", win.w[4]) TGS_TAP4("s_nop 1\n\t", win.w[5])
+    TGS_TAP4("s_nop 1\n\t", win.w[4]) TGS_TAP4("s_nop 1\n\t", win.w[3]) TGS_TAP4("s_nop 1\n\t", win.w[2]) TGS_TAP4("s_nop 1\n\t", win.w[1]) TGS_TAP4("s_nop 1\n\t", win.w[0])
 #undef TGS_TAP4
     {   // tap 0 opens the running sums of output row r + 5 (slot (P + 10) % 11, finished and read 11 rows ago): an assignment, no zeroing pass
         const float w = win.w[0];
