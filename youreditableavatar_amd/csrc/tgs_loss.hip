@@ -57,8 +57,8 @@ __global__ __launch_bounds__(1024) void k_loss_reduce(int n, const float2* __res
 // round 5: the window's neighbours read from a wave-private LDS line instead of DPP shifts (stats 111.6 -> 99.4 us but 108 VGPRs, the gradient
 // pass slower: 60.5 -> 68.8 us), and segments short enough to fill six workgroup slots per CU in one round (43 rows: 109.6 -> 115.4 us -- the
 // ten warm-up rows per segment cost more than the occupancy returns).
-// Round 5: THE SUMS TRAVEL, not the inputs (stats_row): 109.6 -> 94-99 us for the statistics pass at 3 x 2048 x 2048; row addresses are a scalar
-// base + one 32-bit lane offset (at_b).  L1 + SSIM value and gradient 173.9 -> 161-164 us.
+// Round 5: THE SUMS TRAVEL, not the inputs (stats_row): 109.6 -> 94 us for the statistics pass at 3 x 2048 x 2048; row addresses are a scalar
+// base + one 32-bit lane offset (at_b).  L1 + SSIM value and gradient 173.9 -> 160-163 us.
 // =====================================================================================================================================
 constexpr int SS_OUT = WAVE - 2 * LR;       // 54 output columns per wave
 #ifndef TGS_SS_SEG
@@ -105,24 +105,25 @@ __device__ __forceinline__ void stats_row(float x, float y, int r, const StripGe
     // Horizontal window, round 5: the SUMS travel, not the inputs.  h = w[10] x; ten times h = shr1(h) + w[j] x (j = 9 .. 0) leaves
     // sum_j w[j] x(c - j) in lane c -- the window of output column c - 5 -- with ONE instruction per tap and map (v_add_f32_dpp; the shift
     // rides on the add) instead of a shift and a multiply-add, and the products w[j] x are six per map, not eleven: the window is symmetric
-    // (w[j] = w[10 - j], loss_utils.py:23-25) where the registers allow it (the gradient pass).
+    // (w[j] = w[10 - j], loss_utils.py:23-25).
     const float ss = x * x + y * y, xy = x * y;
-    float hx = win.w[0] * x, hy = win.w[0] * y, hss = win.w[0] * ss, hxy = win.w[0] * xy;           // (w[10] = w[0])
-    // (one asm piece per tap, the four chains interleaved: a DPP read is at least three instructions behind the write it depends on -- the
-    //  hazard asks for two wait states -- INSIDE a piece; every piece opens with an s_nop for whatever the compiler put in front of it, a
-    //  register copy of a running sum included: its hazard recogniser does not look into inline asm.
-    //  The products are formed tap by tap, not kept for the symmetric partner: 24 products alive cost two waves per SIMD.)
-#define TGS_TAP4(NOP, W)                                                                                                              \
-    {                                                                                                                                  \
-        const float w_ = (W), px_ = w_ * x, py_ = w_ * y, ps_ = w_ * ss, pq_ = w_ * xy;                                                \
-        asm(NOP "v_add_f32_dpp %[hx], %[hx], %[px] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                             \
-                "v_add_f32_dpp %[hy], %[hy], %[py] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                             \
-                "v_add_f32_dpp %[hs], %[hs], %[ps] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                             \
-                "v_add_f32_dpp %[hq], %[hq], %[pq] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                             \
-            : [hx] "+&v"(hx), [hy] "+&v"(hy), [hs] "+&v"(hss), [hq] "+&v"(hxy) : [px] "v"(px_), [py] "v"(py_), [ps] "v"(ps_), [pq] "v"(pq_)); \
-    }
-    TGS_TAP4("s_nop 1\n\t", win.w[1]) TGS_TAP4("s_nop 1\n\t", win.w[2]) TGS_TAP4("s_nop 1\n\t", win.w[3]) TGS_TAP4("s_nop 1\n\t", win.w[4]) TGS_TAP4("s_nop 1\n\t", win.w[5])
-    TGS_TAP4("s_nop 1\n\t", win.w[4]) TGS_TAP4("s_nop 1\n\t", win.w[3]) TGS_TAP4("s_nop 1\n\t", win.w[2]) TGS_TAP4("s_nop 1\n\t", win.w[1]) TGS_TAP4("s_nop 1\n\t", win.w[0])
+    float tx[LR + 1], ty[LR + 1], ts[LR + 1], tq[LR + 1];
+#pragma unroll
+    for (int j = 0; j <= LR; j++) { const float w = win.w[j]; tx[j] = w * x; ty[j] = w * y; ts[j] = w * ss; tq[j] = w * xy; }
+    float hx = tx[0], hy = ty[0], hss = ts[0], hxy = tq[0];                    // (w[10] = w[0])
+    // ONE asm block, the four chains interleaved: a DPP read is three instructions behind the write it depends on (the hazard asks for two wait
+    // states) and nothing of the compiler's can come between them -- its hazard recogniser does not look into inline asm, so the block opens
+    // with the s_nop that covers whatever was written just in front of it.  (One piece per tap with its own s_nop measured + 2 us.)
+#define TGS_TAP4(K) "v_add_f32_dpp %[hx], %[hx], %[x" #K "] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"   \
+                    "v_add_f32_dpp %[hy], %[hy], %[y" #K "] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"   \
+                    "v_add_f32_dpp %[hs], %[hs], %[s" #K "] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"   \
+                    "v_add_f32_dpp %[hq], %[hq], %[q" #K "] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    asm("s_nop 1\n\t" TGS_TAP4(1) TGS_TAP4(2) TGS_TAP4(3) TGS_TAP4(4) TGS_TAP4(5) TGS_TAP4(4) TGS_TAP4(3) TGS_TAP4(2) TGS_TAP4(1) TGS_TAP4(0)
+        : [hx] "+&v"(hx), [hy] "+&v"(hy), [hs] "+&v"(hss), [hq] "+&v"(hxy)
+        : [x0] "v"(tx[0]), [x1] "v"(tx[1]), [x2] "v"(tx[2]), [x3] "v"(tx[3]), [x4] "v"(tx[4]), [x5] "v"(tx[5]),
+          [y0] "v"(ty[0]), [y1] "v"(ty[1]), [y2] "v"(ty[2]), [y3] "v"(ty[3]), [y4] "v"(ty[4]), [y5] "v"(ty[5]),
+          [s0] "v"(ts[0]), [s1] "v"(ts[1]), [s2] "v"(ts[2]), [s3] "v"(ts[3]), [s4] "v"(ts[4]), [s5] "v"(ts[5]),
+          [q0] "v"(tq[0]), [q1] "v"(tq[1]), [q2] "v"(tq[2]), [q3] "v"(tq[3]), [q4] "v"(tq[4]), [q5] "v"(tq[5]));
 #undef TGS_TAP4
     {   // tap 0 opens the running sums of output row r + 5 (slot (P + 10) % 11, finished and read 11 rows ago): an assignment, no zeroing pass
         const float w = win.w[0];
