@@ -4,7 +4,7 @@ set -x
 # Counter passes never share a run with trace domains other than --kernel-trace (MI355X_MICROARCH.md, rocprofv3 PMC slots: 8 SQ counters or
 # FETCH_SIZE (3 TCC slots) or WRITE_SIZE (2) per pass).
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/${1:-r05_f}
+O=$R/gpurun_out/${1:-r05_g}
 mkdir -p $O
 python3 -c "import sys; sys.path.insert(0, '$R'); from youreditableavatar_amd.build import source_hash; print(source_hash())" > $O/csrc_sha16.txt   # the sources these counters belong to
 cd /tmp && export TMPDIR=/tmp

@@ -785,12 +785,17 @@ __device__ __forceinline__ void cov2d_chain_bwd_f64(float mxf, float myf, float 
     R ty = (R)vm[1] * mx + (R)vm[5] * my + (R)vm[9] * mz + (R)vm[13];
     const R tz = (R)vm[2] * mx + (R)vm[6] * my + (R)vm[10] * mz + (R)vm[14];
     const R limx = (R)(1.3f * cam.tan_fovx), limy = (R)(1.3f * cam.tan_fovy);
-    const R txtz = tx / tz, tytz = ty / tz;
+    // 1 / tz once (v_rcp_f64 + two Newton steps: full double precision for the finite tz > 0.2 of a splat that was not culled), not three IEEE
+    // divisions of ~10 double instructions each: this chain is the long pole of the batch pass's geometry half (354 double instructions per view)
+    R iz = __builtin_amdgcn_rcp(tz);
+    iz = fma(fma(-tz, iz, 1.0), iz, iz);
+    iz = fma(fma(-tz, iz, 1.0), iz, iz);
+    const R txtz = tx * iz, tytz = ty * iz;
     tx = fmin(limx, fmax(-limx, txtz)) * tz;
     ty = fmin(limy, fmax(-limy, tytz)) * tz;
     const R xg = (txtz < -limx || txtz > limx) ? 0.0 : 1.0, yg = (tytz < -limy || tytz > limy) ? 0.0 : 1.0;
     const R fx = cam.focal_x, fy = cam.focal_y;
-    const R iz = 1.0 / tz, iz2 = iz * iz, iz3 = iz2 * iz;
+    const R iz2 = iz * iz, iz3 = iz2 * iz;
     // J (rows): [fx/tz, 0, -fx tx/tz^2], [0, fy/tz, -fy ty/tz^2];  T = W J in GLM terms: T.m[c][r] of the fp32 code.  Written out:
     // t0[k] = T.m[0][k], t1[k] = T.m[1][k]  (k = 0..2): the two rows of J applied to the columns of the view rotation
     const R j00 = fx * iz, j02 = -(fx * tx) * iz2, j11 = fy * iz, j12 = -(fy * ty) * iz2;
@@ -817,12 +822,18 @@ __device__ __forceinline__ void cov2d_chain_bwd_f64(float mxf, float myf, float 
         dLa = d2i * (-cc * cc * g0 + 2 * cb * cc * g1 + (denom - ca * cc) * g2);
         dLc = d2i * (-ca * ca * g2 + 2 * ca * cb * g1 + (denom - ca * cc) * g0);
         dLb = d2i * 2 * (cb * cc * g0 - (denom + 2 * cb * cb) * g1 + ca * cb * g2);
-        dc[0] += t0[0] * t0[0] * dLa + t0[0] * t1[0] * dLb + t1[0] * t1[0] * dLc;
-        dc[3] += t0[1] * t0[1] * dLa + t0[1] * t1[1] * dLb + t1[1] * t1[1] * dLc;
-        dc[5] += t0[2] * t0[2] * dLa + t0[2] * t1[2] * dLb + t1[2] * t1[2] * dLc;
-        dc[1] += 2 * t0[0] * t0[1] * dLa + (t0[0] * t1[1] + t0[1] * t1[0]) * dLb + 2 * t1[0] * t1[1] * dLc;
-        dc[2] += 2 * t0[0] * t0[2] * dLa + (t0[0] * t1[2] + t0[2] * t1[0]) * dLb + 2 * t1[0] * t1[2] * dLc;
-        dc[4] += 2 * t0[2] * t0[1] * dLa + (t0[1] * t1[2] + t0[2] * t1[1]) * dLb + 2 * t1[1] * t1[2] * dLc;
+        // dL_dcov3D = T^T dSig T with dSig = [[dLa, dLb / 2], [dLb / 2, dLc]] (backward.cu:215-229 written out), formed through the two rows
+        // P = dSig T -- 27 double operations instead of 48; entry kl is t0[k] P0[l] + t1[k] P1[l], twice that off the diagonal
+        const R hb = 0.5 * dLb;
+        R P0[3], P1[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { P0[k] = dLa * t0[k] + hb * t1[k]; P1[k] = hb * t0[k] + dLc * t1[k]; }
+        dc[0] += t0[0] * P0[0] + t1[0] * P1[0];
+        dc[3] += t0[1] * P0[1] + t1[1] * P1[1];
+        dc[5] += t0[2] * P0[2] + t1[2] * P1[2];
+        dc[1] += 2 * (t0[0] * P0[1] + t1[0] * P1[1]);
+        dc[2] += 2 * (t0[0] * P0[2] + t1[0] * P1[2]);
+        dc[4] += 2 * (t0[1] * P0[2] + t1[1] * P1[2]);
     }
     // dL_dT (backward.cu:231-242): dT0[k] = 2 (V t0)[k] dLa + (V t1)[k] dLb,  dT1[k] = 2 (V t1)[k] dLc + (V t0)[k] dLb
     R dT0[3], dT1[3];
