@@ -237,11 +237,14 @@ def main():
                 rasterize(v)[0].backward(dL)
         flat.all_reduce()
 
-    for s in range(a.warmup):
-        step(s)
+    # per-stage times FIRST: one untimed pass with events around every stage (each event costs queue time, so the timed region below keeps
+    # only the events of the dominant kernel -- the one the roofline object reports) on ONE stream.  Until round 5 this pass stood between the
+    # warm-up and the timed blocks, and the first block was the slow one in every line (1.86-1.89 ms against 1.72-1.74 for the other two: the
+    # stream pools of the caching allocator and the speculation state had last seen the one-stream pass) -- a second hiccup in one of the other
+    # two blocks then made that block the median (one line in six: 892 Gfrag/s between 946 and 979).  Now the W warm-up steps run directly in
+    # front of the K timed ones, in the configuration that is timed.
+    step(0)
     torch.cuda.synchronize()
-    # per-stage times: one untimed pass with events around every stage (each event costs queue time, so the timed
-    # region below keeps only the events of the dominant kernel -- the one the roofline object reports)
     _C.profile_begin(max(a.warmup, 2) * VPG * 8 + 64)
     if batch is not None:
         batch.streams = 1                                    # one stream: every kernel has the GPU to itself
@@ -253,6 +256,16 @@ def main():
     prof_all = _C.profile_end()
     kern = {k: (ms / max(n, 1)) for k, (ms, n) in prof_all.items() if n > 0}
     dom = max(kern, key=lambda k: prof_all[k][0]) if kern else None          # most time per step (a batched kernel runs once per step)
+    # The interpreter's full garbage collection walks every object torch and the scene set-up have created -- ~65 ms on the round's boxes, at a
+    # step count the allocation counters decide (tools/trainer_protocol.py <deg> 20 8: one 60-70 ms step per ~150, none with the collector off),
+    # i.e. 3 ms per step of whichever block it falls into.  Collect now and move what is alive to the permanent generation: the collector stays
+    # ON for everything the steps allocate.  In FRONT of the warm-up: the collection is a host-side gap of that length, and the GPU should come
+    # to the timed blocks from the warm-up steps, not from idling.
+    gc.collect()
+    gc.freeze()
+    for s in range(a.warmup):
+        step(s)
+    torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     # The timed region carries NO instrumentation: a HIP event around a kernel is a barrier packet in its queue, and the two events per launch
@@ -263,12 +276,7 @@ def main():
     n_blocks_t = 3 if a.steps >= 6 else 1
     bounds = [a.steps * i // n_blocks_t for i in range(n_blocks_t + 1)]
     block_s = []
-    # The interpreter's full garbage collection walks every object torch and the scene set-up have created -- ~65 ms on the round's boxes, at a
-    # step count the allocation counters decide (tools/trainer_protocol.py <deg> 20 8: one 60-70 ms step per ~150, none with the collector off),
-    # i.e. 3 ms per step of whichever 20-step block it falls into.  Collect now and move what is alive to the permanent generation: the
-    # collector stays ON for everything the timed steps allocate.
-    gc.collect()
-    gc.freeze()
+
     for bi in range(n_blocks_t):
         if dist is not None:
             dist.barrier()
@@ -469,10 +477,10 @@ def secondary_workloads(a, cloud, dev, D, W, H, headline_ms):
     def timed(fn, n, warm, blocks=3):
         # median of `blocks` timed blocks of n calls: a block that happens to contain an allocator miss (the per-frame state buffers of the
         # drop-in path are fresh torch tensors sized by the frame's instance count) reported 0.48 instead of 0.38 ms per frame now and then
-        for i in range(warm):
-            fn(i)
         gc.collect()
-        gc.freeze()                                         # (see the headline's timed region: a full collection inside a 20-call block is 3 ms per call)
+        gc.freeze()                                         # (see the headline's timed region: a full collection inside a 20-call block is 3 ms per call;
+        for i in range(warm):                               #  in front of the warm-up, so that the GPU comes to the first block from work, not from idling)
+            fn(i)
         out = []
         for b in range(blocks):
             torch.cuda.synchronize()
