@@ -840,7 +840,7 @@ def test_run_views_at_the_benchmark_configuration(gpu_device):
             tol[key[n] + "_sum"] = max(util.REL_TOL, 2.0 * util.rel_l2(ref_sum, f64_sum))
         off += k
     util.record_parity("config4_two_view_batch_vs_oracle_sum", rep)
-    print({k: f"{v:.2e}" for k, v in rep.items()})
+    print({k: (f"{v:.2e}" if isinstance(v, float) else v) for k, v in rep.items()})
     for k, v in rep.items():
         assert v <= tol.get(k, util.REL_TOL), (k, v, tol.get(k))
 

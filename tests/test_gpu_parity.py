@@ -50,6 +50,7 @@ def test_mid_size_golden(name, gpu_device):
     (20_000, 320, 200, 3, "sh", "scale_rot", 2.0),
     (20_000, 300, 300, 2, "precomp", "scale_rot", 3.0),
     (5_000, 200, 120, 3, "sh", "cov3d", 4.0),
+    (4_000, 320, 240, 1, "sh", "scale_rot", 8.0),        # splats on 16 .. 127 tiles: every per-wave threshold of the slab sums' cooperative pass (round 5)
 ])
 def test_vs_oracle_seeded(P, W, H, deg, mode, cov_mode, scale_mult, gpu_device):
     from youreditableavatar_amd import scenes
@@ -65,7 +66,7 @@ def test_vs_oracle_seeded(P, W, H, deg, mode, cov_mode, scale_mult, gpu_device):
     rep = util.compare(mine, ref)
     if (P, W, H, deg) == (10_000, 256, 256, 0):
         util.record_parity("cfg1", rep, extra=dict(num_rendered=int(mine["num_rendered"]), num_rendered_reference=int(ref["num_rendered"])))
-    print({k: f"{v:.2e}" for k, v in rep.items()})
+    print({k: (f"{v:.2e}" if isinstance(v, float) else v) for k, v in rep.items()})
 
 
 def test_spatially_ordered_cloud_vs_oracle(gpu_device):
@@ -109,7 +110,7 @@ def test_tile_grid_beyond_one_lds_table(gpu_device):
     r = ref["ranges"].reshape(-1, 2)
     assert len(r) > 24576 and (r[24576:, 1] > r[24576:, 0]).sum() > 500       # the second band holds instances
     assert rep["lists_equal"] == 1.0
-    print({k: f"{v:.2e}" for k, v in rep.items()})
+    print({k: (f"{v:.2e}" if isinstance(v, float) else v) for k, v in rep.items()})
 
 
 def test_backward_is_bitwise_reproducible(gpu_device):
