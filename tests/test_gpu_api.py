@@ -202,7 +202,7 @@ def test_baseline_config_full_size_vs_oracle(cfg, gpu_device):
     ref = util.oracle_run(inp, dL)
     rep = util.compare(mine, ref)
     util.record_parity(f"cfg{cfg}", rep, extra=dict(num_rendered=int(mine["num_rendered"]), num_rendered_reference=int(ref["num_rendered"])))
-    print(cfg, {k: f"{v:.2e}" for k, v in rep.items()})
+    print(cfg, {k: (f"{v:.2e}" if isinstance(v, float) else v) for k, v in rep.items()})
 
 
 @pytest.mark.parametrize("scale_mult", [4.0, 6.0])
@@ -221,7 +221,7 @@ def test_large_splats_full_size_vs_oracle(scale_mult, gpu_device):
     tt = ref["tiles_touched"]
     assert ((tt > 4) & (tt <= 64)).mean() > 0.2 and (scale_mult < 6 or (tt > 64).sum() > 100)      # the paths are really taken
     rep = util.compare(mine, ref)
-    print(scale_mult, mine["num_rendered"], ref["num_rendered"], {k: f"{v:.2e}" for k, v in rep.items() if k in ("color", "instances_dropped", "n_contrib_equal", "dL_dmeans2D")})
+    print(scale_mult, mine["num_rendered"], ref["num_rendered"], {k: (f"{v:.2e}" if isinstance(v, float) else v) for k, v in rep.items() if k in ("color", "instances_dropped", "n_contrib_equal", "dL_dmeans2D")})
 
 
 def test_config5_overflow_stress_vs_oracle(gpu_device):
@@ -257,7 +257,7 @@ def test_config5_overflow_stress_vs_oracle(gpu_device):
     rep = util.compare(a, ref)
     util.record_parity("cfg5", rep, extra=dict(longest_list=int(lens.max()), lists_beyond_lds_sort=int((lens > 8192).sum()), num_rendered=int(a["num_rendered"]),
                                                num_rendered_reference=int(ref["num_rendered"])))
-    print(5, {k: f"{v:.2e}" for k, v in rep.items()})
+    print(5, {k: (f"{v:.2e}" if isinstance(v, float) else v) for k, v in rep.items()})
 
 
 def test_fused_accumulate_equals_autograd_sum(gpu_device):

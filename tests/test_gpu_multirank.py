@@ -90,7 +90,7 @@ if ACT is not None:
 t = lambda a, rg=False: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev).requires_grad_(rg)
 names = ("means3D", "opacities", "scales", "rotations", "shs")
 L = {n: t(cloud[n], True) for n in names}
-flat = FlatGradients([L[n] for n in names])
+flat = FlatGradients([L[n] for n in names], sh_params={4: 0})
 cams = [scenes.orbit_camera(W, H, azimuth_deg=a) for a in np.linspace(0.0, 300.0, V)]
 settings = [GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=c.tanfovx, tanfovy=c.tanfovy, bg=t(c.bg), scale_modifier=1.0,
                                           viewmatrix=t(c.viewmatrix), projmatrix=t(c.projmatrix), sh_degree=D, campos=t(c.campos), prefiltered=False, debug=False)

@@ -16,7 +16,7 @@ def test_golden(name, gpu_device):
     ref = dict(gold)
     ref["n_contrib"] = gold["n_contrib"].reshape(H, W)
     rep = util.compare(mine, ref, gold)
-    print(name, {k: f"{v:.2e}" for k, v in rep.items()})
+    print(name, {k: (f"{v:.2e}" if isinstance(v, float) else v) for k, v in rep.items()})
     # per-Gaussian intermediates of visible Gaussians
     vis = gold["radii"] > 0
     assert util.rel_l2(mine["means2D"][vis], gold["means2D"][vis]) <= 1e-6
@@ -42,7 +42,7 @@ def test_mid_size_golden(name, gpu_device):
     mine = util.hip_run(inp, dL)
     rep.update(util.compare_mid(mine, fx, exact_lists=False))
     util.record_parity(name, rep)
-    print(name, {k: f"{v:.2e}" for k, v in rep.items()})
+    print(name, {k: (f"{v:.2e}" if isinstance(v, float) else v) for k, v in rep.items()})
 
 
 @pytest.mark.parametrize("P,W,H,deg,mode,cov_mode,scale_mult", [
@@ -320,7 +320,7 @@ def test_hip_vs_independent_fp64_autograd(mode, seed, gpu_device):
         rep[a] = util.rel_l2(mine[a], ref[b])
     rep["dL_dmeans2D"] = util.rel_l2(mine["dL_dmeans2D"][:, :2], ref["grad_means2D"][:, :2])
     util.record_parity(f"fp64_autograd_{mode}_{name}", rep)
-    print(mode, {k: f"{v:.2e}" for k, v in rep.items()})
+    print(mode, {k: (f"{v:.2e}" if isinstance(v, float) else v) for k, v in rep.items()})
     for k, v in rep.items():
         assert v <= util.REL_TOL, (k, v)
 
@@ -361,6 +361,52 @@ def test_cutoff_flip_scenes_are_the_reference_with_one_decision_taken_the_other_
     util.record_parity(f"cutoff_flip_seed{seed}_scene{scene}", {"vs_fp32_oracle": direct, f"vs_{flipped}": same})
     print(desc, tensor, f"vs fp32 oracle {direct:.2e}, vs {flipped} {same:.2e}")
     assert same <= bound and same < 0.5 * direct, (desc, same, direct)
+
+
+@pytest.mark.xfail(strict=True, reason="round 5's one recorded miss of the frozen criterion: dL_dcov3D of ONE needle splat at 3.2 eta (profiles/r05_fuzz_soak_d.txt)")
+def test_known_miss_seed94_scene71_is_still_the_recorded_one(gpu_device):
+    """Fuzz seed 94, scene 71 (428 Gaussians, 270 x 219, splats x 8): since round 5's pass trim of k_render_bwd (another pairing of the fp32
+    additions in a pass's four-pixel sums) dL_dcov3D of Gaussian 394 -- conic determinant 1.9e-4 -- sits 1.9e-4 from the fp32 oracle where the
+    bar is 2 eta = 1.17e-4.  Kept as a STRICT expected failure: a kernel change that clears the scene turns this test red (update the record), and
+    the second assertion keeps a change that makes it WORSE from hiding behind the xfail (it raises outside the expected assertion: an error)."""
+    from tests import fuzz
+    rng = np.random.default_rng(94)
+    for it in range(72):
+        desc, inp, dL = fuzz.random_scene(rng, it)
+    ref = util.oracle_run(inp, dL)
+    mine = util.hip_run(inp, dL)
+    d = util.rel_l2(np.asarray(mine["dL_dcov3D"]).reshape(np.asarray(ref["dL_dcov3D"]).shape), ref["dL_dcov3D"])
+    util.record_parity("known_miss_seed94_scene71", {"dL_dcov3D_vs_fp32_oracle": d})
+    print(desc, f"dL_dcov3D vs fp32 oracle {d:.3e} (round 5: 1.875e-4)")
+    if d > 4e-4:                                          # more than twice the recorded distance: not the recorded miss any more
+        raise RuntimeError(f"seed 94 scene 71 got worse: dL_dcov3D {d:.3e} from the fp32 oracle (recorded 1.875e-4)")
+    util.compare(mine, ref)                               # the expected failure: AssertionError from the frozen criterion
+
+
+def test_nonfinite_upstream_gradient_stays_with_the_splats_that_cover_its_pixel(gpu_device):
+    """ADVICE of round 5: the per-pixel backward loads the inputs of a tile's padding lanes (W or H not a multiple of 16) from a clamped address
+    -- pixel (0, 0) -- and used to zero them with a multiplication: 0 * NaN = NaN, so a non-finite dL_dpixel at (0, 0) reached every splat on the
+    right / bottom edge tiles.  With a select, and in the reference, only splats that blend into pixel (0, 0) see it."""
+    from youreditableavatar_amd import scenes
+    W, H = 150, 90                                        # neither a multiple of 16: both edges have padding lanes
+    cloud = scenes.make_cloud(4000, 1, seed=5, scale_mult=2.0)
+    cam = scenes.orbit_camera(W, H, azimuth_deg=20.0)
+    inp = util.scene_input(cloud, cam, "sh")
+    dL = scenes.upstream_gradient(W, H, seed=3)
+    clean = util.hip_run(inp, dL)
+    dLn = dL.copy(); dLn[:, 0, 0] = np.nan
+    for lt in (False, True):
+        bad = util.hip_run(inp, dLn, light_tiles=lt)
+        ref = util.oracle_run(inp, dLn)
+        hit = ~np.isfinite(np.asarray(ref["dL_dopacity"]).reshape(-1))
+        mine_hit = ~np.isfinite(np.asarray(bad["dL_dopacity"]).reshape(-1))
+        # splats whose instance in tile 0 lies in front of pixel (0, 0)'s last contributor may differ by the pruned / quadrant-culled instances: the
+        # HIP path must not poison MORE than the reference does, and everything else must be the clean run's value
+        assert not np.any(mine_hit & ~hit), f"{int((mine_hit & ~hit).sum())} splats poisoned beyond the reference's {int(hit.sum())} (light_tiles={lt})"
+        ok = ~hit
+        for k in ("dL_dopacity", "dL_dmeans2D", "dL_dconic"):
+            a = np.asarray(bad[k]).reshape(len(hit), -1)[ok]; b = np.asarray(clean[k]).reshape(len(hit), -1)[ok]
+            assert np.all(np.isfinite(a)) and util.rel_l2(a, b) <= 1e-5, (k, lt)
 
 
 @pytest.mark.parametrize("P,W,H,deg,mode,scale_mult", [(20_000, 320, 200, 3, "sh", 1.0), (60_000, 500, 333, 1, "precomp", 2.0), (3_000, 100, 60, 2, "sh", 6.0)])

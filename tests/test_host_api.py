@@ -183,6 +183,18 @@ def test_tile_bound_policy(monkeypatch):
     assert sp2.light_tiles(key) is False
     sp2.update(key, 1_500_000, None, tiles=9000, tile_guess=0, mid_tiles=2500)
     assert sp2.light_tiles(key) is True
+    # one outlier view must not hold the binning buffer at its size for thousands of calls (ADVICE of round 5): after FAR_CALLS calls below
+    # half of the bound it falls to twice the largest of them; a camera set whose counts stay within a factor of two of the bound keeps it
+    sp3 = _Speculation()
+    sp3.update(key, 3_000_000, None)
+    for _ in range(sp3.FAR_CALLS - 1):
+        sp3.update(key, 700_000, sp3.guess(key))
+    assert sp3.state[key][0] > 2_500_000
+    sp3.update(key, 700_000, sp3.guess(key))
+    assert 1_390_000 <= sp3.state[key][0] <= 1_400_000 and sp3.guess(key) >= 1_390_000 * 1.15
+    for _ in range(3 * sp3.FAR_CALLS):
+        sp3.update(key, 800_000, sp3.guess(key))
+    assert sp3.state[key][0] > 1_100_000                 # 800 k is not below half of the bound: only the slow decay applies
 
 
 def test_deferred_backward_rejects_mixed_batches():

@@ -52,7 +52,7 @@ def _step(rank, world, port, out_q, stored_degree=1, active_degree=None):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     cloud, cams, dLs = _scene(stored_degree)
     params = _params(cloud)
-    grads = multiview.FlatGradients(params)
+    grads = multiview.FlatGradients(params, sh_params={4: 0})
     deg = cloud["sh_degree"] if active_degree is None else active_degree
     mine = multiview.render_batch_sharded(lambda v: OracleRasterize.apply(*params, cams[v], deg),
                                           lambda v, img: torch.from_numpy(dLs[v]), len(cams), grads, sh_degree=active_degree)
@@ -111,7 +111,7 @@ def test_sharded_step_with_live_sh_rows_only_equals_unsharded_sum(active):
         assert p.exitcode == 0
     cloud, cams, dLs = _scene(3)
     params = _params(cloud)
-    grads = multiview.FlatGradients(params)
+    grads = multiview.FlatGradients(params, sh_params={4: 0})
     multiview.render_batch_sharded(lambda v: OracleRasterize.apply(*params, cams[v], active),
                                    lambda v, img: torch.from_numpy(dLs[v]), len(cams), grads, rank=0, world_size=1)
     ref = grads.flat.numpy()
@@ -155,7 +155,8 @@ def _rows_step(rank, world, port, out_q, sh_degree=None):
     params = [torch.zeros(P, 3, requires_grad=True), torch.zeros(P, 1, requires_grad=True), torch.zeros(P, 16, 3, requires_grad=True)]
     if sh_degree is not None:                            # the model's own two SH parameters as well (tetgs_model.py:234-239)
         params += [torch.zeros(P, 1, 3, requires_grad=True), torch.zeros(P, 15, 3, requires_grad=True)]
-    fg = multiview.FlatGradients(params)
+        params += [torch.zeros(P, 4, 3, requires_grad=True)]   # looks like SH by its shape, is not named as SH: reduced whole (ADVICE of round 5)
+    fg = multiview.FlatGradients(params, sh_params=None if sh_degree is None else {2: 0, 3: 0, 4: 1})
     g = torch.Generator().manual_seed(7 + rank)
     fg.flat.copy_(torch.randn(fg.flat.numel(), generator=g))
     if sh_degree is not None:                            # coefficients above the active degree have zero gradient on every rank
@@ -209,10 +210,21 @@ def test_all_reduce_of_live_sh_rows_by_ranges(deg):
 
 
 def test_sh_live_rule():
+    """SH parameters are NAMED by the caller (sh_params: index -> first coefficient); nothing is inferred from shapes"""
     from youreditableavatar_amd.multiview import FlatGradients as F
-    assert F._sh_live((10, 16, 3), 0) == 1 and F._sh_live((10, 16, 3), 1) == 4 and F._sh_live((10, 16, 3), 2) == 9 and F._sh_live((10, 16, 3), 3) is None
-    assert F._sh_live((10, 15, 3), 0) == 0 and F._sh_live((10, 15, 3), 1) == 3 and F._sh_live((10, 15, 3), 3) is None
-    assert F._sh_live((10, 1, 3), 0) is None and F._sh_live((10, 3), 0) is None and F._sh_live((10, 4), 0) is None and F._sh_live((10, 16, 3), None) is None
+    z = lambda *sh: torch.zeros(*sh, requires_grad=True)
+    fg = F([z(10, 16, 3), z(10, 1, 3), z(10, 15, 3), z(10, 3, 3), z(10, 4, 3), z(10, 8, 3), z(10, 3)], sh_params={0: 0, 1: 0, 2: 1})
+    assert [fg._sh_live(0, d) for d in (0, 1, 2, 3)] == [1, 4, 9, None]
+    assert [fg._sh_live(1, d) for d in (0, 1, 2, 3)] == [None, None, None, None]          # the dc tensor: its one coefficient is always live
+    assert [fg._sh_live(2, d) for d in (0, 1, 2, 3)] == [0, 3, 8, None]
+    for i in (3, 4, 5, 6):                               # [P,3,3] / [P,4,3] / [P,8,3] parameters that are not SH: every entry is live at every degree
+        assert all(fg._sh_live(i, d) is None for d in (0, 1, 2, 3))
+    assert fg._sh_live(0, None) is None
+    assert fg.reduced_bytes(sh_degree=0) == 10 * 4 * (3 + 3 + 0 + 9 + 12 + 24 + 3)
+    with pytest.raises(ValueError):
+        F([z(10, 16, 3)])._sh_live(0, 0)                 # an active degree without named SH parameters is an error, not a guess
+    with pytest.raises(ValueError):
+        F([z(10, 3)], sh_params={0: 0})                  # not a [P, M, 3] tensor
 
 
 def test_row_slices_cover_the_flat_buffer_once():

@@ -40,7 +40,7 @@ def test_oracle_matches_mid_size_golden(name):
     # between the emulation's own two builds (FMA contraction on / off: n_contrib equal on 0.999998 of the pixels)
     rep = util.compare_mid(mine, fx, exact_lists=True, nc_frac=0.99999, list_frac=0.995)
     assert name == "m03_cfg3_1080p" or (rep["n_contrib_equal"] == 1.0 and rep["tile_lists_equal"] >= 0.999)
-    print(name, {k: f"{v:.2e}" for k, v in rep.items()})
+    print(name, {k: (f"{v:.2e}" if isinstance(v, float) else v) for k, v in rep.items()})
 
 
 def test_goldens_cover_the_edge_cases():

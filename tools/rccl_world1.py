@@ -22,7 +22,7 @@ cfg = scenes.CONFIGS[cfg_i]; P, W, H, D = cfg["P"], cfg["width"], cfg["height"],
 cloud = scenes.config_cloud(cfg_i)
 g = lambda x, rg=False: torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev).requires_grad_(rg)
 L = {k: g(cloud[k], True) for k in ("means3D", "opacities", "scales", "rotations", "shs")}
-flat = FlatGradients([L[k] for k in ("means3D", "opacities", "scales", "rotations", "shs")])
+flat = FlatGradients([L[k] for k in ("means3D", "opacities", "scales", "rotations", "shs")], sh_params={4: 0})
 S = []
 for k in range(8):
     c = scenes.orbit_camera(W, H, azimuth_deg=(k * 137.5) % 360.0)

@@ -248,24 +248,29 @@ constexpr int BNULL = BCH;
 // of pixel i of a quadrant adds (row_stride4_sum9_banked) --, cell t[j] component 8 and, in its spare half, the record's colour b (the ninth float
 // of a record; the other eight are sA / sB).  Column BNULL swallows the padding entries.
 struct AccTail { double w; float cb; uint32_t pad; };
-constexpr int ACC_PLANE = 2 * (BCH + 1) + 1;       // doubles per pixel-of-quadrant plane: an ODD number of 8-byte slots, so that the four planes' cells of one
+template <int CH>
+struct alignas(16) BwdAccT {
+    static constexpr int PLANE = 2 * (CH + 1) + 1; // doubles per pixel-of-quadrant plane: an ODD number of 8-byte slots, so that the four planes' cells of one
                                                    // entry fall into both halves of the 16-byte bank groups (with an even stride the 64 lanes' atomics used every
                                                    // second 8-byte slot: twice the bank conflicts of the old 8-byte layout, measured + 1 us)
-struct alignas(16) BwdAcc { double v[4][ACC_PLANE]; AccTail t[BCH + 1]; };
+    double v[4][PLANE]; AccTail t[CH + 1];
+};
+using BwdAcc = BwdAccT<BCH>;
+constexpr int ACC_PLANE = BwdAcc::PLANE;
 static_assert(sizeof(AccTail) == 16 && offsetof(BwdAcc, t) == 4 * ACC_PLANE * 8 && offsetof(BwdAcc, t) % 16 == 0, "BwdAcc: 16-byte cells");
-__device__ __forceinline__ double acc_get(const BwdAcc& A, int c, uint32_t j) { return c < 8 ? A.v[c & 3][2 * j + (c >> 2)] : A.t[j].w; }
-__device__ __forceinline__ void acc_clear(BwdAcc& A, uint32_t j)
+template <int CH> __device__ __forceinline__ double acc_get(const BwdAccT<CH>& A, int c, uint32_t j) { return c < 8 ? A.v[c & 3][2 * j + (c >> 2)] : A.t[j].w; }
+template <int CH> __device__ __forceinline__ void acc_clear(BwdAccT<CH>& A, uint32_t j)
 {
 #pragma unroll
     for (int i = 0; i < 4; i++) { A.v[i][2 * j] = 0.0; A.v[i][2 * j + 1] = 0.0; }
     A.t[j].w = 0.0;
 }
 // (zero every sum of the accumulator, all threads of the workgroup; the colour halves of the tail cells are not touched)
-__device__ __forceinline__ void acc_clear_all(BwdAcc& A, uint32_t tid, uint32_t nthreads)
+template <int CH> __device__ __forceinline__ void acc_clear_all(BwdAccT<CH>& A, uint32_t tid, uint32_t nthreads)
 {
     double* v = &A.v[0][0];
-    for (uint32_t i = tid; i < 4u * ACC_PLANE; i += nthreads) v[i] = 0.0;
-    for (uint32_t i = tid; i < (uint32_t)(BCH + 1); i += nthreads) A.t[i].w = 0.0;
+    for (uint32_t i = tid; i < 4u * BwdAccT<CH>::PLANE; i += nthreads) v[i] = 0.0;
+    for (uint32_t i = tid; i < (uint32_t)(CH + 1); i += nthreads) A.t[i].w = 0.0;
 }
 struct alignas(16) BwdShared {
     float4 sA[BCH + 1];                                    // staged records: mean2D, conic xx / xy (pre-scaled for exp2); slot BNULL = the null record
@@ -279,7 +284,8 @@ struct alignas(16) BwdShared {
 };
 static_assert(offsetof(BwdShared, sSlot) < 65536 && sizeof(BwdShared) <= 80 * 1024, "k_render_bwd: records + accumulator inside a 16-bit LDS offset; two workgroups per CU");
 struct BwdPixel { float fx, fy, d0, d1, d2, tfinal_bg; int thr16; uint32_t acc_off; };   // per lane: pixel centre, dL_dpixel, T_final * (bg . dL_dpixel), threshold, byte offset of acc[pixel-of-quadrant]
-__device__ __forceinline__ void bwd_passes(const unsigned short* myq, uint32_t nq, const float4* sA, const float4* sB, BwdAcc& acc, uint32_t base16,
+template <int CH>
+__device__ __forceinline__ void bwd_passes(const unsigned short* myq, uint32_t nq, const float4* sA, const float4* sB, BwdAccT<CH>& acc, uint32_t base16,
                                            const BwdPixel& px, bool first_bank, float& T, float& arA, float vone, float vzero, const QuadMasks& qm)
 {
     const char* cA = reinterpret_cast<const char*>(sA);
@@ -290,7 +296,7 @@ __device__ __forceinline__ void bwd_passes(const unsigned short* myq, uint32_t n
         const uint32_t j16 = jl16 + base16;
         const float4 a = *reinterpret_cast<const float4*>(cA + j16);       // mean2D, conic xx / xy pre-scaled for exp2 (stage_conic)
         const float4 bb = *reinterpret_cast<const float4*>(cB + j16);      // conic yy pre-scaled, opacity, colour r g
-        const float c0 = bb.z, c1 = bb.w, c2 = *reinterpret_cast<const float*>(cAcc + offsetof(BwdAcc, t) + offsetof(AccTail, cb) + j16);
+        const float c0 = bb.z, c1 = bb.w, c2 = *reinterpret_cast<const float*>(cAcc + offsetof(BwdAccT<CH>, t) + offsetof(AccTail, cb) + j16);
         const float dx = a.x - px.fx, dy = a.y - px.fy;
         const float power2 = (a.z * dx + a.w * dy) * dx + (bb.x * dy) * dy;   // log2(e) * power of forward.cu:336
         const float G = __builtin_amdgcn_exp2f(power2);
@@ -322,11 +328,11 @@ __device__ __forceinline__ void bwd_passes(const unsigned short* myq, uint32_t n
         row_stride4_sum9_banked(v, s0, s1);                 // lane (pixel i, slot e): s0 = component i, s1 = component 4 + i of entry e; v[8] complete
         // rows whose list is shorter than the longest of the chunk idle on the null record: their sums are zero, and without this
         // test all of them would add into the ONE spare column -- same-address LDS atomics serialise
-        if (j16 != (uint32_t)BNULL * 16u) {
+        if (j16 != (uint32_t)CH * 16u) {
             double* p = reinterpret_cast<double*>(cAcc + px.acc_off + j16);
             atomicAdd(p, (double)s0);
             atomicAdd(p + 1, (double)s1);
-            if (first_bank) atomicAdd(reinterpret_cast<double*>(cAcc + offsetof(BwdAcc, t) + j16), (double)v[8]);
+            if (first_bank) atomicAdd(reinterpret_cast<double*>(cAcc + offsetof(BwdAccT<CH>, t) + j16), (double)v[8]);
         }
     };
     // Two passes per trip, the offsets one pass ahead in alternating registers (null slots behind the list's end, up to QL_ROW): no register move
@@ -368,18 +374,18 @@ __device__ __forceinline__ void bwd_light_group(const ImgState& s, const BinStat
     const uint32_t qmax = active ? min(td.w, n) : 0u;                  // deepest position any pixel of the tile blended (k_render_fwd wrote it into the descriptor)
     // pixel inputs of a block (5 loads), asked for ONE BLOCK AHEAD: block 0's here, block bi + 1's in front of block bi's passes (round 5: all four
     // blocks' inputs held at once were 20 VGPRs -- with the pass's own registers the light path spilled them right behind their loads)
-    struct PixIn { float Tf, d0, d1, d2; uint32_t lc; };
+    struct PixIn { float Tf, d0, d1, d2; uint32_t lc; bool in; };     // (raw loads from a clamped address; select_loaded at the use)
     auto load_block = [&](int bi) {
         const int blk = 4 * w4 + bi;
         const int px = tx * TILE + (blk & 3) * 4 + (qd & 1) * 2 + (pq & 1);
         const int py = ty * TILE + (blk >> 2) * 4 + (qd >> 1) * 2 + (pq >> 1);
         const bool inside = active && px < W && py < H;
         const size_t pix_id = inside ? (size_t)W * py + px : 0;          // (clamped, not predicated: the five loads are in flight together)
-        const float m = inside ? 1.f : 0.f;
         PixIn r;
-        r.Tf = s.final_T[pix_id] * m;
+        r.in = inside;
+        r.Tf = s.final_T[pix_id];
         r.lc = inside ? s.n_contrib[pix_id] : 0u;
-        r.d0 = dL_dpix[pix_id] * m; r.d1 = dL_dpix[N + pix_id] * m; r.d2 = dL_dpix[2 * N + pix_id] * m;
+        r.d0 = dL_dpix[pix_id]; r.d1 = dL_dpix[N + pix_id]; r.d2 = dL_dpix[2 * N + pix_id];
         return r;
     };
     PixIn nxt = load_block(0);
@@ -416,7 +422,7 @@ __device__ __forceinline__ void bwd_light_group(const ImgState& s, const BinStat
         const PixIn cur = nxt;
         if (bi < 3) nxt = load_block(bi + 1);
         asm volatile("" ::: "memory");                      // (the next block's loads stay here, in front of this block's passes)
-        const float T_final = cur.Tf, dpx0 = cur.d0, dpx1 = cur.d1, dpx2 = cur.d2;
+        const float T_final = select_loaded(cur.in, cur.Tf), dpx0 = select_loaded(cur.in, cur.d0), dpx1 = select_loaded(cur.in, cur.d1), dpx2 = select_loaded(cur.in, cur.d2);
         const uint32_t last_contributor = cur.lc;
         float T = T_final;
         float bg_dot_dpixel = 0.f;                          // backward.cu:533-535
@@ -514,12 +520,14 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
     // Everything the descriptor alone decides is asked for HERE, together: the pixel state AND the first round's records (round 5: the records were
     // asked for behind a barrier that waited for the pixel state -- two memory round trips in a row at the head of every one of 2 900 workgroups).
     const size_t pixc = inside ? pix_id : 0;                // (clamped, not predicated: the loads are in flight together)
-    const float inm = inside ? 1.f : 0.f;
-    const float T_final = s.final_T[pixc] * inm;
+    const float T_raw = s.final_T[pixc];
     const uint32_t last_contributor = inside ? s.n_contrib[pixc] : 0u;
-    float dpx0 = dL_dpix[pixc] * inm, dpx1 = dL_dpix[N + pixc] * inm, dpx2 = dL_dpix[2 * N + pixc] * inm;
+    const float d_raw0 = dL_dpix[pixc], d_raw1 = dL_dpix[N + pixc], d_raw2 = dL_dpix[2 * N + pixc];
     if (ht < qmax) fetch(rg.x + qmax - 1 - ht);
     asm volatile("" ::: "memory");
+    // (the selects behind the loads' issue: an asm statement waits for its operand where it stands)
+    const float T_final = select_loaded(inside, T_raw);
+    float dpx0 = select_loaded(inside, d_raw0), dpx1 = select_loaded(inside, d_raw1), dpx2 = select_loaded(inside, d_raw2);
     float T = T_final;
     float bg_dot_dpixel = 0.f;                              // backward.cu:533-535
     bg_dot_dpixel += bg[0] * dpx0; bg_dot_dpixel += bg[1] * dpx1; bg_dot_dpixel += bg[2] * dpx2;
@@ -607,6 +615,187 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
     stamp(s, tile, 3);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// k_render_bwd_h (round 6): the same passes with EIGHT waves per tile -- wave w walks block w and block 15 - w one after the other in
+// every round, the state of the block it is not walking (T, dL_dpixel . accum_rec, the pixel's inputs) parked in LDS -- and rounds of
+// HCH entries, so that four workgroups fit a CU instead of two.
+// Why (tools/pass_packing.py, profiles/r06_pass_packing.txt): a tile-round lasts as long as its slowest wave, and with one block per
+// wave the slowest wave runs 1.8 x the mean (balance 0.55): 16 wave slots are held for 34.7 k rounds-of-passes where 19.1 k are walked.
+// Two blocks per wave -- a corner block with the opposite corner, a centre block with a centre block -- even the waves out (balance 0.74,
+// pass-equivalents x 0.74), and a workgroup of half the size turns over in half the slots.
+// ---------------------------------------------------------------------------------------------
+#ifndef TGS_HCH
+#define TGS_HCH 192
+#endif
+#ifndef TGS_BWD_HALF
+#define TGS_BWD_HALF 0
+#endif
+constexpr int HW = 8, H_THREADS = 64 * HW;
+constexpr int HCH = TGS_HCH;               // list entries per round
+constexpr int HCAP = (HCH + 63) / 64 * 64;  // capacity of the staged masks (build_own_list_q walks whole 64-entry groups)
+constexpr int H_NPARK = 7;                  // T, arA, dL_dpixel rgb, T_final * (bg . dL_dpixel), first round's threshold
+struct alignas(16) BwdSharedH {
+    float4 sA[HCH + 1];
+    float4 sB[HCH + 1];
+    BwdAccT<HCH> acc;
+    uint32_t sSlot[2][HCH];
+    float2 sFl[2][HCH];
+    uint2 sQ[HCAP];
+    alignas(16) unsigned short lists[HW][HCAP + 8];
+    alignas(16) unsigned short qlists[HW][4][QL_ROW];
+    float park[2][H_NPARK][HW][16];            // per block of a wave and pixel of the block
+};
+static_assert(offsetof(BwdSharedH, sSlot) < 65536 && 2 * HCH <= H_THREADS, "k_render_bwd_h: records + accumulator inside a 16-bit LDS offset; two staging halves");
+__global__ __launch_bounds__(H_THREADS, 8) void k_render_bwd_h(const ImgState s, const BinState b, int W, int H, uint32_t gx,
+                                                               const float* __restrict__ bg, const float* __restrict__ dL_dpix)
+{
+    __shared__ BwdSharedH S;
+    auto& sA = S.sA; auto& sB = S.sB; auto& sSlot = S.sSlot; auto& sFl = S.sFl; auto& acc = S.acc; auto& sQ = S.sQ; auto& lists = S.lists; auto& qlists = S.qlists;
+    const uint4 td = s.tile_desc[blockIdx.x];
+    const uint4 ff = frame_counts(s);
+    if (ff.x & META_ERR_CAPACITY) return;
+    check_tile_bound(s);
+    const uint32_t tile = td.x;
+    const uint32_t tx = tile % gx, ty = tile / gx;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int qd = lane >> 4, pq = (lane >> 2) & 3, e = lane & 3;
+    const uint2 rg = make_uint2(td.y, td.z);
+    const uint32_t n = rg.y - rg.x;
+    if (n == 0) return;
+    set_wave_priority(n);
+    stamp(s, tile, 2);
+    const size_t N = (size_t)W * H;
+    if (threadIdx.x == 0) { sA[HCH] = make_float4(0.f, 0.f, 0.f, 0.f); sB[HCH] = make_float4(0.f, 0.f, 0.f, 0.f); acc.t[HCH].cb = 0.f; }
+    const uint32_t qmax = min(td.w, n);
+    const bool upper = threadIdx.x >= HCH;
+    const uint32_t ht = threadIdx.x < 2 * HCH ? (upper ? threadIdx.x - HCH : threadIdx.x) : 0xffffffffu;
+    float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint2 r2 = make_uint2(0u, 0u);
+    auto fetch = [&](uint32_t pos) {
+        if (!upper) { r4 = b.recA[pos]; r2 = b.qmask[pos]; }
+        else { r4 = b.recB[pos]; r2 = make_uint2(__float_as_uint(b.recC[pos].x), b.slot[pos]); }
+    };
+    // the inputs of both blocks' pixels and the first round's records, in flight together
+    const int pix16 = lane >> 2;                                        // pixel of the block: 4 * quadrant + pixel of the quadrant
+    auto block_px = [&](int blk) { return (int)tx * TILE + (blk & 3) * 4 + (qd & 1) * 2 + (pq & 1); };
+    auto block_py = [&](int blk) { return (int)ty * TILE + (blk >> 2) * 4 + (qd >> 1) * 2 + (pq >> 1); };
+    float Tf[2], d0[2], d1[2], d2[2]; uint32_t lc[2]; bool ins[2];
+#pragma unroll
+    for (int bi = 0; bi < 2; bi++) {
+        const int blk = bi ? 15 - wv : wv;
+        const int px = block_px(blk), py = block_py(blk);
+        const bool inside = px < W && py < H;
+        const size_t pixc = inside ? (size_t)W * py + px : 0;
+        ins[bi] = inside;
+        Tf[bi] = s.final_T[pixc];
+        lc[bi] = inside ? s.n_contrib[pixc] : 0u;
+        d0[bi] = dL_dpix[pixc]; d1[bi] = dL_dpix[N + pixc]; d2[bi] = dL_dpix[2 * N + pixc];
+    }
+    if (ht < qmax) fetch(rg.x + qmax - 1 - ht);
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int bi = 0; bi < 2; bi++) {
+        Tf[bi] = select_loaded(ins[bi], Tf[bi]);
+        d0[bi] = select_loaded(ins[bi], d0[bi]); d1[bi] = select_loaded(ins[bi], d1[bi]); d2[bi] = select_loaded(ins[bi], d2[bi]);
+    }
+    float vone = 1.0f, vzero = 0.0f;
+    const QuadMasks qm = quad_masks();
+    asm volatile("" : "+v"(vone), "+v"(vzero));
+    const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);
+    const float bgr = bg[0], bgg = bg[1], bgb = bg[2];
+    uint32_t qlast[2][4];
+#pragma unroll
+    for (int bi = 0; bi < 2; bi++) {
+        uint32_t m = lc[bi];
+        m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x124, 0xf, 0xf, false));     // row_ror:4
+        m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x128, 0xf, 0xf, false));     // row_ror:8
+#pragma unroll
+        for (int q = 0; q < 4; q++) qlast[bi][q] = (uint32_t)__builtin_amdgcn_readlane((int)m, 16 * q);
+        float bgd = 0.f;
+        bgd += bgr * d0[bi]; bgd += bgg * d1[bi]; bgd += bgb * d2[bi];
+        if (e == 0) {
+            S.park[bi][0][wv][pix16] = Tf[bi]; S.park[bi][1][wv][pix16] = 0.f;
+            S.park[bi][2][wv][pix16] = d0[bi]; S.park[bi][3][wv][pix16] = d1[bi]; S.park[bi][4][wv][pix16] = d2[bi];
+            S.park[bi][5][wv][pix16] = Tf[bi] * bgd;
+            S.park[bi][6][wv][pix16] = __int_as_float(((int)qmax - 1 - (int)lc[bi]) * 16);
+        }
+    }
+    for (uint32_t q = qmax + threadIdx.x; q < n; q += H_THREADS) {
+        float4* row = b.slab + (size_t)b.slot[rg.x + q] * SLAB_ROW;
+        row[0] = make_float4(0.f, 0.f, 0.f, 0.f); row[1] = make_float4(0.f, 0.f, 0.f, 0.f); row[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    auto stage = [&](int buf) {
+        uint32_t h = ht;
+        asm volatile("" : "+v"(h));
+        if (!upper) { stage_conic_a(r4); sA[h] = r4; sQ[h] = r2; }
+        else { sFl[buf][h] = make_float2(r4.x, r4.y); stage_conic_b(r4); sB[h] = r4; acc.t[h].cb = __uint_as_float(r2.x); sSlot[buf][h] = r2.y; }
+    };
+    acc_clear_all(acc, threadIdx.x, H_THREADS);
+    {
+        const uint32_t cnt0 = min((uint32_t)HCH, qmax);
+        if (ht < cnt0) stage(0);
+    }
+    __syncthreads();
+    int rnd = 0, thr_dec = 0;
+    for (uint32_t qhi = qmax; qhi > 0; qhi = qhi > HCH ? qhi - HCH : 0, rnd ^= 1, thr_dec += HCH * 16) {
+        const uint32_t cnt = min((uint32_t)HCH, qhi);
+        if (qhi > HCH && ht < qhi - HCH) fetch(rg.x + qhi - HCH - 1 - ht);
+#pragma unroll 1
+        for (int bi = 0; bi < 2; bi++) {
+            const int blk = bi ? 15 - wv : wv;
+            uint32_t ql[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) ql[q] = bi ? qlast[1][q] : qlast[0][q];
+            if ((ql[0] | ql[1] | ql[2] | ql[3]) == 0u) continue;                    // nothing was blended into this block
+            // (lane-derived values re-derived per block behind a fence: as invariants of the round loop they would sit in VGPRs across the passes)
+            uint32_t ln = (uint32_t)lane;
+            asm volatile("" : "+v"(ln));
+            const uint32_t qd_ = ln >> 4, pq_ = (ln >> 2) & 3u;
+            constexpr int PS = HW * 16;
+            float T, arA;
+            BwdPixel pxl;
+            {
+                const float* pk = &S.park[bi][0][wv][ln >> 2];
+                T = pk[0]; arA = pk[PS];
+                pxl.fx = (float)((int)tx * TILE + (blk & 3) * 4 + (int)((qd_ & 1u) * 2u + (pq_ & 1u)));
+                pxl.fy = (float)((int)ty * TILE + (blk >> 2) * 4 + (int)((qd_ >> 1) * 2u + (pq_ >> 1)));
+                pxl.d0 = pk[2 * PS]; pxl.d1 = pk[3 * PS]; pxl.d2 = pk[4 * PS]; pxl.tfinal_bg = pk[5 * PS];
+                pxl.thr16 = __float_as_int(pk[6 * PS]) - thr_dec;
+                pxl.acc_off = pq_ * (uint32_t)(BwdAccT<HCH>::PLANE * 8);
+            }
+            const uint32_t nl = build_own_list_q<HCAP>(lists[wv], sQ, cnt, blk, lane);
+            const unsigned short* myq = &qlists[wv][qd_][ln & 3u];
+#pragma unroll 1
+            for (uint32_t c0 = 0; c0 < nl; c0 += QCH) {
+                const uint32_t nq = build_chunk_quadrant_lists<TGS_BWD_BOUNDED, 4>(qlists[wv], lists[wv], c0, nl, lane, HCH, qhi - 1, ql);
+                bwd_passes<HCH>(myq, nq, sA, sB, acc, 0u, pxl, pq_ == 0u, T, arA, vone, vzero, qm);
+            }
+            uint32_t l2 = (uint32_t)lane;
+            asm volatile("" : "+v"(l2));
+            if ((l2 & 3u) == 0u) { float* pk = &S.park[bi][0][wv][l2 >> 2]; pk[0] = T; pk[PS] = arA; }
+        }
+        __syncthreads();
+        if (threadIdx.x < cnt) {
+            const uint32_t j = threadIdx.x;
+            const float4 a = sA[j]; const float2 fl = sFl[rnd][j];
+            const float cxx = a.z * UNSCALE_CONIC, cxy = a.w * UNSCALE_CONIC_XY, cyy = fl.x, op = fl.y;
+            const float Sx = (float)acc_get(acc, 3, j), Sy = (float)acc_get(acc, 4, j);
+            float4* row = b.slab + (size_t)sSlot[rnd][j] * SLAB_ROW;
+            row[0] = make_float4((float)acc_get(acc, 0, j), (float)acc_get(acc, 1, j), (float)acc_get(acc, 2, j), op * (-Sx * cxx - Sy * cxy) * ddelx_dx);
+            const ConicHiLo c5 = conic_hilo(op, acc_get(acc, 5, j)), c6 = conic_hilo(op, acc_get(acc, 6, j)), c7 = conic_hilo(op, acc_get(acc, 7, j));
+            row[1] = make_float4(op * (-Sy * cyy - Sx * cxy) * ddely_dy, c5.hi, c6.hi, c7.hi);
+            row[2] = make_float4((float)acc_get(acc, 8, j), c5.lo, c6.lo, c7.lo);
+            acc_clear(acc, j);
+        }
+        if (qhi > HCH) {
+            const uint32_t qn = qhi - HCH, cntn = min((uint32_t)HCH, qn);
+            if (ht < cntn) stage(rnd ^ 1);
+            __syncthreads();
+        }
+    }
+    stamp(s, tile, 3);
+}
 
 // ---------------------------------------------------------------------------------------------
 // Per-Gaussian half of the backward for ONE view (computeCov2DCUDA backward.cu:144-274, preprocessCUDA :346-396,
@@ -1609,6 +1798,9 @@ void launch_render_bwd(hipStream_t st, const ImgState& s, const BinState& b, int
 {
     // (-DTGS_FAST_MATH=0 builds always take the fixed-order kernel: it evaluates exp / the divisions in their accurate forms)
     if (deterministic || !TGS_FAST_MATH) { hipLaunchKernelGGL(k_render_bwd_det, dim3(tiles), dim3(256), 0, st, s, b, W, H, gx, bg, dL_dpix); return; }
+#if TGS_BWD_HALF
+    if (!light) { hipLaunchKernelGGL(k_render_bwd_h, dim3(tiles), dim3(H_THREADS), 0, st, s, b, W, H, gx, bg, dL_dpix); return; }
+#endif
     if (!light) { hipLaunchKernelGGL(k_render_bwd, dim3(tiles), dim3(BWD_THREADS), 0, st, s, b, W, H, gx, bg, dL_dpix, 0, T); return; }
     const uint32_t heavy = mid_tiles < tiles ? mid_tiles : tiles;
     // one-tile workgroups for the (bound on the) tiles with >= LIGHT_MAX instances + light groups for the rest, three tiles each.  With exact

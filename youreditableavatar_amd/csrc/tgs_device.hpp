@@ -272,6 +272,37 @@ __device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(
 
 // Appends `val` (low 16 bits) of every lane whose `ent` has a bit of BITS set to the u16 list at LDS byte address `base` (wave-uniform),
 // in lane order; returns how many (wave-uniform, in an SGPR).  The ranks are only needed by the lanes that write: mbcnt runs under their exec.
+// HAZARDS the hand-written blocks rely on (LLVM's hazard recogniser does not look inside inline asm; ADVICE of round 5):
+//   * gfx940 family: a VALU write of an SGPR / VCC needs 2 wait states before a VALU instruction reads it as a constant.  v_cmp writes vcc, and
+//     v_mbcnt_lo reads vcc_lo: the TWO scalar instructions between them (s_and_saveexec, s_bcnt1) are those wait states -- with no margin.
+//     Whoever removes or moves one of them must put an s_nop in its place.  (The scalar unit's own read of vcc is interlocked.)
+//   * the 16-byte null fill of ql_fill_null and the b16 appends go to the same LDS words: a wave's LDS operations execute in order (one
+//     in-order queue per wave, lgkmcnt counts them in order), so the appends land behind the fill without a wait between them.
+// -DTGS_QL_APPEND_C=1 builds the same three functions from ballot / mbcnt builtins (the compiler's 9-11 instructions per list): the A/B partner
+// for the parity suite after a toolchain update (TGS_LIB_NAME=libtgs_raster_qlc.so TGS_DEFINES=-DTGS_QL_APPEND_C=1 python -m youreditableavatar_amd.build --force).
+#ifndef TGS_QL_APPEND_C
+#define TGS_QL_APPEND_C 0
+#endif
+#if TGS_QL_APPEND_C
+template <uint32_t BITS>
+__device__ __forceinline__ uint32_t ql_append(uint32_t ent, uint32_t val, uint32_t base)
+{
+    const bool on = (ent & BITS) != 0u;
+    const unsigned long long bal = __builtin_amdgcn_ballot_w64(on);
+    const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+    if (on) *reinterpret_cast<__attribute__((address_space(3))) unsigned short*>((uintptr_t)(base + 2u * pos)) = (unsigned short)val;
+    return (uint32_t)__builtin_popcountll(bal);
+}
+template <uint32_t BITS>
+__device__ __forceinline__ uint32_t ql_append_above(uint32_t ent, uint32_t key, uint32_t val, uint32_t base, int thr)
+{
+    const bool on = (ent & BITS) != 0u && (int)key > thr;
+    const unsigned long long bal = __builtin_amdgcn_ballot_w64(on);
+    const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+    if (on) *reinterpret_cast<__attribute__((address_space(3))) unsigned short*>((uintptr_t)(base + 2u * pos)) = (unsigned short)val;
+    return (uint32_t)__builtin_popcountll(bal);
+}
+#else
 template <uint32_t BITS>
 __device__ __forceinline__ uint32_t ql_append(uint32_t ent, uint32_t val, uint32_t base)
 {
@@ -315,6 +346,7 @@ __device__ __forceinline__ uint32_t ql_append_above(uint32_t ent, uint32_t key, 
         : "vcc", "scc", "memory");
     return n;
 }
+#endif
 // the wave's four quadrant lists <- the null slot everywhere (ROW u16 each, contiguous, 16-B aligned)
 template <int ROW>
 __device__ __forceinline__ void ql_fill_null(unsigned short (*ql)[ROW], int lane, int null_slot)
@@ -548,6 +580,17 @@ __device__ __forceinline__ void row_stride4_sum9_banked(float (&v)[9], float& s0
                  : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), [s0] "=&v"(s0), [s1] "=&v"(s1));
 #undef TGS_ROR4
 #undef TGS_ROR8B
+}
+
+// x where `keep`, else 0 -- ONE v_cndmask on the loaded VALUE, for loads issued from a clamped address so that they are in flight together.
+// Neither `keep ? x : 0` (turned back into a load under a branch of its own: one memory round trip per value) nor `x * (keep ? 1 : 0)` (round 5;
+// 0 * NaN = NaN: a non-finite dL_dpixel at the clamped element -- pixel (0, 0) -- reached every padding lane of the right / bottom edge tiles
+// and from there every splat on those tiles; ADVICE of round 5).  Not volatile: the compiler places it like any vector instruction.
+__device__ __forceinline__ float select_loaded(bool keep, float x)
+{
+    float r;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(x), "s"(__builtin_amdgcn_ballot_w64(keep)));
+    return r;
 }
 
 // (error, n_nonempty) of the frame's Meta in ONE load -- the render kernels need both before anything else, and as two loads with a

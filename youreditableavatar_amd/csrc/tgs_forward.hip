@@ -110,6 +110,49 @@ __device__ __forceinline__ bool tile_reachable(float2 xy, float4 co, uint32_t tx
     return !(fminf(fminf(e0, e1), fminf(e2, e3)) > tau * 1.001f);
 }
 
+// The live-tile masks of the wave's rectangles of RANK_TILES + 1 .. COOP_TILES tiles, with the (splat, tile) pairs SPREAD OVER THE LANES
+// (round 6).  Until round 5 the splat's own lane walked its rectangle tile by tile (tile_reachable, ~50 instructions a tile) while the other
+// 63 waited for the largest rectangle of the wave: nothing at config 3 (2.5 tiles per splat: almost every rectangle is <= RANK_TILES), but
+// with mesh-bound splats on 5..64 tiles (the trained scenes: tetgs_edit_2d.py:203) k_preprocess_fwd took 46.6 / 62.0 us at splats x 4 / x 8
+// against 35.4.  Now: prefix sum of the areas, 64 pairs per step, the owner found by a 6-step search in LDS (as wave_emit_instances does for
+// the keys), the answers collected by ONE ballot per step from which every owner cuts its own bits -- no atomics.  Same test, same masks.
+// Convergent: every lane of the wave calls this.
+struct ReachTab { float4 a[WAVE]; float4 b[WAVE]; uint32_t excl[WAVE]; };      // a = (x, y, conic.x, conic.y)  b = (conic.z, opacity, bits(minx | miny << 16), bits(rect width))
+__device__ __forceinline__ unsigned long long wave_live_masks(bool mid, uint32_t area_in, float2 xy, float4 co, uint32_t minx, uint32_t miny, uint32_t rw, ReachTab& tab, int lane)
+{
+    const uint32_t area = mid ? area_in : 0u;
+    const uint32_t incl = wave_iscan_u32(area, lane), total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63), excl = incl - area;
+    tab.excl[lane] = excl;
+    tab.a[lane] = make_float4(xy.x, xy.y, co.x, co.y);
+    tab.b[lane] = make_float4(co.z, co.w, __uint_as_float(minx | (miny << 16)), __uint_as_float(rw));
+    wave_sync();
+    unsigned long long live = 0ull;
+    for (uint32_t base = 0; base < total; base += 64) {     // (wave-uniform)
+        const uint32_t w = base + (uint32_t)lane;
+        bool reach = false;
+        if (w < total) {
+            uint32_t lo = 0, hi = 63;                       // owner: the last lane whose first pair is <= w
+#pragma unroll
+            for (int it = 0; it < 6; it++) { const uint32_t m = (lo + hi + 1) >> 1; if (tab.excl[m] <= w) lo = m; else hi = m - 1; }
+            const float4 a = tab.a[lo], b = tab.b[lo];
+            const uint32_t k = w - tab.excl[lo], rw2 = __float_as_uint(b.w), mm = __float_as_uint(b.z);
+            // k / rw2 for k < 64, 1 <= rw2 <= 64: (k + 1/2) / rw2 is at least 1 / 128 from an integer, v_rcp_f32 is good to 1 ulp
+            const uint32_t ky = (uint32_t)(((float)k + 0.5f) * __builtin_amdgcn_rcpf((float)rw2));
+            reach = tile_reachable(make_float2(a.x, a.y), make_float4(a.z, a.w, b.x, b.y), (mm & 0xffffu) + (k - ky * rw2), (mm >> 16) + ky);
+        }
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(reach);
+        // this lane's pairs of the step: [excl, excl + area) cut with [base, base + 64)
+        const uint32_t s0 = max(excl, base), s1 = min(excl + area, base + 64u);
+        if (s0 < s1) {
+            const uint32_t n = s1 - s0;
+            const unsigned long long bits = (bal >> (s0 - base)) & (n >= 64u ? ~0ull : (1ull << n) - 1ull);
+            live |= bits << (s0 - excl);
+        }
+    }
+    wave_sync();                                            // (the table is reused: the pair kernel's second view)
+    return live;
+}
+
 // One Gaussian of one view: projection, EWA covariance, SH colour, tile rectangle, the mask of the rectangle's live tiles and
 // the 64-B pack line.  Shared by the one-view and the all-views kernel.
 // computeColorFromSH (forward.cu:20-71): colour of a Gaussian seen along (dx, dy, dz) = mean - camera position, from its 16 x 3
@@ -172,15 +215,20 @@ __device__ __forceinline__ GaussIn load_gauss_in(const FwdIn& in, int idx)
 
 template <bool HAS_SH, bool HAS_SCALE_ROT>
 __device__ __forceinline__ uint32_t preprocess_fwd_one(const FwdIn& in, int* __restrict__ radii, const CamParams& cam, const GeomState& g, const ImgState& s,
-                                                       const float4* sh_lds, bool sh_staged, int idx, const GaussIn& gi, const PreColor& pre, bool& prefilter_violation)
+                                                       const float4* sh_lds, bool sh_staged, int idx, const GaussIn& gi, const PreColor& pre, bool& prefilter_violation,
+                                                       ReachTab& rtab)
 {
 #pragma clang fp contract(off)      // projection, covariance, radius and colour un-fused: the oracle's (and the reference's source's) operation order
     uint32_t tiles = 0;
     const ViewMat V = load_mat(cam.view), PM = load_mat(cam.proj);      // uniform -> scalar loads, before any store
     const float camx = cam.campos[0], camy = cam.campos[1], camz = cam.campos[2];
+    int my_radius_i = 0;
+    uint32_t minx = 0, miny = 0, maxx = 0, maxy = 0;
+    // what the rectangle's live mask and the pack line are made of (a Gaussian with a non-empty rectangle: `have`)
+    bool have = false, mid = false;
+    float pix = 0.f, piy = 0.f, conx = 0.f, cony = 0.f, conz = 0.f, opac = 0.f, col0 = 0.f, col1 = 0.f, col2 = 0.f;
+    unsigned long long live_mask = 0ull;
     if (idx < in.P) {
-        int my_radius_i = 0;
-        uint32_t minx = 0, miny = 0, maxx = 0, maxy = 0;
         const float mx = gi.mx, my = gi.my, mz = gi.mz;
         // in_frustum (auxiliary.h:139-164)
         const float* pm = PM.m;
@@ -207,16 +255,16 @@ __device__ __forceinline__ uint32_t preprocess_fwd_one(const FwdIn& in, int* __r
             ok = det != 0.0f;
             if (ok) {
                 const float det_inv = 1.f / det;
-                const float conx = cz * det_inv, cony = -cy * det_inv, conz = cx * det_inv;
-                const float mid = 0.5f * (cx + cz);
-                const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
-                const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+                conx = cz * det_inv; cony = -cy * det_inv; conz = cx * det_inv;
+                const float mid_ev = 0.5f * (cx + cz);
+                const float lambda1 = mid_ev + sqrtf(fmaxf(0.1f, mid_ev * mid_ev - det));
+                const float lambda2 = mid_ev - sqrtf(fmaxf(0.1f, mid_ev * mid_ev - det));
                 const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
-                const float pix = ndc2pix(projx, cam.W), piy = ndc2pix(projy, cam.H);
+                pix = ndc2pix(projx, cam.W); piy = ndc2pix(projy, cam.H);
                 get_rect(pix, piy, (int)my_radius, cam.gx, cam.gy, minx, miny, maxx, maxy);
                 tiles = (maxx - minx) * (maxy - miny);
                 if (tiles != 0) {
-                    float col0, col1, col2;
+                    have = true;
                     if (HAS_SH) {
                         if (pre.valid) {                       // colour of this view evaluated in the staging phase (sh_colors_half_staged)
                             col0 = pre.c0; col1 = pre.c1; col2 = pre.c2;
@@ -240,8 +288,6 @@ __device__ __forceinline__ uint32_t preprocess_fwd_one(const FwdIn& in, int* __r
                         }
                     } else if (in.colors_precomp) {
                         col0 = in.colors_precomp[3 * (size_t)idx]; col1 = in.colors_precomp[3 * (size_t)idx + 1]; col2 = in.colors_precomp[3 * (size_t)idx + 2];
-                    } else {
-                        col0 = col1 = col2 = 0.f;
                     }
                     g.depth[idx] = view_z;
                     my_radius_i = (int)my_radius;
@@ -249,8 +295,7 @@ __device__ __forceinline__ uint32_t preprocess_fwd_one(const FwdIn& in, int* __r
                     // (tile_reachable: the conservative test that masks the 4x4 blocks for the render kernels, applied to the whole
                     // tile, so nothing that could be blended is lost) gets no instance at all -- no count, no key, no sort, no record
                     // (about a fifth of them).  The live tiles of a rectangle of <= COOP_TILES tiles are a 64-bit mask, row-major.
-                    const float opac = gi.opac;
-                    unsigned long long live_mask = 0ull;
+                    opac = gi.opac;
                     if (tiles <= (uint32_t)RANK_TILES) {
                         uint32_t kx = 0, ky = 0;
 #pragma unroll
@@ -262,22 +307,28 @@ __device__ __forceinline__ uint32_t preprocess_fwd_one(const FwdIn& in, int* __r
                         }
                         tiles = (uint32_t)__builtin_popcountll(live_mask);
                     } else if (tiles <= (uint32_t)COOP_TILES) {
-                        uint32_t k = 0;
-                        for (uint32_t ty = miny; ty < maxy; ty++)
-                            for (uint32_t tx = minx; tx < maxx; tx++, k++)
-                                if (!in.prune || tile_reachable(make_float2(pix, piy), make_float4(conx, cony, conz, opac), tx, ty)) live_mask |= 1ull << k;
-                        tiles = (uint32_t)__builtin_popcountll(live_mask);
+                        if (in.prune) mid = true;              // (below, with the whole wave)
+                        else live_mask = tiles >= 64u ? ~0ull : (1ull << tiles) - 1ull;
                     }
-                    // the 64-B pack line in one go (.w of the third quarter: slab offset, k_scatter)
-                    float4* pk = g.pack + 4 * (size_t)idx;
-                    pk[0] = make_float4(pix, piy, conx, cony);
-                    pk[1] = make_float4(conz, opac, col0, col1);
-                    pk[2] = make_float4(col2, __uint_as_float(minx | (miny << 16)), __uint_as_float(maxx | (maxy << 16)), 0.f);
-                    pk[3] = make_float4(__uint_as_float((uint32_t)live_mask), __uint_as_float((uint32_t)(live_mask >> 32)), 0.f, 0.f);
-                    g.live[idx] = make_uint2((uint32_t)live_mask, (uint32_t)(live_mask >> 32));
                 }
             }
         }
+    }
+    // rectangles of RANK_TILES + 1 .. COOP_TILES tiles: their (splat, tile) pairs spread over the wave's lanes
+    if (__builtin_amdgcn_ballot_w64(mid) != 0ull) {          // (wave-uniform; never taken when every splat of the wave is small)
+        const unsigned long long lm = wave_live_masks(mid, tiles, make_float2(pix, piy), make_float4(conx, cony, conz, opac), minx, miny, maxx - minx, rtab, threadIdx.x & 63);
+        if (mid) { live_mask = lm; tiles = (uint32_t)__builtin_popcountll(lm); }
+    }
+    if (have) {
+        // the 64-B pack line in one go (.w of the third quarter: slab offset, k_scatter)
+        float4* pk = g.pack + 4 * (size_t)idx;
+        pk[0] = make_float4(pix, piy, conx, cony);
+        pk[1] = make_float4(conz, opac, col0, col1);
+        pk[2] = make_float4(col2, __uint_as_float(minx | (miny << 16)), __uint_as_float(maxx | (maxy << 16)), 0.f);
+        pk[3] = make_float4(__uint_as_float((uint32_t)live_mask), __uint_as_float((uint32_t)(live_mask >> 32)), 0.f, 0.f);
+        g.live[idx] = make_uint2((uint32_t)live_mask, (uint32_t)(live_mask >> 32));
+    }
+    if (idx < in.P) {
         if (radii) radii[idx] = my_radius_i;
         g.tiles_touched[idx] = tiles;
         g.rect[idx] = make_ushort4((unsigned short)minx, (unsigned short)miny, (unsigned short)maxx, (unsigned short)maxy);
@@ -371,12 +422,13 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd(const FwdIn in, co
 {
     const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
     __shared__ float4 sh_lds[HAS_SH ? SH_HALF * 12 : 1];
+    __shared__ ReachTab rtab[PRE_BLOCK / WAVE];
     PreColor pre[1];
     pre[0].valid = false;
     const GaussIn gi = load_gauss_in<HAS_SCALE_ROT>(in, idx);
     if (HAS_SH && in.M == 16) sh_colors_half_staged<1>(in, &vw, idx, gi, sh_lds, pre);
     bool bad = false;
-    const uint32_t tiles = preprocess_fwd_one<HAS_SH, HAS_SCALE_ROT>(in, vw.radii, vw.cam, vw.g, vw.s, sh_lds, false, idx, gi, pre[0], bad);
+    const uint32_t tiles = preprocess_fwd_one<HAS_SH, HAS_SCALE_ROT>(in, vw.radii, vw.cam, vw.g, vw.s, sh_lds, false, idx, gi, pre[0], bad, rtab[threadIdx.x >> 6]);
     block_sum_tiles(tiles, bad, vw.g, vw.s);
 }
 
@@ -387,6 +439,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd_pair(const FwdIn i
 {
     const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
     __shared__ float4 sh_lds[HAS_SH ? SH_HALF * 12 : 1];
+    __shared__ ReachTab rtab[PRE_BLOCK / WAVE];
     const FwdView vws[2] = {v0, v1};
     PreColor pre[2];
     pre[0].valid = pre[1].valid = false;
@@ -396,7 +449,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd_pair(const FwdIn i
     for (int v = 0; v < 2; v++) {
         const FwdView& vw = v == 0 ? v0 : v1;
         bool bad = false;
-        const uint32_t tiles = preprocess_fwd_one<HAS_SH, HAS_SCALE_ROT>(in, vw.radii, vw.cam, vw.g, vw.s, sh_lds, false, idx, gi, pre[v], bad);
+        const uint32_t tiles = preprocess_fwd_one<HAS_SH, HAS_SCALE_ROT>(in, vw.radii, vw.cam, vw.g, vw.s, sh_lds, false, idx, gi, pre[v], bad, rtab[threadIdx.x >> 6]);
         block_sum_tiles(tiles, bad, vw.g, vw.s);
         __syncthreads();                                   // wsum is reused by the next view
     }
@@ -409,6 +462,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd_batch(const FwdIn 
 {
     const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
     __shared__ float4 sh_lds[HAS_SH ? PRE_BLOCK * 12 : 1];
+    __shared__ ReachTab rtab[PRE_BLOCK / WAVE];
     const bool sh_staged = HAS_SH && in.M == 16;
     const GaussIn gi = load_gauss_in<HAS_SCALE_ROT>(in, idx);
     if (sh_staged) stage_sh_rows(in, sh_lds);
@@ -418,7 +472,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_fwd_batch(const FwdIn 
     for (int v = 0; v < views.n; v++) {
         const FwdView& vw = views.v[v];
         bool bad = false;
-        const uint32_t tiles = preprocess_fwd_one<HAS_SH, HAS_SCALE_ROT>(in, vw.radii, vw.cam, vw.g, vw.s, sh_lds, sh_staged, idx, gi, pre, bad);
+        const uint32_t tiles = preprocess_fwd_one<HAS_SH, HAS_SCALE_ROT>(in, vw.radii, vw.cam, vw.g, vw.s, sh_lds, sh_staged, idx, gi, pre, bad, rtab[threadIdx.x >> 6]);
         block_sum_tiles(tiles, bad, vw.g, vw.s);
         __syncthreads();                                   // wsum is reused by the next view
     }

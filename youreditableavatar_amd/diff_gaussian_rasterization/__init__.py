@@ -71,7 +71,7 @@ class _Speculation:
     workgroups that return at once.  A miss also lifts the bound 10 % above the count that caused it (a run of growing views -- the first
     calls of a camera set -- then misses once or twice, not on every view), and the cool-down is 16 calls after four misses in a row."""
 
-    HEADROOM, DECAY, MAX_MISSES, COOLDOWN, GRANULE = 1.15, 0.999, 4, 16, 65536
+    HEADROOM, DECAY, MAX_MISSES, COOLDOWN, GRANULE, FAR_CALLS = 1.15, 0.999, 4, 16, 65536, 64
 
     def __init__(self):
         self.state = {}
@@ -102,15 +102,27 @@ class _Speculation:
 
     def update(self, key, true_count, guess, tiles=-1, tile_guess=0, mid_tiles=-1):
         st = self.state.setdefault(key, [0, 0, 0, 0, 0])      # [bound, consecutive misses, calls left without speculation, bound on the tiles, light tiles of the last frame]
-        missed_now = guess is not None and (true_count > guess or (tile_guess > 0 and tiles > tile_guess))
-        lift = 1.1 if missed_now else 1.0
+        missed = guess is not None and (true_count > guess or (tile_guess > 0 and tiles > tile_guess))     # (the ONE place that decides what a miss is)
+        lift = 1.1 if missed else 1.0
+        # A bound far above what the views need is memory (112 B per instance): when the last FAR_CALLS calls all stayed below half of it -- one
+        # outlier view long ago, or a camera set that moved closer -- it falls to twice the largest of them at once instead of by 0.1 % per call.
+        far = st[5] if len(st) > 5 else [0, 0]
+        if not missed and 2 * true_count < st[0]:
+            far = [far[0] + 1, max(far[1], int(true_count))]
+            if far[0] >= self.FAR_CALLS:
+                st[0], far = min(st[0], 2 * far[1]), [0, 0]
+        else:
+            far = [0, 0]
+        if len(st) > 5:
+            st[5] = far
+        else:
+            st.append(far)
         st[0] = max(int(true_count * lift), int(st[0] * self.DECAY))
         if tiles >= 0:
             st[3] = max(int(tiles * lift), int(st[3] * self.DECAY))
             if mid_tiles >= 0:
                 st[4] = max(0, int(tiles) - int(mid_tiles))
         if guess is not None:
-            missed = true_count > guess or (tile_guess > 0 and tiles > tile_guess)
             st[1] = st[1] + 1 if missed else 0
             if st[1] >= self.MAX_MISSES:
                 st[1], st[2] = 0, self.COOLDOWN

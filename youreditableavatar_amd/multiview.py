@@ -37,10 +37,19 @@ class FlatGradients:
     across the views of a shard, and ``all_reduce`` sums the whole step with a single collective
     (236 B per Gaussian on the SH path = 118 MB at 500k Gaussians)."""
 
-    def __init__(self, params: Sequence[torch.Tensor]):
+    def __init__(self, params: Sequence[torch.Tensor], sh_params: Optional[dict] = None):
+        """``sh_params``: which parameters hold SH coefficients, NAMED by the caller -- ``{index in params: first coefficient}``: ``{4: 0}``
+        for a full ``[P, 16, 3]`` tensor at position 4 (``sh_coordinates``, tetgs_model.py:268-272), ``{4: 0, 5: 1}`` for the model's
+        ``_sh_coordinates_dc`` ``[P, 1, 3]`` and ``_sh_coordinates_rest`` ``[P, 15, 3]`` (:234-239).  Only these are reduced over their
+        live coefficients by ``all_reduce_rows(..., sh_degree=D)``; nothing is inferred from shapes (round 6, ADVICE: a ``[P, 4, 3]``
+        parameter that is not SH would have been cut to its leading rows)."""
         self.params = list(params)
         if not self.params:
             raise ValueError("no parameters")
+        self.sh_params = {int(k): int(v) for k, v in (sh_params or {}).items()}
+        for i, first in self.sh_params.items():
+            if not (0 <= i < len(self.params)) or self.params[i].dim() != 3 or int(self.params[i].shape[2]) != 3 or first < 0:
+                raise ValueError(f"sh_params[{i}]: not a [P, M, 3] parameter of this buffer")
         dev, dt = self.params[0].device, self.params[0].dtype
         for p in self.params:
             if p.device != dev or p.dtype != dt or not p.is_leaf or not p.requires_grad:
@@ -60,8 +69,11 @@ class FlatGradients:
         SH parameters stored for a higher one are reduced over their live coefficients only (all_reduce_rows)."""
         if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
             return None
-        if sh_degree is not None and any(self._sh_live(p.shape, sh_degree) is not None for p in self.params):
-            works = self.all_reduce_rows(0, int(self.params[0].shape[0]), group=group, sh_degree=sh_degree)
+        if sh_degree is not None and any(self._sh_live(i, sh_degree) is not None for i in range(len(self.params))):
+            P = int(self.params[0].shape[0])
+            if any(int(p.shape[0]) != P for p in self.params):
+                raise ValueError("all_reduce(sh_degree=...) reduces by rows: every parameter must be [P, ...] with the same P")
+            works = self.all_reduce_rows(0, P, group=group, sh_degree=sh_degree)
             if async_op:
                 return works[0] if len(works) == 1 else _PackedReduce(works, [])
             for w in works:
@@ -85,29 +97,28 @@ class FlatGradients:
     # (paint_2dgs.py:61-63).  Coefficients above the active degree get exactly zero gradient on every rank (backward.cu:20-139 writes
     # only the active ones), so their sum over ranks is known without moving a byte: only the (D + 1)^2 live coefficients of each SH
     # parameter are reduced -- packed into a contiguous staging slice, reduced, unpacked on wait().
-    @staticmethod
-    def _sh_live(shape, sh_degree: Optional[int]) -> Optional[int]:
-        """Live leading entries of dim 1 of a parameter [P, M, 3] at the active SH degree: a full coefficient tensor (M a square:
-        tetgs_model.py:268-272's `sh_coordinates`) keeps (D + 1)^2, a "rest" tensor (M + 1 a square: `_sh_coordinates_rest`, :234-239)
-        keeps (D + 1)^2 - 1; None: not an SH parameter / every entry is live."""
-        if sh_degree is None or len(shape) != 3 or int(shape[2]) != 3:
+    def _sh_live(self, index: int, sh_degree: Optional[int]) -> Optional[int]:
+        """Live leading entries of dim 1 of parameter `index` at the active SH degree: an SH parameter whose first entry is coefficient
+        `first` (``sh_params``) keeps (D + 1)^2 - first of them; None: not an SH parameter, or every entry is live.  The dead entries
+        must be exactly zero on every rank (the kernels write zeros there: backward.cu:20-139 touches the active coefficients only)."""
+        if sh_degree is None:
             return None
-        M, n = int(shape[1]), (int(sh_degree) + 1) ** 2
-        r = int(round(M ** 0.5))
-        if r * r == M:
-            return None if n >= M else n
-        r1 = int(round((M + 1) ** 0.5))
-        if r1 * r1 == M + 1:
-            return None if n - 1 >= M else n - 1
-        return None
+        if not self.sh_params:
+            raise ValueError("sh_degree given, but this FlatGradients was built without sh_params: name the SH parameters")
+        first = self.sh_params.get(index)
+        if first is None:
+            return None
+        M = int(self.params[index].shape[1])
+        live = min(max((int(sh_degree) + 1) ** 2 - first, 0), M)
+        return None if live >= M else live
 
     def reduced_bytes(self, count: Optional[int] = None, sh_degree: Optional[int] = None) -> int:
         """Bytes per rank that all_reduce_rows(first, count, sh_degree=...) hands to the collective (count None: all Gaussians)."""
         total = 0
-        for p in self.params:
+        for i, p in enumerate(self.params):
             P = max(int(p.shape[0]), 1)
             row = p.numel() // P
-            live = self._sh_live(p.shape, sh_degree)
+            live = self._sh_live(i, sh_degree)
             if live is not None:
                 row = live * 3
             total += row * (P if count is None else int(count)) * p.element_size()
@@ -133,7 +144,7 @@ class FlatGradients:
         for i, p in enumerate(self.params):
             P = max(int(p.shape[0]), 1)
             row = p.numel() // P
-            live = self._sh_live(p.shape, sh_degree)
+            live = self._sh_live(i, sh_degree)
             if live is None:
                 t = self.flat[off + first * row: off + (first + count) * row]
                 if t.numel():
