@@ -573,8 +573,41 @@ def secondary_workloads(a, cloud, dev, D, W, H, headline_ms):
         ms = timed(lambda i: b2.run_views(S3, big["means3D"], big["opacities"], big["shs"], big["scales"], big["rotations"], None, accumulate=False,
                                           upstream_view=lambda v, image: dL), 6, 3) / len(S3)
         gs[f"x{int(mult)}"] = {"ms_per_frame": round(ms, 4), "frames_rerendered": b2.rejected}
+        try:
+            # per stage, each kernel alone on the GPU (one stream, events around every stage) -- and the SAME cloud one view per step through the unchanged
+            # GaussianRasterizer API with its single-frame fraction of the HBM peak (round 6: large splats are the regime the reference trains in,
+            # tetgs_edit_2d.py:203; the 2.5 tiles per splat of config 3 are the synthetic floor)
+            b2.streams = 1
+            b2.run_views(S3, big["means3D"], big["opacities"], big["shs"], big["scales"], big["rotations"], None, accumulate=False, upstream_view=lambda v, image: dL)
+            torch.cuda.synchronize()
+            _C.profile_begin(64 * len(S3))
+            b2.run_views(S3, big["means3D"], big["opacities"], big["shs"], big["scales"], big["rotations"], None, accumulate=False, upstream_view=lambda v, image: dL)
+            torch.cuda.synchronize()
+            pr = _C.profile_end()
+            gs[f"x{int(mult)}"]["stages_ms_per_frame_alone"] = {k: round(ms_ / len(S3), 4) for k, (ms_, c) in pr.items() if c}
+            counts = []
+
+            def dropin_big(i):
+                for t in big.values():
+                    t.grad = None
+                m2 = torch.zeros(P, 3, device=dev, requires_grad=True)
+                img, _ = GaussianRasterizer(S3[i % len(S3)])(means3D=big["means3D"], means2D=m2, opacities=big["opacities"], shs=big["shs"], scales=big["scales"], rotations=big["rotations"])
+                img.backward(dL)
+            ms1 = timed(dropin_big, 8, 6)
+            rs_ = S3[0]
+            e_ = torch.Tensor([])
+            Rb = int(_C.rasterize_gaussians(rs_.bg, big["means3D"].detach(), e_, big["opacities"].detach(), big["scales"].detach(), big["rotations"].detach(), 1.0, e_, rs_.viewmatrix,
+                                            rs_.projmatrix, rs_.tanfovx, rs_.tanfovy, H, W, big["shs"].detach(), D, rs_.campos, False, False)[0])
+            Cin_ = 12 * (D + 1) ** 2
+            B_ = (430 + 3 * Cin_) * P + 124 * Rb + 40 * W * H
+            gs[f"x{int(mult)}"].update({"dropin_ms_per_frame": round(ms1, 4), "instances_binned_view0": Rb, "frame_algorithmic_bytes": int(B_),
+                                        "frame_hbm_frac": round(B_ / (ms1 * 1e-3) / 1e9 / 8000.0, 5)})
+        except Exception as ex:                             # noqa: BLE001 -- a secondary measurement must not take the line down
+            gs[f"x{int(mult)}"]["breakdown_error"] = repr(ex)[:200]
         del b2, big
         torch.cuda.empty_cache()
+    gs["what"] = ("every splat x 4 / x 8 (most on 5..64 tiles): ms_per_frame in 8-view batches (the headline path), stages_ms_per_frame_alone from a one-stream pass with events "
+                  "around every stage, dropin_ms_per_frame one view per step through GaussianRasterizer; frame_hbm_frac = SURVEY 8d's bytes with THIS frame's binned instances / drop-in time / 8 TB/s")
     res["grown_splats"] = gs
     # ---- the same cloud with its Gaussians numbered along a Morton curve (mesh-bound Gaussians come spatially ordered; the generator's order is random)
     mc = scenes.morton_order(cloud)

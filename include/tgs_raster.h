@@ -371,6 +371,17 @@ int tgs_backward_batch_range(void* stream, int P, int D, int M, int n_views, con
                              float* dL_dopacity, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
                              float* dL_dscale, float* dL_drot, int accumulate, int first, int count);
 
+/* The same with dL_dsh LEVEL-MAJOR (round 6; dsh_plane_stride = 0: exactly tgs_backward_batch_range): coefficient k of Gaussian p is written to
+ * dL_dsh[k * dsh_plane_stride + 3 p + c] (floats), dsh_plane_stride >= 3 P a multiple of 4, dL_dsh 16-byte aligned, M = 16.  Why: the gradients of
+ * the (D + 1)^2 coefficients that are live at the step's active degree are then ONE contiguous piece of the caller's gradient buffer, which a
+ * data-parallel step hands to the collective as it is (multiview.FlatGradients(level_major=True)); the reference's row-major [P, M, 3] layout
+ * (rasterize_points.cu:157) interleaves live and dead coefficients Gaussian by Gaussian. */
+int tgs_backward_batch_range_planes(void* stream, int P, int D, int M, int n_views, const tgs_view_t* views,
+                                    const float* means3D, const float* shs, const float* scales, float scale_modifier,
+                                    const float* rotations, const float* cov3D_precomp,
+                                    float* dL_dopacity, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                                    float* dL_dscale, float* dL_drot, int accumulate, int first, int count, int64_t dsh_plane_stride);
+
 /* ---- "next" row 2: the trainers' photometric loss ----
  * loss = (1 - dssim_factor) * l1_loss(img, gt) + dssim_factor * (1 - ssim(img, gt)), window 11, sigma 1.5, zero padding
  * (Edit_core/utils/loss_utils.py:17-18 and :39-63, composed as in tetgs_texture/refine.py:245-247), over

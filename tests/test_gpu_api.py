@@ -637,6 +637,47 @@ def test_run_views_whole_batch_path(streams, group, gpu_device):
         _C.set_forward_group(2)                 # the default
 
 
+@pytest.mark.parametrize("P", [6000, 6037])
+def test_run_views_with_level_major_sh_gradients(P, gpu_device):
+    """FlatGradients(level_major=True): the batch's per-Gaussian pass writes dL_dsh coefficient plane by coefficient plane
+    (tgs_backward_batch_range_planes) -- the SAME numbers as the row-major pass, bit for bit, at another address; stored and accumulated,
+    range by range, with a ragged last workgroup (P not a multiple of 128), and through the rare paths that go through the one-view kernel
+    (first batch, a view rendered again)."""
+    from diff_gaussian_rasterization import _C
+    from youreditableavatar_amd import scenes
+    from youreditableavatar_amd.multiview import FlatGradients, SyncFreeBatch
+    cloud = scenes.make_cloud(P, 3, seed=43, scale_mult=3.0)
+    cams = [scenes.orbit_camera(176, 112, azimuth_deg=a) for a in (0.0, 100.0, 250.0)]
+    dLs = torch.stack([torch.from_numpy(scenes.upstream_gradient(176, 112, seed=60 + i)) for i in range(3)]).to(gpu_device)
+    names = ("means3D", "opacities", "scales", "rotations", "shs")
+    settings = [_settings(c, 3, gpu_device) for c in cams]
+    _C.set_deterministic(True)
+    try:
+        res = {}
+        for lm in (False, True):
+            L = _leaves(cloud, gpu_device)
+            flat = FlatGradients([L[n] for n in names], sh_params={4: 0}, level_major=lm)
+            assert L["shs"].grad.is_contiguous() != lm
+            batch = SyncFreeBatch(granule=256, streams=2)
+            run = lambda **kw: batch.run_views(settings, L["means3D"], L["opacities"], L["shs"], L["scales"], L["rotations"], lambda images: dLs, **kw)
+            out = []
+            flat.zero_(); run(); out.append([L[n].grad.clone().contiguous() for n in names])                      # first batch: synchronous frames (one-view kernel)
+            flat.zero_(); run(); out.append([L[n].grad.clone().contiguous() for n in names])                      # whole-batch path, accumulate into zeros
+            flat.flat.fill_(7.0); run(accumulate=False, grad_chunks=3, on_chunk=lambda f, c: None)                # stores, in three ranges
+            out.append([L[n].grad.clone().contiguous() for n in names])
+            run(grad_chunks=2, on_chunk=lambda f, c: None); out.append([L[n].grad.clone().contiguous() for n in names])   # accumulates on top: twice the step
+            batch.bound = batch.bound // 3; flat.zero_(); run()                                                     # some views rendered again
+            assert batch.rejected >= 1
+            out.append([L[n].grad.clone().contiguous() for n in names])
+            res[lm] = out
+        for step, (a, b) in enumerate(zip(res[False], res[True])):
+            for n, x, y in zip(names, a, b):
+                assert torch.equal(x, y), (step, n, util.rel_l2(y.cpu().numpy(), x.cpu().numpy()))
+        assert float(res[True][1][4].abs().max()) > 0 and util.rel_l2(res[True][3][4].cpu().numpy(), 2.0 * res[True][2][4].cpu().numpy()) <= 1e-6
+    finally:
+        _C.set_deterministic(False)
+
+
 def test_run_views_with_a_list_beyond_the_lds_sort(gpu_device):
     """The sync-free batch path on a scene whose longest tile list (> 16k entries) does not fit the LDS sort: the frame is NOT rejected
     (the overflow is sorted on the device by k_tile_sort's workers, no host-sized launch), nothing is rendered again, no cooldown,

@@ -82,6 +82,9 @@ if world > 1 or alone:
     kw = dict(device_id=dev) if backend == "nccl" else {}
     dist.init_process_group(backend, timeout=datetime.timedelta(seconds=180), **kw)
 P, W, H, D, V = 7000, 208, 144, 2, 6
+LM = os.environ.get("TGS_LEVEL_MAJOR") == "1"            # SH gradients coefficient plane by coefficient plane (needs the stored degree 3: M = 16)
+if LM:
+    D = 3
 cloud = scenes.make_cloud(P, D, seed=77, scale_mult=3.0)
 ACT = os.environ.get("TGS_ACTIVE_DEGREE")               # render below the stored degree and reduce the live SH rows only
 ACT = None if ACT is None else int(ACT)
@@ -90,7 +93,7 @@ if ACT is not None:
 t = lambda a, rg=False: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev).requires_grad_(rg)
 names = ("means3D", "opacities", "scales", "rotations", "shs")
 L = {n: t(cloud[n], True) for n in names}
-flat = FlatGradients([L[n] for n in names], sh_params={4: 0})
+flat = FlatGradients([L[n] for n in names], sh_params={4: 0}, level_major=LM)
 cams = [scenes.orbit_camera(W, H, azimuth_deg=a) for a in np.linspace(0.0, 300.0, V)]
 settings = [GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=c.tanfovx, tanfovy=c.tanfovy, bg=t(c.bg), scale_modifier=1.0,
                                           viewmatrix=t(c.viewmatrix), projmatrix=t(c.projmatrix), sh_degree=D, campos=t(c.campos), prefiltered=False, debug=False)
@@ -116,6 +119,8 @@ for step in range(4):
     pending.clear()
     torch.cuda.synchronize()
     res[f"flat{step}"] = flat.flat.cpu().numpy().copy()
+    res[f"sh{step}"] = L["shs"].grad.contiguous().cpu().numpy()
+    res[f"staged{step}"] = np.asarray(len(flat.__dict__.get("_stage", {})))
     res[f"calls{step}"] = np.asarray(calls)
 res["rejected"] = np.asarray(batch.rejected)
 res["handles"] = np.asarray(n_handles)
@@ -221,4 +226,29 @@ def test_live_sh_rows_reduce_through_rccl_and_two_ranks(gpu_device, tmp_path, ac
         for r in range(2):
             assert util.rel_l2(two[r][f"flat{step}"], want) <= 2e-6, (step, r)
             assert np.all(two[r][f"flat{step}"][-7000 * 27:].reshape(7000, 9, 3)[:, live:] == 0)
+        assert np.array_equal(two[0][f"flat{step}"], two[1][f"flat{step}"])
+
+
+@pytest.mark.timeout(700)
+@pytest.mark.parametrize("active", [0, 2])
+def test_level_major_live_planes_reduce_without_staging(gpu_device, tmp_path, active):
+    """Round 6: FlatGradients(level_major=True) -- SH stored for degree 3, the step rendered at degree 0 / 2.  The per-Gaussian pass writes dL_dsh
+    plane by plane, all_reduce_rows hands the (D + 1)^2 leading planes of each range to the collective as slices of the flat buffer: nothing is
+    staged (no pack in front of the collective, no unpack behind it), RCCL at world size 1 leaves the gradients bit for bit, two ranks over gloo
+    end with the unsharded step's gradients, and the SH gradients equal the ROW-major run's bit for bit."""
+    env = dict(TGS_ACTIVE_DEGREE=str(active), TGS_LEVEL_MAJOR="1")
+    plain = _launch_workers(tmp_path, 1, "plain", env)[0]
+    rccl = _launch_workers(tmp_path, 1, "rccl", dict(env, TGS_BACKEND="nccl", TGS_EVEN_ALONE="1"))[0]
+    two = _launch_workers(tmp_path, 2, "w2", env)
+    assert list(rccl["handles"]) == [3, 3, 3, 3]
+    live = (active + 1) ** 2
+    for step in range(4):
+        want = plain[f"flat{step}"]
+        sh = plain[f"sh{step}"]
+        assert sh.shape == (7000, 16, 3) and np.abs(sh[:, :live]).max() > 0 and np.all(sh[:, live:] == 0)
+        assert np.array_equal(want, rccl[f"flat{step}"]), step
+        assert int(rccl[f"staged{step}"]) == 0 and int(two[0][f"staged{step}"]) == 0
+        for r in range(2):
+            assert util.rel_l2(two[r][f"flat{step}"], want) <= 2e-6, (step, r)
+            assert np.all(two[r][f"sh{step}"][:, live:] == 0)
         assert np.array_equal(two[0][f"flat{step}"], two[1][f"flat{step}"])

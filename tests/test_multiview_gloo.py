@@ -146,7 +146,7 @@ def test_flat_gradients_are_views():
     assert fg.all_reduce() is None          # no process group: no-op
 
 
-def _rows_step(rank, world, port, out_q, sh_degree=None):
+def _rows_step(rank, world, port, out_q, sh_degree=None, level_major=False):
     """every rank fills its flat buffer with rank-dependent values and reduces it range by range (FlatGradients.all_reduce_rows)"""
     from youreditableavatar_amd import multiview
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
@@ -156,20 +156,28 @@ def _rows_step(rank, world, port, out_q, sh_degree=None):
     if sh_degree is not None:                            # the model's own two SH parameters as well (tetgs_model.py:234-239)
         params += [torch.zeros(P, 1, 3, requires_grad=True), torch.zeros(P, 15, 3, requires_grad=True)]
         params += [torch.zeros(P, 4, 3, requires_grad=True)]   # looks like SH by its shape, is not named as SH: reduced whole (ADVICE of round 5)
-    fg = multiview.FlatGradients(params, sh_params=None if sh_degree is None else {2: 0, 3: 0, 4: 1})
+    fg = multiview.FlatGradients(params, sh_params=None if sh_degree is None else {2: 0, 3: 0, 4: 1}, level_major=level_major)
     g = torch.Generator().manual_seed(7 + rank)
-    fg.flat.copy_(torch.randn(fg.flat.numel(), generator=g))
+    for p in params:                                     # (through the .grad views: a level-major buffer has padding between its planes)
+        p.grad.copy_(torch.randn(p.shape, generator=g))
     if sh_degree is not None:                            # coefficients above the active degree have zero gradient on every rank
         live = (sh_degree + 1) ** 2
         params[2].grad[:, live:] = 0
         params[4].grad[:, live - 1:] = 0
-    mine = fg.flat.clone()
+    cat = lambda: torch.cat([p.grad.contiguous().flatten() for p in params])
+    mine = cat()
     works = []
-    for first in range(0, P, 256):                       # ranges of 256 Gaussians, the last one ragged
-        works += fg.all_reduce_rows(first, min(256, P - first), sh_degree=sh_degree)
+    if level_major == "whole":                           # one call for all Gaussians: whole planes, padding included
+        works += fg.all_reduce_rows(0, P, sh_degree=sh_degree)
+    else:
+        for first in range(0, P, 256):                   # ranges of 256 Gaussians, the last one ragged
+            works += fg.all_reduce_rows(first, min(256, P - first), sh_degree=sh_degree)
     for w in works:
         w.wait()
-    out_q.put((rank, mine.numpy(), fg.flat.clone().numpy()))
+    if level_major:                                      # a level-major buffer hands slices of `flat` to the collective: nothing is staged
+        assert not fg.__dict__.get("_stage") and all(not isinstance(w, multiview._PackedReduce) for w in works)
+        assert params[2].grad.stride() == (3, fg.regions[2][2], 1) and fg.regions[2][2] % 64 == 0 and fg.regions[2][0] % 64 == 0
+    out_q.put((rank, mine.numpy(), cat().numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -207,6 +215,43 @@ def test_all_reduce_of_live_sh_rows_by_ranges(deg):
     total = res[0][1] + res[1][1]
     for _rank, _mine, reduced in res:
         assert np.array_equal(reduced, total)           # live coefficients summed exactly once, dead ones still zero
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("deg,mode", [(0, True), (1, True), (2, "whole"), (3, True), (0, "whole")])
+def test_all_reduce_of_live_sh_rows_level_major(deg, mode):
+    """FlatGradients(level_major=True): the SH gradients are stored coefficient plane by coefficient plane, the live coefficients of a step are
+    the leading planes, and all_reduce_rows hands slices of the flat buffer to the collective -- no staging copy (round 6)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rows_step, args=(r, 2, port, q, deg, mode)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(2)], key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    total = res[0][1] + res[1][1]
+    for _rank, _mine, reduced in res:
+        assert np.array_equal(reduced, total)
+
+
+def test_level_major_gradients_are_views_of_planes():
+    from youreditableavatar_amd.multiview import FlatGradients
+    P = 70
+    a, sh = torch.zeros(P, 3, requires_grad=True), torch.zeros(P, 16, 3, requires_grad=True)
+    fg = FlatGradients([a, sh], sh_params={1: 0}, level_major=True)
+    off, n, stride = fg.regions[1]
+    assert stride == 256 and off == 256 and n == 16 * 256 and fg.flat.numel() == off + n          # 3 P = 210 -> planes of 256 floats, 256-byte aligned
+    w = torch.arange(P * 16 * 3, dtype=torch.float32).view(P, 16, 3)
+    (sh * w).sum().backward()                            # autograd accumulates into the strided .grad in place
+    assert sh.grad.data_ptr() == fg.flat.data_ptr() + 4 * off and torch.equal(sh.grad, w)
+    assert torch.equal(fg.flat[off + 5 * stride: off + 5 * stride + 3 * P].view(P, 3), w[:, 5, :])     # plane 5 = coefficient 5 of every Gaussian
+    sl = fg.row_slices(10, 20)
+    assert len(sl) == 1 + 16 and torch.equal(sl[1 + 5].view(20, 3), w[10:30, 5, :])
+    torch.optim.Adam([a, sh], lr=1e-2).step()            # an optimizer reads the strided gradient like any other
+    assert float(sh.detach().abs().max()) > 0
 
 
 def test_sh_live_rule():

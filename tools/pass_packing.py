@@ -26,9 +26,7 @@ BCH = int(sys.argv[1]) if len(sys.argv) > 1 else 384
 FORWARD = len(sys.argv) > 2 and sys.argv[2] == "forward"      # forward: unbounded lists front to back, rounds of BCH from the list's start, pixels stop at their last contributor
 SCALE = float(os.environ.get("PACK_SCALE", "1"))
 cfg = scenes.CONFIGS[3]; P, W, H, D = cfg["P"], cfg["width"], cfg["height"], cfg["sh_degree"]
-cloud = scenes.config_cloud(3)
-if SCALE != 1.0:
-    cloud = scenes.grown_splats(cloud, SCALE) if hasattr(scenes, "grown_splats") else cloud
+cloud = scenes.config_cloud(3) if SCALE == 1.0 else scenes.make_cloud(P, D, cfg["seed"], scale_mult=SCALE)      # PACK_SCALE=4: tools/stage_times.py 4's frame
 cam = scenes.orbit_camera(W, H, azimuth_deg=0.0)
 color, radii, st = oracle.forward(bg=cam.bg, means3D=cloud["means3D"], opacities=cloud["opacities"], viewmatrix=cam.viewmatrix, projmatrix=cam.projmatrix,
                                   campos=cam.campos, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, image_height=H, image_width=W, sh_degree=D, shs=cloud["shs"],

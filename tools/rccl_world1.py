@@ -85,9 +85,29 @@ torch.cuda.synchronize()
 same0 = bool(torch.equal(ref0, flat.flat))
 deg0 = {"ms_per_step_with_reduce": round(d0_r, 4), "ms_per_step_without": round(d0_n, 4), "bytes_reduced_per_step": flat.reduced_bytes(sh_degree=0),
         "bytes_of_the_whole_buffer": flat.reduced_bytes(), "gradients_unchanged_by_the_one_rank_sum": same0}
+deg0["layout"] = "row-major [P,16,3]: the live coefficients are packed into a staging slice in front of the collective and unpacked behind it"
+# the same with the SH gradients LEVEL-MAJOR (FlatGradients(level_major=True), round 6): the live coefficient is the leading plane of the parameter's
+# region -- a slice of the flat buffer goes to the collective, nothing is staged
+L_lm = {k: g(cloud[k], True) for k in ("means3D", "opacities", "scales", "rotations", "shs")}
+flat_lm = FlatGradients([L_lm[k] for k in ("means3D", "opacities", "scales", "rotations", "shs")], sh_params={4: 0}, level_major=True)
+L, flat = L_lm, flat_lm
+lm_r, _ = timed(True, 10, 4)
+lm_n, _ = timed(False, 10, 2)
+ref1 = flat.flat.clone()
+step(True)
+torch.cuda.synchronize()
+deg0_lm = {"ms_per_step_with_reduce": round(lm_r, 4), "ms_per_step_without": round(lm_n, 4), "overhead_ms": round(lm_r - lm_n, 4),
+           "gradients_unchanged_by_the_one_rank_sum": bool(torch.equal(ref1, flat.flat)), "staging_slices": len(flat.__dict__.get("_stage", {})),
+           "sh_gradients_equal_the_row_major_run": bool(torch.equal(L_lm["shs"].grad.contiguous(), ref0[-P * 48:].view(P, 16, 3))),
+           "layout": "level-major: 16 planes of 3 P floats; the collective takes the leading plane as it is"}
+deg0["overhead_ms"] = round(d0_r - d0_n, 4)
+# ... and the SH-3 headline step with the level-major layout (every plane live: the same 118 MB, written plane by plane)
 S, active = S_full, None
+lm3_n, _ = timed(False, 10, 2)
+lm3_r, _ = timed(True, 10, 2)
+full_lm = {"ms_per_step_with_reduce": round(lm3_r, 4), "ms_per_step_without": round(lm3_n, 4), "row_major_without": round(ms_n, 4)}
 print(json.dumps({"ms_per_step_with_reduce": round(ms_r, 4), "ms_per_step_without": round(ms_n, 4), "backend": str(dist.get_backend()), "collective_handles_per_step": handles,
-                  "gradients_unchanged_by_the_one_rank_sum": same, "frames_rerendered": batch.rejected, "active_sh_degree_0": deg0,
+                  "gradients_unchanged_by_the_one_rank_sum": same, "frames_rerendered": batch.rejected, "active_sh_degree_0": deg0_lm, "active_sh_degree_0_row_major": deg0, "sh_degree_3_level_major": full_lm,
                   "ms_per_step_by_ranges": table, "rccl_cost_per_collective_us_at_world_1": per_collective_us,
                   "range_cutting_cost_frac": {"2": cut2, "4": round(table["4"]["without"] / table["1"]["without"] - 1.0, 4)},
                   "overhead_frac_of_the_default_two_ranges": round(table["2"]["with_reduce"] / table["1"]["without"] - 1.0, 4),

@@ -769,6 +769,15 @@ int tgs_backward_batch_range(void* stream, int P, int D, int M, int n_views, con
                              const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp, float* dL_dopacity,
                              float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int accumulate, int first, int count)
 {
+    return tgs_backward_batch_range_planes(stream, P, D, M, n_views, views, means3D, shs, scales, scale_modifier, rotations, cov3D_precomp, dL_dopacity, dL_dmean3D,
+                                           dL_dcov3D, dL_dsh, dL_dscale, dL_drot, accumulate, first, count, 0);
+}
+
+int tgs_backward_batch_range_planes(void* stream, int P, int D, int M, int n_views, const tgs_view_t* views, const float* means3D, const float* shs,
+                                    const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp, float* dL_dopacity,
+                                    float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int accumulate, int first, int count,
+                                    int64_t dsh_plane_stride)
+{
     hipStream_t st = (hipStream_t)stream;
     g_err[0] = 0;
     const int debug = 0;
@@ -781,12 +790,15 @@ int tgs_backward_batch_range(void* stream, int P, int D, int M, int n_views, con
     if (has_sh && (D < 0 || D > 3 || M < (D + 1) * (D + 1))) return fail(TGS_ERR_INVALID, "SH degree %d needs M >= %d (M=%d)", D, (D + 1) * (D + 1), M);
     if (!means3D || !dL_dopacity || !dL_dmean3D || (has_sh && !dL_dsh) || (has_sr && (!dL_dscale || !dL_drot)) || (!has_sr && !dL_dcov3D))
         return fail(TGS_ERR_INVALID, "NULL required pointer");
+    if (dsh_plane_stride != 0 && (!has_sh || M != 16 || dsh_plane_stride < 3 * (int64_t)P || dsh_plane_stride % 4 != 0 || ((uintptr_t)dL_dsh & 15u) != 0))
+        return fail(TGS_ERR_INVALID, "level-major dL_dsh needs SH colours with M = 16, a plane stride >= 3 P that is a multiple of 4 floats, and a 16-byte aligned dL_dsh");
     BwdIn in;
     memset(&in, 0, sizeof(in));
     in.P = P; in.D = D; in.M = M; in.means3D = means3D; in.shs = shs; in.scales = scales; in.rotations = rotations; in.cov3D_precomp = cov3D_precomp;
     in.dL_dopacity = dL_dopacity; in.dL_dmean3D = dL_dmean3D; in.dL_dcov3D = has_sr ? nullptr : dL_dcov3D; in.dL_dsh = dL_dsh;
     in.dL_dscale = has_sr ? dL_dscale : nullptr; in.dL_drot = has_sr ? dL_drot : nullptr;
     in.block0 = first / PRE_BLOCK; in.nblocks = (int)n_blocks((size_t)count);
+    in.dsh_plane = (long long)dsh_plane_stride;
     for (int v0 = 0; v0 < n_views; v0 += BATCH_VIEWS) {
         BatchViews bv;
         memset(&bv, 0, sizeof(bv));

@@ -1227,6 +1227,10 @@ __device__ __forceinline__ void load_sh_rows_staged(const BwdIn& in, float4* sh_
 // (The one-view kernel keeps its own copy of the math of pergauss_terms: routed through the shared function hipcc
 // allocates 172 VGPRs instead of 132 -- 2 resident waves per SIMD instead of 3 -- and the kernel takes 120 us instead
 // of 98.  tests/test_gpu_api.py::test_batched_backward_equals_per_view_backward keeps the two in step.)
+#ifndef TGS_SH_ROW
+#define TGS_SH_ROW 12
+#endif
+constexpr int SH_ROW = TGS_SH_ROW;
 template <bool HAS_SH, bool HAS_SCALE_ROT>
 __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, const CamParams cam, const GeomState g, const BinState b)
 {
@@ -1251,7 +1255,13 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
     const ViewMat V = load_mat(cam.view), PM = load_mat(cam.proj);
     const float camx = cam.campos[0], camy = cam.campos[1], camz = cam.campos[2];
     // SH rows in, dL_dsh rows out: staged through LDS so that global memory sees 16 B per lane, fully coalesced
-    __shared__ float4 sh_lds[HAS_SH ? PRE_BLOCK * 12 : 1];
+    // Rows of SH_ROW float4 per thread.  12 (192 B: a thread's rows 48 banks apart) puts every fourth lane of a 16-B access on the same banks
+    // (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.61, profiles/r06_a_store_mode_counters.txt); 13 -- an odd number of 16-byte cells -- spreads 16
+    // lanes over all 64 banks; the coalesced side then addresses piece i of the workgroup's 3072 at i + i / 12.  Measured (round 6, -DTGS_SH_ROW=13
+    // against 12, one box, tools/stage_times.py): 62.2-62.6 against 62.8-62.9 us -- the conflicts are not what this kernel waits for (SQ_WAIT_INST_LDS
+    // is 3.6 % of its wave cycles), and 13 leaves 4 KB of the CU's LDS for three workgroups.  12 stays.
+    __shared__ float4 sh_lds[HAS_SH ? PRE_BLOCK * SH_ROW : 1];
+    auto piece = [](uint32_t i) { return SH_ROW == 12 ? i : i + ((i * 43691u) >> 19); };     // i / 12 for i < 3072: 43691 = ceil(2^19 / 12)
     const bool sh_staged = HAS_SH && in.M == 16;
     const size_t base4 = (size_t)blockIdx.x * PRE_BLOCK * 12, total4 = (size_t)in.P * 12;
     const bool in_range = idx < in.P;
@@ -1279,7 +1289,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
         for (int q = 0; q < 12; q++) { const size_t i = base4 + q * PRE_BLOCK + threadIdx.x; r[q] = s4[i < total4 ? i : total4 - 1]; }
         asm volatile("" ::: "memory");                      // (all of the above is asked for before the first wait)
 #pragma unroll
-        for (int q = 0; q < 12; q++) sh_lds[q * PRE_BLOCK + threadIdx.x] = make_float4(r[q].x, r[q].y, r[q].z, r[q].w);
+        for (int q = 0; q < 12; q++) sh_lds[piece(q * PRE_BLOCK + threadIdx.x)] = make_float4(r[q].x, r[q].y, r[q].z, r[q].w);
         __syncthreads();
     }
     float a[NACC];
@@ -1323,7 +1333,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
             if (sh_staged) {
 #pragma unroll
                 for (int q = 0; q < 12; q++) {
-                    if (q * 4 < ncoef * 3) { const float4 t = sh_lds[threadIdx.x * 12 + q]; shv[4 * q] = t.x; shv[4 * q + 1] = t.y; shv[4 * q + 2] = t.z; shv[4 * q + 3] = t.w; }
+                    if (q * 4 < ncoef * 3) { const float4 t = sh_lds[threadIdx.x * SH_ROW + q]; shv[4 * q] = t.x; shv[4 * q + 1] = t.y; shv[4 * q + 2] = t.z; shv[4 * q + 3] = t.w; }
                 }
             } else {
                 const float* sh = in.shs + (size_t)idx * in.M * 3;
@@ -1390,7 +1400,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
                 float o[4];
 #pragma unroll
                 for (int t = 0; t < 4; t++) { const int i = 4 * q + t; o[t] = coef[i / 3] * dRGB[i % 3]; }
-                sh_lds[threadIdx.x * 12 + q] = make_float4(o[0], o[1], o[2], o[3]);
+                sh_lds[threadIdx.x * SH_ROW + q] = make_float4(o[0], o[1], o[2], o[3]);
             }
             __syncthreads();
             float4* d4 = reinterpret_cast<float4*>(in.dL_dsh);
@@ -1406,7 +1416,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
             for (int q = 0; q < 12; q++) {
                 const size_t i = base4 + q * PRE_BLOCK + threadIdx.x;
                 if (i < total4) {
-                    float4 o = sh_lds[q * PRE_BLOCK + threadIdx.x];
+                    float4 o = sh_lds[piece(q * PRE_BLOCK + threadIdx.x)];
                     if (in.accumulate) { o.x += prev[q].x; o.y += prev[q].y; o.z += prev[q].z; o.w += prev[q].w; }
                     d4[i] = o;
                 }
@@ -1707,8 +1717,14 @@ __global__ __launch_bounds__(PRE_BLOCK, TGS_SPLIT_WAVES) void k_preprocess_bwd_b
         }
         dm_lds[0][gl] = dmean[0]; dm_lds[1][gl] = dmean[1]; dm_lds[2][gl] = dmean[2];
         __syncthreads();                                   // (A) the geometry half has the colour half's dL_dmean3D; every SH row has been consumed
+        if (in.dsh_plane == 0) {
 #pragma unroll
-        for (int q = 0; q < 12; q++) sh_lds[gl * 12 + q] = make_float4(o48[4 * q], o48[4 * q + 1], o48[4 * q + 2], o48[4 * q + 3]);
+            for (int q = 0; q < 12; q++) sh_lds[gl * 12 + q] = make_float4(o48[4 * q], o48[4 * q + 1], o48[4 * q + 2], o48[4 * q + 3]);
+        } else {                                           // level-major output: plane k of the workgroup = 128 x 3 consecutive floats (lane stride 3 words: no bank conflict)
+            float* lf = reinterpret_cast<float*>(sh_lds);
+#pragma unroll
+            for (int i = 0; i < 48; i++) lf[(i / 3) * (3 * SPLIT_G) + 3 * gl + (i % 3)] = o48[i];
+        }
         __syncthreads();                                   // (B) the dL_dsh rows are staged
     } else {
         float dopacity = 0.f, dmean[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dscale[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1750,7 +1766,40 @@ __global__ __launch_bounds__(PRE_BLOCK, TGS_SPLIT_WAVES) void k_preprocess_bwd_b
         }
         __syncthreads();                                   // (B)
     }
-    {   // dL_dsh rows out: 6 coalesced 16-B stores per thread
+    if (in.dsh_plane != 0) {
+        // LEVEL-MAJOR dL_dsh (round 6): coefficient k of all Gaussians is one plane, so the (D + 1)^2 LIVE coefficients of a step rendered below the
+        // stored degree are ONE contiguous piece of the gradient buffer -- a data-parallel step hands that piece to the collective as it is
+        // (FlatGradients(level_major=True)), where the row-major layout needed a strided pack and unpack of 28 MB around it (round 5: 0.128 ms per
+        // step).  The workgroup's share of plane k: 384 consecutive floats = 96 float4; 16 planes x 96 = the same 6 coalesced 16-B stores per thread.
+        float* dsh = in.dL_dsh;
+        const long long left = (long long)in.P - (long long)gbase;                                          // (<= 0: a workgroup behind the last Gaussian -- the grid covers whole 256-blocks)
+        const uint32_t nval = 3u * (uint32_t)(left <= 0 ? 0 : (left < (long long)SPLIT_G ? left : (long long)SPLIT_G));   // valid floats of this workgroup per plane
+        float* dst[6]; uint32_t f0[6];
+        float4 prev[6];
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            const uint32_t j = (uint32_t)(q * PRE_BLOCK) + threadIdx.x, k = (j * 683u) >> 16;                  // j / 96 for j < 1536
+            f0[q] = 4u * (j - 96u * k);
+            dst[q] = dsh + (size_t)k * (size_t)in.dsh_plane + 3 * gbase + f0[q];
+            prev[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (in.accumulate) {
+#pragma unroll
+            for (int q = 0; q < 6; q++) if (f0[q] + 3u < nval) prev[q] = *reinterpret_cast<const float4*>(dst[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            float4 o = sh_lds[q * PRE_BLOCK + threadIdx.x];
+            if (f0[q] + 3u < nval) {
+                o.x += prev[q].x; o.y += prev[q].y; o.z += prev[q].z; o.w += prev[q].w;
+                *reinterpret_cast<float4*>(dst[q]) = o;
+            } else {                                        // the last workgroup's ragged end: float by float
+                const float ov[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                for (int i = 0; i < 4; i++) if (f0[q] + (uint32_t)i < nval) dst[q][i] = (in.accumulate ? dst[q][i] : 0.f) + ov[i];
+            }
+        }
+    } else {   // dL_dsh rows out: 6 coalesced 16-B stores per thread
         float4* d4 = reinterpret_cast<float4*>(in.dL_dsh);
         const size_t base4 = gbase * 12, total4 = (size_t)in.P * 12;
         float4 prev[6];
@@ -1822,7 +1871,7 @@ void launch_preprocess_bwd_batch(hipStream_t st, const BwdIn& in, const BatchVie
 {
     const dim3 grid((unsigned)(in.nblocks > 0 ? in.nblocks : n_blocks(in.P))), blk(PRE_BLOCK);
     const bool sh = in.shs != nullptr, sr = in.scales != nullptr;
-    if (sh && in.M == 16) {                                 // two threads per Gaussian: 128 Gaussians per workgroup (the one-thread kernel below: per-view colours, other M)
+    if (sh && in.M == 16) {                                 // two threads per Gaussian: 128 Gaussians per workgroup (the one-thread kernel below: per-view colours, other M; tgs_api refuses dsh_plane != 0 there)
         const dim3 grid2(2 * grid.x);
         if (sr) hipLaunchKernelGGL((k_preprocess_bwd_batch_split<true>), grid2, blk, 0, st, in, views);
         else hipLaunchKernelGGL((k_preprocess_bwd_batch_split<false>), grid2, blk, 0, st, in, views);

@@ -973,6 +973,8 @@ struct BwdIn {
     int accumulate;   // 1: parameter gradients (all but dL_dmean2D / dL_dconic) are added to what the buffers hold
     const Meta* meta; // the frame's Meta: a frame rejected by tgs_forward_async contributes nothing
     int block0, nblocks;   // k_preprocess_bwd_batch only: first PRE_BLOCK-sized block of Gaussians and how many this launch covers (0: all)
+    long long dsh_plane;   // k_preprocess_bwd_batch_split only: 0 = dL_dsh is [P, M, 3] row-major; > 0 = LEVEL-MAJOR, coefficient k of Gaussian p at
+                           // dL_dsh[k * dsh_plane + 3 p + c] (floats; a multiple of 4, dL_dsh 16-byte aligned) -- tgs_backward_batch_range_planes
 };
 
 // One view of a batch for k_preprocess_bwd_batch: everything that differs between the views (kernel argument)

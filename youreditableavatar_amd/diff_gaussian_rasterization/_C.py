@@ -78,6 +78,11 @@ def _load() -> C.CDLL:
     lib.tgs_backward_batch.argtypes = [vp, it, it, it, it, vp, vp, vp, vp, fl, vp, vp, vp, vp, vp, vp, vp, vp, it]
     lib.tgs_backward_batch_range.restype = it
     lib.tgs_backward_batch_range.argtypes = lib.tgs_backward_batch.argtypes + [it, it]
+    try:                                                     # (additive since round 6: an older A/B build of the same ABI version lacks it)
+        lib.tgs_backward_batch_range_planes.restype = it
+        lib.tgs_backward_batch_range_planes.argtypes = lib.tgs_backward_batch_range.argtypes + [C.c_int64]
+    except AttributeError:
+        pass
     lib.tgs_mark_visible.restype = it
     lib.tgs_mark_visible.argtypes = [vp, it, vp, vp, vp, vp]
     lib.tgs_state_field.restype = C.c_int64
@@ -473,13 +478,15 @@ def backward_render_views(stream_handles, P, views, n_views, opt: Optional[_Opti
 
 
 def backward_batch_raw(stream, P, D, M, views, n_views, means3D, shs, scales, scale_modifier, rotations, dL_dopacity, dL_dmean3D, dL_dsh, dL_dscale,
-                       dL_drot, accumulate, first: int = 0, count: Optional[int] = None) -> None:
+                       dL_drot, accumulate, first: int = 0, count: Optional[int] = None, dsh_plane_stride: int = 0) -> None:
     """tgs_backward_batch[_range] on prepared device pointers (scales/rotations path; ``shs`` None: per-view colours, their gradients go to
-    the views' dL_dcolor).  ``first`` / ``count``: only Gaussians [first, first + count) (multiples of 256, or ending at P)."""
-    r = _lib.tgs_backward_batch_range(stream, int(P), int(D), int(M), int(n_views), views if isinstance(views, C.c_void_p) else C.cast(views, C.c_void_p), means3D, shs,
-                                      scales, float(scale_modifier),
-                                      rotations, None, dL_dopacity, dL_dmean3D, None, dL_dsh if shs else None, dL_dscale, dL_drot, 1 if accumulate else 0,
-                                      int(first), int(P - first if count is None else count))
+    the views' dL_dcolor).  ``first`` / ``count``: only Gaussians [first, first + count) (multiples of 256, or ending at P).
+    ``dsh_plane_stride`` > 0: dL_dsh level-major (tgs_backward_batch_range_planes: coefficient k of Gaussian p at k * stride + 3 p)."""
+    args = (stream, int(P), int(D), int(M), int(n_views), views if isinstance(views, C.c_void_p) else C.cast(views, C.c_void_p), means3D, shs,
+            scales, float(scale_modifier),
+            rotations, None, dL_dopacity, dL_dmean3D, None, dL_dsh if shs else None, dL_dscale, dL_drot, 1 if accumulate else 0,
+            int(first), int(P - first if count is None else count))
+    r = _lib.tgs_backward_batch_range_planes(*args, int(dsh_plane_stride)) if dsh_plane_stride else _lib.tgs_backward_batch_range(*args)
     if r < 0:
         raise _err(int(r))
 

@@ -37,12 +37,22 @@ class FlatGradients:
     across the views of a shard, and ``all_reduce`` sums the whole step with a single collective
     (236 B per Gaussian on the SH path = 118 MB at 500k Gaussians)."""
 
-    def __init__(self, params: Sequence[torch.Tensor], sh_params: Optional[dict] = None):
+    PLANE_ALIGN = 64      # floats: level-major planes start on 256-byte boundaries (16-byte stores of the kernel, aligned slices for the collective)
+
+    def __init__(self, params: Sequence[torch.Tensor], sh_params: Optional[dict] = None, level_major: bool = False):
         """``sh_params``: which parameters hold SH coefficients, NAMED by the caller -- ``{index in params: first coefficient}``: ``{4: 0}``
         for a full ``[P, 16, 3]`` tensor at position 4 (``sh_coordinates``, tetgs_model.py:268-272), ``{4: 0, 5: 1}`` for the model's
         ``_sh_coordinates_dc`` ``[P, 1, 3]`` and ``_sh_coordinates_rest`` ``[P, 15, 3]`` (:234-239).  Only these are reduced over their
         live coefficients by ``all_reduce_rows(..., sh_degree=D)``; nothing is inferred from shapes (round 6, ADVICE: a ``[P, 4, 3]``
-        parameter that is not SH would have been cut to its leading rows)."""
+        parameter that is not SH would have been cut to its leading rows).
+
+        ``level_major`` (round 6): the gradients of the named SH parameters are stored coefficient by coefficient -- ``flat`` holds, per SH
+        parameter, M planes of ``plane_stride`` = 3 P (rounded up to 64) floats, and ``p.grad`` is the ``[P, M, 3]`` VIEW of them with strides
+        (3, plane_stride, 1).  The live coefficients of a step rendered below the stored degree are then the leading planes -- one contiguous
+        slice per range of Gaussians and coefficient, handed to the collective as it is: no staging copy in front of it, none behind it
+        (row-major: a strided pack and unpack of 28 MB per step at 500 k Gaussians and degree 0, 0.128 ms where no byte crosses a link).
+        ``SyncFreeBatch.run_views`` sees the strides and lets the per-Gaussian pass write that layout (tgs_backward_batch_range_planes).
+        An optimizer reads such a ``.grad`` like any other strided tensor."""
         self.params = list(params)
         if not self.params:
             raise ValueError("no parameters")
@@ -54,12 +64,27 @@ class FlatGradients:
         for p in self.params:
             if p.device != dev or p.dtype != dt or not p.is_leaf or not p.requires_grad:
                 raise ValueError("parameters must be leaf tensors requiring grad, on one device, of one dtype")
-        total = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(total, dtype=dt, device=dev)
-        off = 0
-        for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
+        self.level_major = bool(level_major) and bool(self.sh_params)
+        # region of parameter i in `flat`: (offset, numel, plane_stride or 0)
+        self.regions, off = [], 0
+        A = self.PLANE_ALIGN
+        for i, p in enumerate(self.params):
+            if self.level_major and i in self.sh_params:
+                off = (off + A - 1) // A * A
+                stride = (3 * int(p.shape[0]) + A - 1) // A * A
+                n = int(p.shape[1]) * stride
+                self.regions.append((off, n, stride))
+            else:
+                n = p.numel()
+                self.regions.append((off, n, 0))
+            off += n
+        self.flat = torch.zeros(off, dtype=dt, device=dev)
+        for p, (o, n, stride) in zip(self.params, self.regions):
+            if stride:
+                P, M = int(p.shape[0]), int(p.shape[1])
+                p.grad = self.flat[o:o + n].view(M, stride)[:, :3 * P].view(M, P, 3).permute(1, 0, 2)     # [P, M, 3], strides (3, stride, 1)
+            else:
+                p.grad = self.flat[o:o + n].view_as(p)
 
     def zero_(self) -> None:
         self.flat.zero_()
@@ -84,11 +109,13 @@ class FlatGradients:
     def row_slices(self, first: int, count: int) -> List[torch.Tensor]:
         """The pieces of ``flat`` that hold the gradients of Gaussians [first, first + count): one contiguous slice per parameter
         (every parameter is [P, ...] row-major, so a range of Gaussians is a range of rows)."""
-        out, off = [], 0
-        for p in self.params:
-            row = p.numel() // max(int(p.shape[0]), 1)
-            out.append(self.flat[off + first * row: off + (first + count) * row])
-            off += p.numel()
+        out = []
+        for p, (off, n, stride) in zip(self.params, self.regions):
+            if stride:                                       # level-major: one slice per coefficient plane
+                out.extend(self.flat[off + k * stride + 3 * first: off + k * stride + 3 * (first + count)] for k in range(int(p.shape[1])))
+            else:
+                row = p.numel() // max(int(p.shape[0]), 1)
+                out.append(self.flat[off + first * row: off + (first + count) * row])
         return out
 
     # ---- live SH rows ------------------------------------------------------------------------------------------------------------
@@ -140,12 +167,19 @@ class FlatGradients:
         too (tests: the RCCL path on a one-GPU box)."""
         if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not even_alone):
             return []
-        pieces, packed, off = [], [], 0
-        for i, p in enumerate(self.params):
+        pieces, packed = [], []
+        for i, (p, (off, n, stride)) in enumerate(zip(self.params, self.regions)):
             P = max(int(p.shape[0]), 1)
             row = p.numel() // P
             live = self._sh_live(i, sh_degree)
-            if live is None:
+            if stride:                                       # level-major: the live coefficients are the leading planes -- slices of `flat`, no staging
+                planes = int(p.shape[1]) if live is None else live
+                if count > 0 and planes > 0:
+                    if first == 0 and count == P:            # all Gaussians: the planes, padding included (zeros), are ONE slice
+                        pieces.append(self.flat[off: off + planes * stride])
+                    else:
+                        pieces.extend(self.flat[off + k * stride + 3 * first: off + k * stride + 3 * (first + count)] for k in range(planes))
+            elif live is None:
                 t = self.flat[off + first * row: off + (first + count) * row]
                 if t.numel():
                     pieces.append(t)
@@ -155,7 +189,6 @@ class FlatGradients:
                 stage.view(count, live, 3).copy_(src)
                 pieces.append(stage)
                 packed.append((src, stage.view(count, live, 3)))
-            off += p.numel()
         if not pieces:
             return []
         if _coalesced_all_reduce_supported(group):
@@ -449,10 +482,18 @@ class SyncFreeBatch:
                 raise RuntimeError("run_views: colors_precomp must be a contiguous float32 GPU tensor [V,P,3]")
         else:
             params["sh"] = shs
-        for name, t in params.items():
-            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.is_leaf and t.grad is not None and t.grad.is_contiguous()):
-                raise RuntimeError(f"run_views: {name} must be a contiguous float32 leaf parameter on the GPU with an allocated .grad (see FlatGradients)")
         M = 0 if precomp else int(shs.size(1))
+        # dL_dsh level-major (FlatGradients(level_major=True)): .grad is the [P, M, 3] view of M planes, strides (3, plane, 1)
+        dsh_plane = 0
+        if not precomp and shs.grad is not None and not shs.grad.is_contiguous():
+            st = shs.grad.stride()
+            if not (M == 16 and st[0] == 3 and st[2] == 1 and st[1] >= 3 * int(shs.size(0)) and st[1] % 4 == 0 and shs.grad.data_ptr() % 16 == 0):
+                raise RuntimeError("run_views: shs.grad must be contiguous, or the level-major view FlatGradients(level_major=True) makes of a [P,16,3] parameter")
+            dsh_plane = int(st[1])
+        for name, t in params.items():
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.is_leaf and t.grad is not None and
+                    (t.grad.is_contiguous() or (name == "sh" and dsh_plane))):
+                raise RuntimeError(f"run_views: {name} must be a contiguous float32 leaf parameter on the GPU with an allocated .grad (see FlatGradients)")
         cap = self.capacity()
         tcap = self.tile_capacity()
         dev = means3D.device
@@ -482,11 +523,15 @@ class SyncFreeBatch:
                 gcol[v].zero_()
                 into["colors_precomp"] = gcol[v]             # per-view colours: their gradient is this view's alone
             else:
-                into["sh"] = shs.grad
-            return _C.rasterize_gaussians_backward_accumulate(rs.bg, means3D.detach(), radii, colors_precomp[v] if precomp else e, scales.detach(),
-                                                              rotations.detach(), rs.scale_modifier, e, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, g,
-                                                              e if precomp else shs.detach(), D, rs.campos, geom, R, binning, img, rs.debug, into,
-                                                              deterministic=self._deterministic)
+                # (the one-view kernel writes rows: with a level-major .grad this rare path -- first batch, a view rendered again -- goes through a row-major temporary)
+                into["sh"] = torch.zeros_like(shs) if dsh_plane else shs.grad
+            g2 = _C.rasterize_gaussians_backward_accumulate(rs.bg, means3D.detach(), radii, colors_precomp[v] if precomp else e, scales.detach(),
+                                                            rotations.detach(), rs.scale_modifier, e, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, g,
+                                                            e if precomp else shs.detach(), D, rs.campos, geom, R, binning, img, rs.debug, into,
+                                                            deterministic=self._deterministic)
+            if dsh_plane and not precomp:
+                shs.grad.add_(into["sh"])
+            return g2
 
         def grad_of(dL, v):
             return dL if dL.dim() == 3 else dL[v]
@@ -634,7 +679,8 @@ class SyncFreeBatch:
             for g0, gcount in ranges:
                 _C.backward_batch_raw(main.cuda_stream, P, D, M, arr, V, means3D.data_ptr(), None if precomp else shs.data_ptr(), scales.data_ptr(),
                                       rs0.scale_modifier, rotations.data_ptr(), opacities.grad.data_ptr(), means3D.grad.data_ptr(),
-                                      None if precomp else shs.grad.data_ptr(), scales.grad.data_ptr(), rotations.grad.data_ptr(), accumulate, g0, gcount)
+                                      None if precomp else shs.grad.data_ptr(), scales.grad.data_ptr(), rotations.grad.data_ptr(), accumulate, g0, gcount,
+                                      dsh_plane_stride=dsh_plane)
                 if eager:
                     on_chunk(g0, gcount)
         self.viewspace_grads = pool["g2d"]
