@@ -189,7 +189,11 @@ int tgs_backward_accumulate(void* stream, int P, int D, int M, int64_t R,
                             float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
                             int debug);
 
-/* tgs_backward (accumulate = 0) / tgs_backward_accumulate (1) with explicit options (deterministic, tile_bound). */
+/* tgs_backward (accumulate = 0) / tgs_backward_accumulate (1) with explicit options (deterministic, tile_bound).
+ * Round 6: the outputs that are intermediates of the reference's two-kernel backward and that its Python layer discards may be NULL here --
+ * dL_dconic always, dL_dcolor when shs != NULL, dL_dcov3D when scales / rotations != NULL (backward.cu:399-557 -> :144-274 hands them from
+ * kernel to kernel; __init__.py:137-152 returns them to inputs that are None): they are then not written -- 52 of the ~300 B the
+ * per-Gaussian kernel stores per Gaussian.  tgs_backward / tgs_backward_accumulate keep the reference's contract (every output required). */
 int tgs_backward_opt(const tgs_options_t* opt, int accumulate, void* stream, int P, int D, int M, int64_t R,
                      const float* background, int width, int height,
                      const float* means3D, const float* shs, const float* colors_precomp,

@@ -118,6 +118,13 @@ def test_argument_validation_needs_no_gpu():
     lib.tgs_backward_batch.restype = it
     lib.tgs_backward_batch.argtypes = [vp, it, it, it, it, vp, vp, vp, vp, fl, vp, vp, vp, vp, vp, vp, vp, vp, it]
     assert lib.tgs_backward_batch(None, 10, 3, 16, 2, None, None, None, None, 1.0, None, None, None, None, None, None, None, None, 0) == INVALID
+    # level-major dL_dsh (round 6): M = 16, a plane stride >= 3 P that is a multiple of 4, a 16-byte aligned pointer
+    lib.tgs_backward_batch_range_planes.restype = it
+    lib.tgs_backward_batch_range_planes.argtypes = lib.tgs_backward_batch.argtypes + [it, it, i64]
+    some = ctypes.c_void_p(4096)
+    planes = lambda M, stride, dsh: lib.tgs_backward_batch_range_planes(None, 1000, 2, M, 1, some, some, some, some, 1.0, some, None, some, some, None, dsh, some, some, 0, 0, 1000, stride)
+    assert planes(9, 3008, some) == INVALID and "level-major" in msg()
+    assert planes(16, 2999, some) == INVALID and planes(16, 3002, some) == INVALID and planes(16, 3008, ctypes.c_void_p(4100)) == INVALID
     lib.tgs_forward_views.restype = it
     lib.tgs_forward_views.argtypes = [vp, it, i64, it, it, it, vp, vp, vp, vp, vp, fl, vp, vp, it, it, vp]
     assert lib.tgs_forward_views(None, 0, 100, 10, 3, 16, None, None, None, None, None, 1.0, None, None, 0, 2, None) == INVALID

@@ -637,6 +637,49 @@ def test_run_views_whole_batch_path(streams, group, gpu_device):
         _C.set_forward_group(2)                 # the default
 
 
+@pytest.mark.parametrize("mode,cov_mode", [("sh", "scale_rot"), ("precomp", "scale_rot"), ("sh", "cov3d")])
+def test_backward_outputs_the_caller_discards_are_not_written(mode, cov_mode, gpu_device):
+    """Round 6: dL_dcolors on the SH path and dL_dcov3D on the scale / rotation path go to inputs that are None (__init__.py:137-152) -- the
+    drop-in backward passes need_colors / need_cov3D = False and the per-Gaussian kernel does not write them (NULL through tgs_backward_opt).
+    Every other output is bit for bit what the call that writes everything returns; a required one (colours with colors_precomp, cov3D with
+    cov3D_precomp) is written whatever the flags say."""
+    from diff_gaussian_rasterization import _C, GaussianRasterizer
+    from youreditableavatar_amd import scenes
+    cloud = scenes.make_cloud(5000, 2, seed=9, scale_mult=2.0)
+    if cov_mode == "cov3d":
+        from oracle.emu_crosscheck_cov import cov3d_from
+        cloud["cov3D_precomp"] = cov3d_from(cloud["scales"], cloud["rotations"])
+    cam = scenes.orbit_camera(200, 120, azimuth_deg=30.0)
+    inp = util.scene_input(cloud, cam, mode, cov_mode)
+    dL = torch.from_numpy(scenes.upstream_gradient(200, 120, seed=4)).to(gpu_device)
+    t = lambda k: (torch.from_numpy(np.ascontiguousarray(inp[k], np.float32)).to(gpu_device) if inp.get(k) is not None else torch.Tensor([]))
+    bg, means3D, opac, view, proj, campos = t("bg"), t("means3D"), t("opacities"), t("viewmatrix"), t("projmatrix"), t("campos")
+    sh, colors, scales, rots, cov = t("shs"), t("colors_precomp"), t("scales"), t("rotations"), t("cov3D_precomp")
+    R, color, radii, geom, binning, img = _C.rasterize_gaussians(bg, means3D, colors, opac, scales, rots, 1.0, cov, view, proj, float(inp["tanfovx"]), float(inp["tanfovy"]), 120, 200,
+                                                                 sh, 2, campos, False, False)
+    bw = lambda **kw: _C.rasterize_gaussians_backward(bg, means3D, radii, colors, scales, rots, 1.0, cov, view, proj, float(inp["tanfovx"]), float(inp["tanfovy"]), dL, sh, 2, campos,
+                                                      geom, R, binning, img, False, deterministic=True, **kw)
+    full = bw()
+    lean = bw(need_colors=False, need_cov3D=False)
+    names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations")
+    for n, a, b in zip(names, full, lean):
+        dropped = (n == "dL_dcolors" and mode == "sh") or (n == "dL_dcov3D" and cov_mode == "scale_rot")
+        if dropped:
+            assert b.numel() == 0 and a.shape[0] == 5000, n
+        else:
+            assert torch.equal(a, b), n
+    # ... and through the drop-in API: the same parameter gradients as before
+    Lp = {k: t(k).requires_grad_(True) for k in ("means3D", "opacities") + (("shs",) if mode == "sh" else ("colors_precomp",)) +
+          (("scales", "rotations") if cov_mode == "scale_rot" else ("cov3D_precomp",))}
+    img2, _ = GaussianRasterizer(_settings(cam, 2, gpu_device))(means3D=Lp["means3D"], means2D=torch.zeros(5000, 3, device=gpu_device, requires_grad=True), opacities=Lp["opacities"],
+                                                               shs=Lp.get("shs"), colors_precomp=Lp.get("colors_precomp"), scales=Lp.get("scales"), rotations=Lp.get("rotations"),
+                                                               cov3D_precomp=Lp.get("cov3D_precomp"))
+    img2.backward(dL)
+    want = dict(means3D=full[3], opacities=full[2], shs=full[5], colors_precomp=full[1], scales=full[6], rotations=full[7], cov3D_precomp=full[4])
+    for k, p in Lp.items():
+        assert p.grad is not None and util.rel_l2(p.grad.cpu().numpy(), want[k].cpu().numpy().reshape(p.grad.shape)) <= 2e-6, k
+
+
 @pytest.mark.parametrize("P", [6000, 6037])
 def test_run_views_with_level_major_sh_gradients(P, gpu_device):
     """FlatGradients(level_major=True): the batch's per-Gaussian pass writes dL_dsh coefficient plane by coefficient plane

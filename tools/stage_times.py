@@ -9,6 +9,8 @@ dev = torch.device("cuda", 0)
 cfg = scenes.CONFIGS[3]; P, W, H, D = cfg["P"], cfg["width"], cfg["height"], cfg["sh_degree"]
 sm = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
 cloud = scenes.make_cloud(P, D, cfg["seed"], scale_mult=sm)
+if os.environ.get("STAGE_MORTON") == "1":            # the same cloud numbered along a 3-D Morton curve (mesh-bound Gaussians come spatially ordered)
+    cloud = scenes.morton_order(cloud)
 if len(sys.argv) > 2:
     cloud["opacities"] = np.full_like(cloud["opacities"], float(sys.argv[2]))
 g = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)

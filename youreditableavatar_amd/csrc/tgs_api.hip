@@ -492,7 +492,9 @@ int tgs_frame_status(void* stream, const void* img_buffer, int64_t* num_rendered
     return TGS_OK;
 }
 
-static int backward_impl(const Opts& opt, int accumulate, void* stream, int P, int D, int M, int64_t R, const float* background, int width, int height, const float* means3D,
+// strict: tgs_backward / tgs_backward_accumulate as the reference's Rasterizer::backward declares them (every output required);
+// tgs_backward_opt: the outputs its caller discards may be NULL (dL_dconic; dL_dcolor with shs; dL_dcov3D with scales + rotations)
+static int backward_impl(bool strict, const Opts& opt, int accumulate, void* stream, int P, int D, int M, int64_t R, const float* background, int width, int height, const float* means3D,
                  const float* shs, const float* colors_precomp, const float* scales, float scale_modifier, const float* rotations,
                  const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx,
                  float tan_fovy, const int* radii, const void* geom_buffer, const void* binning_buffer, const void* img_buffer,
@@ -506,9 +508,9 @@ static int backward_impl(const Opts& opt, int accumulate, void* stream, int P, i
     const bool has_sh = shs != nullptr, has_sr = scales != nullptr && rotations != nullptr;
     if (has_sh == (colors_precomp != nullptr)) return fail(TGS_ERR_INVALID, "provide exactly one of shs / colors_precomp");
     if (has_sr == (cov3D_precomp != nullptr)) return fail(TGS_ERR_INVALID, "provide exactly one of (scales, rotations) / cov3D_precomp");
-    if (!geom_buffer || !binning_buffer || !img_buffer || !radii || !dL_dpix || !dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dmean3D ||
-        (has_sh && !dL_dsh) || (!accumulate && (!dL_dcolor || !dL_dcov3D)) || (accumulate && !has_sh && !dL_dcolor) ||
-        (accumulate && !has_sr && !dL_dcov3D))
+    if (!geom_buffer || !binning_buffer || !img_buffer || !radii || !dL_dpix || !dL_dmean2D || !dL_dopacity || !dL_dmean3D ||
+        (has_sh && !dL_dsh) || (!has_sh && !dL_dcolor) || (!has_sr && !dL_dcov3D) ||
+        (strict && (!dL_dconic || (!accumulate && (!dL_dcolor || !dL_dcov3D)))))
         return fail(TGS_ERR_INVALID, "NULL required pointer");
     const CamParams cam = make_cam(viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, scale_modifier, width, height);
     const size_t N = (size_t)width * height, T = (size_t)cam.gx * cam.gy;
@@ -544,7 +546,7 @@ int tgs_backward(void* stream, int P, int D, int M, int64_t R, const float* back
                  const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
                  float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug)
 {
-    return backward_impl(resolve_options(nullptr), 0, stream, P, D, M, R, background, width, height, means3D, shs, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp,
+    return backward_impl(true, resolve_options(nullptr), 0, stream, P, D, M, R, background, width, height, means3D, shs, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp,
                          viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer, img_buffer, dL_dpix, dL_dmean2D,
                          dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug);
 }
@@ -556,7 +558,7 @@ int tgs_backward_opt(const tgs_options_t* o, int accumulate, void* stream, int P
                      float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
                      int debug)
 {
-    return backward_impl(resolve_options(o), accumulate ? 1 : 0, stream, P, D, M, R, background, width, height, means3D, shs, colors_precomp, scales, scale_modifier, rotations,
+    return backward_impl(false, resolve_options(o), accumulate ? 1 : 0, stream, P, D, M, R, background, width, height, means3D, shs, colors_precomp, scales, scale_modifier, rotations,
                          cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer, img_buffer, dL_dpix, dL_dmean2D,
                          dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug);
 }
@@ -568,7 +570,7 @@ int tgs_backward_accumulate(void* stream, int P, int D, int M, int64_t R, const 
                             const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
                             float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug)
 {
-    return backward_impl(resolve_options(nullptr), 1, stream, P, D, M, R, background, width, height, means3D, shs, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp,
+    return backward_impl(true, resolve_options(nullptr), 1, stream, P, D, M, R, background, width, height, means3D, shs, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp,
                          viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer, img_buffer, dL_dpix, dL_dmean2D,
                          dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug);
 }

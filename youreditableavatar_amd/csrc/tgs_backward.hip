@@ -1240,7 +1240,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
             const size_t j3 = 3 * (size_t)idx;
             in.dL_dmean2D[j3] = 0.f; in.dL_dmean2D[j3 + 1] = 0.f; in.dL_dmean2D[j3 + 2] = 0.f;
             if (!in.accumulate) {                                       // tgs_backward promises that every output element is written: zeros
-                reinterpret_cast<float4*>(in.dL_dconic)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (in.dL_dconic) reinterpret_cast<float4*>(in.dL_dconic)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
                 in.dL_dopacity[idx] = 0.f;
                 if (in.dL_dcolor) { in.dL_dcolor[j3] = 0.f; in.dL_dcolor[j3 + 1] = 0.f; in.dL_dcolor[j3 + 2] = 0.f; }
                 in.dL_dmean3D[j3] = 0.f; in.dL_dmean3D[j3 + 1] = 0.f; in.dL_dmean3D[j3 + 2] = 0.f;
@@ -1433,7 +1433,9 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
     // every output element is written (zeros for culled Gaussians)
     if (!in_range) return;
     in.dL_dmean2D[i3] = a[3]; in.dL_dmean2D[i3 + 1] = a[4]; in.dL_dmean2D[i3 + 2] = 0.f;   // .z never written: backward.cu:545-546
-    reinterpret_cast<float4*>(in.dL_dconic)[idx] = make_float4(a[5], a[6], 0.f, a[7]);   // .z never written: backward.cu:549-551
+    // (dL_dconic, dL_dcolor on the SH path and dL_dcov3D on the scale / rotation path are intermediates of the reference's two-kernel backward that its
+    // callers discard: a caller of tgs_backward_opt may pass NULL for them -- 52 of the ~300 B this kernel writes per Gaussian)
+    if (in.dL_dconic) reinterpret_cast<float4*>(in.dL_dconic)[idx] = make_float4(a[5], a[6], 0.f, a[7]);   // .z never written: backward.cu:549-551
     if (in.accumulate) {
         // fused gradient accumulation of a multi-view batch (youreditableavatar_amd/multiview.py): += on the parameter gradients
         in.dL_dopacity[idx] += a[8];
@@ -1448,10 +1450,12 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
         return;
     }
     in.dL_dopacity[idx] = a[8];
-    in.dL_dcolor[i3] = a[0]; in.dL_dcolor[i3 + 1] = a[1]; in.dL_dcolor[i3 + 2] = a[2];
+    if (in.dL_dcolor) { in.dL_dcolor[i3] = a[0]; in.dL_dcolor[i3 + 1] = a[1]; in.dL_dcolor[i3 + 2] = a[2]; }
     in.dL_dmean3D[i3] = dmean[0]; in.dL_dmean3D[i3 + 1] = dmean[1]; in.dL_dmean3D[i3 + 2] = dmean[2];
+    if (in.dL_dcov3D) {
 #pragma unroll
-    for (int i = 0; i < 6; i++) in.dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
+        for (int i = 0; i < 6; i++) in.dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
+    }
     if (in.dL_dscale) { in.dL_dscale[i3] = dscale[0]; in.dL_dscale[i3 + 1] = dscale[1]; in.dL_dscale[i3 + 2] = dscale[2]; }
     if (in.dL_drot) reinterpret_cast<float4*>(in.dL_drot)[idx] = make_float4(drot[0], drot[1], drot[2], drot[3]);
 }

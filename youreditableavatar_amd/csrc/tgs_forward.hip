@@ -630,22 +630,26 @@ struct MidTab { uint32_t excl[WAVE]; uint2 rect[WAVE]; unsigned long long live[W
 // pairs spread over the lanes (prefix sum of the areas + a 6-step search in LDS; one lane walking a 64-tile rectangle of its own
 // would hold the wave for 64 steps); larger: the whole wave, one rectangle after the other (the reference's thread-serial double
 // loop, rasterizer_impl.cu:98-109, is its tail-latency problem).
+#ifndef TGS_EMIT_RANK
+#define TGS_EMIT_RANK 9
+#endif
+constexpr int EMIT_RANK = TGS_EMIT_RANK;     // rectangles up to this many tiles are walked by the splat's own lane (<= 32: the live mask's low word)
 template <typename F>
 __device__ __forceinline__ void wave_emit_instances(uint32_t tiles, ushort4 r, uint2 live2, unsigned long long key, uint32_t gx, MidTab& tab, int lane, F&& f)
 {
     const uint32_t rw = (uint32_t)r.z - r.x, area = tiles ? rw * ((uint32_t)r.w - r.y) : 0u;
     const unsigned long long live = (unsigned long long)live2.x | ((unsigned long long)live2.y << 32);
-    if (area != 0 && area <= (uint32_t)RANK_TILES) {
+    if (area != 0 && area <= (uint32_t)EMIT_RANK) {
         uint32_t kx = 0, t = (uint32_t)r.y * gx + r.x;
 #pragma unroll
-        for (int k = 0; k < RANK_TILES; k++) {
+        for (int k = 0; k < EMIT_RANK; k++) {
             if ((uint32_t)k < area) {
                 if ((live2.x >> k) & 1u) f(t + kx, key);
                 if (++kx == rw) { kx = 0; t += gx; }
             }
         }
     }
-    const uint32_t mid_area = (area > (uint32_t)RANK_TILES && area <= (uint32_t)COOP_TILES) ? area : 0u;
+    const uint32_t mid_area = (area > (uint32_t)EMIT_RANK && area <= (uint32_t)COOP_TILES) ? area : 0u;
     const uint32_t incl = wave_iscan_u32(mid_area, lane), total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     if (total > 0) {                                        // wave-uniform
         tab.excl[lane] = incl - mid_area;
@@ -977,6 +981,12 @@ __global__ __launch_bounds__(1024) void k_tile_sort(const GeomState g, const Img
     const uint32_t n_nonempty = s.meta->n_nonempty;
     const uint32_t n_heavy = min(s.meta->n_heavy, n_nonempty), n_mid = min(max(s.meta->n_mid, n_heavy), n_nonempty);
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#ifdef TGS_SORT_ONLY      // timing-only builds (results are wrong): 1 = only the heavy class sorts, 2 = only the mid class, 3 = only the light class
+    {
+        const int cls = blockIdx.x < heavy_blocks ? 1 : blockIdx.x < heavy_blocks + mid_blocks ? 2 : blockIdx.x < heavy_blocks + mid_blocks + small_blocks ? 3 : 4;
+        if (cls != TGS_SORT_ONLY && cls != 4) return;
+    }
+#endif
     if (blockIdx.x >= heavy_blocks + mid_blocks + small_blocks) {          // the grid's tail: workers of the lists beyond the LDS sort
         ovf_worker(g, s, b, lk, blockIdx.x - (heavy_blocks + mid_blocks + small_blocks), ovf_blocks, sort_cap, gx);
         return;

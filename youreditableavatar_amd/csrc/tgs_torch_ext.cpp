@@ -121,17 +121,22 @@ py::tuple rasterize_gaussians_backward(const torch::Tensor& background, const to
                                        const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix, float tan_fovx, float tan_fovy,
                                        const torch::Tensor& dL_dout_color, const torch::Tensor& sh, int degree, const torch::Tensor& campos,
                                        const torch::Tensor& geomBuffer, int64_t R, const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer, bool debug,
-                                       bool with_conic, int64_t tile_bound, c10::optional<bool> deterministic, int64_t mid_bound, c10::optional<bool> light_tiles)
+                                       bool with_conic, int64_t tile_bound, c10::optional<bool> deterministic, int64_t mid_bound, c10::optional<bool> light_tiles,
+                                       bool need_colors, bool need_cov3D)
 {
+    // need_colors / need_cov3D = false (extension keywords; the reference's signature has neither): the caller will discard dL_dcolors / dL_dcov3D --
+    // GaussianRasterizer's backward does when the forward was given shs / scales + rotations (__init__.py:137-152 hands them to inputs that are None) --
+    // so they are neither allocated nor written (empty tensors come back); dL_dconic, an intermediate of the reference's two kernels, only on request.
     const c10::Device dev = require_gpu(means3D);
     const int P = (int)means3D.size(0), H = (int)dL_dout_color.size(1), W = (int)dL_dout_color.size(2), M = sh_coeffs(sh);
     c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
     const auto f32 = torch::TensorOptions().dtype(torch::kFloat32).device(dev);
-    torch::Tensor dL_dmeans3D = torch::empty({P, 3}, f32), dL_dmeans2D = torch::empty({P, 3}, f32), dL_dcolors = torch::empty({P, 3}, f32),
-                  dL_dconic = torch::empty({P, 2, 2}, f32), dL_dopacity = torch::empty({P, 1}, f32), dL_dcov3D = torch::empty({P, 6}, f32),
-                  dL_dsh = torch::empty({P, M, 3}, f32);
     const Arg sc(scales, dev, "scales"), rot(rotations, dev, "rotations");
     const bool has_sr = sc.p != nullptr;
+    const bool want_col = need_colors || M == 0, want_cov = need_cov3D || !has_sr;      // (required outputs on the colors_precomp / cov3D_precomp paths)
+    torch::Tensor dL_dmeans3D = torch::empty({P, 3}, f32), dL_dmeans2D = torch::empty({P, 3}, f32), dL_dcolors = torch::empty({want_col ? P : 0, 3}, f32),
+                  dL_dconic = torch::empty({with_conic ? P : 0, 2, 2}, f32), dL_dopacity = torch::empty({P, 1}, f32), dL_dcov3D = torch::empty({want_cov ? P : 0, 6}, f32),
+                  dL_dsh = torch::empty({P, M, 3}, f32);
     // the reference leaves these at zero on the cov3D_precomp path
     torch::Tensor dL_dscales = has_sr ? torch::empty({P, 3}, f32) : torch::zeros({P, 3}, f32), dL_drotations = has_sr ? torch::empty({P, 4}, f32) : torch::zeros({P, 4}, f32);
     if (P != 0) {
@@ -146,8 +151,9 @@ py::tuple rasterize_gaussians_backward(const torch::Tensor& background, const to
             py::gil_scoped_release nogil;
             r = tgs_backward_opt(&opt, 0, stream, P, degree, M, R, bg.p, W, H, means.p, shs.p, col.p, sc.p, scale_modifier, rot.p, cov.p, view.p, proj.p, cam.p, tan_fovx,
                                  tan_fovy, radii_c.data_ptr<int>(), geomBuffer.data_ptr(), binningBuffer.data_ptr(), imageBuffer.data_ptr(), dL.p,
-                                 dL_dmeans2D.data_ptr<float>(), dL_dconic.data_ptr<float>(), dL_dopacity.data_ptr<float>(), dL_dcolors.data_ptr<float>(),
-                                 dL_dmeans3D.data_ptr<float>(), dL_dcov3D.data_ptr<float>(), M ? dL_dsh.data_ptr<float>() : nullptr,
+                                 dL_dmeans2D.data_ptr<float>(), with_conic ? dL_dconic.data_ptr<float>() : nullptr, dL_dopacity.data_ptr<float>(),
+                                 want_col ? dL_dcolors.data_ptr<float>() : nullptr, dL_dmeans3D.data_ptr<float>(), want_cov ? dL_dcov3D.data_ptr<float>() : nullptr,
+                                 M ? dL_dsh.data_ptr<float>() : nullptr,
                                  has_sr ? dL_dscales.data_ptr<float>() : nullptr, has_sr ? dL_drotations.data_ptr<float>() : nullptr, debug);
         }
         if (r < 0) raise_last(r);
@@ -186,7 +192,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
           py::arg("scales"), py::arg("rotations"), py::arg("scale_modifier"), py::arg("cov3D_precomp"), py::arg("viewmatrix"), py::arg("projmatrix"),
           py::arg("tan_fovx"), py::arg("tan_fovy"), py::arg("dL_dout_color"), py::arg("sh"), py::arg("degree"), py::arg("campos"), py::arg("geomBuffer"),
           py::arg("R"), py::arg("binningBuffer"), py::arg("imageBuffer"), py::arg("debug"), py::arg("_with_conic") = false, py::arg("tile_bound") = 0,
-          py::arg("deterministic") = py::none(), py::arg("mid_bound") = 0, py::arg("light_tiles") = py::none());
+          py::arg("deterministic") = py::none(), py::arg("mid_bound") = 0, py::arg("light_tiles") = py::none(), py::arg("need_colors") = true,
+          py::arg("need_cov3D") = true);
     m.def("mark_visible", &mark_visible);
     m.def("abi_version", []() { return tgs_abi_version(); });
     m.def("compiled_abi_version", []() { return TGS_ABI_VERSION; });      // the header THIS module was compiled against

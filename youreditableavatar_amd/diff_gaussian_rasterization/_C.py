@@ -347,17 +347,21 @@ def frame_status(image_buffer: torch.Tensor) -> Tuple[int, int]:
 def _rasterize_gaussians_backward_ctypes(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                          viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos,
                                          geomBuffer, R, binningBuffer, imageBuffer, debug, _with_conic=False, tile_bound: int = 0,
-                                         deterministic: Optional[bool] = None, mid_bound: int = 0, light_tiles: Optional[bool] = None):
+                                         deterministic: Optional[bool] = None, mid_bound: int = 0, light_tiles: Optional[bool] = None,
+                                         need_colors: bool = True, need_cov3D: bool = True):
     """RasterizeGaussiansBackwardCUDA (rasterize_points.cu:117-196) over ctypes (see _rasterize_gaussians_ctypes); return order of :195.
-    ``_with_conic`` (tests only) appends the scratch tensor dL_dconic[P,2,2]."""
+    ``_with_conic`` (tests only) appends the scratch tensor dL_dconic[P,2,2].  ``need_colors`` / ``need_cov3D`` False: the caller discards
+    dL_dcolors (SH path) / dL_dcov3D (scale + rotation path) -- not written, empty tensors returned (as the compiled module does)."""
     dev = _require_gpu(means3D)
     P = int(means3D.size(0))
     H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
     M = int(sh.size(1)) if (sh.dim() > 1 and sh.size(0) != 0) else 0
     with torch.cuda.device(dev):
         e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-        dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dconic = e(P, 3), e(P, 3), e(P, 3), e(P, 2, 2)
-        dL_dopacity, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations = e(P, 1), e(P, 6), e(P, M, 3), e(P, 3), e(P, 4)
+        has_sr0 = scales is not None and scales.numel() != 0
+        want_col, want_cov = bool(need_colors) or M == 0, bool(need_cov3D) or not has_sr0
+        dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dconic = e(P, 3), e(P, 3), e(P if want_col else 0, 3), e(P if _with_conic else 0, 2, 2)
+        dL_dopacity, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations = e(P, 1), e(P if want_cov else 0, 6), e(P, M, 3), e(P, 3), e(P, 4)
         t = dict(bg=_dev_f32(background, dev, "background"), means=_dev_f32(means3D, dev, "means3D"),
                  colors=_dev_f32(colors, dev, "colors"), scales=_dev_f32(scales, dev, "scales"),
                  rots=_dev_f32(rotations, dev, "rotations"), cov=_dev_f32(cov3D_precomp, dev, "cov3D_precomp"),
@@ -374,8 +378,8 @@ def _rasterize_gaussians_backward_ctypes(background, means3D, radii, colors, sca
                                   _p(t["scales"]), float(scale_modifier), _p(t["rots"]), _p(t["cov"]), _p(t["view"]), _p(t["proj"]),
                                   _p(t["campos"]), float(tan_fovx), float(tan_fovy), radii_c.data_ptr(), geomBuffer.data_ptr(),
                                   binningBuffer.data_ptr(), imageBuffer.data_ptr(), _p(t["dL"]), dL_dmeans2D.data_ptr(),
-                                  dL_dconic.data_ptr(), dL_dopacity.data_ptr(), dL_dcolors.data_ptr(), dL_dmeans3D.data_ptr(),
-                                  dL_dcov3D.data_ptr(), dL_dsh.data_ptr() if M else None,
+                                  dL_dconic.data_ptr() if _with_conic else None, dL_dopacity.data_ptr(), dL_dcolors.data_ptr() if want_col else None, dL_dmeans3D.data_ptr(),
+                                  dL_dcov3D.data_ptr() if want_cov else None, dL_dsh.data_ptr() if M else None,
                                   dL_dscales.data_ptr() if has_sr else None, dL_drotations.data_ptr() if has_sr else None,
                                   int(bool(debug)))
             if r < 0:

@@ -129,6 +129,7 @@ class _Speculation:
 
 
 _speculation = _Speculation()
+_KEEP_ALL_OUTPUTS = os.environ.get("TGS_KEEP_ALL_OUTPUTS") == "1"      # A/B: have the backward write dL_dcolors / dL_dcov3D even when autograd drops them
 
 
 class _RasterizeGaussians(torch.autograd.Function):
@@ -182,10 +183,15 @@ class _RasterizeGaussians(torch.autograd.Function):
         # (and the 1024-thread kernel only the ones with >= 128 instances; the rest take the 256-thread one)
         bound = ctx.nonempty_tiles if ctx.nonempty_tiles > 0 else 0
         mid = max(ctx.mid_tiles, 1) if (bound > 0 and ctx.mid_tiles >= 0) else 0
+        # dL_dcolors / dL_dcov3D go to inputs that were None in the forward (empty tensors here, __init__.py:137-152): autograd drops them, so the
+        # native backward neither allocates nor writes them (36 of the ~300 B per Gaussian its per-Gaussian kernel stores; round 6)
+        need_col, need_cov = colors_precomp.numel() != 0 or _KEEP_ALL_OUTPUTS, cov3Ds_precomp.numel() != 0 or _KEEP_ALL_OUTPUTS
         (g_means2D, g_colors, g_opac, g_means3D, g_cov3D, g_sh, g_scales, g_rots) = _call_native(
-            lambda *a: _C.rasterize_gaussians_backward(*a, tile_bound=bound, mid_bound=mid, light_tiles=ctx.light), args, rs.debug, "snapshot_bw.dump", "backward")
-        # forward-argument order (__init__.py:143-153); all eight are always returned
-        return g_means3D, g_means2D, g_sh, g_colors, g_opac, g_scales, g_rots, g_cov3D, None
+            lambda *a: _C.rasterize_gaussians_backward(*a, tile_bound=bound, mid_bound=mid, light_tiles=ctx.light, need_colors=need_col, need_cov3D=need_cov),
+            args, rs.debug, "snapshot_bw.dump", "backward")
+        # forward-argument order (__init__.py:143-153)
+        return (g_means3D, g_means2D, g_sh if sh.numel() != 0 else None, g_colors if need_col else None, g_opac, g_scales if scales.numel() != 0 else None,
+                g_rots if rotations.numel() != 0 else None, g_cov3D if need_cov else None, None)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
