@@ -19,7 +19,7 @@ constexpr int SLAB_ROW = 3;          // float4 per gradient-slab row: 9 sums pad
 // Binning (k_bin_count / k_bin_colscan / k_scatter): the Gaussians are cut into BIN_WGS_MAX (or fewer) contiguous chunks, one fat
 // workgroup each, which count and later emit their instances through a per-tile table in LDS -- no global atomics.
 #ifndef TGS_BIN_WGS_MAX
-#define TGS_BIN_WGS_MAX 128
+#define TGS_BIN_WGS_MAX 256
 #endif
 constexpr int BIN_WGS_MAX = TGS_BIN_WGS_MAX;   // rows of the per-view table (bin_table: BIN_WGS_MAX x T words); TGS_BIN_WGS (environment) selects fewer
 constexpr int BIN_THREADS = 1024;

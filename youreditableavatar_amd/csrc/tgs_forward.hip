@@ -713,23 +713,24 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(int P, uint32_t chunk
     }
 }
 
-// per tile: table[w][t] <- sum of table[w'][t], w' < w; tile_count[t] <- the total.  64 tiles per workgroup, wave q takes a quarter of the chunks.
-__global__ __launch_bounds__(256) void k_bin_colscan(const ImgState s, uint32_t T, uint32_t nchunks)
+// per tile: table[w][t] <- sum of table[w'][t], w' < w; tile_count[t] <- the total.  64 tiles per workgroup, wave q takes 1 / COL_WAVES of the chunks.
+constexpr int COL_WAVES = BIN_WGS_MAX / 32;       // waves per workgroup of k_bin_colscan: every thread carries 32 chunks' counts (4 waves at 128 chunks, 8 at 256)
+__global__ __launch_bounds__(64 * COL_WAVES) void k_bin_colscan(const ImgState s, uint32_t T, uint32_t nchunks)
 {
-    __shared__ uint32_t part[4][WAVE];
+    __shared__ uint32_t part[COL_WAVES][WAVE];
     __shared__ uint32_t bh[34];
     const int q = threadIdx.x >> 6, l = threadIdx.x & 63;
     if (threadIdx.x < 34) bh[threadIdx.x] = 0u;
     const uint32_t t = blockIdx.x * WAVE + l;
-    const uint32_t per = (nchunks + 3) / 4, w0 = min(nchunks, q * per), w1 = min(nchunks, w0 + per);
+    const uint32_t per = (nchunks + COL_WAVES - 1) / COL_WAVES, w0 = min(nchunks, q * per), w1 = min(nchunks, w0 + per);
     uint32_t* col = s.bin_table + t;
-    uint32_t c[BIN_WGS_MAX / 4];
+    uint32_t c[BIN_WGS_MAX / COL_WAVES];
     uint32_t sum = 0;
     if (t < T) {
 #pragma unroll
-        for (int k = 0; k < BIN_WGS_MAX / 4; k++) { c[k] = w0 + k < w1 ? col[(size_t)(w0 + k) * T] : 0u; }
+        for (int k = 0; k < BIN_WGS_MAX / COL_WAVES; k++) { c[k] = w0 + k < w1 ? col[(size_t)(w0 + k) * T] : 0u; }
 #pragma unroll
-        for (int k = 0; k < BIN_WGS_MAX / 4; k++) sum += c[k];
+        for (int k = 0; k < BIN_WGS_MAX / COL_WAVES; k++) sum += c[k];
     }
     part[q][l] = sum;
     __syncthreads();
@@ -737,8 +738,8 @@ __global__ __launch_bounds__(256) void k_bin_colscan(const ImgState s, uint32_t 
         uint32_t run = 0;
         for (int i = 0; i < q; i++) run += part[i][l];
 #pragma unroll
-        for (int k = 0; k < BIN_WGS_MAX / 4; k++) { if (w0 + k < w1) col[(size_t)(w0 + k) * T] = run; run += c[k]; }
-        if (q == 3) {
+        for (int k = 0; k < BIN_WGS_MAX / COL_WAVES; k++) { if (w0 + k < w1) col[(size_t)(w0 + k) * T] = run; run += c[k]; }
+        if (q == COL_WAVES - 1) {
             s.tile_count[t] = run;
             atomicAdd(&bh[length_bucket(run)], 1u);         // the frame's histogram of list lengths (k_scan: tile order), first per workgroup in LDS
         }
@@ -1401,7 +1402,7 @@ void launch_bin_count(hipStream_t st, int P, const GeomState& g, const ImgState&
     bin_shape(P, T, nchunks, chunk, band, lds);
     if (lds > 32 * 1024) (void)hipFuncSetAttribute((const void*)k_bin_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_bin_count, dim3(nchunks), dim3(BIN_THREADS), lds, st, P, chunk, g, s, gx, T, band);
-    hipLaunchKernelGGL(k_bin_colscan, dim3((T + WAVE - 1) / WAVE), dim3(256), 0, st, s, T, nchunks);
+    hipLaunchKernelGGL(k_bin_colscan, dim3((T + WAVE - 1) / WAVE), dim3(64 * COL_WAVES), 0, st, s, T, nchunks);
 }
 void launch_scatter(hipStream_t st, int P, const GeomState& g, const ImgState& s, const BinState& b, uint32_t gx, uint32_t T)
 {
