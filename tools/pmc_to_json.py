@@ -113,6 +113,58 @@ for src, dst in (("bench_default.json", "bench_default.json"), ("bench_under_roc
                  ("dropin_under_rocprof.json", "dropin_under_rocprof.json")):
     if os.path.exists(O + src):
         shutil.copy(O + src, f"{P}/{name}_{dst}")
+# ---- round 6: large splats (x4 / x8), the store-mode drop-in loop, the batch step -- one JSON with, per workload and kernel, FETCH / WRITE (KB per launch as
+# reported + the estimate with the kernel's fetch factor), the SQ / LDS counters where a pass exists, and the kernel's average duration from the same round's kernel stats
+def stats_us(path):
+    try:
+        return {kname({"Kernel_Name": r["Name"]}): float(r["AverageNs"]) / 1e3 for r in csv.DictReader(open(path))}
+    except OSError:
+        return {}
+
+
+extra = {"note": "round 6 (tools/profile_round.sh): the same counter passes over OTHER workloads than tools/pmc_workload.py -- 'x4' / 'x8': one forward + backward frame of config 3 with every "
+                 "splat x 4 / x 8 (tools/stage_times.py; most splats on 5..64 tiles); 'dropin': one view per step through GaussianRasterizer (tools/dropin_loop.py: the STORE-mode "
+                 "k_preprocess_bwd); 'batch': the 8-view step of bench.py on one stream (k_preprocess_fwd_pair, k_preprocess_bwd_batch_split).  hbm_bytes_est = fetch_factor * FETCH + WRITE; "
+                 "tbps = hbm_bytes_est / avg_us of the same workload's kernel stats (a kernel-trace run, not the counter pass).", "csrc_sha16": SRC, "workloads": {}}
+for wl, fetch_d, write_d, sq_ds, stats in (("x4", "pmc_fetch_x4", "pmc_write_x4", (), "rp_x4/rp_kernel_stats.csv"), ("x8", "pmc_fetch_x8", "pmc_write_x8", (), "rp_x8/rp_kernel_stats.csv"),
+                                           ("dropin", "pmc_fetch_dropin", "pmc_write_dropin", ("pmc_sq_dropin", "pmc_lds_dropin"), "rp_dropin/rp_kernel_stats.csv"),
+                                           ("batch", "pmc_fetch_batch", "pmc_write_batch", ("pmc_sq_batch",), "rp1/rp_kernel_stats.csv")):
+    ff, ww, us = load(fetch_d, "FETCH_SIZE"), load(write_d, "WRITE_SIZE"), stats_us(O + stats)
+    if not ff and not ww:
+        continue
+    ks = {}
+    for k in sorted(set(ff) | set(ww)):
+        if "tgs" not in k:
+            continue
+        pat, fac, _src = fetch_factor(k)
+        e = {"FETCH_SIZE_KB": round(ff.get(k, 0.0), 1), "WRITE_SIZE_KB": round(ww.get(k, 0.0), 1), "fetch_factor": fac,
+             "hbm_bytes_est": int((fac * ff.get(k, 0.0) + ww.get(k, 0.0)) * 1024)}
+        if us.get(k):
+            e["avg_us"] = round(us[k], 1)
+            e["tbps"] = round(e["hbm_bytes_est"] / us[k] / 1e6, 2)
+            e["frac_of_8TBps"] = round(e["tbps"] / 8.0, 3)
+        ks[k] = e
+    for d in sq_ds:
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in rows(d):
+            if "tgs" in kname(r):
+                agg[kname(r)][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, cs in agg.items():
+            for c, v in cs.items():
+                ks.setdefault(k, {})[c] = round(sum(v) / len(v), 1)
+    for k, e in ks.items():
+        if e.get("SQ_LDS_IDX_ACTIVE"):
+            e["lds_bank_conflict_frac_of_lds_active"] = round(e.get("SQ_LDS_BANK_CONFLICT", 0.0) / e["SQ_LDS_IDX_ACTIVE"], 3)
+        if e.get("SQ_WAVE_CYCLES"):
+            e["wait_any_frac_of_wave_cycles"] = round(e.get("SQ_WAIT_ANY", 0.0) / e["SQ_WAVE_CYCLES"], 3)
+            if e.get("SQ_WAIT_INST_LDS") is not None:
+                e["wait_lds_frac_of_wave_cycles"] = round(e["SQ_WAIT_INST_LDS"] / e["SQ_WAVE_CYCLES"], 3)
+    extra["workloads"][wl] = ks
+if extra["workloads"]:
+    json.dump(extra, open(f"{P}/{name}_workload_counters.json", "w"), indent=1)
+for src, dst in (("rp_x4/rp_kernel_stats.csv", "kernel_stats_x4.csv"), ("rp_x8/rp_kernel_stats.csv", "kernel_stats_x8.csv"), ("batch_stage_times.txt", "batch_stage_times.txt")):
+    if os.path.exists(O + src):
+        shutil.copy(O + src, f"{P}/{name}_{dst}")
 for k, v in out["kernels"].items():
     print(k, v)
 for k, v in sq["kernels"].items():

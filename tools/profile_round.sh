@@ -4,7 +4,7 @@ set -x
 # Counter passes never share a run with trace domains other than --kernel-trace (MI355X_MICROARCH.md, rocprofv3 PMC slots: 8 SQ counters or
 # FETCH_SIZE (3 TCC slots) or WRITE_SIZE (2) per pass).
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/${1:-r05_g}
+O=$R/gpurun_out/${1:-r06_f}
 mkdir -p $O
 python3 -c "import sys; sys.path.insert(0, '$R'); from youreditableavatar_amd.build import source_hash; print(source_hash())" > $O/csrc_sha16.txt   # the sources these counters belong to
 cd /tmp && export TMPDIR=/tmp
@@ -24,6 +24,25 @@ timeout 420 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/
 # drop-in loop and the trainers' protocol under the kernel trace
 timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d $O/rp_dropin -o rp -- python3 $R/tools/dropin_loop.py > $O/dropin_under_rocprof.json 2> $O/rp_dropin.err
 timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d $O/rp_trainer3 -o rp -- python3 $R/tools/trainer_protocol.py 3 40 > $O/trainer_protocol_sh3.json 2> $O/rp_trainer3.err
+# round 6: large splats as a first-class workload (kernel stats + FETCH / WRITE at x4 / x8), counters over the STORE-MODE per-Gaussian backward (the drop-in loop),
+# and over the batch step (k_preprocess_bwd_batch_split, k_preprocess_fwd_pair)
+for sc in 4 8; do
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/rp_x$sc -o rp -- python3 $R/tools/stage_times.py $sc > $O/rp_x$sc.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_x$sc -o pmc -- python3 $R/tools/stage_times.py $sc > $O/pmc_fetch_x$sc.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_x$sc -o pmc -- python3 $R/tools/stage_times.py $sc > $O/pmc_write_x$sc.log 2>&1
+done
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_dropin -o pmc -- python3 $R/tools/dropin_loop.py 8 > $O/pmc_fetch_dropin.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_dropin -o pmc -- python3 $R/tools/dropin_loop.py 8 > $O/pmc_write_dropin.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES --output-format csv -d $O/pmc_sq_dropin -o pmc -- python3 $R/tools/dropin_loop.py 8 > $O/pmc_sq_dropin.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $O/pmc_lds_dropin -o pmc -- python3 $R/tools/dropin_loop.py 8 > $O/pmc_lds_dropin.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_batch -o pmc -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-secondary --streams 1 > $O/pmc_fetch_batch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_batch -o pmc -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-secondary --streams 1 > $O/pmc_write_batch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES --output-format csv -d $O/pmc_sq_batch -o pmc -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-secondary --streams 1 > $O/pmc_sq_batch.log 2>&1
+timeout 300 python3 $R/tools/batch_stage_times.py 1 0 > $O/batch_stage_times.txt 2>/dev/null
+timeout 300 python3 $R/tools/batch_stage_times.py 1 1 >> $O/batch_stage_times.txt 2>/dev/null
+timeout 300 python3 $R/tools/batch_stage_times.py 4 0 >> $O/batch_stage_times.txt 2>/dev/null
+timeout 300 python3 $R/tools/batch_stage_times.py 4 1 >> $O/batch_stage_times.txt 2>/dev/null
+find $O -name "*counter_collection.csv" -size +6M -delete 2>/dev/null
 # the big per-dispatch traces are not needed once the stats exist (gpurun merges at most 64 MiB back)
 find $O -name "*kernel_trace.csv" -path "*rp*" -delete 2>/dev/null
 ls -R $O | head -60
