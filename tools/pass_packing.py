@@ -204,3 +204,19 @@ print(f"      slowest wave's passes: {int(wpn.amax(1).sum())}   relative PE {p_ 
 ld = lpt(bps, 4)
 s_, p_ = report("4 waves per tile, blocks by LPT on list length", ld, 4)
 print(f"      slowest wave's passes: {int(ld.amax(1).sum())}   relative PE {p_ / t0[1]:.3f}")
+
+# ---- forward only: how many of a tile's staged entries reach each QUARTER (k_render_fwd stages the whole list in every quarter's workgroup) ----
+if FORWARD:
+    AB16 = AQ.view(R, 16, 4).any(dim=2)                       # [R, block]
+    blk_of_quarter = torch.tensor([[0, 1, 4, 5], [2, 3, 6, 7], [8, 9, 12, 13], [10, 11, 14, 15]])
+    AQr = torch.stack([AB16[:, blk_of_quarter[q]].any(dim=1) for q in range(4)], dim=1) & inr[:, None]   # [R, quarter]: entry reaches the quarter (and the quarter's walk has not ended)
+    heavy = lens[tile_of] >= 128
+    staged = int((inr & heavy).sum()) * 4
+    reach = int(AQr[heavy].sum())
+    # rounds per quarter today (all entries up to the tile's deepest position, 256 per round) against compacted staging (256 REACHING entries per round)
+    tq_heavy = torch.unique(tile_of[heavy])
+    r_today = int(((tile_qmax[tq_heavy] + BCH - 1) // BCH).sum()) * 4
+    per_q = torch.zeros(T, 4, dtype=torch.long); per_q.index_add_(0, tile_of[heavy], AQr[heavy].long())
+    r_comp = int(((per_q[tq_heavy] + BCH - 1) // BCH).clamp(min=1).sum())
+    print(f"forward, tiles with >= 128 entries ({tq_heavy.numel()}): entries staged by the four quarters {staged}, of which reach the quarter {reach} ({reach / max(staged, 1):.3f}); "
+          f"quarter-rounds today {r_today}, with staging compacted per quarter {r_comp}")
