@@ -1,5 +1,5 @@
 import csv, collections, sys, glob
-f = glob.glob(sys.argv[1] + '/*/*counter_collection.csv')[0]
+f = glob.glob(sys.argv[1] + '/**/*counter_collection.csv', recursive=True)[0]      # (rocprofv3 -d <dir> -o <name>: directly in <dir>, or one level down)
 rows = list(csv.DictReader(open(f)))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
