@@ -617,187 +617,6 @@ __global__ __launch_bounds__(BWD_THREADS, 8) void k_render_bwd(const ImgState s,
 
 
 // ---------------------------------------------------------------------------------------------
-// k_render_bwd_h (round 6): the same passes with EIGHT waves per tile -- wave w walks block w and block 15 - w one after the other in
-// every round, the state of the block it is not walking (T, dL_dpixel . accum_rec, the pixel's inputs) parked in LDS -- and rounds of
-// HCH entries, so that four workgroups fit a CU instead of two.
-// Why (tools/pass_packing.py, profiles/r06_pass_packing.txt): a tile-round lasts as long as its slowest wave, and with one block per
-// wave the slowest wave runs 1.8 x the mean (balance 0.55): 16 wave slots are held for 34.7 k rounds-of-passes where 19.1 k are walked.
-// Two blocks per wave -- a corner block with the opposite corner, a centre block with a centre block -- even the waves out (balance 0.74,
-// pass-equivalents x 0.74), and a workgroup of half the size turns over in half the slots.
-// ---------------------------------------------------------------------------------------------
-#ifndef TGS_HCH
-#define TGS_HCH 192
-#endif
-#ifndef TGS_BWD_HALF
-#define TGS_BWD_HALF 0
-#endif
-constexpr int HW = 8, H_THREADS = 64 * HW;
-constexpr int HCH = TGS_HCH;               // list entries per round
-constexpr int HCAP = (HCH + 63) / 64 * 64;  // capacity of the staged masks (build_own_list_q walks whole 64-entry groups)
-constexpr int H_NPARK = 7;                  // T, arA, dL_dpixel rgb, T_final * (bg . dL_dpixel), first round's threshold
-struct alignas(16) BwdSharedH {
-    float4 sA[HCH + 1];
-    float4 sB[HCH + 1];
-    BwdAccT<HCH> acc;
-    uint32_t sSlot[2][HCH];
-    float2 sFl[2][HCH];
-    uint2 sQ[HCAP];
-    alignas(16) unsigned short lists[HW][HCAP + 8];
-    alignas(16) unsigned short qlists[HW][4][QL_ROW];
-    float park[2][H_NPARK][HW][16];            // per block of a wave and pixel of the block
-};
-static_assert(offsetof(BwdSharedH, sSlot) < 65536 && 2 * HCH <= H_THREADS, "k_render_bwd_h: records + accumulator inside a 16-bit LDS offset; two staging halves");
-__global__ __launch_bounds__(H_THREADS, 8) void k_render_bwd_h(const ImgState s, const BinState b, int W, int H, uint32_t gx,
-                                                               const float* __restrict__ bg, const float* __restrict__ dL_dpix)
-{
-    __shared__ BwdSharedH S;
-    auto& sA = S.sA; auto& sB = S.sB; auto& sSlot = S.sSlot; auto& sFl = S.sFl; auto& acc = S.acc; auto& sQ = S.sQ; auto& lists = S.lists; auto& qlists = S.qlists;
-    const uint4 td = s.tile_desc[blockIdx.x];
-    const uint4 ff = frame_counts(s);
-    if (ff.x & META_ERR_CAPACITY) return;
-    check_tile_bound(s);
-    const uint32_t tile = td.x;
-    const uint32_t tx = tile % gx, ty = tile / gx;
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int qd = lane >> 4, pq = (lane >> 2) & 3, e = lane & 3;
-    const uint2 rg = make_uint2(td.y, td.z);
-    const uint32_t n = rg.y - rg.x;
-    if (n == 0) return;
-    set_wave_priority(n);
-    stamp(s, tile, 2);
-    const size_t N = (size_t)W * H;
-    if (threadIdx.x == 0) { sA[HCH] = make_float4(0.f, 0.f, 0.f, 0.f); sB[HCH] = make_float4(0.f, 0.f, 0.f, 0.f); acc.t[HCH].cb = 0.f; }
-    const uint32_t qmax = min(td.w, n);
-    const bool upper = threadIdx.x >= HCH;
-    const uint32_t ht = threadIdx.x < 2 * HCH ? (upper ? threadIdx.x - HCH : threadIdx.x) : 0xffffffffu;
-    float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    uint2 r2 = make_uint2(0u, 0u);
-    auto fetch = [&](uint32_t pos) {
-        if (!upper) { r4 = b.recA[pos]; r2 = b.qmask[pos]; }
-        else { r4 = b.recB[pos]; r2 = make_uint2(__float_as_uint(b.recC[pos].x), b.slot[pos]); }
-    };
-    // the inputs of both blocks' pixels and the first round's records, in flight together
-    const int pix16 = lane >> 2;                                        // pixel of the block: 4 * quadrant + pixel of the quadrant
-    auto block_px = [&](int blk) { return (int)tx * TILE + (blk & 3) * 4 + (qd & 1) * 2 + (pq & 1); };
-    auto block_py = [&](int blk) { return (int)ty * TILE + (blk >> 2) * 4 + (qd >> 1) * 2 + (pq >> 1); };
-    float Tf[2], d0[2], d1[2], d2[2]; uint32_t lc[2]; bool ins[2];
-#pragma unroll
-    for (int bi = 0; bi < 2; bi++) {
-        const int blk = bi ? 15 - wv : wv;
-        const int px = block_px(blk), py = block_py(blk);
-        const bool inside = px < W && py < H;
-        const size_t pixc = inside ? (size_t)W * py + px : 0;
-        ins[bi] = inside;
-        Tf[bi] = s.final_T[pixc];
-        lc[bi] = inside ? s.n_contrib[pixc] : 0u;
-        d0[bi] = dL_dpix[pixc]; d1[bi] = dL_dpix[N + pixc]; d2[bi] = dL_dpix[2 * N + pixc];
-    }
-    if (ht < qmax) fetch(rg.x + qmax - 1 - ht);
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int bi = 0; bi < 2; bi++) {
-        Tf[bi] = select_loaded(ins[bi], Tf[bi]);
-        d0[bi] = select_loaded(ins[bi], d0[bi]); d1[bi] = select_loaded(ins[bi], d1[bi]); d2[bi] = select_loaded(ins[bi], d2[bi]);
-    }
-    float vone = 1.0f, vzero = 0.0f;
-    const QuadMasks qm = quad_masks();
-    asm volatile("" : "+v"(vone), "+v"(vzero));
-    const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);
-    const float bgr = bg[0], bgg = bg[1], bgb = bg[2];
-    uint32_t qlast[2][4];
-#pragma unroll
-    for (int bi = 0; bi < 2; bi++) {
-        uint32_t m = lc[bi];
-        m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x124, 0xf, 0xf, false));     // row_ror:4
-        m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x128, 0xf, 0xf, false));     // row_ror:8
-#pragma unroll
-        for (int q = 0; q < 4; q++) qlast[bi][q] = (uint32_t)__builtin_amdgcn_readlane((int)m, 16 * q);
-        float bgd = 0.f;
-        bgd += bgr * d0[bi]; bgd += bgg * d1[bi]; bgd += bgb * d2[bi];
-        if (e == 0) {
-            S.park[bi][0][wv][pix16] = Tf[bi]; S.park[bi][1][wv][pix16] = 0.f;
-            S.park[bi][2][wv][pix16] = d0[bi]; S.park[bi][3][wv][pix16] = d1[bi]; S.park[bi][4][wv][pix16] = d2[bi];
-            S.park[bi][5][wv][pix16] = Tf[bi] * bgd;
-            S.park[bi][6][wv][pix16] = __int_as_float(((int)qmax - 1 - (int)lc[bi]) * 16);
-        }
-    }
-    for (uint32_t q = qmax + threadIdx.x; q < n; q += H_THREADS) {
-        float4* row = b.slab + (size_t)b.slot[rg.x + q] * SLAB_ROW;
-        row[0] = make_float4(0.f, 0.f, 0.f, 0.f); row[1] = make_float4(0.f, 0.f, 0.f, 0.f); row[2] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    auto stage = [&](int buf) {
-        uint32_t h = ht;
-        asm volatile("" : "+v"(h));
-        if (!upper) { stage_conic_a(r4); sA[h] = r4; sQ[h] = r2; }
-        else { sFl[buf][h] = make_float2(r4.x, r4.y); stage_conic_b(r4); sB[h] = r4; acc.t[h].cb = __uint_as_float(r2.x); sSlot[buf][h] = r2.y; }
-    };
-    acc_clear_all(acc, threadIdx.x, H_THREADS);
-    {
-        const uint32_t cnt0 = min((uint32_t)HCH, qmax);
-        if (ht < cnt0) stage(0);
-    }
-    __syncthreads();
-    int rnd = 0, thr_dec = 0;
-    for (uint32_t qhi = qmax; qhi > 0; qhi = qhi > HCH ? qhi - HCH : 0, rnd ^= 1, thr_dec += HCH * 16) {
-        const uint32_t cnt = min((uint32_t)HCH, qhi);
-        if (qhi > HCH && ht < qhi - HCH) fetch(rg.x + qhi - HCH - 1 - ht);
-#pragma unroll 1
-        for (int bi = 0; bi < 2; bi++) {
-            const int blk = bi ? 15 - wv : wv;
-            uint32_t ql[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) ql[q] = bi ? qlast[1][q] : qlast[0][q];
-            if ((ql[0] | ql[1] | ql[2] | ql[3]) == 0u) continue;                    // nothing was blended into this block
-            // (lane-derived values re-derived per block behind a fence: as invariants of the round loop they would sit in VGPRs across the passes)
-            uint32_t ln = (uint32_t)lane;
-            asm volatile("" : "+v"(ln));
-            const uint32_t qd_ = ln >> 4, pq_ = (ln >> 2) & 3u;
-            constexpr int PS = HW * 16;
-            float T, arA;
-            BwdPixel pxl;
-            {
-                const float* pk = &S.park[bi][0][wv][ln >> 2];
-                T = pk[0]; arA = pk[PS];
-                pxl.fx = (float)((int)tx * TILE + (blk & 3) * 4 + (int)((qd_ & 1u) * 2u + (pq_ & 1u)));
-                pxl.fy = (float)((int)ty * TILE + (blk >> 2) * 4 + (int)((qd_ >> 1) * 2u + (pq_ >> 1)));
-                pxl.d0 = pk[2 * PS]; pxl.d1 = pk[3 * PS]; pxl.d2 = pk[4 * PS]; pxl.tfinal_bg = pk[5 * PS];
-                pxl.thr16 = __float_as_int(pk[6 * PS]) - thr_dec;
-                pxl.acc_off = pq_ * (uint32_t)(BwdAccT<HCH>::PLANE * 8);
-            }
-            const uint32_t nl = build_own_list_q<HCAP>(lists[wv], sQ, cnt, blk, lane);
-            const unsigned short* myq = &qlists[wv][qd_][ln & 3u];
-#pragma unroll 1
-            for (uint32_t c0 = 0; c0 < nl; c0 += QCH) {
-                const uint32_t nq = build_chunk_quadrant_lists<TGS_BWD_BOUNDED, 4>(qlists[wv], lists[wv], c0, nl, lane, HCH, qhi - 1, ql);
-                bwd_passes<HCH>(myq, nq, sA, sB, acc, 0u, pxl, pq_ == 0u, T, arA, vone, vzero, qm);
-            }
-            uint32_t l2 = (uint32_t)lane;
-            asm volatile("" : "+v"(l2));
-            if ((l2 & 3u) == 0u) { float* pk = &S.park[bi][0][wv][l2 >> 2]; pk[0] = T; pk[PS] = arA; }
-        }
-        __syncthreads();
-        if (threadIdx.x < cnt) {
-            const uint32_t j = threadIdx.x;
-            const float4 a = sA[j]; const float2 fl = sFl[rnd][j];
-            const float cxx = a.z * UNSCALE_CONIC, cxy = a.w * UNSCALE_CONIC_XY, cyy = fl.x, op = fl.y;
-            const float Sx = (float)acc_get(acc, 3, j), Sy = (float)acc_get(acc, 4, j);
-            float4* row = b.slab + (size_t)sSlot[rnd][j] * SLAB_ROW;
-            row[0] = make_float4((float)acc_get(acc, 0, j), (float)acc_get(acc, 1, j), (float)acc_get(acc, 2, j), op * (-Sx * cxx - Sy * cxy) * ddelx_dx);
-            const ConicHiLo c5 = conic_hilo(op, acc_get(acc, 5, j)), c6 = conic_hilo(op, acc_get(acc, 6, j)), c7 = conic_hilo(op, acc_get(acc, 7, j));
-            row[1] = make_float4(op * (-Sy * cyy - Sx * cxy) * ddely_dy, c5.hi, c6.hi, c7.hi);
-            row[2] = make_float4((float)acc_get(acc, 8, j), c5.lo, c6.lo, c7.lo);
-            acc_clear(acc, j);
-        }
-        if (qhi > HCH) {
-            const uint32_t qn = qhi - HCH, cntn = min((uint32_t)HCH, qn);
-            if (ht < cntn) stage(rnd ^ 1);
-            __syncthreads();
-        }
-    }
-    stamp(s, tile, 3);
-}
-
-// ---------------------------------------------------------------------------------------------
 // Per-Gaussian half of the backward for ONE view (computeCov2DCUDA backward.cu:144-274, preprocessCUDA :346-396,
 // computeCov3D :278-341, computeColorFromSH :20-139), shared by k_preprocess_bwd (one view per launch) and
 // k_preprocess_bwd_batch (all views of a batch per launch).
@@ -1227,10 +1046,6 @@ __device__ __forceinline__ void load_sh_rows_staged(const BwdIn& in, float4* sh_
 // (The one-view kernel keeps its own copy of the math of pergauss_terms: routed through the shared function hipcc
 // allocates 172 VGPRs instead of 132 -- 2 resident waves per SIMD instead of 3 -- and the kernel takes 120 us instead
 // of 98.  tests/test_gpu_api.py::test_batched_backward_equals_per_view_backward keeps the two in step.)
-#ifndef TGS_SH_ROW
-#define TGS_SH_ROW 12
-#endif
-constexpr int SH_ROW = TGS_SH_ROW;
 template <bool HAS_SH, bool HAS_SCALE_ROT>
 __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, const CamParams cam, const GeomState g, const BinState b)
 {
@@ -1255,13 +1070,10 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
     const ViewMat V = load_mat(cam.view), PM = load_mat(cam.proj);
     const float camx = cam.campos[0], camy = cam.campos[1], camz = cam.campos[2];
     // SH rows in, dL_dsh rows out: staged through LDS so that global memory sees 16 B per lane, fully coalesced
-    // Rows of SH_ROW float4 per thread.  12 (192 B: a thread's rows 48 banks apart) puts every fourth lane of a 16-B access on the same banks
-    // (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.61, profiles/r06_a_store_mode_counters.txt); 13 -- an odd number of 16-byte cells -- spreads 16
-    // lanes over all 64 banks; the coalesced side then addresses piece i of the workgroup's 3072 at i + i / 12.  Measured (round 6, -DTGS_SH_ROW=13
-    // against 12, one box, tools/stage_times.py): 62.2-62.6 against 62.8-62.9 us -- the conflicts are not what this kernel waits for (SQ_WAIT_INST_LDS
-    // is 3.6 % of its wave cycles), and 13 leaves 4 KB of the CU's LDS for three workgroups.  12 stays.
-    __shared__ float4 sh_lds[HAS_SH ? PRE_BLOCK * SH_ROW : 1];
-    auto piece = [](uint32_t i) { return SH_ROW == 12 ? i : i + ((i * 43691u) >> 19); };     // i / 12 for i < 3072: 43691 = ceil(2^19 / 12)
+    // (a thread's 12 cells are 48 banks apart: every fourth lane of a 16-B access meets the same banks -- SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.61.
+    // Rows padded to 13 cells are conflict-free and measured the same time (round 6, profiles/r06_tuning.txt): the conflicts are not what this kernel
+    // waits for -- SQ_WAIT_INST_LDS is 3.6 % of its wave cycles.)
+    __shared__ float4 sh_lds[HAS_SH ? PRE_BLOCK * 12 : 1];
     const bool sh_staged = HAS_SH && in.M == 16;
     const size_t base4 = (size_t)blockIdx.x * PRE_BLOCK * 12, total4 = (size_t)in.P * 12;
     const bool in_range = idx < in.P;
@@ -1289,7 +1101,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
         for (int q = 0; q < 12; q++) { const size_t i = base4 + q * PRE_BLOCK + threadIdx.x; r[q] = s4[i < total4 ? i : total4 - 1]; }
         asm volatile("" ::: "memory");                      // (all of the above is asked for before the first wait)
 #pragma unroll
-        for (int q = 0; q < 12; q++) sh_lds[piece(q * PRE_BLOCK + threadIdx.x)] = make_float4(r[q].x, r[q].y, r[q].z, r[q].w);
+        for (int q = 0; q < 12; q++) sh_lds[q * PRE_BLOCK + threadIdx.x] = make_float4(r[q].x, r[q].y, r[q].z, r[q].w);
         __syncthreads();
     }
     float a[NACC];
@@ -1333,7 +1145,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
             if (sh_staged) {
 #pragma unroll
                 for (int q = 0; q < 12; q++) {
-                    if (q * 4 < ncoef * 3) { const float4 t = sh_lds[threadIdx.x * SH_ROW + q]; shv[4 * q] = t.x; shv[4 * q + 1] = t.y; shv[4 * q + 2] = t.z; shv[4 * q + 3] = t.w; }
+                    if (q * 4 < ncoef * 3) { const float4 t = sh_lds[threadIdx.x * 12 + q]; shv[4 * q] = t.x; shv[4 * q + 1] = t.y; shv[4 * q + 2] = t.z; shv[4 * q + 3] = t.w; }
                 }
             } else {
                 const float* sh = in.shs + (size_t)idx * in.M * 3;
@@ -1400,7 +1212,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
                 float o[4];
 #pragma unroll
                 for (int t = 0; t < 4; t++) { const int i = 4 * q + t; o[t] = coef[i / 3] * dRGB[i % 3]; }
-                sh_lds[threadIdx.x * SH_ROW + q] = make_float4(o[0], o[1], o[2], o[3]);
+                sh_lds[threadIdx.x * 12 + q] = make_float4(o[0], o[1], o[2], o[3]);
             }
             __syncthreads();
             float4* d4 = reinterpret_cast<float4*>(in.dL_dsh);
@@ -1416,7 +1228,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess_bwd(const BwdIn in, co
             for (int q = 0; q < 12; q++) {
                 const size_t i = base4 + q * PRE_BLOCK + threadIdx.x;
                 if (i < total4) {
-                    float4 o = sh_lds[piece(q * PRE_BLOCK + threadIdx.x)];
+                    float4 o = sh_lds[q * PRE_BLOCK + threadIdx.x];
                     if (in.accumulate) { o.x += prev[q].x; o.y += prev[q].y; o.z += prev[q].z; o.w += prev[q].w; }
                     d4[i] = o;
                 }
@@ -1851,9 +1663,6 @@ void launch_render_bwd(hipStream_t st, const ImgState& s, const BinState& b, int
 {
     // (-DTGS_FAST_MATH=0 builds always take the fixed-order kernel: it evaluates exp / the divisions in their accurate forms)
     if (deterministic || !TGS_FAST_MATH) { hipLaunchKernelGGL(k_render_bwd_det, dim3(tiles), dim3(256), 0, st, s, b, W, H, gx, bg, dL_dpix); return; }
-#if TGS_BWD_HALF
-    if (!light) { hipLaunchKernelGGL(k_render_bwd_h, dim3(tiles), dim3(H_THREADS), 0, st, s, b, W, H, gx, bg, dL_dpix); return; }
-#endif
     if (!light) { hipLaunchKernelGGL(k_render_bwd, dim3(tiles), dim3(BWD_THREADS), 0, st, s, b, W, H, gx, bg, dL_dpix, 0, T); return; }
     const uint32_t heavy = mid_tiles < tiles ? mid_tiles : tiles;
     // one-tile workgroups for the (bound on the) tiles with >= LIGHT_MAX instances + light groups for the rest, three tiles each.  With exact

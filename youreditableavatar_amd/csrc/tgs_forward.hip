@@ -982,12 +982,6 @@ __global__ __launch_bounds__(1024) void k_tile_sort(const GeomState g, const Img
     const uint32_t n_nonempty = s.meta->n_nonempty;
     const uint32_t n_heavy = min(s.meta->n_heavy, n_nonempty), n_mid = min(max(s.meta->n_mid, n_heavy), n_nonempty);
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#ifdef TGS_SORT_ONLY      // timing-only builds (results are wrong): 1 = only the heavy class sorts, 2 = only the mid class, 3 = only the light class
-    {
-        const int cls = blockIdx.x < heavy_blocks ? 1 : blockIdx.x < heavy_blocks + mid_blocks ? 2 : blockIdx.x < heavy_blocks + mid_blocks + small_blocks ? 3 : 4;
-        if (cls != TGS_SORT_ONLY && cls != 4) return;
-    }
-#endif
     if (blockIdx.x >= heavy_blocks + mid_blocks + small_blocks) {          // the grid's tail: workers of the lists beyond the LDS sort
         ovf_worker(g, s, b, lk, blockIdx.x - (heavy_blocks + mid_blocks + small_blocks), ovf_blocks, sort_cap, gx);
         return;
