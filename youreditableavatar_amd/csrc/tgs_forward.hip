@@ -555,13 +555,20 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const 
     for (uint32_t k = 0; k < w; k++) before += s.tile_count[k * SCAN_THREADS + threadIdx.x];
     const uint32_t c = in ? s.tile_count[t] : 0u;
     if (threadIdx.x < 40) { hist[threadIdx.x] = threadIdx.x < 34 ? __builtin_nontemporal_load(&s.aux->hist[threadIdx.x]) : 0u; lcount[threadIdx.x] = 0u; }
+    __syncthreads();                                        // hist / lcount are published
+    // (c) FIRST (round 6: it stood behind the two scans, a memory round trip at the end of the kernel's chain): rank among this workgroup's tiles of the
+    // same bucket, then ONE global returning atomic per occupied bucket -- issued here, its answer is only needed where the positions are formed below
+    const uint32_t bkt = length_bucket(c);
+    const uint32_t lrank = in ? atomicAdd(&lcount[bkt], 1u) : 0u;
+    __syncthreads();
+    uint32_t gb = 0;
+    if (threadIdx.x < 34) { const uint32_t lc = lcount[threadIdx.x]; if (lc) gb = atomicAdd(&s.aux->cursor[threadIdx.x], lc); }
     unsigned long long tot, pre_tot;
-    const unsigned long long pre = block_exscan_u64(before, lds, pre_tot);    // (only the total is used; the barriers inside also publish hist / lcount)
+    const unsigned long long pre = block_exscan_u64(before, lds, pre_tot);    // (only the total is used)
     (void)pre;
     const unsigned long long ex = block_exscan_u64((unsigned long long)c, lds, tot) + pre_tot;
     if (in) s.ranges[t] = make_uint2((uint32_t)ex, (uint32_t)(ex + c));
     // (b) the frame's bucket stretches: tiles by descending list length (power-of-two buckets; order inside a bucket does not matter)
-    const uint32_t bkt = length_bucket(c);
     if (threadIdx.x < 34) {
         uint32_t acc = 0;
         for (uint32_t b2 = 33; b2 > threadIdx.x; b2--) acc += hist[b2];
@@ -570,10 +577,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(const GeomState g, const 
         if (threadIdx.x == 11) cls[1] = acc + hist[11];    // ... with >= 1024
         if (threadIdx.x == 8) cls[2] = acc + hist[8];      // ... with >= 128
     }
-    // (c) rank among this workgroup's tiles of the same bucket, then ONE global returning atomic per occupied bucket
-    const uint32_t lrank = in ? atomicAdd(&lcount[bkt], 1u) : 0u;
-    __syncthreads();
-    if (threadIdx.x < 34) gbase[threadIdx.x] = lcount[threadIdx.x] ? atomicAdd(&s.aux->cursor[threadIdx.x], lcount[threadIdx.x]) : 0u;
+    if (threadIdx.x < 34) gbase[threadIdx.x] = gb;          // (the atomic's answer, asked for above)
     __syncthreads();
     const uint32_t n_nonempty = cls[0], n_heavy = cls[1], n_mid = cls[2];
     if (in) {
