@@ -363,29 +363,34 @@ def test_cutoff_flip_scenes_are_the_reference_with_one_decision_taken_the_other_
     assert same <= bound and same < 0.5 * direct, (desc, same, direct)
 
 
-@pytest.mark.xfail(strict=True, reason="the recorded misses of the frozen criterion: ONE splat each (profiles/r05_fuzz_soak_d.txt, profiles/r06_fuzz_soak_b.txt)")
-@pytest.mark.parametrize("seed,scene,tensor,recorded", [(94, 71, "dL_dcov3D", 1.875e-4), (104, 25, "dL_dconic", 2.575e-4)])
-def test_known_misses_are_still_the_recorded_ones(seed, scene, tensor, recorded, gpu_device):
-    """The two scenes of 7 584 fuzzed ones (rounds 5-6) that miss the frozen criterion, kept as STRICT expected failures: a kernel change that clears one
-    turns this test red (update the record), and the RuntimeError below keeps a change that makes one WORSE from hiding behind the xfail (it raises
-    outside the expected assertion: an error).
-    * seed 94 / scene 71 (428 Gaussians, 270 x 219, splats x 8; found in round 5): since round 5's pass trim of k_render_bwd, dL_dcov3D of Gaussian 394 --
-      conic determinant 1.9e-4 -- sits 1.9e-4 from the fp32 oracle where the bar is 2 eta = 1.17e-4;
-    * seed 104 / scene 25 (2 752 Gaussians, 29 x 138, splats x 8; found by round 6's soak over twelve NEW seeds, and there with round 5's library to the
-      digit: not a change of round 6): dL_dconic of Gaussian 705 -- radius 1 304 pixels in a 29-pixel-wide image, alpha 0.38 on every pixel -- is 2.6e-4
-      from every build of the oracle (bar 1.95e-4); the fixed-order accurate-math backward is at 2e-6 (profiles/r06_fuzz_soak_b.txt)."""
+@pytest.mark.parametrize("seed,scene,tensor,before,bound", [(94, 71, "dL_dcov3D", 1.875e-4, 1.17e-4), (104, 25, "dL_dconic", 2.575e-4, 1e-5)])
+def test_forward_and_backward_take_the_same_cutoff_decisions(seed, scene, tensor, before, bound, gpu_device):
+    """The two scenes of 7 584 fuzzed ones (rounds 5-6) that missed the frozen criterion -- each ONE splat's gradient:
+    * seed 94 / scene 71 (428 Gaussians, 270 x 219, splats x 8; round 5): dL_dcov3D 1.875e-4 from the fp32 oracle, bar 2 eta = 1.17e-4;
+    * seed 104 / scene 25 (2 752 Gaussians, 29 x 138, splats x 8; found by round 6's soak over twelve new seeds, with round 5's library too): dL_dconic of an
+      image-filling splat 2.575e-4 from every build of the oracle, bar 1.95e-4.
+    Bisected over the image (the backward is linear in dL/d image: tests/tools/diag_pixels.py), the second one was ONE pixel at which the BACKWARD blended an
+    entry the FORWARD had skipped: both kernels evaluate alpha from the same expression, but the compiler had contracted it differently in each (the forward fused
+    t * dx with the rounded c dy^2, the backward rounded t * dx and fused c dy * dy), and on that pair the two roundings fell on different sides of alpha = 1/255 --
+    every entry in front of it at that pixel saw T off by 1/255.  pair_power2 (tgs_device.hpp) is now ONE instruction sequence for both kernels, and BOTH scenes
+    pass (the first had been blamed on the pairing of the four-pixel sums in round 5: it was the same thing, the pass trim had changed the backward's contraction).
+    Regression test: the criterion holds on both, and the tensor that missed is well inside what it was."""
     from tests import fuzz
     rng = np.random.default_rng(seed)
     for it in range(scene + 1):
         desc, inp, dL = fuzz.random_scene(rng, it)
     ref = util.oracle_run(inp, dL)
     mine = util.hip_run(inp, dL)
+    rep = util.compare(mine, ref)
     d = util.rel_l2(np.asarray(mine[tensor]).reshape(np.asarray(ref[tensor]).shape), ref[tensor])
-    util.record_parity(f"known_miss_seed{seed}_scene{scene}", {f"{tensor}_vs_fp32_oracle": d, "recorded": recorded})
-    print(desc, f"{tensor} vs fp32 oracle {d:.3e} (recorded {recorded:.3e})")
-    if d > 2.0 * recorded + 1e-5:                          # more than twice the recorded distance: not the recorded miss any more
-        raise RuntimeError(f"seed {seed} scene {scene} got worse: {tensor} {d:.3e} from the fp32 oracle (recorded {recorded:.3e})")
-    util.compare(mine, ref)                               # the expected failure: AssertionError from the frozen criterion
+    util.record_parity(f"former_miss_seed{seed}_scene{scene}", {f"{tensor}_vs_fp32_oracle": d, "before_the_fix": before})
+    print(desc, f"{tensor} vs fp32 oracle {d:.3e} (before the fix {before:.3e})", {k: v for k, v in rep.items() if "|route" in k})
+    assert d <= bound, (desc, tensor, d)
+    # the forward's decisions are the backward's: final_T replayed by the backward's own alphas would otherwise differ by a factor (1 - alpha) somewhere
+    light = util.hip_run(inp, dL, light_tiles=True)
+    for k in util.GRAD_KEYS:
+        if k in mine:
+            assert util.rel_l2(light[k], mine[k]) <= 1e-5, k        # (the light groups share pair_power2: same decisions, another summation order)
 
 
 def test_nonfinite_upstream_gradient_stays_with_the_splats_that_cover_its_pixel(gpu_device):

@@ -1,1 +1,1 @@
-cd $GRAFT_REPO_ROOT; timeout 900 python -m pytest tests/test_gpu_api.py -m gpu -x -q --timeout 600 -k "discards" 2>&1 | grep -v "^$" | tail -40 | cut -c1-300
+cd $GRAFT_REPO_ROOT; timeout 600 python scratch/dbg_px.py 2>&1 | grep -v amdgpu | tail -60 | cut -c1-220

@@ -298,7 +298,7 @@ __device__ __forceinline__ void bwd_passes(const unsigned short* myq, uint32_t n
         const float4 bb = *reinterpret_cast<const float4*>(cB + j16);      // conic yy pre-scaled, opacity, colour r g
         const float c0 = bb.z, c1 = bb.w, c2 = *reinterpret_cast<const float*>(cAcc + offsetof(BwdAccT<CH>, t) + offsetof(AccTail, cb) + j16);
         const float dx = a.x - px.fx, dy = a.y - px.fy;
-        const float power2 = (a.z * dx + a.w * dy) * dx + (bb.x * dy) * dy;   // log2(e) * power of forward.cu:336
+        const float power2 = pair_power2(a.z, a.w, bb.x, dx, dy);            // log2(e) * power of forward.cu:336, rounded exactly as k_render_fwd rounds it
         const float G = __builtin_amdgcn_exp2f(power2);
         const float alpha = fminf(0.99f, bb.y * G);
         // "contributor >= last_contributor" skip of backward.cu:487 as offset > threshold.  A padding entry has opacity 0 and fails the alpha test.

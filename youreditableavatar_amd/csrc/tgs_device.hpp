@@ -467,6 +467,17 @@ constexpr float LOG2E = 1.4426950408889634f;
 constexpr float UNSCALE_CONIC = -2.0f / LOG2E, UNSCALE_CONIC_XY = -1.0f / LOG2E;
 __device__ __forceinline__ void stage_conic_a(float4& ra) { ra.z *= -0.5f * LOG2E; ra.w *= -LOG2E; }
 __device__ __forceinline__ void stage_conic_b(float4& rb) { rb.x *= -0.5f * LOG2E; }
+// log2(e) * power of one (pixel, entry) pair from the staged conic -- ONE instruction sequence for k_render_fwd and k_render_bwd (round 6).  The backward
+// replays the forward's decisions (alpha >= 1/255, forward.cu:340-343 / backward.cu:500-504) from its own evaluation of alpha; written as a plain
+// expression in both kernels the compiler was free to contract it differently in each, and on one pair in ~10^9 the two evaluations fell on different
+// sides of the cut-off: the forward skipped the entry, the backward blended it, and every entry in front of it at that pixel saw T off by 1 / 255 (fuzz
+// seed 104 scene 25: one pixel, dL_dconic of an image-filling splat 2.6e-4 from the oracle; profiles/r06_fuzz_soak_b.txt).  Explicit fused
+// multiply-adds, contraction off: both kernels round alike, so they decide alike.
+__device__ __forceinline__ float pair_power2(float axx, float axy, float ayy, float dx, float dy)
+{
+#pragma clang fp contract(off)
+    return __builtin_fmaf(__builtin_fmaf(axx, dx, axy * dy), dx, (ayy * dy) * dy);
+}
 
 // ---------------------------------------------------------------------------------------------
 // Hand-scheduled DPP sequences.  hipcc keeps `v_mov_b32 tmp, 0; v_mov_b32_dpp tmp, x` in front of every consumer

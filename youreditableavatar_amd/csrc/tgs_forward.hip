@@ -1140,7 +1140,7 @@ __device__ __forceinline__ bool fwd_q_block_round(const float4* sA, const float4
             const float cc = sC[j];
             const float dx = a.x - pixfx, dy = a.y - pixfy;
 #if TGS_FAST_MATH
-            const float power2 = (a.z * dx + a.w * dy) * dx + (bb.x * dy) * dy;
+            const float power2 = pair_power2(a.z, a.w, bb.x, dx, dy);
             const float alpha = fminf(0.99f, bb.y * __builtin_amdgcn_exp2f(power2));
 #else
             const float power2 = -0.5f * (a.z * dx * dx + bb.x * dy * dy) - a.w * dx * dy;
