@@ -130,8 +130,16 @@ __global__ __launch_bounds__(256) void k_render_bwd_det(const ImgState s, const 
 #pragma unroll
                 for (int u = 0; u < RUNROLL; u++) {
                     dx[u] = a[u].x - pixfx; dy[u] = a[u].y - pixfy;
+#if TGS_FAST_MATH
+                    // alpha exactly as k_render_fwd evaluated it (pair_power2 on the conic scaled as stage_conic_* scales it, v_exp_f32): the backward replays
+                    // the forward's alpha >= 1/255 decisions, so it must round what the forward rounded (round 6; until then this kernel evaluated the
+                    // reference's expression with expf -- another rounding than the forward's, the same hazard pair_power2 removed from the default kernel)
+                    const float power = pair_power2(a[u].z * (-0.5f * LOG2E), a[u].w * (-LOG2E), bb[u].x * (-0.5f * LOG2E), dx[u], dy[u]);
+                    G[u] = __builtin_amdgcn_exp2f(power);
+#else
                     const float power = -0.5f * (a[u].z * dx[u] * dx[u] + bb[u].x * dy[u] * dy[u]) - a[u].w * dx[u] * dy[u];
                     G[u] = tgs_exp(power);
+#endif
                     alpha[u] = fminf(0.99f, bb[u].y * G[u]);
                     // list position of slot j is qhi-1-j; "contributor >= last_contributor" skip of backward.cu:487
                     valid[u] = (qhi - 1 - j[u] < last_contributor) && (j[u] < cnt) && !(power > 0.0f) && !(alpha[u] < 1.0f / 255.0f);
