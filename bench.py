@@ -35,7 +35,7 @@ VALU_PEAK_GWIPS = 1228.8
 # render loops' mix (6 fma/mul + 1 DPP + 1 transcendental per 8: DPP operations issue at half rate, v_exp_f32 at a quarter)
 VALU_MEASURED_FMA_GWIPS = 955.5
 VALU_MEASURED_MIX_GWIPS = 628.4
-PROFILE_SET = "r06_e"          # profiles/<set>_{hbm,sq}_counters.json: the PMC passes the roofline object quotes (tools/profile_round.sh); only
+PROFILE_SET = "r06_f"          # profiles/<set>_{hbm,sq}_counters.json: the PMC passes the roofline object quotes (tools/profile_round.sh); only
                                # used while their csrc_sha16 equals the hash of the sources this run executes (build.source_hash)
 
 
