@@ -381,6 +381,9 @@ def rasterize_accumulate(raster_settings, means3D, means2D, opacities, shs=None,
     return (color, radii, meta) if (return_meta or r_capacity is not None) else (color, radii)
 
 
+_SIDE_STREAMS: dict = {}      # device -> [torch.cuda.Stream]: the side streams of all SyncFreeBatch objects (see __init__)
+
+
 class SyncFreeBatch:
     """Renders the views of one step without a host synchronisation per frame.
 
@@ -414,7 +417,10 @@ class SyncFreeBatch:
         # (k_render_fwd, the loss, k_render_bwd): kernels bound by the L2 atomics / by latency next to kernels bound by VALU issue
         self.split = bool(split)
         self._host: Optional[torch.Tensor] = None
-        self._side = {}
+        # Side streams are shared by every SyncFreeBatch of the process (round 6): HIP multiplexes streams onto a few hardware queues, and a process that
+        # had created a dozen of them -- bench.py's secondary workloads each built a batch object of their own -- ran its later batches up to 10 % slower
+        # than a fresh process did (streams aliasing onto one queue: less overlap between the views).  A trainer has one batch object; this keeps it so.
+        self._side = _SIDE_STREAMS
         self._cooldown = 0                      # batches left to render synchronously (unused since overflow lists are sorted on the device; kept for callers that set it)
         self._pool = None
         self.viewspace_grads: Optional[torch.Tensor] = None
