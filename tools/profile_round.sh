@@ -16,7 +16,9 @@ timeout 420 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/
 timeout 420 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES --output-format csv -d $O/pmc_sq -o pmc -- python3 $R/tools/pmc_workload.py 4 > $O/pmc_sq.log 2>&1
 timeout 420 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM TCC_EA0_ATOMIC_sum --output-format csv -d $O/pmc_sq2 -o pmc -- python3 $R/tools/pmc_workload.py 4 > $O/pmc_sq2.log 2>&1
 timeout 420 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL SQ_LDS_ATOMIC_RETURN SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT --output-format csv -d $O/pmc_sq3 -o pmc -- python3 $R/tools/pmc_workload.py 4 > $O/pmc_sq3.log 2>&1
-(cd $R/tools/microbench && timeout 200 ./valu_issue_rate) > $O/valu_issue_rate.txt 2>&1
+# the probes are rebuilt from their sources first: a binary that travelled with the snapshot may be older than its .hip (rounds 4-6 ran a stale one)
+(cd $R/tools/microbench && for p in valu_issue_rate fetch_calibration; do timeout 300 hipcc -O3 --offload-arch=gfx950 -w $p.hip -o $p; done) > $O/microbench_build.log 2>&1
+(cd $R/tools/microbench && timeout 300 ./valu_issue_rate) > $O/valu_issue_rate.txt 2>&1
 # FETCH_SIZE / WRITE_SIZE calibration on known byte counts in this library's access patterns (tools/fetch_calibration.py -> profiles/<name>_fetch_calibration.json)
 timeout 200 $R/tools/microbench/fetch_calibration > $O/cal_bytes.txt 2>&1
 timeout 420 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/cal_fetch -o pmc -- $R/tools/microbench/fetch_calibration > $O/cal_fetch.log 2>&1
