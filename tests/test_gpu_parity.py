@@ -393,24 +393,35 @@ def test_forward_and_backward_take_the_same_cutoff_decisions(seed, scene, tensor
             assert util.rel_l2(light[k], mine[k]) <= 1e-5, k        # (the light groups share pair_power2: same decisions, another summation order)
 
 
-@pytest.mark.xfail(strict=True, reason="the one recorded miss of round 6's 4 608 scenes on the fixed kernels: a cut-off flip on a scene whose reference noise exceeds the 1e-3 cap (profiles/r06_fuzz_soak_e.txt)")
-def test_known_miss_seed207_scene90_is_still_the_recorded_one(gpu_device):
+KNOWN_CAP_MISSES = [      # (fuzz seed, scene index, recorded dL_dconic distance from the fp32 oracle)
+    pytest.param(207, 90, 1.025e-3, id="seed207_scene90"),
+    pytest.param(308, 9, 2.787e-3, id="seed308_scene9"),
+]
+
+
+@pytest.mark.xfail(strict=True, raises=AssertionError, reason="the two recorded misses of round 6's 6 912 scenes on the fixed kernels: single-pixel cut-off flips on scenes whose reference noise exceeds the 1e-3 cap "
+                                       "(profiles/r06_fuzz_soak_e.txt, _f.txt)")
+@pytest.mark.parametrize("seed,scene,recorded", KNOWN_CAP_MISSES)
+def test_known_cap_misses_are_still_the_recorded_ones(gpu_device, seed, scene, recorded):
     """Fuzz seed 207 / scene 90 (4 924 Gaussians, 283 x 219, SH 2, splats x 8): at ONE pixel the forward (and, consistently, the backward: default and
     fixed-order backward agree to 4e-7) decides a pair of a needle splat on the other side of alpha = 1/255 than the fp32 oracle -- final_T differs by 2.7e-3
     there.  The reference's own builds are ~1e-3 apart on this scene (dL_dconic: HIP is 4.3e-4 from the cut-off-in build, 4.6e-4 from the FMA build, 1.025e-3 from
-    the plain fp32 and the double builds), so the bar is its cap, 1e-3, and the HIP path is 2.5 % over it.  Kept as a STRICT expected failure: a change that clears it
-    turns the test red (update the record); one that doubles the distance raises."""
+    the plain fp32 and the double builds), so the bar is its cap, 1e-3, and the HIP path is 2.5 % over it.
+    Fuzz seed 308 / scene 9 (1 500 Gaussians, 272 x 173, SH 3, splats x 3): the same at one pixel (final_T differs by 3.9e-3), all of the error in one Gaussian;
+    dL_dconic is 2.787e-3 from the plain fp32, the exp2 and the double builds and 3.9e-6 / 4.4e-6 from the cut-off-out and the FMA-contracted builds -- the
+    reference's own builds are 2.8e-3 apart, the bar is the cap.
+    Kept as STRICT expected failures: a change that clears one turns the test red (update the record); one that doubles the distance raises."""
     from tests import fuzz
-    rng = np.random.default_rng(207)
-    for it in range(91):
+    rng = np.random.default_rng(seed)
+    for it in range(scene + 1):
         desc, inp, dL = fuzz.random_scene(rng, it)
     ref = util.oracle_run(inp, dL)
     mine = util.hip_run(inp, dL)
     d = util.rel_l2(np.asarray(mine["dL_dconic"]).reshape(np.asarray(ref["dL_dconic"]).shape), ref["dL_dconic"])
-    util.record_parity("known_miss_seed207_scene90", {"dL_dconic_vs_fp32_oracle": d, "recorded": 1.025e-3})
-    print(desc, f"dL_dconic vs fp32 oracle {d:.3e} (recorded 1.025e-3)")
-    if d > 2.1e-3:
-        raise RuntimeError(f"seed 207 scene 90 got worse: dL_dconic {d:.3e} from the fp32 oracle (recorded 1.025e-3)")
+    util.record_parity(f"known_miss_seed{seed}_scene{scene}", {"dL_dconic_vs_fp32_oracle": d, "recorded": recorded})
+    print(desc, f"dL_dconic vs fp32 oracle {d:.3e} (recorded {recorded:.3e})")
+    if d > 2.05 * recorded:
+        raise RuntimeError(f"seed {seed} scene {scene} got worse: dL_dconic {d:.3e} from the fp32 oracle (recorded {recorded:.3e})")
     util.compare(mine, ref)                               # the expected failure: AssertionError from the frozen criterion
 
 
