@@ -26,7 +26,7 @@ NAMED = {
  "r05_a_bench_default.json": "bench line cited for the host share of the drop-in loop", "r05_b_": "round-5 files cited by DESIGN.md (`k_scan` over several workgroups; issue rates)", "r05_c_bench_default.json": "bench line after the pass trim", "r05_e_": "kernel stats cited in DESIGN.md section 9",
  "r05_final_bench_default.json": "last bench line of round 5", "r05_fuzz_soak": "fuzz soaks at the frozen criterion (a-d: 5 280 scenes, one miss)", "r05_pass_shapes.txt": "lane-slot accounting of the backward mappings (CPU)", "r05_render_decomposition.txt": "timing-only builds of the render pair",
  "r05_ssim_counters.txt": "SQ counters of the SSIM kernels", "r05_step_timeline.txt": "kernels in flight over an 8-view step", "r05_valu_issue_rate_packed_lds_swap.txt": "packed fp32 / permlane swap / LDS read issue rates",
- "r06_b_kernel_stats_dropin.csv": "drop-in kernel stats of the run whose store-mode counters are in r06_store_mode_counters.txt", "r06_large_splats.txt": "x4 / x8: stage times, kernel stats, FETCH / WRITE / SQ counters, rectangle statistics; k_tile_sort by class",
+ "r06_b_kernel_stats_dropin.csv": "drop-in kernel stats of the run whose store-mode counters are in r06_store_mode_counters.txt", "r06_large_splats.txt": "x4 / x8: stage times, kernel stats, FETCH / WRITE / SQ counters, rectangle statistics; k_tile_sort by class; what the entries behind a tile's deepest contributor cost (five variants); the GPU's scattered-store rate (microbench)",
  "r06_pass_packing.txt": "would another assignment of quadrant lists to rows need fewer passes? CPU prediction + the measured 8-waves-per-tile backward", "r06_store_mode_counters.txt": "counters over the STORE-mode k_preprocess_bwd (drop-in loop): 0.62 of the HBM peak",
  "r06_fuzz_soak": "round-6 fuzz soaks at the frozen criterion (a, b: before the cut-off fix; cd, e, f: 6 912 scenes on the fixed kernels, two misses)", "r06_tuning.txt": "round-6 A/B runs by library variant: binning chunks, EMIT_RANK, padded SH rows, discarded outputs, constants sweep, Morton order",
 }
