@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdint>
 #include <vector>
+#include <chrono>
 
 __device__ __forceinline__ uint32_t mix(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
 
@@ -32,6 +33,18 @@ __global__ __launch_bounds__(256) void k_store(unsigned char* buf, uint32_t rows
         float4* p = reinterpret_cast<float4*>(buf + (size_t)r * (MODE == 6 ? 64 : 48));
         p[0] = make_float4(1.f, 2.f, 3.f, 4.f); p[1] = make_float4(5.f, 6.f, 7.f, 8.f); p[2] = make_float4(9.f, 10.f, 11.f, 12.f);
     }
+}
+
+// a vector-bound kernel for the overlap test: 256 threads x iters dependent-free v_fma_f32 (8 accumulators), workgroups of 1024 threads like k_render_bwd's
+__global__ __launch_bounds__(1024) void k_fma(float* out, int iters)
+{
+    float a0 = threadIdx.x, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
+    const float m = 0.999f, c = 1e-3f;
+#pragma unroll 1
+    for (int i = 0; i < iters; i++) {
+        a0 = fmaf(a0, m, c); a1 = fmaf(a1, m, c); a2 = fmaf(a2, m, c); a3 = fmaf(a3, m, c); a4 = fmaf(a4, m, c); a5 = fmaf(a5, m, c); a6 = fmaf(a6, m, c); a7 = fmaf(a7, m, c);
+    }
+    out[blockIdx.x * 1024 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
 }
 
 int main()
@@ -66,6 +79,32 @@ int main()
             }
             const int bytes = mode == 0 ? 1 : (mode == 1 || mode == 5) ? 8 : mode == 2 ? 16 : 48;
             printf("%-58s n %8u  %8.1f us  %7.1f G rows/s  %8.1f GB/s of payload\n", names[mode], n, best * 1e3, n / (best * 1e-3) / 1e9, (double)n * bytes / (best * 1e-3) / 1e9);
+        }
+    }
+    // Do scattered stores ride beside vector work?  k_fma (2 workgroups of 1024 threads per CU, all SIMDs busy) alone, the 2.3 M 48-byte rows alone, both at once on two streams.
+    {
+        float* out = nullptr; hipMalloc(&out, (size_t)512 * 8 * 1024 * 4);
+        hipStream_t sa, sb; hipStreamCreateWithFlags(&sa, hipStreamNonBlocking); hipStreamCreateWithFlags(&sb, hipStreamNonBlocking);
+        hipEvent_t a0, a1, b0, b1; hipEventCreate(&a0); hipEventCreate(&a1); hipEventCreate(&b0); hipEventCreate(&b1);
+        const uint32_t n = 2300000u; const dim3 gs((n + 255) / 256);
+        for (int iters : {350, 700}) {
+            for (int what = 0; what < 3; what++) {           // 0: fma alone, 1: stores alone, 2: both
+                float best = 1e30f, bfma = 0, bst = 0;
+                for (int rep = 0; rep < 4; rep++) {
+                    hipDeviceSynchronize();
+                    const auto t0 = std::chrono::steady_clock::now();
+                    if (what != 1) { hipEventRecord(a0, sa); hipLaunchKernelGGL(k_fma, dim3(512 * 4), dim3(1024), 0, sa, out, iters); hipEventRecord(a1, sa); }
+                    if (what != 0) { hipEventRecord(b0, sb); hipLaunchKernelGGL(k_store<3>, gs, dim3(256), 0, sb, buf, rows, n, 99u + rep); hipEventRecord(b1, sb); }
+                    hipDeviceSynchronize();
+                    const float wall = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                    float f = 0, st = 0;
+                    if (what != 1) hipEventElapsedTime(&f, a0, a1);
+                    if (what != 0) hipEventElapsedTime(&st, b0, b1);
+                    if (rep > 0 && wall < best) { best = wall; bfma = f; bst = st; }
+                }
+                printf("overlap test, k_fma %5d iterations: %-12s wall %7.1f us   k_fma %7.1f us   2.3 M scattered 48-byte rows %7.1f us\n", iters,
+                       what == 0 ? "fma alone" : what == 1 ? "stores alone" : "both at once", best * 1e3, bfma * 1e3, bst * 1e3);
+            }
         }
     }
     return 0;
