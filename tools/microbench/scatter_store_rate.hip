@@ -29,7 +29,16 @@ __global__ __launch_bounds__(256) void k_store(unsigned char* buf, uint32_t rows
     if (MODE == 0) buf[(size_t)r * 48] = 1;
     else if (MODE == 1 || MODE == 5) *reinterpret_cast<uint2*>(buf + (size_t)r * (MODE == 5 ? 8 : 48)) = make_uint2(t, salt);
     else if (MODE == 2) *reinterpret_cast<float4*>(buf + (size_t)r * 48) = make_float4(1.f, 2.f, 3.f, 4.f);
-    else {
+    else if (MODE == 7) {                                 // 48 bytes, one lane, three NON-TEMPORAL stores (global_store_dwordx4 ... nt)
+        typedef float v4 __attribute__((ext_vector_type(4)));
+        v4* p = reinterpret_cast<v4*>(buf + (size_t)r * 48);
+        const v4 a = {1.f, 2.f, 3.f, 4.f};
+        __builtin_nontemporal_store(a, p); __builtin_nontemporal_store(a, p + 1); __builtin_nontemporal_store(a, p + 2);
+    } else if (MODE == 8) {                               // 8 bytes, non-temporal
+        typedef unsigned v2 __attribute__((ext_vector_type(2)));
+        const v2 a = {t, salt};
+        __builtin_nontemporal_store(a, reinterpret_cast<v2*>(buf + (size_t)r * 48));
+    } else {
         float4* p = reinterpret_cast<float4*>(buf + (size_t)r * (MODE == 6 ? 64 : 48));
         p[0] = make_float4(1.f, 2.f, 3.f, 4.f); p[1] = make_float4(5.f, 6.f, 7.f, 8.f); p[2] = make_float4(9.f, 10.f, 11.f, 12.f);
     }
@@ -55,9 +64,9 @@ int main()
     hipMemset(buf, 0, (size_t)rows * 64);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const char* names[] = {"1 byte per row", "8 bytes per row", "16 bytes per row", "48 bytes per row, one lane, three stores", "48 bytes per row, three lanes, one instruction",
-                           "8 bytes, consecutive addresses (coalesced)", "48 bytes per row on a 64-byte pitch (one line per row)"};
+                           "8 bytes, consecutive addresses (coalesced)", "48 bytes per row on a 64-byte pitch (one line per row)", "48 bytes per row, one lane, three non-temporal stores", "8 bytes per row, non-temporal"};
     printf("# tools/microbench/scatter_store_rate.hip on MI355X: n threads each store one piece to a pseudo-random row of a %u-row buffer (48-byte pitch unless said otherwise)\n", rows);
-    for (int mode = 0; mode < 7; mode++) {
+    for (int mode = 0; mode < 9; mode++) {
         for (uint32_t n : {750000u, 2300000u, 9200000u}) {
             const uint32_t threads = mode == 4 ? n * 4u : n;
             const dim3 grid((threads + 255) / 256);
@@ -71,13 +80,15 @@ int main()
                 case 3: hipLaunchKernelGGL(k_store<3>, grid, dim3(256), 0, 0, buf, rows, n, 77u + rep); break;
                 case 4: hipLaunchKernelGGL(k_store<4>, grid, dim3(256), 0, 0, buf, rows, n, 77u + rep); break;
                 case 5: hipLaunchKernelGGL(k_store<5>, grid, dim3(256), 0, 0, buf, rows, n, 77u + rep); break;
-                default: hipLaunchKernelGGL(k_store<6>, grid, dim3(256), 0, 0, buf, rows, n, 77u + rep); break;
+                case 6: hipLaunchKernelGGL(k_store<6>, grid, dim3(256), 0, 0, buf, rows, n, 77u + rep); break;
+                case 7: hipLaunchKernelGGL(k_store<7>, grid, dim3(256), 0, 0, buf, rows, n, 77u + rep); break;
+                default: hipLaunchKernelGGL(k_store<8>, grid, dim3(256), 0, 0, buf, rows, n, 77u + rep); break;
                 }
                 hipEventRecord(e1); hipEventSynchronize(e1);
                 float ms = 0; hipEventElapsedTime(&ms, e0, e1);
                 if (rep > 0 && ms < best) best = ms;     // (first launch: code load)
             }
-            const int bytes = mode == 0 ? 1 : (mode == 1 || mode == 5) ? 8 : mode == 2 ? 16 : 48;
+            const int bytes = mode == 0 ? 1 : (mode == 1 || mode == 5 || mode == 8) ? 8 : mode == 2 ? 16 : 48;
             printf("%-58s n %8u  %8.1f us  %7.1f G rows/s  %8.1f GB/s of payload\n", names[mode], n, best * 1e3, n / (best * 1e-3) / 1e9, (double)n * bytes / (best * 1e-3) / 1e9);
         }
     }
