@@ -621,6 +621,18 @@ def secondary_workloads(a, cloud, dev, D, W, H, headline_ms):
                                           "gathers hit neighbouring lines; the binning has no global atomics, so the order no longer decides its cost)"}
     del b3, co
     torch.cuda.empty_cache()
+    try:
+        # ... and with every splat x 4 on top: spatially ordered AND on 5..64 tiles is what a mesh-bound trained scene looks like (tetgs_edit_2d.py:203)
+        co = {k: g(mc[k] * (4.0 if k == "scales" else 1.0), True) for k in ("means3D", "opacities", "scales", "rotations", "shs")}
+        FlatGradients([co[k] for k in ("means3D", "opacities", "scales", "rotations", "shs")])
+        b4 = SyncFreeBatch(streams=a.streams)
+        ms4 = timed(lambda i: b4.run_views(S4, co["means3D"], co["opacities"], co["shs"], co["scales"], co["rotations"], None, accumulate=False,
+                                           upstream_view=lambda v, image: dL), 6, 3) / len(S4)
+        res["spatially_ordered_gaussians"]["x4_ms_per_frame"] = round(ms4, 4)
+        del b4, co
+    except Exception as ex:                                 # noqa: BLE001 -- a secondary measurement must not take the line down
+        res["spatially_ordered_gaussians"]["x4_error"] = repr(ex)[:200]
+    torch.cuda.empty_cache()
     # ---- alive (pixel, entry) pairs of view 0
     rs = S[0]
     e = torch.Tensor([])

@@ -393,16 +393,18 @@ def test_forward_and_backward_take_the_same_cutoff_decisions(seed, scene, tensor
             assert util.rel_l2(light[k], mine[k]) <= 1e-5, k        # (the light groups share pair_power2: same decisions, another summation order)
 
 
-KNOWN_CAP_MISSES = [      # (fuzz seed, scene index, recorded dL_dconic distance from the fp32 oracle)
-    pytest.param(207, 90, 1.025e-3, id="seed207_scene90"),
-    pytest.param(308, 9, 2.787e-3, id="seed308_scene9"),
+KNOWN_CAP_MISSES = [      # (fuzz seed, scene index, the tensor that misses, its recorded distance from the fp32 oracle)
+    pytest.param(207, 90, "dL_dconic", 1.025e-3, id="seed207_scene90"),
+    pytest.param(308, 9, "dL_dconic", 2.787e-3, id="seed308_scene9"),
+    pytest.param(419, 91, "dL_dmeans2D", 1.812e-3, id="seed419_scene91"),
+    pytest.param(420, 89, "dL_dcov3D", 1.028e-3, id="seed420_scene89"),
 ]
 
 
-@pytest.mark.xfail(strict=True, raises=AssertionError, reason="the two recorded misses of round 6's 6 912 scenes on the fixed kernels: single-pixel cut-off flips on scenes whose reference noise exceeds the 1e-3 cap "
-                                       "(profiles/r06_fuzz_soak_e.txt, _f.txt)")
-@pytest.mark.parametrize("seed,scene,recorded", KNOWN_CAP_MISSES)
-def test_known_cap_misses_are_still_the_recorded_ones(gpu_device, seed, scene, recorded):
+@pytest.mark.xfail(strict=True, raises=AssertionError, reason="the four recorded misses of round 6's 9 216 scenes on the fixed kernels: one-splat differences on scenes whose reference noise exceeds the 1e-3 cap "
+                                       "(profiles/r06_fuzz_soak_e.txt, _f.txt, _g.txt)")
+@pytest.mark.parametrize("seed,scene,tensor,recorded", KNOWN_CAP_MISSES)
+def test_known_cap_misses_are_still_the_recorded_ones(gpu_device, seed, scene, tensor, recorded):
     """Fuzz seed 207 / scene 90 (4 924 Gaussians, 283 x 219, SH 2, splats x 8): at ONE pixel the forward (and, consistently, the backward: default and
     fixed-order backward agree to 4e-7) decides a pair of a needle splat on the other side of alpha = 1/255 than the fp32 oracle -- final_T differs by 2.7e-3
     there.  The reference's own builds are ~1e-3 apart on this scene (dL_dconic: HIP is 4.3e-4 from the cut-off-in build, 4.6e-4 from the FMA build, 1.025e-3 from
@@ -410,6 +412,11 @@ def test_known_cap_misses_are_still_the_recorded_ones(gpu_device, seed, scene, r
     Fuzz seed 308 / scene 9 (1 500 Gaussians, 272 x 173, SH 3, splats x 3): the same at one pixel (final_T differs by 3.9e-3), all of the error in one Gaussian;
     dL_dconic is 2.787e-3 from the plain fp32, the exp2 and the double builds and 3.9e-6 / 4.4e-6 from the cut-off-out and the FMA-contracted builds -- the
     reference's own builds are 2.8e-3 apart, the bar is the cap.
+    Fuzz seed 419 / scene 91 (4 577 Gaussians, 152 x 203, SH 0, splats x 8): one splat, dL_dmeans2D 1.812e-3 from the plain fp32, FMA, exp2 and double builds and
+    1.1e-4 from the cut-off-IN build -- the same kind of flip in the other direction.
+    Fuzz seed 420 / scene 89 (67 Gaussians, 87 x 154, SH 0, splats x 8): no flip -- dL_dconic is 2.5e-6 and dL_dmeans2D 4.9e-5 from the fp32 oracle; one needle splat's
+    dL_dcov3D (an intermediate here: the caller gets dL_dscales / dL_drotations) is 1.028e-3 from the fp32 evaluation of the ill-conditioned chain and 1.59e-3 from the
+    exact one: 2.8 % over the cap.
     Kept as STRICT expected failures: a change that clears one turns the test red (update the record); one that doubles the distance raises."""
     from tests import fuzz
     rng = np.random.default_rng(seed)
@@ -417,11 +424,11 @@ def test_known_cap_misses_are_still_the_recorded_ones(gpu_device, seed, scene, r
         desc, inp, dL = fuzz.random_scene(rng, it)
     ref = util.oracle_run(inp, dL)
     mine = util.hip_run(inp, dL)
-    d = util.rel_l2(np.asarray(mine["dL_dconic"]).reshape(np.asarray(ref["dL_dconic"]).shape), ref["dL_dconic"])
-    util.record_parity(f"known_miss_seed{seed}_scene{scene}", {"dL_dconic_vs_fp32_oracle": d, "recorded": recorded})
-    print(desc, f"dL_dconic vs fp32 oracle {d:.3e} (recorded {recorded:.3e})")
+    d = util.rel_l2(np.asarray(mine[tensor]).reshape(np.asarray(ref[tensor]).shape), ref[tensor])
+    util.record_parity(f"known_miss_seed{seed}_scene{scene}", {f"{tensor}_vs_fp32_oracle": d, "recorded": recorded})
+    print(desc, f"{tensor} vs fp32 oracle {d:.3e} (recorded {recorded:.3e})")
     if d > 2.05 * recorded:
-        raise RuntimeError(f"seed {seed} scene {scene} got worse: dL_dconic {d:.3e} from the fp32 oracle (recorded {recorded:.3e})")
+        raise RuntimeError(f"seed {seed} scene {scene} got worse: {tensor} {d:.3e} from the fp32 oracle (recorded {recorded:.3e})")
     util.compare(mine, ref)                               # the expected failure: AssertionError from the frozen criterion
 
 

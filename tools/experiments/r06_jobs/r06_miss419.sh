@@ -1,0 +1,36 @@
+# round 6: the miss of soak E (seed 419, scene 91): which oracle build reproduces the HIP result?  and the pixel
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r06_miss419; mkdir -p $O; cd $R
+timeout 120 python -c "from oracle import oracle; oracle.build(force=True)" < /dev/null
+echo > $O/diag2.txt
+python - <<'PY' 2>&1 | grep -v amdgpu | tee -a $O/diag2.txt
+import numpy as np, sys
+sys.path.insert(0, '.')
+from tests import fuzz, util, adjudicate
+rng = np.random.default_rng(419)
+for it in range(92):
+    desc, inp, dL = fuzz.random_scene(rng, it)
+mine = util.hip_run(inp, dL)
+det = util.hip_run(inp, dL, deterministic=True)
+print('scene', desc)
+print('default vs fixed-order backward', {k: f"{util.rel_l2(mine[k], det[k]):.3e}" for k in ('dL_dconic', 'dL_dmeans2D', 'dL_dopacity')})
+for variant in ('f32', 'f32_in', 'f32_out', 'f32_fma', 'f32_ex2', 'f64'):
+    o = adjudicate.oracle_variant(inp, dL, variant)
+    print(variant, {k: f"{util.rel_l2(np.asarray(mine[k]).reshape(np.asarray(o[k]).shape), o[k]):.3e}" for k in ('dL_dconic', 'dL_dmeans2D', 'dL_dopacity', 'dL_drotations', 'color')})
+PY
+python - <<'PY' 2>&1 | grep -v amdgpu | tee -a $O/diag2.txt
+import numpy as np, sys
+sys.path.insert(0, '.')
+from tests import fuzz, util
+rng = np.random.default_rng(419)
+for it in range(92):
+    desc, inp, dL = fuzz.random_scene(rng, it)
+mine = util.hip_run(inp, dL); ref = util.oracle_run(inp, dL)
+for k in ('final_T', 'n_contrib'):
+    if k in mine and k in ref:
+        a = np.asarray(mine[k]).reshape(-1).astype(np.float64); b = np.asarray(ref[k]).reshape(-1).astype(np.float64)
+        i = int(np.argmax(np.abs(a - b))); print(k, 'largest difference', a[i] - b[i], 'at flat pixel', i, 'values', a[i], b[i])
+print('keys', sorted(mine.keys()))
+d = np.abs(np.asarray(mine['dL_dconic']).reshape(-1, 3) - np.asarray(ref['dL_dconic']).reshape(-1, 3)).sum(1); g = int(np.argmax(d))
+print('Gaussian with the largest dL_dconic difference', g, 'mine', np.asarray(mine['dL_dconic']).reshape(-1, 3)[g], 'oracle', np.asarray(ref['dL_dconic']).reshape(-1, 3)[g])
+print('its scale', np.asarray(inp['scales'])[g] if 'scales' in inp else None, 'opacity', np.asarray(inp['opacities']).reshape(-1)[g])
+PY

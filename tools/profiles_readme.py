@@ -28,7 +28,7 @@ NAMED = {
  "r05_ssim_counters.txt": "SQ counters of the SSIM kernels", "r05_step_timeline.txt": "kernels in flight over an 8-view step", "r05_valu_issue_rate_packed_lds_swap.txt": "packed fp32 / permlane swap / LDS read issue rates",
  "r06_b_kernel_stats_dropin.csv": "drop-in kernel stats of the run whose store-mode counters are in r06_store_mode_counters.txt", "r06_large_splats.txt": "x4 / x8: stage times, kernel stats, FETCH / WRITE / SQ counters, rectangle statistics; k_tile_sort by class; what the entries behind a tile's deepest contributor cost (five variants); the GPU's scattered-store rate (microbench)",
  "r06_pass_packing.txt": "would another assignment of quadrant lists to rows need fewer passes? CPU prediction + the measured 8-waves-per-tile backward", "r06_store_mode_counters.txt": "counters over the STORE-mode k_preprocess_bwd (drop-in loop): 0.62 of the HBM peak",
- "r06_fuzz_soak": "round-6 fuzz soaks at the frozen criterion (a, b: before the cut-off fix; cd, e, f: 6 912 scenes on the fixed kernels, two misses)", "r06_tuning.txt": "round-6 A/B runs by library variant: binning chunks, EMIT_RANK, padded SH rows, discarded outputs, constants sweep, Morton order",
+ "r06_fuzz_soak": "round-6 fuzz soaks at the frozen criterion (a, b: before the cut-off fix; cd, e, f (F + G): 9 216 scenes on the fixed kernels, four misses)", "r06_tuning.txt": "round-6 A/B runs by library variant: binning chunks, EMIT_RANK, padded SH rows, discarded outputs, constants sweep, Morton order",
 }
 out = ["# profiles/", "", "rocprofv3 summaries and measurement records behind the numbers in DESIGN.md / bench.py.  **Round 6 pruned this directory**: per round the LAST full set",
        "(`tools/profile_round.sh <name>` + `tools/pmc_to_json.py`) and the named experiments stay; the intermediate sets (`r01_a` ... `r05_f`: 297 files) left the tree with commit `d1c03d1` and are in the history.",
