@@ -402,7 +402,7 @@ KNOWN_CAP_MISSES = [      # (fuzz seed, scene index, the tensor that misses, its
 
 
 @pytest.mark.xfail(strict=True, raises=AssertionError, reason="the four recorded misses of round 6's 9 216 scenes on the fixed kernels: one-splat differences on scenes whose reference noise exceeds the 1e-3 cap "
-                                       "(profiles/r06_fuzz_soak_e.txt, _f.txt, _g.txt)")
+                                       "(profiles/r06_fuzz_soak_e.txt, _f.txt: soaks E, F and G)")
 @pytest.mark.parametrize("seed,scene,tensor,recorded", KNOWN_CAP_MISSES)
 def test_known_cap_misses_are_still_the_recorded_ones(gpu_device, seed, scene, tensor, recorded):
     """Fuzz seed 207 / scene 90 (4 924 Gaussians, 283 x 219, SH 2, splats x 8): at ONE pixel the forward (and, consistently, the backward: default and
